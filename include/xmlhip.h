@@ -1,0 +1,198 @@
+/*
+ * xmlhip.h -- C ABI of libxmlhip.so: the MI355X (gfx950) hot path of the XML corpus-level
+ * moment-retrieval model (jayleicn/TVRetrieval, baselines/crossmodal_moment_localization = "xml/").
+ *
+ * The reference has no FFI: its boundary is the Python method surface of XML(nn.Module)
+ * (SURVEY.md 8b).  Each entry point below replaces one stock-PyTorch op sequence of that surface and
+ * cites it.  The host-side mirror (tvretrieval_amd/model_xml.py) binds these through ctypes; a
+ * maintainer of the reference would bind them the same way.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless named h_*; tensors are dense row-major, batch first;
+ *   - `dt` selects the storage type of activations and weights: XML_F32 (exact-f32 MFMA, parity
+ *     config) or XML_BF16 (bf16 storage, f32 accumulation and f32 LayerNorm/softmax statistics);
+ *     LayerNorm affine parameters, biases, masks, scores and probabilities are always f32;
+ *   - masks are float32 1=valid / 0=pad exactly as the reference passes them (start_end_dataset.py:346-370);
+ *   - all calls are asynchronous on `stream`, never allocate, never synchronise and are re-entrant per
+ *     stream; scratch comes from the caller: `ws`/`ws_bytes`, sized by the matching *_workspace_bytes();
+ *   - return value: 0 = XML_OK, negative = xml_status (never throws, never aborts).
+ */
+#ifndef XMLHIP_H
+#define XMLHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* xml_stream_t; /* hipStream_t */
+
+typedef enum { XML_F32 = 0, XML_BF16 = 1 } xml_dtype;
+
+typedef enum {
+  XML_OK = 0,
+  XML_ERR_BAD_ARG = -1,       /* null pointer, negative size, unsupported dtype            */
+  XML_ERR_UNSUPPORTED = -2,   /* shape outside what the kernels implement (see each entry) */
+  XML_ERR_WORKSPACE = -3,     /* ws_bytes smaller than *_workspace_bytes()                 */
+  XML_ERR_LAUNCH = -4         /* hipGetLastError() != hipSuccess after a launch            */
+} xml_status;
+
+/* version / introspection --------------------------------------------------------------------- */
+int xml_abi_version(void);                 /* bumps on any signature change */
+const char* xml_build_arch(void);          /* "gfx950" */
+const char* xml_status_string(int status);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight packing.  load_state_dict-time conversion of f32 checkpoint tensors (xml/train.py:219-223
+ * layout) into the device dtype; `n` elements, round-to-nearest-even for bf16.
+ * --------------------------------------------------------------------------------------------- */
+int xml_pack_weights(const float* src, void* dst, int dt, int64_t n, xml_stream_t stream);
+/* generic dtype conversion of activations (either direction) */
+int xml_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K1+K2: LinearLayer + TrainablePositionalEncoding
+ *   y = LN_pos( ReLU( LN_in(x) W^T + b ) + E[l] )      l = row % seq_len
+ * replaces LinearLayer.forward (xml/model_components.py:156-163) followed by
+ * TrainablePositionalEncoding.forward (:76-89) as called from XML.encode_input (xml/model_xml.py:387-390).
+ *   x      (rows, d_in)  raw features, f32 or dt (x_dt)
+ *   w      (hidden, d_in) dt;  b (hidden) f32;  ln_in_{g,b} (d_in) f32
+ *   pos    (>= seq_len, hidden) dt;  ln_pos_{g,b} (hidden) f32
+ *   y      (rows, hidden) dt
+ * Requirements: d_in % 8 == 0, hidden % 8 == 0.
+ * --------------------------------------------------------------------------------------------- */
+size_t xml_linear_ln_relu_pos_workspace_bytes(int64_t rows, int d_in, int hidden, int dt);
+int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const float* ln_in_b,
+                           const void* w, const float* b, const void* pos, const float* ln_pos_g,
+                           const float* ln_pos_b, void* y, int64_t rows, int seq_len, int d_in,
+                           int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K3+K4: BertAttention = BertSelfAttention + BertSelfOutput (no FFN)
+ *   y = LN( dense( MHA(x, x, x, key_mask) ) + x )
+ * replaces BertAttention.forward (xml/model_components.py:207-216, :266-303, :313-317).
+ * Additive mask (1-m)*-10000, scale 1/sqrt(dh) applied after QK^T, as the reference does.
+ *   x (n, seq_len, hidden) dt; key_mask (n, seq_len) f32
+ *   wqkv (3*hidden, hidden) dt = [query; key; value] weights stacked; bqkv (3*hidden) f32
+ *   wo (hidden, hidden) dt; bo (hidden) f32; ln_{g,b} (hidden) f32
+ * Requirements: seq_len <= 128, hidden % (32*n_heads) == 0.
+ * --------------------------------------------------------------------------------------------- */
+size_t xml_attention_block_workspace_bytes(int64_t n, int seq_len, int hidden, int dt);
+int xml_attention_block(const void* x, const float* key_mask, const void* wqkv, const float* bqkv,
+                        const void* wo, const float* bo, const float* ln_g, const float* ln_b,
+                        void* y, int64_t n, int seq_len, int hidden, int n_heads, int dt, void* ws,
+                        size_t ws_bytes, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cross-attention step of XML.cross_context_encoder (xml/model_xml.py:369-371):
+ *   y = LN( MHA(q=main, k=v=side, mask = main_mask (x) side_mask) + main )
+ *   main (n, lq, hidden), side (n, lk, hidden) dt; masks f32
+ *   wq (hidden,hidden), wkv (2*hidden,hidden) = [key; value] dt; bq (hidden), bkv (2*hidden) f32
+ * --------------------------------------------------------------------------------------------- */
+size_t xml_cross_attention_workspace_bytes(int64_t n, int lq, int lk, int hidden, int dt);
+int xml_cross_attention(const void* main_x, const float* main_mask, const void* side_x,
+                        const float* side_mask, const void* wq, const float* bq, const void* wkv,
+                        const float* bkv, const float* ln_g, const float* ln_b, void* y, int64_t n,
+                        int lq, int lk, int hidden, int n_heads, int dt, void* ws, size_t ws_bytes,
+                        xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K5: modular query pooling, XML.get_modularized_queries (xml/model_xml.py:410-423)
+ *   a = softmax_l( mask_logits(enc W_m^T) );  out[m] = sum_l a[l,m] enc[l]
+ *   enc (n, lq, hidden) dt; mask (n, lq) f32; w_m (n_mod, hidden) f32, n_mod in {1,2}
+ *   out (n_mod, n, hidden) dt     (n_mod == 1: the reference returns the same vector twice)
+ * --------------------------------------------------------------------------------------------- */
+int xml_modular_pool(const void* enc, const float* mask, const float* w_m, void* out, int64_t n,
+                     int lq, int hidden, int n_mod, int dt, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Plain linear y = x W^T + b  (video_query_linear / sub_query_linear, xml/model_xml.py:459-460,524)
+ *   x (rows, k) dt; w (n, k) dt; b (n) f32 or NULL; y (rows, n) dt.  k % 8 == 0, n % 8 == 0.
+ * --------------------------------------------------------------------------------------------- */
+int xml_linear(const void* x, const void* w, const float* b, void* y, int64_t rows, int n, int k,
+               int relu, int dt, xml_stream_t stream);
+
+/* Row-wise L2 normalisation, F.normalize(x, dim=-1) eps=1e-12 (xml/model_xml.py:446-447).
+ * Done once per corpus for feat1 ("ctx normalisation precomputed at corpus-encode time"). */
+int xml_l2norm_rows(const void* x, void* y, int64_t rows, int d, int dt, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K6: video-level scores = similarity GEMM #1 with fused masked max over clips
+ *   out[q,v] = max_l mask_logits( qn[q] . cn[v,l] )      (xml/model_xml.py:448-452)
+ *   combine == 0: out = s;   combine == 1: out = (out + s) * 0.5   ((video+sub)/divisor, :572-574)
+ *   qn (nq, hidden) dt, L2-normalised;  cn (nv, lpad, hidden) dt, L2-normalised (zero rows beyond a
+ *   video's stored length);  mask (nv, lpad) f32;  out (nq, nv) f32, row stride ld_out.
+ * Requirements: lpad % 16 == 0, lpad <= 128, hidden % 8 == 0.
+ * --------------------------------------------------------------------------------------------- */
+int xml_q2c_scores(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out,
+                   int nq, int nv, int lpad, int hidden, int combine, int dt, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K8: per-row top-k, torch.topk(exp(alpha*s), k) (xml/inference.py:317,347-348)
+ *   scores (rows, n) f32 row stride ld; optional idx_in (rows, n) int32 payload (NULL: column index)
+ *   out_val (rows, k) f32 = alpha != 0 ? expf(alpha*s) : s, descending; out_idx (rows, k) int32.
+ *   Order: value descending, then payload/column index ascending (torch leaves ties unspecified).
+ *   k <= 256, k <= n.
+ * --------------------------------------------------------------------------------------------- */
+size_t xml_topk_rows_workspace_bytes(int rows, int n, int k);
+int xml_topk_rows(const float* scores, int64_t ld, const int32_t* idx_in, float* out_val,
+                  int32_t* out_idx, int rows, int n, int k, float alpha, void* ws, size_t ws_bytes,
+                  xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K7: similarity contraction #2 + ConvSE start/end scorer on selected (query, video) pairs
+ *   sim_m[l]  = q'_m . feat2_m[v,l]                       m in {video, sub}
+ *   merged:   x = (sim_v + sim_s)/2 ; st = conv(x, w_st[0]) ; ed = conv(x, w_ed[0])
+ *   separate: st = (conv(sim_v, w_st[0]) (+ conv(sim_s, w_st[1]))) / n_mod   (same for ed)
+ *   then mask_logits, optionally softmax over l in [0, l_ref)
+ * replaces get_merged_st_ed_prob / _get_st_ed_prob (xml/model_xml.py:455-551) and the softmax at
+ * xml/inference.py:321-322.  The reference evaluates all (q,v) pairs and discards all but the
+ * top-k videos (xml/inference.py:365-367); here only the listed pairs are evaluated.
+ *   q_lin[m]  (nq, hidden) dt  = module_query_linear(modular query)
+ *   feat2[m]  (nv, lpad, hidden) dt (rows l >= l_ref are zero); mask (nv, lpad) f32
+ *   pair_vid  (nq, kpairs) int32 video index per pair, < 0 = skip (output rows zero-filled)
+ *   conv_w    (2 * n_conv * ksize) f32: [st filters..., ed filters...]; n_conv = merged ? 1 : n_mod
+ *   st_out, ed_out (nq, kpairs, lpad) f32
+ * Requirements: lpad % 16 == 0, lpad <= 128, ksize odd <= 15, n_mod in {1,2}.
+ * --------------------------------------------------------------------------------------------- */
+typedef struct {
+  int nq, nv, kpairs, lpad, l_ref, hidden;
+  int n_mod;        /* number of modalities present (1 or 2) */
+  int merged;       /* 1: average similarities then one conv pair (merge_two_stream) */
+  int ksize;        /* conv kernel size (config.conv_kernel_size, default 5) */
+  int softmax;      /* 1: emit probabilities, 0: emit masked logits */
+  int dt;
+} xml_convse_desc;
+size_t xml_convse_rerank_workspace_bytes(const xml_convse_desc* d);
+int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1,
+                      const void* feat2_0, const void* feat2_1, const float* mask0,
+                      const float* mask1, const int32_t* pair_vid, const float* conv_w,
+                      float* st_out, float* ed_out, void* ws, size_t ws_bytes, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * K9+K10: banded moment candidates + per-query top-n
+ *   score(r,i,j) = (st[q,r,i] * w[q,r]) * ed[q,r,j]   for min_l <= j-i < max_l, j < l_ref
+ * replaces einsum("qvm,qv,qvn->qvmn") * length mask, flat sort, [:max_before_nms]
+ * (xml/inference.py:365-386, :170-192) and the index decoding of :423-431; with kpairs == 1 it is the
+ * SVMR path (get_svmr_res_from_st_ed_probs, xml/inference.py:195-241, utils/tensor_utils.py:133-141).
+ *   st, ed (nq, kpairs, lpad) f32 probabilities; w (nq, kpairs) f32 or NULL (= 1)
+ *   out_score (nq, n_out) f32 descending; out_flat (nq, n_out) int32 = (r*l_ref + i)*l_ref + j
+ *   (the reference's flat index); ties broken by ascending flat index; when fewer than n_out
+ *   candidates exist the tail is score 0 / flat -1.
+ * Requirements: n_out <= 1024, lpad <= 128.
+ * --------------------------------------------------------------------------------------------- */
+int xml_moment_topk(const float* st, const float* ed, const float* w, float* out_score,
+                    int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l,
+                    int n_out, xml_stream_t stream);
+
+/* Row-wise LayerNorm of (a [+ b]) -- exposed for the host-side mirror and tests.
+ *   y = LN(a + b) * g + beta;  a,b,y (rows, d) dt (b may be NULL), x_dt of `a` may be XML_F32. */
+int xml_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta,
+                      void* y, int64_t rows, int d, int dt, xml_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XMLHIP_H */

@@ -1,0 +1,87 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and exports every symbol
+that include/xmlhip.h declares (no compute calls: there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from tvretrieval_amd import _lib
+    if not os.path.isfile(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build()
+    return _lib.load()
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "xmlhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(xml_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_header_symbol_is_exported_and_bound(lib):
+    from tvretrieval_amd import _lib
+    syms = header_symbols()
+    assert len(syms) >= 20
+    for s in syms:
+        assert hasattr(lib, s), "libxmlhip.so does not export %s" % s
+        assert s in _lib.SIGNATURES, "ctypes binding missing for %s" % s
+    assert set(_lib.SIGNATURES) <= set(syms), set(_lib.SIGNATURES) - set(syms)
+
+
+def test_abi_identity(lib):
+    assert lib.xml_abi_version() == 1
+    assert lib.xml_build_arch() == b"gfx950"
+    assert lib.xml_status_string(0) == b"ok"
+    assert lib.xml_status_string(-2) == b"unsupported shape"
+
+
+def test_argument_validation_without_gpu(lib):
+    """Entry points validate before launching: bad arguments return error codes, never crash."""
+    import ctypes
+    from tvretrieval_amd._lib import ConvseDesc
+    assert lib.xml_q2c_scores(None, None, None, None, 0, 1, 1, 16, 8, 0, 0, None) == -1
+    assert lib.xml_topk_rows(None, 0, None, None, None, 1, 1, 1, 0.0, None, 0, None) == -1
+    assert lib.xml_linear(None, None, None, None, 1, 8, 8, 0, 0, None) == -1
+    d = ConvseDesc(nq=10, nv=20, kpairs=5, lpad=128, l_ref=100, hidden=768, n_mod=2, merged=1, ksize=5, softmax=1, dt=1)
+    assert lib.xml_convse_rerank_workspace_bytes(ctypes.byref(d)) > 20 * 4
+    assert lib.xml_attention_block_workspace_bytes(4, 128, 768, 1) >= 4 * 128 * 768 * (3 * 2 + 2 + 4)
+    assert lib.xml_linear_ln_relu_pos_workspace_bytes(512, 3072, 768, 0) >= 512 * (3072 + 768) * 4
+
+
+def test_product_path_fails_loudly_without_gpu():
+    """No CPU fallback: CPU tensors are rejected by the ops layer."""
+    import torch
+    from tvretrieval_amd import _lib, ops
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.XmlHipError):
+        ops.l2norm_rows(torch.zeros(4, 8))
+    with pytest.raises(_lib.XmlHipError):
+        ops.topk_rows(torch.zeros(4, 8), 2)
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    """{"model", "model_cfg", "epoch"} (xml/train.py:219-223) incl. the EasyDict config survives torch.save/load."""
+    import torch
+    from conftest import load_golden
+    from tvretrieval_amd.easydict_compat import register_easydict_module
+    from tvretrieval_amd.model_xml import XML
+    register_easydict_module()
+    d, cfg, sd = load_golden("xml_video_sub_cross_h128")
+    m = XML(cfg)
+    assert set(m.state_dict().keys()) == set(sd.keys())
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    path = str(tmp_path / "model.ckpt")
+    torch.save({"model": m.state_dict(), "model_cfg": m.config, "epoch": 3}, path)
+    ck = torch.load(path, weights_only=False)
+    assert ck["epoch"] == 3 and ck["model_cfg"].hidden_size == cfg["hidden_size"]
+    ck["model_cfg"]["stack_conv_predictor_conv_kernel_sizes"] = -1      # xml/inference.py:538
+    m2 = XML(ck["model_cfg"])
+    m2.load_state_dict(ck["model"])
+    for k, v in m2.state_dict().items():
+        assert torch.equal(v, torch.from_numpy(sd[k]))

@@ -1,0 +1,340 @@
+"""GPU parity tests, kernel by kernel: the HIP path (through the C ABI, via tvretrieval_amd.ops) against the CPU
+oracle on the same seeded inputs.  fp32 storage: 1e-4 absolute on similarity scores / logits (BASELINE.json);
+bf16 storage: looser, stated per test.  Run on the MI355X box:  pytest -m gpu"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import xml_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _tol(dtype, f32=1e-4, bf16=3e-2):
+    return f32 if dtype == torch.float32 else bf16
+
+
+def close(name, got, want, atol, rtol=0.0):
+    got = got.detach().float().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
+    want = want.detach().float().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
+    err = np.abs(got - want)
+    lim = atol + rtol * np.abs(want)
+    bad = err > lim
+    assert not bad.any(), "%s: %d/%d off, max err %.3e at %s (got %r want %r)" % (
+        name, bad.sum(), bad.size, err.max(), np.unravel_index(err.argmax(), err.shape),
+        got.flat[err.argmax()], want.flat[err.argmax()])
+
+
+def bf16_grid(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return bf16_grid(torch.randn(*shape, generator=g) * scale)
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from tvretrieval_amd import ops as o
+    o._lib.load()
+    return o
+
+
+def dev(t, dtype=None):
+    t = t.to(DEV)
+    return t.to(dtype).contiguous() if dtype is not None else t.contiguous()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(5, 24, 40), (300, 136, 96), (257, 768, 3072), (128, 128, 64)])
+def test_linear(ops, dtype, shape):
+    m, n, k = shape
+    x, w, b = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5), rnd(n, seed=3)
+    want = torch.nn.functional.linear(x, w, b)
+    got = ops.linear(dev(x, dtype), dev(w, dtype), dev(b))
+    close("linear", got, want, _tol(dtype, 2e-5, 2e-2), 1e-2 if dtype == torch.bfloat16 else 1e-5)
+    got = ops.linear(dev(x, dtype), dev(w, dtype), None, relu=True)
+    close("linear relu", got, torch.relu(torch.nn.functional.linear(x, w)), _tol(dtype, 2e-5, 2e-2),
+          1e-2 if dtype == torch.bfloat16 else 1e-5)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layernorm_l2norm_convert(ops, dtype):
+    a, b = rnd(37, 200, seed=4), rnd(37, 200, seed=5)
+    g, beta = 1 + 0.1 * rnd(200, seed=6), 0.1 * rnd(200, seed=7)
+    want = torch.nn.functional.layer_norm(a + b, (200,), g, beta, 1e-5)
+    got = ops.add_layernorm(dev(a), dev(b, dtype), dev(g), dev(beta), out_dtype=dtype)
+    close("add_layernorm", got, want, _tol(dtype, 1e-5, 2e-2))
+    want = torch.nn.functional.normalize(a, dim=-1)
+    got = ops.l2norm_rows(dev(a, dtype))
+    close("l2norm", got, want, _tol(dtype, 1e-6, 4e-3))
+    z = torch.zeros(3, 64)
+    close("l2norm zero rows", ops.l2norm_rows(dev(z, dtype)), z, 0)
+    close("convert", ops.convert(dev(a), dtype), a.to(dtype).float(), 0)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(3, 17, 96, 128), (2, 128, 3072, 768), (9, 30, 64, 256)])
+def test_linear_ln_relu_pos(ops, dtype, shape):
+    n, l, d_in, h = shape
+    x = rnd(n, l, d_in, seed=10)
+    sd = {"LayerNorm.weight": 1 + 0.1 * rnd(d_in, seed=11), "LayerNorm.bias": 0.1 * rnd(d_in, seed=12),
+          "net.1.weight": rnd(h, d_in, seed=13, scale=d_in ** -0.5), "net.1.bias": 0.1 * rnd(h, seed=14)}
+    pe = {"position_embeddings.weight": rnd(l + 3, h, seed=15, scale=0.5), "LayerNorm.weight": 1 + 0.1 * rnd(h, seed=16),
+          "LayerNorm.bias": 0.1 * rnd(h, seed=17)}
+    want = O.trainable_pos_enc(O.linear_layer(x, O.Weights(sd)), O.Weights(pe))
+    got = ops.linear_ln_relu_pos(dev(x), dev(sd["LayerNorm.weight"]), dev(sd["LayerNorm.bias"]),
+                                 dev(sd["net.1.weight"], dtype), dev(sd["net.1.bias"]),
+                                 dev(pe["position_embeddings.weight"], dtype), dev(pe["LayerNorm.weight"]),
+                                 dev(pe["LayerNorm.bias"]))
+    close("linear_ln_relu_pos", got, want, _tol(dtype, 5e-5, 6e-2))
+
+
+def _att_weights(h, seed):
+    s = h ** -0.5
+    sd = {}
+    for i, nm in enumerate(["query", "key", "value"]):
+        sd["self.%s.weight" % nm] = rnd(h, h, seed=seed + i, scale=s)
+        sd["self.%s.bias" % nm] = 0.1 * rnd(h, seed=seed + 10 + i)
+    sd["output.dense.weight"] = rnd(h, h, seed=seed + 20, scale=s)
+    sd["output.dense.bias"] = 0.1 * rnd(h, seed=seed + 21)
+    sd["output.LayerNorm.weight"] = 1 + 0.1 * rnd(h, seed=seed + 22)
+    sd["output.LayerNorm.bias"] = 0.1 * rnd(h, seed=seed + 23)
+    return sd
+
+
+def _ragged_mask(n, l, seed, full_first=True):
+    g = torch.Generator().manual_seed(seed)
+    lens = torch.randint(1, l + 1, (n,), generator=g)
+    if full_first:
+        lens[0] = l
+    return (torch.arange(l)[None] < lens[:, None]).float()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(5, 40, 128, 4), (3, 128, 768, 4), (4, 100, 256, 4), (6, 13, 128, 4), (2, 128, 512, 4)])
+def test_attention_block(ops, dtype, shape):
+    n, l, h, nh = shape
+    if dtype == torch.float32 and h == 768 and l > 100:
+        pass  # 135 KB of LDS: still within the 160 KB CU budget
+    x = rnd(n, l, h, seed=30)
+    mask = _ragged_mask(n, l, 31)
+    sd = _att_weights(h, 40)
+    want = O.bert_attention(x, mask.unsqueeze(1), O.Weights(sd), nh)
+    wqkv = torch.cat([sd["self.query.weight"], sd["self.key.weight"], sd["self.value.weight"]], 0)
+    bqkv = torch.cat([sd["self.query.bias"], sd["self.key.bias"], sd["self.value.bias"]], 0)
+    got = ops.attention_block(dev(x, dtype), dev(mask), dev(wqkv, dtype), dev(bqkv), dev(sd["output.dense.weight"], dtype),
+                              dev(sd["output.dense.bias"]), dev(sd["output.LayerNorm.weight"]),
+                              dev(sd["output.LayerNorm.bias"]), nh)
+    close("attention_block (incl. padded rows)", got, want, _tol(dtype, 1e-4, 8e-2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(4, 33, 33, 128, 4), (2, 128, 128, 768, 4), (3, 20, 20, 256, 4)])
+def test_cross_attention(ops, dtype, shape):
+    n, lq, lk, h, nh = shape
+    main, side = rnd(n, lq, h, seed=50), rnd(n, lk, h, seed=51)
+    mm, sm = _ragged_mask(n, lq, 52), _ragged_mask(n, lk, 53)
+    sd = _att_weights(h, 60)
+    att = {k[5:]: v for k, v in sd.items() if k.startswith("self.")}
+    g, b = sd["output.LayerNorm.weight"], sd["output.LayerNorm.bias"]
+    cross_mask = torch.einsum("bm,bn->bmn", mm, sm)
+    cross = O.bert_self_attention(main, side, side, cross_mask, O.Weights(att), nh)
+    want = torch.nn.functional.layer_norm(cross + main, (h,), g, b, 1e-5)
+    wkv = torch.cat([att["key.weight"], att["value.weight"]], 0)
+    bkv = torch.cat([att["key.bias"], att["value.bias"]], 0)
+    got = ops.cross_attention(dev(main, dtype), dev(mm), dev(side, dtype), dev(sm), dev(att["query.weight"], dtype),
+                              dev(att["query.bias"]), dev(wkv, dtype), dev(bkv), dev(g), dev(b), nh)
+    # padded query rows see (score - 10000): fp32 absorbs ~1e-3 of the score there (same in the reference)
+    close("cross_attention (incl. padded rows)", got, want, _tol(dtype, 2e-4, 8e-2))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n_mod", [1, 2])
+def test_modular_pool(ops, dtype, n_mod):
+    n, lq, h = 11, 30, 256
+    enc = rnd(n, lq, h, seed=70)
+    mask = _ragged_mask(n, lq, 71)
+    wm = rnd(n_mod, h, seed=72, scale=h ** -0.5)
+    sc = torch.softmax(O.mask_logits(enc @ wm.t(), mask.unsqueeze(2)), dim=1)
+    want = torch.einsum("blm,bld->mbd", sc, enc)
+    got = ops.modular_pool(dev(enc, dtype), dev(mask), dev(wm))
+    close("modular_pool", got, want, _tol(dtype, 1e-5, 2e-2))
+
+
+def _normed(*shape, seed):
+    return bf16_grid(torch.nn.functional.normalize(rnd(*shape, seed=seed), dim=-1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(7, 10, 40, 128), (130, 9, 128, 768), (300, 37, 100, 256), (1, 1, 128, 768),
+                                   (256, 33, 16, 128)])
+def test_q2c_scores(ops, dtype, shape):
+    nq, nv, l, h = shape
+    lpad = (l + 15) // 16 * 16
+    q, c = _normed(nq, h, seed=80), _normed(nv, l, h, seed=81)
+    mask = _ragged_mask(nv, l, 82)
+    s = torch.einsum("md,nld->mln", q, c)
+    want = torch.max(O.mask_logits(s, mask.t().unsqueeze(0)), dim=1)[0]
+    cpad = torch.zeros(nv, lpad, h); cpad[:, :l] = c
+    mpad = torch.zeros(nv, lpad); mpad[:, :l] = mask
+    got = ops.q2c_scores(dev(q, dtype), dev(cpad, dtype), dev(mpad))
+    close("q2c", got, want, _tol(dtype, 1e-5, 1e-5))   # inputs are bf16-exact, accumulation is f32 in both modes
+    # second modality averaged in place: (a + b) / 2
+    got2 = ops.q2c_scores(dev(q, dtype), dev(cpad, dtype), dev(mpad), out=got.clone(), combine=True)
+    close("q2c combine", got2, (want + want) / 2, 1e-5)
+
+
+def test_q2c_swizzle_equivalence(ops):
+    import ctypes
+    lib = ops._lib.load()
+    q, c = _normed(1100, 256, seed=83), _normed(70, 128, 256, seed=84)
+    mask = _ragged_mask(70, 128, 85)
+    a = ops.q2c_scores(dev(q, torch.bfloat16), dev(c, torch.bfloat16), dev(mask))
+    lib.xml_debug_set_q2c_swizzle(ctypes.c_int(0))
+    try:
+        b = ops.q2c_scores(dev(q, torch.bfloat16), dev(c, torch.bfloat16), dev(mask))
+    finally:
+        lib.xml_debug_set_q2c_swizzle(ctypes.c_int(1))
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("shape", [(5, 10, 4), (9, 2179, 100), (3, 21793, 100), (4, 300, 256), (2, 7, 7)])
+def test_topk_rows(ops, shape):
+    rows, n, k = shape
+    s = rnd(rows, n, seed=90) * 0.3
+    s[0, : min(n, 50)] = 0.125          # heavy ties at the top
+    if rows > 1:
+        s[1] = torch.round(s[1] * 8) / 8    # ties everywhere, threshold inside a tie group
+    vals, idx = ops.topk_rows(dev(s), k, alpha=20.0)
+    vals, idx = vals.cpu(), idx.cpu().long()
+    wv, wi = torch.topk(torch.exp(20.0 * s), k, dim=1)
+    close("topk values", vals, wv, 0, 1e-5)
+    assert torch.equal(torch.gather(s, 1, idx), torch.gather(s, 1, wi)), "selected scores differ"
+    for r in range(rows):       # (score desc, index asc) order; no duplicates
+        key = [(-float(s[r, i]), int(i)) for i in idx[r]]
+        assert key == sorted(key) and len(set(idx[r].tolist())) == k
+        thr = float(s[r, idx[r, -1]])  # ties at the threshold resolved to the lowest columns
+        tied = (s[r] == thr).nonzero().flatten().tolist()
+        took = sorted(i for i in idx[r].tolist() if float(s[r, i]) == thr)
+        assert took == tied[:len(took)]
+    # payload + raw values
+    pay = torch.randperm(n, generator=torch.Generator().manual_seed(1)).int().repeat(rows, 1)
+    v2, i2 = ops.topk_rows(dev(s), k, alpha=0.0, idx_in=dev(pay))
+    close("topk raw", v2, torch.topk(s, k, dim=1)[0], 0)
+    assert torch.equal(torch.gather(s, 1, torch.argsort(pay.long(), dim=1).gather(1, i2.cpu().long())),
+                       torch.topk(s, k, dim=1)[0])
+
+
+def _conv_case(nq, nv, l, h, merged, n_mod, seed):
+    g = torch.Generator().manual_seed(seed)
+    q = [rnd(nq, h, seed=seed + 1 + m, scale=0.3) for m in range(n_mod)]
+    f = [rnd(nv, l, h, seed=seed + 5 + m, scale=0.3) for m in range(n_mod)]
+    mask = _ragged_mask(nv, l, seed + 9)
+    n_conv = 1 if merged else n_mod
+    cw = rnd(2 * n_conv * 5, seed=seed + 11, scale=0.5)
+    return q, f, mask, cw
+
+
+def _conv_oracle(q, f, mask, cw, merged, pair_vid, softmax):
+    n_mod = len(q)
+    n_conv = 1 if merged else n_mod
+    wst, wed = cw[:n_conv * 5].view(n_conv, 1, 1, 5), cw[n_conv * 5:].view(n_conv, 1, 1, 5)
+    sims = [torch.einsum("md,nld->mnl", q[m], f[m]) for m in range(n_mod)]
+    nq, nv, l = sims[0].shape
+    conv = lambda x, w: torch.nn.functional.conv1d(x.reshape(nq * nv, 1, l), w, padding=2).view(nq, nv, l)
+    if merged:
+        x = (sims[0] + sims[1]) / 2
+        st, ed = O.mask_logits(conv(x, wst[0]), mask), O.mask_logits(conv(x, wed[0]), mask)
+    else:
+        st = sum(O.mask_logits(conv(sims[m], wst[m]), mask) for m in range(n_mod)) / n_mod
+        ed = sum(O.mask_logits(conv(sims[m], wed[m]), mask) for m in range(n_mod)) / n_mod
+    if softmax:
+        st, ed = torch.softmax(st, -1), torch.softmax(ed, -1)
+    rows = torch.arange(nq).unsqueeze(1)
+    return st[rows, pair_vid.long()], ed[rows, pair_vid.long()]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(7, 10, 40, 128, True, 2), (40, 6, 128, 768, True, 2), (9, 12, 100, 256, False, 1),
+                                  (5, 8, 24, 128, False, 2)])
+@pytest.mark.parametrize("softmax", [False, True])
+def test_convse_rerank(ops, dtype, case, softmax):
+    nq, nv, l, h, merged, n_mod = case
+    lpad = (l + 15) // 16 * 16
+    q, f, mask, cw = _conv_case(nq, nv, l, h, merged, n_mod, 100)
+    g = torch.Generator().manual_seed(7)
+    k = min(5, nv)
+    pair = torch.stack([torch.randperm(nv, generator=g)[:k] for _ in range(nq)]).int()
+    pair[0, :] = pair[0, 0]       # many queries on one video + repeated pairs
+    pair[:, 0] = 1                 # one video selected by every query (chunks of 32 when nq > 32)
+    want_st, want_ed = _conv_oracle(q, f, mask, cw, merged, pair, softmax)
+    fp = [torch.zeros(nv, lpad, h) for _ in f]
+    for a, b in zip(fp, f):
+        a[:, :l] = b
+    mp = torch.zeros(nv, lpad); mp[:, :l] = mask
+    pair_skip = pair.clone()
+    pair_skip[-1, -1] = -1
+    st, ed = ops.convse_rerank([dev(x, dtype) for x in q], [dev(x, dtype) for x in fp], [dev(mp)] * n_mod,
+                               dev(pair_skip), dev(cw), l, merged, 5, softmax=softmax)
+    assert float(st[-1, -1].abs().max()) == 0 and float(ed[-1, -1].abs().max()) == 0, "skipped pair not zeroed"
+    st, ed = st[..., :l].cpu(), ed[..., :l].cpu()
+    want_st[-1, -1] = 0; want_ed[-1, -1] = 0
+    if softmax:
+        close("convse st prob", st, want_st, _tol(dtype, 1e-5, 1e-5), 1e-4)
+        close("convse ed prob", ed, want_ed, _tol(dtype, 1e-5, 1e-5), 1e-4)
+    else:
+        close("convse st logits", st, want_st, 1e-4, 1e-5)   # inputs bf16-exact, f32 accumulation in both modes
+        close("convse ed logits", ed, want_ed, 1e-4, 1e-5)
+
+
+def _check_moment_lists(sc, fl, want_s, want_i, l_ref):
+    """scores equal to 1e-6 relative; indices equal except inside groups of (near-)tied scores."""
+    sc, fl = sc.cpu().numpy(), fl.cpu().numpy()
+    want_s, want_i = want_s.numpy(), want_i.numpy()
+    for q in range(len(sc)):
+        npos = int((want_s[q] > 0).sum())
+        np.testing.assert_allclose(sc[q][:npos], want_s[q][:npos], rtol=2e-6, atol=0)
+        assert (sc[q][npos:] == 0).all() and (fl[q][npos:] == -1).all()
+        mism = np.nonzero(fl[q][:npos] != want_i[q][:npos])[0]
+        for i in mism:   # allowed only where the neighbouring scores are within rounding of each other
+            j = int(np.nonzero(want_i[q][:npos] == fl[q][i])[0][0]) if fl[q][i] in want_i[q][:npos] else None
+            assert j is not None and abs(want_s[q][j] - want_s[q][i]) <= 4e-6 * want_s[q][i], (q, i, j)
+
+
+@pytest.mark.parametrize("case", [(6, 5, 40, 60), (4, 100, 128, 200), (3, 1, 100, 200), (2, 3, 7, 50), (3, 100, 100, 200)])
+def test_moment_topk(ops, case):
+    nq, k, l, n_out = case
+    lpad = (l + 15) // 16 * 16
+    g = torch.Generator().manual_seed(120)
+    mask = (torch.arange(l)[None, None] < torch.randint(3, l + 1, (nq, k, 1), generator=g)).float()
+    st = torch.softmax(O.mask_logits(torch.randn(nq, k, l, generator=g) * 3, mask), -1)
+    ed = torch.softmax(O.mask_logits(torch.randn(nq, k, l, generator=g) * 3, mask), -1)
+    w = torch.exp(20 * (torch.rand(nq, k, generator=g) * 0.3))
+    w, _ = torch.sort(w, dim=1, descending=True)
+    prod = torch.einsum("qvm,qv,qvn->qvmn", st, w, ed) * torch.from_numpy(O.min_max_length_mask(l, 2, 16))
+    ws, wi = torch.sort(prod.reshape(nq, -1), dim=1, descending=True)
+    stp, edp = torch.zeros(nq, k, lpad), torch.zeros(nq, k, lpad)
+    stp[..., :l], edp[..., :l] = st, ed
+    sc, fl = ops.moment_topk(dev(stp), dev(edp), dev(w), l, 2, 16, n_out)
+    _check_moment_lists(sc, fl, ws[:, :n_out], wi[:, :n_out], l)
+
+
+def test_moment_topk_flat_distribution_fallback(ops):
+    """uniform probabilities: every candidate ties -> list overflow -> exact radix-select fallback."""
+    nq, k, l, n_out = 2, 100, 128, 200
+    st = torch.full((nq, k, l), 1.0 / l)
+    ed = torch.full((nq, k, l), 1.0 / l)
+    w = torch.ones(nq, k)
+    w[:, 0] = 2.0
+    sc, fl = ops.moment_topk(dev(st), dev(ed), dev(w), l, 2, 16, n_out)
+    sc, fl = sc.cpu(), fl.cpu()
+    assert torch.allclose(sc, torch.full_like(sc, 2.0 / l / l))
+    assert ((fl >= 0) & (fl < l * l)).all(), "all winners must come from the boosted video 0"
+    for q in range(nq):
+        assert len(set(fl[q].tolist())) == n_out

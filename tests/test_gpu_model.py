@@ -1,0 +1,253 @@
+"""GPU parity tests at the drop-in boundary: tvretrieval_amd.model_xml.XML / tvretrieval_amd.inference against
+(a) the golden vectors captured from the reference and (b) the CPU oracle on larger seeded inputs.
+fp32 compute: scores within 1e-4, top-k indices / spans identical (ties within rounding excepted).
+bf16 compute: reported as top-k overlap (BASELINE.json: bf16 configs are judged by overlap / R@1)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import xml_oracle as O
+from test_gpu_kernels import close, DEV
+
+pytestmark = pytest.mark.gpu
+
+MODEL_CASES = ["xml_video_sub_cross_h128", "xml_video_only_h256", "xml_sub_only_h128",
+               "xml_video_sub_nocross_nomerge_h128"]
+
+
+def build_model(cfg, sd, dtype=torch.float32):
+    from tvretrieval_amd.model_xml import XML
+    m = XML(cfg, compute_dtype=dtype)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    return m.to(DEV).eval()
+
+
+def T(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV)
+
+
+@pytest.mark.parametrize("name", MODEL_CASES)
+def test_golden_fp32(name):
+    d, cfg, sd = load_golden(name)
+    m = build_model(cfg, sd)
+    dummy = torch.zeros(len(d["ctx_lens"]), 2, 2, device=DEV)
+    vf = T(d["video_feat"]) if m.use_video else dummy
+    vm = T(d["video_mask"]) if m.use_video else dummy
+    sf = T(d["sub_feat"]) if m.use_sub else dummy
+    sm = T(d["sub_mask"]) if m.use_sub else dummy
+    with torch.no_grad():
+        # intermediates first: localise a failure to one kernel
+        first = "video" if m.use_video else "sub"
+        proj, enc1 = getattr(m, first + "_input_proj"), getattr(m, first + "_encoder1")
+        feat, mask = (vf, vm) if m.use_video else (sf, sm)
+        from tvretrieval_amd import ops
+        p, e = proj.packed(torch.float32), m.ctx_pos_embed.packed(torch.float32)
+        x = ops.linear_ln_relu_pos(feat, p["ln_g"], p["ln_b"], p["w"], p["b"], e["pos"], e["ln_g"], e["ln_b"])
+        close("ctx_pos_embed out", x, d["int/ctx_pos_embed"], 1e-4)
+        v1, v2, s1, s2 = m.encode_context(vf, vm, sf, sm)
+        for k, t in (("vf1", v1), ("vf2", v2), ("sf1", s1), ("sf2", s2)):
+            if k in d:
+                close(k + " (incl. padded rows)", t, d[k], 2e-4)
+            else:
+                assert t is None
+        vq, sq = m.encode_query(T(d["query_feat"]), T(d["query_mask"]))
+        close("video_query", vq, d["video_query"], 1e-4)
+        close("sub_query", sq, d["sub_query"], 1e-4)
+        q2c, st, ed = m.get_pred_from_raw_query(T(d["query_feat"]), T(d["query_mask"]), v1, v2,
+                                                vm if m.use_video else None, s1, s2, sm if m.use_sub else None,
+                                                cross=True)
+        close("q2c cross", q2c, d["q2c_cross"], 1e-4)
+        close("st cross", st, d["st_cross"], 1e-3, 1e-6)     # logits are O(1..10); -1e10 fills compare exactly
+        close("ed cross", ed, d["ed_cross"], 1e-3, 1e-6)
+        n = d["q2c_pair"].shape[0]
+        sel = lambda t: None if t is None else t[:n].contiguous()
+        q2c_p, st_p, ed_p = m.get_pred_from_raw_query(T(d["query_feat"])[:n], T(d["query_mask"])[:n], sel(v1), sel(v2),
+                                                      sel(vm) if m.use_video else None, sel(s1), sel(s2),
+                                                      sel(sm) if m.use_sub else None, cross=False)
+        close("q2c pair", q2c_p, d["q2c_pair"], 1e-4)
+        close("st pair", st_p, d["st_pair"], 1e-3, 1e-6)
+        close("ed pair", ed_p, d["ed_pair"], 1e-3, 1e-6)
+
+
+class GoldenDataset(object):
+    """The reference's eval-dataset contract (xml/start_end_dataset.py:171-343) over fixture arrays."""
+
+    def __init__(self, d, use_video, use_sub):
+        self.d = d
+        self.n_v = len(d["ctx_lens"])
+        self.n_q = len(d["query_gt_video"])
+        self.use_video, self.use_sub = use_video, use_sub
+        self.video2idx = {"vid_%03d" % i: int(d["video_idx"][i]) for i in range(self.n_v)}
+        self.mode, self.gt = "query", False
+
+    def set_data_mode(self, mode):
+        self.mode = mode
+
+    def load_gt_vid_name_for_query(self, flag):
+        self.gt = flag
+
+    def __len__(self):
+        return self.n_q if self.mode == "query" else self.n_v
+
+    def __getitem__(self, i):
+        if self.mode == "context":
+            mi = dict(video_feat=self.d["video_feat/%d" % i], sub_feat=self.d["sub_feat/%d" % i])
+            return dict(meta=dict(vid_name="vid_%03d" % i, duration=0.0), model_inputs=mi)
+        meta = dict(desc_id=5000 + i, desc="query %d" % i,
+                    vid_name="vid_%03d" % int(self.d["query_gt_video"][i]) if self.gt else None)
+        return dict(meta=meta, model_inputs=dict(query_feat=self.d["query_feat/%d" % i]))
+
+
+def _compare_lists(got, want, task):
+    """[video_idx, st, ed, score] lists: scores to 1e-4 relative; ids/spans identical unless scores tie to rounding."""
+    assert len(got) == want.shape[0]
+    for qi, e in enumerate(got):
+        g = np.array(e["predictions"], dtype=np.float64).reshape(-1, 4)
+        w = want[qi]
+        w = w[w[:, 3] > 0]
+        assert len(g) >= min(len(w), len(g)) and len(g) <= want.shape[1]
+        n = min(len(g), len(w))
+        assert n == len(w) or len(g) == want.shape[1], (task, qi, len(g), len(w))
+        np.testing.assert_allclose(g[:n, 3], w[:n, 3], rtol=1e-4, err_msg="%s q%d scores" % (task, qi))
+        for i in np.nonzero((g[:n, :3] != w[:n, :3]).any(1))[0]:
+            j = np.nonzero((w[:n, :3] == g[i, :3]).all(1))[0]
+            assert len(j) == 1 and abs(w[j[0], 3] - w[i, 3]) <= 2e-4 * w[i, 3], (task, qi, i, g[i], w[i])
+
+
+@pytest.mark.parametrize("name", ["pipeline_video_sub_h128", "pipeline_video_only_h128"])
+def test_golden_pipeline_fp32(name):
+    """compute_context_info -> compute_query2ctx_info(VCMR, SVMR, VR) vs the reference driver's own output."""
+    import argparse
+    from tvretrieval_amd import inference as inf
+    d, cfg, sd = load_golden(name)
+    o = json.loads(str(d["opt"]))
+    m = build_model(cfg, sd)
+    ds = GoldenDataset(d, m.use_video, m.use_sub)
+    opt = argparse.Namespace(eval_context_bsz=o["eval_context_bsz"], eval_query_bsz=o["eval_query_bsz"],
+                             device=torch.device(DEV), q2c_alpha=o["q2c_alpha"], min_pred_l=o["min_pred_l"],
+                             max_pred_l=o["max_pred_l"], clip_length=o["clip_length"], debug=False,
+                             external_inference_vr_res_path=None, max_ctx_l=cfg["max_ctx_l"])
+    with torch.no_grad():
+        ctx = inf.compute_context_info(m, ds, opt)
+        for k in ["video_feat1", "video_feat2", "video_mask", "sub_feat1", "sub_feat2", "sub_mask"]:
+            if ("ctx/" + k) in d:
+                close("ctx " + k, ctx[k], d["ctx/" + k], 2e-4)
+        res = inf.compute_query2ctx_info(m, ds, opt, ctx, max_before_nms=o["max_before_nms"],
+                                         max_n_videos=o["max_vcmr_video"], tasks=("SVMR", "VCMR", "VR"))
+    for task in ("VR", "VCMR", "SVMR"):
+        _compare_lists(res[task], d["res/" + task], task)
+
+
+@pytest.mark.parametrize("name", ["xml_video_sub_cross_h128", "xml_video_only_h256"])
+def test_golden_bf16_overlap(name):
+    """bf16 compute on the same fixtures: features within bf16 rounding of the fp32 reference, and the video
+    ranking agrees with the reference wherever the reference's own margin exceeds bf16 noise."""
+    d, cfg, sd = load_golden(name)
+    m = build_model(cfg, sd, torch.bfloat16)
+    dummy = torch.zeros(len(d["ctx_lens"]), 2, 2, device=DEV)
+    with torch.no_grad():
+        v1, v2, s1, s2 = m.encode_context(T(d["video_feat"]) if m.use_video else dummy,
+                                          T(d["video_mask"]) if m.use_video else dummy,
+                                          T(d["sub_feat"]) if m.use_sub else dummy,
+                                          T(d["sub_mask"]) if m.use_sub else dummy)
+        for k, t in (("vf1", v1), ("vf2", v2), ("sf1", s1), ("sf2", s2)):
+            if k in d:
+                assert t.dtype == torch.bfloat16
+                close(k, t, d[k], 0.12, 0.02)
+        q2c, st, ed = m.get_pred_from_raw_query(T(d["query_feat"]), T(d["query_mask"]), v1, v2,
+                                                T(d["video_mask"]) if m.use_video else None, s1, s2,
+                                                T(d["sub_mask"]) if m.use_sub else None, cross=True)
+    close("q2c bf16", q2c, d["q2c_cross"], 2e-2)
+    want = d["q2c_cross"]
+    got = q2c.cpu().numpy()
+    for q in range(len(want)):
+        order = np.argsort(-want[q])
+        if want[q][order[0]] - want[q][order[1]] > 5e-2:
+            assert int(np.argmax(got[q])) == int(order[0])
+
+
+def _synthetic_model(ctx_mode, hidden, dv, ds_, dq, max_ctx_l, dtype, seed=0, cross=True, merge=True):
+    from tvretrieval_amd.model_xml import XML
+    cfg = dict(merge_two_stream=merge, cross_att=cross, span_predictor_type="conv", encoder_type="transformer",
+               visual_input_size=dv, sub_input_size=ds_, query_input_size=dq, hidden_size=hidden, conv_kernel_size=5,
+               stack_conv_predictor_conv_kernel_sizes=-1, conv_stride=1, max_ctx_l=max_ctx_l, max_desc_l=30,
+               input_drop=0.1, drop=0.1, n_heads=4, initializer_range=0.02, ctx_mode=ctx_mode, margin=0.1,
+               ranking_loss_type="hinge", lw_neg_q=1, lw_neg_ctx=1, lw_st_ed=0.01, use_hard_negative=False,
+               hard_pool_size=20, use_self_attention=True, no_modular=False)
+    if ctx_mode != "video_sub":
+        cfg["merge_two_stream"] = False
+        cfg["cross_att"] = False
+    torch.manual_seed(seed)
+    m = XML(cfg, compute_dtype=dtype)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():   # richer than N(0, 0.02): avoids near-identical videos (see tools/make_golden.py)
+        for n_, p in m.named_parameters():
+            if n_.lower().endswith("layernorm.weight"):
+                p.copy_(1 + 0.2 * torch.randn(p.shape, generator=g))
+            elif n_.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif "predictor" in n_:
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+            elif p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) / np.sqrt(p.shape[-1]))
+            p.copy_(p.to(torch.bfloat16).float())
+    return m.to(DEV).eval(), cfg
+
+
+def _feats(n, lens, dim, seed):
+    g = torch.Generator().manual_seed(seed)
+    l = int(max(lens))
+    x = torch.zeros(n, l, dim)
+    mask = torch.zeros(n, l)
+    for i, li in enumerate(lens):
+        v = torch.randn(int(li), dim, generator=g)
+        x[i, :li] = (v / (v.norm(dim=-1, keepdim=True) + 1e-5)).to(torch.bfloat16).float()
+        mask[i, :li] = 1
+    return x, mask
+
+
+@pytest.mark.parametrize("ctx_mode,hidden", [("video_sub", 768), ("video", 256)])
+def test_search_vs_oracle_fp32(ctx_mode, hidden):
+    """BASELINE configs[0]/[1]-shaped case at a size the oracle finishes in seconds: full VCMR search (encode,
+    K6, top-k, ConvSE, moment top-n) against the reference formulation on CPU."""
+    from tvretrieval_amd import inference as inf
+    nv, nq, l = 48, 33, 128
+    m, cfg = _synthetic_model(ctx_mode, hidden, 512, 256, 256, l, torch.float32, seed=5)
+    rng = np.random.default_rng(3)
+    lens = rng.integers(20, l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, 512, 1)
+    sf, sm = _feats(nv, lens, 256, 2)
+    qf, qm = _feats(nq, rng.integers(5, 31, nq), 256, 3)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    om = O.OracleXML(cfg, sd)
+    with torch.no_grad():
+        ov1, ov2, os1, os2 = om.encode_context(vf, vm, sf, sm)
+        q2c, st, ed = om.get_pred_from_raw_query(qf, qm, ov1, ov2, vm if om.use_video else None, os1, os2,
+                                                 sm if om.use_sub else None, cross=True)
+        want = O.vcmr_tail(q2c, st, ed, 20.0, 10, 2, 16, 200)
+        bs = 16
+        batches = [(vf[b:b + bs].to(DEV), vm[b:b + bs].to(DEV), sf[b:b + bs].to(DEV), sm[b:b + bs].to(DEV))
+                   for b in range(0, nv, bs)]
+        # all batches are padded to the same L here, so batching does not change padded-row semantics
+        index = inf.build_corpus_index(m, batches)
+        out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=200)
+    close("q2c", out["q2c"], q2c, 1e-4)
+    close("top scores", out["top_scores"], want["top_scores"], 0, 2e-3)   # exp(20 s): 1e-4 on s -> 2e-3 relative
+    gi, wi = out["top_indices"].cpu().numpy(), want["top_indices"].numpy()
+    ws = want["top_scores"].numpy()
+    for q in range(nq):
+        for i in np.nonzero(gi[q] != wi[q])[0]:
+            j = np.nonzero(wi[q] == gi[q][i])[0]
+            assert len(j) == 1 and abs(ws[q][j[0]] - ws[q][i]) <= 4e-3 * ws[q][i], ("video rank", q, i)
+    same = (gi == wi).all(1)
+    assert same.mean() > 0.8
+    fs, fi = out["flat_scores"].cpu().numpy(), out["flat_indices"].cpu().numpy()
+    wfs, wfi = want["flat_scores"].numpy(), want["flat_indices"].numpy()
+    for q in np.nonzero(same)[0]:
+        np.testing.assert_allclose(fs[q], wfs[q], rtol=5e-3)
+        agree = (fi[q] == wfi[q]).mean()
+        assert agree > 0.9, ("moment order", q, agree)
+        assert set(fi[q][:100].tolist()) <= set(wfi[q].tolist()) | {-1}

@@ -1,0 +1,96 @@
+"""ctypes binding of libxmlhip.so (C ABI declared in include/xmlhip.h).
+
+There is NO fallback: if the HIP library is missing or fails to load, importing the product path raises.
+The library is built in-tree by `tvretrieval_amd/csrc/build.sh` (called from `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libxmlhip.so")
+
+XML_F32 = 0
+XML_BF16 = 1
+
+ABI_VERSION = 1
+
+
+class XmlHipError(RuntimeError):
+    pass
+
+
+class ConvseDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in
+                ("nq", "nv", "kpairs", "lpad", "l_ref", "hidden", "n_mod", "merged", "ksize", "softmax", "dt")]
+
+
+# name -> (restype, argtypes)   -- must list every symbol of include/xmlhip.h (tests/test_capi.py checks)
+SIGNATURES = {
+    "xml_abi_version": (c_int, []),
+    "xml_build_arch": (c_char_p, []),
+    "xml_status_string": (c_char_p, [c_int]),
+    "xml_pack_weights": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p]),
+    "xml_convert": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "xml_linear_ln_relu_pos_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "xml_linear_ln_relu_pos": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                       c_void_p]),
+    "xml_attention_block_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "xml_attention_block": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "xml_cross_attention_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "xml_cross_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                    c_void_p, c_size_t, c_void_p]),
+    "xml_modular_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                 c_void_p]),
+    "xml_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "xml_l2norm_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "xml_q2c_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
+                               c_int, c_void_p]),
+    "xml_topk_rows_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "xml_topk_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
+                              c_void_p, c_size_t, c_void_p]),
+    "xml_convse_rerank_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvseDesc)]),
+    "xml_convse_rerank": (c_int, [ctypes.POINTER(ConvseDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "xml_moment_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
+                                c_int, c_int, c_void_p]),
+    "xml_add_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                  c_void_p]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libxmlhip.so (once).  Raises XmlHipError if it is missing: there is no CPU path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise XmlHipError(
+            "libxmlhip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(tvretrieval_amd/csrc/build.sh). The HIP extension is mandatory; there is no fallback." % LIB_PATH)
+    try:
+        lib = ctypes.CDLL(LIB_PATH)
+    except OSError as e:
+        raise XmlHipError("failed to load %s: %s" % (LIB_PATH, e))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise XmlHipError("libxmlhip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.xml_abi_version() != ABI_VERSION:
+        raise XmlHipError("libxmlhip.so ABI %d != binding ABI %d" % (lib.xml_abi_version(), ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def check(status, what):
+    if status != 0:
+        msg = load().xml_status_string(status).decode()
+        raise XmlHipError("%s failed: %s (%d)" % (what, msg, status))

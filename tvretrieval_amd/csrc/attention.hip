@@ -1,0 +1,366 @@
+// K3/K4/K5: multi-head attention of the XML encoders.
+//   reference: BertSelfAttention.forward   xml/model_components.py:266-303
+//              BertAttention.forward       xml/model_components.py:207-216
+//              cross_context_encoder       xml/model_xml.py:357-373
+//              get_modularized_queries     xml/model_xml.py:410-423
+//
+// Attention core: one workgroup (4 waves) per (sequence, head).  L <= 128, so the whole K tile, then the
+// whole V^T tile, live in LDS and the L x L score tile lives in registers (16-row query tiles, two per wave):
+//   phase A  S = Q K^T  (MFMA, K rows from LDS)  ->  s/sqrt(dh) + (1-mask)*-1e4  ->  softmax in registers
+//   phase B  O = P V    (P through a per-wave LDS patch to reach the A-operand layout, V^T rows from LDS)
+// Statistics and accumulation are f32 for both storage types.
+#include "gemm.h"
+#include "internal.h"
+
+template <typename T> struct ChunkOf { static constexpr int elems = 64 / (int)sizeof(T); };  // K elems per MFMA chunk
+
+template <typename T, typename OutT, int DH>
+__global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict__ Q, int ldq,
+                                                             const T* __restrict__ Kp, int ldk,
+                                                             const T* __restrict__ Vp, int ldv,
+                                                             const float* __restrict__ q_mask,
+                                                             const float* __restrict__ k_mask, OutT* __restrict__ out,
+                                                             int ldo, int lq, int lk, float inv_div_unused,
+                                                             float sqrt_dh) {
+  constexpr int CE = ChunkOf<T>::elems;       // 32 (bf16) / 16 (f32)
+  constexpr int VEC = 16 / (int)sizeof(T);    // elements per 16-byte vector
+  constexpr int DCH = DH / CE;                // chunks along dh
+  constexpr int DT16 = DH / 16;               // 16-wide output tiles along dh
+  constexpr int MAXNT = 8;                    // key tiles of 16 (L <= 128)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int n = blockIdx.x, head = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int lkp = (lk + CE - 1) / CE * CE;    // keys padded to the MFMA K chunk
+  const int nkt = (lk + 15) / 16;             // key tiles that hold at least one real key
+  const int k_stride = DH * (int)sizeof(T) + 16;     // bytes, +16 keeps ds_read_b128 conflict-free
+  const int vt_stride = lkp * (int)sizeof(T) + 16;
+  const int kv_bytes = max(((lk + 15) / 16 * 16) * k_stride, DH * vt_stride);
+  char* s_kv = smem;
+  char* s_p = smem + kv_bytes + wave * (16 * vt_stride);
+
+  const T* qbase = Q + (int64_t)n * lq * ldq + head * DH;
+  const T* kbase = Kp + (int64_t)n * lk * ldk + head * DH;
+  const T* vbase = Vp + (int64_t)n * lk * ldv + head * DH;
+
+  // ---- stage K rows ------------------------------------------------------------------------------
+  {
+    const int rows16 = (lk + 15) / 16 * 16;
+    constexpr int VPR = DH / VEC;  // 16-byte vectors per row
+    for (int i = tid; i < rows16 * VPR; i += 256) {
+      const int r = i / VPR, c = i % VPR;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (r < lk) v = ld_global16(kbase + (int64_t)r * ldk + c * VEC);
+      *reinterpret_cast<uint4*>(s_kv + r * k_stride + c * 16) = v;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase A: scores + softmax, two query tiles per wave -----------------------------------------
+  f32x4 p[2][MAXNT];
+  const int nqt = (lq + 15) / 16;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qt = wave + t * 4;
+#pragma unroll
+    for (int j = 0; j < MAXNT; ++j) p[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (qt >= nqt) continue;
+    const int qrow = qt * 16 + fr;
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      uint4 a = make_uint4(0, 0, 0, 0);
+      if (qrow < lq) a = ld_global16(qbase + (int64_t)qrow * ldq + c * CE + fg * VEC);
+#pragma unroll
+      for (int j = 0; j < MAXNT; ++j) {
+        if (j < nkt) {
+          const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
+          Mma<T>::chunk(p[t][j], a, b);
+        }
+      }
+    }
+    // element (row = fg*4 + r, col = j*16 + fr)
+    float km[MAXNT];
+#pragma unroll
+    for (int j = 0; j < MAXNT; ++j) {
+      const int col = j * 16 + fr;
+      km[j] = (col < lk) ? k_mask[(int64_t)n * lk + col] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = qt * 16 + fg * 4 + r;
+      const float qm = (q_mask && row < lq) ? q_mask[(int64_t)n * lq + row] : 1.f;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < MAXNT; ++j) {
+        const int col = j * 16 + fr;
+        float s = -INFINITY;
+        if (col < lk) s = p[t][j][r] / sqrt_dh + (1.f - qm * km[j]) * -10000.f;
+        p[t][j][r] = s;
+        mx = fmaxf(mx, s);
+      }
+      mx = lane16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < MAXNT; ++j) {
+        const float e = expf(p[t][j][r] - mx);   // exp(-inf) = 0 for padded key columns
+        p[t][j][r] = e;
+        sum += e;
+      }
+      sum = lane16_sum(sum);
+#pragma unroll
+      for (int j = 0; j < MAXNT; ++j) p[t][j][r] = p[t][j][r] / sum;
+    }
+  }
+  __syncthreads();
+
+  // ---- stage V^T (overwrites K) -------------------------------------------------------------------
+  {
+    constexpr int VPR = DH / VEC;
+    for (int i = tid; i < lkp * VPR; i += 256) {
+      const int r = i / VPR, c = i % VPR;  // key r, dh vector c
+      float vals[VEC];
+      if (r < lk) {
+        const uint4 v = ld_global16(vbase + (int64_t)r * ldv + c * VEC);
+        unpack16<T>(v, vals);
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) vals[e] = 0.f;
+      }
+#pragma unroll
+      for (int e = 0; e < VEC; ++e)
+        DT<T>::st(reinterpret_cast<T*>(s_kv + (c * VEC + e) * vt_stride) + r, vals[e]);
+    }
+  }
+  __syncthreads();
+
+  // ---- phase B: O = P V ----------------------------------------------------------------------------
+  const int nkc = lkp / CE;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qt = wave + t * 4;
+    if (qt >= nqt) continue;
+    // P (C layout) -> per-wave LDS patch [16][lkp] as T
+#pragma unroll
+    for (int j = 0; j < MAXNT; ++j) {
+      const int col = j * 16 + fr;
+      if (col < lkp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          DT<T>::st(reinterpret_cast<T*>(s_p + (fg * 4 + r) * vt_stride) + col, p[t][j][r]);
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): the patch is wave-private, no block barrier needed
+    __builtin_amdgcn_wave_barrier();
+    f32x4 o[DT16];
+#pragma unroll
+    for (int d = 0; d < DT16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nkc; ++c) {
+      const uint4 a = *reinterpret_cast<const uint4*>(s_p + fr * vt_stride + c * 64 + fg * 16);
+#pragma unroll
+      for (int d = 0; d < DT16; ++d) {
+        const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (d * 16 + fr) * vt_stride + c * 64 + fg * 16);
+        Mma<T>::chunk(o[d], a, b);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = qt * 16 + fg * 4 + r;
+      if (row >= lq) continue;
+      OutT* po = out + ((int64_t)n * lq + row) * ldo + head * DH;
+#pragma unroll
+      for (int d = 0; d < DT16; ++d) DT<OutT>::st(po + d * 16 + fr, o[d][r]);
+    }
+  }
+}
+
+static size_t attn_lds_bytes(int lk, int dh, int dt) {
+  const int es = (int)dt_size(dt), ce = 64 / es;
+  const int lkp = (lk + ce - 1) / ce * ce;
+  const size_t k_stride = (size_t)dh * es + 16, vt_stride = (size_t)lkp * es + 16;
+  const size_t kvb = std::max((size_t)((lk + 15) / 16 * 16) * k_stride, (size_t)dh * vt_stride);
+  return kvb + 4 * 16 * vt_stride;
+}
+
+template <typename T, typename OutT, int DH>
+static int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
+                       const float* k_mask, void* out, int64_t n, int lq, int lk, int hidden, int n_heads,
+                       size_t lds, hipStream_t st) {
+  auto kern = attention_core_kernel<T, OutT, DH>;
+  if (lds > 64 * 1024) {
+    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return XML_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(kern, dim3((unsigned)n, n_heads), dim3(256), lds, st, (const T*)q, ldq, (const T*)k, ldk,
+                     (const T*)v, ldv, q_mask, k_mask, (OutT*)out, hidden, lq, lk, 0.f, sqrtf((float)DH));
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+template <typename T, typename OutT>
+static int dispatch_attn_dh(int dh, const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                            const float* q_mask, const float* k_mask, void* out, int64_t n, int lq, int lk,
+                            int hidden, int n_heads, size_t lds, hipStream_t st) {
+#define XML_ATTN_CASE(D)                                                                                     \
+  case D:                                                                                                    \
+    return launch_attn<T, OutT, D>(q, ldq, k, ldk, v, ldv, q_mask, k_mask, out, n, lq, lk, hidden, n_heads, \
+                                   lds, st);
+  switch (dh) {
+    XML_ATTN_CASE(32)
+    XML_ATTN_CASE(64)
+    XML_ATTN_CASE(96)
+    XML_ATTN_CASE(128)
+    XML_ATTN_CASE(192)
+    default:
+      return XML_ERR_UNSUPPORTED;
+  }
+#undef XML_ATTN_CASE
+}
+
+int xmli_attention_core(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
+                        const float* k_mask, void* out, int out_f32, int64_t n, int lq, int lk, int hidden,
+                        int n_heads, int dt, hipStream_t st) {
+  if (n <= 0 || lq <= 0 || lk <= 0 || n_heads <= 0 || hidden % n_heads) return XML_ERR_BAD_ARG;
+  if (lq > 128 || lk > 128) return XML_ERR_UNSUPPORTED;
+  const int dh = hidden / n_heads;
+  const size_t lds = attn_lds_bytes(lk, dh, dt);
+  if (lds > 160 * 1024) return XML_ERR_UNSUPPORTED;
+  if (dt == XML_F32)
+    return dispatch_attn_dh<float, float>(dh, q, ldq, k, ldk, v, ldv, q_mask, k_mask, out, n, lq, lk, hidden,
+                                          n_heads, lds, st);
+  if (dt == XML_BF16) {
+    if (out_f32)
+      return dispatch_attn_dh<bf16_t, float>(dh, q, ldq, k, ldk, v, ldv, q_mask, k_mask, out, n, lq, lk, hidden,
+                                             n_heads, lds, st);
+    return dispatch_attn_dh<bf16_t, bf16_t>(dh, q, ldq, k, ldk, v, ldv, q_mask, k_mask, out, n, lq, lk, hidden,
+                                            n_heads, lds, st);
+  }
+  return XML_ERR_BAD_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// public: BertAttention block.   ws = [ qkv (rows x 3H) dt | att (rows x H) dt | pre-LN (rows x H) f32 ]
+// ---------------------------------------------------------------------------------------------------
+extern "C" size_t xml_attention_block_workspace_bytes(int64_t n, int seq_len, int hidden, int dt) {
+  const size_t rows = (size_t)n * seq_len;
+  return align_up(rows * 3 * hidden * dt_size(dt), 256) + align_up(rows * hidden * dt_size(dt), 256) +
+         align_up(rows * hidden * 4, 256);
+}
+
+extern "C" int xml_attention_block(const void* x, const float* key_mask, const void* wqkv, const float* bqkv,
+                                   const void* wo, const float* bo, const float* ln_g, const float* ln_b, void* y,
+                                   int64_t n, int seq_len, int hidden, int n_heads, int dt, void* ws, size_t ws_bytes,
+                                   xml_stream_t stream) {
+  if (!x || !key_mask || !wqkv || !bqkv || !wo || !bo || !ln_g || !ln_b || !y || !ws) return XML_ERR_BAD_ARG;
+  if (n <= 0 || seq_len <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (seq_len > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
+  if (ws_bytes < xml_attention_block_workspace_bytes(n, seq_len, hidden, dt)) return XML_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t rows = n * seq_len;
+  char* qkv = (char*)ws;
+  char* att = qkv + align_up((size_t)rows * 3 * hidden * dt_size(dt), 256);
+  char* pre = att + align_up((size_t)rows * hidden * dt_size(dt), 256);
+  int rc = xmli_gemm(x, wqkv, bqkv, nullptr, qkv, rows, 3 * hidden, hidden, 0, 0, 1, 0, dt, st);
+  if (rc) return rc;
+  const size_t es = dt_size(dt);
+  rc = xmli_attention_core(qkv, 3 * hidden, qkv + (size_t)hidden * es, 3 * hidden, qkv + (size_t)2 * hidden * es,
+                           3 * hidden, nullptr, key_mask, att, 0, n, seq_len, seq_len, hidden, n_heads, dt, st);
+  if (rc) return rc;
+  rc = xmli_gemm(att, wo, bo, x, pre, rows, hidden, hidden, 0, /*residual*/ 2, 1, /*out_f32*/ 1, dt, st);
+  if (rc) return rc;
+  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_g, ln_b, y, rows, hidden, hidden, dt, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// public: cross-attention + residual LayerNorm.
+//   ws = [ q (n*lq x H) dt | kv (n*lk x 2H) dt | att f32 (n*lq x H) ]
+// ---------------------------------------------------------------------------------------------------
+extern "C" size_t xml_cross_attention_workspace_bytes(int64_t n, int lq, int lk, int hidden, int dt) {
+  return align_up((size_t)n * lq * hidden * dt_size(dt), 256) + align_up((size_t)n * lk * 2 * hidden * dt_size(dt), 256) +
+         align_up((size_t)n * lq * hidden * 4, 256);
+}
+
+extern "C" int xml_cross_attention(const void* main_x, const float* main_mask, const void* side_x,
+                                   const float* side_mask, const void* wq, const float* bq, const void* wkv,
+                                   const float* bkv, const float* ln_g, const float* ln_b, void* y, int64_t n, int lq,
+                                   int lk, int hidden, int n_heads, int dt, void* ws, size_t ws_bytes,
+                                   xml_stream_t stream) {
+  if (!main_x || !main_mask || !side_x || !side_mask || !wq || !bq || !wkv || !bkv || !ln_g || !ln_b || !y || !ws)
+    return XML_ERR_BAD_ARG;
+  if (n <= 0 || lq <= 0 || lk <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (lq > 128 || lk > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
+  if (ws_bytes < xml_cross_attention_workspace_bytes(n, lq, lk, hidden, dt)) return XML_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t es = dt_size(dt);
+  char* q = (char*)ws;
+  char* kv = q + align_up((size_t)n * lq * hidden * es, 256);
+  char* att = kv + align_up((size_t)n * lk * 2 * hidden * es, 256);
+  int rc = xmli_gemm(main_x, wq, bq, nullptr, q, n * lq, hidden, hidden, 0, 0, 1, 0, dt, st);
+  if (rc) return rc;
+  rc = xmli_gemm(side_x, wkv, bkv, nullptr, kv, n * lk, 2 * hidden, hidden, 0, 0, 1, 0, dt, st);
+  if (rc) return rc;
+  rc = xmli_attention_core(q, hidden, kv, 2 * hidden, kv + (size_t)hidden * es, 2 * hidden, main_mask, side_mask, att,
+                           /*out_f32*/ 1, n, lq, lk, hidden, n_heads, dt, st);
+  if (rc) return rc;
+  return xmli_add_layernorm(att, XML_F32, main_x, ln_g, ln_b, y, n * lq, hidden, hidden, dt, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// public: K5 modular pooling.  One workgroup per query.
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void modular_pool_kernel(const T* __restrict__ enc, const float* __restrict__ mask,
+                                                           const float* __restrict__ wm, T* __restrict__ out,
+                                                           int64_t n, int lq, int hidden, int n_mod) {
+  __shared__ float s_att[2][128];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* e = enc + (int64_t)q * lq * hidden;
+  for (int l = wave; l < lq; l += 4) {
+    for (int m = 0; m < n_mod; ++m) {
+      float s = 0.f;
+      for (int h = lane; h < hidden; h += 64) s += DT<T>::ld(e + (int64_t)l * hidden + h) * wm[m * hidden + h];
+      s = wave_sum(s);
+      if (lane == 0) {
+        const float mk = mask[(int64_t)q * lq + l];
+        s_att[m][l] = s * mk + (1.f - mk) * -1e10f;  // mask_logits, xml/model_xml.py:640-641
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < n_mod) {
+    float mx = -INFINITY;
+    for (int l = 0; l < lq; ++l) mx = fmaxf(mx, s_att[tid][l]);
+    float sum = 0.f;
+    for (int l = 0; l < lq; ++l) {
+      const float ev = expf(s_att[tid][l] - mx);
+      s_att[tid][l] = ev;
+      sum += ev;
+    }
+    for (int l = 0; l < lq; ++l) s_att[tid][l] /= sum;
+  }
+  __syncthreads();
+  for (int h = tid; h < hidden; h += 256) {
+    for (int m = 0; m < n_mod; ++m) {
+      float acc = 0.f;
+      for (int l = 0; l < lq; ++l) acc += s_att[m][l] * DT<T>::ld(e + (int64_t)l * hidden + h);
+      DT<T>::st(out + ((int64_t)m * n + q) * hidden + h, acc);
+    }
+  }
+}
+
+extern "C" int xml_modular_pool(const void* enc, const float* mask, const float* w_m, void* out, int64_t n, int lq,
+                                int hidden, int n_mod, int dt, xml_stream_t stream) {
+  if (!enc || !mask || !w_m || !out || n <= 0 || lq <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (n_mod < 1 || n_mod > 2 || lq > 128) return XML_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(modular_pool_kernel<float>, dim3((unsigned)n), dim3(256), 0, st, (const float*)enc, mask, w_m,
+                       (float*)out, n, lq, hidden, n_mod);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(modular_pool_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, st, (const bf16_t*)enc, mask,
+                       w_m, (bf16_t*)out, n, lq, hidden, n_mod);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}

@@ -1,0 +1,119 @@
+// Shared device helpers for libxmlhip (gfx950 / CDNA4 only: wave64, MFMA 16x16 f32-accumulate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/xmlhip.h"
+
+#define XML_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    if (hipGetLastError() != hipSuccess) return XML_ERR_LAUNCH; \
+  } while (0)
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_v __attribute__((ext_vector_type(8)));
+
+static constexpr int WAVE = 64;
+
+// ---- dtype traits ------------------------------------------------------------------------------
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
+  u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> struct DT;
+template <> struct DT<float> {
+  static constexpr int id = XML_F32;
+  static constexpr int vec = 4;  // elements per 16-byte vector
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct DT<bf16_t> {
+  static constexpr int id = XML_BF16;
+  static constexpr int vec = 8;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+// 16-byte vector <-> floats
+template <typename T> __device__ __forceinline__ void unpack16(const uint4& v, float* out);
+template <> __device__ __forceinline__ void unpack16<float>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x); out[1] = __uint_as_float(v.y);
+  out[2] = __uint_as_float(v.z); out[3] = __uint_as_float(v.w);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(const uint4& v, float* out) {
+  out[0] = __uint_as_float(v.x << 16); out[1] = __uint_as_float(v.x & 0xffff0000u);
+  out[2] = __uint_as_float(v.y << 16); out[3] = __uint_as_float(v.y & 0xffff0000u);
+  out[4] = __uint_as_float(v.z << 16); out[5] = __uint_as_float(v.z & 0xffff0000u);
+  out[6] = __uint_as_float(v.w << 16); out[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+template <typename T> __device__ __forceinline__ uint4 pack16(const float* in);
+template <> __device__ __forceinline__ uint4 pack16<float>(const float* in) {
+  return make_uint4(__float_as_uint(in[0]), __float_as_uint(in[1]), __float_as_uint(in[2]), __float_as_uint(in[3]));
+}
+template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
+  uint4 v;
+  v.x = (uint32_t)f32_to_bf16(in[0]) | ((uint32_t)f32_to_bf16(in[1]) << 16);
+  v.y = (uint32_t)f32_to_bf16(in[2]) | ((uint32_t)f32_to_bf16(in[3]) << 16);
+  v.z = (uint32_t)f32_to_bf16(in[4]) | ((uint32_t)f32_to_bf16(in[5]) << 16);
+  v.w = (uint32_t)f32_to_bf16(in[6]) | ((uint32_t)f32_to_bf16(in[7]) << 16);
+  return v;
+}
+
+// ---- MFMA "chunk": one 64-byte slice of K for a 16x16 output tile -------------------------------
+// Lane l supplies 16 bytes of row (l & 15) at byte offset (l >> 4) * 16 of the 64-byte K chunk, for both
+// operands (A rows = output rows, B rows = output columns; both K-contiguous).
+//   bf16: the 16 bytes are 8 consecutive k  -> one v_mfma_f32_16x16x32_bf16
+//   f32 : the 16 bytes are 4 consecutive k  -> four v_mfma_f32_16x16x4_f32; MFMA j consumes element j of
+//         every lane, i.e. k = 4*(l>>4) + j.  Both operands use the same k permutation, so the dot product
+//         is over the same 16 k values (summation order differs from sequential k; exact f32 fma chain).
+// Accumulator layout (both): acc[r] = D[row = (l >> 4) * 4 + r][col = l & 15].
+template <typename T> struct Mma;
+template <> struct Mma<float> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+template <> struct Mma<bf16_t> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; bf16x8_v v; } ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, acc, 0, 0, 0);
+  }
+};
+
+// ---- wave / block reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+// reductions over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float lane16_max(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ float lane16_sum(float v) {
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ uint4 ld_global16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void st_global16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+static inline size_t dt_size(int dt) { return dt == XML_F32 ? 4 : 2; }

@@ -1,0 +1,263 @@
+// K7: similarity contraction #2 + ConvSE start/end scorer, evaluated only on the selected (query, video) pairs.
+//   reference: get_merged_st_ed_prob   xml/model_xml.py:455-502   (merge_two_stream)
+//              _get_st_ed_prob         xml/model_xml.py:512-551   (single stream / no merge)
+//              softmax over clips      xml/inference.py:321-322
+//
+// The reference contracts every query with every clip of every video ((Nq,Nv,L) fp32, 111.6 GB at the TVR
+// shape) and then keeps only the rows of the top-k videos (xml/inference.py:365-367).  Here the pair list
+// is inverted on the device (video -> the queries that selected it), so each video's feat2 tile (L x H) is
+// fetched from HBM once and contracted on the MFMA pipe against the <= TM query vectors of a chunk:
+//   bytes ~= Nv*L*H*b*modalities (+ L2-resident query vectors) instead of Nq*k*L*H*b*modalities.
+// Epilogue per pair row, in LDS: k-tap zero-padded cross-correlation x2 (start / end filters), mask_logits,
+// softmax over clips.
+#include "gemm.h"
+
+static constexpr int TM = 32;            // pairs per workgroup chunk
+static constexpr int LP = 128 + 4;       // padded row length of the LDS similarity patch (floats)
+
+struct ConvseWs {
+  int32_t* counts;     // [nv]   pairs per video
+  int32_t* offsets;    // [nv+1] exclusive scan of counts
+  int32_t* cursor;     // [nv]
+  int32_t* chunk_off;  // [nv+1] exclusive scan of ceil(count / TM)
+  int32_t* bucket;     // [P]    pair ids grouped by video
+};
+
+static size_t convse_ws_layout(const xml_convse_desc* d, ConvseWs* w, char* base) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    char* p = base ? base + off : nullptr;
+    off += align_up(bytes, 256);
+    return p;
+  };
+  const size_t nv = (size_t)d->nv, P = (size_t)d->nq * d->kpairs;
+  char* counts = take(nv * 4);
+  char* cursor = take(nv * 4);   // counts and cursor are adjacent: one memset clears both
+  char* offsets = take((nv + 1) * 4);
+  char* chunk_off = take((nv + 1) * 4);
+  char* bucket = take(P * 4);
+  if (w) {
+    w->counts = (int32_t*)counts; w->cursor = (int32_t*)cursor; w->offsets = (int32_t*)offsets;
+    w->chunk_off = (int32_t*)chunk_off; w->bucket = (int32_t*)bucket;
+  }
+  return off;
+}
+
+extern "C" size_t xml_convse_rerank_workspace_bytes(const xml_convse_desc* d) {
+  if (!d) return 0;
+  return convse_ws_layout(d, nullptr, nullptr);
+}
+
+__global__ void convse_count_kernel(const int32_t* __restrict__ pair_vid, int32_t* __restrict__ counts, int64_t P,
+                                    int nv, float* __restrict__ st_out, float* __restrict__ ed_out, int lpad) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int v = pair_vid[p];
+  if (v >= 0 && v < nv) {
+    atomicAdd(&counts[v], 1);
+  } else {
+    for (int l = 0; l < lpad; ++l) { st_out[p * lpad + l] = 0.f; ed_out[p * lpad + l] = 0.f; }
+  }
+}
+
+// single workgroup: exclusive scans of counts and of ceil(counts / TM)
+__global__ __launch_bounds__(1024) void convse_scan_kernel(const int32_t* __restrict__ counts,
+                                                           int32_t* __restrict__ offsets,
+                                                           int32_t* __restrict__ chunk_off, int nv) {
+  __shared__ int32_t sa[1024], sb[1024];
+  __shared__ int32_t carry_a, carry_b;
+  const int tid = threadIdx.x;
+  if (tid == 0) { carry_a = 0; carry_b = 0; }
+  __syncthreads();
+  for (int base = 0; base < nv; base += 1024) {
+    const int i = base + tid;
+    const int c = i < nv ? counts[i] : 0;
+    const int ch = (c + TM - 1) / TM;
+    sa[tid] = c; sb[tid] = ch;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const int va = tid >= o ? sa[tid - o] : 0, vb = tid >= o ? sb[tid - o] : 0;
+      __syncthreads();
+      sa[tid] += va; sb[tid] += vb;
+      __syncthreads();
+    }
+    if (i < nv) { offsets[i] = carry_a + sa[tid] - c; chunk_off[i] = carry_b + sb[tid] - ch; }
+    __syncthreads();
+    if (tid == 1023) { carry_a += sa[1023]; carry_b += sb[1023]; }
+    __syncthreads();
+  }
+  if (tid == 0) { offsets[nv] = carry_a; chunk_off[nv] = carry_b; }
+}
+
+__global__ void convse_fill_kernel(const int32_t* __restrict__ pair_vid, const int32_t* __restrict__ offsets,
+                                   int32_t* __restrict__ cursor, int32_t* __restrict__ bucket, int64_t P, int nv) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int v = pair_vid[p];
+  if (v < 0 || v >= nv) return;
+  const int pos = atomicAdd(&cursor[v], 1);
+  bucket[offsets[v] + pos] = (int32_t)p;
+}
+
+struct ConvseArgs {
+  const void* q_lin[2];
+  const void* feat2[2];
+  const float* mask[2];
+  const float* conv_w;
+  float* st_out;
+  float* ed_out;
+  const int32_t* offsets;
+  const int32_t* chunk_off;
+  const int32_t* bucket;
+  int nv, kpairs, lpad, l_ref, hidden, n_mod, merged, ksize, softmax;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
+  using Cfg = GemmCfg<T, TM, 128, 1, 4>;
+  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
+  __shared__ float sim[2][TM][LP];
+  __shared__ int32_t s_pair[TM];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x;
+  if (chunk >= a.chunk_off[a.nv]) return;
+  // video owning this chunk: last v with chunk_off[v] <= chunk
+  int lo = 0, hi = a.nv;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (a.chunk_off[mid] <= chunk) lo = mid; else hi = mid;
+  }
+  const int v = lo;
+  const int first = a.offsets[v] + (chunk - a.chunk_off[v]) * TM;
+  const int cnt = min(TM, a.offsets[v + 1] - first);
+  if (tid < TM) s_pair[tid] = tid < cnt ? a.bucket[first + tid] : -1;
+  __syncthreads();
+
+  const int lane = tid & 63, wn = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n_sim = a.merged ? 1 : a.n_mod;
+  f32x4 acc[Cfg::MT][Cfg::NT];
+  for (int m = 0; m < a.n_mod; ++m) {
+    const T* ql = reinterpret_cast<const T*>(a.q_lin[m]);
+    const T* f2 = reinterpret_cast<const T*>(a.feat2[m]);
+    auto a_row = [&](int r) -> const char* {
+      const int p = s_pair[r];
+      return p >= 0 ? reinterpret_cast<const char*>(ql + (int64_t)(p / a.kpairs) * a.hidden) : nullptr;
+    };
+    auto b_row = [&](int r) -> const char* {
+      return r < a.lpad ? reinterpret_cast<const char*>(f2 + ((int64_t)v * a.lpad + r) * a.hidden) : nullptr;
+    };
+    if (a.merged && m > 0)
+      gemm_mainloop<T, Cfg, false>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem);
+    else
+      gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem);
+    if (!a.merged || m == a.n_mod - 1) {
+      const float scale = (a.merged && a.n_mod == 2) ? 0.5f : 1.f;
+      const int si = a.merged ? 0 : m;
+#pragma unroll
+      for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < Cfg::NT; ++nt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            sim[si][mt * 16 + fg * 4 + r][wn * 32 + nt * 16 + fr] = acc[mt][nt][r] * scale;
+    }
+  }
+  __syncthreads();
+
+  // ---- ConvSE epilogue: each wave owns TM/4 pair rows; a lane owns clips lane and lane + 64 ----------
+  const int half = a.ksize >> 1;
+  const float inv_mod = 1.f / (float)n_sim;
+  for (int row = wn; row < cnt; row += 4) {
+    const int p = s_pair[row];
+    float st[2], ed[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int l = lane + h * 64;
+      float s_acc = 0.f, e_acc = 0.f;
+      if (l < a.l_ref) {
+        for (int si = 0; si < n_sim; ++si) {
+          const float* wst = a.conv_w + si * a.ksize;
+          const float* wed = a.conv_w + (n_sim + si) * a.ksize;
+          float cs = 0.f, ce = 0.f;
+          for (int t = 0; t < a.ksize; ++t) {
+            const int j = l + t - half;
+            const float x = (j >= 0 && j < a.l_ref) ? sim[si][row][j] : 0.f;
+            cs += wst[t] * x;
+            ce += wed[t] * x;
+          }
+          const float mk = a.mask[a.merged ? 0 : si][(int64_t)v * a.lpad + l];
+          const float fill = (1.f - mk) * -1e10f;
+          s_acc += cs * mk + fill;   // mask_logits, xml/model_xml.py:640-641
+          e_acc += ce * mk + fill;
+        }
+        if (n_sim > 1) { s_acc *= inv_mod; e_acc *= inv_mod; }
+      } else {
+        s_acc = -INFINITY; e_acc = -INFINITY;
+      }
+      st[h] = s_acc; ed[h] = e_acc;
+    }
+    if (a.softmax) {
+      const float ms = wave_max(fmaxf(st[0], st[1])), me = wave_max(fmaxf(ed[0], ed[1]));
+      float es[2], ee[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { es[h] = expf(st[h] - ms); ee[h] = expf(ed[h] - me); }
+      const float ss = wave_sum(es[0] + es[1]), se = wave_sum(ee[0] + ee[1]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) { st[h] = es[h] / ss; ed[h] = ee[h] / se; }
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int l = lane + h * 64;
+      if (l < a.lpad) {
+        const bool in = l < a.l_ref;
+        a.st_out[(int64_t)p * a.lpad + l] = in ? st[h] : 0.f;
+        a.ed_out[(int64_t)p * a.lpad + l] = in ? ed[h] : 0.f;
+      }
+    }
+  }
+}
+
+extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1,
+                                 const void* feat2_0, const void* feat2_1, const float* mask0, const float* mask1,
+                                 const int32_t* pair_vid, const float* conv_w, float* st_out, float* ed_out, void* ws,
+                                 size_t ws_bytes, xml_stream_t stream) {
+  if (!d || !q_lin0 || !feat2_0 || !mask0 || !pair_vid || !conv_w || !st_out || !ed_out || !ws) return XML_ERR_BAD_ARG;
+  if (d->nq <= 0 || d->nv <= 0 || d->kpairs <= 0 || d->hidden <= 0) return XML_ERR_BAD_ARG;
+  if (d->n_mod < 1 || d->n_mod > 2 || (d->n_mod == 2 && (!q_lin1 || !feat2_1))) return XML_ERR_BAD_ARG;
+  if (d->n_mod == 2 && !d->merged && !mask1) return XML_ERR_BAD_ARG;
+  if (d->merged && d->n_mod != 2) return XML_ERR_BAD_ARG;
+  if (d->lpad % 16 || d->lpad > 128 || d->l_ref > d->lpad || d->l_ref <= 0 || d->hidden % 8) return XML_ERR_UNSUPPORTED;
+  if (!(d->ksize & 1) || d->ksize > 15 || d->ksize < 1) return XML_ERR_UNSUPPORTED;
+  if (d->dt != XML_F32 && d->dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (ws_bytes < xml_convse_rerank_workspace_bytes(d)) return XML_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  ConvseWs w;
+  convse_ws_layout(d, &w, (char*)ws);
+  const int64_t P = (int64_t)d->nq * d->kpairs;
+  // counts and cursor are the first two (adjacent, 256-aligned) regions
+  if (hipMemsetAsync(w.counts, 0, (size_t)((char*)w.offsets - (char*)w.counts), st) != hipSuccess) return XML_ERR_LAUNCH;
+  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, P, d->nv, st_out,
+                     ed_out, d->lpad);
+  XML_CHECK_LAUNCH();
+  hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, d->nv);
+  XML_CHECK_LAUNCH();
+  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.cursor, w.bucket,
+                     P, d->nv);
+  XML_CHECK_LAUNCH();
+  ConvseArgs a;
+  a.q_lin[0] = q_lin0; a.q_lin[1] = q_lin1;
+  a.feat2[0] = feat2_0; a.feat2[1] = feat2_1;
+  a.mask[0] = mask0; a.mask[1] = mask1 ? mask1 : mask0;
+  a.conv_w = conv_w; a.st_out = st_out; a.ed_out = ed_out;
+  a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket;
+  a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
+  a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax;
+  const int64_t max_chunks = P / TM + (P < d->nv ? P : d->nv);
+  if (d->dt == XML_F32)
+    hipLaunchKernelGGL(convse_kernel<float>, dim3((unsigned)max_chunks), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(convse_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), 0, st, a);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}

@@ -1,0 +1,14 @@
+// Cross-file internal entry points of libxmlhip (not part of the C ABI).
+#pragma once
+#include "common.h"
+
+// out = act(A W^T + bias) + addend ; add_mode 0 none / 1 positional table row (m % seq_len) / 2 residual row m
+int xmli_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
+              int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st);
+// y = LN(a + b) ; a may be f32 while b / y are dt ; rows of y have stride ld_out (>= d, tail zero-filled)
+int xmli_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
+                       int64_t rows, int d, int ld_out, int dt, hipStream_t st);
+// multi-head attention core on projected Q / K / V (see attention.hip)
+int xmli_attention_core(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
+                        const float* q_mask, const float* k_mask, void* out, int out_f32, int64_t n, int lq, int lk,
+                        int hidden, int n_heads, int dt, hipStream_t st);

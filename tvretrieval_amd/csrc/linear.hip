@@ -1,0 +1,234 @@
+// Projections and row-wise normalisations of the XML encoders (K1, K2, K4 and the query linears).
+//   reference: LinearLayer.forward           xml/model_components.py:156-163
+//              TrainablePositionalEncoding   xml/model_components.py:76-89
+//              BertSelfOutput.forward        xml/model_components.py:313-317
+#include "gemm.h"
+#include "internal.h"
+
+// ---------------------------------------------------------------------------------------------------
+// GEMM + epilogue:  out[m][n] = act(acc + bias[n]) + addend      (OutT = float when a LayerNorm follows)
+//   add_mode 0: none; 1: addend[(m % seq_len)][n] (positional table); 2: addend[m][n] (residual)
+// ---------------------------------------------------------------------------------------------------
+template <typename T, typename OutT, typename AddT>
+__global__ __launch_bounds__(256) void gemm_bias_act_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                            const float* __restrict__ bias,
+                                                            const AddT* __restrict__ addend, OutT* __restrict__ out,
+                                                            int64_t M, int N, int K, int relu, int add_mode,
+                                                            int seq_len) {
+  using Cfg = GemmCfg<T, 128, 128, 2, 2>;
+  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
+  const int64_t m0 = (int64_t)blockIdx.y * Cfg::BM;
+  const int n0 = blockIdx.x * Cfg::BN;
+  f32x4 acc[Cfg::MT][Cfg::NT];
+  auto a_row = [&](int r) -> const char* {
+    const int64_t m = m0 + r;
+    return m < M ? reinterpret_cast<const char*>(A + m * K) : nullptr;
+  };
+  auto b_row = [&](int r) -> const char* {
+    const int n = n0 + r;
+    return n < N ? reinterpret_cast<const char*>(W + (int64_t)n * K) : nullptr;
+  };
+  gemm_mainloop<T, Cfg>(acc, a_row, b_row, K * (int)sizeof(T), smem);
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+#pragma unroll
+  for (int mt = 0; mt < Cfg::MT; ++mt) {
+#pragma unroll
+    for (int nt = 0; nt < Cfg::NT; ++nt) {
+      const int n = n0 + wn * (Cfg::BN / Cfg::WN) + nt * 16 + (lane & 15);
+      if (n >= N) continue;
+      const float b = bias ? bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + wm * (Cfg::BM / Cfg::WM) + mt * 16 + (lane >> 4) * 4 + r;
+        if (m >= M) continue;
+        float v = acc[mt][nt][r] + b;
+        if (relu) v = fmaxf(v, 0.f);
+        if (add_mode == 1) v += DT<AddT>::ld(addend + (int64_t)(m % seq_len) * N + n);
+        else if (add_mode == 2) v += DT<AddT>::ld(addend + m * N + n);
+        DT<OutT>::st(out + m * N + n, v);
+      }
+    }
+  }
+}
+
+template <typename T, typename OutT, typename AddT>
+static int launch_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
+                       int N, int K, int relu, int add_mode, int seq_len, hipStream_t st) {
+  dim3 grid(cdiv(N, 128), cdiv(M, 128));
+  hipLaunchKernelGGL((gemm_bias_act_kernel<T, OutT, AddT>), grid, dim3(256), 0, st, (const T*)A, (const T*)W, bias,
+                     (const AddT*)addend, (OutT*)out, M, N, K, relu, add_mode, seq_len);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// out_f32: write f32 regardless of dt (pre-LayerNorm values keep full precision)
+int xmli_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
+              int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st) {
+  if (M <= 0 || N <= 0 || K <= 0) return XML_ERR_BAD_ARG;
+  if (dt == XML_F32) {
+    if (K % 4) return XML_ERR_UNSUPPORTED;
+    return launch_gemm<float, float, float>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+  } else if (dt == XML_BF16) {
+    if (K % 8) return XML_ERR_UNSUPPORTED;
+    if (out_f32) return launch_gemm<bf16_t, float, bf16_t>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+    return launch_gemm<bf16_t, bf16_t, bf16_t>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+  }
+  return XML_ERR_BAD_ARG;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Row-wise LayerNorm of (a [+ b]); one wave per row, f32 statistics (two-pass mean / variance).
+// ---------------------------------------------------------------------------------------------------
+template <typename InT, typename BT, typename OutT>
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const InT* __restrict__ a, const BT* __restrict__ b,
+                                                            const float* __restrict__ g,
+                                                            const float* __restrict__ beta, OutT* __restrict__ y,
+                                                            int64_t rows, int d, int ld_out, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const InT* pa = a + row * d;
+  const BT* pb = b ? b + row * d : nullptr;
+  float s = 0.f;
+  for (int i = lane; i < d; i += 64) s += DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f);
+  const float mean = wave_sum(s) / (float)d;
+  float v = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const float x = DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f) - mean;
+    v += x * x;
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+  OutT* py = y + row * ld_out;
+  for (int i = lane; i < d; i += 64) {
+    const float x = DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f);
+    DT<OutT>::st(py + i, (x - mean) * rstd * g[i] + beta[i]);
+  }
+  for (int i = d + lane; i < ld_out; i += 64) DT<OutT>::st(py + i, 0.f);  // zero K padding
+}
+
+template <typename InT, typename BT, typename OutT>
+static int launch_ln(const void* a, const void* b, const float* g, const float* beta, void* y, int64_t rows, int d,
+                     int ld_out, hipStream_t st) {
+  hipLaunchKernelGGL((add_layernorm_kernel<InT, BT, OutT>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const InT*)a,
+                     (const BT*)b, g, beta, (OutT*)y, rows, d, ld_out, 1e-5f);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+int xmli_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
+                       int64_t rows, int d, int ld_out, int dt, hipStream_t st) {
+  if (rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
+  if (dt == XML_F32) {
+    if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
+    return launch_ln<float, float, float>(a, b, g, beta, y, rows, d, ld_out, st);
+  }
+  if (a_dt == XML_F32) return launch_ln<float, bf16_t, bf16_t>(a, b, g, beta, y, rows, d, ld_out, st);
+  return launch_ln<bf16_t, bf16_t, bf16_t>(a, b, g, beta, y, rows, d, ld_out, st);
+}
+
+extern "C" int xml_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta,
+                                 void* y, int64_t rows, int d, int dt, xml_stream_t stream) {
+  if (!a || !g || !beta || !y) return XML_ERR_BAD_ARG;
+  return xmli_add_layernorm(a, a_dt, b, g, beta, y, rows, d, d, dt, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// F.normalize(x, dim=-1): x / max(||x||_2, 1e-12)
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows,
+                                                          int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const T* px = x + row * d;
+  float s = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const float v = DT<T>::ld(px + i);
+    s += v * v;
+  }
+  const float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+  for (int i = lane; i < d; i += 64) DT<T>::st(y + row * d + i, DT<T>::ld(px + i) / nrm);
+}
+
+extern "C" int xml_l2norm_rows(const void* x, void* y, int64_t rows, int d, int dt, xml_stream_t stream) {
+  if (!x || !y || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(l2norm_rows_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, (float*)y, rows, d);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(l2norm_rows_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, d);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// dtype conversion
+// ---------------------------------------------------------------------------------------------------
+template <typename S, typename D>
+__global__ void convert_kernel(const S* __restrict__ s, D* __restrict__ d, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    DT<D>::st(d + i, DT<S>::ld(s + i));
+}
+
+extern "C" int xml_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, xml_stream_t stream) {
+  if (!src || !dst || n < 0) return XML_ERR_BAD_ARG;
+  if (n == 0) return XML_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int grid = (int)((n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096);
+  if (src_dt == XML_F32 && dst_dt == XML_BF16)
+    hipLaunchKernelGGL((convert_kernel<float, bf16_t>), dim3(grid), dim3(256), 0, st, (const float*)src, (bf16_t*)dst, n);
+  else if (src_dt == XML_BF16 && dst_dt == XML_F32)
+    hipLaunchKernelGGL((convert_kernel<bf16_t, float>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (float*)dst, n);
+  else if (src_dt == XML_F32 && dst_dt == XML_F32)
+    hipLaunchKernelGGL((convert_kernel<float, float>), dim3(grid), dim3(256), 0, st, (const float*)src, (float*)dst, n);
+  else if (src_dt == XML_BF16 && dst_dt == XML_BF16)
+    hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), dim3(grid), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+extern "C" int xml_pack_weights(const float* src, void* dst, int dt, int64_t n, xml_stream_t stream) {
+  return xml_convert(src, XML_F32, dst, dt, n, stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// public: plain linear
+// ---------------------------------------------------------------------------------------------------
+extern "C" int xml_linear(const void* x, const void* w, const float* b, void* y, int64_t rows, int n, int k, int relu,
+                          int dt, xml_stream_t stream) {
+  if (!x || !w || !y) return XML_ERR_BAD_ARG;
+  return xmli_gemm(x, w, b, nullptr, y, rows, n, k, relu, 0, 1, 0, dt, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// public: K1 + K2
+//   ws layout: [ LN_in(x) as dt (rows x d_in) | pre-LN f32 (rows x hidden) ]
+// ---------------------------------------------------------------------------------------------------
+extern "C" size_t xml_linear_ln_relu_pos_workspace_bytes(int64_t rows, int d_in, int hidden, int dt) {
+  return align_up((size_t)rows * d_in * dt_size(dt), 256) + align_up((size_t)rows * hidden * 4, 256);
+}
+
+extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const float* ln_in_b,
+                                      const void* w, const float* b, const void* pos, const float* ln_pos_g,
+                                      const float* ln_pos_b, void* y, int64_t rows, int seq_len, int d_in, int hidden,
+                                      int dt, void* ws, size_t ws_bytes, xml_stream_t stream) {
+  if (!x || !ln_in_g || !ln_in_b || !w || !b || !pos || !ln_pos_g || !ln_pos_b || !y || !ws) return XML_ERR_BAD_ARG;
+  if (rows <= 0 || seq_len <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (d_in % 8 || hidden % 8) return XML_ERR_UNSUPPORTED;
+  if (ws_bytes < xml_linear_ln_relu_pos_workspace_bytes(rows, d_in, hidden, dt)) return XML_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* xn = (char*)ws;
+  char* pre = xn + align_up((size_t)rows * d_in * dt_size(dt), 256);
+  int rc = xmli_add_layernorm(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_in, dt, st);
+  if (rc) return rc;
+  rc = xmli_gemm(xn, w, b, pos, pre, rows, hidden, d_in, /*relu*/ 1, /*add_mode*/ 1, seq_len, /*out_f32*/ 1, dt, st);
+  if (rc) return rc;
+  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, dt, st);
+}

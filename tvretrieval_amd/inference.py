@@ -1,0 +1,265 @@
+"""Corpus-level retrieval drivers: host-side mirror of the hot loops of the reference's
+baselines/crossmodal_moment_localization/inference.py ("xml/inference.py").
+
+  compute_context_info     <- xml/inference.py:32-97     (HOT LOOP A: encode the corpus once)
+  compute_query2ctx_info   <- xml/inference.py:252-445   (HOT LOOP B: per query batch, VCMR / SVMR / VR)
+  vcmr_search              the device part of HOT LOOP B (:302-386) on resident tensors, used by bench.py
+
+What changed by design (outputs are the same lists):
+  * the corpus lives in HBM as a `CorpusIndex`: feat1 stored L2-normalised (the reference re-normalises it for
+    every query batch, xml/model_xml.py:447), feat2 and masks padded to a multiple of 16 clips;
+  * the (Nq, Nv, L) st/ed tensors are never built: ConvSE runs only on the top-k (and GT) videos per query;
+  * the (Nq, k, L, L) product + full sort is replaced by a banded top-n kernel.
+Everything on the device goes through tvretrieval_amd.ops (HIP); numpy only formats the result lists.
+"""
+import numpy as np
+import torch
+
+from . import ops as hip_ops
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class CorpusIndex(object):
+    """Encoded corpus resident in HBM.
+
+    modalities : list of "video" / "sub" in model order
+    feat1n[m]  : (Nv, lpad, H) compute dtype, L2-normalised rows (zero rows beyond each batch's own length)
+    feat2[m]   : (Nv, lpad, H) compute dtype
+    mask[m]    : (Nv, lpad) float32
+    l_ref      : the reference's context length = global max clip count (xml/inference.py:71-87)
+    video_offset : global index of local video 0 (corpus shards, tvretrieval_amd.dist)
+    """
+
+    def __init__(self, modalities, feat1n, feat2, mask, l_ref, video_offset=0, n_total=None):
+        self.modalities = list(modalities)
+        self.feat1n, self.feat2, self.mask = feat1n, feat2, mask
+        self.l_ref = int(l_ref)
+        self.lpad = int(feat2[self.modalities[0]].shape[1])
+        self.n_videos = int(feat2[self.modalities[0]].shape[0])
+        self.video_offset = int(video_offset)
+        self.n_total = int(n_total if n_total is not None else self.n_videos)
+
+    @property
+    def device(self):
+        return self.feat2[self.modalities[0]].device
+
+    def hbm_bytes(self):
+        tot = 0
+        for d in (self.feat1n, self.feat2, self.mask):
+            for t in d.values():
+                tot += t.numel() * t.element_size()
+        return tot
+
+
+def pad_batch(seqs, device=None, dtype=torch.float32):
+    """pad_sequences_1d (utils/tensor_utils.py:5-53) for a list of (L_i, D) arrays -> (N, Lmax, D), (N, Lmax)."""
+    lens = [len(s) for s in seqs]
+    lmax = max(lens)
+    first = torch.as_tensor(seqs[0])
+    out = torch.zeros((len(seqs), lmax) + tuple(first.shape[1:]), dtype=dtype)
+    mask = torch.zeros((len(seqs), lmax), dtype=torch.float32)
+    for i, s in enumerate(seqs):
+        out[i, :lens[i]] = torch.as_tensor(s, dtype=dtype)
+        mask[i, :lens[i]] = 1
+    if device is not None:
+        out, mask = out.to(device, non_blocking=True), mask.to(device, non_blocking=True)
+    return out, mask
+
+
+def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, video_offset=0, n_total=None,
+                       l_ref=None):
+    """Encode context batches and assemble the resident index.
+
+    context_batches: iterable of (video_feat, video_mask, sub_feat, sub_mask) device tensors (unused modality:
+    None).  Each batch is encoded at its own padded length and zero-filled beyond it when concatenated, exactly
+    like cat_tensor (xml/inference.py:71-87), so rows >= a batch's max length are 0 and rows between a video's
+    length and its batch max hold the encoder's outputs at padded positions (both observable through the 5-tap
+    ConvSE)."""
+    mods = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
+    parts = {m: dict(f1=[], f2=[], mk=[]) for m in mods}
+    for video_feat, video_mask, sub_feat, sub_mask in context_batches:
+        v1, v2, s1, s2 = model.encode_context(video_feat, video_mask, sub_feat, sub_mask)
+        if "video" in parts:
+            parts["video"]["f1"].append(v1), parts["video"]["f2"].append(v2), parts["video"]["mk"].append(video_mask.float())
+        if "sub" in parts:
+            parts["sub"]["f1"].append(s1), parts["sub"]["f2"].append(s2), parts["sub"]["mk"].append(sub_mask.float())
+    batch_max = max(t.shape[1] for t in parts[mods[0]]["f2"])
+    l_ref = batch_max if l_ref is None else int(l_ref)
+    assert l_ref >= batch_max
+    lpad = _round_up(l_ref, 16)
+
+    def cat(tensors):
+        n = sum(t.shape[0] for t in tensors)
+        out = tensors[0].new_zeros((n, lpad) + tuple(tensors[0].shape[2:]))
+        r = 0
+        for t in tensors:
+            out[r:r + t.shape[0], :t.shape[1]] = t
+            r += t.shape[0]
+        return out
+
+    feat1n, feat2, mask, raw = {}, {}, {}, {}
+    for m in mods:
+        f1 = cat(parts[m]["f1"])
+        feat1n[m] = ops.l2norm_rows(f1)
+        feat2[m] = cat(parts[m]["f2"])
+        mask[m] = cat(parts[m]["mk"])
+        if keep_raw:
+            raw[m] = f1
+    idx = CorpusIndex(mods, feat1n, feat2, mask, l_ref, video_offset, n_total)
+    idx.raw_feat1 = raw
+    return idx
+
+
+def compute_context_info(model, eval_dataset, opt, ops=hip_ops):
+    """Mirror of compute_context_info (xml/inference.py:32-97): same dict keys, plus "index" (CorpusIndex).
+    `eval_dataset` follows the reference's dataset contract (set_data_mode("context"), items with "meta" and
+    "model_inputs" {video_feat, sub_feat}); batches of opt.eval_context_bsz in dataset order."""
+    eval_dataset.set_data_mode("context")
+    device = opt.device
+    metas = []
+
+    def batches():
+        n = len(eval_dataset)
+        for b in range(0, n, opt.eval_context_bsz):
+            items = [eval_dataset[i] for i in range(b, min(n, b + opt.eval_context_bsz))]
+            metas.extend(e["meta"] for e in items)
+            vf = vm = sf = sm = None
+            if model.use_video:
+                vf, vm = pad_batch([e["model_inputs"]["video_feat"] for e in items], device)
+            if model.use_sub:
+                sf, sm = pad_batch([e["model_inputs"]["sub_feat"] for e in items], device)
+            yield vf, vm, sf, sm
+
+    index = build_corpus_index(model, batches(), ops=ops, keep_raw=True)
+    lr = index.l_ref
+    g = lambda d, m: d[m][:, :lr] if m in d else None
+    return dict(video_metas=metas,
+                video_feat1=g(index.raw_feat1, "video"), video_feat2=g(index.feat2, "video"),
+                video_mask=g(index.mask, "video"),
+                sub_feat1=g(index.raw_feat1, "sub"), sub_feat2=g(index.feat2, "sub"), sub_mask=g(index.mask, "sub"),
+                index=index)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device stages of HOT LOOP B
+# ---------------------------------------------------------------------------------------------------------
+def stage_query_vectors(model, query_feat, query_mask):
+    """encode_query -> per-modality modular query vectors, in index.modalities order."""
+    vq, sq = model.encode_query(query_feat, query_mask)
+    out = {}
+    if model.use_video:
+        out["video"] = vq
+    if model.use_sub:
+        out["sub"] = sq
+    return out
+
+
+def stage_q2c(index, qvec, ops=hip_ops):
+    """K6 over the local corpus: (Nq, Nv_local) f32 = mean over modalities of max-over-clips cosine."""
+    q2c = None
+    for m in index.modalities:
+        qn = ops.l2norm_rows(qvec[m].contiguous())
+        if q2c is None:
+            q2c = ops.q2c_scores(qn, index.feat1n[m], index.mask[m])
+        else:
+            ops.q2c_scores(qn, index.feat1n[m], index.mask[m], out=q2c, combine=True)
+    return q2c
+
+
+def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops):
+    """K7 on the listed (query, local video) pairs -> softmaxed st / ed (Nq, K, lpad)."""
+    mods = index.modalities
+    q_lin = [getattr(model, m + "_query_linear")(qvec[m].contiguous()) for m in mods]
+    merged = bool(model.config.merge_two_stream and len(mods) == 2)
+    return ops.convse_rerank(q_lin, [index.feat2[m] for m in mods], [index.mask[m] for m in mods], pair_vid,
+                             model._conv_weights(), index.l_ref, merged, model.config.conv_kernel_size, softmax=True)
+
+
+def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200, q2c_alpha=20.0,
+                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops):
+    """Device part of compute_query2ctx_info for one query batch (xml/inference.py:308-386), single GPU.
+
+    Returns device tensors:
+      top_scores (Nq,K) f32 = exp(alpha*q2c) desc, top_indices (Nq,K) int32 video (meta) indices,
+      flat_scores (Nq,n) f32 desc, flat_indices (Nq,n) int32 into (K, l_ref, l_ref)  [-1 = no candidate]
+      and, if svmr_video (Nq,) int32 is given, svmr_scores / svmr_flat (Nq,n) over (l_ref, l_ref)."""
+    qvec = stage_query_vectors(model, query_feat, query_mask)
+    q2c = stage_q2c(index, qvec, ops)
+    k = min(max_vcmr_video, index.n_videos)
+    top_w, top_i = ops.topk_rows(q2c, k, alpha=q2c_alpha)
+    st, ed = stage_span_probs(model, index, qvec, top_i, ops)
+    fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
+    out = dict(q2c=q2c, top_scores=top_w, top_indices=top_i, flat_scores=fs, flat_indices=fi)
+    if svmr_video is not None:
+        pv = svmr_video.to(torch.int32).reshape(-1, 1).contiguous()
+        st1, ed1 = stage_span_probs(model, index, qvec, pv, ops)
+        ss, sf = ops.moment_topk(st1, ed1, None, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
+        out.update(svmr_scores=ss, svmr_flat=sf, svmr_st=st1[:, 0], svmr_ed=ed1[:, 0])
+    return out
+
+
+def decode_flat(flat, l_ref):
+    """(r, st_idx, ed_idx) of the reference's flat index over (K, L, L) (np.unravel_index, :423-425)."""
+    flat = np.asarray(flat).astype(np.int64)
+    r = flat // (l_ref * l_ref)
+    rem = flat - r * l_ref * l_ref
+    return r, rem // l_ref, rem % l_ref
+
+
+def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=1000, max_n_videos=100,
+                           tasks=("SVMR",), ops=hip_ops):
+    """Mirror of compute_query2ctx_info (xml/inference.py:252-445).  Same result dict:
+    {"VCMR"|"SVMR"|"VR": [dict(desc_id, desc, predictions=[[video_idx, st, ed, score], ...]), ...]}.
+    External VR re-ranking (opt.external_inference_vr_res_path) is a "next" row."""
+    if getattr(opt, "external_inference_vr_res_path", None) is not None:
+        raise NotImplementedError("external VR re-ranking hook is not built yet (SURVEY.md 8f-4)")
+    is_svmr, is_vr, is_vcmr = "SVMR" in tasks, "VR" in tasks, "VCMR" in tasks
+    index = ctx_info["index"]
+    video2idx = eval_dataset.video2idx
+    video_metas = ctx_info["video_metas"]
+    meta_vid = np.array([video2idx[m["vid_name"]] for m in video_metas])
+    eval_dataset.set_data_mode("query")
+    eval_dataset.load_gt_vid_name_for_query(is_svmr)
+    name2meta = {e["vid_name"]: i for i, e in enumerate(video_metas)}
+    clip = opt.clip_length
+    l_ref = index.l_ref
+    n = len(eval_dataset)
+    res = dict(SVMR=[], VCMR=[], VR=[])
+    for b in range(0, n, opt.eval_query_bsz):
+        items = [eval_dataset[i] for i in range(b, min(n, b + opt.eval_query_bsz))]
+        metas = [e["meta"] for e in items]
+        qf, qm = pad_batch([e["model_inputs"]["query_feat"] for e in items], opt.device)
+        gt = None
+        if is_svmr:
+            gt = torch.tensor([name2meta[m["vid_name"]] for m in metas], dtype=torch.int32, device=opt.device)
+        out = vcmr_search(model, index, qf, qm, max_vcmr_video=max_n_videos, max_before_nms=max_before_nms,
+                          q2c_alpha=opt.q2c_alpha, min_pred_l=opt.min_pred_l, max_pred_l=opt.max_pred_l,
+                          svmr_video=gt, ops=ops)
+        host = {k: v.cpu().numpy() for k, v in out.items() if k != "q2c"}
+        for i, m in enumerate(metas):
+            if is_vr:
+                preds = [[int(meta_vid[v]), 0, 0, float(s)] for v, s in
+                         zip(host["top_indices"][i][:100], host["top_scores"][i][:100])]
+                res["VR"].append(dict(desc_id=m["desc_id"], desc=m["desc"], predictions=preds))
+            if is_vcmr:
+                valid = host["flat_indices"][i] >= 0
+                r, si, ei = decode_flat(host["flat_indices"][i][valid], l_ref)
+                vids = meta_vid[host["top_indices"][i][r]]
+                st_s = si.astype(np.float32) * clip
+                ed_s = ei.astype(np.float32) * clip + clip
+                preds = [[int(v), float(a), float(e), float(s)] for v, a, e, s in
+                         zip(vids, st_s, ed_s, host["flat_scores"][i][valid])]
+                res["VCMR"].append(dict(desc_id=m["desc_id"], desc=m["desc"], predictions=preds))
+            if is_svmr:
+                valid = host["svmr_flat"][i] >= 0
+                _, si, ei = decode_flat(host["svmr_flat"][i][valid], l_ref)
+                vid = int(video2idx[m["vid_name"]])
+                preds = [[vid, float(a * clip), float((e + 1) * clip), float(s)] for a, e, s in
+                         zip(si, ei, host["svmr_scores"][i][valid])]
+                res["SVMR"].append(dict(desc_id=m["desc_id"], desc=m["desc"], predictions=preds))
+        if getattr(opt, "debug", False):
+            break
+    return {k: v for k, v in res.items() if len(v) != 0}

@@ -1,0 +1,460 @@
+"""XML (Cross-modal Moment Localization) -- host-side mirror of the reference model class whose compute runs in
+hand-written HIP kernels (libxmlhip.so, include/xmlhip.h).
+
+Mirrors `XML(nn.Module)` of the reference (baselines/crossmodal_moment_localization/model_xml.py:52-641,
+"xml/" below): same constructor (`XML(config)` with the keys of xml_base_config, xml/model_xml.py:19-49), same
+method names and argument meaning, same `state_dict()` key names and shapes and the same checkpoint dict
+(`{"model", "model_cfg", "epoch"}`, xml/train.py:219-223), so reference checkpoints load unchanged.
+
+What is different by design: the nn.Module tree below only HOLDS parameters (fp32 masters, as in the checkpoint).
+No torch op computes anything on the hot path -- each method packs the weights once per (dtype, parameter
+version) and dispatches to the C ABI through tvretrieval_amd.ops.  There is no CPU fallback: tensors must be on
+the GPU and libxmlhip.so must load.
+
+Scope: transformer encoder + conv span predictor (the reference defaults).  The cnn / gru /
+lstm encoder ablations, `cat_linear` predictor, stacked conv predictors and `no_modular` are not implemented and
+raise at construction.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .easydict_compat import EasyDict as edict
+
+xml_base_config = edict(
+    merge_two_stream=True, cross_att=True, span_predictor_type="conv", encoder_type="transformer",
+    add_pe_rnn=False, visual_input_size=2048, query_input_size=768, sub_input_size=768, hidden_size=500,
+    conv_kernel_size=5, stack_conv_predictor_conv_kernel_sizes=-1, conv_stride=1, max_ctx_l=100, max_desc_l=30,
+    input_drop=0.1, drop=0.1, n_heads=4, ctx_mode="video_sub", margin=0.1, ranking_loss_type="hinge",
+    lw_neg_q=1, lw_neg_ctx=1, lw_st_ed=1, use_hard_negative=False, hard_pool_size=20, use_self_attention=True,
+    no_modular=False, pe_type="none", initializer_range=0.02,
+)
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class _PackedMixin(object):
+    """Caches device-dtype copies of a holder's parameters; re-packs when any parameter changed in place
+    (optimizer step, load_state_dict) or moved (.to())."""
+
+    def _pack_key(self, dtype):
+        return (dtype,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+
+    def packed(self, dtype):
+        key = self._pack_key(dtype)
+        if getattr(self, "_pk_key", None) != key:
+            with torch.no_grad():
+                self._pk = self._build_packed(dtype)
+            self._pk_key = key
+        return self._pk
+
+
+def _w(t, dtype):
+    t = t.detach().contiguous()
+    return t if dtype == torch.float32 else ops.pack_weights(t.float(), dtype)
+
+
+def _f(t):
+    return t.detach().float().contiguous()
+
+
+class LinearLayer(nn.Module, _PackedMixin):
+    """Parameter holder with the reference's key names (LayerNorm.*, net.1.*), xml/model_components.py:141-163."""
+
+    def __init__(self, in_hsz, out_hsz, dropout=0.1):
+        super().__init__()
+        self.LayerNorm = nn.LayerNorm(in_hsz)
+        self.net = nn.Sequential(nn.Dropout(dropout), nn.Linear(in_hsz, out_hsz))
+
+    def _build_packed(self, dtype):
+        lin = self.net[1]
+        return dict(ln_g=_f(self.LayerNorm.weight), ln_b=_f(self.LayerNorm.bias), w=_w(lin.weight, dtype),
+                    b=_f(lin.bias))
+
+
+class TrainablePositionalEncoding(nn.Module, _PackedMixin):
+    """Holder: position_embeddings.weight, LayerNorm.*  (xml/model_components.py:67-89)."""
+
+    def __init__(self, max_position_embeddings, hidden_size, dropout=0.1):
+        super().__init__()
+        self.position_embeddings = nn.Embedding(max_position_embeddings, hidden_size)
+        self.LayerNorm = nn.LayerNorm(hidden_size)
+        self.dropout = nn.Dropout(dropout)
+
+    def _build_packed(self, dtype):
+        return dict(pos=_w(self.position_embeddings.weight, dtype), ln_g=_f(self.LayerNorm.weight),
+                    ln_b=_f(self.LayerNorm.bias))
+
+
+class BertSelfAttention(nn.Module, _PackedMixin):
+    """Holder: query/key/value Linear (xml/model_components.py:244-259).  Packed as stacked [q;k;v] and [k;v]."""
+
+    def __init__(self, hidden_size, num_attention_heads, dropout=0.1):
+        super().__init__()
+        if hidden_size % num_attention_heads != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)"
+                             % (hidden_size, num_attention_heads))
+        self.num_attention_heads = num_attention_heads
+        self.query = nn.Linear(hidden_size, hidden_size)
+        self.key = nn.Linear(hidden_size, hidden_size)
+        self.value = nn.Linear(hidden_size, hidden_size)
+        self.dropout = nn.Dropout(dropout)
+
+    def _build_packed(self, dtype):
+        q, k, v = self.query, self.key, self.value
+        return dict(
+            wqkv=_w(torch.cat([q.weight, k.weight, v.weight], 0), dtype),
+            bqkv=_f(torch.cat([q.bias, k.bias, v.bias], 0)),
+            wq=_w(q.weight, dtype), bq=_f(q.bias),
+            wkv=_w(torch.cat([k.weight, v.weight], 0), dtype), bkv=_f(torch.cat([k.bias, v.bias], 0)))
+
+
+class BertSelfOutput(nn.Module, _PackedMixin):
+    def __init__(self, hidden_size, dropout=0.1):
+        super().__init__()
+        self.dense = nn.Linear(hidden_size, hidden_size)
+        self.LayerNorm = nn.LayerNorm(hidden_size)
+        self.dropout = nn.Dropout(dropout)
+
+    def _build_packed(self, dtype):
+        return dict(wo=_w(self.dense.weight, dtype), bo=_f(self.dense.bias), ln_g=_f(self.LayerNorm.weight),
+                    ln_b=_f(self.LayerNorm.bias))
+
+
+class BertAttention(nn.Module):
+    """Holder: self.{query,key,value}, output.{dense,LayerNorm} (xml/model_components.py:201-216)."""
+
+    def __init__(self, hidden_size, num_attention_heads, dropout=0.1):
+        super().__init__()
+        self.self = BertSelfAttention(hidden_size, num_attention_heads, dropout)
+        self.output = BertSelfOutput(hidden_size, dropout)
+
+    def forward(self, input_tensor, attention_mask):
+        """input (N, L, H) compute dtype; attention_mask (N, 1, L) or (N, L) float 1=valid (key mask)."""
+        if attention_mask.dim() == 3:
+            attention_mask = attention_mask[:, 0]
+        a = self.self.packed(input_tensor.dtype)
+        o = self.output.packed(input_tensor.dtype)
+        return ops.attention_block(input_tensor.contiguous(), attention_mask.float().contiguous(), a["wqkv"],
+                                   a["bqkv"], o["wo"], o["bo"], o["ln_g"], o["ln_b"],
+                                   self.self.num_attention_heads)
+
+
+class _QueryLinear(nn.Linear, _PackedMixin):
+    """video_query_linear / sub_query_linear: nn.Linear parameters, HIP forward."""
+
+    def _build_packed(self, dtype):
+        return dict(w=_w(self.weight, dtype), b=_f(self.bias))
+
+    def forward(self, x):
+        p = self.packed(x.dtype)
+        return ops.linear(x.contiguous(), p["w"], p["b"])
+
+
+class XML(nn.Module):
+    def __init__(self, config, compute_dtype=torch.float32):
+        super().__init__()
+        if not isinstance(config, edict):
+            config = edict(dict(config))
+        self.config = config
+        self.compute_dtype = compute_dtype
+        if config.get("encoder_type", "transformer") != "transformer":
+            raise NotImplementedError("only encoder_type='transformer' is built (SURVEY.md section 2, #2)")
+        if config.get("span_predictor_type", "conv") != "conv":
+            raise NotImplementedError("only span_predictor_type='conv' is built")
+        if config.get("stack_conv_predictor_conv_kernel_sizes", -1) != -1:
+            raise NotImplementedError("stacked conv predictors are disabled at inference by the reference "
+                                      "(xml/inference.py:538) and are not built")
+        if config.get("no_modular", False):
+            raise NotImplementedError("no_modular ablation is not built")
+        if config.get("conv_stride", 1) != 1:
+            raise NotImplementedError("conv_stride != 1 is not built")
+        hsz, nh = config.hidden_size, config.n_heads
+        self.query_pos_embed = TrainablePositionalEncoding(config.max_desc_l, hsz, config.input_drop)
+        self.ctx_pos_embed = TrainablePositionalEncoding(config.max_ctx_l, hsz, config.input_drop)
+        self.query_input_proj = LinearLayer(config.query_input_size, hsz, config.input_drop)
+        self.query_encoder = BertAttention(hsz, nh, config.drop)
+
+        def conv():
+            k = config.conv_kernel_size
+            return nn.Conv1d(1, 1, k, stride=1, padding=k // 2, bias=False)
+
+        self.use_video = "video" in config.ctx_mode
+        self.use_sub = "sub" in config.ctx_mode
+        for name, use, in_size in (("video", self.use_video, config.visual_input_size),
+                                   ("sub", self.use_sub, config.sub_input_size)):
+            if not use:
+                continue
+            setattr(self, name + "_input_proj", LinearLayer(in_size, hsz, config.input_drop))
+            setattr(self, name + "_encoder1", BertAttention(hsz, nh, config.drop))
+            setattr(self, name + "_encoder2", BertAttention(hsz, nh, config.drop))
+            if config.cross_att:
+                setattr(self, name + "_cross_att", BertSelfAttention(hsz, nh, config.drop))
+                setattr(self, name + "_cross_layernorm", nn.LayerNorm(hsz))
+            else:
+                setattr(self, name + "_encoder3", BertAttention(hsz, nh, config.drop))
+            setattr(self, name + "_query_linear", _QueryLinear(hsz, hsz))
+            if not config.merge_two_stream:
+                setattr(self, name + "_st_predictor", conv())
+                setattr(self, name + "_ed_predictor", conv())
+        self.modular_vector_mapping = nn.Linear(hsz, int(self.use_sub) + int(self.use_video), bias=False)
+        if config.merge_two_stream:
+            self.merged_st_predictor = conv()
+            self.merged_ed_predictor = conv()
+        self.reset_parameters()
+
+    # ---- parameter management ------------------------------------------------------------------------
+    def reset_parameters(self):
+        """Same initial distribution as the reference (xml/model_xml.py:185-201)."""
+        def re_init(module):
+            if isinstance(module, (nn.Linear, nn.Embedding)):
+                module.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+            elif isinstance(module, nn.LayerNorm):
+                module.bias.data.zero_()
+                module.weight.data.fill_(1.0)
+            elif isinstance(module, nn.Conv1d):
+                module.reset_parameters()
+            if isinstance(module, nn.Linear) and module.bias is not None:
+                module.bias.data.zero_()
+        self.apply(re_init)
+
+    def set_compute_dtype(self, dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        return self
+
+    def set_hard_negative(self, use_hard_negative, hard_pool_size):
+        self.config.use_hard_negative = use_hard_negative
+        self.config.hard_pool_size = hard_pool_size
+
+    def set_train_st_ed(self, lw_st_ed):
+        self.config.lw_st_ed = lw_st_ed
+
+    def _conv_weights(self):
+        """flat f32 [st filters..., ed filters...] in modality order (video, sub) or merged."""
+        if self.config.merge_two_stream and self.use_video and self.use_sub:
+            st, ed = [self.merged_st_predictor], [self.merged_ed_predictor]
+        else:
+            names = [n for n, u in (("video", self.use_video), ("sub", self.use_sub)) if u]
+            st = [getattr(self, n + "_st_predictor") for n in names]
+            ed = [getattr(self, n + "_ed_predictor") for n in names]
+        return torch.cat([m.weight.detach().float().reshape(-1) for m in st + ed]).contiguous()
+
+    def _ln_params(self, ln):
+        return _f(ln.weight), _f(ln.bias)
+
+    # ---- encoders ------------------------------------------------------------------------------------
+    def encode_input(self, feat, mask, input_proj_layer, encoder_layer, pos_embed_layer):
+        """xml/model_xml.py:377-392.  feat (N, L, D_in) f32 (or compute dtype), mask (N, L) float."""
+        dt = self.compute_dtype
+        p, e = input_proj_layer.packed(dt), pos_embed_layer.packed(dt)
+        if feat.shape[1] > e["pos"].shape[0]:
+            raise IndexError("sequence length %d exceeds the positional table (%d)" % (feat.shape[1], e["pos"].shape[0]))
+        if feat.dtype not in (torch.float32, dt):
+            feat = feat.float()
+        x = ops.linear_ln_relu_pos(feat.contiguous(), p["ln_g"], p["ln_b"], p["w"], p["b"], e["pos"], e["ln_g"],
+                                   e["ln_b"])
+        return encoder_layer(x, mask)
+
+    def cross_context_encoder(self, main_context_feat, main_context_mask, side_context_feat, side_context_mask,
+                              cross_att_layer, norm_layer, self_att_layer):
+        """xml/model_xml.py:357-373."""
+        c = cross_att_layer.packed(main_context_feat.dtype)
+        g, b = self._ln_params(norm_layer)
+        res = ops.cross_attention(main_context_feat, main_context_mask.float().contiguous(), side_context_feat,
+                                  side_context_mask.float().contiguous(), c["wq"], c["bq"], c["wkv"], c["bkv"], g, b,
+                                  cross_att_layer.num_attention_heads)
+        return self_att_layer(res, main_context_mask)
+
+    def cross_encode_context(self, video_feat, video_mask, sub_feat, sub_mask):
+        """xml/model_xml.py:344-355."""
+        ev = self.encode_input(video_feat, video_mask, self.video_input_proj, self.video_encoder1, self.ctx_pos_embed)
+        es = self.encode_input(sub_feat, sub_mask, self.sub_input_proj, self.sub_encoder1, self.ctx_pos_embed)
+        xv = self.cross_context_encoder(ev, video_mask, es, sub_mask, self.video_cross_att,
+                                        self.video_cross_layernorm, self.video_encoder2)
+        xs = self.cross_context_encoder(es, sub_mask, ev, video_mask, self.sub_cross_att,
+                                        self.sub_cross_layernorm, self.sub_encoder2)
+        return ev, xv, es, xs
+
+    def non_cross_encode_context(self, context_feat, context_mask, module_name="video"):
+        """xml/model_xml.py:297-329: encoder1 -> feat1 ; encoder2 -> encoder3 -> feat2."""
+        f1 = self.encode_input(context_feat, context_mask, getattr(self, module_name + "_input_proj"),
+                               getattr(self, module_name + "_encoder1"), self.ctx_pos_embed)
+        f2 = getattr(self, module_name + "_encoder2")(f1, context_mask)
+        f2 = getattr(self, module_name + "_encoder3")(f2, context_mask)
+        return f1, f2
+
+    def encode_context(self, video_feat, video_mask, sub_feat, sub_mask):
+        """xml/model_xml.py:331-342.  Unused modalities return None."""
+        if self.config.cross_att:
+            assert self.use_video and self.use_sub
+            return self.cross_encode_context(video_feat, video_mask, sub_feat, sub_mask)
+        v1 = v2 = s1 = s2 = None
+        if self.use_video:
+            v1, v2 = self.non_cross_encode_context(video_feat, video_mask, "video")
+        if self.use_sub:
+            s1, s2 = self.non_cross_encode_context(sub_feat, sub_mask, "sub")
+        return v1, v2, s1, s2
+
+    def get_modularized_queries(self, encoded_query, query_mask, return_modular_att=False):
+        """xml/model_xml.py:399-423."""
+        if return_modular_att:
+            raise NotImplementedError("visualisation outputs are out of scope")
+        wm = _f(self.modular_vector_mapping.weight)
+        out = ops.modular_pool(encoded_query.contiguous(), query_mask.float().contiguous(), wm)
+        return (out[0], out[1]) if out.shape[0] == 2 else (out[0], out[0])
+
+    def encode_query(self, query_feat, query_mask):
+        """xml/model_xml.py:291-295."""
+        enc = self.encode_input(query_feat, query_mask, self.query_input_proj, self.query_encoder,
+                                self.query_pos_embed)
+        return self.get_modularized_queries(enc, query_mask)
+
+    # ---- scores --------------------------------------------------------------------------------------
+    @staticmethod
+    def pad_context(feat, lpad):
+        """(N, L, H) -> (N, lpad, H), zero rows beyond L (device memory plumbing only)."""
+        n, l = feat.shape[:2]
+        if l == lpad:
+            return feat.contiguous()
+        out = feat.new_zeros((n, lpad) + tuple(feat.shape[2:]))
+        out[:, :l] = feat
+        return out
+
+    def get_video_level_scores(self, modularied_query, context_feat1, context_mask):
+        """xml/model_xml.py:436-453 -> (Nq, Nv) f32."""
+        lpad = _round_up(context_feat1.shape[1], 16)
+        qn = ops.l2norm_rows(modularied_query.contiguous())
+        cn = ops.l2norm_rows(self.pad_context(context_feat1, lpad))
+        return ops.q2c_scores(qn, cn, self.pad_context(context_mask.float(), lpad))
+
+    def _span_logits(self, queries, feats2, masks, names, cross, softmax=False, pair_vid=None):
+        """Shared K7 dispatch.  queries/feats2/masks: per-modality lists; returns (st, ed) (Nq, K, L) f32."""
+        l_ref = feats2[0].shape[1]
+        lpad = _round_up(l_ref, 16)
+        merged = bool(self.config.merge_two_stream and self.use_video and self.use_sub and len(names) == 2)
+        q_lin = [getattr(self, n + "_query_linear")(q.contiguous()) for n, q in zip(names, queries)]
+        f2 = [self.pad_context(f, lpad) for f in feats2]
+        mk = [self.pad_context(m.float(), lpad) for m in masks]
+        nq, nv = q_lin[0].shape[0], f2[0].shape[0]
+        if pair_vid is None:
+            if cross:
+                pair_vid = torch.arange(nv, dtype=torch.int32, device=q_lin[0].device).repeat(nq, 1).contiguous()
+            else:
+                assert nq == nv, "cross=False pairs query i with video i"
+                pair_vid = torch.arange(nv, dtype=torch.int32, device=q_lin[0].device).unsqueeze(1).contiguous()
+        if merged:
+            conv_w = torch.cat([self.merged_st_predictor.weight.detach().float().reshape(-1),
+                                self.merged_ed_predictor.weight.detach().float().reshape(-1)]).contiguous()
+        else:
+            conv_w = torch.cat([getattr(self, n + "_st_predictor").weight.detach().float().reshape(-1) for n in names] +
+                               [getattr(self, n + "_ed_predictor").weight.detach().float().reshape(-1) for n in names]
+                               ).contiguous()
+        st, ed = ops.convse_rerank(q_lin, f2, mk, pair_vid, conv_w, l_ref, merged, self.config.conv_kernel_size,
+                                   softmax=softmax)
+        st, ed = st[..., :l_ref], ed[..., :l_ref]
+        if not cross and pair_vid.shape[1] == 1:
+            st, ed = st[:, 0], ed[:, 0]
+        return st, ed
+
+    def get_merged_st_ed_prob(self, video_query, video_feat, sub_query, sub_feat, context_mask, cross=False,
+                              return_similaity=False):
+        """xml/model_xml.py:455-502 (masked logits)."""
+        assert self.use_video and self.use_sub and not return_similaity
+        return self._span_logits([video_query, sub_query], [video_feat, sub_feat], [context_mask, context_mask],
+                                 ["video", "sub"], cross)
+
+    def get_st_ed_prob(self, modularied_query, context_feat2, context_mask, module_name="video", cross=False):
+        """xml/model_xml.py:504-551 (masked logits, single stream)."""
+        return self._span_logits([modularied_query], [context_feat2], [context_mask], [module_name], cross)
+
+    def get_pred_from_raw_query(self, query_feat, query_mask, video_feat1, video_feat2, video_mask,
+                                sub_feat1, sub_feat2, sub_mask, cross=False):
+        """xml/model_xml.py:553-586 -> (q2ctx (Nq,Nv), st logits, ed logits); cross=True: (Nq,Nv,L)."""
+        video_query, sub_query = self.encode_query(query_feat, query_mask)
+        return self.get_pred_from_modular_query(video_query, sub_query, video_feat1, video_feat2, video_mask,
+                                                sub_feat1, sub_feat2, sub_mask, cross)
+
+    def get_pred_from_modular_query(self, video_query, sub_query, video_feat1, video_feat2, video_mask,
+                                    sub_feat1, sub_feat2, sub_mask, cross=False):
+        q2c = None
+        for use, q, f1, m in ((self.use_video, video_query, video_feat1, video_mask),
+                              (self.use_sub, sub_query, sub_feat1, sub_mask)):
+            if not use:
+                continue
+            lpad = _round_up(f1.shape[1], 16)
+            qn = ops.l2norm_rows(q.contiguous())
+            cn = ops.l2norm_rows(self.pad_context(f1, lpad))
+            mk = self.pad_context(m.float(), lpad)
+            if q2c is None:
+                q2c = ops.q2c_scores(qn, cn, mk)
+            else:
+                ops.q2c_scores(qn, cn, mk, out=q2c, combine=True)   # (video + sub) / 2
+        names = [n for n, u in (("video", self.use_video), ("sub", self.use_sub)) if u]
+        qs = dict(video=video_query, sub=sub_query)
+        fs = dict(video=video_feat2, sub=sub_feat2)
+        ms = dict(video=video_mask, sub=sub_mask)
+        st, ed = self._span_logits([qs[n] for n in names], [fs[n] for n in names], [ms[n] for n in names], names,
+                                   cross)
+        return q2c, st, ed
+
+    def forward(self, query_feat, query_mask, video_feat, video_mask, sub_feat, sub_mask, tef_feat, tef_mask,
+                st_ed_indices, neg_ctx_rank=None, neg_q_rank=None):
+        """XML.forward (xml/model_xml.py:212-251): loss VALUES through the HIP forward kernels.
+
+        Round-1 status: forward only (no autograd through the HIP kernels yet); dropout is not applied.  The
+        in-batch negatives of get_neg_scores (xml/model_xml.py:608-624) are drawn with torch.randint on the CPU
+        generator in the reference's order unless rank indices are injected."""
+        cfg = self.config
+        v1, v2, s1, s2 = self.encode_context(video_feat, video_mask, sub_feat, sub_mask)
+        q2c, st, ed = self.get_pred_from_raw_query(query_feat, query_mask, v1, v2, video_mask, s1, s2, sub_mask,
+                                                   cross=False)
+        loss_st_ed = 0
+        if cfg.lw_st_ed != 0:
+            ce = nn.functional.cross_entropy
+            loss_st_ed = ce(st, st_ed_indices[:, 0]) + ce(ed, st_ed_indices[:, 1])
+        loss_neg_ctx, loss_neg_q = 0, 0
+        if cfg.lw_neg_ctx != 0 or cfg.lw_neg_q != 0:
+            loss_neg_ctx, loss_neg_q = self.get_video_level_loss(q2c, neg_ctx_rank, neg_q_rank)
+        loss_st_ed = cfg.lw_st_ed * loss_st_ed
+        loss_neg_ctx = cfg.lw_neg_ctx * loss_neg_ctx
+        loss_neg_q = cfg.lw_neg_q * loss_neg_q
+        loss = loss_st_ed + loss_neg_ctx + loss_neg_q
+        return loss, {"loss_st_ed": float(loss_st_ed), "loss_neg_ctx": float(loss_neg_ctx),
+                      "loss_neg_q": float(loss_neg_q), "loss_overall": float(loss)}
+
+    def get_video_level_loss(self, query_context_scores, neg_ctx_rank=None, neg_q_rank=None):
+        """xml/model_xml.py:588-637 on the (N, N) in-batch score matrix (tiny; torch ops on device tensors)."""
+        cfg = self.config
+        n = len(query_context_scores)
+        ar = torch.arange(n, device=query_context_scores.device)
+        pos = query_context_scores[ar, ar]
+        masked = query_context_scores.detach().clone()
+        masked[ar, ar] = 999
+
+        def neg(sc, sc_masked, ranks):
+            order = torch.sort(sc_masked, descending=True, dim=1)[1]
+            if ranks is None:
+                hi = min(1 + cfg.hard_pool_size, n) if cfg.use_hard_negative else n
+                ranks = torch.randint(1, hi, size=(n,))
+            return sc[ar, order[ar, torch.as_tensor(ranks).long().to(sc.device)]]
+
+        def rank_loss(p, ng):
+            if cfg.ranking_loss_type == "hinge":
+                return torch.clamp(cfg.margin + ng - p, min=0).sum() / len(p)
+            if cfg.ranking_loss_type == "lse":
+                return torch.log1p(torch.exp(ng - p)).sum() / len(p)
+            raise NotImplementedError("Only support 'hinge' and 'lse'")
+
+        neg_ctx = neg(query_context_scores, masked, neg_ctx_rank)
+        neg_q = neg(query_context_scores.transpose(0, 1), masked.transpose(0, 1), neg_q_rank)
+        return rank_loss(pos, neg_ctx), rank_loss(pos, neg_q)
+
+
+def mask_logits(target, mask):
+    """Kept for API parity (xml/model_xml.py:640-641); the kernels apply it in their epilogues."""
+    return target * mask + (1 - mask) * (-1e10)

@@ -1,0 +1,237 @@
+"""Thin tensor-level wrappers over the C ABI (include/xmlhip.h).
+
+PyTorch is plumbing here: it owns device memory (torch.empty), the current HIP stream and nothing else.
+Every function launches hand-written gfx950 kernels from libxmlhip.so and fails loudly when the library or a
+GPU tensor is missing -- there is no eager/CPU fallback.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import XML_BF16, XML_F32, ConvseDesc, check
+
+_DT = {torch.float32: XML_F32, torch.bfloat16: XML_BF16}
+
+
+def dt_of(t):
+    try:
+        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+    except KeyError:
+        raise _lib.XmlHipError("unsupported dtype %s (float32 / bfloat16 only)" % (t.dtype if hasattr(t, "dtype") else t))
+
+
+def _req(t, name, dtype=None):
+    if not isinstance(t, torch.Tensor):
+        raise _lib.XmlHipError("%s: expected a tensor" % name)
+    if not t.is_cuda:
+        raise _lib.XmlHipError("%s: tensor must live on the GPU (got %s); the HIP path has no CPU fallback"
+                               % (name, t.device))
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.XmlHipError("%s: expected dtype %s, got %s" % (name, dtype, t.dtype))
+    if not t.is_contiguous():
+        raise _lib.XmlHipError("%s: tensor must be contiguous" % name)
+    return t
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+_ws_cache = {}
+
+
+def _workspace(nbytes, device):
+    """Grow-only scratch buffer per (device, stream).  The C ABI never allocates."""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    buf = _ws_cache.get(key)
+    nbytes = max(int(nbytes), 256)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def convert(x, dtype):
+    """xml_convert: dtype conversion on the device (round-to-nearest-even to bf16)."""
+    _req(x, "x")
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    check(_lib.load().xml_convert(_p(x), dt_of(x), _p(out), dt_of(dtype), x.numel(), _stream()), "xml_convert")
+    return out
+
+
+def pack_weights(w_f32, dtype):
+    _req(w_f32, "w", torch.float32)
+    out = torch.empty(w_f32.shape, dtype=dtype, device=w_f32.device)
+    check(_lib.load().xml_pack_weights(_p(w_f32), _p(out), dt_of(dtype), w_f32.numel(), _stream()), "xml_pack_weights")
+    return out
+
+
+def linear_ln_relu_pos(x, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
+    """K1+K2.  x (N, L, D_in) f32 or compute dtype; w (H, D_in) compute dtype -> (N, L, H)."""
+    _req(x, "x"); _req(w, "w"); _req(pos, "pos", w.dtype)
+    n, seq_len, d_in = x.shape
+    hidden = w.shape[0]
+    assert w.shape[1] == d_in and pos.shape[1] == hidden and pos.shape[0] >= seq_len, "shape mismatch"
+    for t, nm in ((ln_in_g, "ln_in_g"), (ln_in_b, "ln_in_b"), (b, "b"), (ln_pos_g, "ln_pos_g"), (ln_pos_b, "ln_pos_b")):
+        _req(t, nm, torch.float32)
+    lib = _lib.load()
+    dt = dt_of(w)
+    rows = n * seq_len
+    y = torch.empty((n, seq_len, hidden), dtype=w.dtype, device=x.device)
+    nb = lib.xml_linear_ln_relu_pos_workspace_bytes(rows, d_in, hidden, dt)
+    ws = _workspace(nb, x.device)
+    check(lib.xml_linear_ln_relu_pos(_p(x), dt_of(x), _p(ln_in_g), _p(ln_in_b), _p(w), _p(b), _p(pos), _p(ln_pos_g),
+                                     _p(ln_pos_b), _p(y), rows, seq_len, d_in, hidden, dt, _p(ws), ws.numel(),
+                                     _stream()), "xml_linear_ln_relu_pos")
+    return y
+
+
+def attention_block(x, key_mask, wqkv, bqkv, wo, bo, ln_g, ln_b, n_heads):
+    """K3+K4 (BertAttention).  x (N, L, H); key_mask (N, L) f32."""
+    _req(x, "x"); _req(key_mask, "key_mask", torch.float32); _req(wqkv, "wqkv", x.dtype); _req(wo, "wo", x.dtype)
+    for t, nm in ((bqkv, "bqkv"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b")):
+        _req(t, nm, torch.float32)
+    n, seq_len, hidden = x.shape
+    lib = _lib.load()
+    dt = dt_of(x)
+    y = torch.empty_like(x)
+    ws = _workspace(lib.xml_attention_block_workspace_bytes(n, seq_len, hidden, dt), x.device)
+    check(lib.xml_attention_block(_p(x), _p(key_mask), _p(wqkv), _p(bqkv), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(y),
+                                  n, seq_len, hidden, n_heads, dt, _p(ws), ws.numel(), _stream()),
+          "xml_attention_block")
+    return y
+
+
+def cross_attention(main_x, main_mask, side_x, side_mask, wq, bq, wkv, bkv, ln_g, ln_b, n_heads):
+    """LN(MHA(main, side, side, main_mask (x) side_mask) + main), xml/model_xml.py:369-371."""
+    _req(main_x, "main_x"); _req(side_x, "side_x", main_x.dtype)
+    _req(main_mask, "main_mask", torch.float32); _req(side_mask, "side_mask", torch.float32)
+    _req(wq, "wq", main_x.dtype); _req(wkv, "wkv", main_x.dtype)
+    for t, nm in ((bq, "bq"), (bkv, "bkv"), (ln_g, "ln_g"), (ln_b, "ln_b")):
+        _req(t, nm, torch.float32)
+    n, lq, hidden = main_x.shape
+    lk = side_x.shape[1]
+    lib = _lib.load()
+    dt = dt_of(main_x)
+    y = torch.empty_like(main_x)
+    ws = _workspace(lib.xml_cross_attention_workspace_bytes(n, lq, lk, hidden, dt), main_x.device)
+    check(lib.xml_cross_attention(_p(main_x), _p(main_mask), _p(side_x), _p(side_mask), _p(wq), _p(bq), _p(wkv),
+                                  _p(bkv), _p(ln_g), _p(ln_b), _p(y), n, lq, lk, hidden, n_heads, dt, _p(ws),
+                                  ws.numel(), _stream()), "xml_cross_attention")
+    return y
+
+
+def modular_pool(enc, mask, w_m):
+    """K5.  enc (N, Lq, H); mask (N, Lq) f32; w_m (n_mod, H) f32 -> (n_mod, N, H)."""
+    _req(enc, "enc"); _req(mask, "mask", torch.float32); _req(w_m, "w_m", torch.float32)
+    n, lq, hidden = enc.shape
+    n_mod = w_m.shape[0]
+    out = torch.empty((n_mod, n, hidden), dtype=enc.dtype, device=enc.device)
+    check(_lib.load().xml_modular_pool(_p(enc), _p(mask), _p(w_m), _p(out), n, lq, hidden, n_mod, dt_of(enc),
+                                       _stream()), "xml_modular_pool")
+    return out
+
+
+def linear(x, w, b=None, relu=False):
+    """y = x W^T + b.  x (..., K), w (N, K) same dtype."""
+    _req(x, "x"); _req(w, "w", x.dtype)
+    if b is not None:
+        _req(b, "b", torch.float32)
+    k = x.shape[-1]
+    rows = x.numel() // k
+    y = torch.empty(x.shape[:-1] + (w.shape[0],), dtype=x.dtype, device=x.device)
+    check(_lib.load().xml_linear(_p(x), _p(w), _p(b), _p(y), rows, w.shape[0], k, int(relu), dt_of(x), _stream()),
+          "xml_linear")
+    return y
+
+
+def l2norm_rows(x):
+    _req(x, "x")
+    d = x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.load().xml_l2norm_rows(_p(x), _p(y), x.numel() // d, d, dt_of(x), _stream()), "xml_l2norm_rows")
+    return y
+
+
+def add_layernorm(a, b, g, beta, out_dtype=None):
+    _req(a, "a"); _req(g, "g", torch.float32); _req(beta, "beta", torch.float32)
+    out_dtype = out_dtype or (b.dtype if b is not None else a.dtype)
+    d = a.shape[-1]
+    y = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    check(_lib.load().xml_add_layernorm(_p(a), dt_of(a), _p(b), _p(g), _p(beta), _p(y), a.numel() // d, d,
+                                        dt_of(out_dtype), _stream()), "xml_add_layernorm")
+    return y
+
+
+def q2c_scores(qn, cn, mask, out=None, combine=False):
+    """K6.  qn (Nq, H) and cn (Nv, Lpad, H) L2-normalised; mask (Nv, Lpad) f32 -> out (Nq, Nv) f32."""
+    _req(qn, "qn"); _req(cn, "cn", qn.dtype); _req(mask, "mask", torch.float32)
+    nq, hidden = qn.shape
+    nv, lpad, h2 = cn.shape
+    assert h2 == hidden and tuple(mask.shape) == (nv, lpad)
+    if out is None:
+        assert not combine
+        out = torch.empty((nq, nv), dtype=torch.float32, device=qn.device)
+    _req(out, "out", torch.float32)
+    check(_lib.load().xml_q2c_scores(_p(qn), _p(cn), _p(mask), _p(out), out.stride(0), nq, nv, lpad, hidden,
+                                     int(combine), dt_of(qn), _stream()), "xml_q2c_scores")
+    return out
+
+
+def topk_rows(scores, k, alpha=0.0, idx_in=None):
+    """K8.  scores (rows, n) f32 -> (values (rows, k) f32 [exp(alpha*s) if alpha], indices (rows, k) int32)."""
+    _req(scores, "scores", torch.float32)
+    rows, n = scores.shape
+    if idx_in is not None:
+        _req(idx_in, "idx_in", torch.int32)
+        assert idx_in.shape == scores.shape
+    vals = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
+    idx = torch.empty((rows, k), dtype=torch.int32, device=scores.device)
+    check(_lib.load().xml_topk_rows(_p(scores), scores.stride(0), _p(idx_in), _p(vals), _p(idx), rows, n, k,
+                                    float(alpha), None, 0, _stream()), "xml_topk_rows")
+    return vals, idx
+
+
+def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, softmax=True):
+    """K7.  q_lin / feat2 / masks: lists over modalities (len 1 or 2).
+    q_lin[m] (Nq, H); feat2[m] (Nv, Lpad, H); masks[m] (Nv, Lpad) f32; pair_vid (Nq, K) int32;
+    conv_w flat f32 [st filters..., ed filters...].  Returns st, ed (Nq, K, Lpad) f32."""
+    n_mod = len(q_lin)
+    for m in range(n_mod):
+        _req(q_lin[m], "q_lin"); _req(feat2[m], "feat2", q_lin[m].dtype); _req(masks[m], "mask", torch.float32)
+    _req(pair_vid, "pair_vid", torch.int32); _req(conv_w, "conv_w", torch.float32)
+    nq, hidden = q_lin[0].shape
+    nv, lpad, _ = feat2[0].shape
+    kpairs = pair_vid.shape[1]
+    d = ConvseDesc(nq=nq, nv=nv, kpairs=kpairs, lpad=lpad, l_ref=int(l_ref), hidden=hidden, n_mod=n_mod,
+                   merged=int(merged), ksize=int(ksize), softmax=int(softmax), dt=dt_of(q_lin[0]))
+    n_conv = 1 if merged else n_mod
+    assert conv_w.numel() == 2 * n_conv * ksize
+    lib = _lib.load()
+    st = torch.empty((nq, kpairs, lpad), dtype=torch.float32, device=pair_vid.device)
+    ed = torch.empty_like(st)
+    ws = _workspace(lib.xml_convse_rerank_workspace_bytes(ctypes.byref(d)), pair_vid.device)
+    check(lib.xml_convse_rerank(ctypes.byref(d), _p(q_lin[0]), _p(q_lin[1]) if n_mod > 1 else None, _p(feat2[0]),
+                                _p(feat2[1]) if n_mod > 1 else None, _p(masks[0]),
+                                _p(masks[1]) if n_mod > 1 else None, _p(pair_vid), _p(conv_w), _p(st), _p(ed),
+                                _p(ws), ws.numel(), _stream()), "xml_convse_rerank")
+    return st, ed
+
+
+def moment_topk(st, ed, w, l_ref, min_l, max_l, n_out):
+    """K9/K10.  st, ed (Nq, K, Lpad) f32 probabilities; w (Nq, K) f32 or None.
+    Returns (scores (Nq, n_out) f32 desc, flat (Nq, n_out) int32 = (r*l_ref + i)*l_ref + j, -1 = empty)."""
+    _req(st, "st", torch.float32); _req(ed, "ed", torch.float32)
+    if w is not None:
+        _req(w, "w", torch.float32)
+    nq, kpairs, lpad = st.shape
+    sc = torch.empty((nq, n_out), dtype=torch.float32, device=st.device)
+    fl = torch.empty((nq, n_out), dtype=torch.int32, device=st.device)
+    check(_lib.load().xml_moment_topk(_p(st), _p(ed), _p(w), _p(sc), _p(fl), nq, kpairs, lpad, int(l_ref), int(min_l),
+                                      int(max_l), int(n_out), _stream()), "xml_moment_topk")
+    return sc, fl

@@ -1,0 +1,235 @@
+#!/usr/bin/env python
+"""bench.py -- queries/sec of full VCMR (query features in -> top-100 videos + top-200 moments out) over a resident
+TVR-shaped corpus, on N MI355X of one node.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[2]/[3], "c3"): XML video+sub, cross-attention, merged ConvSE, H=768, bf16;
+21 793 videos x 128 clips (Dv=3072, Ds=768), 10 000 queries x <=30 tokens (Dq=768); synthetic L2-normalised
+features (seed 2018), random-init weights (XML.reset_parameters, seed 0).  One STEP = one pass of the hot path over
+all 10 000 queries: query encoder -> similarity GEMM with fused max-over-clips (K6, both modalities) -> top-100
+videos (K8) -> ConvSE on the selected pairs (K7) -> banded moment top-200 (K9).  The corpus is encoded once by the
+HIP context encoder before the timed region (reported as encode_videos_per_s) and stays in HBM.
+N > 1: the corpus is sharded by video range (strong scaling: total work fixed), exact two-phase all-gather merge
+(tvretrieval_amd/dist.py).
+
+Prints ONE JSON line (rank 0).  `roofline` prices the dominant kernel (K6) against the dense bf16 MFMA peak using
+its algorithmic flops 2*Nq*Nv_local*L*H per launch and HIP-event durations measured inside the timed region;
+`cpu_baseline` is the oracle (reference formulation, torch CPU) on a bounded sample, rank 0 / N=1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_queries, n_videos, clips, hidden, Dv, Ds, Dq, ctx_mode, dtype)
+    "c3": (10000, 21793, 128, 768, 3072, 768, 768, "video_sub", "bf16"),
+    "c2": (256, 2000, 128, 768, 3072, 768, 768, "video", "f32"),
+    "tiny": (64, 300, 128, 256, 512, 256, 256, "video_sub", "bf16"),
+}
+PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
+CHUNK = 256                                       # videos per encode batch (shard boundaries align to it)
+
+
+def model_config(hidden, dv, ds, dq, ctx_mode, max_ctx_l):
+    two = ctx_mode == "video_sub"
+    return dict(merge_two_stream=two, cross_att=two, span_predictor_type="conv", encoder_type="transformer",
+                visual_input_size=dv, sub_input_size=ds, query_input_size=dq, hidden_size=hidden, conv_kernel_size=5,
+                stack_conv_predictor_conv_kernel_sizes=-1, conv_stride=1, max_ctx_l=max_ctx_l, max_desc_l=30,
+                input_drop=0.1, drop=0.1, n_heads=4, initializer_range=0.02, ctx_mode=ctx_mode, margin=0.1,
+                ranking_loss_type="hinge", lw_neg_q=1, lw_neg_ctx=1, lw_st_ed=0.01, use_hard_negative=False,
+                hard_pool_size=20, use_self_attention=True, no_modular=False)
+
+
+def synth_rows(n, l, d, seed, device):
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.randn((n, l, d), generator=g, device=device, dtype=torch.float32)
+    return x / (x.norm(dim=-1, keepdim=True) + 1e-5)    # l2_normalize_np_array, utils/basic_utils.py:82-84
+
+
+def context_batches(lo, hi, l, dv, ds, use_video, use_sub, device):
+    for b in range(lo, hi, CHUNK):
+        n = min(CHUNK, hi - b)
+        cid = b // CHUNK
+        mask = torch.ones((n, l), device=device)
+        vf = synth_rows(n, l, dv, 2018 + 2 * cid, device) if use_video else None
+        sf = synth_rows(n, l, ds, 2018 + 2 * cid + 1, device) if use_sub else None
+        yield vf, mask if use_video else None, sf, mask if use_sub else None
+
+
+def synth_queries(nq, dq, device):
+    g = torch.Generator(device="cpu").manual_seed(2018)
+    lens = torch.randint(5, 31, (nq,), generator=g)
+    mask = (torch.arange(30)[None] < lens[:, None]).float().to(device)
+    qf = synth_rows(nq, 30, dq, 2017, device) * mask[..., None]
+    return qf.contiguous(), mask.contiguous()
+
+
+def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name):
+    """Oracle (reference formulation, torch CPU fp32) on a bounded slice, extrapolated linearly in Nv."""
+    from oracle import xml_oracle as O
+    nq_s, nv_s = 50, min(1000, index.n_videos)
+    sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    om = O.OracleXML(cfg, sd)
+    mods = index.modalities
+    f1 = {m: index.feat1n[m][:nv_s, :index.l_ref].float().cpu() for m in mods}
+    f2 = {m: index.feat2[m][:nv_s, :index.l_ref].float().cpu() for m in mods}
+    mk = {m: index.mask[m][:nv_s, :index.l_ref].float().cpu() for m in mods}
+    q, qmask = qf[:nq_s].float().cpu(), qm[:nq_s].float().cpu()
+    g = lambda d, m: d[m] if m in d else None
+
+    def run():
+        with torch.no_grad():
+            q2c, st, ed = om.get_pred_from_raw_query(q, qmask, g(f1, "video"), g(f2, "video"), g(mk, "video"),
+                                                     g(f1, "sub"), g(f2, "sub"), g(mk, "sub"), cross=True)
+            return O.vcmr_tail(q2c, st, ed, 20.0, min(100, nv_s), 2, 16, 200)
+    run()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        run()
+        ts.append(time.perf_counter() - t0)
+    t = float(np.median(ts))
+    qps_sample = nq_s / t
+    return dict(value=qps_sample * nv_s / n_total, unit="queries/s", cores=torch.get_num_threads(), kind="port",
+                host_cpus=os.cpu_count(),
+                sample="oracle (reference formulation, torch-CPU fp32): %d queries x %d videos x %d clips, H=%d, %s; "
+                       "median of 3 after 1 warm-up = %.2f s (%.1f q/s on the sample); value extrapolated linearly "
+                       "in Nv to %d videos" % (nq_s, nv_s, index.l_ref, cfg["hidden_size"], cfg["ctx_mode"], t,
+                                               qps_sample, n_total))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, "--gpus must equal WORLD_SIZE under torch.distributed.run"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import dist as xdist
+    from tvretrieval_amd.model_xml import XML
+
+    nq, nv, l, hidden, dv, ds, dq, ctx_mode, dtname = WORKLOADS[args.workload]
+    dtype = torch.bfloat16 if dtname == "bf16" else torch.float32
+    cfg = model_config(hidden, dv, ds, dq, ctx_mode, l)
+    torch.manual_seed(0)
+    model = XML(cfg, compute_dtype=dtype).to(device).eval()
+
+    # ---- one-off: encode this rank's shard of the corpus (HOT LOOP A), untimed for the metric -------------
+    lo, hi = xdist.shard_range(nv, rank, world, align=CHUNK)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        index = inf.build_corpus_index(model, context_batches(lo, hi, l, dv, ds, model.use_video, model.use_sub, device),
+                                       video_offset=lo, n_total=nv, l_ref=l)
+    torch.cuda.synchronize()
+    enc_s = time.perf_counter() - t0
+    qf, qm = synth_queries(nq, dq, device)
+
+    ev = []      # (start, end) HIP event pairs around every K6 launch of the timed region
+    def k6_timer():
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev.append((s, e))
+        return s, e
+
+    def step():
+        with torch.no_grad():
+            if world == 1:
+                return inf.vcmr_search(model, index, qf, qm)
+            return xdist.sharded_vcmr_search(model, index, qf, qm)
+
+    for _ in range(args.warmup):
+        step()
+    inf.K6_TIMER = k6_timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    inf.K6_TIMER = None
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    k6_ms = [s.elapsed_time(e) for s, e in ev]
+    k6_avg_ms = float(np.mean(k6_ms))
+    flops_per_launch = 2.0 * nq * index.n_videos * index.lpad * hidden
+    achieved = flops_per_launch / (k6_avg_ms * 1e-3) / 1e12
+
+    # ---- stage breakdown, one extra untimed step --------------------------------------------------------
+    breakdown = {}
+    if world == 1:
+        def timed(name, fn):
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record(); r = fn(); e.record(); torch.cuda.synchronize()
+            breakdown[name] = round(s.elapsed_time(e), 3)
+            return r
+        with torch.no_grad():
+            qvec = timed("query_encode", lambda: inf.stage_query_vectors(model, qf, qm))
+            q2c = timed("q2c_k6", lambda: inf.stage_q2c(index, qvec))
+            tw, ti = timed("topk_k8", lambda: inf.hip_ops.topk_rows(q2c, min(100, index.n_videos), alpha=20.0))
+            st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti))
+            timed("moment_k9", lambda: inf.hip_ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
+
+    res = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        res = {
+            "metric": "queries/sec VCMR over 21.8K-video corpus", "value": nq * args.steps / elapsed,
+            "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtname, "data": "synthetic",
+            "config": {"workload": "%s: XML %s ConvSE VCMR, %d queries x %d videos x %d clips, H=%d, top-100 videos, "
+                                   "top-200 moments" % (args.workload, ctx_mode, nq, nv, l, hidden),
+                       "global_batch": nq, "parallelism": "corpus-shard x%d" % world, "videos_per_gpu": index.n_videos},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtname], "unit": "TFLOP/s",
+                         "frac": achieved / PEAK_TFLOPS[dtname], "traffic": None, "kernel": "q2c_scores_kernel",
+                         "launches_timed": len(k6_ms), "avg_launch_ms": k6_avg_ms,
+                         "flops_per_launch": flops_per_launch},
+            "encode_videos_per_s": (hi - lo) * world / enc_s if enc_s > 0 else None,
+            "corpus_hbm_gb_per_gpu": index.hbm_bytes() / 1e9,
+            "breakdown_ms": breakdown,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return res
+
+
+if __name__ == "__main__":
+    main()

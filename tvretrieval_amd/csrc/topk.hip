@@ -9,7 +9,8 @@
 #include "common.h"
 
 __device__ __forceinline__ uint32_t ord_key(float f) {
-  const uint32_t u = __float_as_uint(f);
+  uint32_t u = __float_as_uint(f);
+  if (u == 0x80000000u) u = 0u;  // -0.0 ties with +0.0, as in torch.topk
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending uint order == ascending float order
 }
 __device__ __forceinline__ float key_to_float(uint32_t k) {

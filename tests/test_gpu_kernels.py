@@ -190,18 +190,30 @@ def test_q2c_scores(ops, dtype, shape):
     close("q2c combine", got2, (want + want) / 2, 1e-5)
 
 
-def test_q2c_swizzle_equivalence(ops):
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("lpad", [128, 48])
+def test_q2c_variants_equivalent(ops, dtype, lpad):
+    """128x128 register-staged kernel (with / without XCD swizzle) == 256x256 LDS-DMA kernel, bit for bit:
+    every accumulator sees the same MFMA sequence over K."""
     import ctypes
     lib = ops._lib.load()
-    q, c = _normed(1100, 256, seed=83), _normed(70, 128, 256, seed=84)
-    mask = _ragged_mask(70, 128, 85)
-    a = ops.q2c_scores(dev(q, torch.bfloat16), dev(c, torch.bfloat16), dev(mask))
-    lib.xml_debug_set_q2c_swizzle(ctypes.c_int(0))
+    q, c = _normed(1100, 256, seed=83), _normed(70, lpad, 256, seed=84)
+    mask = _ragged_mask(70, lpad, 85)
+    args = (dev(q, dtype), dev(c, dtype), dev(mask))
+    res = []
     try:
-        b = ops.q2c_scores(dev(q, torch.bfloat16), dev(c, torch.bfloat16), dev(mask))
+        for variant, swz in ((2, 1), (1, 1), (1, 0)):
+            lib.xml_debug_set_q2c_variant(ctypes.c_int(variant))
+            lib.xml_debug_set_q2c_swizzle(ctypes.c_int(swz))
+            res.append(ops.q2c_scores(*args))
+            res.append(ops.q2c_scores(*args, out=res[-1].clone(), combine=True))
     finally:
+        lib.xml_debug_set_q2c_variant(ctypes.c_int(0))
         lib.xml_debug_set_q2c_swizzle(ctypes.c_int(1))
-    assert torch.equal(a, b)
+    for r in res[2::2]:
+        assert torch.equal(res[0], r)
+    for r in res[3::2]:
+        assert torch.equal(res[1], r)
 
 
 @pytest.mark.parametrize("shape", [(5, 10, 4), (9, 2179, 100), (3, 21793, 100), (4, 300, 256), (2, 7, 7)])

@@ -1,7 +1,8 @@
 // ABI bookkeeping for libxmlhip.so.
 #include "common.h"
 
-extern "C" int xml_abi_version(void) { return 1; }
+extern "C" int xml_abi_version(void) {
+  return 1; }
 extern "C" const char* xml_build_arch(void) { return "gfx950"; }
 extern "C" const char* xml_status_string(int status) {
   switch (status) {

@@ -220,6 +220,7 @@ static int dispatch_attn_dh(int dh, const void* q, int ldq, const void* k, int l
 int xmli_attention_core(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
                         const float* k_mask, void* out, int out_f32, int64_t n, int lq, int lk, int hidden,
                         int n_heads, int dt, hipStream_t st) {
+  XML_ENTER();
   if (n <= 0 || lq <= 0 || lk <= 0 || n_heads <= 0 || hidden % n_heads) return XML_ERR_BAD_ARG;
   if (lq > 128 || lk > 128) return XML_ERR_UNSUPPORTED;
   const int dh = hidden / n_heads;
@@ -251,6 +252,7 @@ extern "C" int xml_attention_block(const void* x, const float* key_mask, const v
                                    const void* wo, const float* bo, const float* ln_g, const float* ln_b, void* y,
                                    int64_t n, int seq_len, int hidden, int n_heads, int dt, void* ws, size_t ws_bytes,
                                    xml_stream_t stream) {
+  XML_ENTER();
   if (!x || !key_mask || !wqkv || !bqkv || !wo || !bo || !ln_g || !ln_b || !y || !ws) return XML_ERR_BAD_ARG;
   if (n <= 0 || seq_len <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
   if (seq_len > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
@@ -285,6 +287,7 @@ extern "C" int xml_cross_attention(const void* main_x, const float* main_mask, c
                                    const float* bkv, const float* ln_g, const float* ln_b, void* y, int64_t n, int lq,
                                    int lk, int hidden, int n_heads, int dt, void* ws, size_t ws_bytes,
                                    xml_stream_t stream) {
+  XML_ENTER();
   if (!main_x || !main_mask || !side_x || !side_mask || !wq || !bq || !wkv || !bkv || !ln_g || !ln_b || !y || !ws)
     return XML_ERR_BAD_ARG;
   if (n <= 0 || lq <= 0 || lk <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
@@ -350,6 +353,7 @@ __global__ __launch_bounds__(256) void modular_pool_kernel(const T* __restrict__
 
 extern "C" int xml_modular_pool(const void* enc, const float* mask, const float* w_m, void* out, int64_t n, int lq,
                                 int hidden, int n_mod, int dt, xml_stream_t stream) {
+  XML_ENTER();
   if (!enc || !mask || !w_m || !out || n <= 0 || lq <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
   if (n_mod < 1 || n_mod > 2 || lq > 128) return XML_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;

@@ -4,6 +4,10 @@
 #include <stdint.h>
 #include "../../include/xmlhip.h"
 
+// hipGetLastError() also reports stale, non-sticky errors left by OTHER runtime users in this thread (e.g. the
+// caching allocator's hipErrorNotReady event polls), so every entry point clears the slot before launching.
+#define XML_ENTER() (void)hipGetLastError()
+
 #define XML_CHECK_LAUNCH()                                   \
   do {                                                       \
     if (hipGetLastError() != hipSuccess) return XML_ERR_LAUNCH; \

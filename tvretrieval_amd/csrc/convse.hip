@@ -222,6 +222,7 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
                                  const void* feat2_0, const void* feat2_1, const float* mask0, const float* mask1,
                                  const int32_t* pair_vid, const float* conv_w, float* st_out, float* ed_out, void* ws,
                                  size_t ws_bytes, xml_stream_t stream) {
+  XML_ENTER();
   if (!d || !q_lin0 || !feat2_0 || !mask0 || !pair_vid || !conv_w || !st_out || !ed_out || !ws) return XML_ERR_BAD_ARG;
   if (d->nq <= 0 || d->nv <= 0 || d->kpairs <= 0 || d->hidden <= 0) return XML_ERR_BAD_ARG;
   if (d->n_mod < 1 || d->n_mod > 2 || (d->n_mod == 2 && (!q_lin1 || !feat2_1))) return XML_ERR_BAD_ARG;

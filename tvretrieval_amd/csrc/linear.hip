@@ -66,6 +66,7 @@ static int launch_gemm(const void* A, const void* W, const float* bias, const vo
 // out_f32: write f32 regardless of dt (pre-LayerNorm values keep full precision)
 int xmli_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
               int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st) {
+  XML_ENTER();
   if (M <= 0 || N <= 0 || K <= 0) return XML_ERR_BAD_ARG;
   if (dt == XML_F32) {
     if (K % 4) return XML_ERR_UNSUPPORTED;
@@ -119,6 +120,7 @@ static int launch_ln(const void* a, const void* b, const float* g, const float* 
 
 int xmli_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
                        int64_t rows, int d, int ld_out, int dt, hipStream_t st) {
+  XML_ENTER();
   if (rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
   if (dt == XML_F32) {
     if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
@@ -130,6 +132,7 @@ int xmli_add_layernorm(const void* a, int a_dt, const void* b, const float* g, c
 
 extern "C" int xml_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta,
                                  void* y, int64_t rows, int d, int dt, xml_stream_t stream) {
+  XML_ENTER();
   if (!a || !g || !beta || !y) return XML_ERR_BAD_ARG;
   return xmli_add_layernorm(a, a_dt, b, g, beta, y, rows, d, d, dt, (hipStream_t)stream);
 }
@@ -154,6 +157,7 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const T* __restrict__ 
 }
 
 extern "C" int xml_l2norm_rows(const void* x, void* y, int64_t rows, int d, int dt, xml_stream_t stream) {
+  XML_ENTER();
   if (!x || !y || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dt == XML_F32)
@@ -176,6 +180,7 @@ __global__ void convert_kernel(const S* __restrict__ s, D* __restrict__ d, int64
 }
 
 extern "C" int xml_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, xml_stream_t stream) {
+  XML_ENTER();
   if (!src || !dst || n < 0) return XML_ERR_BAD_ARG;
   if (n == 0) return XML_OK;
   hipStream_t st = (hipStream_t)stream;
@@ -195,6 +200,7 @@ extern "C" int xml_convert(const void* src, int src_dt, void* dst, int dst_dt, i
 }
 
 extern "C" int xml_pack_weights(const float* src, void* dst, int dt, int64_t n, xml_stream_t stream) {
+  XML_ENTER();
   return xml_convert(src, XML_F32, dst, dt, n, stream);
 }
 
@@ -203,6 +209,7 @@ extern "C" int xml_pack_weights(const float* src, void* dst, int dt, int64_t n, 
 // ---------------------------------------------------------------------------------------------------
 extern "C" int xml_linear(const void* x, const void* w, const float* b, void* y, int64_t rows, int n, int k, int relu,
                           int dt, xml_stream_t stream) {
+  XML_ENTER();
   if (!x || !w || !y) return XML_ERR_BAD_ARG;
   return xmli_gemm(x, w, b, nullptr, y, rows, n, k, relu, 0, 1, 0, dt, (hipStream_t)stream);
 }
@@ -219,6 +226,7 @@ extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_i
                                       const void* w, const float* b, const void* pos, const float* ln_pos_g,
                                       const float* ln_pos_b, void* y, int64_t rows, int seq_len, int d_in, int hidden,
                                       int dt, void* ws, size_t ws_bytes, xml_stream_t stream) {
+  XML_ENTER();
   if (!x || !ln_in_g || !ln_in_b || !w || !b || !pos || !ln_pos_g || !ln_pos_b || !y || !ws) return XML_ERR_BAD_ARG;
   if (rows <= 0 || seq_len <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
   if (d_in % 8 || hidden % 8) return XML_ERR_UNSUPPORTED;

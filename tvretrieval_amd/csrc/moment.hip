@@ -195,6 +195,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
 extern "C" int xml_moment_topk(const float* st, const float* ed, const float* w, float* out_score, int32_t* out_flat,
                                int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
                                xml_stream_t stream) {
+  XML_ENTER();
   if (!st || !ed || !out_score || !out_flat || nq <= 0 || kpairs <= 0 || lpad <= 0 || l_ref <= 0 || n_out <= 0)
     return XML_ERR_BAD_ARG;
   if (l_ref > lpad || min_l < 0 || max_l <= min_l) return XML_ERR_BAD_ARG;

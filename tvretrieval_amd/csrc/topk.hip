@@ -133,6 +133,7 @@ extern "C" size_t xml_topk_rows_workspace_bytes(int rows, int n, int k) {
 extern "C" int xml_topk_rows(const float* scores, int64_t ld, const int32_t* idx_in, float* out_val,
                              int32_t* out_idx, int rows, int n, int k, float alpha, void* ws, size_t ws_bytes,
                              xml_stream_t stream) {
+  XML_ENTER();
   (void)ws; (void)ws_bytes;
   if (!scores || !out_val || !out_idx || rows <= 0 || n <= 0 || k <= 0 || ld < n) return XML_ERR_BAD_ARG;
   if (k > 256 || k > n) return XML_ERR_UNSUPPORTED;

@@ -193,7 +193,7 @@ def test_q2c_scores(ops, dtype, shape):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("lpad", [128, 48])
 def test_q2c_variants_equivalent(ops, dtype, lpad):
-    """128x128 register-staged kernel (with / without XCD swizzle) == 256x256 LDS-DMA kernel, bit for bit:
+    """128x128 register-staged kernel (with / without XCD swizzle) == 256x256 LDS-DMA kernels (ring / double buffer), bit for bit:
     every accumulator sees the same MFMA sequence over K."""
     import ctypes
     lib = ops._lib.load()
@@ -202,7 +202,7 @@ def test_q2c_variants_equivalent(ops, dtype, lpad):
     args = (dev(q, dtype), dev(c, dtype), dev(mask))
     res = []
     try:
-        for variant, swz in ((2, 1), (1, 1), (1, 0)):
+        for variant, swz in ((3, 1), (2, 1), (1, 1), (1, 0)):
             lib.xml_debug_set_q2c_variant(ctypes.c_int(variant))
             lib.xml_debug_set_q2c_swizzle(ctypes.c_int(swz))
             res.append(ops.q2c_scores(*args))

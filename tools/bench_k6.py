@@ -19,7 +19,10 @@ def main():
         if a.startswith("--variants="):
             variants = [int(x) for x in a.split("=")[1].split(",")]
     dtype = torch.float32 if "--f32" in sys.argv else torch.bfloat16
+    abl = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--ablation=")]
     lib = ops._lib.load()
+    if abl:
+        lib.xml_debug_set_q2c_ablation(ctypes.c_int(abl[0]))
     g = torch.Generator(device="cuda").manual_seed(0)
     q = torch.nn.functional.normalize(torch.randn(nq, h, device="cuda", generator=g), dim=-1).to(dtype)
     c = torch.empty(nv, 128, h, device="cuda", dtype=dtype)

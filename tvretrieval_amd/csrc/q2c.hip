@@ -89,10 +89,12 @@ __global__ __launch_bounds__(256) void q2c_scores_kernel(const T* __restrict__ q
 }
 
 static int g_q2c_xcd_swizzle = 1;
-static int g_q2c_variant = 0;   // 0 auto, 1 force the 128x128 register-staged kernel, 2 force the 256x256 LDS-DMA kernel
+static int g_q2c_variant = 0;   // 0 auto, 1: 128x128 register-staged, 2: 256x256 LDS-DMA double buffer, 3: 256x256 LDS-DMA ring
 extern "C" void xml_debug_set_q2c_swizzle(int on) { g_q2c_xcd_swizzle = on; }
 extern "C" void xml_debug_set_q2c_variant(int v) { g_q2c_variant = v; }
 
+int xmli_q2c_scores_ring(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int nq, int nv,
+                         int lpad, int hidden, int combine, int dt, hipStream_t st);
 int xmli_q2c_scores_256(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int nq, int nv,
                         int lpad, int hidden, int combine, int dt, hipStream_t st);
 
@@ -105,7 +107,9 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
   hipStream_t st = (hipStream_t)stream;
   if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
   const bool dma_ok = ((size_t)hidden * dt_size(dt)) % 128 == 0;
-  if ((g_q2c_variant == 0 || g_q2c_variant == 2) && dma_ok)
+  if ((g_q2c_variant == 0 || g_q2c_variant == 3) && dma_ok)
+    return xmli_q2c_scores_ring(qn, cn, mask, out, ld_out, nq, nv, lpad, hidden, combine, dt, st);
+  if (g_q2c_variant == 2 && dma_ok)
     return xmli_q2c_scores_256(qn, cn, mask, out, ld_out, nq, nv, lpad, hidden, combine, dt, st);
   const int vpt = 128 / lpad;
   const int tq = cdiv(nq, 128), tc = cdiv(nv, vpt);

@@ -18,7 +18,7 @@
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void glb_void;
 
-template <typename T>
+template <typename T, int ABL = 0>   // ABL: perf ablations only (1: DMA for the first K tile only, 2: no MFMA)
 __global__ __launch_bounds__(512, 2) void q2c_scores_kernel_256(const T* __restrict__ qn, const T* __restrict__ cn,
                                                                 const float* __restrict__ mask,
                                                                 float* __restrict__ out, int64_t ld_out, int nq,
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512, 2) void q2c_scores_kernel_256(const T* __restr
   for (int kt = 0; kt < nk; ++kt) {
     __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's DMA pieces of stage kt have landed
     __syncthreads();                      // ... and everybody's; everybody is done reading the other stage
-    if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+    if (kt + 1 < nk && ABL != 1) issue(kt + 1, (kt + 1) & 1);
     const char* st = smem + (kt & 1) * STAGE_BYTES;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -110,7 +110,14 @@ __global__ __launch_bounds__(512, 2) void q2c_scores_kernel_256(const T* __restr
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 8; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
+        for (int n = 0; n < 8; ++n) {
+          if (ABL == 2) {
+            asm volatile("" ::"v"(fa[m].x), "v"(fb[n].x));
+            asm volatile("" ::"v"(fa[m].w), "v"(fb[n].w));
+          } else {
+            Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
+          }
+        }
     }
   }
 
@@ -148,6 +155,9 @@ __global__ __launch_bounds__(512, 2) void q2c_scores_kernel_256(const T* __restr
   }
 }
 
+int g_q2c_ablation = 0;
+extern "C" void xml_debug_set_q2c_ablation(int v) { g_q2c_ablation = v; }
+
 template <typename T>
 static int launch_q2c256(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int nq, int nv,
                          int lpad, int hidden, int combine, hipStream_t st) {
@@ -156,7 +166,9 @@ static int launch_q2c256(const void* qn, const void* cn, const float* mask, floa
   const int64_t nsup = (int64_t)((tq + 7) / 8) * ((tc + 3) / 4);
   const unsigned grid = (unsigned)(((nsup + 7) / 8) * 8 * 32);
   const int lds = 2 * 2 * 256 * 128;
-  auto kern = q2c_scores_kernel_256<T>;
+  extern int g_q2c_ablation;
+  auto kern = g_q2c_ablation == 1 ? q2c_scores_kernel_256<T, 1>
+              : g_q2c_ablation == 2 ? q2c_scores_kernel_256<T, 2> : q2c_scores_kernel_256<T, 0>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const T*)qn, (const T*)cn, mask, out, ld_out, nq, nv, lpad,

@@ -184,7 +184,7 @@ def main():
 
     k6_ms = [s.elapsed_time(e) for s, e in ev]
     k6_avg_ms = float(np.mean(k6_ms))
-    flops_per_launch = 2.0 * nq * index.n_videos * index.lpad * hidden
+    flops_per_launch = 2.0 * nq * index.n_videos * index.lpad * hidden * len(index.modalities)
     achieved = flops_per_launch / (k6_avg_ms * 1e-3) / 1e12
 
     # ---- stage breakdown, one extra untimed step --------------------------------------------------------

@@ -129,6 +129,16 @@ int xml_l2norm_rows(const void* x, void* y, int64_t rows, int d, int dt, xml_str
 int xml_q2c_scores(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out,
                    int nq, int nv, int lpad, int hidden, int combine, int dt, xml_stream_t stream);
 
+/* K6 for all modalities of the model in ONE launch (the form the retrieval engine uses):
+ *   out[q,v] = ( sum_m max_l mask_logits( qn[m][q] . cn[m][v,l] ) ) / n_mod        n_mod in {1, 2}
+ * = get_video_level_scores per modality + the (video + sub) / divisor of xml/model_xml.py:572-574.
+ * At lpad == 128 this is a persistent kernel: one workgroup per CU, both modalities of a 256 x 256 tile back to
+ * back, a single never-drained LDS-DMA stream (tvretrieval_amd/csrc/q2c_persist.hip); other paddings run the
+ * per-modality kernels.  qn1 / cn1 / mask1 are ignored when n_mod == 1. */
+int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0, const float* mask0, const void* qn1,
+                         const void* cn1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
+                         int lpad, int hidden, int dt, xml_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K8: per-row top-k, torch.topk(exp(alpha*s), k) (xml/inference.py:317,347-348)
  *   scores (rows, n) f32 row stride ld; optional idx_in (rows, n) int32 payload (NULL: column index)

@@ -23,6 +23,14 @@ class CpuOps(object):
         return out
 
     @staticmethod
+    def q2c_scores_fused(qn, cn, masks, out=None):
+        acc = None
+        for m in range(len(qn)):
+            s = CpuOps.q2c_scores(qn[m], cn[m], masks[m])
+            acc = s if acc is None else (acc + s) * 0.5
+        return acc
+
+    @staticmethod
     def topk_rows(scores, k, alpha=0.0, idx_in=None):
         n = scores.shape[1]
         pay = idx_in.long() if idx_in is not None else torch.arange(n).repeat(scores.shape[0], 1)

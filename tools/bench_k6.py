@@ -54,6 +54,18 @@ def main():
         else:
             print("  bitwise equal to first variant:", bool(torch.equal(ref, out[:256, :512])))
     lib.xml_debug_set_q2c_variant(ctypes.c_int(0))
+    if "--fused" in sys.argv:   # both modalities in one launch (persistent kernel), reusing the same operands twice
+        q2 = q.clone(); c2 = c.clone()
+        for _ in range(2):
+            ops.q2c_scores_fused([q, q2], [c, c2], [mask, mask], out=out)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+        for s, e in evs:
+            s.record(); ops.q2c_scores_fused([q, q2], [c, c2], [mask, mask], out=out); e.record()
+        torch.cuda.synchronize()
+        ms = sorted(s.elapsed_time(e) for s, e in evs)
+        print("fused x2 modalities: median %.3f ms -> %.1f TFLOP/s" % (ms[2], 2 * flops / ms[2] / 1e9), flush=True)
+        print("  equals single-modality result (a+a)/2:", bool(torch.equal(ref, out[:256, :512])))
 
 
 if __name__ == "__main__":

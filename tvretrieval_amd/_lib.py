@@ -49,6 +49,8 @@ SIGNATURES = {
     "xml_l2norm_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "xml_q2c_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_void_p]),
+    "xml_q2c_scores_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                     c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "xml_topk_rows_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "xml_topk_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float,
                               c_void_p, c_size_t, c_void_p]),

@@ -109,6 +109,17 @@ __device__ __forceinline__ float lane16_max(float v) {
   for (int o = 8; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
   return v;
 }
+// same reduction with DPP row rotations (v_max_f32_dpp row_ror:8/4/2/1): no LDS crossbar traffic, all 16 lanes
+// of each row end up with the row maximum
+__device__ __forceinline__ float lane16_max_dpp(float v) {
+#define XML_ROR(x, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + (n), 0xf, 0xf, false))
+  v = fmaxf(v, XML_ROR(v, 8));
+  v = fmaxf(v, XML_ROR(v, 4));
+  v = fmaxf(v, XML_ROR(v, 2));
+  v = fmaxf(v, XML_ROR(v, 1));
+#undef XML_ROR
+  return v;
+}
 __device__ __forceinline__ float lane16_sum(float v) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

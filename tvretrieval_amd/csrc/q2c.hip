@@ -89,10 +89,12 @@ __global__ __launch_bounds__(256) void q2c_scores_kernel(const T* __restrict__ q
 }
 
 static int g_q2c_xcd_swizzle = 1;
-static int g_q2c_variant = 0;   // 0 auto, 1: 128x128 register-staged, 2: 256x256 LDS-DMA double buffer, 3: 256x256 LDS-DMA ring
+static int g_q2c_variant = 0;   // 0 auto, 1: 128x128 register-staged, 2: 256x256 LDS-DMA double buffer, 3: 256x256 LDS-DMA ring, 4: persistent fused
 extern "C" void xml_debug_set_q2c_swizzle(int on) { g_q2c_xcd_swizzle = on; }
 extern "C" void xml_debug_set_q2c_variant(int v) { g_q2c_variant = v; }
 
+int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
+                            float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st);
 int xmli_q2c_scores_ring(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int nq, int nv,
                          int lpad, int hidden, int combine, int dt, hipStream_t st);
 int xmli_q2c_scores_256(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int nq, int nv,
@@ -107,6 +109,13 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
   hipStream_t st = (hipStream_t)stream;
   if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
   const bool dma_ok = ((size_t)hidden * dt_size(dt)) % 128 == 0;
+  const bool persist_ok = lpad == 128 && ((size_t)hidden * dt_size(dt)) % 64 == 0 && (size_t)hidden * dt_size(dt) >= 192;
+  if ((g_q2c_variant == 0 || g_q2c_variant == 4) && persist_ok && !combine) {
+    const void* q[2] = {qn, qn};
+    const void* c[2] = {cn, cn};
+    const float* m[2] = {mask, mask};
+    return xmli_q2c_scores_persist(1, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, st);
+  }
   if ((g_q2c_variant == 0 || g_q2c_variant == 3) && dma_ok)
     return xmli_q2c_scores_ring(qn, cn, mask, out, ld_out, nq, nv, lpad, hidden, combine, dt, st);
   if (g_q2c_variant == 2 && dma_ok)
@@ -131,4 +140,26 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
     return XML_ERR_BAD_ARG;
   XML_CHECK_LAUNCH();
   return XML_OK;
+}
+
+extern "C" int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0, const float* mask0, const void* qn1,
+                                    const void* cn1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
+                                    int lpad, int hidden, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (n_mod < 1 || n_mod > 2 || !qn0 || !cn0 || !mask0 || !out) return XML_ERR_BAD_ARG;
+  if (n_mod == 2 && (!qn1 || !cn1 || !mask1)) return XML_ERR_BAD_ARG;
+  if (nq <= 0 || nv <= 0 || lpad <= 0 || hidden <= 0 || ld_out < nv) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (lpad % 16 || lpad > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
+  const size_t kb = (size_t)hidden * dt_size(dt);
+  const bool persist_ok = lpad == 128 && kb % 64 == 0 && kb >= 192;
+  if ((g_q2c_variant == 0 || g_q2c_variant == 4) && persist_ok) {
+    const void* q[2] = {qn0, qn1};
+    const void* c[2] = {cn0, cn1};
+    const float* m[2] = {mask0, mask1};
+    return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream);
+  }
+  int rc = xml_q2c_scores(qn0, cn0, mask0, out, ld_out, nq, nv, lpad, hidden, 0, dt, stream);
+  if (rc || n_mod == 1) return rc;
+  return xml_q2c_scores(qn1, cn1, mask1, out, ld_out, nq, nv, lpad, hidden, 1, dt, stream);
 }

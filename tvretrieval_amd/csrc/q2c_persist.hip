@@ -1,0 +1,267 @@
+// K6, persistent fused variant (the one the engine uses): one workgroup per CU walks a static list of
+// 256 x 256 tiles, both modalities of a tile back to back, with ONE continuous LDS-DMA stream.
+//
+// Why (measured, profiles/r01_k6_notes.md): with one launch-time workgroup per tile, ~10 us of every ~26 us tile
+// was fixed cost -- workgroup launch on a CU that can hold only one (128 KiB of LDS), a cold DMA pipeline
+// (~2.2 us round trip), epilogue + drain.  t(K) = 17.4 ms + 1.11 ms per 32-wide K slice at the TVR shape: 40 % of
+// the kernel was not the K loop.  Here
+//   * 256 workgroups stay resident; the DMA unit stream (see q2c_ring.hip for the ring / phase / stagger schedule,
+//     which is unchanged) runs LEAD units ahead of the MFMA phases ACROSS modality and tile boundaries, so the
+//     pipeline never drains and the epilogue of a tile overlaps the loads of the next one;
+//   * video and sub scores of a tile are produced back to back and combined in registers:
+//     out = (max_l s_video + max_l s_sub) * 0.5  -- one plain store per (query, video), no read-modify-write;
+//   * the clip masks of a tile arrive by the same DMA stream (1 KiB) and are read from LDS in the epilogue, so the
+//     only VMEM ops besides the stream are the result stores (a compiler-visible global load would make hipcc
+//     drain the hand-counted stream with vmcnt(0));
+//   * DMA addressing is SGPR base (tile / slice, scalar adds) + loop-invariant 32-bit VGPR row offset.
+// Tile order: workgroup j runs on XCD j % 8 (observed, speed only).  The 32 workgroups of an XCD form an
+// 8 (query tiles) x 4 (clip tiles) super-tile; an XCD keeps its query group and walks clip groups, so the 3 MiB of
+// query operands stay in that XCD's 4 MiB L2 and only clip tiles stream in (6 % instead of 19 % line misses).
+#include "common.h"
+
+struct Q2cPersistArgs {
+  const void* qn[2];
+  const void* cn[2];
+  const float* mask[2];
+  float* out;
+  int64_t ld_out;
+  int nq, nv, hidden, n_mod, tq, tc;
+};
+
+__device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
+__device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+// Specialised to lpad == 128 (one video per 128-column group -- the TVR shape): no per-column divisions, one
+// reduction per accumulator row.  Other clip paddings use the per-modality kernels (q2c_ring.hip / q2c256.hip).
+template <typename T>
+__global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
+  constexpr int ROWB = 64;
+  constexpr int OPER_BYTES = 256 * ROWB;
+  constexpr int SLOT_BYTES = 2 * OPER_BYTES;
+  constexpr int RING_BYTES = 4 * SLOT_BYTES;
+  constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
+  constexpr int STASH_OFF = RING_BYTES + 2048;    // 256 rows x 2 videos f32: modality-0 maxima of the current tile
+  constexpr int LEAD = 5;                         // odd: a segment can only end on the h = 0 issue slot
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int xcd = blockIdx.x & 7;
+  const int qt_off = (blockIdx.x >> 3) & 7, ct_off = blockIdx.x >> 6;   // position inside the 8 x 4 super-tile
+  const int k_bytes = a.hidden * (int)sizeof(T);
+  const int n_units = 2 * (k_bytes / ROWB);
+  const int n_qgroups = (a.tq + 7) >> 3;
+  const int cr = (((a.tc + 3) >> 2) + 7) >> 3;    // rounds per query group on one XCD
+
+  // tile of (query group g, round c):  qt = 8 g + qt_off,  ct = 4 (8 c + xcd) + ct_off
+  auto tile_valid = [&](int g, int c) -> bool { return (8 * g + qt_off) < a.tq && (4 * (8 * c + xcd) + ct_off) < a.tc; };
+  auto advance = [&](int& g, int& c) {            // next valid (g, c) in walk order, g == n_qgroups when exhausted
+    do {
+      if (++c == cr) { c = 0; ++g; }
+    } while (g < n_qgroups && !tile_valid(g, c));
+  };
+
+  // ---- issue side (runs LEAD units ahead of the compute side) ----------------------------------------------
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const uint32_t lds_wave = lds0 + wave * 2048;
+  int i_g = 0, i_c = -1, i_mod = 0, i_unit = 0, i_seg = 0;
+  uint32_t i_gslice = 0, i_count = 0;
+  uint32_t voff_a0 = 0, voff_a1 = 0, voff_b0 = 0, voff_b1 = 0;
+  const char* sbase_a = nullptr;
+  const char* sbase_b = nullptr;
+
+  auto setup_issue_segment = [&](bool new_tile) {
+    const int q0 = (8 * i_g + qt_off) * 256, v0 = (4 * (8 * i_c + xcd) + ct_off) * 2;
+    int lane_o = lane;                              // opaque copy: keeps LICM from hoisting (and keeping live across
+    asm volatile("" : "+v"(lane_o));                // the MFMA loop) everything derived from the lane id below
+    if (new_tile) {
+      const int rsub = lane_o >> 2, pslot = lane_o & 3;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int row = (wave * 2 + i) * 16 + rsub;                     // 0..255
+        const int slot = pslot ^ swz4p(row);
+        const int qrow = (q0 + row < a.nq) ? row : 0;                   // clamp to the tile's first row
+        const int brow = (v0 + (row >> 7) < a.nv) ? row : (row & 127);  // second video missing: re-read the first
+        const uint32_t va = (uint32_t)qrow * k_bytes + slot * 16;
+        const uint32_t vb = (uint32_t)brow * k_bytes + slot * 16;
+        if (i == 0) { voff_a0 = va; voff_b0 = vb; } else { voff_a1 = va; voff_b1 = vb; }
+      }
+    }
+    sbase_a = reinterpret_cast<const char*>(a.qn[i_mod]) + (int64_t)q0 * k_bytes;
+    sbase_b = reinterpret_cast<const char*>(a.cn[i_mod]) + (int64_t)v0 * 128 * k_bytes;
+    if (wave == 0) {   // mask patch of the segment: lane l carries columns 4 l .. 4 l + 3 of the tile's 256 columns
+      const int mrow = (v0 + (lane_o >> 5) < a.nv) ? lane_o : (lane_o & 31);
+      const char* sbase_m = reinterpret_cast<const char*>(a.mask[i_mod]) + (int64_t)v0 * 128 * 4;
+      dma16s((uint32_t)mrow * 16, sbase_m, lds0 + MASK_OFF + (i_seg & 1) * 1024);
+    }
+  };
+  auto issue_unit = [&]() {       // fast path only: two DMA instructions
+    if (i_g >= n_qgroups) return;
+    const int koff = (i_unit >> 1) * ROWB;
+    const uint32_t dst = lds_wave + (i_gslice & 3) * SLOT_BYTES + (i_unit & 1) * OPER_BYTES;
+    if (i_unit & 1) {
+      dma16s(voff_b0, sbase_b + koff, dst);
+      dma16s(voff_b1, sbase_b + koff, dst + 1024);
+      ++i_gslice;
+    } else {
+      dma16s(voff_a0, sbase_a + koff, dst);
+      dma16s(voff_a1, sbase_a + koff, dst + 1024);
+    }
+    ++i_count;
+    ++i_unit;
+  };
+  auto advance_issue_segment = [&]() {   // called at ONE program point (after the h = 0 issue slot)
+    if (i_unit != n_units || i_g >= n_qgroups) return;
+    i_unit = 0;
+    ++i_seg;
+    bool new_tile = false;
+    if (++i_mod == a.n_mod) {
+      i_mod = 0;
+      advance(i_g, i_c);
+      new_tile = true;
+    }
+    if (i_g < n_qgroups) setup_issue_segment(new_tile);
+  };
+
+  advance(i_g, i_c);
+  if (i_g >= n_qgroups) return;
+  setup_issue_segment(true);
+
+  // ---- compute side ---------------------------------------------------------------------------------------------
+  const int a_off = (wm * 64 + fr) * ROWB + ((fg ^ swz4p(fr)) << 4);
+  const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ swz4p(fr)) << 4);
+  int c_g = i_g, c_c = i_c, c_mod = 0, c_seg = 0;
+  uint32_t c_gslice = 0;
+  const int slices_per_seg = n_units >> 1;
+
+  for (int u = 0; u < LEAD; ++u) issue_unit();      // n_units >= 6: no segment end inside the prologue
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (wave >= 4) __builtin_amdgcn_s_barrier();      // stagger the second wave group by one barrier interval
+
+  for (;;) {      // one iteration = one (tile, modality) segment
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint4 fa[4], fb[4];
+    for (int c_slice = 0; c_slice < slices_per_seg; ++c_slice) {
+      const char* slot = smem + (c_gslice & 3) * SLOT_BYTES;
+      // ---------------- phase h = 0 ----------------
+#pragma unroll
+      for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const uint4*>(slot + a_off + m * 16 * ROWB);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const uint4*>(slot + b_off + n * 16 * ROWB);
+      issue_unit();
+      advance_issue_segment();
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+      // ---------------- phase h = 1 ----------------
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
+      issue_unit();
+      ++c_gslice;
+      {   // the next slice (global units 2 c_gslice, 2 c_gslice + 1) must have landed before the next barrier
+        const int fly = (int)(i_count - (2 * c_gslice + 2));   // units issued beyond the ones needed next
+        if (fly >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (fly == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (fly == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) Mma<T>::chunk(acc[m][n + 4], fa[m], fb[n]);
+      __builtin_amdgcn_s_setprio(0);
+      __builtin_amdgcn_s_barrier();
+    }
+    // ---- end of a (tile, modality) segment: mask_logits + max over the video's 128 clips, inside the wave -----
+    {
+      const int q0 = (8 * c_g + qt_off) * 256, vid = (4 * (8 * c_c + xcd) + ct_off) * 2 + wn;
+      int fr_e = fr, fg_e = fg;                     // opaque copies (see setup_issue_segment)
+      asm volatile("" : "+v"(fr_e), "+v"(fg_e));
+      const float* mpatch = reinterpret_cast<const float*>(smem + MASK_OFF + (c_seg & 1) * 1024) + wn * 128 + fr_e;
+      float* stash = reinterpret_cast<float*>(smem + STASH_OFF) + wn;
+      const bool last_mod = c_mod == a.n_mod - 1;
+      const bool vid_ok = vid < a.nv;
+      float mk[8];
+#pragma unroll
+      for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? mpatch[n * 16] : 0.f;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int lrow = wm * 64 + m * 16 + fg_e * 4 + r;
+          float mx = -INFINITY;
+#pragma unroll
+          for (int n = 0; n < 8; ++n)
+            mx = fmaxf(mx, acc[m][n][r] * mk[n] + (1.f - mk[n]) * -1e10f);   // mask_logits, xml/model_xml.py:640-641
+          float red = lane16_max_dpp(mx);
+          if (fr_e == 0) {
+            if (!last_mod) {
+              stash[lrow * 2] = red;
+            } else {
+              if (a.n_mod == 2) red = (stash[lrow * 2] + red) * 0.5f;        // (video + sub) / 2, xml/model_xml.py:574
+              if (q0 + lrow < a.nq && vid_ok) a.out[(int64_t)(q0 + lrow) * a.ld_out + vid] = red;
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);   // one row at a time: keeps the epilogue's register peak low
+        }
+      }
+    }
+    ++c_seg;
+    if (++c_mod == a.n_mod) {
+      c_mod = 0;
+      advance(c_g, c_c);
+      if (c_g >= n_qgroups) break;
+    }
+  }
+  if (wave < 4) __builtin_amdgcn_s_barrier();      // balance the stagger
+}
+
+template <typename T>
+static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
+  const int lds = 4 * 2 * 256 * 64 + 2048 + 2048;
+  auto kern = q2c_persist_kernel<T>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    return XML_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// Requirements (checked by the caller, which otherwise uses the per-modality kernels): lpad == 128,
+// hidden * sizeof(T) a multiple of 64 bytes and >= 3 slices.
+int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
+                            float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st) {
+  Q2cPersistArgs a;
+  for (int m = 0; m < 2; ++m) {
+    a.qn[m] = qn[m < n_mod ? m : 0];
+    a.cn[m] = cn[m < n_mod ? m : 0];
+    a.mask[m] = mask[m < n_mod ? m : 0];
+  }
+  if (lpad != 128) return XML_ERR_UNSUPPORTED;
+  a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
+  a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
+  if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st);
+  return launch_q2c_persist<float>(a, st);
+}

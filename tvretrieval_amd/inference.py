@@ -161,19 +161,15 @@ K6_TIMER = None   # bench.py: callable returning (start, end) torch.cuda.Event p
 
 
 def stage_q2c(index, qvec, ops=hip_ops):
-    """K6 over the local corpus: (Nq, Nv_local) f32 = mean over modalities of max-over-clips cosine."""
-    q2c = None
-    for m in index.modalities:
-        qn = ops.l2norm_rows(qvec[m].contiguous())
-        ev = K6_TIMER() if K6_TIMER is not None else None
-        if ev:
-            ev[0].record()
-        if q2c is None:
-            q2c = ops.q2c_scores(qn, index.feat1n[m], index.mask[m])
-        else:
-            ops.q2c_scores(qn, index.feat1n[m], index.mask[m], out=q2c, combine=True)
-        if ev:
-            ev[1].record()
+    """K6 over the local corpus: (Nq, Nv_local) f32 = mean over modalities of max-over-clips cosine (one launch)."""
+    mods = index.modalities
+    qn = [ops.l2norm_rows(qvec[m].contiguous()) for m in mods]
+    ev = K6_TIMER() if K6_TIMER is not None else None
+    if ev:
+        ev[0].record()
+    q2c = ops.q2c_scores_fused(qn, [index.feat1n[m] for m in mods], [index.mask[m] for m in mods])
+    if ev:
+        ev[1].record()
     return q2c
 
 

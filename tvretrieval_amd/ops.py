@@ -183,6 +183,25 @@ def q2c_scores(qn, cn, mask, out=None, combine=False):
     return out
 
 
+def q2c_scores_fused(qn, cn, masks, out=None):
+    """K6 for all modalities in one launch.  qn / cn / masks: lists (len 1 or 2) of (Nq,H), (Nv,Lpad,H), (Nv,Lpad) f32.
+    out (Nq, Nv) f32 = mean over modalities of the masked max-over-clips cosine."""
+    n_mod = len(qn)
+    for m in range(n_mod):
+        _req(qn[m], "qn"); _req(cn[m], "cn", qn[m].dtype); _req(masks[m], "mask", torch.float32)
+        assert qn[m].shape == qn[0].shape and cn[m].shape == cn[0].shape and tuple(masks[m].shape) == tuple(cn[0].shape[:2])
+    nq, hidden = qn[0].shape
+    nv, lpad, _ = cn[0].shape
+    if out is None:
+        out = torch.empty((nq, nv), dtype=torch.float32, device=qn[0].device)
+    _req(out, "out", torch.float32)
+    j = 1 if n_mod > 1 else 0
+    check(_lib.load().xml_q2c_scores_fused(n_mod, _p(qn[0]), _p(cn[0]), _p(masks[0]), _p(qn[j]), _p(cn[j]),
+                                           _p(masks[j]), _p(out), out.stride(0), nq, nv, lpad, hidden, dt_of(qn[0]),
+                                           _stream()), "xml_q2c_scores_fused")
+    return out
+
+
 def topk_rows(scores, k, alpha=0.0, idx_in=None):
     """K8.  scores (rows, n) f32 -> (values (rows, k) f32 [exp(alpha*s) if alpha], indices (rows, k) int32)."""
     _req(scores, "scores", torch.float32)

@@ -109,7 +109,7 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
   hipStream_t st = (hipStream_t)stream;
   if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
   const bool dma_ok = ((size_t)hidden * dt_size(dt)) % 128 == 0;
-  const bool persist_ok = lpad == 128 && ((size_t)hidden * dt_size(dt)) % 64 == 0 && (size_t)hidden * dt_size(dt) >= 192;
+  const bool persist_ok = lpad == 128 && ((size_t)hidden * dt_size(dt)) % 128 == 0 && (size_t)hidden * dt_size(dt) >= 384;
   if ((g_q2c_variant == 0 || g_q2c_variant == 4) && persist_ok && !combine) {
     const void* q[2] = {qn, qn};
     const void* c[2] = {cn, cn};
@@ -152,7 +152,7 @@ extern "C" int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0,
   if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
   if (lpad % 16 || lpad > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
   const size_t kb = (size_t)hidden * dt_size(dt);
-  const bool persist_ok = lpad == 128 && kb % 64 == 0 && kb >= 192;
+  const bool persist_ok = lpad == 128 && kb % 128 == 0 && kb >= 384;
   if ((g_q2c_variant == 0 || g_q2c_variant == 4) && persist_ok) {
     const void* q[2] = {qn0, qn1};
     const void* c[2] = {cn0, cn1};

@@ -41,7 +41,25 @@ __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3
 
 // Specialised to lpad == 128 (one video per 128-column group -- the TVR shape): no per-column divisions, one
 // reduction per accumulator row.  Other clip paddings use the per-modality kernels (q2c_ring.hip / q2c256.hip).
-template <typename T>
+//
+// K-loop schedule ("one barrier per slice"; measured reason in profiles/r01_k6_notes.md: with two barriers per
+// 16-MFMA phase the waves spent 41 % of their cycles parked at barriers / waitcnts and issued 2.4 SALU per MFMA):
+//   slice g (32 K-elements; ring slot g & 3) is consumed as two 16-MFMA halves h0 (column tiles 0-3) and h1 (4-7);
+//   fragments are double-buffered in registers, so LDS reads always run under the other half's MFMAs:
+//
+//     read  fbH <- B[4..7](g)
+//     MFMA  h0(g):  acc[:,0..3] += fa x fbL
+//     s_waitcnt vmcnt(8)      my DMAs of slice g+1 have landed (slices g+2, g+3 may still fly)
+//     s_waitcnt lgkmcnt(0)    all my LDS reads of slice g have returned
+//     s_barrier               => slice g+1 is readable by everyone, slot g & 3 is free for everyone
+//     DMA   slice g+4 -> slot g & 3          (3 slices = 96 KiB in flight per CU)
+//     read  fa' <- A(g+1), fbL <- B[0..3](g+1)
+//     MFMA  h1(g):  acc[:,4..7] += fa x fbH
+//     fa <-> fa'
+//
+//   No wave-group stagger and no s_setprio: the two waves of a SIMD drift apart by themselves and keep the MFMA
+//   pipe busy from either wave's ready cluster.
+template <typename T, int ABL = 0>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
 __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
@@ -49,7 +67,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int RING_BYTES = 4 * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
   constexpr int STASH_OFF = RING_BYTES + 2048;    // 256 rows x 2 videos f32: modality-0 maxima of the current tile
-  constexpr int LEAD = 5;                         // odd: a segment can only end on the h = 0 issue slot
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -59,7 +76,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int xcd = blockIdx.x & 7;
   const int qt_off = (blockIdx.x >> 3) & 7, ct_off = blockIdx.x >> 6;   // position inside the 8 x 4 super-tile
   const int k_bytes = a.hidden * (int)sizeof(T);
-  const int n_units = 2 * (k_bytes / ROWB);
+  const int slices_per_seg = k_bytes / ROWB;      // even (k_bytes % 128 == 0)
   const int n_qgroups = (a.tq + 7) >> 3;
   const int cr = (((a.tc + 3) >> 2) + 7) >> 3;    // rounds per query group on one XCD
 
@@ -71,11 +88,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     } while (g < n_qgroups && !tile_valid(g, c));
   };
 
-  // ---- issue side (runs LEAD units ahead of the compute side) ----------------------------------------------
+  // ---- issue side (DMA stream, runs up to 3 slices ahead of the slice being computed) ---------------------
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const uint32_t lds_wave = lds0 + wave * 2048;
-  int i_g = 0, i_c = -1, i_mod = 0, i_unit = 0, i_seg = 0;
-  uint32_t i_gslice = 0, i_count = 0;
+  int i_g = 0, i_c = -1, i_mod = 0, i_slice = 0, i_seg = 0;
+  uint32_t i_gs = 0;                               // slices issued so far (global) -> ring slot
   uint32_t voff_a0 = 0, voff_a1 = 0, voff_b0 = 0, voff_b1 = 0;
   const char* sbase_a = nullptr;
   const char* sbase_b = nullptr;
@@ -105,32 +122,28 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       dma16s((uint32_t)mrow * 16, sbase_m, lds0 + MASK_OFF + (i_seg & 1) * 1024);
     }
   };
-  auto issue_unit = [&]() {       // fast path only: two DMA instructions
+  auto issue_slice = [&]() {      // 4 DMA instructions: this wave's 32 rows of A and of B
     if (i_g >= n_qgroups) return;
-    const int koff = (i_unit >> 1) * ROWB;
-    const uint32_t dst = lds_wave + (i_gslice & 3) * SLOT_BYTES + (i_unit & 1) * OPER_BYTES;
-    if (i_unit & 1) {
-      dma16s(voff_b0, sbase_b + koff, dst);
-      dma16s(voff_b1, sbase_b + koff, dst + 1024);
-      ++i_gslice;
-    } else {
+    const int koff = i_slice * ROWB;
+    const uint32_t dst = lds_wave + (i_gs & 3) * SLOT_BYTES;
+    if (ABL != 1 || i_gs < 4) {
       dma16s(voff_a0, sbase_a + koff, dst);
       dma16s(voff_a1, sbase_a + koff, dst + 1024);
+      dma16s(voff_b0, sbase_b + koff, dst + OPER_BYTES);
+      dma16s(voff_b1, sbase_b + koff, dst + OPER_BYTES + 1024);
     }
-    ++i_count;
-    ++i_unit;
-  };
-  auto advance_issue_segment = [&]() {   // called at ONE program point (after the h = 0 issue slot)
-    if (i_unit != n_units || i_g >= n_qgroups) return;
-    i_unit = 0;
-    ++i_seg;
-    bool new_tile = false;
-    if (++i_mod == a.n_mod) {
-      i_mod = 0;
-      advance(i_g, i_c);
-      new_tile = true;
+    ++i_gs;
+    if (++i_slice == slices_per_seg) {   // next segment: other modality of the tile, or the next tile
+      i_slice = 0;
+      ++i_seg;
+      bool new_tile = false;
+      if (++i_mod == a.n_mod) {
+        i_mod = 0;
+        advance(i_g, i_c);
+        new_tile = true;
+      }
+      if (i_g < n_qgroups) setup_issue_segment(new_tile);
     }
-    if (i_g < n_qgroups) setup_issue_segment(new_tile);
   };
 
   advance(i_g, i_c);
@@ -141,13 +154,23 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int a_off = (wm * 64 + fr) * ROWB + ((fg ^ swz4p(fr)) << 4);
   const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ swz4p(fr)) << 4);
   int c_g = i_g, c_c = i_c, c_mod = 0, c_seg = 0;
-  uint32_t c_gslice = 0;
-  const int slices_per_seg = n_units >> 1;
+  uint32_t c_gs = 0;                               // global index of the slice being computed
+  bool more = true;                                // a slice c_gs + 1 exists
 
-  for (int u = 0; u < LEAD; ++u) issue_unit();      // n_units >= 6: no segment end inside the prologue
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  // prologue: slices 0..3 in flight, slice 0 landed, first fragments in registers.  The issue side needs
+  // slices_per_seg >= 4 here (no segment end inside the first 3 issues is required; 4th may end a segment).
+  issue_slice(); issue_slice(); issue_slice(); issue_slice();
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
-  if (wave >= 4) __builtin_amdgcn_s_barrier();      // stagger the second wave group by one barrier interval
+
+  uint4 faA[4], faB[4], fbL[4], fbH[4];
+  {
+    const char* slot = smem;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) faA[m] = *reinterpret_cast<const uint4*>(slot + a_off + m * 16 * ROWB);
+#pragma unroll
+    for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(slot + b_off + n * 16 * ROWB);
+  }
 
   for (;;) {      // one iteration = one (tile, modality) segment
     f32x4 acc[4][8];
@@ -155,44 +178,54 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     for (int m = 0; m < 4; ++m)
 #pragma unroll
       for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
-    uint4 fa[4], fb[4];
-    for (int c_slice = 0; c_slice < slices_per_seg; ++c_slice) {
-      const char* slot = smem + (c_gslice & 3) * SLOT_BYTES;
-      // ---------------- phase h = 0 ----------------
+
+    auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4], bool last_of_stream_possible) {
+      const char* slot = smem + (c_gs & 3) * SLOT_BYTES;
 #pragma unroll
-      for (int m = 0; m < 4; ++m) fa[m] = *reinterpret_cast<const uint4*>(slot + a_off + m * 16 * ROWB);
-#pragma unroll
-      for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const uint4*>(slot + b_off + n * 16 * ROWB);
-      issue_unit();
-      advance_issue_segment();
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
+      for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_s_barrier();
-      // ---------------- phase h = 1 ----------------
-#pragma unroll
-      for (int n = 0; n < 4; ++n) fb[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
-      issue_unit();
-      ++c_gslice;
-      {   // the next slice (global units 2 c_gslice, 2 c_gslice + 1) must have landed before the next barrier
-        const int fly = (int)(i_count - (2 * c_gslice + 2));   // units issued beyond the ones needed next
-        if (fly >= 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else if (fly == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else if (fly == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        for (int n = 0; n < 4; ++n) {
+          if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbL[n].x), "v"(fc[m].w), "v"(fbL[n].w));
+          else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+        }
+      {   // slice c_gs + 1 must have landed (mine) before the barrier; later slices may stay in flight
+        const int fly = (int)(i_gs - (c_gs + 2));
+        if (fly >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (fly == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_s_setprio(1);
+      issue_slice();                                  // slice c_gs + 4 -> the slot just released
+      ++c_gs;
+      if (more) {
+        const char* nslot = smem + (c_gs & 3) * SLOT_BYTES;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
+      }
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
-        for (int n = 0; n < 4; ++n) Mma<T>::chunk(acc[m][n + 4], fa[m], fb[n]);
-      __builtin_amdgcn_s_setprio(0);
-      __builtin_amdgcn_s_barrier();
+        for (int n = 0; n < 4; ++n) {
+          if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbH[n].x), "v"(fc[m].w), "v"(fbH[n].w));
+          else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+        }
+    };
+
+    for (int c_slice = 0; c_slice < slices_per_seg; c_slice += 2) {
+      slice_step(faA, faB, false);
+      if (c_slice + 2 >= slices_per_seg) {            // the slice after the next one closes the segment:
+        // does a further segment exist?  (compute-side lookahead of the walk, scalar only)
+        int ng = c_g, nc = c_c;
+        bool has_next = c_mod + 1 < a.n_mod;
+        if (!has_next) { advance(ng, nc); has_next = ng < n_qgroups; }
+        more = has_next;
+      }
+      slice_step(faB, faA, true);
     }
     // ---- end of a (tile, modality) segment: mask_logits + max over the video's 128 clips, inside the wave -----
     {
@@ -235,13 +268,14 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       if (c_g >= n_qgroups) break;
     }
   }
-  if (wave < 4) __builtin_amdgcn_s_barrier();      // balance the stagger
 }
 
 template <typename T>
 static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
   const int lds = 4 * 2 * 256 * 64 + 2048 + 2048;
-  auto kern = q2c_persist_kernel<T>;
+  extern int g_q2c_ablation;
+  auto kern = g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
+                                                                                     : q2c_persist_kernel<T, 0>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
@@ -250,7 +284,8 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
 }
 
 // Requirements (checked by the caller, which otherwise uses the per-modality kernels): lpad == 128,
-// hidden * sizeof(T) a multiple of 64 bytes and >= 3 slices.
+// hidden * sizeof(T) a multiple of 128 bytes (an even number of 64-byte slices) and at least 6 slices:
+// the mask patch of segment s+2 is fetched 4 slices ahead and must not land before the epilogue of segment s.
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                             float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st) {
   Q2cPersistArgs a;

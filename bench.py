@@ -202,6 +202,11 @@ def main():
             st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti))
             timed("moment_k9", lambda: inf.hip_ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
 
+    traffic = None      # fabric/HBM bytes per K6 launch from the committed PMC passes (same command, same shape)
+    tpath = os.path.join(ROOT, "profiles", "r01_k6_traffic.json")
+    if world == 1 and args.workload == "c3" and os.path.isfile(tpath):
+        traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+
     res = None
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -213,7 +218,12 @@ def main():
                                    "top-200 moments" % (args.workload, ctx_mode, nq, nv, l, hidden),
                        "global_batch": nq, "parallelism": "corpus-shard x%d" % world, "videos_per_gpu": index.n_videos},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtname], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_TFLOPS[dtname], "traffic": None, "kernel": "q2c_scores_kernel",
+                         "frac": achieved / PEAK_TFLOPS[dtname], "traffic": traffic,
+                         "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
+                                         "profiles/r01_k6_traffic.json; algorithmic bytes = %.3g" % (
+                                             len(index.modalities) * (index.n_videos * index.lpad * hidden * 2.0
+                                                                      + nq * hidden * 2.0) + nq * index.n_videos * 4.0),
+                         "kernel": "q2c_persist_kernel",
                          "launches_timed": len(k6_ms), "avg_launch_ms": k6_avg_ms,
                          "flops_per_launch": flops_per_launch},
             "encode_videos_per_s": (hi - lo) * world / enc_s if enc_s > 0 else None,

@@ -75,6 +75,9 @@ def load():
         raise XmlHipError(
             "libxmlhip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(tvretrieval_amd/csrc/build.sh). The HIP extension is mandatory; there is no fallback." % LIB_PATH)
+    # PyTorch ships its own libamdhip64.so; it must be the first HIP runtime mapped into the process, otherwise
+    # libxmlhip.so binds /opt/rocm's copy and the two runtimes do not share streams / allocations (launches fail).
+    import torch  # noqa: F401
     try:
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:

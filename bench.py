@@ -117,6 +117,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU code path even with 1 rank (testing)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -159,7 +160,7 @@ def main():
 
     def step():
         with torch.no_grad():
-            if world == 1:
+            if world == 1 and not args.force_sharded:
                 return inf.vcmr_search(model, index, qf, qm)
             return xdist.sharded_vcmr_search(model, index, qf, qm)
 

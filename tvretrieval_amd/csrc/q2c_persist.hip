@@ -196,17 +196,17 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         else if (fly == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      issue_slice();                                  // slice c_gs + 4 -> the slot just released
+      __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0), as a builtin: hipcc must KNOW the fbH reads have
+      __builtin_amdgcn_s_barrier();                     // returned, or it waits for the reads issued below before h1
       ++c_gs;
-      if (more) {
+      if (more) {                                       // reads first: their latency hides under the DMA issue + h1
         const char* nslot = smem + (c_gs & 3) * SLOT_BYTES;
 #pragma unroll
         for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
 #pragma unroll
         for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
       }
+      issue_slice();                                    // slice c_gs + 3 -> the slot just released
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll

@@ -394,6 +394,22 @@ def test_moment_topk(ops, case):
     _check_moment_lists(sc, fl, ws[:, :n_out], wi[:, :n_out], l)
 
 
+def test_moment_topk_skipped_pairs_and_near_flat(ops):
+    """w == 0 marks pairs owned by another shard (never candidates); near-flat probabilities with slowly decaying
+    video weights make row maxima useless as a bound (the leading-pair bound + overflow refinement must work)."""
+    nq, k, l, n_out = 5, 100, 128, 200
+    g = torch.Generator().manual_seed(121)
+    st = torch.softmax(torch.randn(nq, k, l, generator=g) * 0.05, -1)
+    ed = torch.softmax(torch.randn(nq, k, l, generator=g) * 0.05, -1)
+    w, _ = torch.sort(torch.exp(20 * (0.2 + 0.01 * torch.rand(nq, k, generator=g))), dim=1, descending=True)
+    w[:, 1::3] = 0.0            # every third slot lives on another rank
+    w[0, 0] = 0.0
+    prod = torch.einsum("qvm,qv,qvn->qvmn", st, w, ed) * torch.from_numpy(O.min_max_length_mask(l, 2, 16))
+    ws, wi = torch.sort(prod.reshape(nq, -1), dim=1, descending=True)
+    sc, fl = ops.moment_topk(dev(st), dev(ed), dev(w), l, 2, 16, n_out)
+    _check_moment_lists(sc, fl, ws[:, :n_out], wi[:, :n_out], l)
+
+
 def test_moment_topk_flat_distribution_fallback(ops):
     """uniform probabilities: every candidate ties -> list overflow -> exact radix-select fallback."""
     nq, k, l, n_out = 2, 100, 128, 200

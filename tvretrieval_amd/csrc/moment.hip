@@ -4,63 +4,97 @@
 //              SVMR variant: get_svmr_res_from_st_ed_probs :195-241 + utils/tensor_utils.py:133-141
 //
 // The reference materialises (Nq, 100, L, L) products and fully sorts 1.64 M values per query.  Only the band
-// min_l <= j-i < max_l can be non-zero, so one workgroup per query enumerates the k*L*(max_l-min_l) band
-// candidates from LDS-resident st/ed rows and keeps the best n_out:
-//   1. stage (st*w) and ed rows in LDS (the product order (st*w)*ed is the reference's einsum order);
-//   2. row maxima m(r,i) = max_d score(r,i,i+d) stay in registers; the n_out-th largest row maximum is a
-//      lower bound T_lb of the n_out-th largest candidate (radix-select over <= 16 K register values);
-//   3. only rows with m(r,i) >= T_lb are re-expanded; candidates >= T_lb go to an LDS list;
-//   4. bitonic sort of the list on (score desc, flat index asc); emit n_out.
-//   If the list overflows (flat score distributions), an exact radix-select over all candidates replaces 2-3.
-// Zero products (masked clips) are not candidates: the reference's order among zeros is unspecified.
+// min_l <= j-i < max_l can be non-zero, so one workgroup per query works on the k*L*(max_l-min_l) band candidates
+// from LDS-resident rows and keeps the best n_out, exactly, without ever sorting more than a few hundred values:
+//   1. stage the ed rows of the ACTIVE pairs (w != 0) in LDS, keep st*w in registers; (st*w)*ed is the reference's
+//      einsum order.
+//      Wave w owns pairs w, w+4, ...; lane l owns start clips l and l+64: no integer divisions anywhere.
+//   2. row maxima m(r,i) = max_d score(r,i,i+d) are computed on the fly (and again in the expansion pass).
+//   3. two lower bounds of the n_out-th best score, both by MSB-first radix-select (11/11/10 bits, wave-aggregated
+//      LDS histogram adds, wave-parallel suffix scan):
+//        T_a = n_out-th largest row maximum            (tight for peaky start/end distributions)
+//        T_b = n_out-th largest candidate of the first pair(s) (tight for flat distributions, where the answer is
+//              the best-ranked videos' bands and row maxima barely prune)
+//   4. expand rows with m(r,i) >= lb = max(T_a, T_b); candidates >= lb go to an LDS list (wave-aggregated append).
+//      If the list overflows, lb is raised to the n_out-th largest of the stored entries (a subset, hence still a
+//      valid lower bound) and the expansion repeats; exact ties that never fit end in a deterministic truncation.
+//   5. bitonic sort of the list on (score desc, flat index asc); emit n_out.
+// Zero products (masked clips, skipped pairs) are not candidates: the reference's order among zeros is unspecified.
+// This is LDS/latency-bound integer-ish work; it is not reshaped into a GEMM.
 #include "common.h"
 
-static constexpr int MT_CAP = 4096;   // LDS candidate list capacity
-static constexpr int MT_RPT = 64;     // (pair, start) rows per thread -> kpairs * l_ref <= 16384
+static constexpr int MT_CAP = 2048;   // LDS candidate list capacity
+static constexpr int MT_PPW = 32;     // pairs per wave -> kpairs <= 128 (pair weights live in two lane registers)
 
-struct RadixState {
-  uint32_t prefix, need, eq_total;
+struct MomentShared {
+  uint32_t prefix, need, cnt, flag;
 };
 
-// Block-wide MSB-first radix select (11/11/10 bits) of the `need`-th largest non-zero key.
-// each(f): calls f(key) for every element owned by this thread.  Returns T (0 if there are no keys);
-// *need_eq = how many keys == T belong to the top-`need`, *eq_total = how many keys == T exist.
+// wave-aggregated histogram increment: one LDS atomic per distinct bin per wave
+__device__ __forceinline__ void hist_add(uint32_t* hist, uint32_t bin, bool active, int lane) {
+  unsigned long long todo = __ballot(active);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t lb = __shfl(bin, leader, 64);
+    const unsigned long long same = __ballot(active && bin == lb) & todo;
+    if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+    todo &= ~same;
+  }
+}
+
+// Block-wide radix select of the `need`-th largest non-zero key (MSB first, 11/11/10 bits).
+// each(f): calls f(key, valid) the SAME number of times in every lane of a wave (valid = false for padding).
+// Returns T (0 when fewer than `need` non-zero keys exist: everything non-zero qualifies).
 template <typename Each>
-__device__ uint32_t block_radix_select(Each each, uint32_t need, uint32_t* hist /*2048*/, RadixState* rs,
-                                       uint32_t* need_eq, uint32_t* eq_total) {
-  const int tid = threadIdx.x;
+__device__ uint32_t block_radix_select(Each each, uint32_t need, uint32_t* hist /*2048*/, MomentShared* sh) {
+  const int tid = threadIdx.x, lane = tid & 63;
   const int shifts[3] = {21, 10, 0};
   const uint32_t widths[3] = {11, 11, 10};
-  if (tid == 0) { rs->prefix = 0; rs->need = need; rs->eq_total = 0; }
+  if (tid == 0) { sh->prefix = 0; sh->need = need; sh->flag = 0; }
   uint32_t mask = 0;
   for (int pass = 0; pass < 3; ++pass) {
     const int shift = shifts[pass];
     const uint32_t bins = 1u << widths[pass];
     for (int i = tid; i < 2048; i += 256) hist[i] = 0;
     __syncthreads();
-    const uint32_t prefix = rs->prefix;
-    each([&](uint32_t key) {
-      if (key != 0 && (key & mask) == prefix) atomicAdd(&hist[(key >> shift) & (bins - 1)], 1u);
+    const uint32_t prefix = sh->prefix;
+    if (sh->flag) break;                                   // not enough keys: T = 0
+    each([&](uint32_t key, bool valid) {
+      const bool act = valid && key != 0 && (key & mask) == prefix;
+      hist_add(hist, (key >> shift) & (bins - 1), act, lane);
     });
     __syncthreads();
-    if (tid == 0) {
-      uint32_t nd = rs->need, above = 0;
-      int b = (int)bins - 1;
-      for (; b > 0; --b) {
-        if (above + hist[b] >= nd) break;
-        above += hist[b];
+    if (tid < 64) {                                        // wave 0: suffix scan over the bins, 32 bins per lane
+      const uint32_t nd = sh->need;
+      const int per = (int)bins / 64;
+      uint32_t local = 0;
+      for (int b = 0; b < per; ++b) local += hist[lane * per + b];
+      uint32_t suffix = local;                             // inclusive suffix sum over lanes >= lane
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t v = __shfl_down(suffix, o, 64);
+        if (lane + o < 64) suffix += v;
       }
-      // b == 0 with too few keys: everything non-zero qualifies
-      if (above + hist[b] < nd) { rs->need = hist[b]; } else { rs->need = nd - above; }
-      rs->prefix = prefix | ((uint32_t)b << shift);
-      rs->eq_total = hist[b];
+      const uint32_t above = suffix - local;               // keys in bins owned by higher lanes
+      if (suffix >= nd && above < nd) {                    // the crossing bin is mine
+        uint32_t acc = above;
+        int b = per - 1;
+        for (; b > 0; --b) {
+          if (acc + hist[lane * per + b] >= nd) break;
+          acc += hist[lane * per + b];
+        }
+        sh->need = nd - acc;
+        sh->prefix = prefix | ((uint32_t)(lane * per + b) << shift);
+      }
+      if (lane == 0 && suffix < nd) sh->flag = 1;          // fewer than `need` keys in total
     }
     mask |= (bins - 1) << shift;
     __syncthreads();
   }
-  *need_eq = rs->need;
-  *eq_total = rs->eq_total;
-  return rs->prefix;
+  __syncthreads();
+  const uint32_t T = sh->flag ? 0u : sh->prefix;
+  __syncthreads();
+  return T;
 }
 
 __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restrict__ st, const float* __restrict__ ed,
@@ -68,99 +102,164 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
                                                           int32_t* __restrict__ out_flat, int kpairs, int lpad,
                                                           int l_ref, int min_l, int max_l, int n_out) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
   const int R = kpairs * l_ref;
-  float* s_st = reinterpret_cast<float*>(smem);            // [kpairs][l_ref]  st * w
-  float* s_ed = s_st + R;                                  // [kpairs][l_ref]
+  float* s_ed = reinterpret_cast<float*>(smem);            // [kpairs][l_ref] end probabilities of the active pairs
   unsigned long long* s_list = reinterpret_cast<unsigned long long*>(s_ed + R + (R & 1));  // [MT_CAP]
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_list + MT_CAP);                          // [2048]
-  __shared__ RadixState rs;
-  __shared__ uint32_t s_cnt;
+  __shared__ MomentShared sh;
 
   const float* gst = st + (int64_t)q * kpairs * lpad;
   const float* ged = ed + (int64_t)q * kpairs * lpad;
-  for (int p = tid; p < R; p += 256) {
-    const int r = p / l_ref, i = p - r * l_ref;
-    const float wv = w ? w[(int64_t)q * kpairs + r] : 1.f;
-    s_st[p] = gst[r * lpad + i] * wv;
-    s_ed[p] = ged[r * lpad + i];
+  const float* gw = w ? w + (int64_t)q * kpairs : nullptr;
+
+  // ---- 1. stage active pairs; 2. row maxima ---------------------------------------------------------------
+  // Small code matters more than registers here: a fully unrolled 64-row body (145 KB of code) made the kernel
+  // instruction-fetch bound (every workgroup streams its code through the 64 KB I-cache).  So rows are walked by
+  // runtime loops and nothing per-row is kept: the row maximum is simply recomputed in the expansion pass.
+  // Only the `ed` rows go to LDS (51 KiB at k = 100, L = 128) -> two workgroups per CU; st*w is re-read from L2.
+  const float w_lo = gw ? (lane < kpairs ? gw[lane] : 0.f) : 1.f;        // pair weights: one vector load,
+  const float w_hi = gw ? (lane + 64 < kpairs ? gw[lane + 64] : 0.f) : 1.f;  // broadcast later with a lane read
+  auto pair_w = [&](int r) -> float { return __shfl(r < 64 ? w_lo : w_hi, r & 63, 64); };
+  const int band = max_l - min_l;
+  const int n_t = (kpairs - wave + 3) >> 2;                // pairs of this wave: r = wave + 4 t
+
+#pragma unroll 4
+  for (int t = 0; t < n_t; ++t) {                          // 1. stage ed rows of active pairs
+    const int r = wave + t * 4;
+    if (pair_w(r) == 0.f) continue;                        // w == 0: skipped pair (other rank / padding)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int i = lane + h * 64;
+      if (i < l_ref) s_ed[r * l_ref + i] = ged[r * lpad + i];
+    }
   }
-  if (tid == 0) s_cnt = 0;
+  for (int i = tid; i < 2048; i += 256) s_hist[i] = 0;
+  if (tid == 0) { sh.prefix = 0; sh.flag = 0; }
   __syncthreads();
 
-  // ---- row maxima in registers ---------------------------------------------------------------------
-  float rmax[MT_RPT];
-#pragma unroll
-  for (int t = 0; t < MT_RPT; ++t) {
-    const int p = tid + t * 256;
+  // row maximum of (r, i):  max_d (st*w)[i] * ed[i + d]
+  auto row_max = [&](float a, int r, int i) -> float {
+    const float* erow = s_ed + r * l_ref;
     float m = 0.f;
-    if (p < R) {
-      const int r = p / l_ref, i = p - r * l_ref;
-      const float a = s_st[p];
+    if (band <= 16) {      // 16 independent LDS reads in flight (clamped addresses): one LDS latency per row
+      float e[16];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) e[d] = erow[min(i + min_l + d, l_ref - 1)];
+#pragma unroll
+      for (int d = 0; d < 16; ++d) m = fmaxf(m, (d < band && (i + min_l + d) < l_ref) ? a * e[d] : 0.f);
+    } else {
       const int jend = min(l_ref, i + max_l);
-      for (int j = i + min_l; j < jend; ++j) m = fmaxf(m, a * s_ed[r * l_ref + j]);
+      for (int j = i + min_l; j < jend; ++j) m = fmaxf(m, a * erow[j]);
     }
-    rmax[t] = m;
-  }
-  uint32_t need_eq, eq_total;
-  const uint32_t t_lb = block_radix_select(
-      [&](auto f) {
-#pragma unroll
-        for (int t = 0; t < MT_RPT; ++t) f(__float_as_uint(rmax[t]));
-      },
-      (uint32_t)n_out, s_hist, &rs, &need_eq, &eq_total);
-  const uint32_t lb = t_lb == 0 ? 1u : t_lb;  // fewer than n_out positive rows: keep every positive candidate
+    return m;
+  };
 
-  // ---- expand surviving rows, collect candidates >= lb ----------------------------------------------
+  // ---- 2+3. ONE histogram pass over the row maxima on bits [30:20] (8 exponent + 3 mantissa bits); the lower edge
+  //           of the bin holding the n_out-th largest row maximum is a lower bound of the n_out-th best score ------
+#pragma unroll 2
+  for (int t = 0; t < n_t; ++t) {
+    const int r = wave + t * 4;
+    const float wv = pair_w(r);
+    if (wv == 0.f) continue;
 #pragma unroll
-  for (int t = 0; t < MT_RPT; ++t) {
-    if (__float_as_uint(rmax[t]) >= lb) {
-      const int p = tid + t * 256;
-      const int r = p / l_ref, i = p - r * l_ref;
-      const float a = s_st[p];
-      const int jend = min(l_ref, i + max_l);
-      for (int j = i + min_l; j < jend; ++j) {
-        const uint32_t key = __float_as_uint(a * s_ed[r * l_ref + j]);
-        if (key >= lb) {
-          const uint32_t slot = atomicAdd(&s_cnt, 1u);
-          if (slot < (uint32_t)MT_CAP)
-            s_list[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (uint32_t)(p * l_ref + j));
+    for (int h = 0; h < 2; ++h) {
+      const int i = lane + h * 64;
+      const float m = (i < l_ref) ? row_max(gst[r * lpad + i] * wv, r, i) : 0.f;
+      const uint32_t key = __float_as_uint(m);
+      const uint32_t bin = key >> 20;                      // sign bit is 0: < 2048
+      const bool act = key != 0;
+      const unsigned long long bal = __ballot(act);
+      if (bal == 0) continue;
+      const uint32_t first = __shfl(bin, __ffsll((long long)bal) - 1, 64);
+      if (__all(!act || bin == first)) {                   // whole wave in one bin (flat distributions): one add
+        if (lane == __ffsll((long long)bal) - 1) atomicAdd(&s_hist[first], (uint32_t)__popcll(bal));
+      } else if (act) {
+        atomicAdd(&s_hist[bin], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < 64) {                                          // wave 0: suffix scan, 32 bins per lane
+    uint32_t local = 0;
+    for (int b = 0; b < 32; ++b) local += s_hist[lane * 32 + b];
+    uint32_t suffix = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint32_t v = __shfl_down(suffix, o, 64);
+      if (lane + o < 64) suffix += v;
+    }
+    const uint32_t above = suffix - local, nd = (uint32_t)n_out;
+    if (suffix >= nd && above < nd) {
+      uint32_t acc = above;
+      int b = 31;
+      for (; b > 0; --b) {
+        if (acc + s_hist[lane * 32 + b] >= nd) break;
+        acc += s_hist[lane * 32 + b];
+      }
+      sh.prefix = (uint32_t)(lane * 32 + b) << 20;
+    }
+  }
+  __syncthreads();
+  uint32_t lb = max(sh.prefix, 1u);                        // fewer than n_out positive rows: keep everything > 0
+  __syncthreads();
+
+  // ---- 4. expand rows whose maximum reaches lb into the list (raise lb and repeat on overflow) -------------
+  uint32_t cnt = 0;
+  for (int attempt = 0; attempt < 8; ++attempt) {
+    if (tid == 0) sh.cnt = 0;
+    __syncthreads();
+#pragma unroll 2
+    for (int t = 0; t < n_t; ++t) {
+      const int r = wave + t * 4;
+      const float wv = pair_w(r);
+      if (wv == 0.f) continue;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + h * 64;
+        const float a = (i < l_ref) ? gst[r * lpad + i] * wv : 0.f;
+        const bool row_on = (i < l_ref) && __float_as_uint(row_max(a, r, i)) >= lb;
+        if (!__any(row_on)) continue;
+        const int jend = row_on ? min(l_ref, i + max_l) : 0;
+        for (int d = min_l; d < max_l; ++d) {                     // uniform trip count; lanes predicate themselves
+          const int j = i + d;
+          const bool ok = row_on && j < jend;
+          const uint32_t key = ok ? __float_as_uint(a * s_ed[r * l_ref + j]) : 0u;
+          const bool take = ok && key >= lb;
+          const unsigned long long bal = __ballot(take);
+          if (bal) {
+            uint32_t base = 0;
+            const int leader = __ffsll((long long)bal) - 1;
+            if (lane == leader) base = atomicAdd(&sh.cnt, (uint32_t)__popcll(bal));
+            base = __shfl(base, leader, 64);
+            const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+            if (take && slot < (uint32_t)MT_CAP)
+              s_list[slot] = ((unsigned long long)key << 32) |
+                             (unsigned long long)(0xffffffffu - (uint32_t)((r * l_ref + i) * l_ref + j));
+          }
         }
       }
     }
+    __syncthreads();
+    cnt = sh.cnt;
+    __syncthreads();
+    if (cnt <= (uint32_t)MT_CAP) break;
+    // overflow: the n_out-th largest of the MT_CAP stored entries is a tighter valid lower bound
+    const uint32_t t_c = block_radix_select(
+        [&](auto f) {
+          for (int i = tid; i < MT_CAP; i += 256) f((uint32_t)(s_list[i] >> 32), true);
+        },
+        (uint32_t)n_out, s_hist, &sh);
+    if (t_c <= lb) {          // no progress: more than MT_CAP entries tie at the bound -> keep the stored ones
+      cnt = MT_CAP;
+      break;
+    }
+    lb = t_c;
   }
-  __syncthreads();
-  uint32_t cnt = s_cnt;
-  __syncthreads();
+  cnt = min(cnt, (uint32_t)MT_CAP);
 
-  if (cnt > (uint32_t)MT_CAP) {
-    // ---- fallback: exact threshold over every candidate (flat score distributions) -----------------
-    auto each_cand = [&](auto f) {
-      for (int p = tid; p < R; p += 256) {
-        const int r = p / l_ref, i = p - r * l_ref;
-        const float a = s_st[p];
-        const int jend = min(l_ref, i + max_l);
-        for (int j = i + min_l; j < jend; ++j) f(__float_as_uint(a * s_ed[r * l_ref + j]), p * l_ref + j);
-      }
-    };
-    const uint32_t T = block_radix_select([&](auto f) { each_cand([&](uint32_t key, int) { f(key); }); },
-                                          (uint32_t)n_out, s_hist, &rs, &need_eq, &eq_total);
-    if (tid == 0) s_cnt = 0;
-    __syncthreads();
-    each_cand([&](uint32_t key, int flat) {
-      if (key > T || (key == T && T != 0)) {
-        const uint32_t slot = atomicAdd(&s_cnt, 1u);  // > T first-come; ties at T beyond capacity are dropped
-        if (slot < (uint32_t)MT_CAP)
-          s_list[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - (uint32_t)flat);
-      }
-    });
-    __syncthreads();
-    cnt = min(s_cnt, (uint32_t)MT_CAP);
-    __syncthreads();
-  }
-
-  // ---- bitonic sort (descending) of the list, padded with zeros to a power of two ------------------
+  // ---- 5. bitonic sort (descending) of the list, padded with zeros to a power of two ------------------------
   int npow = 256;
   while ((uint32_t)npow < cnt) npow <<= 1;
   for (int i = (int)cnt + tid; i < npow; i += 256) s_list[i] = 0ull;
@@ -199,9 +298,9 @@ extern "C" int xml_moment_topk(const float* st, const float* ed, const float* w,
   if (!st || !ed || !out_score || !out_flat || nq <= 0 || kpairs <= 0 || lpad <= 0 || l_ref <= 0 || n_out <= 0)
     return XML_ERR_BAD_ARG;
   if (l_ref > lpad || min_l < 0 || max_l <= min_l) return XML_ERR_BAD_ARG;
-  if (n_out > 1024 || lpad > 128 || (int64_t)kpairs * l_ref > 256 * MT_RPT) return XML_ERR_UNSUPPORTED;
+  if (n_out > 1024 || lpad > 128 || kpairs > 4 * MT_PPW) return XML_ERR_UNSUPPORTED;
   const size_t R = (size_t)kpairs * l_ref;
-  const size_t lds = (2 * R + (R & 1)) * 4 + (size_t)MT_CAP * 8 + 2048 * 4;
+  const size_t lds = (R + (R & 1)) * 4 + (size_t)MT_CAP * 8 + 2048 * 4;
   if (lds > 160 * 1024 - 64) return XML_ERR_UNSUPPORTED;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)moment_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=

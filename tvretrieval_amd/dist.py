@@ -101,7 +101,8 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
     own = (top_gid >= lo) & (top_gid < hi)
     pair_local = torch.where(own, top_gid - lo, torch.full_like(top_gid, -1)).contiguous()
     st, ed = inf.stage_span_probs(model, index, qvec, pair_local, ops)
-    loc_fs, loc_fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
+    w_local = torch.where(own, top_w, torch.zeros_like(top_w)).contiguous()   # w == 0 marks slots owned elsewhere:
+    loc_fs, loc_fi = ops.moment_topk(st, ed, w_local, index.l_ref, min_pred_l, max_pred_l, max_before_nms)  # skipped
     all_fs = _all_gather_cat(loc_fs, group, world)
     all_fi = _all_gather_cat(loc_fi, group, world)
     if world == 1:

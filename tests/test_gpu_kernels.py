@@ -51,7 +51,8 @@ def dev(t, dtype=None):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(5, 24, 40), (300, 136, 96), (257, 768, 3072), (128, 128, 64)])
+@pytest.mark.parametrize("shape", [(5, 24, 40), (300, 136, 96), (257, 768, 3072), (128, 128, 64), (1000, 2304, 768),
+                                   (513, 200, 128), (256, 128, 64)])
 def test_linear(ops, dtype, shape):
     m, n, k = shape
     x, w, b = rnd(m, k, seed=1), rnd(n, k, seed=2, scale=k ** -0.5), rnd(n, seed=3)

@@ -1,0 +1,184 @@
+// Projection GEMM on the 256 x 256 LDS-DMA ring (the K-loop schedule of q2c_persist.hip, one tile per workgroup):
+//   out[m][n] = act(A[m] . W[n] + bias[n]) + addend        A (M, K), W (N, K) both K-contiguous
+// Used for the encoder projections (K1, QKV, output dense) when K * sizeof(T) is a multiple of 128 bytes and
+// M >= 256; the 128 x 128 register-staged kernel (linear.hip) covers every other shape.
+#include "common.h"
+#include "internal.h"
+
+__device__ __forceinline__ void g256_dma(uint32_t voff, const char* sbase, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+__device__ __forceinline__ int g256_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+template <typename T, typename OutT, typename AddT>
+__global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W,
+                                                         const float* __restrict__ bias,
+                                                         const AddT* __restrict__ addend, OutT* __restrict__ out,
+                                                         int64_t M, int N, int K, int relu, int add_mode, int seq_len,
+                                                         int tm, int tn) {
+  constexpr int ROWB = 64;
+  constexpr int OPER_BYTES = 256 * ROWB;
+  constexpr int SLOT_BYTES = 2 * OPER_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  // XCD-aware tile order: 8 (M tiles) x 4 (N tiles) super-tiles per XCD
+  const int b = blockIdx.x;
+  const int xcd = b & 7, local = b >> 3;
+  const int sup = (local >> 5) * 8 + xcd;
+  const int w32 = local & 31;
+  const int sm = (tm + 7) >> 3;
+  const int mt_ = (sup % sm) * 8 + (w32 & 7);
+  const int nt_ = (sup / sm) * 4 + (w32 >> 3);
+  if (mt_ >= tm || nt_ >= tn) return;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int64_t m0 = (int64_t)mt_ * 256;
+  const int n0 = nt_ * 256;
+  const int k_bytes = K * (int)sizeof(T);
+  const int n_slices = k_bytes / ROWB;
+
+  uint32_t voff_a[2], voff_b[2];
+  {
+    const int rsub = lane >> 2, pslot = lane & 3;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = (wave * 2 + i) * 16 + rsub;
+      const int slot = pslot ^ g256_swz(row);
+      voff_a[i] = (uint32_t)((m0 + row < M) ? row : 0) * k_bytes + slot * 16;
+      voff_b[i] = (uint32_t)((n0 + row < N) ? row : 0) * k_bytes + slot * 16;
+    }
+  }
+  const char* sbase_a = reinterpret_cast<const char*>(A) + m0 * k_bytes;
+  const char* sbase_b = reinterpret_cast<const char*>(W) + (int64_t)n0 * k_bytes;
+  const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 2048;
+  int i_slice = 0;
+  auto issue_slice = [&]() {
+    if (i_slice >= n_slices) return;
+    const int koff = i_slice * ROWB;
+    const uint32_t dst = lds_wave + (i_slice & 3) * SLOT_BYTES;
+    g256_dma(voff_a[0], sbase_a + koff, dst);
+    g256_dma(voff_a[1], sbase_a + koff, dst + 1024);
+    g256_dma(voff_b[0], sbase_b + koff, dst + OPER_BYTES);
+    g256_dma(voff_b[1], sbase_b + koff, dst + OPER_BYTES + 1024);
+    ++i_slice;
+  };
+
+  const int a_off = (wm * 64 + fr) * ROWB + ((fg ^ g256_swz(fr)) << 4);
+  const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ g256_swz(fr)) << 4);
+
+  issue_slice(); issue_slice(); issue_slice(); issue_slice();
+  {
+    const int fly = i_slice - 1;      // slices allowed in flight after slice 0 has landed
+    if (fly >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    else if (fly == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (fly == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __builtin_amdgcn_s_barrier();
+
+  f32x4 acc[4][8];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  uint4 faA[4], faB[4], fbL[4], fbH[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) faA[m] = *reinterpret_cast<const uint4*>(smem + a_off + m * 16 * ROWB);
+#pragma unroll
+  for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(smem + b_off + n * 16 * ROWB);
+
+  int c_slice = 0;
+  auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4]) {
+    const char* slot = smem + (c_slice & 3) * SLOT_BYTES;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+    {
+      const int fly = i_slice - (c_slice + 2);
+      if (fly >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else if (fly == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): all reads of this slot have returned
+    __builtin_amdgcn_s_barrier();
+    ++c_slice;
+    if (c_slice < n_slices) {
+      const char* nslot = smem + (c_slice & 3) * SLOT_BYTES;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
+    }
+    issue_slice();
+#pragma unroll
+    for (int m = 0; m < 4; ++m)
+#pragma unroll
+      for (int n = 0; n < 4; ++n) Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+  };
+  for (int s = 0; s < n_slices; s += 2) {
+    slice_step(faA, faB);
+    slice_step(faB, faA);
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------------
+#pragma unroll
+  for (int nt = 0; nt < 8; ++nt) {
+    const int n = n0 + wn * 128 + nt * 16 + fr;
+    if (n >= N) continue;
+    const float bv = bias ? bias[n] : 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int64_t m = m0 + wm * 64 + mt * 16 + fg * 4 + r;
+        if (m >= M) continue;
+        float v = acc[mt][nt][r] + bv;
+        if (relu) v = fmaxf(v, 0.f);
+        if (add_mode == 1) v += DT<AddT>::ld(addend + (int64_t)(m % seq_len) * N + n);
+        else if (add_mode == 2) v += DT<AddT>::ld(addend + m * N + n);
+        DT<OutT>::st(out + m * N + n, v);
+      }
+    }
+  }
+}
+
+template <typename T, typename OutT, typename AddT>
+static int launch_gemm256(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
+                          int N, int K, int relu, int add_mode, int seq_len, hipStream_t st) {
+  const int tm = cdiv(M, 256), tn = cdiv(N, 256);
+  const int64_t nsup = (int64_t)((tm + 7) / 8) * ((tn + 3) / 4);
+  const unsigned grid = (unsigned)(((nsup + 7) / 8) * 8 * 32);
+  const int lds = 4 * 2 * 256 * 64;
+  auto kern = gemm256_kernel<T, OutT, AddT>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    return XML_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const T*)A, (const T*)W, bias, (const AddT*)addend,
+                     (OutT*)out, M, N, K, relu, add_mode, seq_len, tm, tn);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+bool xmli_gemm256_eligible(int64_t M, int N, int K, int dt) {
+  const size_t kb = (size_t)K * dt_size(dt);
+  return M >= 256 && N >= 128 && kb % 128 == 0 && kb >= 256;
+}
+
+int xmli_gemm256(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
+                 int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st) {
+  if (dt == XML_F32)
+    return launch_gemm256<float, float, float>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+  if (out_f32)
+    return launch_gemm256<bf16_t, float, bf16_t>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+  return launch_gemm256<bf16_t, bf16_t, bf16_t>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+}

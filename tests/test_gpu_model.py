@@ -134,7 +134,16 @@ def test_golden_pipeline_fp32(name):
         ctx = inf.compute_context_info(m, ds, opt)
         for k in ["video_feat1", "video_feat2", "video_mask", "sub_feat1", "sub_feat2", "sub_mask"]:
             if ("ctx/" + k) in d:
-                close("ctx " + k, ctx[k], d["ctx/" + k], 2e-4)
+                want = d["ctx/" + k]
+                if want.ndim == 3:
+                    # valid clips: tight.  Padded clips of cross-attended streams see (score - 10000) in fp32, i.e.
+                    # scores quantised to 2^-10 in the reference as well as here: compare those at 1e-3.
+                    valid = d["ctx/" + k.split("_")[0] + "_mask"][..., None] > 0
+                    got = ctx[k].float().cpu().numpy()
+                    close("ctx " + k + " (valid clips)", np.where(valid, got, 0), np.where(valid, want, 0), 2e-4)
+                    close("ctx " + k + " (padded clips)", np.where(valid, 0, got), np.where(valid, 0, want), 1e-3)
+                else:
+                    close("ctx " + k, ctx[k], want, 0)
         res = inf.compute_query2ctx_info(m, ds, opt, ctx, max_before_nms=o["max_before_nms"],
                                          max_n_videos=o["max_vcmr_video"], tasks=("SVMR", "VCMR", "VR"))
     for task in ("VR", "VCMR", "SVMR"):

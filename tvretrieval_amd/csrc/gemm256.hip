@@ -131,25 +131,73 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
     slice_step(faB, faA);
   }
 
-  // ---- epilogue ------------------------------------------------------------------------------------------
+  // ---- epilogue through LDS: 16-byte coalesced stores --------------------------------------------------------
+  // An MFMA accumulator holds 4 rows x 1 column per lane, so direct stores are 2- or 4-byte pieces (32-64 B
+  // segments).  Each wave instead parks 32 rows x 128 columns of f32 in its private 16.5 KiB patch of the (now idle)
+  // ring and re-reads it row-major: lane l then owns 8 consecutive columns of one row -> 16 B (bf16) / 2 x 16 B
+  // (f32) stores, 256-512 contiguous bytes per row, with bias / ReLU / addend applied on the way out.
+  __syncthreads();                                  // every wave is done reading the ring
+  constexpr int PLD = 132;                          // padded patch row (floats): conflict-free column writes
+  float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PLD);
+  const int orow = lane >> 4, ocol = (lane & 15) * 8;
+  const int ncol0 = n0 + wn * 128 + ocol;
+  float bv[8];
 #pragma unroll
-  for (int nt = 0; nt < 8; ++nt) {
-    const int n = n0 + wn * 128 + nt * 16 + fr;
-    if (n >= N) continue;
-    const float bv = bias ? bias[n] : 0.f;
+  for (int j = 0; j < 8; ++j) bv[j] = (bias && ncol0 + j < N) ? bias[ncol0 + j] : 0.f;
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+  for (int half = 0; half < 2; ++half) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int64_t m = m0 + wm * 64 + mt * 16 + fg * 4 + r;
-        if (m >= M) continue;
-        float v = acc[mt][nt][r] + bv;
-        if (relu) v = fmaxf(v, 0.f);
-        if (add_mode == 1) v += DT<AddT>::ld(addend + (int64_t)(m % seq_len) * N + n);
-        else if (add_mode == 2) v += DT<AddT>::ld(addend + m * N + n);
-        DT<OutT>::st(out + m * N + n, v);
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) patch[(mt * 16 + fg * 4 + r) * PLD + nt * 16 + fr] = acc[half * 2 + mt][nt][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int prow = it * 4 + orow;               // 0..31
+      const int64_t m = m0 + wm * 64 + half * 32 + prow;
+      const float4 v0 = *reinterpret_cast<const float4*>(patch + prow * PLD + ocol);
+      const float4 v1 = *reinterpret_cast<const float4*>(patch + prow * PLD + ocol + 4);
+      float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      if (m >= M) continue;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        v[j] += bv[j];
+        if (relu) v[j] = fmaxf(v[j], 0.f);
+      }
+      if (ncol0 + 8 <= N && (N & 7) == 0) {         // full 8-column group, 16-byte aligned rows
+        if (add_mode) {
+          const int64_t arow = add_mode == 1 ? (m % seq_len) : m;
+          float av[8];
+          if (sizeof(AddT) == 2) {
+            unpack16<bf16_t>(ld_global16(addend + arow * N + ncol0), av);
+          } else {
+            unpack16<float>(ld_global16(addend + arow * N + ncol0), av);
+            unpack16<float>(ld_global16(addend + arow * N + ncol0 + 4), av + 4);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] += av[j];
+        }
+        if (sizeof(OutT) == 2) {
+          st_global16(out + m * N + ncol0, pack16<bf16_t>(v));
+        } else {
+          st_global16(out + m * N + ncol0, pack16<float>(v));
+          st_global16(out + m * N + ncol0 + 4, pack16<float>(v + 4));
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const int n = ncol0 + j;
+          if (n >= N) continue;
+          float x = v[j];
+          if (add_mode == 1) x += DT<AddT>::ld(addend + (int64_t)(m % seq_len) * N + n);
+          else if (add_mode == 2) x += DT<AddT>::ld(addend + m * N + n);
+          DT<OutT>::st(out + m * N + n, x);
+        }
       }
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -159,7 +207,7 @@ static int launch_gemm256(const void* A, const void* W, const float* bias, const
   const int tm = cdiv(M, 256), tn = cdiv(N, 256);
   const int64_t nsup = (int64_t)((tm + 7) / 8) * ((tn + 3) / 4);
   const unsigned grid = (unsigned)(((nsup + 7) / 8) * 8 * 32);
-  const int lds = 4 * 2 * 256 * 64;
+  const int lds = 8 * 32 * 132 * 4;     // epilogue patches (135 168 B) >= the 4 x 32 KiB ring
   auto kern = gemm256_kernel<T, OutT, AddT>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;

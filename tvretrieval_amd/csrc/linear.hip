@@ -101,19 +101,44 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const InT* __restric
   if (row >= rows) return;
   const InT* pa = a + row * d;
   const BT* pb = b ? b + row * d : nullptr;
-  float s = 0.f;
-  for (int i = lane; i < d; i += 64) s += DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f);
-  const float mean = wave_sum(s) / (float)d;
-  float v = 0.f;
-  for (int i = lane; i < d; i += 64) {
-    const float x = DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f) - mean;
-    v += x * x;
-  }
-  const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
   OutT* py = y + row * ld_out;
-  for (int i = lane; i < d; i += 64) {
-    const float x = DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f);
-    DT<OutT>::st(py + i, (x - mean) * rstd * g[i] + beta[i]);
+  if (d <= 64 * 16) {
+    // the row stays in registers (<= 16 values per lane): one read of the inputs instead of three
+    float x[16];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + k * 64;
+      x[k] = (i < d) ? DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f) : 0.f;
+      s += x[k];
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float c = (lane + k * 64 < d) ? x[k] - mean : 0.f;
+      v += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + k * 64;
+      if (i < d) DT<OutT>::st(py + i, (x[k] - mean) * rstd * g[i] + beta[i]);
+    }
+  } else {
+    float s = 0.f;
+    for (int i = lane; i < d; i += 64) s += DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f);
+    const float mean = wave_sum(s) / (float)d;
+    float v = 0.f;
+    for (int i = lane; i < d; i += 64) {
+      const float x = DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f) - mean;
+      v += x * x;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+    for (int i = lane; i < d; i += 64) {
+      const float x = DT<InT>::ld(pa + i) + (pb ? DT<BT>::ld(pb + i) : 0.f);
+      DT<OutT>::st(py + i, (x - mean) * rstd * g[i] + beta[i]);
+    }
   }
   for (int i = d + lane; i < ld_out; i += 64) DT<OutT>::st(py + i, 0.f);  // zero K padding
 }

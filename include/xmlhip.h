@@ -202,6 +202,20 @@ int xml_moment_topk(const float* st, const float* ed, const float* w, float* out
 int xml_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta,
                       void* y, int64_t rows, int d, int dt, xml_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * HOST post-processing ("next" row 8f-1; pointers are HOST memory): greedy temporal NMS.
+ *   xml_nms_vcmr_host = filter_vcmr_by_nms (baselines/clip_alignment_with_language/inference.py:189-225):
+ *     first max_before predictions, grouped by video in order of appearance, NMS per video
+ *     (temporal_non_maximum_suppression, utils/temporal_nms.py:25-74, IoU over the hull, keep while IoU <= thd),
+ *     merged, stable-sorted by score, truncated to max_after.
+ *   xml_nms_svmr_host = post_processing_svmr_nms (:247-265) for one query.
+ *   out_index receives indices into the input arrays in output order; *n_out their number.
+ * --------------------------------------------------------------------------------------------- */
+int xml_nms_vcmr_host(const int64_t* vid, const double* st, const double* ed, const double* score, int n,
+                      double thd, int max_before, int max_after, int32_t* out_index, int32_t* n_out);
+int xml_nms_svmr_host(const double* st, const double* ed, const double* score, int n, double thd,
+                      int max_before, int max_after, int32_t* out_index, int32_t* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -260,3 +260,53 @@ def test_search_vs_oracle_fp32(ctx_mode, hidden):
         agree = (fi[q] == wfi[q]).mean()
         assert agree > 0.9, ("moment order", q, agree)
         assert set(fi[q][:100].tolist()) <= set(wfi[q].tolist()) | {-1}
+
+
+def test_svmr_only_external_vr_and_eval_epoch(tmp_path):
+    """"next" rows 8f-1/2/4 end to end on the golden pipeline fixture: SVMR-only path == the SVMR list of the full
+    run, external-VR re-ranking fed with this model's own VR output reproduces its VCMR list, eval_epoch runs NMS
+    + evaluator on top."""
+    import argparse
+    import copy
+    from tvretrieval_amd import inference as inf
+    d, cfg, sd = load_golden("pipeline_video_sub_h128")
+    o = json.loads(str(d["opt"]))
+    m = build_model(cfg, sd)
+    ds = GoldenDataset(d, m.use_video, m.use_sub)
+    opt = argparse.Namespace(eval_context_bsz=o["eval_context_bsz"], eval_query_bsz=o["eval_query_bsz"],
+                             device=torch.device(DEV), q2c_alpha=o["q2c_alpha"], min_pred_l=o["min_pred_l"],
+                             max_pred_l=o["max_pred_l"], clip_length=o["clip_length"], debug=False,
+                             external_inference_vr_res_path=None, max_ctx_l=cfg["max_ctx_l"],
+                             max_before_nms=o["max_before_nms"], max_vcmr_video=o["max_vcmr_video"], nms_thd=o["nms_thd"],
+                             dset_name="tvr")
+    with torch.no_grad():
+        ctx = inf.compute_context_info(m, ds, opt)
+        full = inf.compute_query2ctx_info(m, ds, opt, ctx, max_before_nms=o["max_before_nms"],
+                                          max_n_videos=o["max_vcmr_video"], tasks=("SVMR", "VCMR", "VR"))
+        svmr = inf.compute_query2ctx_info_svmr_only(m, ds, opt, ctx, max_before_nms=o["max_before_nms"])
+        assert svmr["SVMR"] == full["SVMR"]
+        _compare_lists(svmr["SVMR"], d["res/SVMR"], "SVMR-only")
+        # external VR: cosine-like scores s with exp(alpha*s) == this model's weights
+        ext = dict(video2idx=ds.video2idx, VR=copy.deepcopy(full["VR"]))
+        for e in ext["VR"]:
+            for p in e["predictions"]:
+                p[3] = float(np.log(p[3]) / o["q2c_alpha"])
+        path = str(tmp_path / "ext_vr.json")
+        json.dump(ext, open(path, "w"))
+        opt.external_inference_vr_res_path = path
+        rer = inf.compute_query2ctx_info(m, ds, opt, ctx, max_before_nms=o["max_before_nms"],
+                                         max_n_videos=o["max_vcmr_video"], tasks=("VCMR", "VR"))
+        opt.external_inference_vr_res_path = None
+        for a, b in zip(rer["VCMR"], full["VCMR"]):
+            ga, gb = np.array(a["predictions"]), np.array(b["predictions"])
+            np.testing.assert_allclose(ga[:, 3], gb[:, 3], rtol=2e-5)
+            assert (ga[:, :3] == gb[:, :3]).mean() > 0.95
+        gt = [dict(desc_id=5000 + i, desc="", type=["v", "t", "vt"][i % 3], vid_name="vid_%03d" % int(d["query_gt_video"][i]),
+                   ts=[3.0, 9.0]) for i in range(ds.n_q)]
+        sub, met, sub_nms, met_nms = inf.eval_epoch(m, ds, opt, tasks=("SVMR", "VCMR", "VR"), ground_truth=gt)
+    assert set(met) == {"VCMR", "SVMR", "VR", "VCMR_by_type", "SVMR_by_type", "VR_by_type"}
+    assert 0.0 <= met["VR"]["r100"] <= 100.0 and met["VR"]["r1"] <= met["VR"]["r100"]
+    assert set(met_nms) == {"VCMR", "SVMR", "VCMR_by_type", "SVMR_by_type"}
+    for i in range(ds.n_q):
+        np.testing.assert_allclose(np.array(sub_nms["VCMR"][i]["predictions"]).reshape(-1, 4)[:, :3],
+                                   d["nms/VCMR/%d" % i][:, :3], atol=1e-6)

@@ -18,3 +18,15 @@ for name, ww in (("all pairs", w), ("1/8 owned", torch.where((torch.arange(100, 
     torch.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) for s, e in evs)
     print("%s: median %.3f ms" % (name, ms[2]))
+# fixed-cost probes
+one = torch.zeros_like(w); one[:, 0] = w[:, 0]
+for name, ww, n_out in (("1 pair owned", one, 200), ("1 pair owned, n_out=16", one, 16)):
+    for _ in range(2):
+        ops.moment_topk(st, ed, ww, 128, 2, 16, n_out)
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(5)]
+    for s, e in evs:
+        s.record(); ops.moment_topk(st, ed, ww, 128, 2, 16, n_out); e.record()
+    torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in evs)
+    print("%s: median %.3f ms" % (name, ms[2]))

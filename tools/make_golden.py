@@ -327,6 +327,47 @@ def gen_train_case(ns, name, cfg, seed, bsz, len_lo, len_hi):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def gen_eval_case(ns, name, seed, n_q, n_v, didemo):
+    """standalone_eval/eval.py eval_retrieval on a synthetic submission + ground truth (the reference's own
+    known-answer input file is a missing large blob)."""
+    rng = np.random.default_rng(seed)
+    video2idx = {"v%03d" % i: 100 + 3 * i for i in range(n_v)}
+    names = list(video2idx)
+    gt, sub = [], dict(video2idx=video2idx, VCMR=[], SVMR=[], VR=[])
+    for q in range(n_q):
+        vn = names[int(rng.integers(0, n_v))]
+        st = float(np.round(rng.uniform(0, 60), 2)); ed = st + float(np.round(rng.uniform(1.5, 20), 2))
+        if didemo:
+            ts = [[st + float(rng.integers(-1, 2)) * 5.0, ed + float(rng.integers(-1, 2)) * 5.0] for _ in range(4)]
+        else:
+            ts = [st, ed]
+        gt.append(dict(desc_id=900 + q, desc="q%d" % q, type=["v", "t", "vt"][int(rng.integers(0, 3))], vid_name=vn,
+                       ts=ts, duration=90.0))
+        n_pred = int(rng.integers(3, 121))
+
+        def moment(correct):
+            if correct:
+                return [round(st + float(rng.normal(0, 2.0)), 2), round(ed + float(rng.normal(0, 2.0)), 2)]
+            a = float(np.round(rng.uniform(0, 70), 2))
+            return [a, a + float(np.round(rng.uniform(1.5, 24), 2))]
+        vc, sv, vr = [], [], []
+        for j in range(n_pred):
+            right_vid = rng.random() < 0.15
+            v = video2idx[vn] if right_vid else video2idx[names[int(rng.integers(0, n_v))]]
+            vc.append([v] + moment(right_vid and rng.random() < 0.6) + [float(1.0 / (j + 1))])
+            sv.append([video2idx[vn]] + moment(rng.random() < 0.2) + [float(1.0 / (j + 1))])
+        perm = rng.permutation(n_v)[:min(n_v, n_pred)]
+        vr = [[video2idx[names[int(i)]], 0, 0, float(1.0 / (j + 1))] for j, i in enumerate(perm)]
+        for k, lst in (("VCMR", vc), ("SVMR", sv), ("VR", vr)):
+            sub[k].append(dict(desc_id=900 + q, desc="q%d" % q, predictions=lst))
+    metrics = ns.standalone_eval.eval_retrieval(sub, gt, iou_thds=(0.5, 0.7), verbose=False, match_number=True,
+                                                use_desc_type=not didemo)
+    path = os.path.join(OUT_DIR, name + ".json")
+    with open(path, "w") as f:
+        json.dump(dict(submission=sub, ground_truth=gt, use_desc_type=not didemo, metrics=metrics), f)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.parse_args()
@@ -349,6 +390,8 @@ def main():
     gen_pipeline_case(ns, "pipeline_video_only_h128",
                       model_cfg(ctx_mode="video", max_ctx_l=30), 22, n_v=11, len_lo=8, len_hi=30,
                       n_q=7, ctx_bsz=4, q_bsz=3, kvid=5, nbefore=40, nms_thd=0.5)
+    gen_eval_case(ns, "eval_tvr_style", 41, n_q=60, n_v=25, didemo=False)
+    gen_eval_case(ns, "eval_didemo_style", 42, n_q=30, n_v=12, didemo=True)
     gen_train_case(ns, "train_step_video_sub_h128", model_cfg(max_ctx_l=24, lw_st_ed=0.01, visual_input_size=48, sub_input_size=32,
                                                            query_input_size=32), 31, bsz=6,
                    len_lo=6, len_hi=24)

@@ -59,6 +59,10 @@ SIGNATURES = {
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "xml_moment_topk": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int,
                                 c_int, c_int, c_void_p]),
+    "xml_nms_vcmr_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, ctypes.c_double, c_int, c_int, c_void_p,
+                                  c_void_p]),
+    "xml_nms_svmr_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_double, c_int, c_int, c_void_p,
+                                  c_void_p]),
     "xml_add_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                   c_void_p]),
 }

@@ -49,15 +49,24 @@ extern "C" size_t xml_convse_rerank_workspace_bytes(const xml_convse_desc* d) {
 }
 
 __global__ void convse_count_kernel(const int32_t* __restrict__ pair_vid, int32_t* __restrict__ counts, int64_t P,
-                                    int nv, float* __restrict__ st_out, float* __restrict__ ed_out, int lpad) {
+                                    int nv) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int v = pair_vid[p];
-  if (v >= 0 && v < nv) {
-    atomicAdd(&counts[v], 1);
-  } else {
-    for (int l = 0; l < lpad; ++l) { st_out[p * lpad + l] = 0.f; ed_out[p * lpad + l] = 0.f; }
-  }
+  if (v >= 0 && v < nv) atomicAdd(&counts[v], 1);
+}
+
+// rows of skipped pairs (pair_vid < 0: owned by another shard / padding) are zero-filled, 16 B per thread, coalesced
+__global__ void convse_zero_skipped_kernel(const int32_t* __restrict__ pair_vid, float* __restrict__ st_out,
+                                           float* __restrict__ ed_out, int64_t P, int nv, int lpad4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t p = i / lpad4;
+  if (p >= P) return;
+  const int v = pair_vid[p];
+  if (v >= 0 && v < nv) return;
+  const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+  reinterpret_cast<float4*>(st_out)[i] = z;
+  reinterpret_cast<float4*>(ed_out)[i] = z;
 }
 
 // single workgroup: exclusive scans of counts and of ceil(counts / TM)
@@ -238,8 +247,10 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   const int64_t P = (int64_t)d->nq * d->kpairs;
   // counts and cursor are the first two (adjacent, 256-aligned) regions
   if (hipMemsetAsync(w.counts, 0, (size_t)((char*)w.offsets - (char*)w.counts), st) != hipSuccess) return XML_ERR_LAUNCH;
-  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, P, d->nv, st_out,
-                     ed_out, d->lpad);
+  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, P, d->nv);
+  XML_CHECK_LAUNCH();
+  hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P * (d->lpad / 4), 256)), dim3(256), 0, st, pair_vid, st_out,
+                     ed_out, P, d->nv, d->lpad / 4);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, d->nv);
   XML_CHECK_LAUNCH();

@@ -183,17 +183,22 @@ def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops):
 
 
 def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200, q2c_alpha=20.0,
-                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops):
+                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops, external_top=None):
     """Device part of compute_query2ctx_info for one query batch (xml/inference.py:308-386), single GPU.
 
     Returns device tensors:
       top_scores (Nq,K) f32 = exp(alpha*q2c) desc, top_indices (Nq,K) int32 video (meta) indices,
       flat_scores (Nq,n) f32 desc, flat_indices (Nq,n) int32 into (K, l_ref, l_ref)  [-1 = no candidate]
-      and, if svmr_video (Nq,) int32 is given, svmr_scores / svmr_flat (Nq,n) over (l_ref, l_ref)."""
+      and, if svmr_video (Nq,) int32 is given, svmr_scores / svmr_flat (Nq,n) over (l_ref, l_ref).
+    external_top = (indices (Nq,K) int32, weights (Nq,K) f32): use these videos / weights instead of K6 + K8."""
     qvec = stage_query_vectors(model, query_feat, query_mask)
-    q2c = stage_q2c(index, qvec, ops)
-    k = min(max_vcmr_video, index.n_videos)
-    top_w, top_i = ops.topk_rows(q2c, k, alpha=q2c_alpha)
+    if external_top is None:
+        q2c = stage_q2c(index, qvec, ops)
+        k = min(max_vcmr_video, index.n_videos)
+        top_w, top_i = ops.topk_rows(q2c, k, alpha=q2c_alpha)
+    else:   # external video-retrieval results replace K6/K8 (xml/inference.py:349-355): (meta idx int32, exp(alpha*s))
+        q2c = None
+        top_i, top_w = external_top
     st, ed = stage_span_probs(model, index, qvec, top_i, ops)
     fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
     out = dict(q2c=q2c, top_scores=top_w, top_indices=top_i, flat_scores=fs, flat_indices=fi)
@@ -217,13 +222,21 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
                            tasks=("SVMR",), ops=hip_ops):
     """Mirror of compute_query2ctx_info (xml/inference.py:252-445).  Same result dict:
     {"VCMR"|"SVMR"|"VR": [dict(desc_id, desc, predictions=[[video_idx, st, ed, score], ...]), ...]}.
-    External VR re-ranking (opt.external_inference_vr_res_path) is a "next" row."""
-    if getattr(opt, "external_inference_vr_res_path", None) is not None:
-        raise NotImplementedError("external VR re-ranking hook is not built yet (SURVEY.md 8f-4)")
+    opt.external_inference_vr_res_path (xml/inference.py:264-273,349-355): re-rank the videos of another model's VR
+    submission instead of this model's own top-k."""
     is_svmr, is_vr, is_vcmr = "SVMR" in tasks, "VR" in tasks, "VCMR" in tasks
     index = ctx_info["index"]
     video2idx = eval_dataset.video2idx
     video_metas = ctx_info["video_metas"]
+    external_query2video = None
+    if getattr(opt, "external_inference_vr_res_path", None) is not None:
+        # load_external_vr_res2 (xml/inference.py:244-249,264-273): desc_id -> top video predictions of another model
+        import json
+        from .postproc import get_submission_top_n
+        with open(opt.external_inference_vr_res_path, "r") as f:
+            ext = get_submission_top_n(json.load(f), top_n=max_n_videos)["VR"]
+        external_query2video = {e["desc_id"]: e["predictions"] for e in ext}
+        video_idx2meta_idx = {video2idx[m["vid_name"]]: i for i, m in enumerate(video_metas)}
     meta_vid = np.array([video2idx[m["vid_name"]] for m in video_metas])
     eval_dataset.set_data_mode("query")
     eval_dataset.load_gt_vid_name_for_query(is_svmr)
@@ -239,10 +252,16 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
         gt = None
         if is_svmr:
             gt = torch.tensor([name2meta[m["vid_name"]] for m in metas], dtype=torch.int32, device=opt.device)
+        external_top = None
+        if external_query2video is not None:
+            info = [external_query2video[m["desc_id"]] for m in metas]
+            ext_i = torch.tensor([[video_idx2meta_idx[p[0]] for p in e] for e in info], dtype=torch.int32)
+            ext_w = torch.exp(opt.q2c_alpha * torch.tensor([[p[3] for p in e] for e in info], dtype=torch.float32))
+            external_top = (ext_i.to(opt.device).contiguous(), ext_w.to(opt.device).contiguous())
         out = vcmr_search(model, index, qf, qm, max_vcmr_video=max_n_videos, max_before_nms=max_before_nms,
                           q2c_alpha=opt.q2c_alpha, min_pred_l=opt.min_pred_l, max_pred_l=opt.max_pred_l,
-                          svmr_video=gt, ops=ops)
-        host = {k: v.cpu().numpy() for k, v in out.items() if k != "q2c"}
+                          svmr_video=gt, ops=ops, external_top=external_top)
+        host = {k: v.cpu().numpy() for k, v in out.items() if v is not None and k != "q2c"}
         for i, m in enumerate(metas):
             if is_vr:
                 preds = [[int(meta_vid[v]), 0, 0, float(s)] for v, s in
@@ -267,3 +286,76 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
         if getattr(opt, "debug", False):
             break
     return {k: v for k, v in res.items() if len(v) != 0}
+
+
+def compute_query2ctx_info_svmr_only(model, eval_dataset, opt, ctx_info, max_before_nms=1000, max_n_videos=200,
+                                     tasks=("SVMR",), ops=hip_ops):
+    """Mirror of compute_query2ctx_info_svmr_only (xml/inference.py:107-167): every query is scored against its
+    ground-truth video only (K7 with one pair per query + K9 with k = 1); no corpus-wide similarity."""
+    index = ctx_info["index"]
+    video2idx = eval_dataset.video2idx
+    name2meta = {e["vid_name"]: i for i, e in enumerate(ctx_info["video_metas"])}
+    eval_dataset.set_data_mode("query")
+    eval_dataset.load_gt_vid_name_for_query(True)
+    clip, l_ref = opt.clip_length, index.l_ref
+    res = []
+    n = len(eval_dataset)
+    for b in range(0, n, opt.eval_query_bsz):
+        items = [eval_dataset[i] for i in range(b, min(n, b + opt.eval_query_bsz))]
+        metas = [e["meta"] for e in items]
+        qf, qm = pad_batch([e["model_inputs"]["query_feat"] for e in items], opt.device)
+        gt = torch.tensor([name2meta[m["vid_name"]] for m in metas], dtype=torch.int32, device=opt.device)
+        qvec = stage_query_vectors(model, qf, qm)
+        st1, ed1 = stage_span_probs(model, index, qvec, gt.reshape(-1, 1).contiguous(), ops)
+        ss, sf = ops.moment_topk(st1, ed1, None, l_ref, opt.min_pred_l, opt.max_pred_l, max_before_nms)
+        ss, sf = ss.cpu().numpy(), sf.cpu().numpy()
+        for i, m in enumerate(metas):
+            valid = sf[i] >= 0
+            _, si, ei = decode_flat(sf[i][valid], l_ref)
+            vid = int(video2idx[m["vid_name"]])
+            preds = [[vid, float(a * clip), float((e + 1) * clip), float(s)] for a, e, s in zip(si, ei, ss[i][valid])]
+            res.append(dict(desc_id=m["desc_id"], desc=m["desc"], predictions=preds))
+        if getattr(opt, "debug", False):
+            break
+    return dict(SVMR=res)
+
+
+def get_eval_res(model, eval_dataset, opt, tasks, max_after_nms, ops=hip_ops):
+    """Mirror of get_eval_res (xml/inference.py:448-464)."""
+    context_info = compute_context_info(model, eval_dataset, opt, ops=ops)
+    if "VCMR" in tasks or "VR" in tasks:
+        eval_res = compute_query2ctx_info(model, eval_dataset, opt, context_info, max_before_nms=opt.max_before_nms,
+                                          max_n_videos=opt.max_vcmr_video, tasks=tasks, ops=ops)
+    else:
+        eval_res = compute_query2ctx_info_svmr_only(model, eval_dataset, opt, context_info,
+                                                    max_before_nms=opt.max_before_nms, max_n_videos=max_after_nms,
+                                                    tasks=tasks, ops=ops)
+    eval_res["video2idx"] = eval_dataset.video2idx
+    return eval_res
+
+
+def eval_epoch(model, eval_dataset, opt, tasks=("SVMR",), max_after_nms=100, ground_truth=None, ops=hip_ops):
+    """The in-memory part of eval_epoch (xml/inference.py:473-531): raw results -> top-n submission -> metrics, and
+    the same again after temporal NMS when opt.nms_thd != -1.  (File writing stays with the caller.)
+    Returns (submission, metrics, submission_after_nms, metrics_after_nms)."""
+    from . import evaluate, postproc
+    raw = get_eval_res(model, eval_dataset, opt, tasks, max_after_nms, ops=ops)
+    import copy
+    submission = postproc.get_submission_top_n(copy.deepcopy(raw), top_n=max_after_nms)
+    use_desc_type = getattr(opt, "dset_name", "tvr") == "tvr"
+    metrics = None
+    if ground_truth is not None:
+        metrics = evaluate.eval_retrieval(submission, ground_truth, iou_thds=(0.5, 0.7), verbose=False,
+                                          match_number=not getattr(opt, "debug", False), use_desc_type=use_desc_type)
+    sub_nms = metrics_nms = None
+    if getattr(opt, "nms_thd", -1) != -1:
+        sub_nms = dict(video2idx=raw["video2idx"])
+        for k, fn in (("SVMR", postproc.post_processing_svmr_nms), ("VCMR", postproc.post_processing_vcmr_nms)):
+            if k in raw:
+                sub_nms[k] = fn(copy.deepcopy(raw[k]), nms_thd=opt.nms_thd, max_before_nms=opt.max_before_nms,
+                                max_after_nms=max_after_nms)
+        if ground_truth is not None:
+            metrics_nms = evaluate.eval_retrieval(sub_nms, ground_truth, iou_thds=(0.5, 0.7), verbose=False,
+                                                  match_number=not getattr(opt, "debug", False),
+                                                  use_desc_type=use_desc_type)
+    return submission, metrics, sub_nms, metrics_nms

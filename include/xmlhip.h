@@ -118,6 +118,10 @@ int xml_linear(const void* x, const void* w, const float* b, void* y, int64_t ro
  * Done once per corpus for feat1 ("ctx normalisation precomputed at corpus-encode time"). */
 int xml_l2norm_rows(const void* x, void* y, int64_t rows, int d, int dt, xml_stream_t stream);
 
+/* Dataset-side feature normalisation ("next" row 8f-3), l2_normalize_np_array (utils/basic_utils.py:82-84):
+ * y = x / (||x||_2 + eps), eps = 1e-5 in the reference; f32 (rows, d); all-zero padding rows stay zero. */
+int xml_l2norm_rows_eps(const float* x, float* y, int64_t rows, int d, float eps, xml_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K6: video-level scores = similarity GEMM #1 with fused masked max over clips
  *   out[q,v] = max_l mask_logits( qn[q] . cn[v,l] )      (xml/model_xml.py:448-452)

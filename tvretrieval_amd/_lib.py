@@ -47,6 +47,7 @@ SIGNATURES = {
                                  c_void_p]),
     "xml_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "xml_l2norm_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "xml_l2norm_rows_eps": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "xml_q2c_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
                                c_int, c_void_p]),
     "xml_q2c_scores_fused": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,

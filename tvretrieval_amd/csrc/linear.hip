@@ -190,6 +190,28 @@ __global__ __launch_bounds__(256) void l2norm_rows_kernel(const T* __restrict__ 
   for (int i = lane; i < d; i += 64) DT<T>::st(y + row * d + i, DT<T>::ld(px + i) / nrm);
 }
 
+// dataset-side normalisation, l2_normalize_np_array (utils/basic_utils.py:82-84): x / (||x||_2 + eps); f32 in,
+// f32 out; zero (padding) rows stay zero
+__global__ __launch_bounds__(256) void l2norm_add_eps_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                             int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* px = x + row * d;
+  float s = 0.f;
+  for (int i = lane; i < d; i += 64) s += px[i] * px[i];
+  const float den = sqrtf(wave_sum(s)) + eps;
+  for (int i = lane; i < d; i += 64) y[row * d + i] = px[i] / den;
+}
+
+extern "C" int xml_l2norm_rows_eps(const float* x, float* y, int64_t rows, int d, float eps, xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !y || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
+  hipLaunchKernelGGL(l2norm_add_eps_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, x, y, rows, d, eps);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
 extern "C" int xml_l2norm_rows(const void* x, void* y, int64_t rows, int d, int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!x || !y || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;

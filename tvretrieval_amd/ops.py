@@ -158,6 +158,15 @@ def l2norm_rows(x):
     return y
 
 
+def l2norm_rows_eps(x, eps=1e-5):
+    """dataset normalisation x / (||x|| + eps) on the device (f32)."""
+    _req(x, "x", torch.float32)
+    d = x.shape[-1]
+    y = torch.empty_like(x)
+    check(_lib.load().xml_l2norm_rows_eps(_p(x), _p(y), x.numel() // d, d, float(eps), _stream()), "xml_l2norm_rows_eps")
+    return y
+
+
 def add_layernorm(a, b, g, beta, out_dtype=None):
     _req(a, "a"); _req(g, "g", torch.float32); _req(beta, "beta", torch.float32)
     out_dtype = out_dtype or (b.dtype if b is not None else a.dtype)

@@ -206,6 +206,89 @@ int xml_moment_topk(const float* st, const float* ed, const float* w, float* out
 int xml_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta,
                       void* y, int64_t rows, int d, int dt, xml_stream_t stream);
 
+/* =============================================================================================
+ * TRAINING STEP (BASELINE config 5): backward kernels + loss heads + BertAdam.
+ * The reference relies on torch autograd for XML.forward (xml/model_xml.py:212-251) and
+ * loss.backward() / optimizer.step() (xml/train.py:78-95); these entries are the hand-written backward of
+ * each forward op above.  Activation gradients use dt, parameter gradients are f32 and ACCUMULATE (+=)
+ * unless stated otherwise.
+ * ============================================================================================= */
+
+/* y[b][c][r] = x[b][r][c]; x (batch, rows, cols) contiguous, y rows have stride ld_out >= rows
+ * (columns beyond `rows` are not written: pre-zero a padded destination). */
+int xml_transpose_batched(const void* x, void* y, int batch, int rows, int cols, int ld_out, int dt,
+                          xml_stream_t stream);
+/* out[c] (+)= sum_r x[r][c]   -- bias / positional-table gradients. */
+int xml_colsum(const void* x, int x_dt, float* out, int64_t rows, int cols, int accumulate,
+               xml_stream_t stream);
+/* dx = dy * (y > 0)   -- F.relu backward (LinearLayer, xml/model_components.py:163). */
+int xml_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, int dt, xml_stream_t stream);
+/* y (y_dt) += x (x_dt). */
+int xml_add_inplace(void* y, int y_dt, const void* x, int x_dt, int64_t n, xml_stream_t stream);
+/* LayerNorm backward of y = LN(a [+ b]) * g + beta: dx (grad of a and of b), dg +=, dbeta +=.
+ *   d <= 1024: one wave per row.  d > 1024 (input LayerNorm over raw features): b must be NULL, dx may be NULL,
+ *   ws = rows * 16 bytes of scratch. */
+int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx,
+                      float* dg, float* dbeta, int64_t rows, int d, int dt, void* ws, size_t ws_bytes,
+                      xml_stream_t stream);
+/* out[z] = scale * A[z] B[z]^T for z < batch; A (M,K), B (N,K) contiguous, out (M,N) dt or f32.
+ * K % 8 == 0 (bf16) / % 4 (f32).  Used for the per-head products of attention forward/backward and,
+ * with batch = 1 and transposed operands, for dX = dY W and dW = dY^T X of nn.Linear. */
+int xml_gemm_batched(const void* A, const void* B, void* out, int batch, int M, int N, int K, float scale,
+                     int out_f32, int dt, xml_stream_t stream);
+/* token-major (n*L, ld) columns [col0 + h*dh, +dh)  <->  per-(sequence, head) matrices
+ *   dst (n, heads, l8, dh) rows >= L zero;  dstT (n, heads, dh, l8) columns >= L zero; either may be NULL. */
+int xml_split_heads(const void* src, int ld, int col0, int64_t n, int L, int l8, int heads, int dh,
+                    void* dst, void* dstT, int dt, xml_stream_t stream);
+int xml_merge_heads(const void* src, void* dst, int ld, int col0, int64_t n, int L, int l8, int heads,
+                    int dh, int dt, xml_stream_t stream);
+/* BertSelfAttention softmax on materialised scores (xml/model_components.py:288-296) and its backward.
+ *   S (n*heads, lq8, lk8) f32 = Q K^T;  P = softmax_j(S / sqrt_dh + (1 - q_mask*k_mask) * -1e4), j < lk.
+ *   dP == NULL: writes P and (optionally) P^T, zero padded.   dP != NULL: writes dS = P*(dP - sum P*dP)/sqrt_dh
+ *   and dS^T.  q_mask may be NULL (= 1).  lk <= 128. */
+int xml_attn_softmax(const float* S, const float* dP, const float* q_mask, const float* k_mask, void* P,
+                     void* PT, void* dS, void* dST, int64_t n, int heads, int lq, int lk, int lq8, int lk8,
+                     float sqrt_dh, int dt, xml_stream_t stream);
+/* get_modularized_queries backward (xml/model_xml.py:410-423): denc (n, lq, hidden) dt written, dw_m += . */
+int xml_modular_pool_bwd(const void* enc, const float* mask, const float* w_m, const void* dout, void* denc,
+                         float* dw_m, int64_t n, int lq, int hidden, int n_mod, int dt, xml_stream_t stream);
+/* F.normalize(dim=-1) backward; dy is f32, dx is dt. */
+int xml_l2norm_bwd(const void* x, const float* dy, void* dx, int64_t rows, int d, int dt,
+                   xml_stream_t stream);
+/* xml_q2c_scores backward for the in-batch (N x N) training scores: the gradient of max_l goes to the arg-max
+ * clip.  qn (nq,hidden), cn (nv,l,hidden), mask (nv,l); dqn / dcn f32, zeroed here; `scale` multiplies dscores
+ * (1 / number of modalities when the scores were averaged). */
+int xml_q2c_scores_bwd(const void* qn, const void* cn, const float* mask, const float* dscores,
+                       int64_t ld_ds, float scale, float* dqn, float* dcn, int nq, int nv, int l, int hidden,
+                       int dt, xml_stream_t stream);
+/* einsum("bd,bld->bl") of the cross=False branch (xml/model_xml.py:478-479,532) and its backward. */
+int xml_pair_sim(const void* q, const void* f2, float* sim, int64_t n, int l, int hidden, int dt,
+                 xml_stream_t stream);
+int xml_pair_sim_bwd(const void* q, const void* f2, const float* dsim, void* dq, void* df2, int64_t n, int l,
+                     int hidden, int dt, xml_stream_t stream);
+/* Span loss head = conv1d start/end predictors + mask_logits + cross entropy (xml/model_xml.py:237-240,
+ * 478-500, 532-550, F.cross_entropy mean reduction).  sim_i (n, l) f32; conv_w = [st filters | ed filters],
+ * each n_filt x ks with n_filt = merged ? 1 : n_sim; st_ed (n, 2) int64 targets.
+ *   gout == NULL: *loss_out = mean_b CE(st) + CE(ed).
+ *   gout != NULL: dsim_i and dconv_w (both overwritten) = *gout * d loss. */
+int xml_span_loss(const float* sim0, const float* sim1, const float* conv_w, const float* mask0,
+                  const float* mask1, const int64_t* st_ed, int merged, int n_sim, int ks, int n, int l,
+                  const float* gout, float* loss_out, float* dsim0, float* dsim1, float* dconv_w,
+                  xml_stream_t stream);
+/* In-batch ranking loss (get_video_level_loss, xml/model_xml.py:588-637) on scores (n, n) f32 with the
+ * torch.randint draws of get_neg_scores (:622) passed in as rank positions ranks_ctx / ranks_q (n) int32.
+ *   gout == NULL: losses[0] = loss_neg_ctx, losses[1] = loss_neg_q (unweighted).
+ *   gout (2 floats) != NULL: dscores (overwritten) = gout[0] * d loss_neg_ctx + gout[1] * d loss_neg_q. */
+int xml_rank_loss(const float* scores, const int* ranks_ctx, const int* ranks_q, float margin, int lse,
+                  int n, const float* gout, float* losses, float* dscores, xml_stream_t stream);
+/* BertAdam.step (xml/optimization.py:273-338) over one flat f32 buffer holding every tensor:
+ * per-tensor clip_grad_norm_ (gradient rescaled in place), m/v update, m/(sqrt(v)+eps) + wd*p, no bias
+ * correction, p -= seg_lr[s] * lr_mult * update.  seg_off (n_seg+1) int64, seg_lr / seg_wd / norms (n_seg) f32,
+ * all device memory. */
+int xml_bert_adam_step(float* p, float* g, float* m, float* v, const int64_t* seg_off, const float* seg_lr,
+                       const float* seg_wd, int n_seg, int64_t total, float lr_mult, float b1, float b2,
+                       float eps, float max_grad_norm, float* norms, xml_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * HOST post-processing ("next" row 8f-1; pointers are HOST memory): greedy temporal NMS.
  *   xml_nms_vcmr_host = filter_vcmr_by_nms (baselines/clip_alignment_with_language/inference.py:189-225):

@@ -415,3 +415,37 @@ def vcmr_nms(all_video_predictions, nms_threshold, max_before_nms=1000, max_afte
         for p in temporal_nms(preds, nms_threshold):
             merged.append([vid] + list(p))
     return sorted(merged, key=lambda x: x[3], reverse=True)[:max_after_nms]
+
+
+# ------------------------------------------------------------------------------------------
+# optimizer (xml/optimization.py)
+# ------------------------------------------------------------------------------------------
+def warmup_linear(progress, warmup):
+    """WarmupLinearSchedule.get_lr_, xml/optimization.py:166-169."""
+    if progress < warmup:
+        return progress / warmup
+    return max((progress - 1.0) / (warmup - 1.0), 0.0)
+
+
+def bert_adam_step(params, grads, state, step, weight_decay, lr=1e-4, warmup=-1, t_total=-1, b1=0.9, b2=0.999, e=1e-6,
+                   max_grad_norm=1.0, **_):
+    """BertAdam.step for the warmup_linear schedule, xml/optimization.py:273-338.  params / grads / weight_decay:
+    dicts keyed by parameter name; state: dict name -> (m, v), created on first use.  Updates params and grads
+    (the per-tensor clip rescales the gradient in place) and returns nothing; `step` is the per-parameter step
+    counter BEFORE this call (identical for all parameters)."""
+    mult = 1.0 if t_total < 0 else warmup_linear(float(step) / float(t_total), max(warmup, 0.0))
+    for k, p in params.items():
+        g = grads[k]
+        if k not in state:
+            state[k] = (torch.zeros_like(p), torch.zeros_like(p))
+        m, v = state[k]
+        if max_grad_norm > 0:
+            coef = max_grad_norm / (float(g.norm(2)) + 1e-6)     # clip_grad_norm_ on one tensor
+            if coef < 1:
+                g.mul_(coef)
+        m.mul_(b1).add_(g, alpha=1 - b1)
+        v.mul_(b2).addcmul_(g, g, value=1 - b2)
+        update = m / (v.sqrt() + e)
+        if weight_decay[k] > 0.0:
+            update = update + weight_decay[k] * p
+        p.sub_(lr * mult * update)

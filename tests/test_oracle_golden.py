@@ -144,18 +144,37 @@ def test_pipeline(name):
         np.testing.assert_allclose(got, want)
 
 
-def test_training_forward_loss():
-    d, cfg, sd = load_golden("train_step_video_sub_h128")
+NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight"]     # xml/train.py:355-362
+
+
+@pytest.mark.parametrize("name", ["train_step_video_sub_h128", "train_step_nocross_lse_h128"])
+def test_training_steps(name):
+    """loss / gradients of step 1 and the parameters after three BertAdam steps of the reference."""
+    d, cfg, _ = load_golden(name)
     sd = {k[len("sd_before/"):]: v for k, v in d.items() if k.startswith("sd_before/")}
-    params = {k: torch.from_numpy(v.copy()).requires_grad_(True) for k, v in sd.items()}
-    m = O.OracleXML(cfg, params)
-    loss, parts = m.forward_loss(d["query_feat"], d["query_mask"], d["video_feat"], d["video_mask"], d["sub_feat"],
-                                 d["sub_mask"], d["st_ed_indices"], d["neg_ctx_rank"], d["neg_q_rank"])
-    assert abs(float(loss) - float(d["loss"])) < 1e-5
-    assert abs(parts["loss_st_ed"] - float(d["loss_st_ed"])) < 1e-5
-    assert abs(parts["loss_neg_ctx"] - float(d["loss_neg_ctx"])) < 1e-5
-    assert abs(parts["loss_neg_q"] - float(d["loss_neg_q"])) < 1e-5
-    loss.backward()
+    params = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
+    okw = json.loads(str(d["optim"]))
+    wd = {k: (0.0 if any(nd in k for nd in NO_DECAY) else okw["weight_decay"]) for k in params}
+    state = {}
+    for it in range(3):
+        leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        m = O.OracleXML(cfg, leaf)
+        loss, parts = m.forward_loss(d["query_feat"], d["query_mask"], d["video_feat"], d["video_mask"],
+                                     d["sub_feat"], d["sub_mask"], d["st_ed_indices"], d["neg_ctx_rank_steps"][it],
+                                     d["neg_q_rank_steps"][it])
+        assert abs(float(loss) - float(d["step_losses"][it])) < 2e-5
+        loss.backward()
+        if it == 0:
+            assert abs(float(loss) - float(d["loss"])) < 1e-5
+            assert abs(parts["loss_st_ed"] - float(d["loss_st_ed"])) < 1e-5
+            assert abs(parts["loss_neg_ctx"] - float(d["loss_neg_ctx"])) < 1e-5
+            assert abs(parts["loss_neg_q"] - float(d["loss_neg_q"])) < 1e-5
+            for k, p in leaf.items():
+                if ("grad/" + k) in d:
+                    _close(p.grad, d["grad/" + k], rtol=1e-4, atol=1e-6)
+        with torch.no_grad():
+            grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in leaf.items()}
+            trainable = {k: params[k] for k in params if leaf[k].grad is not None}
+            O.bert_adam_step(trainable, grads, state, it, wd, **{k: v for k, v in okw.items() if k != "weight_decay"})
     for k, p in params.items():
-        if ("grad/" + k) in d:
-            _close(p.grad, d["grad/" + k], rtol=1e-4, atol=1e-6)
+        _close(p, d["sd_after3/" + k], rtol=1e-4, atol=2e-6)

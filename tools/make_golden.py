@@ -304,24 +304,35 @@ def gen_train_case(ns, name, cfg, seed, bsz, len_lo, len_hi):
         no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
         groups = [{"params": [p for n, p in params if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
                   {"params": [p for n, p in params if any(nd in n for nd in no_decay)], "weight_decay": 0.0}]
-        optim = ns.optimization.BertAdam(groups, lr=1e-4, weight_decay=0.01, warmup=0.01, t_total=1000,
-                                         schedule="warmup_linear")
+        okw = dict(lr=1e-4, weight_decay=0.01, warmup=0.1, t_total=10, schedule="warmup_linear")
+        optim = ns.optimization.BertAdam(groups, **okw)
         tv = torch.from_numpy
-        loss, ld = model(tv(qfeat), tv(qmask), tv(vfeat), tv(vmask), tv(sfeat), tv(smask), None, None, tv(st_ed))
-        optim.zero_grad()
-        loss.backward()
-        grads = {n: p.grad.detach().numpy().copy() for n, p in params if p.grad is not None}
-        optim.step()
+        n_steps = 3
+        step_losses = []
+        for it in range(n_steps):          # the same batch three times: lr multiplier is 0 at step 0, then 1.0, 0.889
+            loss, ld = model(tv(qfeat), tv(qmask), tv(vfeat), tv(vmask), tv(sfeat), tv(smask), None, None, tv(st_ed))
+            optim.zero_grad()
+            loss.backward()
+            if it == 0:
+                grads = {n: p.grad.detach().numpy().copy() for n, p in params if p.grad is not None}
+                first = (float(loss), dict(ld))
+            step_losses.append(float(loss))
+            optim.step()
+            if it == 0:     # warmup_linear gives multiplier 0 at step 0: the first step only updates the moments
+                for k, v in model.state_dict().items():
+                    assert np.array_equal(v.detach().numpy(), out["sd_before/" + k]), k
     finally:
         torch.randint = orig_randint
-    assert len(draws) == 2
-    out.update(neg_ctx_rank=draws[0], neg_q_rank=draws[1], loss=np.float64(float(loss)),
+    assert len(draws) == 2 * n_steps
+    ld = first[1]
+    out.update(neg_ctx_rank=draws[0], neg_q_rank=draws[1], loss=np.float64(first[0]),
+               neg_ctx_rank_steps=np.stack(draws[0::2]), neg_q_rank_steps=np.stack(draws[1::2]),
+               step_losses=np.array(step_losses, dtype=np.float64),
                loss_st_ed=np.float64(ld["loss_st_ed"]), loss_neg_ctx=np.float64(ld["loss_neg_ctx"]),
                loss_neg_q=np.float64(ld["loss_neg_q"]))
     out.update({"grad/" + k: v for k, v in grads.items()})
-    out.update({"sd_after/" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()})
-    out["optim"] = json.dumps(dict(lr=1e-4, weight_decay=0.01, warmup=0.01, t_total=1000, schedule="warmup_linear",
-                                   b1=0.9, b2=0.999, e=1e-6, max_grad_norm=1.0))
+    out.update({"sd_after3/" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()})
+    out["optim"] = json.dumps(dict(b1=0.9, b2=0.999, e=1e-6, max_grad_norm=1.0, **okw))
     path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
@@ -369,6 +380,12 @@ def gen_eval_case(ns, name, seed, n_q, n_v, didemo):
 
 
 def main():
+    only = sys.argv.pop(1) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else ""
+    if only:      # regenerate a subset: python tools/make_golden.py train_step
+        g = globals()
+        for fn in ("gen_model_case", "gen_pipeline_case", "gen_eval_case", "gen_train_case"):
+            orig = g[fn]
+            g[fn] = (lambda o: lambda ns, name, *a, **k: o(ns, name, *a, **k) if only in name else None)(orig)
     ap = argparse.ArgumentParser()
     ap.parse_args()
     os.makedirs(OUT_DIR, exist_ok=True)
@@ -395,6 +412,10 @@ def main():
     gen_train_case(ns, "train_step_video_sub_h128", model_cfg(max_ctx_l=24, lw_st_ed=0.01, visual_input_size=48, sub_input_size=32,
                                                            query_input_size=32), 31, bsz=6,
                    len_lo=6, len_hi=24)
+    gen_train_case(ns, "train_step_nocross_lse_h128",
+                   model_cfg(max_ctx_l=20, lw_st_ed=0.5, visual_input_size=40, sub_input_size=32, query_input_size=32,
+                             cross_att=False, merge_two_stream=False, ranking_loss_type="lse", use_hard_negative=True,
+                             hard_pool_size=3), 32, bsz=7, len_lo=5, len_hi=19)
 
 
 if __name__ == "__main__":

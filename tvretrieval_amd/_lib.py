@@ -66,6 +66,35 @@ SIGNATURES = {
                                   c_void_p]),
     "xml_add_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                   c_void_p]),
+    # ---- training step (train.hip) ----
+    "xml_transpose_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "xml_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "xml_relu_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "xml_add_inplace": (c_int, [c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "xml_layernorm_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                  c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "xml_gemm_batched": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int, c_int,
+                                 c_void_p]),
+    "xml_split_heads": (c_int, [c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int,
+                                c_void_p]),
+    "xml_merge_heads": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int, c_int, c_int, c_int,
+                                c_void_p]),
+    "xml_attn_softmax": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                 c_int, c_int, c_int, c_int, c_int, c_float, c_int, c_void_p]),
+    "xml_modular_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                     c_int, c_int, c_void_p]),
+    "xml_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "xml_q2c_scores_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float, c_void_p, c_void_p, c_int, c_int,
+                                   c_int, c_int, c_int, c_void_p]),
+    "xml_pair_sim": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "xml_pair_sim_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int,
+                                 c_void_p]),
+    "xml_span_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int,
+                              c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "xml_rank_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                              c_void_p]),
+    "xml_bert_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
+                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,261 @@
+"""torch.autograd.Function nodes whose forward AND backward are libxmlhip.so kernels.
+
+The reference trains with torch autograd over eager ops (xml/train.py:78-95).  Here autograd is only the tape:
+each node below records what its hand-written backward kernel needs and launches it.  Parameters are the f32
+masters of model_xml.XML (so `.grad` is f32, as the reference's); activations and their gradients use the
+compute dtype (f32 or bf16).  Dropout is not applied (see train.py).
+
+Nodes (reference op -> node):
+  nn.Linear (+ReLU)                         LinearFn          dX = dY W, dW = dY^T X (MFMA GEMMs), db = colsum
+  nn.LayerNorm(a [+ b])                     LayerNormFn
+  BertSelfAttention core                    AttentionCoreFn   softmax(QK^T/sqrt(d) + mask) V per head
+  get_modularized_queries                   ModularPoolFn
+  get_video_level_scores                    VideoLevelScoresFn
+  einsum("bd,bld->bl")                      PairSimFn
+  conv predictors + CE                      SpanLossFn
+  get_video_level_loss                      RankLossFn
+"""
+import torch
+
+from . import ops
+from . import train_ops as T
+
+F32 = torch.float32
+
+
+def _r8(x):
+    return (x + 7) // 8 * 8
+
+
+def _packed(w, dtype):
+    w = w.detach()
+    return w.contiguous() if dtype == F32 else ops.pack_weights(w.float().contiguous(), dtype)
+
+
+class LinearFn(torch.autograd.Function):
+    """y = [relu](x W^T + b); x (..., K) compute dtype, W (N, K) / b (N) f32 masters."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        w = _packed(weight, x.dtype)
+        y = ops.linear(x.contiguous(), w, None if bias is None else bias.detach().float().contiguous(), relu=relu)
+        ctx.relu = relu
+        ctx.has_bias = bias is not None
+        ctx.save_for_backward(x, w, y if relu else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.relu:
+            dy = T.relu_bwd(y, dy)
+        n, k = w.shape
+        rows = x.numel() // k
+        dy2, x2 = dy.view(rows, n), x.contiguous().view(rows, k)
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wt = T.transpose(w, _r8(n)) if n % 8 else T.transpose(w)              # (K, N[8])
+            a = dy2
+            if n % 8:                                                              # pad the reduction dim
+                a = torch.zeros((rows, _r8(n)), dtype=dy.dtype, device=dy.device)
+                a[:, :n] = dy2
+            dx = T.gemm_batched(a, wt).view(x.shape)
+        if ctx.needs_input_grad[1]:
+            r8 = _r8(rows)
+            dyt = T.transpose(dy2, r8)                                            # (N, rows8)
+            xt = T.transpose(x2, r8)                                              # (K, rows8)
+            dw = T.gemm_batched(dyt, xt, out_f32=True)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = T.colsum(dy2, rows, n)
+        return dx, dw, db, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """y = LN(a [+ b]) * g + beta; a may be raw f32 features (no gradient), b optional residual."""
+
+    @staticmethod
+    def forward(ctx, a, b, g, beta, out_dtype):
+        gf, bf = g.detach().float().contiguous(), beta.detach().float().contiguous()
+        a = a.contiguous()
+        b = None if b is None else b.contiguous()
+        y = ops.add_layernorm(a, b, gf, bf, out_dtype=out_dtype)
+        ctx.save_for_backward(a, b, gf)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        a, b, g = ctx.saved_tensors
+        need_dx = ctx.needs_input_grad[0] or (b is not None and ctx.needs_input_grad[1])
+        dx, dg, dbeta = T.layernorm_bwd(a, b, g, dy.contiguous(), need_dx=need_dx)
+        da = db = None
+        if ctx.needs_input_grad[0]:
+            da = dx if dx.dtype == a.dtype else ops.convert(dx, a.dtype)
+        if b is not None and ctx.needs_input_grad[1]:
+            db = dx if dx.dtype == b.dtype else ops.convert(dx, b.dtype)
+        return da, db, dg, dbeta, None
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """Multi-head softmax(Q K^T / sqrt(dh) + (1 - q_mask (x) k_mask) * -1e4) V (xml/model_components.py:266-303,
+    dropout on the probabilities omitted).  q (N, Lq, H), k / v (N, Lk, H); masks f32 (q_mask may be None)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, q_mask, k_mask, heads):
+        n, lq, hidden = q.shape
+        lk = k.shape[1]
+        dh = hidden // heads
+        q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        qh, _ = T.split_heads(q, heads)
+        kh, _ = T.split_heads(k, heads)
+        _, vht = T.split_heads(v, heads, want=False, want_t=True)
+        s = T.gemm_batched(qh, kh, out_f32=True)                       # (N*h, lq8, lk8)
+        p, _ = T.attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype)
+        oh = T.gemm_batched(p, vht)                                    # (N*h, lq8, dh)
+        out = T.merge_heads(oh, n, lq, heads)
+        ctx.heads = heads
+        ctx.save_for_backward(q, k, v, s, q_mask, k_mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, s, q_mask, k_mask = ctx.saved_tensors
+        heads = ctx.heads
+        n, lq, hidden = q.shape
+        lk = k.shape[1]
+        dh = hidden // heads
+        doh, doht = T.split_heads(dout.contiguous(), heads, want=True, want_t=True)
+        vh, _ = T.split_heads(v, heads)
+        dp = T.gemm_batched(doh, vh, out_f32=True)                     # dP = dO V^T
+        _, pt = T.attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype, want_t=True)
+        ds, dst = T.attn_softmax_bwd(s, dp, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype)
+        dvh = T.gemm_batched(pt, doht)                                 # dV = P^T dO      (lk8, dh)
+        _, qht = T.split_heads(q, heads, want=False, want_t=True)
+        _, kht = T.split_heads(k, heads, want=False, want_t=True)
+        dqh = T.gemm_batched(ds, kht)                                  # dQ = dS K        (lq8, dh)
+        dkh = T.gemm_batched(dst, qht)                                 # dK = dS^T Q      (lk8, dh)
+        return (T.merge_heads(dqh, n, lq, heads), T.merge_heads(dkh, n, lk, heads), T.merge_heads(dvh, n, lk, heads),
+                None, None, None)
+
+
+class ModularPoolFn(torch.autograd.Function):
+    """get_modularized_queries (xml/model_xml.py:410-423) -> (n_mod, N, H)."""
+
+    @staticmethod
+    def forward(ctx, enc, mask, wm):
+        wmf = wm.detach().float().contiguous()
+        enc = enc.contiguous()
+        out = ops.modular_pool(enc, mask, wmf)
+        ctx.save_for_backward(enc, mask, wmf)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        enc, mask, wmf = ctx.saved_tensors
+        denc, dwm = T.modular_pool_bwd(enc, mask, wmf, dout.contiguous())
+        return denc, None, dwm
+
+
+class VideoLevelScoresFn(torch.autograd.Function):
+    """get_video_level_scores per modality, averaged (xml/model_xml.py:436-453,572-574): F.normalize both sides,
+    cosine vs every clip, mask_logits, max over clips -> (Nq, Nv) f32.
+    forward(n_mod, queries..., feat1s..., masks...)."""
+
+    @staticmethod
+    def forward(ctx, n_mod, *rest):
+        saved = []
+        scores = None
+        for i in range(n_mod):
+            query, feat1, mask = rest[i].contiguous(), rest[n_mod + i].contiguous(), rest[2 * n_mod + i]
+            n, l, hidden = feat1.shape
+            lpad = (l + 15) // 16 * 16
+            qn = ops.l2norm_rows(query)
+            cn = ops.l2norm_rows(feat1)
+            if lpad != l:
+                cn_p = torch.zeros((n, lpad, hidden), dtype=cn.dtype, device=cn.device)
+                mk_p = torch.zeros((n, lpad), dtype=F32, device=cn.device)
+                cn_p[:, :l] = cn
+                mk_p[:, :l] = mask
+            else:
+                cn_p, mk_p = cn, mask.contiguous()
+            if scores is None:
+                scores = ops.q2c_scores(qn, cn_p, mk_p)
+            else:
+                ops.q2c_scores(qn, cn_p, mk_p, out=scores, combine=True)      # (a + b) / 2
+            saved += [query, feat1, qn, cn_p, mk_p]
+        assert n_mod in (1, 2)
+        ctx.n_mod = n_mod
+        ctx.save_for_backward(*saved)
+        return scores
+
+    @staticmethod
+    def backward(ctx, dscores):
+        n_mod = ctx.n_mod
+        dscores = dscores.contiguous()
+        dq, df = [], []
+        for i in range(n_mod):
+            query, feat1, qn, cn_p, mk_p = ctx.saved_tensors[5 * i:5 * i + 5]
+            dqn, dcn = T.q2c_scores_bwd(qn, cn_p, mk_p, dscores, scale=1.0 / n_mod)
+            if cn_p.shape[1] != feat1.shape[1]:
+                dcn = dcn[:, :feat1.shape[1]].contiguous()
+            dq.append(T.l2norm_bwd(query, dqn))
+            df.append(T.l2norm_bwd(feat1, dcn))
+        return (None,) + tuple(dq) + tuple(df) + (None,) * n_mod
+
+
+class PairSimFn(torch.autograd.Function):
+    """sim[b][l] = q[b] . f2[b][l]   (cross=False branch, xml/model_xml.py:478-479,532) -> f32."""
+
+    @staticmethod
+    def forward(ctx, q, f2):
+        q, f2 = q.contiguous(), f2.contiguous()
+        ctx.save_for_backward(q, f2)
+        return T.pair_sim(q, f2)
+
+    @staticmethod
+    def backward(ctx, dsim):
+        q, f2 = ctx.saved_tensors
+        return T.pair_sim_bwd(q, f2, dsim.contiguous())
+
+
+class SpanLossFn(torch.autograd.Function):
+    """conv1d start / end predictors + mask_logits + F.cross_entropy on (N, L) similarities.
+    forward(merged, ks, st_ed, n_sim, sims..., masks..., filters...) with filters = st filters then ed filters,
+    each an nn.Conv1d weight (1, 1, ks)."""
+
+    @staticmethod
+    def forward(ctx, merged, ks, st_ed, n_sim, *rest):
+        sims = [t.contiguous() for t in rest[:n_sim]]
+        masks = [t.contiguous() for t in rest[n_sim:2 * n_sim]]
+        filters = rest[2 * n_sim:]
+        conv_w = torch.cat([f.detach().float().reshape(-1) for f in filters]).contiguous()
+        ctx.cfg = (merged, ks, n_sim, [f.shape for f in filters])
+        ctx.save_for_backward(conv_w, st_ed, *sims, *masks)
+        return T.span_loss(sims, conv_w, masks, st_ed, merged, ks)
+
+    @staticmethod
+    def backward(ctx, gout):
+        merged, ks, n_sim, fshapes = ctx.cfg
+        conv_w, st_ed = ctx.saved_tensors[:2]
+        sims = list(ctx.saved_tensors[2:2 + n_sim])
+        masks = list(ctx.saved_tensors[2 + n_sim:])
+        dsims, dconv = T.span_loss(sims, conv_w, masks, st_ed, merged, ks, gout=gout.reshape(1).float().contiguous())
+        dfilters = [dconv[i * ks:(i + 1) * ks].reshape(s) for i, s in enumerate(fshapes)]
+        return (None, None, None, None) + tuple(dsims) + (None,) * n_sim + tuple(dfilters)
+
+
+class RankLossFn(torch.autograd.Function):
+    """get_video_level_loss (xml/model_xml.py:588-637) -> (2,) f32 [loss_neg_ctx, loss_neg_q] (unweighted)."""
+
+    @staticmethod
+    def forward(ctx, scores, ranks_ctx, ranks_q, margin, lse):
+        scores = scores.contiguous()
+        ctx.cfg = (margin, lse)
+        ctx.save_for_backward(scores, ranks_ctx, ranks_q)
+        return T.rank_loss(scores, ranks_ctx, ranks_q, margin, lse)
+
+    @staticmethod
+    def backward(ctx, gout):
+        scores, ranks_ctx, ranks_q = ctx.saved_tensors
+        margin, lse = ctx.cfg
+        return T.rank_loss(scores, ranks_ctx, ranks_q, margin, lse, gout=gout.float().contiguous()), None, None, None, None

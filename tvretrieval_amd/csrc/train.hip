@@ -1,0 +1,1002 @@
+// Training-step kernels (SURVEY.md 8 a14 / BASELINE config 5): backward of the XML encoders and scorers + BertAdam.
+//   reference: XML.forward + losses      xml/model_xml.py:212-251,588-637   (autograd does the backward there)
+//              BertAdam.step             xml/optimization.py:273-338
+// Round-1 goal is a CORRECT hand-written backward (parity with the reference's autograd on the golden training-step
+// fixture); these kernels reuse the tested 128x128 MFMA mainloop (gemm.h) and simple wave-per-row reductions and
+// are not tuned yet.  Activation gradients use the activation dtype, parameter gradients are f32 and ACCUMULATE.
+#include "gemm.h"
+#include "internal.h"
+
+// ---------------------------------------------------------------------------------------------------------
+// batched transpose: y[b][c][r] = x[b][r][c]
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x, T* __restrict__ y, int rows,
+                                                        int cols, int ld_out) {
+  __shared__ T tile[32][33];
+  const int64_t boff = (int64_t)blockIdx.z * rows * cols;
+  const int64_t yoff = (int64_t)blockIdx.z * cols * ld_out;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = r0 + ty + i * 8, c = c0 + tx;
+    if (r < rows && c < cols) tile[ty + i * 8][tx] = x[boff + (int64_t)r * cols + c];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = c0 + ty + i * 8, r = r0 + tx;
+    if (r < rows && c < cols) y[yoff + (int64_t)c * ld_out + r] = tile[tx][ty + i * 8];
+  }
+}
+
+// y rows have stride ld_out >= rows; columns [rows, ld_out) are left untouched (callers pre-zero padded buffers)
+extern "C" int xml_transpose_batched(const void* x, void* y, int batch, int rows, int cols, int ld_out, int dt,
+                                     xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !y || batch <= 0 || rows <= 0 || cols <= 0 || ld_out < rows) return XML_ERR_BAD_ARG;
+  dim3 grid(cdiv(cols, 32), cdiv(rows, 32), batch);
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, rows, cols, ld_out);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(transpose_kernel<bf16_t>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, rows, cols, ld_out);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// column sums: out[c] (+)= sum_r x[r][c]   (bias / positional-table gradients)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, float* __restrict__ out, int64_t rows,
+                                                     int cols, int64_t rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float s = 0.f;
+  for (int64_t r = r0; r < r1; ++r) s += DT<T>::ld(x + r * cols + c);
+  atomicAdd(out + c, s);
+}
+
+extern "C" int xml_colsum(const void* x, int x_dt, float* out, int64_t rows, int cols, int accumulate,
+                          xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !out || rows <= 0 || cols <= 0) return XML_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (!accumulate && hipMemsetAsync(out, 0, (size_t)cols * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  const int64_t rpb = 256;
+  dim3 grid(cdiv(cols, 256), cdiv(rows, rpb));
+  if (x_dt == XML_F32)
+    hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, rows, cols, rpb);
+  else if (x_dt == XML_BF16)
+    hipLaunchKernelGGL(colsum_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, out, rows, cols, rpb);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// elementwise: relu backward, in-place add, scaled copy to f32 accumulators
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void relu_bwd_kernel(const T* __restrict__ y, const T* __restrict__ dy, T* __restrict__ dx, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    DT<T>::st(dx + i, DT<T>::ld(y + i) > 0.f ? DT<T>::ld(dy + i) : 0.f);
+}
+template <typename Y, typename X>
+__global__ void add_inplace_kernel(Y* __restrict__ y, const X* __restrict__ x, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    DT<Y>::st(y + i, DT<Y>::ld(y + i) + DT<X>::ld(x + i));
+}
+static inline int ew_grid(int64_t n) { return (int)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192); }
+
+extern "C" int xml_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!y || !dy || !dx || n <= 0) return XML_ERR_BAD_ARG;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(relu_bwd_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)y, (const float*)dy, (float*)dx, n);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(relu_bwd_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, n);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// y (y_dt) += x (x_dt)
+extern "C" int xml_add_inplace(void* y, int y_dt, const void* x, int x_dt, int64_t n, xml_stream_t stream) {
+  XML_ENTER();
+  if (!y || !x || n <= 0) return XML_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 g(ew_grid(n)), b(256);
+  if (y_dt == XML_F32 && x_dt == XML_F32) hipLaunchKernelGGL((add_inplace_kernel<float, float>), g, b, 0, st, (float*)y, (const float*)x, n);
+  else if (y_dt == XML_F32 && x_dt == XML_BF16) hipLaunchKernelGGL((add_inplace_kernel<float, bf16_t>), g, b, 0, st, (float*)y, (const bf16_t*)x, n);
+  else if (y_dt == XML_BF16 && x_dt == XML_BF16) hipLaunchKernelGGL((add_inplace_kernel<bf16_t, bf16_t>), g, b, 0, st, (bf16_t*)y, (const bf16_t*)x, n);
+  else if (y_dt == XML_BF16 && x_dt == XML_F32) hipLaunchKernelGGL((add_inplace_kernel<bf16_t, float>), g, b, 0, st, (bf16_t*)y, (const float*)x, n);
+  else return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LayerNorm backward.  x = a (+ b);  y = (x - mean) * rstd * g + beta
+//   dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat * xhat)),  dxhat = dy * g
+//   dg += sum_rows dy * xhat,  dbeta += sum_rows dy          (f32, accumulated with one atomic per column per block)
+// One wave per row (d <= 1024 values in registers); a block walks ROWS_PER_BLOCK rows and keeps column partials.
+// ---------------------------------------------------------------------------------------------------------
+template <typename InT, typename BT, typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restrict__ a, const BT* __restrict__ b,
+                                                            const float* __restrict__ g, const T* __restrict__ dy,
+                                                            T* __restrict__ dx, float* __restrict__ dg,
+                                                            float* __restrict__ dbeta, int64_t rows, int d,
+                                                            float eps, int rows_per_wave) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float pg[16], pb[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) { pg[k] = 0.f; pb[k] = 0.f; }
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const int64_t row = row0 + rr;
+    if (row >= rows) break;
+    float x[16], gy[16];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + k * 64;
+      x[k] = (i < d) ? DT<InT>::ld(a + row * d + i) + (b ? DT<BT>::ld(b + row * d + i) : 0.f) : 0.f;
+      s += x[k];
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float v = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float c = (lane + k * 64 < d) ? x[k] - mean : 0.f;
+      v += c * c;
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + k * 64;
+      if (i < d) {
+        const float xh = (x[k] - mean) * rstd;
+        const float dyv = DT<T>::ld(dy + row * d + i);
+        x[k] = xh;
+        gy[k] = dyv * g[i];
+        s1 += gy[k];
+        s2 += gy[k] * xh;
+        pg[k] += dyv * xh;
+        pb[k] += dyv;
+      } else {
+        gy[k] = 0.f;
+      }
+    }
+    s1 = wave_sum(s1) / (float)d;
+    s2 = wave_sum(s2) / (float)d;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = lane + k * 64;
+      if (i < d) DT<T>::st(dx + row * d + i, rstd * (gy[k] - s1 - x[k] * s2));
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int i = lane + k * 64;
+    if (i < d) {
+      if (dg) atomicAdd(dg + i, pg[k]);
+      if (dbeta) atomicAdd(dbeta + i, pb[k]);
+    }
+  }
+}
+
+// wide rows (d > 1024, e.g. the 3072-d input LayerNorm): row statistics -> column sums -> elementwise dx
+template <typename InT, typename T>
+__global__ __launch_bounds__(256) void ln_bwd_stats_kernel(const InT* __restrict__ a, const float* __restrict__ g,
+                                                           const T* __restrict__ dy, float* __restrict__ stats,
+                                                           int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const InT* pa = a + row * d;
+  float s = 0.f;
+  for (int i = lane; i < d; i += 64) s += DT<InT>::ld(pa + i);
+  const float mean = wave_sum(s) / (float)d;
+  float v = 0.f;
+  for (int i = lane; i < d; i += 64) { const float c = DT<InT>::ld(pa + i) - mean; v += c * c; }
+  const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+  float s1 = 0.f, s2 = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const float gy = DT<T>::ld(dy + row * d + i) * g[i];
+    s1 += gy;
+    s2 += gy * (DT<InT>::ld(pa + i) - mean) * rstd;
+  }
+  s1 = wave_sum(s1) / (float)d;
+  s2 = wave_sum(s2) / (float)d;
+  if (lane == 0) { stats[row * 4 + 0] = mean; stats[row * 4 + 1] = rstd; stats[row * 4 + 2] = s1; stats[row * 4 + 3] = s2; }
+}
+template <typename InT, typename T>
+__global__ __launch_bounds__(256) void ln_bwd_cols_kernel(const InT* __restrict__ a, const float* __restrict__ g,
+                                                          const T* __restrict__ dy, const float* __restrict__ stats,
+                                                          T* __restrict__ dx, float* __restrict__ dg,
+                                                          float* __restrict__ dbeta, int64_t rows, int d,
+                                                          int64_t rows_per_block) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= d) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  const float gc = g[c];
+  float pg = 0.f, pb = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const float mean = stats[r * 4], rstd = stats[r * 4 + 1];
+    const float xh = (DT<InT>::ld(a + r * d + c) - mean) * rstd;
+    const float dyv = DT<T>::ld(dy + r * d + c);
+    pg += dyv * xh;
+    pb += dyv;
+    if (dx) DT<T>::st(dx + r * d + c, rstd * (dyv * gc - stats[r * 4 + 2] - xh * stats[r * 4 + 3]));
+  }
+  if (dg) atomicAdd(dg + c, pg);
+  if (dbeta) atomicAdd(dbeta + c, pb);
+}
+
+template <typename InT, typename T>
+static int ln_bwd_wide(const void* a, const float* g, const void* dy, void* dx, float* dg, float* dbeta, int64_t rows,
+                       int d, float* stats, hipStream_t st) {
+  hipLaunchKernelGGL((ln_bwd_stats_kernel<InT, T>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const InT*)a, g, (const T*)dy,
+                     stats, rows, d, 1e-5f);
+  const int64_t rpb = 64;
+  hipLaunchKernelGGL((ln_bwd_cols_kernel<InT, T>), dim3(cdiv(d, 256), cdiv(rows, rpb)), dim3(256), 0, st, (const InT*)a,
+                     g, (const T*)dy, stats, (T*)dx, dg, dbeta, rows, d, rpb);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// dx may be NULL only on the wide path (input features need no gradient); ws: rows*16 bytes, needed when d > 1024
+extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx,
+                                 float* dg, float* dbeta, int64_t rows, int d, int dt, void* ws, size_t ws_bytes,
+                                 xml_stream_t stream) {
+  XML_ENTER();
+  if (!a || !g || !dy || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (d > 1024) {
+    if (b) return XML_ERR_UNSUPPORTED;
+    if (!ws || ws_bytes < (size_t)rows * 16) return XML_ERR_WORKSPACE;
+    if (dt == XML_F32 && a_dt == XML_F32) return ln_bwd_wide<float, float>(a, g, dy, dx, dg, dbeta, rows, d, (float*)ws, st);
+    if (dt == XML_BF16 && a_dt == XML_F32) return ln_bwd_wide<float, bf16_t>(a, g, dy, dx, dg, dbeta, rows, d, (float*)ws, st);
+    if (dt == XML_BF16 && a_dt == XML_BF16) return ln_bwd_wide<bf16_t, bf16_t>(a, g, dy, dx, dg, dbeta, rows, d, (float*)ws, st);
+    return XML_ERR_BAD_ARG;
+  }
+  if (!dx) return XML_ERR_BAD_ARG;
+  const int rpw = 8;
+  const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
+  if (dt == XML_F32) {
+    if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float, float, float>), grid, blk, 0, st, (const float*)a, (const float*)b, g,
+                       (const float*)dy, (float*)dx, dg, dbeta, rows, d, 1e-5f, rpw);
+  } else if (dt == XML_BF16) {
+    if (a_dt == XML_F32)
+      hipLaunchKernelGGL((layernorm_bwd_kernel<float, bf16_t, bf16_t>), grid, blk, 0, st, (const float*)a, (const bf16_t*)b,
+                         g, (const bf16_t*)dy, (bf16_t*)dx, dg, dbeta, rows, d, 1e-5f, rpw);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, bf16_t>), grid, blk, 0, st, (const bf16_t*)a,
+                         (const bf16_t*)b, g, (const bf16_t*)dy, (bf16_t*)dx, dg, dbeta, rows, d, 1e-5f, rpw);
+  } else {
+    return XML_ERR_BAD_ARG;
+  }
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// contiguous batched GEMM: out[z] = scale * A[z] B[z]^T,  A (M,K), B (N,K) K-contiguous, out (M,N) as T or f32
+// ---------------------------------------------------------------------------------------------------------
+template <typename T, typename OutT>
+__global__ __launch_bounds__(256) void gemm_batched_kernel(const T* __restrict__ A, const T* __restrict__ B,
+                                                           OutT* __restrict__ out, int M, int N, int K, float scale) {
+  using Cfg = GemmCfg<T, 128, 128, 2, 2>;
+  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
+  const int64_t z = blockIdx.z;
+  const T* Az = A + z * (int64_t)M * K;
+  const T* Bz = B + z * (int64_t)N * K;
+  OutT* Oz = out + z * (int64_t)M * N;
+  const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
+  f32x4 acc[Cfg::MT][Cfg::NT];
+  auto a_row = [&](int r) -> const char* { return (m0 + r) < M ? reinterpret_cast<const char*>(Az + (int64_t)(m0 + r) * K) : nullptr; };
+  auto b_row = [&](int r) -> const char* { return (n0 + r) < N ? reinterpret_cast<const char*>(Bz + (int64_t)(n0 + r) * K) : nullptr; };
+  gemm_mainloop<T, Cfg>(acc, a_row, b_row, K * (int)sizeof(T), smem);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+#pragma unroll
+  for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < Cfg::NT; ++nt) {
+      const int n = n0 + wn * 64 + nt * 16 + (lane & 15);
+      if (n >= N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + mt * 16 + (lane >> 4) * 4 + r;
+        if (m < M) DT<OutT>::st(Oz + (int64_t)m * N + n, acc[mt][nt][r] * scale);
+      }
+    }
+}
+
+extern "C" int xml_gemm_batched(const void* A, const void* B, void* out, int batch, int M, int N, int K, float scale,
+                                int out_f32, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!A || !B || !out || batch <= 0 || M <= 0 || N <= 0 || K <= 0) return XML_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(cdiv(N, 128), cdiv(M, 128), batch);
+  if (dt == XML_F32) {
+    if (K % 4) return XML_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL((gemm_batched_kernel<float, float>), grid, dim3(256), 0, st, (const float*)A, (const float*)B,
+                       (float*)out, M, N, K, scale);
+  } else if (dt == XML_BF16) {
+    if (K % 8) return XML_ERR_UNSUPPORTED;
+    if (out_f32)
+      hipLaunchKernelGGL((gemm_batched_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B,
+                         (float*)out, M, N, K, scale);
+    else
+      hipLaunchKernelGGL((gemm_batched_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)A,
+                         (const bf16_t*)B, (bf16_t*)out, M, N, K, scale);
+  } else {
+    return XML_ERR_BAD_ARG;
+  }
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// head split / merge between the (n*L, ld) token-major layout and per-(sequence, head) contiguous matrices
+//   dst  [n][h][l8][dh]   (rows >= L zero)      dstT [n][h][dh][l8]   (columns >= L zero)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ void split_heads_kernel(const T* __restrict__ src, int ld, int col0, int L, int l8, int heads, int dh,
+                                   T* __restrict__ dst, T* __restrict__ dstT, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % dh);
+    const int l = (int)((i / dh) % l8);
+    const int h = (int)((i / ((int64_t)dh * l8)) % heads);
+    const int64_t n = i / ((int64_t)dh * l8 * heads);
+    T v = 0;
+    if (l < L) v = src[(n * L + l) * ld + col0 + h * dh + d];
+    if (dst) dst[i] = v;
+    if (dstT) dstT[((n * heads + h) * dh + d) * l8 + l] = v;
+  }
+}
+template <typename T>
+__global__ void merge_heads_kernel(const T* __restrict__ src, T* __restrict__ dst, int ld, int col0, int L, int l8,
+                                   int heads, int dh, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % dh);
+    const int h = (int)((i / dh) % heads);
+    const int l = (int)((i / ((int64_t)dh * heads)) % L);
+    const int64_t n = i / ((int64_t)dh * heads * L);
+    dst[(n * L + l) * ld + col0 + h * dh + d] = src[((n * heads + h) * l8 + l) * dh + d];
+  }
+}
+
+extern "C" int xml_split_heads(const void* src, int ld, int col0, int64_t n, int L, int l8, int heads, int dh, void* dst,
+                               void* dstT, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!src || (!dst && !dstT) || n <= 0 || L <= 0 || l8 < L) return XML_ERR_BAD_ARG;
+  const int64_t total = n * heads * l8 * dh;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(split_heads_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld, col0, L, l8, heads, dh, (float*)dst, (float*)dstT, total);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(split_heads_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld, col0, L, l8, heads, dh, (bf16_t*)dst, (bf16_t*)dstT, total);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+extern "C" int xml_merge_heads(const void* src, void* dst, int ld, int col0, int64_t n, int L, int l8, int heads, int dh,
+                               int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!src || !dst || n <= 0 || L <= 0 || l8 < L) return XML_ERR_BAD_ARG;
+  const int64_t total = n * L * heads * dh;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(merge_heads_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, ld, col0, L, l8, heads, dh, total);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(merge_heads_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, ld, col0, L, l8, heads, dh, total);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// attention softmax (recompute) and its backward on materialised per-head score matrices
+//   S (f32) [n*h][lq8][lk8] raw QK^T;   P = softmax_j( S / sqrt_dh + (1 - qm*km) * -1e4 )  over j < lk
+//   fwd writes P and P^T (T, zero padded);  bwd: dS = P * (dP - sum_j P*dP) / sqrt_dh  -> dS, dS^T (T)
+// one wave per (batch, query row); lk <= 128
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void attn_softmax_kernel(const float* __restrict__ S, const float* __restrict__ dP,
+                                                           const float* __restrict__ q_mask,
+                                                           const float* __restrict__ k_mask, T* __restrict__ P,
+                                                           T* __restrict__ PT, T* __restrict__ dS, T* __restrict__ dST,
+                                                           int heads, int lq, int lk, int lq8, int lk8, float sqrt_dh,
+                                                           int64_t total_rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= total_rows) return;
+  const int i = (int)(row % lq8);
+  const int64_t z = row / lq8;               // (sequence, head)
+  const int64_t n = z / heads;
+  const float* srow = S + (z * lq8 + i) * lk8;
+  const float qm = (q_mask && i < lq) ? q_mask[n * lq + i] : 1.f;
+  float p[2], mx = -INFINITY;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = lane + h * 64;
+    float s = -INFINITY;
+    if (i < lq && j < lk) s = srow[j] / sqrt_dh + (1.f - qm * k_mask[n * lk + j]) * -10000.f;
+    p[h] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    p[h] = (i < lq) ? expf(p[h] - mx) : 0.f;
+    sum += p[h];
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) p[h] = (i < lq) ? p[h] / sum : 0.f;
+  if (!dP) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int j = lane + h * 64;
+      if (j < lk8) {
+        DT<T>::st(P + (z * lq8 + i) * lk8 + j, p[h]);
+        if (PT) DT<T>::st(PT + (z * lk8 + j) * lq8 + i, p[h]);
+      }
+    }
+    return;
+  }
+  const float* drow = dP + (z * lq8 + i) * lk8;
+  float dp[2], dot = 0.f;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = lane + h * 64;
+    dp[h] = (i < lq && j < lk) ? drow[j] : 0.f;
+    dot += p[h] * dp[h];
+  }
+  dot = wave_sum(dot);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int j = lane + h * 64;
+    if (j < lk8) {
+      const float v = p[h] * (dp[h] - dot) / sqrt_dh;
+      DT<T>::st(dS + (z * lq8 + i) * lk8 + j, v);
+      DT<T>::st(dST + (z * lk8 + j) * lq8 + i, v);
+    }
+  }
+}
+
+// dP == NULL: forward (writes P, optionally P^T);  dP != NULL: backward (writes dS and dS^T)
+extern "C" int xml_attn_softmax(const float* S, const float* dP, const float* q_mask, const float* k_mask, void* P,
+                                void* PT, void* dS, void* dST, int64_t n, int heads, int lq, int lk, int lq8, int lk8,
+                                float sqrt_dh, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!S || !k_mask || n <= 0 || lq <= 0 || lk <= 0 || lk > 128 || lk8 > 128) return XML_ERR_BAD_ARG;
+  if ((!dP && !P) || (dP && (!dS || !dST))) return XML_ERR_BAD_ARG;
+  const int64_t rows = n * heads * lq8;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(attn_softmax_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, S, dP, q_mask,
+                       k_mask, (float*)P, (float*)PT, (float*)dS, (float*)dST, heads, lq, lk, lq8, lk8, sqrt_dh, rows);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(attn_softmax_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, S, dP, q_mask,
+                       k_mask, (bf16_t*)P, (bf16_t*)PT, (bf16_t*)dS, (bf16_t*)dST, heads, lq, lk, lq8, lk8, sqrt_dh, rows);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// modular query pooling backward (forward: attention.hip modular_pool_kernel; xml/model_xml.py:410-423)
+//   a = softmax_l(mask_logits(enc w_m)),  mq[m] = sum_l a[l][m] enc[l]
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void modular_pool_bwd_kernel(const T* __restrict__ enc, const float* __restrict__ mask,
+                                                               const float* __restrict__ wm, const T* __restrict__ dout,
+                                                               T* __restrict__ denc, float* __restrict__ dwm, int64_t n,
+                                                               int lq, int hidden, int n_mod) {
+  __shared__ float s_att[2][128], s_da[2][128], s_dsc[2][128];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* e = enc + (int64_t)q * lq * hidden;
+  for (int l = wave; l < lq; l += 4)
+    for (int m = 0; m < n_mod; ++m) {
+      const T* dm = dout + ((int64_t)m * n + q) * hidden;
+      float s = 0.f, d = 0.f;
+      for (int h = lane; h < hidden; h += 64) {
+        const float ev = DT<T>::ld(e + (int64_t)l * hidden + h);
+        s += ev * wm[m * hidden + h];
+        d += ev * DT<T>::ld(dm + h);
+      }
+      s = wave_sum(s);
+      d = wave_sum(d);
+      if (lane == 0) {
+        const float mk = mask[(int64_t)q * lq + l];
+        s_att[m][l] = s * mk + (1.f - mk) * -1e10f;
+        s_da[m][l] = d;
+      }
+    }
+  __syncthreads();
+  if (tid < n_mod) {
+    float mx = -INFINITY;
+    for (int l = 0; l < lq; ++l) mx = fmaxf(mx, s_att[tid][l]);
+    float sum = 0.f;
+    for (int l = 0; l < lq; ++l) { const float ev = expf(s_att[tid][l] - mx); s_att[tid][l] = ev; sum += ev; }
+    float dot = 0.f;
+    for (int l = 0; l < lq; ++l) { s_att[tid][l] /= sum; dot += s_att[tid][l] * s_da[tid][l]; }
+    for (int l = 0; l < lq; ++l)
+      s_dsc[tid][l] = s_att[tid][l] * (s_da[tid][l] - dot) * mask[(int64_t)q * lq + l];
+  }
+  __syncthreads();
+  for (int h = tid; h < hidden; h += 256) {
+    float dw[2] = {0.f, 0.f}, dm[2] = {0.f, 0.f}, w[2] = {0.f, 0.f};
+    for (int m = 0; m < n_mod; ++m) {
+      dm[m] = DT<T>::ld(dout + ((int64_t)m * n + q) * hidden + h);
+      w[m] = wm[m * hidden + h];
+    }
+    for (int l = 0; l < lq; ++l) {
+      const float ev = DT<T>::ld(e + (int64_t)l * hidden + h);
+      float g = 0.f;
+      for (int m = 0; m < n_mod; ++m) {
+        g += s_att[m][l] * dm[m] + s_dsc[m][l] * w[m];
+        dw[m] += s_dsc[m][l] * ev;
+      }
+      DT<T>::st(denc + ((int64_t)q * lq + l) * hidden + h, g);
+    }
+    for (int m = 0; m < n_mod; ++m) atomicAdd(dwm + m * hidden + h, dw[m]);
+  }
+}
+
+extern "C" int xml_modular_pool_bwd(const void* enc, const float* mask, const float* w_m, const void* dout, void* denc,
+                                    float* dw_m, int64_t n, int lq, int hidden, int n_mod, int dt,
+                                    xml_stream_t stream) {
+  XML_ENTER();
+  if (!enc || !mask || !w_m || !dout || !denc || !dw_m || n <= 0 || lq <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (n_mod < 1 || n_mod > 2 || lq > 128) return XML_ERR_UNSUPPORTED;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(modular_pool_bwd_kernel<float>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const float*)enc, mask, w_m, (const float*)dout, (float*)denc, dw_m, n, lq, hidden, n_mod);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(modular_pool_bwd_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)enc, mask, w_m, (const bf16_t*)dout, (bf16_t*)denc, dw_m, n, lq, hidden, n_mod);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// F.normalize backward: y = x / max(|x|, eps);  dx = (dy - y (y . dy)) / max(|x|, eps)    dy is f32
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const T* __restrict__ x, const float* __restrict__ dy,
+                                                         T* __restrict__ dx, int64_t rows, int d, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  float ss = 0.f, xd = 0.f;
+  for (int i = lane; i < d; i += 64) {
+    const float v = DT<T>::ld(x + row * d + i);
+    ss += v * v;
+    xd += v * dy[row * d + i];
+  }
+  ss = wave_sum(ss);
+  xd = wave_sum(xd);
+  const float nrm = sqrtf(ss);
+  const float den = fmaxf(nrm, eps);
+  for (int i = lane; i < d; i += 64) {
+    const float v = DT<T>::ld(x + row * d + i);
+    // norm clamped at eps is a constant: only the (dy / den) term survives there
+    const float g = nrm > eps ? (dy[row * d + i] - v * xd / (den * den)) / den : dy[row * d + i] / den;
+    DT<T>::st(dx + row * d + i, g);
+  }
+}
+
+extern "C" int xml_l2norm_bwd(const void* x, const float* dy, void* dx, int64_t rows, int d, int dt,
+                              xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !dy || !dx || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(l2norm_bwd_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x, dy, (float*)dx, rows, d, 1e-12f);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(l2norm_bwd_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, dy, (bf16_t*)dx, rows, d, 1e-12f);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// in-batch video-level scores backward (forward: xml_q2c_scores; xml/model_xml.py:436-453)
+//   scores[m][n] = max_l mask_logits(qn[m] . cn[n][l]);  the gradient goes to the arg-max clip (first on ties)
+//   dqn / dcn are f32 and are ZEROED here; pairs with dscores == 0 are skipped (the ranking loss touches <= 3N pairs)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void q2c_scores_bwd_kernel(const T* __restrict__ qn, const T* __restrict__ cn,
+                                                             const float* __restrict__ mask,
+                                                             const float* __restrict__ dscores, int ld_ds,
+                                                             float scale, float* __restrict__ dqn,
+                                                             float* __restrict__ dcn, int nq, int nv, int L,
+                                                             int hidden) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.x;
+  if (m >= nq) return;
+  const float g = dscores[(int64_t)m * ld_ds + n] * scale;
+  if (g == 0.f) return;
+  const T* q = qn + (int64_t)m * hidden;
+  float best = -INFINITY;
+  int best_l = 0x7fffffff;
+  for (int l = lane; l < L; l += 64) {
+    const T* c = cn + ((int64_t)n * L + l) * hidden;
+    float s = 0.f;
+    for (int h = 0; h < hidden; ++h) s += DT<T>::ld(q + h) * DT<T>::ld(c + h);
+    const float mk = mask[(int64_t)n * L + l];
+    s = s * mk + (1.f - mk) * -1e10f;
+    if (s > best) { best = s; best_l = l; }
+  }
+  for (int off = 32; off; off >>= 1) {
+    const float ob = __shfl_xor(best, off);
+    const int ol = __shfl_xor(best_l, off);
+    if (ob > best || (ob == best && ol < best_l)) { best = ob; best_l = ol; }
+  }
+  const float gm = g * mask[(int64_t)n * L + best_l];
+  if (gm == 0.f) return;
+  const T* c = cn + ((int64_t)n * L + best_l) * hidden;
+  for (int h = lane; h < hidden; h += 64) {
+    atomicAdd(dqn + (int64_t)m * hidden + h, gm * DT<T>::ld(c + h));
+    atomicAdd(dcn + ((int64_t)n * L + best_l) * hidden + h, gm * DT<T>::ld(q + h));
+  }
+}
+
+extern "C" int xml_q2c_scores_bwd(const void* qn, const void* cn, const float* mask, const float* dscores, int64_t ld_ds,
+                                  float scale, float* dqn, float* dcn, int nq, int nv, int l, int hidden, int dt,
+                                  xml_stream_t stream) {
+  XML_ENTER();
+  if (!qn || !cn || !mask || !dscores || !dqn || !dcn || nq <= 0 || nv <= 0 || l <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dqn, 0, (size_t)nq * hidden * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  if (hipMemsetAsync(dcn, 0, (size_t)nv * l * hidden * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  dim3 grid(nv, cdiv(nq, 4));
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(q2c_scores_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)qn, (const float*)cn, mask, dscores, (int)ld_ds, scale, dqn, dcn, nq, nv, l, hidden);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(q2c_scores_bwd_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qn, (const bf16_t*)cn, mask, dscores, (int)ld_ds, scale, dqn, dcn, nq, nv, l, hidden);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// paired query-clip similarity (cross=False branch, einsum("bd,bld->bl"), xml/model_xml.py:478-479,532)
+// ---------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void pair_sim_kernel(const T* __restrict__ q, const T* __restrict__ f2,
+                                                       float* __restrict__ sim, int64_t n, int L, int hidden) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (b, l)
+  if (row >= n * L) return;
+  const int64_t b = row / L;
+  float s = 0.f;
+  for (int h = lane; h < hidden; h += 64) s += DT<T>::ld(q + b * hidden + h) * DT<T>::ld(f2 + row * hidden + h);
+  s = wave_sum(s);
+  if (lane == 0) sim[row] = s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void pair_sim_bwd_kernel(const T* __restrict__ q, const T* __restrict__ f2,
+                                                           const float* __restrict__ dsim, T* __restrict__ dq,
+                                                           T* __restrict__ df2, int L, int hidden) {
+  const int64_t b = blockIdx.x;
+  for (int h = threadIdx.x; h < hidden; h += 256) {
+    const float qv = DT<T>::ld(q + b * hidden + h);
+    float acc = 0.f;
+    for (int l = 0; l < L; ++l) {
+      const float g = dsim[b * L + l];
+      acc += g * DT<T>::ld(f2 + (b * L + l) * hidden + h);
+      DT<T>::st(df2 + (b * L + l) * hidden + h, g * qv);
+    }
+    DT<T>::st(dq + b * hidden + h, acc);
+  }
+}
+
+extern "C" int xml_pair_sim(const void* q, const void* f2, float* sim, int64_t n, int l, int hidden, int dt,
+                            xml_stream_t stream) {
+  XML_ENTER();
+  if (!q || !f2 || !sim || n <= 0 || l <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(pair_sim_kernel<float>, dim3(cdiv(n * l, 4)), dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)f2, sim, n, l, hidden);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(pair_sim_kernel<bf16_t>, dim3(cdiv(n * l, 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)f2, sim, n, l, hidden);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+extern "C" int xml_pair_sim_bwd(const void* q, const void* f2, const float* dsim, void* dq, void* df2, int64_t n, int l,
+                                int hidden, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!q || !f2 || !dsim || !dq || !df2 || n <= 0 || l <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(pair_sim_bwd_kernel<float>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)f2, dsim, (float*)dq, (float*)df2, l, hidden);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(pair_sim_bwd_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)f2, dsim, (bf16_t*)dq, (bf16_t*)df2, l, hidden);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// span (start / end) loss head, forward and backward in one kernel (xml/model_xml.py:237-240,478-500,532-550):
+//   merged : s = (sim0 + sim1) / 2 ; st = mask_logits(conv(s, w_st), mask0)
+//   split  : st = sum_i mask_logits(conv(sim_i, w_st_i), mask_i) / n_sim
+//   loss   = mean_b [ CE(st_b, idx_st_b) + CE(ed_b, idx_ed_b) ]
+// conv_w = [st filters (n_filt x ks) | ed filters (n_filt x ks)], n_filt = merged ? 1 : n_sim.
+// gout == NULL: writes loss_out (pre-zeroed by the entry).  gout != NULL: writes dsim_i and accumulates dconv_w,
+// all scaled by *gout.  One wave per batch row, L <= 128.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void span_loss_kernel(const float* __restrict__ sim0, const float* __restrict__ sim1,
+                                                        const float* __restrict__ conv_w,
+                                                        const float* __restrict__ mask0, const float* __restrict__ mask1,
+                                                        const int64_t* __restrict__ st_ed, int merged, int n_sim, int ks,
+                                                        int n, int L, const float* __restrict__ gout,
+                                                        float* __restrict__ loss_out, float* __restrict__ dsim0,
+                                                        float* __restrict__ dsim1, float* __restrict__ dconv_w) {
+  __shared__ float s_sim[4][2][160];    // per wave, per stream, zero halo of 16 on both sides
+  __shared__ float s_dc[4][2][160];     // d(conv output) per filter
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= n) return;
+  const int pad = ks / 2;
+  const int n_filt = merged ? 1 : n_sim;
+  float (*S)[160] = s_sim[wave];
+  float (*DC)[160] = s_dc[wave];
+  for (int i = lane; i < 160; i += 64) { S[0][i] = 0.f; S[1][i] = 0.f; }
+  for (int l = lane; l < L; l += 64) {
+    const float a = sim0[(int64_t)b * L + l];
+    const float c = n_sim > 1 ? sim1[(int64_t)b * L + l] : 0.f;
+    if (merged) S[0][16 + l] = (a + c) * 0.5f;
+    else { S[0][16 + l] = a; S[1][16 + l] = c; }
+  }
+  __builtin_amdgcn_wave_barrier();
+  float total = 0.f;
+  for (int se = 0; se < 2; ++se) {              // 0 = start head, 1 = end head
+    const float* w = conv_w + se * n_filt * ks;
+    const int target = (int)st_ed[(int64_t)b * 2 + se];
+    float logit[2], mx = -INFINITY;
+    for (int h = 0; h < 2; ++h) {
+      const int l = lane + h * 64;
+      float v = -INFINITY;
+      if (l < L) {
+        v = 0.f;
+        for (int f = 0; f < n_filt; ++f) {
+          float c = 0.f;
+          for (int t = 0; t < ks; ++t) c += w[f * ks + t] * S[f][16 + l + t - pad];
+          const float mk = (f == 0 ? mask0 : mask1)[(int64_t)b * L + l];
+          v += c * mk + (1.f - mk) * -1e10f;
+        }
+        if (!merged) v /= (float)n_sim;
+      }
+      logit[h] = v;
+      mx = fmaxf(mx, v);
+    }
+    mx = wave_max(mx);
+    float sum = 0.f;
+    for (int h = 0; h < 2; ++h) sum += (lane + h * 64 < L) ? expf(logit[h] - mx) : 0.f;
+    sum = wave_sum(sum);
+    const float lse = mx + logf(sum);
+    float tl = 0.f;
+    for (int h = 0; h < 2; ++h) if (lane + h * 64 == target) tl = logit[h];
+    tl = wave_sum(tl);
+    total += lse - tl;
+    if (gout) {
+      const float go = gout[0] / (float)n;
+      for (int i = lane; i < 160; i += 64) { DC[0][i] = 0.f; DC[1][i] = 0.f; }
+      __builtin_amdgcn_wave_barrier();
+      for (int h = 0; h < 2; ++h) {
+        const int l = lane + h * 64;
+        if (l < L) {
+          float dl = (expf(logit[h] - lse) - (l == target ? 1.f : 0.f)) * go;
+          if (!merged) dl /= (float)n_sim;
+          for (int f = 0; f < n_filt; ++f) DC[f][16 + l] = dl * (f == 0 ? mask0 : mask1)[(int64_t)b * L + l];
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int f = 0; f < n_filt; ++f) {
+        for (int t = 0; t < ks; ++t) {       // dw[t] = sum_l dc[l] * s[l + t - pad]
+          float a = 0.f;
+          for (int l = lane; l < L; l += 64) a += DC[f][16 + l] * S[f][16 + l + t - pad];
+          a = wave_sum(a);
+          if (lane == 0) atomicAdd(dconv_w + (se * n_filt + f) * ks + t, a);
+        }
+        for (int l = lane; l < L; l += 64) {  // ds[l] = sum_t w[t] * dc[l - t + pad]
+          float a = 0.f;
+          for (int t = 0; t < ks; ++t) a += w[f * ks + t] * DC[f][16 + l - t + pad];
+          if (merged) {
+            atomicAdd(dsim0 + (int64_t)b * L + l, 0.5f * a);
+            if (n_sim > 1) atomicAdd(dsim1 + (int64_t)b * L + l, 0.5f * a);
+          } else {
+            atomicAdd((f == 0 ? dsim0 : dsim1) + (int64_t)b * L + l, a);
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  if (!gout && lane == 0) atomicAdd(loss_out, total / (float)n);
+}
+
+extern "C" int xml_span_loss(const float* sim0, const float* sim1, const float* conv_w, const float* mask0,
+                             const float* mask1, const int64_t* st_ed, int merged, int n_sim, int ks, int n, int l,
+                             const float* gout, float* loss_out, float* dsim0, float* dsim1, float* dconv_w,
+                             xml_stream_t stream) {
+  XML_ENTER();
+  if (!sim0 || !conv_w || !mask0 || !st_ed || n <= 0 || l <= 0) return XML_ERR_BAD_ARG;
+  if (n_sim < 1 || n_sim > 2 || (n_sim == 2 && (!sim1 || (!merged && !mask1))) || (merged && n_sim != 2)) return XML_ERR_BAD_ARG;
+  if (l > 128 || ks < 1 || ks > 31 || !(ks & 1)) return XML_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (!gout) {
+    if (!loss_out) return XML_ERR_BAD_ARG;
+    if (hipMemsetAsync(loss_out, 0, 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  } else {
+    if (!dsim0 || !dconv_w || (n_sim == 2 && !dsim1)) return XML_ERR_BAD_ARG;
+    const int n_filt = merged ? 1 : n_sim;
+    if (hipMemsetAsync(dsim0, 0, (size_t)n * l * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (n_sim == 2 && hipMemsetAsync(dsim1, 0, (size_t)n * l * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (hipMemsetAsync(dconv_w, 0, (size_t)2 * n_filt * ks * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(span_loss_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, sim0, sim1, conv_w, mask0, mask1 ? mask1 : mask0,
+                     st_ed, merged, n_sim, ks, n, l, gout, loss_out, dsim0, dsim1, dconv_w);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// in-batch ranking loss, forward and backward (get_video_level_loss / get_neg_scores / get_ranking_loss,
+// xml/model_xml.py:588-637).  For query i the negative context is the entry of row i (diagonal masked to 999,
+// sorted descending) at position ranks_ctx[i]; the negative query likewise on column i with ranks_q[i].
+//   losses[0] = mean_i rank(pos_i, neg_ctx_i)   losses[1] = mean_i rank(pos_i, neg_q_i)
+//   hinge: max(0, margin + neg - pos);  lse: log1p(exp(neg - pos))
+// grid (n, 2); gout == NULL: losses (pre-zeroed);  gout[2] != NULL: dscores (pre-zeroed) += gout[side] * d loss
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rank_loss_kernel(const float* __restrict__ scores, const int* __restrict__ ranks_ctx,
+                                                        const int* __restrict__ ranks_q, float margin, int lse, int n,
+                                                        const float* __restrict__ gout, float* __restrict__ losses,
+                                                        float* __restrict__ dscores) {
+  __shared__ float row[1024];
+  const int i = blockIdx.x, side = blockIdx.y;
+  auto at = [&](int a, int b2) { return side == 0 ? (int64_t)a * n + b2 : (int64_t)b2 * n + a; };
+  for (int j = threadIdx.x; j < n; j += 256) row[j] = (j == i) ? 999.f : scores[at(i, j)];
+  __syncthreads();
+  const int want = (side == 0 ? ranks_ctx : ranks_q)[i];
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float v = row[j];
+    int cnt = 0;
+    for (int k = 0; k < n; ++k) cnt += (row[k] > v || (row[k] == v && k < j)) ? 1 : 0;
+    if (cnt != want) continue;
+    const float pos = scores[(int64_t)i * n + i];
+    const float neg = scores[at(i, j)];
+    const float x = neg - pos;
+    if (!gout) {
+      const float lv = lse ? log1pf(expf(x)) : fmaxf(margin + x, 0.f);
+      atomicAdd(losses + side, lv / (float)n);
+    } else {
+      const float d = lse ? 1.f / (1.f + expf(-x)) : (margin + x > 0.f ? 1.f : 0.f);
+      const float g = gout[side] * d / (float)n;
+      if (g != 0.f) {
+        atomicAdd(dscores + at(i, j), g);
+        atomicAdd(dscores + (int64_t)i * n + i, -g);
+      }
+    }
+  }
+}
+
+extern "C" int xml_rank_loss(const float* scores, const int* ranks_ctx, const int* ranks_q, float margin, int lse, int n,
+                             const float* gout, float* losses, float* dscores, xml_stream_t stream) {
+  XML_ENTER();
+  if (!scores || !ranks_ctx || !ranks_q || n <= 0) return XML_ERR_BAD_ARG;
+  if (n > 1024) return XML_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (!gout) {
+    if (!losses) return XML_ERR_BAD_ARG;
+    if (hipMemsetAsync(losses, 0, 8, st) != hipSuccess) return XML_ERR_LAUNCH;
+  } else {
+    if (!dscores) return XML_ERR_BAD_ARG;
+    if (hipMemsetAsync(dscores, 0, (size_t)n * n * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(rank_loss_kernel, dim3(n, 2), dim3(256), 0, st, scores, ranks_ctx, ranks_q, margin, lse, n, gout,
+                     losses, dscores);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// BertAdam over one flat f32 parameter buffer (xml/optimization.py:273-338): per-TENSOR gradient-norm clip
+// (clip_grad_norm_(p, max_grad_norm), coefficient max_norm / (norm + 1e-6) clamped to 1, applied to the gradient
+// in place), no bias correction, decoupled weight decay, lr = seg_lr[s] * lr_mult (schedule multiplier).
+//   seg_off (n_seg + 1) int64: tensor s owns [seg_off[s], seg_off[s+1]).  norms: n_seg floats of scratch.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int find_seg(const int64_t* __restrict__ seg_off, int n_seg, int64_t i) {
+  int lo = 0, hi = n_seg - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (seg_off[mid] <= i) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+__global__ __launch_bounds__(256) void adam_norm_kernel(const float* __restrict__ g, const int64_t* __restrict__ seg_off,
+                                                        int n_seg, int64_t total, float* __restrict__ norms) {
+  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const bool valid = i0 < total;
+  const int s_first = valid ? find_seg(seg_off, n_seg, i0) : -1;
+  int s = s_first;
+  float acc = 0.f;
+  if (valid)
+    for (int k = 0; k < 4 && i0 + k < total; ++k) {
+      while (i0 + k >= seg_off[s + 1]) {      // crossed into the next tensor: flush
+        atomicAdd(norms + s, acc);
+        acc = 0.f;
+        ++s;
+      }
+      acc += g[i0 + k] * g[i0 + k];
+    }
+  // wave-level pre-reduction when the whole wave sits in one tensor
+  const int s0 = __shfl(s_first, 0);
+  if (__all(s_first == s0 && s == s0)) {
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0 && s0 >= 0) atomicAdd(norms + s0, acc);
+  } else if (valid) {
+    atomicAdd(norms + s, acc);
+  }
+}
+__global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                          float* __restrict__ v, const int64_t* __restrict__ seg_off,
+                                                          const float* __restrict__ seg_lr,
+                                                          const float* __restrict__ seg_wd, int n_seg, int64_t total,
+                                                          const float* __restrict__ norms, float lr_mult, float b1,
+                                                          float b2, float eps, float max_grad_norm) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const int s = find_seg(seg_off, n_seg, i);
+  float gi = g[i];
+  if (max_grad_norm > 0.f) {
+    const float coef = max_grad_norm / (sqrtf(norms[s]) + 1e-6f);
+    if (coef < 1.f) { gi *= coef; g[i] = gi; }
+  }
+  const float mi = m[i] * b1 + (1.f - b1) * gi;
+  const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+  m[i] = mi;
+  v[i] = vi;
+  float upd = mi / (sqrtf(vi) + eps);
+  const float wd = seg_wd[s];
+  if (wd > 0.f) upd += wd * p[i];
+  p[i] -= seg_lr[s] * lr_mult * upd;
+}
+
+extern "C" int xml_bert_adam_step(float* p, float* g, float* m, float* v, const int64_t* seg_off, const float* seg_lr,
+                                  const float* seg_wd, int n_seg, int64_t total, float lr_mult, float b1, float b2,
+                                  float eps, float max_grad_norm, float* norms, xml_stream_t stream) {
+  XML_ENTER();
+  if (!p || !g || !m || !v || !seg_off || !seg_lr || !seg_wd || !norms || n_seg <= 0 || total <= 0) return XML_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (max_grad_norm > 0.f) {
+    if (hipMemsetAsync(norms, 0, (size_t)n_seg * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(adam_norm_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, g, seg_off, n_seg, total, norms);
+  }
+  hipLaunchKernelGGL(adam_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p, g, m, v, seg_off, seg_lr, seg_wd,
+                     n_seg, total, norms, lr_mult, b1, b2, eps, max_grad_norm);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}

@@ -41,8 +41,14 @@ class _PackedMixin(object):
     """Caches device-dtype copies of a holder's parameters; re-packs when any parameter changed in place
     (optimizer step, load_state_dict) or moved (.to())."""
 
+    _generation = 0     # bumped by optimizers that update parameters through raw kernels (no _version change)
+
+    @staticmethod
+    def bump_generation():
+        _PackedMixin._generation += 1
+
     def _pack_key(self, dtype):
-        return (dtype,) + tuple((p.data_ptr(), p._version) for p in self.parameters())
+        return (dtype, _PackedMixin._generation) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self, dtype):
         key = self._pack_key(dtype)

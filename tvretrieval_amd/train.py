@@ -1,0 +1,338 @@
+"""One XML training step on HIP kernels: forward graph, hand-written backward, BertAdam, gradient all-reduce.
+
+Mirrors the reference's training inner loop (xml/train.py:62-111): `loss, loss_dict = model(**inputs)`;
+`optimizer.zero_grad(); loss.backward(); [clip_grad_norm_]; optimizer.step()`.
+
+  * `xml_forward_train(model, ...)` is XML.forward (xml/model_xml.py:212-251) assembled from the autograd nodes of
+    autograd.py -- every forward and backward op is a libxmlhip.so kernel; torch autograd only keeps the tape.
+  * `BertAdam` has the reference's constructor and schedule semantics (xml/optimization.py:219-338) but owns ONE flat
+    f32 buffer for parameters / gradients / moments and updates it with two kernel launches per step.
+  * `allreduce_gradients` averages the flat gradient buffer over ranks in size-bounded buckets (RCCL over xGMI,
+    one process per GPU); the reference has no multi-process training (it wraps nn.DataParallel, xml/train.py:236).
+
+Status: dropout (input_drop / drop / cross_att_drop, active in the reference's train mode) is not applied --
+parity is pinned on the eval-mode training-step fixture (tests/golden/train_step_video_sub_h128.npz).
+"""
+import math
+
+import torch
+
+from . import train_ops as T
+from .autograd import (AttentionCoreFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn, SpanLossFn,
+                       VideoLevelScoresFn)
+
+F32 = torch.float32
+
+
+class _PosTableFn(torch.autograd.Function):
+    """position_embeddings(arange(L)) broadcast over the batch (xml/model_components.py:83-87) in compute dtype;
+    backward = column sums over the batch."""
+
+    @staticmethod
+    def forward(ctx, weight, n, seq_len, dtype):
+        if seq_len > weight.shape[0]:
+            raise IndexError("sequence length %d exceeds the positional table (%d)" % (seq_len, weight.shape[0]))
+        from . import ops
+        rows = weight.detach()[:seq_len].contiguous()
+        rows = rows if dtype == F32 else ops.pack_weights(rows.float(), dtype)
+        ctx.shape = tuple(weight.shape)
+        ctx.n, ctx.seq_len = n, seq_len
+        return rows.unsqueeze(0).expand(n, seq_len, rows.shape[1]).contiguous()
+
+    @staticmethod
+    def backward(ctx, dy):
+        hidden = ctx.shape[1]
+        dw = torch.zeros(ctx.shape, dtype=F32, device=dy.device)
+        T.colsum(dy.contiguous(), ctx.n, ctx.seq_len * hidden, out=dw.view(-1)[:ctx.seq_len * hidden])
+        return dw, None, None, None
+
+
+def _bert_attention(mod, x, key_mask, dt):
+    """BertAttention = BertSelfAttention + BertSelfOutput (xml/model_components.py:201-216,313-317)."""
+    sa, so = mod.self, mod.output
+    q = LinearFn.apply(x, sa.query.weight, sa.query.bias, False)
+    k = LinearFn.apply(x, sa.key.weight, sa.key.bias, False)
+    v = LinearFn.apply(x, sa.value.weight, sa.value.bias, False)
+    a = AttentionCoreFn.apply(q, k, v, None, key_mask, sa.num_attention_heads)
+    d = LinearFn.apply(a, so.dense.weight, so.dense.bias, False)
+    return LayerNormFn.apply(d, x, so.LayerNorm.weight, so.LayerNorm.bias, dt)
+
+
+def _encode_input(model, feat, mask, proj, enc, pos):
+    """encode_input (xml/model_xml.py:377-392)."""
+    dt = model.compute_dtype
+    if feat.dtype not in (F32, dt):
+        feat = feat.float()
+    n, seq_len = feat.shape[:2]
+    x = LayerNormFn.apply(feat.contiguous(), None, proj.LayerNorm.weight, proj.LayerNorm.bias, dt)
+    x = LinearFn.apply(x, proj.net[1].weight, proj.net[1].bias, True)
+    p = _PosTableFn.apply(pos.position_embeddings.weight, n, seq_len, dt)
+    x = LayerNormFn.apply(x, p, pos.LayerNorm.weight, pos.LayerNorm.bias, dt)
+    return _bert_attention(enc, x, mask, dt)
+
+
+def _cross_context(model, main, main_mask, side, side_mask, cross, norm, self_att):
+    """cross_context_encoder (xml/model_xml.py:357-373)."""
+    dt = model.compute_dtype
+    q = LinearFn.apply(main, cross.query.weight, cross.query.bias, False)
+    k = LinearFn.apply(side, cross.key.weight, cross.key.bias, False)
+    v = LinearFn.apply(side, cross.value.weight, cross.value.bias, False)
+    a = AttentionCoreFn.apply(q, k, v, main_mask, side_mask, cross.num_attention_heads)
+    res = LayerNormFn.apply(a, main, norm.weight, norm.bias, dt)
+    return _bert_attention(self_att, res, main_mask, dt)
+
+
+def encode_context_train(model, video_feat, video_mask, sub_feat, sub_mask):
+    """encode_context (xml/model_xml.py:331-355,297-329) with gradient tape."""
+    cfg = model.config
+    dt = model.compute_dtype
+    if cfg.cross_att:
+        ev = _encode_input(model, video_feat, video_mask, model.video_input_proj, model.video_encoder1,
+                           model.ctx_pos_embed)
+        es = _encode_input(model, sub_feat, sub_mask, model.sub_input_proj, model.sub_encoder1, model.ctx_pos_embed)
+        xv = _cross_context(model, ev, video_mask, es, sub_mask, model.video_cross_att, model.video_cross_layernorm,
+                            model.video_encoder2)
+        xs = _cross_context(model, es, sub_mask, ev, video_mask, model.sub_cross_att, model.sub_cross_layernorm,
+                            model.sub_encoder2)
+        return ev, xv, es, xs
+    out = []
+    for name, use, feat, mask in (("video", model.use_video, video_feat, video_mask),
+                                  ("sub", model.use_sub, sub_feat, sub_mask)):
+        if not use:
+            out += [None, None]
+            continue
+        f1 = _encode_input(model, feat, mask, getattr(model, name + "_input_proj"), getattr(model, name + "_encoder1"),
+                           model.ctx_pos_embed)
+        f2 = _bert_attention(getattr(model, name + "_encoder2"), f1, mask, dt)
+        f2 = _bert_attention(getattr(model, name + "_encoder3"), f2, mask, dt)
+        out += [f1, f2]
+    return tuple(out)
+
+
+def draw_negative_ranks(model, bsz):
+    """The two torch.randint draws of get_neg_scores (xml/model_xml.py:608-624), in the reference's call order
+    (negative contexts first, then negative queries), on the CPU generator like the reference."""
+    cfg = model.config
+    hi = min(1 + cfg.hard_pool_size, bsz) if cfg.use_hard_negative else bsz
+    return torch.randint(1, hi, size=(bsz,)), torch.randint(1, hi, size=(bsz,))
+
+
+def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub_feat, sub_mask, st_ed_indices,
+                      neg_ctx_rank=None, neg_q_rank=None):
+    """XML.forward (xml/model_xml.py:212-251) -> (loss 0-d tensor with grad_fn, loss dict of floats)."""
+    cfg = model.config
+    dev = query_feat.device
+    fm = lambda m: None if m is None else m.float().contiguous()       # noqa: E731
+    query_mask, video_mask, sub_mask = fm(query_mask), fm(video_mask), fm(sub_mask)
+    v1, v2, s1, s2 = encode_context_train(model, video_feat, video_mask, sub_feat, sub_mask)
+    enc_q = _encode_input(model, query_feat, query_mask, model.query_input_proj, model.query_encoder,
+                          model.query_pos_embed)
+    mq = ModularPoolFn.apply(enc_q, query_mask, model.modular_vector_mapping.weight)
+    video_query, sub_query = (mq[0], mq[1]) if mq.shape[0] == 2 else (mq[0], mq[0])
+
+    names = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
+    qs = dict(video=video_query, sub=sub_query)
+    f1 = dict(video=v1, sub=s1)
+    f2 = dict(video=v2, sub=s2)
+    ms = dict(video=video_mask, sub=sub_mask)
+    bsz = query_feat.shape[0]
+    zero = torch.zeros((), dtype=F32, device=dev)
+
+    loss_st_ed = zero
+    if cfg.lw_st_ed != 0:
+        sims = []
+        for n in names:
+            lin = getattr(model, n + "_query_linear")
+            sims.append(PairSimFn.apply(LinearFn.apply(qs[n], lin.weight, lin.bias, False), f2[n]))
+        merged = bool(cfg.merge_two_stream and len(names) == 2)
+        if merged:
+            masks = [ms["video"], ms["video"]]
+            filters = [model.merged_st_predictor.weight, model.merged_ed_predictor.weight]
+        else:
+            masks = [ms[n] for n in names]
+            filters = [getattr(model, n + "_st_predictor").weight for n in names] + \
+                      [getattr(model, n + "_ed_predictor").weight for n in names]
+        loss_st_ed = SpanLossFn.apply(merged, cfg.conv_kernel_size, st_ed_indices.long().contiguous(), len(sims),
+                                      *sims, *masks, *filters)
+
+    loss_neg_ctx = loss_neg_q = zero
+    if cfg.lw_neg_ctx != 0 or cfg.lw_neg_q != 0:
+        q2c = VideoLevelScoresFn.apply(len(names), *[qs[n] for n in names], *[f1[n] for n in names],
+                                       *[ms[n] for n in names])
+        if neg_ctx_rank is None or neg_q_rank is None:
+            neg_ctx_rank, neg_q_rank = draw_negative_ranks(model, bsz)
+        to_dev = lambda r: torch.as_tensor(r).to(device=dev, dtype=torch.int32).contiguous()   # noqa: E731
+        if cfg.ranking_loss_type not in ("hinge", "lse"):
+            raise NotImplementedError("Only support 'hinge' and 'lse'")
+        losses = RankLossFn.apply(q2c, to_dev(neg_ctx_rank), to_dev(neg_q_rank), float(cfg.margin),
+                                  cfg.ranking_loss_type == "lse")
+        loss_neg_ctx, loss_neg_q = losses[0], losses[1]
+
+    loss_st_ed = cfg.lw_st_ed * loss_st_ed
+    loss_neg_ctx = cfg.lw_neg_ctx * loss_neg_ctx
+    loss_neg_q = cfg.lw_neg_q * loss_neg_q
+    loss = loss_st_ed + loss_neg_ctx + loss_neg_q
+    return loss, {"loss_st_ed": float(loss_st_ed), "loss_neg_ctx": float(loss_neg_ctx),
+                  "loss_neg_q": float(loss_neg_q), "loss_overall": float(loss)}
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optimizer
+# ---------------------------------------------------------------------------------------------------------
+def _sched_warmup_linear(progress, warmup):
+    if progress < warmup:
+        return progress / warmup
+    return max((progress - 1.0) / (warmup - 1.0), 0.0)
+
+
+def _sched_warmup_constant(progress, warmup):
+    return progress / warmup if progress < warmup else 1.0
+
+
+def _sched_warmup_cosine(progress, warmup, cycles=0.5):
+    if progress < warmup:
+        return progress / warmup
+    progress = (progress - warmup) / (1 - warmup)
+    return 0.5 * (1.0 + math.cos(math.pi * cycles * 2 * progress))
+
+
+_SCHEDULES = {None: None, "none": None, "warmup_linear": _sched_warmup_linear,
+              "warmup_constant": _sched_warmup_constant, "warmup_cosine": _sched_warmup_cosine}
+
+
+class BertAdam(object):
+    """BERT Adam with decoupled weight decay, per-tensor gradient clipping and no bias correction
+    (xml/optimization.py:219-338), fused over a flat buffer.
+
+    `params`: iterable of parameters or of param-group dicts ({"params": [...], "weight_decay": ..., "lr": ...}) as in
+    the reference (xml/train.py:355-362).  At construction every parameter is re-pointed into one flat f32 device
+    buffer (`.data` becomes a view) and gets a persistent `.grad` view into a flat gradient buffer, so that
+    zero_grad / all-reduce / step each touch one allocation."""
+
+    def __init__(self, params, lr, warmup=-1, t_total=-1, schedule="warmup_linear", b1=0.9, b2=0.999, e=1e-6,
+                 weight_decay=0.01, max_grad_norm=1.0):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if schedule not in _SCHEDULES:
+            raise ValueError("Invalid schedule parameter: {}".format(schedule))
+        if not 0.0 <= b1 < 1.0:
+            raise ValueError("Invalid b1 parameter: {} - should be in [0.0, 1.0[".format(b1))
+        if not 0.0 <= b2 < 1.0:
+            raise ValueError("Invalid b2 parameter: {} - should be in [0.0, 1.0[".format(b2))
+        if not e >= 0.0:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(e))
+        if not 0.0 <= warmup < 1.0 and not warmup == -1:
+            raise ValueError("Invalid warmup: {} - should be in [0.0, 1.0[ or -1".format(warmup))
+        params = list(params)
+        groups = params if params and isinstance(params[0], dict) else [{"params": params}]
+        self.param_groups = []
+        for g in groups:
+            g = dict(g)
+            g["params"] = list(g["params"])
+            g.setdefault("lr", lr)
+            g.setdefault("weight_decay", weight_decay)
+            self.param_groups.append(g)
+        self.defaults = dict(lr=lr, warmup=max(warmup, 0.0), t_total=float(t_total), schedule=schedule, b1=b1, b2=b2,
+                             e=e, weight_decay=weight_decay, max_grad_norm=max_grad_norm)
+        self.step_count = 0
+        self._flatten()
+
+    def _flatten(self):
+        plist, lrs, wds = [], [], []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if not p.requires_grad:
+                    continue
+                if not p.is_cuda or p.dtype != F32:
+                    raise RuntimeError("BertAdam: parameters must be f32 tensors on the GPU (no CPU path)")
+                plist.append(p)
+                lrs.append(g["lr"])
+                wds.append(g["weight_decay"])
+        if not plist:
+            raise ValueError("optimizer got an empty parameter list")
+        dev = plist[0].device
+        offs = [0]
+        for p in plist:
+            offs.append(offs[-1] + (p.numel() + 3) // 4 * 4)        # keep every tensor 16-byte aligned
+        total = offs[-1]
+        self.flat_p = torch.zeros(total, dtype=F32, device=dev)
+        self.flat_g = torch.zeros(total, dtype=F32, device=dev)
+        self.flat_m = torch.zeros(total, dtype=F32, device=dev)
+        self.flat_v = torch.zeros(total, dtype=F32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(plist, offs):
+                view = self.flat_p[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+        self.params = plist
+        self.seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
+        self.seg_lr = torch.tensor(lrs, dtype=F32, device=dev)
+        self.seg_wd = torch.tensor(wds, dtype=F32, device=dev)
+        self.norms = torch.zeros(len(plist), dtype=F32, device=dev)
+
+    def zero_grad(self):
+        self.flat_g.zero_()
+        for p, o in zip(self.params, self.seg_off.tolist()):
+            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+                p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
+
+    def lr_multiplier(self, step=None):
+        """_LRSchedule.get_lr (xml/optimization.py:40-55)."""
+        d = self.defaults
+        fn = _SCHEDULES[d["schedule"]]
+        if fn is None or d["t_total"] < 0:
+            return 1.0
+        return fn(float(self.step_count if step is None else step) / d["t_total"], d["warmup"])
+
+    def get_lr(self):
+        if self.step_count == 0:
+            return [0]
+        m = self.lr_multiplier()
+        return [g["lr"] * m for g in self.param_groups for _ in g["params"]]
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        d = self.defaults
+        T.bert_adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.seg_off, self.seg_lr, self.seg_wd,
+                         self.norms, self.lr_multiplier(), d["b1"], d["b2"], d["e"], d["max_grad_norm"])
+        self.step_count += 1
+        from .model_xml import _PackedMixin
+        _PackedMixin.bump_generation()          # cached low-precision weight copies are stale now
+        return loss
+
+
+def allreduce_gradients(optimizer, group=None, bucket_bytes=64 << 20):
+    """Average the flat gradient buffer over ranks: a few large all-reduces (64 MiB buckets by default -- ring
+    collectives over xGMI are per-link bound, so fewer and larger beats per-tensor), issued back-to-back and
+    awaited together.  No-op without an initialised process group or at world size 1."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    world = dist.get_world_size(group)
+    flat = optimizer.flat_g
+    step = max(bucket_bytes // 4, 1)
+    # RCCL reduces with AVG directly; gloo (CPU tests) has no AVG, so sum and scale there
+    avg = flat.is_cuda
+    works = []
+    for o in range(0, flat.numel(), step):
+        works.append(dist.all_reduce(flat[o:o + step], op=dist.ReduceOp.AVG if avg else dist.ReduceOp.SUM, group=group,
+                                     async_op=True))
+    for w in works:
+        w.wait()
+    if not avg:
+        flat.div_(world)
+
+
+def train_step(model, optimizer, batch, grad_clip=-1, group=None):
+    """One iteration of the reference's loop (xml/train.py:78-95): forward, zero_grad, backward, [global clip],
+    all-reduce (multi-process only), optimizer step.  `batch` = dict of the XML.forward keyword arguments."""
+    loss, loss_dict = xml_forward_train(model, **batch)
+    optimizer.zero_grad()
+    loss.backward()
+    allreduce_gradients(optimizer, group)
+    if grad_clip != -1:
+        raise NotImplementedError("global clip_grad_norm_ (xml/train.py:88-90, off by default) is not built; "
+                                  "BertAdam clips per tensor with max_grad_norm")
+    optimizer.step()
+    return loss, loss_dict

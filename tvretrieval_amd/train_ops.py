@@ -1,0 +1,228 @@
+"""Tensor-level wrappers over the training-step entries of the C ABI (include/xmlhip.h, "TRAINING STEP" block).
+
+Same rules as ops.py: torch owns device memory and the stream, every function launches kernels of libxmlhip.so,
+nothing falls back to eager torch.
+"""
+import math
+
+import torch
+
+from . import _lib
+from ._lib import check
+from .ops import _p, _req, _stream, _workspace, dt_of
+
+F32 = torch.float32
+
+
+def _r8(x):
+    return (x + 7) // 8 * 8
+
+
+def transpose(x, ld_out=None):
+    """(B, R, C) or (R, C) -> (B, C, ld_out>=R) / (C, ld_out); padding columns are zero."""
+    _req(x, "x")
+    squeeze = x.dim() == 2
+    if squeeze:
+        x = x.unsqueeze(0)
+    b, r, c = x.shape
+    ld = r if ld_out is None else ld_out
+    y = (torch.zeros if ld != r else torch.empty)((b, c, ld), dtype=x.dtype, device=x.device)
+    check(_lib.load().xml_transpose_batched(_p(x), _p(y), b, r, c, ld, dt_of(x), _stream()), "xml_transpose_batched")
+    return y[0] if squeeze else y
+
+
+def colsum(x, rows, cols, out=None):
+    """sum over rows of x viewed as (rows, cols) -> f32 (cols,)."""
+    _req(x, "x")
+    acc = out is not None
+    if out is None:
+        out = torch.empty(cols, dtype=F32, device=x.device)
+    check(_lib.load().xml_colsum(_p(x), dt_of(x), _p(out), rows, cols, int(acc), _stream()), "xml_colsum")
+    return out
+
+
+def relu_bwd(y, dy):
+    _req(y, "y"); _req(dy, "dy", y.dtype)
+    dx = torch.empty_like(dy)
+    check(_lib.load().xml_relu_bwd(_p(y), _p(dy), _p(dx), y.numel(), dt_of(y), _stream()), "xml_relu_bwd")
+    return dx
+
+
+def add_inplace(y, x):
+    _req(y, "y"); _req(x, "x")
+    assert y.numel() == x.numel()
+    check(_lib.load().xml_add_inplace(_p(y), dt_of(y), _p(x), dt_of(x), y.numel(), _stream()), "xml_add_inplace")
+    return y
+
+
+def layernorm_bwd(a, b, g, dy, need_dx=True):
+    """-> (dx or None, dg f32, dbeta f32) for y = LN(a [+ b]) * g + beta; a/b/dy (..., d)."""
+    _req(a, "a"); _req(g, "g", F32); _req(dy, "dy")
+    d = a.shape[-1]
+    rows = a.numel() // d
+    dg = torch.zeros(d, dtype=F32, device=a.device)
+    dbeta = torch.zeros(d, dtype=F32, device=a.device)
+    dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (need_dx or d <= 1024) else None
+    ws = _workspace(rows * 16, a.device) if d > 1024 else None
+    check(_lib.load().xml_layernorm_bwd(_p(a), dt_of(a), _p(b), _p(g), _p(dy), _p(dx), _p(dg), _p(dbeta), rows, d,
+                                        dt_of(dy), _p(ws), 0 if ws is None else ws.numel(), _stream()),
+          "xml_layernorm_bwd")
+    return dx, dg, dbeta
+
+
+def gemm_batched(a, b, scale=1.0, out_f32=False):
+    """out[z] = scale * a[z] @ b[z]^T ; a (B, M, K), b (B, N, K) -> (B, M, N) (2-D inputs: B = 1, 2-D output)."""
+    _req(a, "a"); _req(b, "b", a.dtype)
+    squeeze = a.dim() == 2
+    if squeeze:
+        a, b = a.unsqueeze(0), b.unsqueeze(0)
+    bt, m, k = a.shape
+    n = b.shape[1]
+    assert b.shape[0] == bt and b.shape[2] == k, "gemm_batched: shape mismatch"
+    out = torch.empty((bt, m, n), dtype=F32 if out_f32 else a.dtype, device=a.device)
+    check(_lib.load().xml_gemm_batched(_p(a), _p(b), _p(out), bt, m, n, k, float(scale), int(out_f32), dt_of(a),
+                                       _stream()), "xml_gemm_batched")
+    return out[0] if squeeze else out
+
+
+def split_heads(x, heads, want=True, want_t=False, col0=0, width=None):
+    """x (N, L, ld) -> [(N*heads, L8, dh)], [(N*heads, dh, L8)] taking columns [col0, col0 + width)."""
+    _req(x, "x")
+    n, l, ld = x.shape
+    width = ld - col0 if width is None else width
+    dh = width // heads
+    l8 = _r8(l)
+    dst = torch.empty((n * heads, l8, dh), dtype=x.dtype, device=x.device) if want else None
+    dst_t = torch.empty((n * heads, dh, l8), dtype=x.dtype, device=x.device) if want_t else None
+    check(_lib.load().xml_split_heads(_p(x), ld, col0, n, l, l8, heads, dh, _p(dst), _p(dst_t), dt_of(x), _stream()),
+          "xml_split_heads")
+    return dst, dst_t
+
+
+def merge_heads(xh, n, l, heads):
+    """(N*heads, L8, dh) -> (N, L, heads*dh)."""
+    _req(xh, "xh")
+    l8, dh = xh.shape[1], xh.shape[2]
+    out = torch.empty((n, l, heads * dh), dtype=xh.dtype, device=xh.device)
+    check(_lib.load().xml_merge_heads(_p(xh), _p(out), heads * dh, 0, n, l, l8, heads, dh, dt_of(xh), _stream()),
+          "xml_merge_heads")
+    return out
+
+
+def attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, dtype, want_t=False):
+    lq8, lk8 = s.shape[1], s.shape[2]
+    p = torch.empty((n * heads, lq8, lk8), dtype=dtype, device=s.device)
+    pt = torch.empty((n * heads, lk8, lq8), dtype=dtype, device=s.device) if want_t else None
+    check(_lib.load().xml_attn_softmax(_p(s), None, _p(q_mask), _p(k_mask), _p(p), _p(pt), None, None, n, heads, lq,
+                                       lk, lq8, lk8, math.sqrt(dh), dt_of(dtype), _stream()), "xml_attn_softmax")
+    return p, pt
+
+
+def attn_softmax_bwd(s, dp, q_mask, k_mask, n, heads, lq, lk, dh, dtype):
+    lq8, lk8 = s.shape[1], s.shape[2]
+    ds = torch.empty((n * heads, lq8, lk8), dtype=dtype, device=s.device)
+    dst = torch.empty((n * heads, lk8, lq8), dtype=dtype, device=s.device)
+    check(_lib.load().xml_attn_softmax(_p(s), _p(dp), _p(q_mask), _p(k_mask), None, None, _p(ds), _p(dst), n, heads,
+                                       lq, lk, lq8, lk8, math.sqrt(dh), dt_of(dtype), _stream()), "xml_attn_softmax")
+    return ds, dst
+
+
+def modular_pool_bwd(enc, mask, wm, dout):
+    _req(enc, "enc"); _req(mask, "mask", F32); _req(wm, "wm", F32); _req(dout, "dout", enc.dtype)
+    n, lq, hidden = enc.shape
+    n_mod = wm.shape[0]
+    denc = torch.empty_like(enc)
+    dwm = torch.zeros_like(wm)
+    check(_lib.load().xml_modular_pool_bwd(_p(enc), _p(mask), _p(wm), _p(dout), _p(denc), _p(dwm), n, lq, hidden,
+                                           n_mod, dt_of(enc), _stream()), "xml_modular_pool_bwd")
+    return denc, dwm
+
+
+def l2norm_bwd(x, dy):
+    _req(x, "x"); _req(dy, "dy", F32)
+    d = x.shape[-1]
+    dx = torch.empty_like(x)
+    check(_lib.load().xml_l2norm_bwd(_p(x), _p(dy), _p(dx), x.numel() // d, d, dt_of(x), _stream()), "xml_l2norm_bwd")
+    return dx
+
+
+def q2c_scores_bwd(qn, cn, mask, dscores, scale=1.0):
+    _req(qn, "qn"); _req(cn, "cn", qn.dtype); _req(mask, "mask", F32); _req(dscores, "dscores", F32)
+    nq, hidden = qn.shape
+    nv, l, _ = cn.shape
+    dqn = torch.empty((nq, hidden), dtype=F32, device=qn.device)
+    dcn = torch.empty((nv, l, hidden), dtype=F32, device=qn.device)
+    check(_lib.load().xml_q2c_scores_bwd(_p(qn), _p(cn), _p(mask), _p(dscores), dscores.stride(0), float(scale), _p(dqn), _p(dcn),
+                                         nq, nv, l, hidden, dt_of(qn), _stream()), "xml_q2c_scores_bwd")
+    return dqn, dcn
+
+
+def pair_sim(q, f2):
+    _req(q, "q"); _req(f2, "f2", q.dtype)
+    n, l, hidden = f2.shape
+    sim = torch.empty((n, l), dtype=F32, device=q.device)
+    check(_lib.load().xml_pair_sim(_p(q), _p(f2), _p(sim), n, l, hidden, dt_of(q), _stream()), "xml_pair_sim")
+    return sim
+
+
+def pair_sim_bwd(q, f2, dsim):
+    _req(q, "q"); _req(f2, "f2", q.dtype); _req(dsim, "dsim", F32)
+    n, l, hidden = f2.shape
+    dq, df2 = torch.empty_like(q), torch.empty_like(f2)
+    check(_lib.load().xml_pair_sim_bwd(_p(q), _p(f2), _p(dsim), _p(dq), _p(df2), n, l, hidden, dt_of(q), _stream()),
+          "xml_pair_sim_bwd")
+    return dq, df2
+
+
+def span_loss(sims, conv_w, masks, st_ed, merged, ks, gout=None):
+    """sims: 1 or 2 (N, L) f32; conv_w flat f32 [st filters | ed filters]; masks like sims; st_ed (N, 2) int64.
+    gout None -> loss (0-d f32).  gout (1,) f32 -> (dsims list, dconv_w)."""
+    for t in sims:
+        _req(t, "sim", F32)
+    for t in masks:
+        _req(t, "mask", F32)
+    _req(conv_w, "conv_w", F32); _req(st_ed, "st_ed", torch.int64)
+    n, l = sims[0].shape
+    n_sim = len(sims)
+    s1 = sims[1] if n_sim > 1 else None
+    m1 = masks[1] if len(masks) > 1 else None
+    lib = _lib.load()
+    if gout is None:
+        loss = torch.empty(1, dtype=F32, device=sims[0].device)
+        check(lib.xml_span_loss(_p(sims[0]), _p(s1), _p(conv_w), _p(masks[0]), _p(m1), _p(st_ed), int(merged), n_sim,
+                                ks, n, l, None, _p(loss), None, None, None, _stream()), "xml_span_loss")
+        return loss[0]
+    _req(gout, "gout", F32)
+    dsims = [torch.empty_like(s) for s in sims]
+    dconv = torch.empty_like(conv_w)
+    check(lib.xml_span_loss(_p(sims[0]), _p(s1), _p(conv_w), _p(masks[0]), _p(m1), _p(st_ed), int(merged), n_sim, ks, n,
+                            l, _p(gout), None, _p(dsims[0]), _p(dsims[1]) if n_sim > 1 else None, _p(dconv),
+                            _stream()), "xml_span_loss")
+    return dsims, dconv
+
+
+def rank_loss(scores, ranks_ctx, ranks_q, margin, lse, gout=None):
+    """scores (N, N) f32, ranks int32 (N,).  gout None -> losses (2,) f32; else dscores (N, N)."""
+    _req(scores, "scores", F32); _req(ranks_ctx, "ranks_ctx", torch.int32); _req(ranks_q, "ranks_q", torch.int32)
+    n = scores.shape[0]
+    assert scores.shape == (n, n)
+    lib = _lib.load()
+    if gout is None:
+        losses = torch.empty(2, dtype=F32, device=scores.device)
+        check(lib.xml_rank_loss(_p(scores), _p(ranks_ctx), _p(ranks_q), float(margin), int(lse), n, None, _p(losses),
+                                None, _stream()), "xml_rank_loss")
+        return losses
+    _req(gout, "gout", F32)
+    ds = torch.empty_like(scores)
+    check(lib.xml_rank_loss(_p(scores), _p(ranks_ctx), _p(ranks_q), float(margin), int(lse), n, _p(gout), None, _p(ds),
+                            _stream()), "xml_rank_loss")
+    return ds
+
+
+def bert_adam_step(p, g, m, v, seg_off, seg_lr, seg_wd, norms, lr_mult, b1, b2, eps, max_grad_norm):
+    for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (seg_lr, "seg_lr"), (seg_wd, "seg_wd"), (norms, "norms")):
+        _req(t, nm, F32)
+    _req(seg_off, "seg_off", torch.int64)
+    check(_lib.load().xml_bert_adam_step(_p(p), _p(g), _p(m), _p(v), _p(seg_off), _p(seg_lr), _p(seg_wd),
+                                         seg_lr.numel(), p.numel(), float(lr_mult), float(b1), float(b2), float(eps),
+                                         float(max_grad_norm), _p(norms), _stream()), "xml_bert_adam_step")

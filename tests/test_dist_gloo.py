@@ -100,3 +100,36 @@ def test_shard_range():
             assert h0 == l1 and l0 <= h0
         for lo, hi in spans:
             assert lo % a == 0 or lo == n
+
+
+# ---------------------------------------------------------------------------------------------------------
+# data-parallel training: bucketed gradient averaging over the flat gradient buffer (tvretrieval_amd.train)
+# ---------------------------------------------------------------------------------------------------------
+def _grad_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tvretrieval_amd.train import allreduce_gradients
+
+        class Holder(object):       # what allreduce_gradients needs from BertAdam: the flat gradient buffer
+            pass
+        h = Holder()
+        g = torch.Generator().manual_seed(100 + rank)
+        h.flat_g = torch.randn(10007, generator=g)
+        mine = h.flat_g.clone()
+        allreduce_gradients(h, bucket_bytes=4096 * 4)      # 3 buckets, the last one ragged
+        others = [torch.randn(10007, generator=torch.Generator().manual_seed(100 + r)) for r in range(world)]
+        want = sum(others) / world
+        ok = torch.allclose(h.flat_g, want, rtol=0, atol=1e-6) and torch.equal(mine, others[rank])
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_allreduce_buckets_world2():
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_grad_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)

@@ -303,3 +303,18 @@ def test_train_step_bf16_runs_and_descends():
     losses = [float(train_step(m, opt, batch)[0]) for _ in range(12)]
     assert all(math.isfinite(x) for x in losses)
     assert losses[-1] < losses[0] - 0.02, losses
+
+
+def test_model_forward_dispatch():
+    """XML.forward: autograd on -> training graph; no_grad -> fused inference kernels; same loss values."""
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    m = build_train_model(cfg, d)
+    args = (T(d["query_feat"]), T(d["query_mask"]), T(d["video_feat"]), T(d["video_mask"]), T(d["sub_feat"]),
+            T(d["sub_mask"]), None, None, T(d["st_ed_indices"]))
+    loss, parts = m(*args, neg_ctx_rank=d["neg_ctx_rank"], neg_q_rank=d["neg_q_rank"])
+    assert loss.requires_grad
+    with torch.no_grad():
+        loss2, parts2 = m(*args, neg_ctx_rank=d["neg_ctx_rank"], neg_q_rank=d["neg_q_rank"])
+    assert abs(float(loss) - float(d["loss"])) < 2e-5 and abs(float(loss2) - float(d["loss"])) < 2e-5
+    for k in ("loss_st_ed", "loss_neg_ctx", "loss_neg_q"):
+        assert abs(parts[k] - parts2[k]) < 2e-5

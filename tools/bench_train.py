@@ -1,0 +1,117 @@
+"""Time one XML training step (BASELINE.json configs[4]: batch 128 video+sub, bf16) on the HIP kernels.
+
+    python tools/bench_train.py [--bsz 128] [--ctx-l 100] [--hidden 768] [--dtype bf16] [--steps 10]
+    python -m torch.distributed.run --nproc-per-node N ... tools/bench_train.py     (data parallel, RCCL all-reduce)
+
+Synthetic features of TVR shape (video 3072-d, subtitle / query 768-d), random-init weights.  Prints one JSON line:
+ms per step split into forward / backward / all-reduce / optimizer, and pairs (query + video) per second.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--bsz", type=int, default=128)
+    ap.add_argument("--ctx-l", type=int, default=100)
+    ap.add_argument("--desc-l", type=int, default=30)
+    ap.add_argument("--hidden", type=int, default=768)
+    ap.add_argument("--dv", type=int, default=3072)
+    ap.add_argument("--ds", type=int, default=768)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from tvretrieval_amd.model_xml import XML, xml_base_config
+    from tvretrieval_amd.train import BertAdam, allreduce_gradients, xml_forward_train
+
+    cfg = dict(xml_base_config)
+    cfg.update(visual_input_size=a.dv, sub_input_size=a.ds, query_input_size=a.ds, hidden_size=a.hidden,
+               max_ctx_l=a.ctx_l, max_desc_l=a.desc_l, lw_st_ed=0.01)
+    dt = torch.bfloat16 if a.dtype == "bf16" else torch.float32
+    torch.manual_seed(1234)
+    model = XML(cfg, compute_dtype=dt).to(dev)
+    named = list(model.named_parameters())
+    no_decay = ["bias", "LayerNorm.bias", "LayerNorm.weight"]
+    opt = BertAdam([{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
+                    {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}],
+                   lr=1e-4, warmup=0.01, t_total=10000)
+    g = torch.Generator().manual_seed(77 + rank)
+    n, lc, lq = a.bsz, a.ctx_l, a.desc_l
+    lens = torch.randint(lc // 2, lc + 1, (n,), generator=g)
+    lens[0] = lc
+    qlens = torch.randint(5, lq + 1, (n,), generator=g)
+    qlens[0] = lq
+    mk = lambda ls, l: (torch.arange(l)[None] < ls[:, None]).float()                 # noqa: E731
+
+    def feats(l, d, m):
+        x = torch.nn.functional.normalize(torch.randn(n, l, d, generator=g), dim=-1) * m[:, :, None]
+        return x.to(dev)
+    vm, qm = mk(lens, lc), mk(qlens, lq)
+    st = torch.stack([torch.randint(0, int(x), (1,), generator=g)[0] for x in lens])
+    ed = torch.stack([torch.randint(int(s), int(x), (1,), generator=g)[0] for s, x in zip(st, lens)])
+    batch = dict(query_feat=feats(lq, a.ds, qm), query_mask=qm.to(dev), video_feat=feats(lc, a.dv, vm),
+                 video_mask=vm.to(dev), sub_feat=feats(lc, a.ds, vm), sub_mask=vm.to(dev),
+                 st_ed_indices=torch.stack([st, ed], 1).to(dev))
+
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+    acc = dict(fwd=0.0, bwd=0.0, allreduce=0.0, optim=0.0)
+    losses = []
+    wall0 = None
+    for it in range(a.warmup + a.steps):
+        if it == a.warmup:
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            wall0 = time.perf_counter()
+        e = [ev() for _ in range(5)]
+        e[0].record()
+        loss, parts = xml_forward_train(model, **batch)
+        e[1].record()
+        opt.zero_grad()
+        loss.backward()
+        e[2].record()
+        allreduce_gradients(opt)
+        e[3].record()
+        opt.step()
+        e[4].record()
+        if it >= a.warmup:
+            torch.cuda.synchronize()
+            for k, i in (("fwd", 0), ("bwd", 1), ("allreduce", 2), ("optim", 3)):
+                acc[k] += e[i].elapsed_time(e[i + 1])
+            losses.append(parts["loss_overall"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    wall = (time.perf_counter() - wall0) / a.steps * 1e3
+    if rank == 0:
+        n_param = sum(p.numel() for p in model.parameters())
+        print(json.dumps(dict(metric="xml_train_step", ms_per_step=round(wall, 3),
+                              pairs_per_s=round(a.bsz * world / wall * 1e3, 1), n_gpus=world, dtype=a.dtype,
+                              breakdown_ms={k: round(v / a.steps, 3) for k, v in acc.items()},
+                              config=dict(bsz_per_gpu=a.bsz, ctx_l=lc, desc_l=lq, hidden=a.hidden, dv=a.dv,
+                                          params=n_param),
+                              loss_first=round(losses[0], 4), loss_last=round(losses[-1], 4))))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

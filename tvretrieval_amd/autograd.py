@@ -60,7 +60,7 @@ class LinearFn(torch.autograd.Function):
             if n % 8:                                                              # pad the reduction dim
                 a = torch.zeros((rows, _r8(n)), dtype=dy.dtype, device=dy.device)
                 a[:, :n] = dy2
-            dx = T.gemm_batched(a, wt).view(x.shape)
+            dx = ops.linear(a, wt).view(x.shape)                                   # dX = dY W
         if ctx.needs_input_grad[1]:
             r8 = _r8(rows)
             dyt = T.transpose(dy2, r8)                                            # (N, rows8)

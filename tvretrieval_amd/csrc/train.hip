@@ -68,7 +68,7 @@ extern "C" int xml_colsum(const void* x, int x_dt, float* out, int64_t rows, int
   if (!x || !out || rows <= 0 || cols <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (!accumulate && hipMemsetAsync(out, 0, (size_t)cols * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
-  const int64_t rpb = 256;
+  const int64_t rpb = rows >= 4096 ? 32 : 256;
   dim3 grid(cdiv(cols, 256), cdiv(rows, rpb));
   if (x_dt == XML_F32)
     hipLaunchKernelGGL(colsum_kernel<float>, grid, dim3(256), 0, st, (const float*)x, out, rows, cols, rpb);
@@ -129,16 +129,42 @@ extern "C" int xml_add_inplace(void* y, int y_dt, const void* x, int x_dt, int64
 //   dg += sum_rows dy * xhat,  dbeta += sum_rows dy          (f32, accumulated with one atomic per column per block)
 // One wave per row (d <= 1024 values in registers); a block walks ROWS_PER_BLOCK rows and keeps column partials.
 // ---------------------------------------------------------------------------------------------------------
+// 8 consecutive elements as floats (16-byte loads for bf16, 2 x 16 bytes for f32)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* out) {
+  if constexpr (sizeof(T) == 2) {
+    unpack16<bf16_t>(*reinterpret_cast<const uint4*>(p), out);
+  } else {
+    unpack16<float>(*reinterpret_cast<const uint4*>(p), out);
+    unpack16<float>(*reinterpret_cast<const uint4*>(p + 4), out + 4);
+  }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float* in) {
+  if constexpr (sizeof(T) == 2) {
+    *reinterpret_cast<uint4*>(p) = pack16<bf16_t>(in);
+  } else {
+    *reinterpret_cast<uint4*>(p) = pack16<float>(in);
+    *reinterpret_cast<uint4*>(p + 4) = pack16<float>(in + 4);
+  }
+}
+
+// d % 8 == 0, d <= 1024: lane owns the 8-element vectors v = lane + 64*k (k < 2).  A block (4 waves) walks
+// 4 * rows_per_wave rows, combines the column partials of its waves in LDS and issues one atomic per column.
 template <typename InT, typename BT, typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restrict__ a, const BT* __restrict__ b,
                                                             const float* __restrict__ g, const T* __restrict__ dy,
                                                             T* __restrict__ dx, float* __restrict__ dg,
                                                             float* __restrict__ dbeta, int64_t rows, int d,
                                                             float eps, int rows_per_wave) {
+  __shared__ float s_pg[4][1024], s_pb[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float pg[16], pb[16];
+  const int nvec = d >> 3;
+  float pg[16], pb[16], gv[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) { pg[k] = 0.f; pb[k] = 0.f; }
+  for (int k = 0; k < 2; ++k) {
+    const int v = lane + k * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { pg[k * 8 + j] = 0.f; pb[k * 8 + j] = 0.f; gv[k * 8 + j] = v < nvec ? g[v * 8 + j] : 0.f; }
+  }
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
   for (int rr = 0; rr < rows_per_wave; ++rr) {
     const int64_t row = row0 + rr;
@@ -146,51 +172,68 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
     float x[16], gy[16];
     float s = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = lane + k * 64;
-      x[k] = (i < d) ? DT<InT>::ld(a + row * d + i) + (b ? DT<BT>::ld(b + row * d + i) : 0.f) : 0.f;
-      s += x[k];
+    for (int k = 0; k < 2; ++k) {
+      const int v = lane + k * 64;
+      if (v < nvec) {
+        ld8<InT>(a + row * d + v * 8, x + k * 8);
+        if (b) {
+          float t[8];
+          ld8<BT>(b + row * d + v * 8, t);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[k * 8 + j] += t[j];
+        }
+        ld8<T>(dy + row * d + v * 8, gy + k * 8);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { x[k * 8 + j] = 0.f; gy[k * 8 + j] = 0.f; }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += x[k * 8 + j];
     }
     const float mean = wave_sum(s) / (float)d;
-    float v = 0.f;
+    float var = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const float c = (lane + k * 64 < d) ? x[k] - mean : 0.f;
-      v += c * c;
-    }
-    const float rstd = 1.0f / sqrtf(wave_sum(v) / (float)d + eps);
+    for (int k = 0; k < 2; ++k)
+      if (lane + k * 64 < nvec)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float c = x[k * 8 + j] - mean; var += c * c; }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = lane + k * 64;
-      if (i < d) {
-        const float xh = (x[k] - mean) * rstd;
-        const float dyv = DT<T>::ld(dy + row * d + i);
-        x[k] = xh;
-        gy[k] = dyv * g[i];
-        s1 += gy[k];
-        s2 += gy[k] * xh;
-        pg[k] += dyv * xh;
-        pb[k] += dyv;
-      } else {
-        gy[k] = 0.f;
-      }
+    for (int i = 0; i < 16; ++i) {        // padding vectors hold x = gy = g = 0 -> xh = -mean*rstd but dy = 0
+      const float xh = (x[i] - mean) * rstd;
+      const float dyv = gy[i];
+      x[i] = xh;
+      gy[i] = dyv * gv[i];
+      s1 += gy[i];
+      s2 += gy[i] * xh;
+      pg[i] += dyv * xh;
+      pb[i] += dyv;
     }
     s1 = wave_sum(s1) / (float)d;
     s2 = wave_sum(s2) / (float)d;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = lane + k * 64;
-      if (i < d) DT<T>::st(dx + row * d + i, rstd * (gy[k] - s1 - x[k] * s2));
+    for (int k = 0; k < 2; ++k) {
+      const int v = lane + k * 64;
+      if (v < nvec) {
+        float o[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rstd * (gy[k * 8 + j] - s1 - x[k * 8 + j] * s2);
+        st8<T>(dx + row * d + v * 8, o);
+      }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int i = lane + k * 64;
-    if (i < d) {
-      if (dg) atomicAdd(dg + i, pg[k]);
-      if (dbeta) atomicAdd(dbeta + i, pb[k]);
-    }
+  for (int k = 0; k < 2; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_pg[wave][v * 8 + j] = pg[k * 8 + j]; s_pb[wave][v * 8 + j] = pb[k * 8 + j]; }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    if (dg) atomicAdd(dg + c, s_pg[0][c] + s_pg[1][c] + s_pg[2][c] + s_pg[3][c]);
+    if (dbeta) atomicAdd(dbeta + c, s_pb[0][c] + s_pb[1][c] + s_pb[2][c] + s_pb[3][c]);
   }
 }
 
@@ -262,7 +305,7 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
   XML_ENTER();
   if (!a || !g || !dy || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (d > 1024) {
+  if (d > 1024 || (d & 7)) {
     if (b) return XML_ERR_UNSUPPORTED;
     if (!ws || ws_bytes < (size_t)rows * 16) return XML_ERR_WORKSPACE;
     if (dt == XML_F32 && a_dt == XML_F32) return ln_bwd_wide<float, float>(a, g, dy, dx, dg, dbeta, rows, d, (float*)ws, st);
@@ -271,7 +314,7 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
     return XML_ERR_BAD_ARG;
   }
   if (!dx) return XML_ERR_BAD_ARG;
-  const int rpw = 8;
+  const int rpw = rows >= 8192 ? 16 : (rows >= 1024 ? 4 : 1);
   const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
   if (dt == XML_F32) {
     if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
@@ -294,20 +337,26 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
 // ---------------------------------------------------------------------------------------------------------
 // contiguous batched GEMM: out[z] = scale * A[z] B[z]^T,  A (M,K), B (N,K) K-contiguous, out (M,N) as T or f32
 // ---------------------------------------------------------------------------------------------------------
-template <typename T, typename OutT>
+// KSPLIT > 1 (f32 output only, batch == 1): blockIdx.z walks K ranges of `kc` elements and the partial products are
+// accumulated with f32 atomics into a pre-zeroed output -- the weight-gradient GEMMs (N x K_in outputs, reduction
+// over all batch rows) would otherwise fill only a few dozen workgroups.
+template <typename T, typename OutT, bool SPLIT>
 __global__ __launch_bounds__(256) void gemm_batched_kernel(const T* __restrict__ A, const T* __restrict__ B,
-                                                           OutT* __restrict__ out, int M, int N, int K, float scale) {
+                                                           OutT* __restrict__ out, int M, int N, int K, int kc,
+                                                           float scale) {
   using Cfg = GemmCfg<T, 128, 128, 2, 2>;
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
-  const int64_t z = blockIdx.z;
-  const T* Az = A + z * (int64_t)M * K;
-  const T* Bz = B + z * (int64_t)N * K;
+  const int64_t z = SPLIT ? 0 : blockIdx.z;
+  const int k0 = SPLIT ? blockIdx.z * kc : 0;
+  const int klen = SPLIT ? (K - k0 < kc ? K - k0 : kc) : K;
+  const T* Az = A + z * (int64_t)M * K + k0;
+  const T* Bz = B + z * (int64_t)N * K + k0;
   OutT* Oz = out + z * (int64_t)M * N;
   const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128;
   f32x4 acc[Cfg::MT][Cfg::NT];
   auto a_row = [&](int r) -> const char* { return (m0 + r) < M ? reinterpret_cast<const char*>(Az + (int64_t)(m0 + r) * K) : nullptr; };
   auto b_row = [&](int r) -> const char* { return (n0 + r) < N ? reinterpret_cast<const char*>(Bz + (int64_t)(n0 + r) * K) : nullptr; };
-  gemm_mainloop<T, Cfg>(acc, a_row, b_row, K * (int)sizeof(T), smem);
+  gemm_mainloop<T, Cfg>(acc, a_row, b_row, klen * (int)sizeof(T), smem);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
 #pragma unroll
@@ -319,7 +368,9 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const T* __restrict__
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 64 + mt * 16 + (lane >> 4) * 4 + r;
-        if (m < M) DT<OutT>::st(Oz + (int64_t)m * N + n, acc[mt][nt][r] * scale);
+        if (m >= M) continue;
+        if constexpr (SPLIT) atomicAdd(reinterpret_cast<float*>(Oz) + (int64_t)m * N + n, acc[mt][nt][r] * scale);
+        else DT<OutT>::st(Oz + (int64_t)m * N + n, acc[mt][nt][r] * scale);
       }
     }
 }
@@ -328,23 +379,39 @@ extern "C" int xml_gemm_batched(const void* A, const void* B, void* out, int bat
                                 int out_f32, int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!A || !B || !out || batch <= 0 || M <= 0 || N <= 0 || K <= 0) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (K % (dt == XML_F32 ? 4 : 8)) return XML_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  dim3 grid(cdiv(N, 128), cdiv(M, 128), batch);
-  if (dt == XML_F32) {
-    if (K % 4) return XML_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL((gemm_batched_kernel<float, float>), grid, dim3(256), 0, st, (const float*)A, (const float*)B,
-                       (float*)out, M, N, K, scale);
-  } else if (dt == XML_BF16) {
-    if (K % 8) return XML_ERR_UNSUPPORTED;
-    if (out_f32)
-      hipLaunchKernelGGL((gemm_batched_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)A, (const bf16_t*)B,
-                         (float*)out, M, N, K, scale);
-    else
-      hipLaunchKernelGGL((gemm_batched_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)A,
-                         (const bf16_t*)B, (bf16_t*)out, M, N, K, scale);
-  } else {
-    return XML_ERR_BAD_ARG;
+  const int tiles = cdiv(N, 128) * cdiv(M, 128);
+  const bool f32_out = (dt == XML_F32) || out_f32;
+  if (batch == 1 && f32_out && K >= 1024 && tiles < 256) {
+    int ks = cdiv(768, tiles);                       // aim at >= 3 workgroups per CU
+    int kc = (cdiv(K, ks) + 63) / 64 * 64;           // K range per workgroup, 64-element granules
+    if (kc < 256) kc = 256;
+    ks = cdiv(K, kc);
+    if (ks > 1) {
+      if (hipMemsetAsync(out, 0, (size_t)M * N * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+      dim3 grid(cdiv(N, 128), cdiv(M, 128), ks);
+      if (dt == XML_F32)
+        hipLaunchKernelGGL((gemm_batched_kernel<float, float, true>), grid, dim3(256), 0, st, (const float*)A,
+                           (const float*)B, (float*)out, M, N, K, kc, scale);
+      else
+        hipLaunchKernelGGL((gemm_batched_kernel<bf16_t, float, true>), grid, dim3(256), 0, st, (const bf16_t*)A,
+                           (const bf16_t*)B, (float*)out, M, N, K, kc, scale);
+      XML_CHECK_LAUNCH();
+      return XML_OK;
+    }
   }
+  dim3 grid(cdiv(N, 128), cdiv(M, 128), batch);
+  if (dt == XML_F32)
+    hipLaunchKernelGGL((gemm_batched_kernel<float, float, false>), grid, dim3(256), 0, st, (const float*)A,
+                       (const float*)B, (float*)out, M, N, K, 0, scale);
+  else if (out_f32)
+    hipLaunchKernelGGL((gemm_batched_kernel<bf16_t, float, false>), grid, dim3(256), 0, st, (const bf16_t*)A,
+                       (const bf16_t*)B, (float*)out, M, N, K, 0, scale);
+  else
+    hipLaunchKernelGGL((gemm_batched_kernel<bf16_t, bf16_t, false>), grid, dim3(256), 0, st, (const bf16_t*)A,
+                       (const bf16_t*)B, (bf16_t*)out, M, N, K, 0, scale);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }
@@ -353,43 +420,72 @@ extern "C" int xml_gemm_batched(const void* A, const void* B, void* out, int bat
 // head split / merge between the (n*L, ld) token-major layout and per-(sequence, head) contiguous matrices
 //   dst  [n][h][l8][dh]   (rows >= L zero)      dstT [n][h][dh][l8]   (columns >= L zero)
 // ---------------------------------------------------------------------------------------------------------
+// block = (64-row tile of l, one (sequence, head)); the tile goes through LDS so that both the row-major copy and
+// the transposed copy are written with 16-byte vectors
 template <typename T>
-__global__ void split_heads_kernel(const T* __restrict__ src, int ld, int col0, int L, int l8, int heads, int dh,
-                                   T* __restrict__ dst, T* __restrict__ dstT, int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int d = (int)(i % dh);
-    const int l = (int)((i / dh) % l8);
-    const int h = (int)((i / ((int64_t)dh * l8)) % heads);
-    const int64_t n = i / ((int64_t)dh * l8 * heads);
-    T v = 0;
-    if (l < L) v = src[(n * L + l) * ld + col0 + h * dh + d];
-    if (dst) dst[i] = v;
-    if (dstT) dstT[((n * heads + h) * dh + d) * l8 + l] = v;
+__global__ __launch_bounds__(256) void split_heads_kernel(const T* __restrict__ src, int ld, int col0, int L, int l8,
+                                                          int heads, int dh, T* __restrict__ dst, T* __restrict__ dstT) {
+  constexpr int EV = 16 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* tile = reinterpret_cast<T*>(smem_raw);            // [64][dh + EV]
+  const int pitch = dh + EV;
+  const int l0 = blockIdx.x * 64;
+  const int64_t z = blockIdx.y;
+  const int64_t n = z / heads;
+  const int h = (int)(z % heads);
+  const int nvec = dh / EV;
+  for (int idx = threadIdx.x; idx < 64 * nvec; idx += 256) {
+    const int row = idx / nvec, vc = idx % nvec;
+    const int l = l0 + row;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (l < L) v = *reinterpret_cast<const uint4*>(src + (n * L + l) * ld + col0 + h * dh + vc * EV);
+    *reinterpret_cast<uint4*>(tile + row * pitch + vc * EV) = v;
+    if (dst && l < l8) *reinterpret_cast<uint4*>(dst + (z * l8 + l) * dh + vc * EV) = v;
+  }
+  if (!dstT) return;
+  __syncthreads();
+  constexpr int LV = 64 / EV;                          // l-vectors per tile row of the transposed copy
+  for (int idx = threadIdx.x; idx < dh * LV; idx += 256) {
+    const int d = idx / LV, lc = idx % LV;
+    const int l = l0 + lc * EV;
+    if (l >= l8) continue;
+    T tmp[EV];
+#pragma unroll
+    for (int j = 0; j < EV; ++j) tmp[j] = tile[(lc * EV + j) * pitch + d];
+    *reinterpret_cast<uint4*>(dstT + (z * dh + d) * l8 + l) = *reinterpret_cast<const uint4*>(tmp);
   }
 }
 template <typename T>
 __global__ void merge_heads_kernel(const T* __restrict__ src, T* __restrict__ dst, int ld, int col0, int L, int l8,
-                                   int heads, int dh, int64_t total) {
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int d = (int)(i % dh);
-    const int h = (int)((i / dh) % heads);
-    const int l = (int)((i / ((int64_t)dh * heads)) % L);
-    const int64_t n = i / ((int64_t)dh * heads * L);
-    dst[(n * L + l) * ld + col0 + h * dh + d] = src[((n * heads + h) * l8 + l) * dh + d];
+                                   int heads, int dh, int64_t total_vec) {
+  constexpr int EV = 16 / sizeof(T);
+  const int nvec = dh / EV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_vec; i += (int64_t)gridDim.x * blockDim.x) {
+    const int vc = (int)(i % nvec);
+    const int h = (int)((i / nvec) % heads);
+    const int l = (int)((i / ((int64_t)nvec * heads)) % L);
+    const int64_t n = i / ((int64_t)nvec * heads * L);
+    *reinterpret_cast<uint4*>(dst + (n * L + l) * ld + col0 + h * dh + vc * EV) =
+        *reinterpret_cast<const uint4*>(src + ((n * heads + h) * l8 + l) * dh + vc * EV);
   }
 }
 
 extern "C" int xml_split_heads(const void* src, int ld, int col0, int64_t n, int L, int l8, int heads, int dh, void* dst,
                                void* dstT, int dt, xml_stream_t stream) {
   XML_ENTER();
-  if (!src || (!dst && !dstT) || n <= 0 || L <= 0 || l8 < L) return XML_ERR_BAD_ARG;
-  const int64_t total = n * heads * l8 * dh;
-  if (dt == XML_F32)
-    hipLaunchKernelGGL(split_heads_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld, col0, L, l8, heads, dh, (float*)dst, (float*)dstT, total);
-  else if (dt == XML_BF16)
-    hipLaunchKernelGGL(split_heads_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld, col0, L, l8, heads, dh, (bf16_t*)dst, (bf16_t*)dstT, total);
-  else
+  if (!src || (!dst && !dstT) || n <= 0 || L <= 0 || l8 < L || (l8 & 7)) return XML_ERR_BAD_ARG;
+  if ((dh & 7) || (ld & 7) || (col0 & 7) || dh > 256) return XML_ERR_UNSUPPORTED;     // 16-byte vectors, <= 64 KB LDS
+  dim3 grid(cdiv(l8, 64), (unsigned)(n * heads));
+  if (dt == XML_F32) {
+    const size_t lds = (size_t)64 * (dh + 4) * 4;
+    if (lds > 65536) return XML_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(split_heads_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, (const float*)src, ld, col0, L, l8, heads, dh, (float*)dst, (float*)dstT);
+  } else if (dt == XML_BF16) {
+    const size_t lds = (size_t)64 * (dh + 8) * 2;
+    hipLaunchKernelGGL(split_heads_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, (const bf16_t*)src, ld, col0, L, l8, heads, dh, (bf16_t*)dst, (bf16_t*)dstT);
+  } else {
     return XML_ERR_BAD_ARG;
+  }
   XML_CHECK_LAUNCH();
   return XML_OK;
 }
@@ -398,13 +494,16 @@ extern "C" int xml_merge_heads(const void* src, void* dst, int ld, int col0, int
                                int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!src || !dst || n <= 0 || L <= 0 || l8 < L) return XML_ERR_BAD_ARG;
-  const int64_t total = n * L * heads * dh;
-  if (dt == XML_F32)
+  if ((dh & 7) || (ld & 7) || (col0 & 7)) return XML_ERR_UNSUPPORTED;
+  if (dt == XML_F32) {
+    const int64_t total = n * L * heads * (dh / 4);
     hipLaunchKernelGGL(merge_heads_kernel<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const float*)src, (float*)dst, ld, col0, L, l8, heads, dh, total);
-  else if (dt == XML_BF16)
+  } else if (dt == XML_BF16) {
+    const int64_t total = n * L * heads * (dh / 8);
     hipLaunchKernelGGL(merge_heads_kernel<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, (bf16_t*)dst, ld, col0, L, l8, heads, dh, total);
-  else
+  } else {
     return XML_ERR_BAD_ARG;
+  }
   XML_CHECK_LAUNCH();
   return XML_OK;
 }
@@ -936,29 +1035,48 @@ __device__ __forceinline__ int find_seg(const int64_t* __restrict__ seg_off, int
   }
   return lo;
 }
+// one block = 4096 consecutive elements; when they all belong to one tensor (the common case) the block reduces
+// in registers / LDS and issues a single atomic
 __global__ __launch_bounds__(256) void adam_norm_kernel(const float* __restrict__ g, const int64_t* __restrict__ seg_off,
                                                         int n_seg, int64_t total, float* __restrict__ norms) {
-  const int64_t i0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
-  const bool valid = i0 < total;
-  const int s_first = valid ? find_seg(seg_off, n_seg, i0) : -1;
-  int s = s_first;
-  float acc = 0.f;
-  if (valid)
-    for (int k = 0; k < 4 && i0 + k < total; ++k) {
-      while (i0 + k >= seg_off[s + 1]) {      // crossed into the next tensor: flush
-        atomicAdd(norms + s, acc);
-        acc = 0.f;
-        ++s;
+  __shared__ float s_part[4];
+  const int64_t base = (int64_t)blockIdx.x * 4096;
+  const int64_t last = base + 4095 < total ? base + 4095 : total - 1;
+  const int s_lo = find_seg(seg_off, n_seg, base);
+  const bool uniform = last < seg_off[s_lo + 1];
+  if (uniform) {
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int64_t i = base + it * 1024 + threadIdx.x * 4;
+      if (i + 3 < total) {
+        const float4 v = *reinterpret_cast<const float4*>(g + i);
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      } else {
+        for (int k = 0; k < 4; ++k) if (i + k < total) acc += g[i + k] * g[i + k];
       }
-      acc += g[i0 + k] * g[i0 + k];
     }
-  // wave-level pre-reduction when the whole wave sits in one tensor
-  const int s0 = __shfl(s_first, 0);
-  if (__all(s_first == s0 && s == s0)) {
     acc = wave_sum(acc);
-    if ((threadIdx.x & 63) == 0 && s0 >= 0) atomicAdd(norms + s0, acc);
-  } else if (valid) {
-    atomicAdd(norms + s, acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(norms + s_lo, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+    return;
+  }
+  const int lane = threadIdx.x & 63;
+  for (int it = 0; it < 16; ++it) {       // tensor boundary inside the block: segmented reduction per wave
+    const int64_t i = base + it * 256 + threadIdx.x;
+    const bool valid = i < total;
+    const int seg = valid ? find_seg(seg_off, n_seg, i) : -1;
+    const float val = valid ? g[i] * g[i] : 0.f;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int s_cur = __shfl(seg, leader);
+      const bool mine = valid && seg == s_cur;
+      const float part = wave_sum(mine ? val : 0.f);
+      if (lane == leader) atomicAdd(norms + s_cur, part);
+      todo &= ~__ballot(mine);
+    }
   }
 }
 __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -993,7 +1111,7 @@ extern "C" int xml_bert_adam_step(float* p, float* g, float* m, float* v, const 
   hipStream_t st = (hipStream_t)stream;
   if (max_grad_norm > 0.f) {
     if (hipMemsetAsync(norms, 0, (size_t)n_seg * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
-    hipLaunchKernelGGL(adam_norm_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, g, seg_off, n_seg, total, norms);
+    hipLaunchKernelGGL(adam_norm_kernel, dim3(cdiv(total, 4096)), dim3(256), 0, st, g, seg_off, n_seg, total, norms);
   }
   hipLaunchKernelGGL(adam_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p, g, m, v, seg_off, seg_lr, seg_wd,
                      n_seg, total, norms, lr_mult, b1, b2, eps, max_grad_norm);

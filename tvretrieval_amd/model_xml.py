@@ -410,11 +410,17 @@ class XML(nn.Module):
 
     def forward(self, query_feat, query_mask, video_feat, video_mask, sub_feat, sub_mask, tef_feat, tef_mask,
                 st_ed_indices, neg_ctx_rank=None, neg_q_rank=None):
-        """XML.forward (xml/model_xml.py:212-251): loss VALUES through the HIP forward kernels.
+        """XML.forward (xml/model_xml.py:212-251) -> (loss, loss dict).
 
-        Round-1 status: forward only (no autograd through the HIP kernels yet); dropout is not applied.  The
+        With autograd enabled this is the training graph of tvretrieval_amd.train (HIP forward + hand-written HIP
+        backward nodes; `loss.backward()` fills the f32 `.grad` of every parameter).  Under torch.no_grad() the
+        fused inference kernels compute the loss values only.  Dropout is not applied in either mode.  The
         in-batch negatives of get_neg_scores (xml/model_xml.py:608-624) are drawn with torch.randint on the CPU
         generator in the reference's order unless rank indices are injected."""
+        if torch.is_grad_enabled():
+            from .train import xml_forward_train
+            return xml_forward_train(self, query_feat, query_mask, video_feat, video_mask, sub_feat, sub_mask,
+                                     st_ed_indices, neg_ctx_rank, neg_q_rank)
         cfg = self.config
         v1, v2, s1, s2 = self.encode_context(video_feat, video_mask, sub_feat, sub_mask)
         q2c, st, ed = self.get_pred_from_raw_query(query_feat, query_mask, v1, v2, video_mask, s1, s2, sub_mask,

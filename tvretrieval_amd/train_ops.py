@@ -62,8 +62,9 @@ def layernorm_bwd(a, b, g, dy, need_dx=True):
     rows = a.numel() // d
     dg = torch.zeros(d, dtype=F32, device=a.device)
     dbeta = torch.zeros(d, dtype=F32, device=a.device)
-    dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (need_dx or d <= 1024) else None
-    ws = _workspace(rows * 16, a.device) if d > 1024 else None
+    wide = d > 1024 or d % 8 != 0
+    dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (need_dx or not wide) else None
+    ws = _workspace(rows * 16, a.device) if wide else None
     check(_lib.load().xml_layernorm_bwd(_p(a), dt_of(a), _p(b), _p(g), _p(dy), _p(dx), _p(dg), _p(dbeta), rows, d,
                                         dt_of(dy), _p(ws), 0 if ws is None else ws.numel(), _stream()),
           "xml_layernorm_bwd")

@@ -37,6 +37,16 @@ __device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase, uint32_
       : "memory");
 }
 
+// same, with the non-temporal hint: streamed clip tiles should not displace the L2-resident query group
+__device__ __forceinline__ void dma16s_nt(uint32_t voff, const char* sbase, uint32_t lds_dst) {
+  uint32_t keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_dst)
+      : "memory");
+}
+
 __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // Specialised to lpad == 128 (one video per 128-column group -- the TVR shape): no per-column divisions, one
@@ -129,8 +139,13 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     if (ABL != 1 || i_gs < 4) {
       dma16s(voff_a0, sbase_a + koff, dst);
       dma16s(voff_a1, sbase_a + koff, dst + 1024);
-      dma16s(voff_b0, sbase_b + koff, dst + OPER_BYTES);
-      dma16s(voff_b1, sbase_b + koff, dst + OPER_BYTES + 1024);
+      if (ABL == 3) {
+        dma16s_nt(voff_b0, sbase_b + koff, dst + OPER_BYTES);
+        dma16s_nt(voff_b1, sbase_b + koff, dst + OPER_BYTES + 1024);
+      } else {
+        dma16s(voff_b0, sbase_b + koff, dst + OPER_BYTES);
+        dma16s(voff_b1, sbase_b + koff, dst + OPER_BYTES + 1024);
+      }
     }
     ++i_gs;
     if (++i_slice == slices_per_seg) {   // next segment: other modality of the tile, or the next tile
@@ -275,7 +290,7 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
   const int lds = 4 * 2 * 256 * 64 + 2048 + 2048;
   extern int g_q2c_ablation;
   auto kern = g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
-                                                                                     : q2c_persist_kernel<T, 0>;
+             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : q2c_persist_kernel<T, 0>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);

@@ -39,7 +39,8 @@ WORKLOADS = {
     "tiny": (64, 300, 128, 256, 512, 256, 256, "video_sub", "bf16"),
 }
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
-CHUNK = 256                                       # videos per encode batch (shard boundaries align to it)
+CHUNK = 256                                       # videos per synthetic / encode batch
+SHARD_ALIGN = 64                                  # shard boundaries: one K6 round of an XCD set = 8 XCDs x 4 tiles x 2 videos
 
 
 def model_config(hidden, dv, ds, dq, ctx_mode, max_ctx_l):
@@ -59,12 +60,14 @@ def synth_rows(n, l, d, seed, device):
 
 
 def context_batches(lo, hi, l, dv, ds, use_video, use_sub, device):
-    for b in range(lo, hi, CHUNK):
-        n = min(CHUNK, hi - b)
-        cid = b // CHUNK
-        mask = torch.ones((n, l), device=device)
-        vf = synth_rows(n, l, dv, 2018 + 2 * cid, device) if use_video else None
-        sf = synth_rows(n, l, ds, 2018 + 2 * cid + 1, device) if use_sub else None
+    """Videos [lo, hi) of the synthetic corpus.  Chunk c (videos 256 c .. 256 c + 255) is generated from its own seed,
+    so the corpus content does not depend on how it is sharded."""
+    for cid in range(lo // CHUNK, (hi + CHUNK - 1) // CHUNK):
+        b0 = cid * CHUNK
+        r0, r1 = max(lo, b0) - b0, min(hi, b0 + CHUNK) - b0
+        mask = torch.ones((r1 - r0, l), device=device)
+        vf = synth_rows(CHUNK, l, dv, 2018 + 2 * cid, device)[r0:r1].contiguous() if use_video else None
+        sf = synth_rows(CHUNK, l, ds, 2018 + 2 * cid + 1, device)[r0:r1].contiguous() if use_sub else None
         yield vf, mask if use_video else None, sf, mask if use_sub else None
 
 
@@ -142,7 +145,7 @@ def main():
     model = XML(cfg, compute_dtype=dtype).to(device).eval()
 
     # ---- one-off: encode this rank's shard of the corpus (HOT LOOP A), untimed for the metric -------------
-    lo, hi = xdist.shard_range(nv, rank, world, align=CHUNK)
+    lo, hi = xdist.shard_range(nv, rank, world, align=SHARD_ALIGN)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     with torch.no_grad():

@@ -310,3 +310,36 @@ def test_svmr_only_external_vr_and_eval_epoch(tmp_path):
     for i in range(ds.n_q):
         np.testing.assert_allclose(np.array(sub_nms["VCMR"][i]["predictions"]).reshape(-1, 4)[:, :3],
                                    d["nms/VCMR/%d" % i][:, :3], atol=1e-6)
+
+
+def test_c1_single_query_single_video_svmr():
+    """BASELINE configs[0]: SVMR with 1 query x 1 video (128 clips, d=768), video-only context, against the
+    reference formulation: span logits, softmaxed probabilities, the banded top-n moments of the given video."""
+    from tvretrieval_amd import inference as inf
+    l = 128
+    m, cfg = _synthetic_model("video", 768, 768, 768, 768, l, torch.float32, seed=9)
+    vf, vm = _feats(1, [l], 768, 11)
+    qf, qm = _feats(1, [17], 768, 12)
+    dummy = torch.zeros(1, 2, 2)
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    om = O.OracleXML(cfg, sd)
+    with torch.no_grad():
+        ov1, ov2, _, _ = om.encode_context(vf, vm, dummy, dummy)
+        q2c, st, ed = om.get_pred_from_raw_query(qf, qm, ov1, ov2, vm, None, None, None, cross=True)
+        st_p, ed_p = torch.softmax(st[:, 0], -1), torch.softmax(ed[:, 0], -1)
+        want = O.svmr_tail(st_p.numpy(), ed_p.numpy(), 2, 16, 200)          # (1, n, 3): st idx, ed idx, score
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), None, None)])
+        out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=100, max_before_nms=200,
+                              svmr_video=torch.zeros(1, dtype=torch.int32, device=DEV))
+    assert out["top_indices"].shape == (1, 1) and int(out["top_indices"][0, 0]) == 0
+    close("q2c", out["q2c"], q2c, 1e-4)
+    close("svmr st prob", out["svmr_st"][:, :l], st_p, 0, 2e-3)
+    close("svmr ed prob", out["svmr_ed"][:, :l], ed_p, 0, 2e-3)
+    gs, gf = out["svmr_scores"].cpu().numpy()[0], out["svmr_flat"].cpu().numpy()[0]
+    ws, wf = want[0, :, 2], (want[0, :, 0] * l + want[0, :, 1]).astype(np.int64)
+    n = int((ws > 0).sum())
+    assert n > 100 and (gf[n:] == -1).all()
+    np.testing.assert_allclose(gs[:n], ws[:n], rtol=5e-3)
+    assert (gf[:n] == wf[:n]).mean() > 0.9
+    # VCMR over a one-video corpus ranks the same spans (weight exp(20 s) is a common factor)
+    assert (out["flat_indices"].cpu().numpy()[0][:n] == gf[:n]).mean() > 0.95

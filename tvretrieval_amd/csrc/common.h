@@ -67,6 +67,24 @@ template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
   return v;
 }
 
+// 8 consecutive elements as floats (16-byte loads for bf16, 2 x 16 bytes for f32)
+template <typename T> __device__ __forceinline__ void ld8(const T* p, float* out) {
+  if constexpr (sizeof(T) == 2) {
+    unpack16<bf16_t>(*reinterpret_cast<const uint4*>(p), out);
+  } else {
+    unpack16<float>(*reinterpret_cast<const uint4*>(p), out);
+    unpack16<float>(*reinterpret_cast<const uint4*>(p + 4), out + 4);
+  }
+}
+template <typename T> __device__ __forceinline__ void st8(T* p, const float* in) {
+  if constexpr (sizeof(T) == 2) {
+    *reinterpret_cast<uint4*>(p) = pack16<bf16_t>(in);
+  } else {
+    *reinterpret_cast<uint4*>(p) = pack16<float>(in);
+    *reinterpret_cast<uint4*>(p + 4) = pack16<float>(in + 4);
+  }
+}
+
 // ---- MFMA "chunk": one 64-byte slice of K for a 16x16 output tile -------------------------------
 // Lane l supplies 16 bytes of row (l & 15) at byte offset (l >> 4) * 16 of the 64-byte K chunk, for both
 // operands (A rows = output rows, B rows = output columns; both K-contiguous).

@@ -143,11 +143,79 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const InT* __restric
   for (int i = d + lane; i < ld_out; i += 64) DT<OutT>::st(py + i, 0.f);  // zero K padding
 }
 
+// Vectorised variant (d % 8 == 0, d <= 64 * 8 * VPL): lane owns the 8-element vectors lane + 64 k, the row stays in
+// registers, inputs are read once with 16-byte loads.  VPL = 2 covers the hidden size (<= 1024), 6 / 8 the raw
+// feature rows of the input LayerNorm (3072 / 4096).
+template <typename InT, typename BT, typename OutT, int VPL>
+__global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __restrict__ a, const BT* __restrict__ b,
+                                                                const float* __restrict__ g,
+                                                                const float* __restrict__ beta, OutT* __restrict__ y,
+                                                                int64_t rows, int d, int ld_out, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int nvec = d >> 3;
+  const InT* pa = a + row * d;
+  const BT* pb = b ? b + row * d : nullptr;
+  OutT* py = y + row * ld_out;
+  float x[VPL * 8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec) {
+      ld8<InT>(pa + v * 8, x + k * 8);
+      if (pb) {
+        float t[8];
+        ld8<BT>(pb + v * 8, t);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[k * 8 + j] += t[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[k * 8 + j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += x[k * 8 + j];
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < VPL; ++k)
+    if (lane + k * 64 < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float c = x[k * 8 + j] - mean; var += c * c; }
+  const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);
+#pragma unroll
+  for (int k = 0; k < VPL; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec) {
+      float gv[8], bv[8], o[8];
+      ld8<float>(g + v * 8, gv);
+      ld8<float>(beta + v * 8, bv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = (x[k * 8 + j] - mean) * rstd * gv[j] + bv[j];
+      st8<OutT>(py + v * 8, o);
+    }
+  }
+  for (int i = d + lane; i < ld_out; i += 64) DT<OutT>::st(py + i, 0.f);  // zero K padding
+}
+
 template <typename InT, typename BT, typename OutT>
 static int launch_ln(const void* a, const void* b, const float* g, const float* beta, void* y, int64_t rows, int d,
                      int ld_out, hipStream_t st) {
-  hipLaunchKernelGGL((add_layernorm_kernel<InT, BT, OutT>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const InT*)a,
-                     (const BT*)b, g, beta, (OutT*)y, rows, d, ld_out, 1e-5f);
+  const dim3 grid(cdiv(rows, 4)), blk(256);
+  const bool vec = (d % 8 == 0) && (ld_out % 8 == 0);     // 16-byte aligned rows on both sides
+#define XML_LN_VEC(VPL)                                                                                              \
+  hipLaunchKernelGGL((add_layernorm_vec_kernel<InT, BT, OutT, VPL>), grid, blk, 0, st, (const InT*)a, (const BT*)b, g, \
+                     beta, (OutT*)y, rows, d, ld_out, 1e-5f)
+  if (vec && d <= 1024) XML_LN_VEC(2);
+  else if (vec && d <= 3072) XML_LN_VEC(6);
+  else if (vec && d <= 4096) XML_LN_VEC(8);
+  else
+    hipLaunchKernelGGL((add_layernorm_kernel<InT, BT, OutT>), grid, blk, 0, st, (const InT*)a, (const BT*)b, g, beta,
+                       (OutT*)y, rows, d, ld_out, 1e-5f);
+#undef XML_LN_VEC
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

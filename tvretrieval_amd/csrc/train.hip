@@ -129,24 +129,6 @@ extern "C" int xml_add_inplace(void* y, int y_dt, const void* x, int x_dt, int64
 //   dg += sum_rows dy * xhat,  dbeta += sum_rows dy          (f32, accumulated with one atomic per column per block)
 // One wave per row (d <= 1024 values in registers); a block walks ROWS_PER_BLOCK rows and keeps column partials.
 // ---------------------------------------------------------------------------------------------------------
-// 8 consecutive elements as floats (16-byte loads for bf16, 2 x 16 bytes for f32)
-template <typename T> __device__ __forceinline__ void ld8(const T* p, float* out) {
-  if constexpr (sizeof(T) == 2) {
-    unpack16<bf16_t>(*reinterpret_cast<const uint4*>(p), out);
-  } else {
-    unpack16<float>(*reinterpret_cast<const uint4*>(p), out);
-    unpack16<float>(*reinterpret_cast<const uint4*>(p + 4), out + 4);
-  }
-}
-template <typename T> __device__ __forceinline__ void st8(T* p, const float* in) {
-  if constexpr (sizeof(T) == 2) {
-    *reinterpret_cast<uint4*>(p) = pack16<bf16_t>(in);
-  } else {
-    *reinterpret_cast<uint4*>(p) = pack16<float>(in);
-    *reinterpret_cast<uint4*>(p + 4) = pack16<float>(in + 4);
-  }
-}
-
 // d % 8 == 0, d <= 1024: lane owns the 8-element vectors v = lane + 64*k (k < 2).  A block (4 waves) walks
 // 4 * rows_per_wave rows, combines the column partials of its waves in LDS and issues one atomic per column.
 template <typename InT, typename BT, typename T>

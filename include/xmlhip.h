@@ -281,6 +281,11 @@ int xml_span_loss(const float* sim0, const float* sim1, const float* conv_w, con
  *   gout (2 floats) != NULL: dscores (overwritten) = gout[0] * d loss_neg_ctx + gout[1] * d loss_neg_q. */
 int xml_rank_loss(const float* scores, const int* ranks_ctx, const int* ranks_q, float margin, int lse,
                   int n, const float* gout, float* losses, float* dscores, xml_stream_t stream);
+/* nn.Dropout in training mode (LinearLayer, TrainablePositionalEncoding, BertSelfAttention probabilities,
+ * BertSelfOutput; xml/model_components.py:88,151,239,297,315): y = keep(i) ? x / (1 - p) : 0 with a counter-based
+ * mask that is a pure function of (seed, element index) -- the backward pass calls it again on the gradient.
+ * 0 <= p < 1; y == x allowed.  Not torch's Philox stream: statistically, not bitwise, equal to the reference. */
+int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dt, xml_stream_t stream);
 /* BertAdam.step (xml/optimization.py:273-338) over one flat f32 buffer holding every tensor:
  * per-tensor clip_grad_norm_ (gradient rescaled in place), m/v update, m/(sqrt(v)+eps) + wd*p, no bias
  * correction, p -= seg_lr[s] * lr_mult * update.  seg_off (n_seg+1) int64, seg_lr / seg_wd / norms (n_seg) f32,

@@ -234,7 +234,7 @@ def build_train_model(cfg, d, dtype=F32):
     m = XML(cfg, compute_dtype=dtype)
     sd = {k[len("sd_before/"):]: torch.from_numpy(np.asarray(v)) for k, v in d.items() if k.startswith("sd_before/")}
     m.load_state_dict(sd)
-    return m.to(DEV)
+    return m.to(DEV).eval()     # the fixtures were captured from the reference in eval mode (dropout off)
 
 
 def T(a):
@@ -318,3 +318,72 @@ def test_model_forward_dispatch():
     assert abs(float(loss) - float(d["loss"])) < 2e-5 and abs(float(loss2) - float(d["loss"])) < 2e-5
     for k in ("loss_st_ed", "loss_neg_ctx", "loss_neg_q"):
         assert abs(parts[k] - parts2[k]) < 2e-5
+
+
+def test_dropout_kernel_statistics_and_backward():
+    from tvretrieval_amd.autograd import DropoutFn
+    from tvretrieval_amd import train_ops as TO
+    x = torch.ones(1 << 20, device=DEV)
+    for p in (0.1, 0.5):
+        y = TO.dropout(x, p, seed=1234)
+        keep = (y != 0).float().mean().item()
+        assert abs(keep - (1 - p)) < 4e-3, (p, keep)                     # ~4 sigma at n = 2^20
+        assert torch.allclose(y[y != 0], torch.full((1,), 1 / (1 - p), device=DEV))
+        assert torch.equal(y, TO.dropout(x, p, seed=1234))                # pure function of (seed, index)
+        y2 = TO.dropout(x, p, seed=1235)
+        both = ((y != 0) & (y2 != 0)).float().mean().item()               # independent masks across seeds
+        assert abs(both - (1 - p) ** 2) < 6e-3, (p, both)
+    # no visible structure along rows of a (rows, 768) activation: per-column keep rates stay binomial
+    y = TO.dropout(torch.ones(4096, 768, device=DEV), 0.1, seed=77)
+    col = (y != 0).float().mean(0)
+    assert float((col - 0.9).abs().max()) < 0.03
+    # backward = the same mask and scale
+    xx = torch.randn(1000, 64, device=DEV, requires_grad=True)
+    out = DropoutFn.apply(xx, 0.3, 99)
+    out.backward(torch.ones_like(out))
+    assert torch.equal(xx.grad != 0, out != 0)
+    assert torch.allclose(xx.grad[xx.grad != 0], torch.full((1,), 1 / 0.7, device=DEV))
+    # bf16
+    yb = TO.dropout(torch.ones(1 << 16, device=DEV, dtype=torch.bfloat16), 0.1, seed=5)
+    assert abs((yb != 0).float().mean().item() - 0.9) < 0.01
+
+
+def test_attention_probs_dropout_matches_masked_reference():
+    """AttentionCoreFn with dropout on the probabilities == torch attention with the SAME mask injected."""
+    from tvretrieval_amd.autograd import AttentionCoreFn
+    from tvretrieval_amd import train_ops as TO
+    n, l, hsz, heads, p, seed = 2, 24, 128, 4, 0.2, 4242
+    dh = hsz // heads
+    q, k, v = rnd(n, l, hsz, seed=1), rnd(n, l, hsz, seed=2), rnd(n, l, hsz, seed=3)
+    km = lens_mask(n, l, seed=4, lo=5)
+    mask = TO.dropout(torch.ones(n * heads, l, l, device=DEV), p, seed).view(n, heads, l, l)    # l % 8 == 0: no padding
+
+    def ref(q, k, v):
+        add = (1 - km[:, None, None, :]) * -10000.0
+        sp = lambda t: t.view(n, l, heads, dh).permute(0, 2, 1, 3)     # noqa: E731
+        s = torch.matmul(sp(q), sp(k).transpose(-1, -2)) / math.sqrt(dh) + add
+        o = torch.matmul(torch.softmax(s, -1) * mask, sp(v))
+        return o.permute(0, 2, 1, 3).reshape(n, l, hsz)
+    run_pair(lambda q, k, v: AttentionCoreFn.apply(q, k, v, None, km, heads, p, seed), ref, [q, k, v],
+             [True, True, True], tol=5e-5)
+
+
+def test_train_mode_step_with_dropout_runs():
+    """model.train(): dropout active at every site; repeatable under torch.manual_seed, different from eval, finite."""
+    from tvretrieval_amd.train import xml_forward_train
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    m = build_train_model(cfg, d).train()
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]), neg_ctx_rank=d["neg_ctx_rank"], neg_q_rank=d["neg_q_rank"])
+    torch.manual_seed(3)
+    l1, _ = xml_forward_train(m, **batch)
+    l1.backward()
+    g1 = m.video_encoder1.self.query.weight.grad.clone()
+    m.zero_grad()
+    torch.manual_seed(3)
+    l2, _ = xml_forward_train(m, **batch)
+    l2.backward()
+    assert float(l1) == float(l2) and torch.equal(g1, m.video_encoder1.self.query.weight.grad)
+    assert math.isfinite(float(l1)) and abs(float(l1) - float(d["loss"])) > 1e-6
+    assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)

@@ -71,6 +71,19 @@ class LinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class DropoutFn(torch.autograd.Function):
+    """nn.Dropout in training mode; the mask is regenerated from (seed, index) in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        ctx.p, ctx.seed = p, seed
+        return T.dropout(x.contiguous(), p, seed)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return T.dropout(dy.contiguous(), ctx.p, ctx.seed), None, None
+
+
 class LayerNormFn(torch.autograd.Function):
     """y = LN(a [+ b]) * g + beta; a may be raw f32 features (no gradient), b optional residual."""
 
@@ -101,7 +114,7 @@ class AttentionCoreFn(torch.autograd.Function):
     dropout on the probabilities omitted).  q (N, Lq, H), k / v (N, Lk, H); masks f32 (q_mask may be None)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, q_mask, k_mask, heads):
+    def forward(ctx, q, k, v, q_mask, k_mask, heads, p_drop=0.0, seed=0):
         n, lq, hidden = q.shape
         lk = k.shape[1]
         dh = hidden // heads
@@ -111,9 +124,12 @@ class AttentionCoreFn(torch.autograd.Function):
         _, vht = T.split_heads(v, heads, want=False, want_t=True)
         s = T.gemm_batched(qh, kh, out_f32=True)                       # (N*h, lq8, lk8)
         p, _ = T.attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype)
+        if p_drop > 0:
+            T.dropout(p, p_drop, seed, out=p)                          # attention_probs dropout, :297
         oh = T.gemm_batched(p, vht)                                    # (N*h, lq8, dh)
         out = T.merge_heads(oh, n, lq, heads)
         ctx.heads = heads
+        ctx.drop = (p_drop, seed)
         ctx.save_for_backward(q, k, v, s, q_mask, k_mask)
         return out
 
@@ -126,8 +142,15 @@ class AttentionCoreFn(torch.autograd.Function):
         dh = hidden // heads
         doh, doht = T.split_heads(dout.contiguous(), heads, want=True, want_t=True)
         vh, _ = T.split_heads(v, heads)
-        dp = T.gemm_batched(doh, vh, out_f32=True)                     # dP = dO V^T
-        _, pt = T.attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype, want_t=True)
+        dp = T.gemm_batched(doh, vh, out_f32=True)                     # dP = dO V^T   (w.r.t. the dropped probs)
+        p_drop, seed = ctx.drop
+        if p_drop > 0:
+            p, _ = T.attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype)
+            T.dropout(p, p_drop, seed, out=p)
+            pt = T.transpose(p)                                        # dropped P^T for dV
+            T.dropout(dp, p_drop, seed, out=dp)                        # through the dropout: same mask, same scale
+        else:
+            _, pt = T.attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype, want_t=True)
         ds, dst = T.attn_softmax_bwd(s, dp, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype)
         dvh = T.gemm_batched(pt, doht)                                 # dV = P^T dO      (lk8, dh)
         _, qht = T.split_heads(q, heads, want=False, want_t=True)
@@ -135,7 +158,7 @@ class AttentionCoreFn(torch.autograd.Function):
         dqh = T.gemm_batched(ds, kht)                                  # dQ = dS K        (lq8, dh)
         dkh = T.gemm_batched(dst, qht)                                 # dK = dS^T Q      (lk8, dh)
         return (T.merge_heads(dqh, n, lq, heads), T.merge_heads(dkh, n, lk, heads), T.merge_heads(dvh, n, lk, heads),
-                None, None, None)
+                None, None, None, None, None)
 
 
 class ModularPoolFn(torch.autograd.Function):

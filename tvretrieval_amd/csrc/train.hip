@@ -1100,3 +1100,40 @@ extern "C" int xml_bert_adam_step(float* p, float* g, float* m, float* v, const 
   XML_CHECK_LAUNCH();
   return XML_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// nn.Dropout (training mode): y = keep(i) ? x / (1 - p) : 0 with a counter-based mask keep(i) = hash(seed, i) >= p 2^32.
+// The mask is a pure function of (seed, element index), so the backward pass re-applies the same call to the
+// gradient instead of storing a mask.  In place (y == x) is allowed.  The random stream is NOT torch's Philox
+// stream: dropout is statistically, not bitwise, equivalent to the reference's.
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t drop_hash(uint64_t i, uint32_t s0, uint32_t s1) {
+  uint32_t h = (uint32_t)i * 0x9E3779B1u + s0;
+  h ^= (uint32_t)(i >> 32) * 0x85EBCA77u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h += s1; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+template <typename T>
+__global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, uint32_t thresh, float scale,
+                               uint32_t s0, uint32_t s1) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    DT<T>::st(y + i, drop_hash((uint64_t)i, s0, s1) >= thresh ? DT<T>::ld(x + i) * scale : 0.f);
+}
+
+extern "C" int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !y || n <= 0 || !(p >= 0.f) || p >= 1.f) return XML_ERR_BAD_ARG;
+  const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
+  const float scale = 1.f / (1.f - p);
+  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32) * 0x27D4EB2Fu + 0x165667B1u;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, thresh, scale, s0, s1);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n, thresh, scale, s0, s1);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}

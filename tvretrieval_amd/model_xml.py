@@ -413,8 +413,9 @@ class XML(nn.Module):
         """XML.forward (xml/model_xml.py:212-251) -> (loss, loss dict).
 
         With autograd enabled this is the training graph of tvretrieval_amd.train (HIP forward + hand-written HIP
-        backward nodes; `loss.backward()` fills the f32 `.grad` of every parameter).  Under torch.no_grad() the
-        fused inference kernels compute the loss values only.  Dropout is not applied in either mode.  The
+        backward nodes; `loss.backward()` fills the f32 `.grad` of every parameter; dropout is applied in
+        `model.train()` mode).  Under torch.no_grad() the fused inference kernels compute the loss values only
+        (no dropout, as in `model.eval()`).  The
         in-batch negatives of get_neg_scores (xml/model_xml.py:608-624) are drawn with torch.randint on the CPU
         generator in the reference's order unless rank indices are injected."""
         if torch.is_grad_enabled():

@@ -10,16 +10,19 @@ Mirrors the reference's training inner loop (xml/train.py:62-111): `loss, loss_d
   * `allreduce_gradients` averages the flat gradient buffer over ranks in size-bounded buckets (RCCL over xGMI,
     one process per GPU); the reference has no multi-process training (it wraps nn.DataParallel, xml/train.py:236).
 
-Status: dropout (input_drop / drop / cross_att_drop, active in the reference's train mode) is not applied --
-parity is pinned on the eval-mode training-step fixture (tests/golden/train_step_video_sub_h128.npz).
+Dropout: in `model.train()` mode the four dropout sites of the reference (LinearLayer input, positional encoding
+output, attention probabilities, BertSelfOutput; xml/model_components.py:88,151,239,297,315) are applied by a
+counter-based mask kernel (xml_dropout) seeded from torch's CPU generator -- statistically, not bitwise, the
+reference's stream.  Parity is pinned in `model.eval()` mode on the training-step fixtures
+(tests/golden/train_step_*.npz), which the reference also produced in eval mode.
 """
 import math
 
 import torch
 
 from . import train_ops as T
-from .autograd import (AttentionCoreFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn, SpanLossFn,
-                       VideoLevelScoresFn)
+from .autograd import (AttentionCoreFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn,
+                       SpanLossFn, VideoLevelScoresFn)
 
 F32 = torch.float32
 
@@ -47,14 +50,30 @@ class _PosTableFn(torch.autograd.Function):
         return dw, None, None, None
 
 
+def _seed():
+    """A fresh 62-bit dropout seed from torch's CPU generator (so torch.manual_seed makes a run repeatable)."""
+    return int(torch.randint(0, 2 ** 62, (1,)).item())
+
+
+def _drop(x, module):
+    """module: an nn.Dropout holder of the parameter tree; identity in eval mode or with p == 0."""
+    if not module.training or module.p <= 0:
+        return x
+    return DropoutFn.apply(x, float(module.p), _seed())
+
+
+def _probs_drop(sa):
+    return (float(sa.dropout.p), _seed()) if (sa.training and sa.dropout.p > 0) else (0.0, 0)
+
+
 def _bert_attention(mod, x, key_mask, dt):
     """BertAttention = BertSelfAttention + BertSelfOutput (xml/model_components.py:201-216,313-317)."""
     sa, so = mod.self, mod.output
     q = LinearFn.apply(x, sa.query.weight, sa.query.bias, False)
     k = LinearFn.apply(x, sa.key.weight, sa.key.bias, False)
     v = LinearFn.apply(x, sa.value.weight, sa.value.bias, False)
-    a = AttentionCoreFn.apply(q, k, v, None, key_mask, sa.num_attention_heads)
-    d = LinearFn.apply(a, so.dense.weight, so.dense.bias, False)
+    a = AttentionCoreFn.apply(q, k, v, None, key_mask, sa.num_attention_heads, *_probs_drop(sa))
+    d = _drop(LinearFn.apply(a, so.dense.weight, so.dense.bias, False), so.dropout)
     return LayerNormFn.apply(d, x, so.LayerNorm.weight, so.LayerNorm.bias, dt)
 
 
@@ -65,9 +84,9 @@ def _encode_input(model, feat, mask, proj, enc, pos):
         feat = feat.float()
     n, seq_len = feat.shape[:2]
     x = LayerNormFn.apply(feat.contiguous(), None, proj.LayerNorm.weight, proj.LayerNorm.bias, dt)
-    x = LinearFn.apply(x, proj.net[1].weight, proj.net[1].bias, True)
+    x = LinearFn.apply(_drop(x, proj.net[0]), proj.net[1].weight, proj.net[1].bias, True)
     p = _PosTableFn.apply(pos.position_embeddings.weight, n, seq_len, dt)
-    x = LayerNormFn.apply(x, p, pos.LayerNorm.weight, pos.LayerNorm.bias, dt)
+    x = _drop(LayerNormFn.apply(x, p, pos.LayerNorm.weight, pos.LayerNorm.bias, dt), pos.dropout)
     return _bert_attention(enc, x, mask, dt)
 
 
@@ -77,7 +96,7 @@ def _cross_context(model, main, main_mask, side, side_mask, cross, norm, self_at
     q = LinearFn.apply(main, cross.query.weight, cross.query.bias, False)
     k = LinearFn.apply(side, cross.key.weight, cross.key.bias, False)
     v = LinearFn.apply(side, cross.value.weight, cross.value.bias, False)
-    a = AttentionCoreFn.apply(q, k, v, main_mask, side_mask, cross.num_attention_heads)
+    a = AttentionCoreFn.apply(q, k, v, main_mask, side_mask, cross.num_attention_heads, *_probs_drop(cross))
     res = LayerNormFn.apply(a, main, norm.weight, norm.bias, dt)
     return _bert_attention(self_att, res, main_mask, dt)
 
@@ -172,8 +191,9 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
     loss_neg_ctx = cfg.lw_neg_ctx * loss_neg_ctx
     loss_neg_q = cfg.lw_neg_q * loss_neg_q
     loss = loss_st_ed + loss_neg_ctx + loss_neg_q
-    return loss, {"loss_st_ed": float(loss_st_ed), "loss_neg_ctx": float(loss_neg_ctx),
-                  "loss_neg_q": float(loss_neg_q), "loss_overall": float(loss)}
+    f = lambda t: float(t.detach()) if torch.is_tensor(t) else float(t)      # noqa: E731
+    return loss, {"loss_st_ed": f(loss_st_ed), "loss_neg_ctx": f(loss_neg_ctx), "loss_neg_q": f(loss_neg_q),
+                  "loss_overall": f(loss)}
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -220,6 +220,14 @@ def rank_loss(scores, ranks_ctx, ranks_q, margin, lse, gout=None):
     return ds
 
 
+def dropout(x, p, seed, out=None):
+    """y = mask(seed) * x / (1 - p); the same call on a gradient is the backward pass."""
+    _req(x, "x")
+    y = torch.empty_like(x) if out is None else out
+    check(_lib.load().xml_dropout(_p(x), _p(y), x.numel(), float(p), int(seed), dt_of(x), _stream()), "xml_dropout")
+    return y
+
+
 def bert_adam_step(p, g, m, v, seg_off, seg_lr, seg_wd, norms, lr_mult, b1, b2, eps, max_grad_norm):
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (seg_lr, "seg_lr"), (seg_wd, "seg_wd"), (norms, "norms")):
         _req(t, nm, F32)

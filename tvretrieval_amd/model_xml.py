@@ -412,60 +412,31 @@ class XML(nn.Module):
                 st_ed_indices, neg_ctx_rank=None, neg_q_rank=None):
         """XML.forward (xml/model_xml.py:212-251) -> (loss, loss dict).
 
-        With autograd enabled this is the training graph of tvretrieval_amd.train (HIP forward + hand-written HIP
-        backward nodes; `loss.backward()` fills the f32 `.grad` of every parameter; dropout is applied in
-        `model.train()` mode).  Under torch.no_grad() the fused inference kernels compute the loss values only
-        (no dropout, as in `model.eval()`).  The
+        This is the graph of tvretrieval_amd.train: HIP forward kernels recorded as autograd nodes with hand-written
+        HIP backward (`loss.backward()` fills the f32 `.grad` of every parameter); under torch.no_grad() the same
+        kernels just compute the loss values.  Dropout is applied in `model.train()` mode only.  The
         in-batch negatives of get_neg_scores (xml/model_xml.py:608-624) are drawn with torch.randint on the CPU
         generator in the reference's order unless rank indices are injected."""
-        if torch.is_grad_enabled():
-            from .train import xml_forward_train
-            return xml_forward_train(self, query_feat, query_mask, video_feat, video_mask, sub_feat, sub_mask,
-                                     st_ed_indices, neg_ctx_rank, neg_q_rank)
-        cfg = self.config
-        v1, v2, s1, s2 = self.encode_context(video_feat, video_mask, sub_feat, sub_mask)
-        q2c, st, ed = self.get_pred_from_raw_query(query_feat, query_mask, v1, v2, video_mask, s1, s2, sub_mask,
-                                                   cross=False)
-        loss_st_ed = 0
-        if cfg.lw_st_ed != 0:
-            ce = nn.functional.cross_entropy
-            loss_st_ed = ce(st, st_ed_indices[:, 0]) + ce(ed, st_ed_indices[:, 1])
-        loss_neg_ctx, loss_neg_q = 0, 0
-        if cfg.lw_neg_ctx != 0 or cfg.lw_neg_q != 0:
-            loss_neg_ctx, loss_neg_q = self.get_video_level_loss(q2c, neg_ctx_rank, neg_q_rank)
-        loss_st_ed = cfg.lw_st_ed * loss_st_ed
-        loss_neg_ctx = cfg.lw_neg_ctx * loss_neg_ctx
-        loss_neg_q = cfg.lw_neg_q * loss_neg_q
-        loss = loss_st_ed + loss_neg_ctx + loss_neg_q
-        return loss, {"loss_st_ed": float(loss_st_ed), "loss_neg_ctx": float(loss_neg_ctx),
-                      "loss_neg_q": float(loss_neg_q), "loss_overall": float(loss)}
+        from .train import xml_forward_train
+        return xml_forward_train(self, query_feat, query_mask, video_feat, video_mask, sub_feat, sub_mask,
+                                 st_ed_indices, neg_ctx_rank, neg_q_rank)
 
     def get_video_level_loss(self, query_context_scores, neg_ctx_rank=None, neg_q_rank=None):
-        """xml/model_xml.py:588-637 on the (N, N) in-batch score matrix (tiny; torch ops on device tensors)."""
+        """xml/model_xml.py:588-637 on the (N, N) in-batch score matrix -> (loss_neg_ctx, loss_neg_q), unweighted
+        (xml_rank_loss kernel; differentiable when the scores carry a graph)."""
+        from .autograd import RankLossFn
+        from .train import draw_negative_ranks
         cfg = self.config
-        n = len(query_context_scores)
-        ar = torch.arange(n, device=query_context_scores.device)
-        pos = query_context_scores[ar, ar]
-        masked = query_context_scores.detach().clone()
-        masked[ar, ar] = 999
-
-        def neg(sc, sc_masked, ranks):
-            order = torch.sort(sc_masked, descending=True, dim=1)[1]
-            if ranks is None:
-                hi = min(1 + cfg.hard_pool_size, n) if cfg.use_hard_negative else n
-                ranks = torch.randint(1, hi, size=(n,))
-            return sc[ar, order[ar, torch.as_tensor(ranks).long().to(sc.device)]]
-
-        def rank_loss(p, ng):
-            if cfg.ranking_loss_type == "hinge":
-                return torch.clamp(cfg.margin + ng - p, min=0).sum() / len(p)
-            if cfg.ranking_loss_type == "lse":
-                return torch.log1p(torch.exp(ng - p)).sum() / len(p)
+        if cfg.ranking_loss_type not in ("hinge", "lse"):
             raise NotImplementedError("Only support 'hinge' and 'lse'")
-
-        neg_ctx = neg(query_context_scores, masked, neg_ctx_rank)
-        neg_q = neg(query_context_scores.transpose(0, 1), masked.transpose(0, 1), neg_q_rank)
-        return rank_loss(pos, neg_ctx), rank_loss(pos, neg_q)
+        n = len(query_context_scores)
+        if neg_ctx_rank is None or neg_q_rank is None:
+            neg_ctx_rank, neg_q_rank = draw_negative_ranks(self, n)
+        dev = query_context_scores.device
+        to_dev = lambda r: torch.as_tensor(r).to(device=dev, dtype=torch.int32).contiguous()   # noqa: E731
+        losses = RankLossFn.apply(query_context_scores.float().contiguous(), to_dev(neg_ctx_rank), to_dev(neg_q_rank),
+                                  float(cfg.margin), cfg.ranking_loss_type == "lse")
+        return losses[0], losses[1]
 
 
 def mask_logits(target, mask):

@@ -1,0 +1,56 @@
+"""Run under `python -m torch.distributed.run --nproc-per-node 1` on a GPU box (tests/test_gpu_dist.py does):
+pushes every collective of the sharded VCMR pass and of the data-parallel gradient averaging through a REAL
+single-rank RCCL group (backend "nccl"), and checks the result against the unsharded search.  This is what one
+GPU can verify of the N > 1 path: dtypes (f32 / int32 / bf16), contiguity, API usage, stream ordering."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+from conftest import load_golden  # noqa: E402
+
+
+def main():
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("nccl", device_id=dev)
+    from tvretrieval_amd import dist as xd
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd.model_xml import XML
+    from tvretrieval_amd.train import allreduce_gradients
+    xd.SKIP_TRIVIAL_COLLECTIVES = False
+    d, cfg, sd = load_golden("xml_video_sub_cross_h128")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)       # noqa: E731
+    for dtype in (torch.float32, torch.bfloat16):
+        m = XML(cfg, compute_dtype=dtype)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            index = inf.build_corpus_index(m, [(T(d["video_feat"]), T(d["video_mask"]), T(d["sub_feat"]), T(d["sub_mask"]))])
+            qf, qm = T(d["query_feat"]), T(d["query_mask"])
+            want = inf.vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50)
+            got = xd.sharded_vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50)
+        for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"):
+            assert torch.equal(got[k], want[k]), (str(dtype), k)
+
+    class Holder(object):
+        pass
+    h = Holder()
+    h.flat_g = torch.randn(1 << 20, device=dev)
+    ref = h.flat_g.clone()
+    allreduce_gradients(h, bucket_bytes=1 << 20)      # 4 buckets, ReduceOp.AVG on RCCL
+    torch.cuda.synchronize()
+    assert torch.allclose(h.flat_g, ref)
+    dist.barrier()
+    dist.destroy_process_group()
+    print("RCCL_WORLD1_OK")
+
+
+if __name__ == "__main__":
+    main()

@@ -24,6 +24,11 @@ from . import inference as inf
 from . import ops as hip_ops
 
 
+# world-size-1 groups skip the collectives; tests flip this to push the real RCCL calls (dtypes, contiguity, API use)
+# through a single-rank group, which is all a 1-GPU box can exercise
+SKIP_TRIVIAL_COLLECTIVES = True
+
+
 def shard_range(n_total, rank, world, align=1):
     """Contiguous, balanced [lo, hi) of `n_total` items for `rank`; boundaries multiples of `align`."""
     blocks = (n_total + align - 1) // align
@@ -35,7 +40,7 @@ def shard_range(n_total, rank, world, align=1):
 
 def _all_gather_cat(t, group, world):
     """all-gather equal-shaped (Nq, k) tensors and lay them out as (Nq, world*k)."""
-    if world == 1:
+    if world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized()):
         return t
     t = t.contiguous()
     out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)   # rank-major concat
@@ -45,7 +50,7 @@ def _all_gather_cat(t, group, world):
 
 def _all_gather_rows(t, group, world):
     """all-gather equal-shaped (n, H) row blocks into (world*n, H)."""
-    if world == 1:
+    if world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized()):
         return t
     t = t.contiguous()
     out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
@@ -57,7 +62,7 @@ def encode_queries_sharded(model, query_feat, query_mask, group=None):
     """Each rank encodes a contiguous 1/P slice of the (replicated) raw queries; all-gather the modular vectors."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1:
+    if world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized()):
         return inf.stage_query_vectors(model, query_feat, query_mask)
     nq = query_feat.shape[0]
     per = (nq + world - 1) // world
@@ -105,7 +110,7 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
     loc_fs, loc_fi = ops.moment_topk(st, ed, w_local, index.l_ref, min_pred_l, max_pred_l, max_before_nms)  # skipped
     all_fs = _all_gather_cat(loc_fs, group, world)
     all_fi = _all_gather_cat(loc_fi, group, world)
-    if world == 1:
+    if world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized()):
         fs, fi = loc_fs, loc_fi
     else:
         fs, fi = ops.topk_rows(all_fs, max_before_nms, alpha=0.0, idx_in=all_fi)

@@ -327,7 +327,10 @@ def allreduce_gradients(optimizer, group=None, bucket_bytes=64 << 20):
     collectives over xGMI are per-link bound, so fewer and larger beats per-tensor), issued back-to-back and
     awaited together.  No-op without an initialised process group or at world size 1."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    from . import dist as xdist
+    if not (dist.is_available() and dist.is_initialized()):
+        return
+    if dist.get_world_size(group) == 1 and xdist.SKIP_TRIVIAL_COLLECTIVES:
         return
     world = dist.get_world_size(group)
     flat = optimizer.flat_g

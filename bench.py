@@ -230,8 +230,7 @@ def main():
                                          "profiles/r01_k6_traffic.json; algorithmic bytes = %.3g" % (
                                              len(index.modalities) * (index.n_videos * index.lpad * hidden * 2.0
                                                                       + nq * hidden * 2.0) + nq * index.n_videos * 4.0),
-                         # small query batches (< 8 query tiles) run the per-tile ring kernel (csrc/q2c.hip)
-                         "kernel": "q2c_persist_kernel" if (nq + 255) // 256 >= 7 else "q2c_scores_kernel_ring",
+                         "kernel": "q2c_persist_kernel",
                          "launches_timed": len(k6_ms), "avg_launch_ms": k6_avg_ms,
                          "flops_per_launch": flops_per_launch},
             "encode_videos_per_s": (hi - lo) * world / enc_s if enc_s > 0 else None,

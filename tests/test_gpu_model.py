@@ -343,3 +343,27 @@ def test_c1_single_query_single_video_svmr():
     assert (gf[:n] == wf[:n]).mean() > 0.9
     # VCMR over a one-video corpus ranks the same spans (weight exp(20 s) is a common factor)
     assert (out["flat_indices"].cpu().numpy()[0][:n] == gf[:n]).mean() > 0.95
+
+
+def test_hip_graph_replay_equals_eager():
+    """GraphedVcmrSearch (one HIP graph per query-batch shape) returns exactly what the eager pass returns, for
+    several different batches replayed through the same graph."""
+    from tvretrieval_amd import inference as inf
+    nv, nq, l = 40, 50, 128
+    m, cfg = _synthetic_model("video_sub", 256, 512, 256, 256, l, torch.bfloat16, seed=7)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(20, l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, 512, 1)
+    sf, sm = _feats(nv, lens, 256, 2)
+    with torch.no_grad():
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))])
+        g = inf.GraphedVcmrSearch(m, index, nq, 30, 256, max_vcmr_video=10, max_before_nms=100)
+        for seed in (3, 4, 5):
+            qf, qm = _feats(nq, np.concatenate([[30], rng.integers(5, 31, nq - 1)]), 256, seed)
+            want = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=100)
+            want = {k: v.clone() for k, v in want.items() if v is not None}
+            got = g(qf.to(DEV), qm.to(DEV))
+            for k in ("q2c", "top_scores", "top_indices", "flat_scores", "flat_indices"):
+                assert torch.equal(got[k], want[k]), (seed, k)
+    with pytest.raises(ValueError):
+        g(qf[:10].to(DEV), qm[:10].to(DEV))

@@ -227,6 +227,11 @@ __global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
   }
 }
 
+__global__ void convse_zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0u;
+}
+
 extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1,
                                  const void* feat2_0, const void* feat2_1, const float* mask0, const float* mask1,
                                  const int32_t* pair_vid, const float* conv_w, float* st_out, float* ed_out, void* ws,
@@ -245,8 +250,14 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   ConvseWs w;
   convse_ws_layout(d, &w, (char*)ws);
   const int64_t P = (int64_t)d->nq * d->kpairs;
-  // counts and cursor are the first two (adjacent, 256-aligned) regions
-  if (hipMemsetAsync(w.counts, 0, (size_t)((char*)w.offsets - (char*)w.counts), st) != hipSuccess) return XML_ERR_LAUNCH;
+  // counts and cursor are the first two (adjacent, 256-aligned) regions.  Zeroed by a kernel, not hipMemsetAsync:
+  // as a memset NODE of a captured HIP graph the reset did not happen on the second replay (stale cursors ->
+  // out-of-bounds bucket writes, seen with inference.GraphedVcmrSearch); a kernel node replays faithfully.
+  {
+    const int64_t nwords = (int64_t)((char*)w.offsets - (char*)w.counts) / 4;
+    hipLaunchKernelGGL(convse_zero_words_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, st, (uint32_t*)w.counts, nwords);
+    XML_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, P, d->nv);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P * (d->lpad / 4), 256)), dim3(256), 0, st, pair_vid, st_out,

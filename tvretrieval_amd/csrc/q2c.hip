@@ -102,14 +102,6 @@ int xmli_q2c_scores_ring(const void* qn, const void* cn, const float* mask, floa
 int xmli_q2c_scores_256(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int nq, int nv,
                         int lpad, int hidden, int combine, int dt, hipStream_t st);
 
-// The persistent kernel statically assigns 8 query tiles x 4 clip tiles to the 32 workgroups of an XCD: with fewer
-// than 8 query tiles (nq <= 1792) most of them idle (C2: 256 queries = 1/8 of the chip), so small query batches go
-// to the one-workgroup-per-tile ring kernel.
-static bool persist_fills_chip(int nq) {
-  const int tq = cdiv(nq, 256);
-  return tq * 5 >= ((tq + 7) / 8) * 8 * 4;     // >= 80 % of the query-tile slots used
-}
-
 extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int nq,
                               int nv, int lpad, int hidden, int combine, int dt, xml_stream_t stream) {
   XML_ENTER();
@@ -120,7 +112,7 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
   if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
   const bool dma_ok = ((size_t)hidden * dt_size(dt)) % 128 == 0;
   const bool persist_ok = lpad == 128 && ((size_t)hidden * dt_size(dt)) % 128 == 0 && (size_t)hidden * dt_size(dt) >= 384;
-  if (((g_q2c_variant == 0 && persist_fills_chip(nq)) || g_q2c_variant == 4) && persist_ok && !combine) {
+  if ((g_q2c_variant == 0 || g_q2c_variant == 4) && persist_ok && !combine) {
     const void* q[2] = {qn, qn};
     const void* c[2] = {cn, cn};
     const float* m[2] = {mask, mask};
@@ -169,7 +161,7 @@ extern "C" int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0,
   if (lpad % 16 || lpad > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
   const size_t kb = (size_t)hidden * dt_size(dt);
   const bool persist_ok = lpad == 128 && kb % 128 == 0 && kb >= 384;
-  if (((g_q2c_variant == 0 && persist_fills_chip(nq)) || g_q2c_variant == 4) && persist_ok) {
+  if ((g_q2c_variant == 0 || g_q2c_variant == 4) && persist_ok) {
     const void* q[2] = {qn0, qn1};
     const void* c[2] = {cn0, cn1};
     const float* m[2] = {mask0, mask1};

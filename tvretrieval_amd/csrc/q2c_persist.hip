@@ -26,6 +26,7 @@ struct Q2cPersistArgs {
   float* out;
   int64_t ld_out;
   int nq, nv, hidden, n_mod, tq, tc;
+  int qsh;     // log2 of the query tiles per XCD super-tile (0..3): the 32 workgroups of an XCD form 2^qsh x 2^(5-qsh)
 };
 
 __device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase, uint32_t lds_dst) {
@@ -84,14 +85,17 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int fr = lane & 15, fg = lane >> 4;
   const int xcd = blockIdx.x & 7;
-  const int qt_off = (blockIdx.x >> 3) & 7, ct_off = blockIdx.x >> 6;   // position inside the 8 x 4 super-tile
+  const int qsh = a.qsh, csh = 5 - a.qsh;        // super-tile = 2^qsh query tiles x 2^csh clip tiles (8 x 4 when nq is large)
+  const int qt_off = (blockIdx.x >> 3) & ((1 << qsh) - 1), ct_off = blockIdx.x >> (3 + qsh);
   const int k_bytes = a.hidden * (int)sizeof(T);
   const int slices_per_seg = k_bytes / ROWB;      // even (k_bytes % 128 == 0)
-  const int n_qgroups = (a.tq + 7) >> 3;
-  const int cr = (((a.tc + 3) >> 2) + 7) >> 3;    // rounds per query group on one XCD
+  const int n_qgroups = (a.tq + (1 << qsh) - 1) >> qsh;
+  const int cr = (((a.tc + (1 << csh) - 1) >> csh) + 7) >> 3;    // rounds per query group on one XCD
 
-  // tile of (query group g, round c):  qt = 8 g + qt_off,  ct = 4 (8 c + xcd) + ct_off
-  auto tile_valid = [&](int g, int c) -> bool { return (8 * g + qt_off) < a.tq && (4 * (8 * c + xcd) + ct_off) < a.tc; };
+  // tile of (query group g, round c):  qt = 2^qsh g + qt_off,  ct = 2^csh (8 c + xcd) + ct_off
+  auto tile_valid = [&](int g, int c) -> bool {
+    return ((g << qsh) + qt_off) < a.tq && ((((c << 3) + xcd) << csh) + ct_off) < a.tc;
+  };
   auto advance = [&](int& g, int& c) {            // next valid (g, c) in walk order, g == n_qgroups when exhausted
     do {
       if (++c == cr) { c = 0; ++g; }
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const char* sbase_b = nullptr;
 
   auto setup_issue_segment = [&](bool new_tile) {
-    const int q0 = (8 * i_g + qt_off) * 256, v0 = (4 * (8 * i_c + xcd) + ct_off) * 2;
+    const int q0 = ((i_g << qsh) + qt_off) * 256, v0 = ((((i_c << 3) + xcd) << csh) + ct_off) * 2;
     int lane_o = lane;                              // opaque copy: keeps LICM from hoisting (and keeping live across
     asm volatile("" : "+v"(lane_o));                // the MFMA loop) everything derived from the lane id below
     if (new_tile) {
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     }
     // ---- end of a (tile, modality) segment: mask_logits + max over the video's 128 clips, inside the wave -----
     {
-      const int q0 = (8 * c_g + qt_off) * 256, vid = (4 * (8 * c_c + xcd) + ct_off) * 2 + wn;
+      const int q0 = ((c_g << qsh) + qt_off) * 256, vid = ((((c_c << 3) + xcd) << csh) + ct_off) * 2 + wn;
       int fr_e = fr, fg_e = fg;                     // opaque copies (see setup_issue_segment)
       asm volatile("" : "+v"(fr_e), "+v"(fg_e));
       const float* mpatch = reinterpret_cast<const float*>(smem + MASK_OFF + (c_seg & 1) * 1024) + wn * 128 + fr_e;
@@ -312,6 +316,7 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
   if (lpad != 128) return XML_ERR_UNSUPPORTED;
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
+  a.qsh = a.tq >= 5 ? 3 : a.tq >= 3 ? 2 : a.tq == 2 ? 1 : 0;     // few queries: more workgroups share a query tile
   if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st);
   return launch_q2c_persist<float>(a, st);
 }

@@ -210,6 +210,45 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
     return out
 
 
+class GraphedVcmrSearch(object):
+    """vcmr_search for ONE fixed query-batch shape, captured once into a HIP graph and replayed.
+
+    The reference serves queries in batches of `eval_query_bsz` = 50 (xml/config.py); at that size the pass is a
+    chain of ~25 short kernels and the time goes to launch latency, not to the kernels.  One graph launch replaces
+    the chain.  Inputs are copied into static buffers, the returned tensors are the graph's static outputs
+    (overwritten by the next call: copy them if they must outlive it).  Weights are packed and workspaces sized by
+    two eager warm-up passes before the capture; the corpus index and the model weights must not be re-allocated
+    afterwards (re-create the object after load_state_dict / an optimizer step)."""
+
+    def __init__(self, model, index, nq, lq, d_in, **search_kwargs):
+        dev = next(model.parameters()).device
+        self.query_feat = torch.zeros((nq, lq, d_in), dtype=torch.float32, device=dev)
+        self.query_mask = torch.zeros((nq, lq), dtype=torch.float32, device=dev)
+        self.query_mask[:, 0] = 1.0
+        self._args = (model, index)
+        self._kw = dict(search_kwargs)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):
+                vcmr_search(model, index, self.query_feat, self.query_mask, **self._kw)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = vcmr_search(model, index, self.query_feat, self.query_mask, **self._kw)
+
+    def __call__(self, query_feat, query_mask):
+        if tuple(query_feat.shape) != tuple(self.query_feat.shape) or tuple(query_mask.shape) != tuple(self.query_mask.shape):
+            raise ValueError("GraphedVcmrSearch was captured for queries %s / masks %s, got %s / %s"
+                             % (tuple(self.query_feat.shape), tuple(self.query_mask.shape), tuple(query_feat.shape),
+                                tuple(query_mask.shape)))
+        self.query_feat.copy_(query_feat)
+        self.query_mask.copy_(query_mask)
+        self.graph.replay()
+        return self.out
+
+
 def decode_flat(flat, l_ref):
     """(r, st_idx, ed_idx) of the reference's flat index over (K, L, L) (np.unravel_index, :423-425)."""
     flat = np.asarray(flat).astype(np.int64)

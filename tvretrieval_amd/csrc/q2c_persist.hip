@@ -70,7 +70,7 @@ __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3
 //
 //   No wave-group stagger and no s_setprio: the two waves of a SIMD drift apart by themselves and keep the MFMA
 //   pipe busy from either wave's ready cluster.
-template <typename T, int ABL = 0>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
+template <typename T, int ABL = 0, bool PHASED = true>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
 __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
@@ -83,6 +83,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
+  const int grp = wave >> 2;                      // waves w and w + 4 share a SIMD
   const int fr = lane & 15, fg = lane >> 4;
   const int xcd = blockIdx.x & 7;
   const int qsh = a.qsh, csh = 5 - a.qsh;        // super-tile = 2^qsh query tiles x 2^csh clip tiles (8 x 4 when nq is large)
@@ -218,21 +219,41 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0), as a builtin: hipcc must KNOW the fbH reads have
       __builtin_amdgcn_s_barrier();                     // returned, or it waits for the reads issued below before h1
       ++c_gs;
-      if (more) {                                       // reads first: their latency hides under the DMA issue + h1
-        const char* nslot = smem + (c_gs & 3) * SLOT_BYTES;
+      auto next_reads = [&]() {
+        if (more) {                                     // their latency hides under the DMA issue + MFMAs
+          const char* nslot = smem + (c_gs & 3) * SLOT_BYTES;
 #pragma unroll
-        for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
+          for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
-      }
-      issue_slice();                                    // slice c_gs + 3 -> the slot just released
-#pragma unroll
-      for (int m = 0; m < 4; ++m)
-#pragma unroll
-        for (int n = 0; n < 4; ++n) {
-          if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbH[n].x), "v"(fc[m].w), "v"(fbH[n].w));
-          else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+          for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
         }
+      };
+      auto h1 = [&]() {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) {
+            if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbH[n].x), "v"(fc[m].w), "v"(fbH[n].w));
+            else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+          }
+      };
+      // The two waves of a SIMD (w and w + 4) leave the barrier together.  If both ran [reads, DMA issue, MFMA]
+      // the matrix pipe would idle through both preambles (~250 cycles per slice); so the second group runs its
+      // 16 MFMAs FIRST (their operands were complete before the barrier) and its preamble under the first
+      // group's MFMAs.
+      // (The MFMA block itself stays outside any branch: accumulators updated in both arms of a branch get phi
+      // copies -- 350 spilled VGPRs when tried.)
+      if (!PHASED || !grp) {
+        next_reads();
+        issue_slice();                                  // slice c_gs + 3 -> the slot just released
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      h1();
+      __builtin_amdgcn_sched_barrier(0);
+      if (PHASED && grp) {
+        next_reads();
+        issue_slice();
+      }
     };
 
     for (int c_slice = 0; c_slice < slices_per_seg; c_slice += 2) {
@@ -294,7 +315,8 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
   const int lds = 4 * 2 * 256 * 64 + 2048 + 2048;
   extern int g_q2c_ablation;
   auto kern = g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
-             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : q2c_persist_kernel<T, 0>;
+             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
+                                                                                     : q2c_persist_kernel<T, 0, true>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);

@@ -384,6 +384,9 @@ def test_train_mode_step_with_dropout_runs():
     torch.manual_seed(3)
     l2, _ = xml_forward_train(m, **batch)
     l2.backward()
-    assert float(l1) == float(l2) and torch.equal(g1, m.video_encoder1.self.query.weight.grad)
+    # same masks -> same loss and gradients up to the summation order of the f32 atomics (loss reduction, split-K,
+    # LayerNorm column sums); a different mask moves the loss by ~1e-2
+    assert abs(float(l1) - float(l2)) < 1e-6
+    assert torch.allclose(g1, m.video_encoder1.self.query.weight.grad, rtol=1e-4, atol=1e-7)
     assert math.isfinite(float(l1)) and abs(float(l1) - float(d["loss"])) > 1e-6
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)

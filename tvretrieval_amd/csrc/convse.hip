@@ -12,7 +12,7 @@
 // softmax over clips.
 #include "gemm.h"
 
-static constexpr int TM = 32;            // pairs per workgroup chunk
+static constexpr int TM = 64;            // pairs per workgroup chunk (a video has ~46 pairs at C3: one chunk each)
 static constexpr int LP = 128 + 4;       // padded row length of the LDS similarity patch (floats)
 
 struct ConvseWs {
@@ -124,9 +124,13 @@ struct ConvseArgs {
 template <typename T>
 __global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
   using Cfg = GemmCfg<T, TM, 128, 1, 4>;
-  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
-  __shared__ float sim[2][TM][LP];
+  // dynamic LDS: [ GEMM staging | similarity patches ].  With ONE similarity patch (merged streams or a single
+  // modality) the patch is written once after the last GEMM and overlays the staging area (49 KiB -> 3 workgroups
+  // per CU); two independent streams need their patches while the second GEMM still stages.
+  extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int32_t s_pair[TM];
+  const int n_sim_l = a.merged ? 1 : a.n_mod;
+  float (*sim)[TM][LP] = reinterpret_cast<float (*)[TM][LP]>(n_sim_l == 1 ? smem : smem + Cfg::LDS_BYTES);
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x;
   if (chunk >= a.chunk_off[a.nv]) return;
@@ -163,6 +167,7 @@ __global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
     if (!a.merged || m == a.n_mod - 1) {
       const float scale = (a.merged && a.n_mod == 2) ? 0.5f : 1.f;
       const int si = a.merged ? 0 : m;
+      if (n_sim_l == 1) __syncthreads();     // every wave is done with the staging area the patch overlays
 #pragma unroll
       for (int mt = 0; mt < Cfg::MT; ++mt)
 #pragma unroll
@@ -277,10 +282,21 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
   a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax;
   const int64_t max_chunks = P / TM + (P < d->nv ? P : d->nv);
-  if (d->dt == XML_F32)
-    hipLaunchKernelGGL(convse_kernel<float>, dim3((unsigned)max_chunks), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(convse_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), 0, st, a);
+  const int n_sim = d->merged ? 1 : d->n_mod;
+  const size_t patch = (size_t)TM * LP * 4;
+  if (d->dt == XML_F32) {
+    using Cfg = GemmCfg<float, TM, 128, 1, 4>;
+    const size_t lds = n_sim == 1 ? (Cfg::LDS_BYTES > patch ? Cfg::LDS_BYTES : patch) : Cfg::LDS_BYTES + 2 * patch;
+    if (hipFuncSetAttribute((const void*)convse_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(convse_kernel<float>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
+  } else {
+    using Cfg = GemmCfg<bf16_t, TM, 128, 1, 4>;
+    const size_t lds = n_sim == 1 ? (Cfg::LDS_BYTES > patch ? Cfg::LDS_BYTES : patch) : Cfg::LDS_BYTES + 2 * patch;
+    if (hipFuncSetAttribute((const void*)convse_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(convse_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
+  }
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -351,12 +351,105 @@ __global__ __launch_bounds__(256) void modular_pool_kernel(const T* __restrict__
   }
 }
 
+// Short sequences (lq <= 32, hidden % 8 == 0, hidden <= 1024 -- the query encoder: 30 tokens): every token row is
+// read ONCE with 16-byte loads and stays in registers (a wave owns tokens wave, wave + 4, ...); scores go through
+// LDS for the softmax, each wave weights its own rows, the four partial sums meet in LDS.
+template <typename T>
+__global__ __launch_bounds__(256) void modular_pool_small_kernel(const T* __restrict__ enc, const float* __restrict__ mask,
+                                                                 const float* __restrict__ wm, T* __restrict__ out,
+                                                                 int64_t n, int lq, int hidden, int n_mod) {
+  __shared__ float s_att[2][32];
+  __shared__ float s_part[4][2][1024];
+  const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nvec = hidden >> 3;
+  const T* e = enc + (int64_t)q * lq * hidden;
+  float x[8][16];                       // up to 8 tokens per wave, 2 vectors of 8 per lane
+  float w0[16], w1[16];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = lane + k * 64;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      w0[k * 8 + j] = v < nvec ? wm[v * 8 + j] : 0.f;
+      w1[k * 8 + j] = (v < nvec && n_mod > 1) ? wm[hidden + v * 8 + j] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int l = wave + t * 4;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int v = lane + k * 64;
+      if (l < lq && v < nvec) ld8<T>(e + (int64_t)l * hidden + v * 8, x[t] + k * 8);
+      else
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[t][k * 8 + j] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s0 += x[t][k * 8 + j] * w0[k * 8 + j]; s1 += x[t][k * 8 + j] * w1[k * 8 + j]; }
+    }
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0 && l < lq) {
+      const float mk = mask[(int64_t)q * lq + l];
+      s_att[0][l] = s0 * mk + (1.f - mk) * -1e10f;   // mask_logits, xml/model_xml.py:640-641
+      s_att[1][l] = s1 * mk + (1.f - mk) * -1e10f;
+    }
+  }
+  __syncthreads();
+  if (tid < n_mod) {
+    float mx = -INFINITY;
+    for (int l = 0; l < lq; ++l) mx = fmaxf(mx, s_att[tid][l]);
+    float sum = 0.f;
+    for (int l = 0; l < lq; ++l) { const float ev = expf(s_att[tid][l] - mx); s_att[tid][l] = ev; sum += ev; }
+    for (int l = 0; l < lq; ++l) s_att[tid][l] /= sum;
+  }
+  __syncthreads();
+  float a0[16], a1[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int l = wave + t * 4;
+    if (l < lq) {
+      const float p0 = s_att[0][l], p1 = n_mod > 1 ? s_att[1][l] : 0.f;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { a0[i] += p0 * x[t][i]; a1[i] += p1 * x[t][i]; }
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { s_part[wave][0][v * 8 + j] = a0[k * 8 + j]; s_part[wave][1][v * 8 + j] = a1[k * 8 + j]; }
+  }
+  __syncthreads();
+  for (int i = tid; i < n_mod * hidden; i += 256) {
+    const int m = i / hidden, h = i - m * hidden;
+    DT<T>::st(out + ((int64_t)m * n + q) * hidden + h,
+              s_part[0][m][h] + s_part[1][m][h] + s_part[2][m][h] + s_part[3][m][h]);
+  }
+}
+
 extern "C" int xml_modular_pool(const void* enc, const float* mask, const float* w_m, void* out, int64_t n, int lq,
                                 int hidden, int n_mod, int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!enc || !mask || !w_m || !out || n <= 0 || lq <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
   if (n_mod < 1 || n_mod > 2 || lq > 128) return XML_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  if (lq <= 32 && hidden % 8 == 0 && hidden <= 1024) {
+    if (dt == XML_F32)
+      hipLaunchKernelGGL(modular_pool_small_kernel<float>, dim3((unsigned)n), dim3(256), 0, st, (const float*)enc, mask,
+                         w_m, (float*)out, n, lq, hidden, n_mod);
+    else if (dt == XML_BF16)
+      hipLaunchKernelGGL(modular_pool_small_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, st, (const bf16_t*)enc,
+                         mask, w_m, (bf16_t*)out, n, lq, hidden, n_mod);
+    else
+      return XML_ERR_BAD_ARG;
+    XML_CHECK_LAUNCH();
+    return XML_OK;
+  }
   if (dt == XML_F32)
     hipLaunchKernelGGL(modular_pool_kernel<float>, dim3((unsigned)n), dim3(256), 0, st, (const float*)enc, mask, w_m,
                        (float*)out, n, lq, hidden, n_mod);

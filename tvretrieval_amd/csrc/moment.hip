@@ -208,8 +208,67 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   // ---- 4. expand rows whose maximum reaches lb into the list (raise lb and repeat on overflow) -------------
   uint32_t cnt = 0;
   for (int attempt = 0; attempt < 8; ++attempt) {
-    if (tid == 0) sh.cnt = 0;
+    if (tid == 0) { sh.cnt = 0; sh.need = 0; }
     __syncthreads();
+    // 4a. rows whose maximum reaches lb -> compact list (row id, st*w) in the histogram area (free between step 3
+    //     and the overflow refinement).  Expanding rows in place costs ~14 ballot/atomic iterations per 64-row block
+    //     with typically 1-2 live rows in it: that was most of this kernel's time.
+    unsigned long long* s_rows = reinterpret_cast<unsigned long long*>(s_hist);   // [1024]: (a bits << 32) | row id
+#pragma unroll 2
+    for (int t = 0; t < n_t; ++t) {
+      const int r = wave + t * 4;
+      const float wv = pair_w(r);
+      if (wv == 0.f) continue;
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int i = lane + h * 64;
+        const float a = (i < l_ref) ? gst[r * lpad + i] * wv : 0.f;
+        const bool row_on = (i < l_ref) && __float_as_uint(row_max(a, r, i)) >= lb;
+        const unsigned long long bal = __ballot(row_on);
+        if (bal == 0) continue;
+        uint32_t base = 0;
+        const int leader = __ffsll((long long)bal) - 1;
+        if (lane == leader) base = atomicAdd(&sh.need, (uint32_t)__popcll(bal));
+        base = __shfl(base, leader, 64);
+        const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+        if (row_on && slot < 1024u)
+          s_rows[slot] = ((unsigned long long)__float_as_uint(a) << 32) | (unsigned long long)(uint32_t)(r * l_ref + i);
+      }
+    }
+    __syncthreads();
+    const uint32_t n_rows = sh.need;
+    if (n_rows <= 1024u) {
+      // 4b. one (row, offset) item per lane: every lane of every wave has work
+      const int total = (int)n_rows * band;
+      const int total_r = (total + 255) & ~255;
+      for (int idx = tid; idx < total_r; idx += 256) {
+        bool take = false;
+        uint32_t key = 0, flat = 0;
+        if (idx < total) {
+          const int row = idx / band, d = idx - row * band;
+          const unsigned long long e = s_rows[row];
+          const int ri = (int)(uint32_t)(e & 0xffffffffull);       // r * l_ref + i
+          const int r = ri / l_ref, i = ri - r * l_ref;
+          const int j = i + min_l + d;
+          if (j < l_ref) {
+            key = __float_as_uint(__uint_as_float((uint32_t)(e >> 32)) * s_ed[r * l_ref + j]);
+            take = key >= lb;
+            flat = (uint32_t)(ri * l_ref + j);
+          }
+        }
+        const unsigned long long bal = __ballot(take);
+        if (bal) {
+          uint32_t base = 0;
+          const int leader = __ffsll((long long)bal) - 1;
+          if (lane == leader) base = atomicAdd(&sh.cnt, (uint32_t)__popcll(bal));
+          base = __shfl(base, leader, 64);
+          const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+          if (take && slot < (uint32_t)MT_CAP)
+            s_list[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - flat);
+        }
+      }
+    } else {
+      // more than 1024 live rows (n_out close to the number of rows): expand in place
 #pragma unroll 2
     for (int t = 0; t < n_t; ++t) {
       const int r = wave + t * 4;
@@ -240,6 +299,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
           }
         }
       }
+    }
     }
     __syncthreads();
     cnt = sh.cnt;

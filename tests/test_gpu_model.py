@@ -367,3 +367,96 @@ def test_hip_graph_replay_equals_eager():
                 assert torch.equal(got[k], want[k]), (seed, k)
     with pytest.raises(ValueError):
         g(qf[:10].to(DEV), qm[:10].to(DEV))
+
+
+def test_full_scale_c3_pipeline_properties():
+    """BASELINE configs[2] at FULL size (10 000 queries x 21 793 videos x 128 clips, H=768, video_sub, bf16) through
+    the whole search pass, checked by size-independent properties and by sampled comparisons with the reference
+    formulation (oracle on CPU for a few (query, video) pairs):
+      K6/K8  top-100: scores descending, indices unique and in range, score == exp(20 * q2c[q, idx]);
+             idempotence (top-k of the selected scores reproduces the list); sampled q2c entries vs fp32 recomputation;
+      K7     start / end rows are probability vectors; sampled rows vs conv1d + softmax on CPU;
+      K9     top-200: scores descending, flat indices unique, inside the length band, score == st*w*ed recomputed."""
+    import bench
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import ops as hops
+    from tvretrieval_amd.model_xml import XML
+    nq, nv, l, hidden, dv, ds_, dq, ctx_mode, _ = bench.WORKLOADS["c3"]
+    torch.manual_seed(0)
+    cfg = bench.model_config(hidden, dv, ds_, dq, ctx_mode, l)
+    m = XML(cfg, compute_dtype=torch.bfloat16).to(DEV).eval()
+    with torch.no_grad():
+        index = inf.build_corpus_index(m, bench.context_batches(0, nv, l, dv, ds_, True, True, torch.device(DEV)),
+                                       n_total=nv, l_ref=l)
+        qf, qm = bench.synth_queries(nq, dq, torch.device(DEV))
+        qvec = inf.stage_query_vectors(m, qf, qm)
+        out = inf.vcmr_search(m, index, qf, qm)
+        st, ed = inf.stage_span_probs(m, index, qvec, out["top_indices"])
+    q2c, tw, ti = out["q2c"], out["top_scores"], out["top_indices"].long()
+    fs, fi = out["flat_scores"], out["flat_indices"].long()
+    assert q2c.shape == (nq, nv) and tw.shape == (nq, 100) and fs.shape == (nq, 200)
+    # ---- K6 / K8
+    assert bool(torch.isfinite(q2c).all()) and float(q2c.abs().max()) <= 1.0 + 1e-3          # mean of two cosines
+    assert bool((tw[:, :-1] >= tw[:, 1:]).all())
+    assert int(ti.min()) >= 0 and int(ti.max()) < nv
+    assert bool((torch.sort(ti, dim=1)[0][:, 1:] != torch.sort(ti, dim=1)[0][:, :-1]).all())     # unique per row
+    sel = torch.gather(q2c, 1, ti)
+    assert torch.allclose(tw, torch.exp(20.0 * sel), rtol=1e-5, atol=0)
+    kth = sel[:, -1:]
+    assert int((q2c > kth).sum(1).max()) <= 99                      # nothing outside the list beats its last entry
+    tw2, pos2 = hops.topk_rows(sel.contiguous(), 100, alpha=20.0)
+    assert torch.equal(tw2, tw) and bool((pos2.long() == torch.arange(100, device=DEV)[None]).all())   # idempotent
+    g = torch.Generator().manual_seed(1)
+    qs = torch.randint(0, nq, (6,), generator=g).tolist()
+    for q in qs:                                                     # sampled exact recomputation, fp32 on the GPU
+        vs = ti[q, :8]
+        want = 0
+        for mod in index.modalities:
+            qn = torch.nn.functional.normalize(qvec[mod][q].float(), dim=-1)
+            c = index.feat1n[mod][vs].float()
+            want = want + torch.einsum("d,vld->vl", qn, c).max(1)[0]
+        want = want / len(index.modalities)
+        # bf16 operands (incl. the normalised query rounded to bf16 inside the kernel path): 3 significant digits
+        assert float((q2c[q, vs] - want).abs().max()) < 4e-3
+    # ---- K7
+    assert st.shape == (nq, 100, index.lpad)
+    assert torch.allclose(st.sum(-1), torch.ones(nq, 100, device=DEV), atol=2e-3)
+    assert torch.allclose(ed.sum(-1), torch.ones(nq, 100, device=DEV), atol=2e-3)
+    assert float(st.min()) >= 0 and float(ed.min()) >= 0
+    wst = m.merged_st_predictor.weight.detach().float().cpu()
+    wed = m.merged_ed_predictor.weight.detach().float().cpu()
+    for q in qs[:3]:
+        vs = ti[q, :5]
+        sims = 0
+        for mod in index.modalities:
+            lin = getattr(m, mod + "_query_linear")
+            ql = torch.nn.functional.linear(qvec[mod][q].float().cpu(), lin.weight.detach().float().cpu(),
+                                            lin.bias.detach().float().cpu())
+            sims = sims + torch.einsum("d,vld->vl", ql, index.feat2[mod][vs].float().cpu())
+        sims = (sims / 2).unsqueeze(1)
+        want_st = torch.softmax(torch.nn.functional.conv1d(sims, wst, padding=2).squeeze(1), -1)
+        want_ed = torch.softmax(torch.nn.functional.conv1d(sims, wed, padding=2).squeeze(1), -1)
+        # bf16 storage of the projected query (the CPU side keeps f32): logits of O(10) move by ~1e-2, peaked
+        # softmax probabilities by a few 1e-3
+        assert float((st[q, :5, :l].cpu() - want_st).abs().max()) < 1e-2
+        assert float((ed[q, :5, :l].cpu() - want_ed).abs().max()) < 1e-2
+    # ---- K9
+    assert bool((fs[:, :-1] >= fs[:, 1:]).all()) and float(fs.min()) >= 0
+    valid = fi >= 0
+    assert bool(valid[:, 0].all())
+    r = fi // (l * l)
+    i = (fi // l) % l
+    j = fi % l
+    assert bool(((r < 100) & (r >= 0))[valid].all())
+    d = (j - i)[valid]
+    assert int(d.min()) >= 2 and int(d.max()) < 16                              # min_pred_l <= ed - st < max_pred_l
+    srt = torch.sort(torch.where(valid, fi, -1 - torch.arange(200, device=DEV)[None].expand_as(fi)), dim=1)[0]
+    assert bool((srt[:, 1:] != srt[:, :-1]).all())                              # unique moments per query
+    ar = torch.arange(nq, device=DEV)[:, None].expand_as(fi)
+    rr, ii, jj = r.clamp(0, 99), i.clamp(0, l - 1), j.clamp(0, l - 1)
+    rec = (st[ar, rr, ii] * tw[ar, rr]) * ed[ar, rr, jj]                        # (st * w) * ed, the reference's order
+    assert torch.allclose(fs[valid], rec[valid], rtol=2e-6, atol=0)
+    # the best moment of every query can not be beaten by any banded product of its best-weighted video
+    best_v0 = ((st[:, 0, :l, None] * tw[:, 0, None, None]) * ed[:, 0, None, :l])
+    band = torch.from_numpy(O.min_max_length_mask(l, 2, 16)).to(DEV)
+    assert bool((fs[:, 0] >= (best_v0 * band).amax((1, 2)) * (1 - 1e-6)).all())

@@ -176,7 +176,8 @@ typedef struct {
   int n_mod;        /* number of modalities present (1 or 2) */
   int merged;       /* 1: average similarities then one conv pair (merge_two_stream) */
   int ksize;        /* conv kernel size (config.conv_kernel_size, default 5) */
-  int softmax;      /* 1: emit probabilities, 0: emit masked logits */
+  int softmax;      /* bit 0: 1 = emit probabilities, 0 = emit masked logits;
+                       bit 1: leave the rows of skipped pairs (pair_vid < 0) unwritten instead of zero-filling */
   int dt;
 } xml_convse_desc;
 size_t xml_convse_rerank_workspace_bytes(const xml_convse_desc* d);

@@ -44,7 +44,7 @@ class CpuOps(object):
         return vals, idx.int()
 
     @staticmethod
-    def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, softmax=True):
+    def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, softmax=True, zero_skipped=True):
         n_mod = len(q_lin)
         n_conv = 1 if merged else n_mod
         wst = conv_w[:n_conv * ksize].view(n_conv, 1, 1, ksize)

@@ -363,6 +363,29 @@ def test_convse_rerank(ops, dtype, case, softmax):
         close("convse ed logits", ed, want_ed, 1e-4, 1e-5)
 
 
+def test_convse_unzeroed_skipped_rows_never_reach_k9(ops):
+    """Sharded pass: K7 leaves the rows of pairs owned by another rank unwritten (zero_skipped=False) and K9 skips
+    pairs of weight 0 -- poisoning those rows must not change the moments."""
+    nq, nv, l, h = 12, 9, 64, 128
+    q, f, mask, cw = _conv_case(nq, nv, l, h, True, 2, 100)
+    g = torch.Generator().manual_seed(11)
+    pair = torch.stack([torch.randperm(nv, generator=g)[:6] for _ in range(nq)]).int()
+    own = torch.rand(nq, 6, generator=g) < 0.4
+    own[:, 0] = True
+    pair_local = torch.where(own, pair, torch.full_like(pair, -1))
+    args = ([dev(x, torch.bfloat16) for x in q], [dev(x, torch.bfloat16) for x in f], [dev(mask)] * 2, dev(pair_local),
+            dev(cw), l, True, 5)
+    st0, ed0 = ops.convse_rerank(*args, softmax=True, zero_skipped=True)
+    st1, ed1 = ops.convse_rerank(*args, softmax=True, zero_skipped=False)
+    o = dev(own)
+    assert torch.equal(st0[o], st1[o]) and torch.equal(ed0[o], ed1[o])
+    st1[~o] = float("nan"); ed1[~o] = float("nan")
+    w = torch.where(o, dev(torch.rand(nq, 6, generator=g) + 0.5), torch.zeros(nq, 6, device=DEV)).contiguous()
+    a = ops.moment_topk(st0, ed0, w, l, 2, 16, 60)
+    b = ops.moment_topk(st1.contiguous(), ed1.contiguous(), w, l, 2, 16, 60)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def _check_moment_lists(sc, fl, want_s, want_i, l_ref):
     """scores equal to 1e-6 relative; indices equal except inside groups of (near-)tied scores."""
     sc, fl = sc.cpu().numpy(), fl.cpu().numpy()

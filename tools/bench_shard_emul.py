@@ -73,7 +73,7 @@ def main():
                 wl = torch.where(own, top_w, torch.zeros_like(top_w)).contiguous()
                 return pl, wl
             pair_local, w_local = timed("ownership_masks", prep)
-            st, ed = timed("convse_k7_owned", lambda: inf.stage_span_probs(model, index, qvec, pair_local))
+            st, ed = timed("convse_k7_owned", lambda: inf.stage_span_probs(model, index, qvec, pair_local, zero_skipped=False))
             fs, fi = timed("moment_k9_owned", lambda: ops.moment_topk(st, ed, w_local, index.l_ref, 2, 16, n_out))
             all_fs = fs.repeat(1, W).contiguous()
             all_fi = fi.repeat(1, W).contiguous()

@@ -265,9 +265,11 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   }
   hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, P, d->nv);
   XML_CHECK_LAUNCH();
-  hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P * (d->lpad / 4), 256)), dim3(256), 0, st, pair_vid, st_out,
-                     ed_out, P, d->nv, d->lpad / 4);
-  XML_CHECK_LAUNCH();
+  if (!(d->softmax & 2)) {     // bit 1: the caller never reads the rows of skipped pairs
+    hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P * (d->lpad / 4), 256)), dim3(256), 0, st, pair_vid,
+                       st_out, ed_out, P, d->nv, d->lpad / 4);
+    XML_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, d->nv);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.cursor, w.bucket,
@@ -280,7 +282,7 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   a.conv_w = conv_w; a.st_out = st_out; a.ed_out = ed_out;
   a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket;
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
-  a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax;
+  a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax & 1;
   const int64_t max_chunks = P / TM + (P < d->nv ? P : d->nv);
   const int n_sim = d->merged ? 1 : d->n_mod;
   const size_t patch = (size_t)TM * LP * 4;

@@ -105,7 +105,7 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
     lo, hi = index.video_offset, index.video_offset + index.n_videos
     own = (top_gid >= lo) & (top_gid < hi)
     pair_local = torch.where(own, top_gid - lo, torch.full_like(top_gid, -1)).contiguous()
-    st, ed = inf.stage_span_probs(model, index, qvec, pair_local, ops)
+    st, ed = inf.stage_span_probs(model, index, qvec, pair_local, ops, zero_skipped=False)   # K9 skips w == 0 pairs
     w_local = torch.where(own, top_w, torch.zeros_like(top_w)).contiguous()   # w == 0 marks slots owned elsewhere:
     loc_fs, loc_fi = ops.moment_topk(st, ed, w_local, index.l_ref, min_pred_l, max_pred_l, max_before_nms)  # skipped
     all_fs = _all_gather_cat(loc_fs, group, world)

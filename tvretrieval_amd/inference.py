@@ -173,13 +173,14 @@ def stage_q2c(index, qvec, ops=hip_ops):
     return q2c
 
 
-def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops):
+def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=True):
     """K7 on the listed (query, local video) pairs -> softmaxed st / ed (Nq, K, lpad)."""
     mods = index.modalities
     q_lin = [getattr(model, m + "_query_linear")(qvec[m].contiguous()) for m in mods]
     merged = bool(model.config.merge_two_stream and len(mods) == 2)
     return ops.convse_rerank(q_lin, [index.feat2[m] for m in mods], [index.mask[m] for m in mods], pair_vid,
-                             model._conv_weights(), index.l_ref, merged, model.config.conv_kernel_size, softmax=True)
+                             model._conv_weights(), index.l_ref, merged, model.config.conv_kernel_size, softmax=True,
+                             zero_skipped=zero_skipped)
 
 
 def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200, q2c_alpha=20.0,

@@ -225,10 +225,12 @@ def topk_rows(scores, k, alpha=0.0, idx_in=None):
     return vals, idx
 
 
-def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, softmax=True):
+def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, softmax=True, zero_skipped=True):
     """K7.  q_lin / feat2 / masks: lists over modalities (len 1 or 2).
     q_lin[m] (Nq, H); feat2[m] (Nv, Lpad, H); masks[m] (Nv, Lpad) f32; pair_vid (Nq, K) int32;
-    conv_w flat f32 [st filters..., ed filters...].  Returns st, ed (Nq, K, Lpad) f32."""
+    conv_w flat f32 [st filters..., ed filters...].  Returns st, ed (Nq, K, Lpad) f32.
+    zero_skipped=False leaves the rows of skipped pairs (pair_vid < 0) unwritten -- for callers that never read them
+    (the sharded pass: K9 skips pairs of weight 0)."""
     n_mod = len(q_lin)
     for m in range(n_mod):
         _req(q_lin[m], "q_lin"); _req(feat2[m], "feat2", q_lin[m].dtype); _req(masks[m], "mask", torch.float32)
@@ -237,7 +239,8 @@ def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, s
     nv, lpad, _ = feat2[0].shape
     kpairs = pair_vid.shape[1]
     d = ConvseDesc(nq=nq, nv=nv, kpairs=kpairs, lpad=lpad, l_ref=int(l_ref), hidden=hidden, n_mod=n_mod,
-                   merged=int(merged), ksize=int(ksize), softmax=int(softmax), dt=dt_of(q_lin[0]))
+                   merged=int(merged), ksize=int(ksize), softmax=int(bool(softmax)) | (0 if zero_skipped else 2),
+                   dt=dt_of(q_lin[0]))
     n_conv = 1 if merged else n_mod
     assert conv_w.numel() == 2 * n_conv * ksize
     lib = _lib.load()

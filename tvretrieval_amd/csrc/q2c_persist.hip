@@ -48,6 +48,12 @@ __device__ __forceinline__ void dma16s_nt(uint32_t voff, const char* sbase, uint
       : "memory");
 }
 
+// value of `v` in the lane selected by a DPP control word (row_mirror 0x140, row_half_mirror 0x141, quad_perm 0x00-0xff)
+template <int CTRL>
+__device__ __forceinline__ float dpp_read(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+
 __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // Specialised to lpad == 128 (one video per 128-column group -- the TVR shape): no per-column divisions, one
@@ -279,25 +285,54 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       float mk[8];
 #pragma unroll
       for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? mpatch[n * 16] : 0.f;
+      // every clip of this wave's video valid (the common case): x * 1 + (1 - 1) * -1e10 == x exactly, so the 128
+      // multiply-adds of mask_logits are skipped (wave-uniform branch; the epilogue is pure VALU time during which
+      // this wave issues no MFMA)
+      bool all_on = true;
+#pragma unroll
+      for (int n = 0; n < 8; ++n) all_on = all_on && (mk[n] == 1.f);
+      const bool fast = __all(all_on);
+      // in-lane maxima over the 8 column tiles: x[m * 4 + r] belongs to tile row m * 16 + fg * 4 + r
+      float x[16];
 #pragma unroll
       for (int m = 0; m < 4; ++m) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int lrow = wm * 64 + m * 16 + fg_e * 4 + r;
           float mx = -INFINITY;
+          if (fast) {
 #pragma unroll
-          for (int n = 0; n < 8; ++n)
-            mx = fmaxf(mx, acc[m][n][r] * mk[n] + (1.f - mk[n]) * -1e10f);   // mask_logits, xml/model_xml.py:640-641
-          float red = lane16_max_dpp(mx);
-          if (fr_e == 0) {
-            if (!last_mod) {
-              stash[lrow * 2] = red;
-            } else {
-              if (a.n_mod == 2) red = (stash[lrow * 2] + red) * 0.5f;        // (video + sub) / 2, xml/model_xml.py:574
-              if (q0 + lrow < a.nq && vid_ok) a.out[(int64_t)(q0 + lrow) * a.ld_out + vid] = red;
-            }
+            for (int n = 0; n < 8; ++n) mx = fmaxf(mx, acc[m][n][r]);
+          } else {
+#pragma unroll
+            for (int n = 0; n < 8; ++n)
+              mx = fmaxf(mx, acc[m][n][r] * mk[n] + (1.f - mk[n]) * -1e10f);   // mask_logits, xml/model_xml.py:640-641
           }
-          __builtin_amdgcn_sched_barrier(0);   // one row at a time: keeps the epilogue's register peak low
+          x[m * 4 + r] = mx;
+        }
+        __builtin_amdgcn_sched_barrier(0);   // one row block at a time: keeps the epilogue's register peak low
+      }
+      // Reduce-scatter over the 16 lanes that share fg: after four mirror exchanges (row, half-row, quad, pair) lane fr
+      // holds the 16-lane maximum of x[fr].  45 VALU ops instead of 16 full butterflies (128), and every lane ends up
+      // with exactly one row: one LDS op / one store per lane instead of 16 single-lane ones.
+      {
+        const bool b8 = (fr_e & 8) != 0, b4 = (fr_e & 4) != 0, b2 = (fr_e & 2) != 0, b1 = (fr_e & 1) != 0;
+        float y[8], z[4], u[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+          y[i] = fmaxf(b8 ? x[i + 8] : x[i], dpp_read<0x140>(b8 ? x[i] : x[i + 8]));        // row_mirror: fr <-> 15 - fr
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          z[i] = fmaxf(b4 ? y[i + 4] : y[i], dpp_read<0x141>(b4 ? y[i] : y[i + 4]));        // row_half_mirror
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          u[i] = fmaxf(b2 ? z[i + 2] : z[i], dpp_read<0x1B>(b2 ? z[i] : z[i + 2]));         // quad_perm [3,2,1,0]
+        float red = fmaxf(b1 ? u[1] : u[0], dpp_read<0xB1>(b1 ? u[0] : u[1]));              // quad_perm [1,0,3,2]
+        const int lrow = wm * 64 + (fr_e >> 2) * 16 + fg_e * 4 + (fr_e & 3);
+        if (!last_mod) {
+          stash[lrow * 2] = red;
+        } else {
+          if (a.n_mod == 2) red = (stash[lrow * 2] + red) * 0.5f;            // (video + sub) / 2, xml/model_xml.py:574
+          if (q0 + lrow < a.nq && vid_ok) a.out[(int64_t)(q0 + lrow) * a.ld_out + vid] = red;
         }
       }
     }

@@ -95,6 +95,8 @@ extern "C" void xml_debug_set_q2c_variant(int v) { g_q2c_variant = v; }
 
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                             float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st);
+int xmli_q2c_scores_persist32(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
+                              float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st);
 int xmli_q2c_scores_persist4(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                              float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st);
 int xmli_q2c_scores_ring(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int nq, int nv,
@@ -117,6 +119,12 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
     const void* c[2] = {cn, cn};
     const float* m[2] = {mask, mask};
     return xmli_q2c_scores_persist(1, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, st);
+  }
+  if (g_q2c_variant == 6 && persist_ok && !combine && dt == XML_BF16) {
+    const void* q[2] = {qn, qn};
+    const void* c[2] = {cn, cn};
+    const float* m[2] = {mask, mask};
+    return xmli_q2c_scores_persist32(1, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, st);
   }
   if (g_q2c_variant == 5 && persist_ok && !combine) {
     const void* q[2] = {qn, qn};
@@ -166,6 +174,12 @@ extern "C" int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0,
     const void* c[2] = {cn0, cn1};
     const float* m[2] = {mask0, mask1};
     return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream);
+  }
+  if (g_q2c_variant == 6 && persist_ok && dt == XML_BF16) {
+    const void* q[2] = {qn0, qn1};
+    const void* c[2] = {cn0, cn1};
+    const float* m[2] = {mask0, mask1};
+    return xmli_q2c_scores_persist32(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream);
   }
   if (g_q2c_variant == 5 && persist_ok) {
     const void* q[2] = {qn0, qn1};

@@ -143,8 +143,12 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       dma16s((uint32_t)mrow * 16, sbase_m, lds0 + MASK_OFF + (i_seg & 1) * 1024);
     }
   };
-  auto issue_slice = [&]() {      // 4 DMA instructions: this wave's 32 rows of A and of B
-    if (i_g >= n_qgroups) return;
+  // 4 DMA instructions: this wave's 32 rows of A and of B.  The stream SATURATES: once the walk is exhausted it keeps
+  // re-fetching slice 0 of the last segment into the slots it would have used (valid addresses, dead data), so that
+  // the consumer side needs no end-of-stream cases: always 2 slices in flight behind the awaited one (vmcnt(8)),
+  // fragment reads unconditional.  ~8 fewer scalar branches per slice; the kernel drains the stream before it exits.
+  bool exhausted = false;
+  auto issue_slice = [&]() {
     const int koff = i_slice * ROWB;
     const uint32_t dst = lds_wave + (i_gs & 3) * SLOT_BYTES;
     if (ABL != 1 || i_gs < 4) {
@@ -159,7 +163,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       }
     }
     ++i_gs;
-    if (++i_slice == slices_per_seg) {   // next segment: other modality of the tile, or the next tile
+    if (!exhausted && ++i_slice == slices_per_seg) {   // next segment: other modality of the tile, or the next tile
       i_slice = 0;
       ++i_seg;
       bool new_tile = false;
@@ -169,6 +173,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         new_tile = true;
       }
       if (i_g < n_qgroups) setup_issue_segment(new_tile);
+      else exhausted = true;                             // sbase_a / sbase_b keep pointing at the last segment
     }
   };
 
@@ -181,7 +186,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ swz4p(fr)) << 4);
   int c_g = i_g, c_c = i_c, c_mod = 0, c_seg = 0;
   uint32_t c_gs = 0;                               // global index of the slice being computed
-  bool more = true;                                // a slice c_gs + 1 exists
 
   // prologue: slices 0..3 in flight, slice 0 landed, first fragments in registers.  The issue side needs
   // slices_per_seg >= 4 here (no segment end inside the first 3 issues is required; 4th may end a segment).
@@ -216,23 +220,17 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
           if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbL[n].x), "v"(fc[m].w), "v"(fbL[n].w));
           else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
         }
-      {   // slice c_gs + 1 must have landed (mine) before the barrier; later slices may stay in flight
-        const int fly = (int)(i_gs - (c_gs + 2));
-        if (fly >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (fly == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+      // slice c_gs + 1 must have landed (mine) before the barrier; the two younger slices stay in flight
+      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0), as a builtin: hipcc must KNOW the fbH reads have
       __builtin_amdgcn_s_barrier();                     // returned, or it waits for the reads issued below before h1
       ++c_gs;
-      auto next_reads = [&]() {
-        if (more) {                                     // their latency hides under the DMA issue + MFMAs
-          const char* nslot = smem + (c_gs & 3) * SLOT_BYTES;
+      auto next_reads = [&]() {                         // their latency hides under the DMA issue + MFMAs
+        const char* nslot = smem + (c_gs & 3) * SLOT_BYTES;
 #pragma unroll
-          for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
+        for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
 #pragma unroll
-          for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
-        }
+        for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
       };
       auto h1 = [&]() {
 #pragma unroll
@@ -264,13 +262,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
     for (int c_slice = 0; c_slice < slices_per_seg; c_slice += 2) {
       slice_step(faA, faB, false);
-      if (c_slice + 2 >= slices_per_seg) {            // the slice after the next one closes the segment:
-        // does a further segment exist?  (compute-side lookahead of the walk, scalar only)
-        int ng = c_g, nc = c_c;
-        bool has_next = c_mod + 1 < a.n_mod;
-        if (!has_next) { advance(ng, nc); has_next = ng < n_qgroups; }
-        more = has_next;
-      }
       slice_step(faB, faA, true);
     }
     // ---- end of a (tile, modality) segment: mask_logits + max over the video's 128 clips, inside the wave -----
@@ -343,6 +334,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       if (c_g >= n_qgroups) break;
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the saturated stream still has DMAs in flight: nothing may
+  __builtin_amdgcn_s_barrier();                         // land in this LDS allocation after the workgroup is gone
 }
 
 template <typename T>

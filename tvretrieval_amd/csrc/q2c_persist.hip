@@ -17,6 +17,8 @@
 // Tile order: workgroup j runs on XCD j % 8 (observed, speed only).  The 32 workgroups of an XCD form an
 // 8 (query tiles) x 4 (clip tiles) super-tile; an XCD keeps its query group and walks clip groups, so the 3 MiB of
 // query operands stay in that XCD's 4 MiB L2 and only clip tiles stream in (6 % instead of 19 % line misses).
+#include <type_traits>
+
 #include "common.h"
 
 struct Q2cPersistArgs {
@@ -47,6 +49,24 @@ __device__ __forceinline__ void dma16s_nt(uint32_t voff, const char* sbase, uint
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
+
+// first K chunk of a segment: C = 0 as an inline constant (no 128 v_mov per segment to clear the accumulators)
+template <typename T> struct MmaInit;
+template <> struct MmaInit<float> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+template <> struct MmaInit<bf16_t> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; bf16x8_v v; } ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+};
 
 // value of `v` in the lane selected by a DPP control word (row_mirror 0x140, row_half_mirror 0x141, quad_perm 0x00-0xff)
 template <int CTRL>
@@ -203,13 +223,10 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   }
 
   for (;;) {      // one iteration = one (tile, modality) segment
-    f32x4 acc[4][8];
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4][8];       // written by the first slice of the segment (MmaInit: C = 0)
 
-    auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4], bool last_of_stream_possible) {
+    auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4], auto init_tag) {
+      constexpr bool INIT = decltype(init_tag)::value;
       const char* slot = smem + (c_gs & 3) * SLOT_BYTES;
 #pragma unroll
       for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
@@ -218,6 +235,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
           if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbL[n].x), "v"(fc[m].w), "v"(fbL[n].w));
+          else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n], fc[m], fbL[n]);
           else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
         }
       // slice c_gs + 1 must have landed (mine) before the barrier; the two younger slices stay in flight
@@ -238,6 +256,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 #pragma unroll
           for (int n = 0; n < 4; ++n) {
             if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbH[n].x), "v"(fc[m].w), "v"(fbH[n].w));
+            else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
             else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
           }
       };
@@ -260,9 +279,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       }
     };
 
-    for (int c_slice = 0; c_slice < slices_per_seg; c_slice += 2) {
-      slice_step(faA, faB, false);
-      slice_step(faB, faA, true);
+    slice_step(faA, faB, std::true_type{});               // slices_per_seg is even and >= 6
+    slice_step(faB, faA, std::false_type{});
+    for (int c_slice = 2; c_slice < slices_per_seg; c_slice += 2) {
+      slice_step(faA, faB, std::false_type{});
+      slice_step(faB, faA, std::false_type{});
     }
     // ---- end of a (tile, modality) segment: mask_logits + max over the video's 128 clips, inside the wave -----
     {

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // re-fetching slice 0 of the last segment into the slots it would have used (valid addresses, dead data), so that
   // the consumer side needs no end-of-stream cases: always 2 slices in flight behind the awaited one (vmcnt(8)),
   // fragment reads unconditional.  ~8 fewer scalar branches per slice; the kernel drains the stream before it exits.
-  bool exhausted = false;
+  int i_left = slices_per_seg, i_inc = 1;              // slices left to issue in the current segment; slice increment
   auto issue_slice = [&]() {
     const int koff = i_slice * ROWB;
     const uint32_t dst = lds_wave + (i_gs & 3) * SLOT_BYTES;
@@ -183,8 +183,10 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       }
     }
     ++i_gs;
-    if (!exhausted && ++i_slice == slices_per_seg) {   // next segment: other modality of the tile, or the next tile
+    i_slice += i_inc;
+    if (--i_left == 0) {                                 // next segment: other modality of the tile, or the next tile
       i_slice = 0;
+      i_left = slices_per_seg;
       ++i_seg;
       bool new_tile = false;
       if (++i_mod == a.n_mod) {
@@ -193,7 +195,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         new_tile = true;
       }
       if (i_g < n_qgroups) setup_issue_segment(new_tile);
-      else exhausted = true;                             // sbase_a / sbase_b keep pointing at the last segment
+      else { i_left = 0x7fffffff; i_inc = 0; }           // exhausted: slice 0 of the last segment from now on
     }
   };
 
@@ -222,6 +224,10 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(slot + b_off + n * 16 * ROWB);
   }
 
+  // The whole segment loop exists twice, once per wave group: the de-phased order of [preamble, MFMA] is then
+  // straight-line code instead of two wave-uniform branches per slice.
+  auto run = [&](auto grp_tag) {
+  constexpr bool GRP1 = decltype(grp_tag)::value;
   for (;;) {      // one iteration = one (tile, modality) segment
     f32x4 acc[4][8];       // written by the first slice of the segment (MmaInit: C = 0)
 
@@ -266,14 +272,14 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // group's MFMAs.
       // (The MFMA block itself stays outside any branch: accumulators updated in both arms of a branch get phi
       // copies -- 350 spilled VGPRs when tried.)
-      if (!PHASED || !grp) {
+      if (!GRP1) {
         next_reads();
         issue_slice();                                  // slice c_gs + 3 -> the slot just released
       }
       __builtin_amdgcn_sched_barrier(0);
       h1();
       __builtin_amdgcn_sched_barrier(0);
-      if (PHASED && grp) {
+      if (GRP1) {
         next_reads();
         issue_slice();
       }
@@ -355,6 +361,9 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       if (c_g >= n_qgroups) break;
     }
   }
+  };
+  if (PHASED && grp) run(std::true_type{});
+  else run(std::false_type{});
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the saturated stream still has DMAs in flight: nothing may
   __builtin_amdgcn_s_barrier();                         // land in this LDS allocation after the workgroup is gone
 }

@@ -40,6 +40,21 @@ __device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase, uint32_
       : "memory");
 }
 
+// the four pieces of a slice (2 x 1 KiB of A, 2 x 1 KiB of B) in one statement: M0 is advanced by immediates
+// (0x400 to the next piece, 0x3c00 from A's second piece to B's first: OPER_BYTES - 0x400) and left as is -- the
+// compiler reserves M0 and sets it itself before any instruction of its own that reads it
+__device__ __forceinline__ void dma_slice4(uint32_t va0, uint32_t va1, uint32_t vb0, uint32_t vb1, const char* sa,
+                                           const char* sb, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, m0, 0x3c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6"
+      :
+      : "v"(va0), "v"(va1), "v"(vb0), "v"(vb1), "s"(lds_dst), "s"(sa), "s"(sb)
+      : "memory", "scc");
+}
+
 // same, with the non-temporal hint: streamed clip tiles should not displace the L2-resident query group
 __device__ __forceinline__ void dma16s_nt(uint32_t voff, const char* sbase, uint32_t lds_dst) {
   uint32_t keep;
@@ -172,14 +187,13 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     const int koff = i_slice * ROWB;
     const uint32_t dst = lds_wave + (i_gs & 3) * SLOT_BYTES;
     if (ABL != 1 || i_gs < 4) {
-      dma16s(voff_a0, sbase_a + koff, dst);
-      dma16s(voff_a1, sbase_a + koff, dst + 1024);
       if (ABL == 3) {
+        dma16s(voff_a0, sbase_a + koff, dst);
+        dma16s(voff_a1, sbase_a + koff, dst + 1024);
         dma16s_nt(voff_b0, sbase_b + koff, dst + OPER_BYTES);
         dma16s_nt(voff_b1, sbase_b + koff, dst + OPER_BYTES + 1024);
       } else {
-        dma16s(voff_b0, sbase_b + koff, dst + OPER_BYTES);
-        dma16s(voff_b1, sbase_b + koff, dst + OPER_BYTES + 1024);
+        dma_slice4(voff_a0, voff_a1, voff_b0, voff_b1, sbase_a + koff, sbase_b + koff, dst);
       }
     }
     ++i_gs;

@@ -242,6 +242,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // straight-line code instead of two wave-uniform branches per slice.
   auto run = [&](auto grp_tag) {
   constexpr bool GRP1 = decltype(grp_tag)::value;
+  float stash = 0.f;                   // modality-0 maximum of this lane's row of the current tile
   for (;;) {      // one iteration = one (tile, modality) segment
     f32x4 acc[4][8];       // written by the first slice of the segment (MmaInit: C = 0)
 
@@ -258,10 +259,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
           else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n], fc[m], fbL[n]);
           else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
         }
-      // slice c_gs + 1 must have landed (mine) before the barrier; the two younger slices stay in flight
-      asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0), as a builtin: hipcc must KNOW the fbH reads have
-      __builtin_amdgcn_s_barrier();                     // returned, or it waits for the reads issued below before h1
+      // ONE wait: vmcnt(8) -- my DMAs of slice c_gs + 1 have landed, the two younger slices stay in flight -- and
+      // lgkmcnt(0) -- all my LDS reads of slice c_gs have returned (as a builtin: hipcc must KNOW the fbH reads are
+      // complete, or it waits for the reads issued below before h1)
+      __builtin_amdgcn_s_waitcnt(0x0078);
+      __builtin_amdgcn_s_barrier();
       ++c_gs;
       auto next_reads = [&]() {                         // their latency hides under the DMA issue + MFMAs
         const char* nslot = smem + (c_gs & 3) * SLOT_BYTES;
@@ -311,7 +313,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       int fr_e = fr, fg_e = fg;                     // opaque copies (see setup_issue_segment)
       asm volatile("" : "+v"(fr_e), "+v"(fg_e));
       const float* mpatch = reinterpret_cast<const float*>(smem + MASK_OFF + (c_seg & 1) * 1024) + wn * 128 + fr_e;
-      float* stash = reinterpret_cast<float*>(smem + STASH_OFF) + wn;
       const bool last_mod = c_mod == a.n_mod - 1;
       const bool vid_ok = vid < a.nv;
       float mk[8];
@@ -361,9 +362,9 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         float red = fmaxf(b1 ? u[1] : u[0], dpp_read<0xB1>(b1 ? u[0] : u[1]));              // quad_perm [1,0,3,2]
         const int lrow = wm * 64 + (fr_e >> 2) * 16 + fg_e * 4 + (fr_e & 3);
         if (!last_mod) {
-          stash[lrow * 2] = red;
+          stash = red;                       // the lane <-> row mapping is the same for both modalities of a tile
         } else {
-          if (a.n_mod == 2) red = (stash[lrow * 2] + red) * 0.5f;            // (video + sub) / 2, xml/model_xml.py:574
+          if (a.n_mod == 2) red = (stash + red) * 0.5f;                      // (video + sub) / 2, xml/model_xml.py:574
           if (q0 + lrow < a.nq && vid_ok) a.out[(int64_t)(q0 + lrow) * a.ld_out + vid] = red;
         }
       }

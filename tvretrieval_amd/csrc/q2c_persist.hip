@@ -118,7 +118,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int SLOT_BYTES = 2 * OPER_BYTES;
   constexpr int RING_BYTES = 4 * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
-  constexpr int STASH_OFF = RING_BYTES + 2048;    // 256 rows x 2 videos f32: modality-0 maxima of the current tile
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -385,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
 template <typename T>
 static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
-  const int lds = 4 * 2 * 256 * 64 + 2048 + 2048;
+  const int lds = 4 * 2 * 256 * 64 + 2048;       // ring + two mask patches
   extern int g_q2c_ablation;
   auto kern = g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
              : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>

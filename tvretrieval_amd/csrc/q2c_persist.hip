@@ -116,7 +116,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
   constexpr int SLOT_BYTES = 2 * OPER_BYTES;
-  constexpr int RING_BYTES = 4 * SLOT_BYTES;
+  constexpr int NSLOT = (ABL == 7) ? 5 : 4;        // ABL 7 (experiment): 5-slot ring, masks assumed all-valid
+  constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     }
     sbase_a = reinterpret_cast<const char*>(a.qn[i_mod]) + (int64_t)q0 * k_bytes;
     sbase_b = reinterpret_cast<const char*>(a.cn[i_mod]) + (int64_t)v0 * 128 * k_bytes;
-    if (wave == 0) {   // mask patch of the segment: lane l carries columns 4 l .. 4 l + 3 of the tile's 256 columns
+    if (ABL != 7 && wave == 0) {   // mask patch of the segment: lane l carries columns 4 l .. 4 l + 3 of the tile's 256 columns
       const int mrow = (v0 + (lane_o >> 5) < a.nv) ? lane_o : (lane_o & 31);
       const char* sbase_m = reinterpret_cast<const char*>(a.mask[i_mod]) + (int64_t)v0 * 128 * 4;
       dma16s((uint32_t)mrow * 16, sbase_m, lds0 + MASK_OFF + (i_seg & 1) * 1024);
@@ -181,10 +182,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // re-fetching slice 0 of the last segment into the slots it would have used (valid addresses, dead data), so that
   // the consumer side needs no end-of-stream cases: always 2 slices in flight behind the awaited one (vmcnt(8)),
   // fragment reads unconditional.  ~8 fewer scalar branches per slice; the kernel drains the stream before it exits.
+  int i_slot = 0;
   int i_left = slices_per_seg, i_inc = 1;              // slices left to issue in the current segment; slice increment
   auto issue_slice = [&]() {
     const int koff = i_slice * ROWB;
-    const uint32_t dst = lds_wave + (i_gs & 3) * SLOT_BYTES;
+    const uint32_t dst = lds_wave + i_slot * SLOT_BYTES;
     if (ABL != 1 || i_gs < 4) {
       if (ABL == 3) {
         dma16s(voff_a0, sbase_a + koff, dst);
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       }
     }
     ++i_gs;
+    if (++i_slot == NSLOT) i_slot = 0;
     i_slice += i_inc;
     if (--i_left == 0) {                                 // next segment: other modality of the tile, or the next tile
       i_slice = 0;
@@ -221,11 +224,17 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ swz4p(fr)) << 4);
   int c_g = i_g, c_c = i_c, c_mod = 0, c_seg = 0;
   uint32_t c_gs = 0;                               // global index of the slice being computed
+  int c_slot = 0;                                  // its ring slot
 
   // prologue: slices 0..3 in flight, slice 0 landed, first fragments in registers.  The issue side needs
   // slices_per_seg >= 4 here (no segment end inside the first 3 issues is required; 4th may end a segment).
   issue_slice(); issue_slice(); issue_slice(); issue_slice();
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if (NSLOT == 5) {
+    issue_slice();
+    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  }
   __builtin_amdgcn_s_barrier();
 
   uint4 faA[4], faB[4], fbL[4], fbH[4];
@@ -247,7 +256,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
     auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4], auto init_tag) {
       constexpr bool INIT = decltype(init_tag)::value;
-      const char* slot = smem + (c_gs & 3) * SLOT_BYTES;
+      const char* slot = smem + c_slot * SLOT_BYTES;
 #pragma unroll
       for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
 #pragma unroll
@@ -261,11 +270,13 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // ONE wait: vmcnt(8) -- my DMAs of slice c_gs + 1 have landed, the two younger slices stay in flight -- and
       // lgkmcnt(0) -- all my LDS reads of slice c_gs have returned (as a builtin: hipcc must KNOW the fbH reads are
       // complete, or it waits for the reads issued below before h1)
-      __builtin_amdgcn_s_waitcnt(0x0078);
+      if (NSLOT == 5) __builtin_amdgcn_s_waitcnt(0x007c);    // vmcnt(12): three younger slices in flight
+      else __builtin_amdgcn_s_waitcnt(0x0078);
       __builtin_amdgcn_s_barrier();
       ++c_gs;
+      if (++c_slot == NSLOT) c_slot = 0;
       auto next_reads = [&]() {                         // their latency hides under the DMA issue + MFMAs
-        const char* nslot = smem + (c_gs & 3) * SLOT_BYTES;
+        const char* nslot = smem + c_slot * SLOT_BYTES;
 #pragma unroll
         for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
 #pragma unroll
@@ -316,7 +327,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       const bool vid_ok = vid < a.nv;
       float mk[8];
 #pragma unroll
-      for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? mpatch[n * 16] : 0.f;
+      for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? (ABL == 7 ? 1.f : mpatch[n * 16]) : 0.f;
       // every clip of this wave's video valid (the common case): x * 1 + (1 - 1) * -1e10 == x exactly, so the 128
       // multiply-adds of mask_logits are skipped (wave-uniform branch; the epilogue is pure VALU time during which
       // this wave issues no MFMA)
@@ -384,10 +395,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
 template <typename T>
 static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
-  const int lds = 4 * 2 * 256 * 64 + 2048;       // ring + two mask patches
+  extern int g_q2c_ablation;
+  const int lds = g_q2c_ablation == 7 ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring + two mask patches
   extern int g_q2c_ablation;
   auto kern = g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
-             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
+             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
                                                                                      : q2c_persist_kernel<T, 0, true>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;

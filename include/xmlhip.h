@@ -287,6 +287,9 @@ int xml_rank_loss(const float* scores, const int* ranks_ctx, const int* ranks_q,
  * mask that is a pure function of (seed, element index) -- the backward pass calls it again on the gradient.
  * 0 <= p < 1; y == x allowed.  Not torch's Philox stream: statistically, not bitwise, equal to the reference. */
 int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dt, xml_stream_t stream);
+/* torch.nn.utils.clip_grad_norm_ over all gradients (xml/train.py:88-90, `--grad_clip`, off by default): g (n) f32 is
+ * the flat gradient buffer; scaled in place by max_norm / (||g||_2 + 1e-6) when that is < 1.  ws: 4 bytes of scratch. */
+int xml_clip_grad_norm(float* g, int64_t n, float max_norm, float* ws, xml_stream_t stream);
 /* BertAdam.step (xml/optimization.py:273-338) over one flat f32 buffer holding every tensor:
  * per-tensor clip_grad_norm_ (gradient rescaled in place), m/v update, m/(sqrt(v)+eps) + wd*p, no bias
  * correction, p -= seg_lr[s] * lr_mult * update.  seg_off (n_seg+1) int64, seg_lr / seg_wd / norms (n_seg) f32,

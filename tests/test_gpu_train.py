@@ -390,3 +390,15 @@ def test_train_mode_step_with_dropout_runs():
     assert torch.allclose(g1, m.video_encoder1.self.query.weight.grad, rtol=1e-4, atol=1e-7)
     assert math.isfinite(float(l1)) and abs(float(l1) - float(d["loss"])) > 1e-6
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
+
+
+def test_global_grad_clip():
+    from tvretrieval_amd import train_ops as TO
+    for scale, n in ((5.0, 100003), (1e-4, 4096)):          # clipped / left alone
+        g = rnd(n, seed=3, scale=scale)
+        want = g.clone()
+        torch.nn.utils.clip_grad_norm_([torch.nn.Parameter(want)], 1.0)      # reference semantics on a plain tensor
+        p = torch.nn.Parameter(torch.zeros_like(g)); p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([p], 1.0)
+        got = TO.clip_grad_norm(g.clone(), 1.0)
+        check("clip", got, p.grad, 2e-6)

@@ -1137,3 +1137,41 @@ extern "C" int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t 
   XML_CHECK_LAUNCH();
   return XML_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// torch.nn.utils.clip_grad_norm_ over ALL gradients (xml/train.py:88-90, `grad_clip`, off by default): one flat f32
+// buffer, total L2 norm, g *= max_norm / (norm + 1e-6) when that coefficient is < 1.  ws: one float of scratch.
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g, int64_t n, float* __restrict__ out) {
+  __shared__ float s_part[4];
+  float acc = 0.f;
+  for (int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; i < n; i += (int64_t)gridDim.x * 1024) {
+    if (i + 3 < n) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    } else {
+      for (int k = 0; k < 4 && i + k < n; ++k) acc += g[i + k] * g[i + k];
+    }
+  }
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+}
+__global__ void clip_scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ sumsq, float max_norm) {
+  const float coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);
+  if (coef >= 1.f) return;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] *= coef;
+}
+
+extern "C" int xml_clip_grad_norm(float* g, int64_t n, float max_norm, float* ws, xml_stream_t stream) {
+  XML_ENTER();
+  if (!g || !ws || n <= 0 || !(max_norm > 0.f)) return XML_ERR_BAD_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(ws, 0, 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  const int blocks = (int)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048);
+  hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, n, ws);
+  hipLaunchKernelGGL(clip_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, n, ws, max_norm);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}

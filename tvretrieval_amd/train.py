@@ -354,8 +354,7 @@ def train_step(model, optimizer, batch, grad_clip=-1, group=None):
     optimizer.zero_grad()
     loss.backward()
     allreduce_gradients(optimizer, group)
-    if grad_clip != -1:
-        raise NotImplementedError("global clip_grad_norm_ (xml/train.py:88-90, off by default) is not built; "
-                                  "BertAdam clips per tensor with max_grad_norm")
+    if grad_clip != -1:                                   # nn.utils.clip_grad_norm_(model.parameters(), grad_clip)
+        T.clip_grad_norm(optimizer.flat_g, grad_clip)
     optimizer.step()
     return loss, loss_dict

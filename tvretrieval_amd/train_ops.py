@@ -228,6 +228,15 @@ def dropout(x, p, seed, out=None):
     return y
 
 
+def clip_grad_norm(flat_g, max_norm):
+    """In-place global-norm clip of the flat gradient buffer (torch.nn.utils.clip_grad_norm_ semantics)."""
+    _req(flat_g, "flat_g", F32)
+    ws = torch.empty(1, dtype=F32, device=flat_g.device)
+    check(_lib.load().xml_clip_grad_norm(_p(flat_g), flat_g.numel(), float(max_norm), _p(ws), _stream()),
+          "xml_clip_grad_norm")
+    return flat_g
+
+
 def bert_adam_step(p, g, m, v, seg_off, seg_lr, seg_wd, norms, lr_mult, b1, b2, eps, max_grad_norm):
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (seg_lr, "seg_lr"), (seg_wd, "seg_wd"), (norms, "norms")):
         _req(t, nm, F32)

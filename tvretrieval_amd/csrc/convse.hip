@@ -21,6 +21,7 @@ struct ConvseWs {
   int32_t* cursor;     // [nv]
   int32_t* chunk_off;  // [nv+1] exclusive scan of ceil(count / TM)
   int32_t* bucket;     // [P]    pair ids grouped by video
+  int32_t* chunk_vid;  // [P / TM + min(P, nv)] video of every chunk (saves a 15-step dependent binary search per workgroup)
 };
 
 static size_t convse_ws_layout(const xml_convse_desc* d, ConvseWs* w, char* base) {
@@ -36,7 +37,9 @@ static size_t convse_ws_layout(const xml_convse_desc* d, ConvseWs* w, char* base
   char* offsets = take((nv + 1) * 4);
   char* chunk_off = take((nv + 1) * 4);
   char* bucket = take(P * 4);
+  char* chunk_vid = take((P / TM + (P < nv ? P : nv) + 1) * 4);
   if (w) {
+    w->chunk_vid = (int32_t*)chunk_vid;
     w->counts = (int32_t*)counts; w->cursor = (int32_t*)cursor; w->offsets = (int32_t*)offsets;
     w->chunk_off = (int32_t*)chunk_off; w->bucket = (int32_t*)bucket;
   }
@@ -72,7 +75,8 @@ __global__ void convse_zero_skipped_kernel(const int32_t* __restrict__ pair_vid,
 // single workgroup: exclusive scans of counts and of ceil(counts / TM)
 __global__ __launch_bounds__(1024) void convse_scan_kernel(const int32_t* __restrict__ counts,
                                                            int32_t* __restrict__ offsets,
-                                                           int32_t* __restrict__ chunk_off, int nv) {
+                                                           int32_t* __restrict__ chunk_off,
+                                                           int32_t* __restrict__ chunk_vid, int nv) {
   __shared__ int32_t sa[1024], sb[1024];
   __shared__ int32_t carry_a, carry_b;
   const int tid = threadIdx.x;
@@ -90,7 +94,12 @@ __global__ __launch_bounds__(1024) void convse_scan_kernel(const int32_t* __rest
       sa[tid] += va; sb[tid] += vb;
       __syncthreads();
     }
-    if (i < nv) { offsets[i] = carry_a + sa[tid] - c; chunk_off[i] = carry_b + sb[tid] - ch; }
+    if (i < nv) {
+      offsets[i] = carry_a + sa[tid] - c;
+      const int c0 = carry_b + sb[tid] - ch;
+      chunk_off[i] = c0;
+      for (int j = 0; j < ch; ++j) chunk_vid[c0 + j] = i;
+    }
     __syncthreads();
     if (tid == 1023) { carry_a += sa[1023]; carry_b += sb[1023]; }
     __syncthreads();
@@ -118,6 +127,7 @@ struct ConvseArgs {
   const int32_t* offsets;
   const int32_t* chunk_off;
   const int32_t* bucket;
+  const int32_t* chunk_vid;
   int nv, kpairs, lpad, l_ref, hidden, n_mod, merged, ksize, softmax;
 };
 
@@ -134,13 +144,7 @@ __global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x;
   if (chunk >= a.chunk_off[a.nv]) return;
-  // video owning this chunk: last v with chunk_off[v] <= chunk
-  int lo = 0, hi = a.nv;
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    if (a.chunk_off[mid] <= chunk) lo = mid; else hi = mid;
-  }
-  const int v = lo;
+  const int v = a.chunk_vid[chunk];                // video owning this chunk
   const int first = a.offsets[v] + (chunk - a.chunk_off[v]) * TM;
   const int cnt = min(TM, a.offsets[v + 1] - first);
   if (tid < TM) s_pair[tid] = tid < cnt ? a.bucket[first + tid] : -1;
@@ -270,7 +274,8 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
                        st_out, ed_out, P, d->nv, d->lpad / 4);
     XML_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, d->nv);
+  hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid,
+                     d->nv);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.cursor, w.bucket,
                      P, d->nv);
@@ -280,7 +285,7 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   a.feat2[0] = feat2_0; a.feat2[1] = feat2_1;
   a.mask[0] = mask0; a.mask[1] = mask1 ? mask1 : mask0;
   a.conv_w = conv_w; a.st_out = st_out; a.ed_out = ed_out;
-  a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket;
+  a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket; a.chunk_vid = w.chunk_vid;
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
   a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax & 1;
   const int64_t max_chunks = P / TM + (P < d->nv ? P : d->nv);

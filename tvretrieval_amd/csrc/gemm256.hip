@@ -2,6 +2,8 @@
 //   out[m][n] = act(A[m] . W[n] + bias[n]) + addend        A (M, K), W (N, K) both K-contiguous
 // Used for the encoder projections (K1, QKV, output dense) when K * sizeof(T) is a multiple of 128 bytes and
 // M >= 256; the 128 x 128 register-staged kernel (linear.hip) covers every other shape.
+#include <type_traits>
+
 #include "common.h"
 #include "internal.h"
 
@@ -13,6 +15,35 @@ __device__ __forceinline__ void g256_dma(uint32_t voff, const char* sbase, uint3
       : "v"(voff), "s"(sbase), "s"(lds_dst)
       : "memory");
 }
+// the four pieces of a slice in one statement, M0 advanced by immediates (see q2c_persist.hip: every scalar
+// instruction and branch in the per-slice path of a wave is issue time its partner wave's MFMAs do not fully cover)
+__device__ __forceinline__ void g256_dma4(uint32_t va0, uint32_t va1, uint32_t vb0, uint32_t vb1, const char* sa,
+                                          const char* sb, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, m0, 0x3c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6"
+      :
+      : "v"(va0), "v"(va1), "v"(vb0), "v"(vb1), "s"(lds_dst), "s"(sa), "s"(sb)
+      : "memory", "scc");
+}
+template <typename T> struct G256Init;      // first K chunk of the tile: C = 0 as an inline constant
+template <> struct G256Init<float> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+template <> struct G256Init<bf16_t> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; bf16x8_v v; } ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+};
 __device__ __forceinline__ int g256_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 template <typename T, typename OutT, typename AddT>
@@ -60,76 +91,98 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   const char* sbase_b = reinterpret_cast<const char*>(W) + (int64_t)n0 * k_bytes;
   const uint32_t lds_wave = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + wave * 2048;
   int i_slice = 0;
-  auto issue_slice = [&]() {
-    if (i_slice >= n_slices) return;
+  auto issue_slice = [&]() {        // callers guarantee i_slice < n_slices
     const int koff = i_slice * ROWB;
     const uint32_t dst = lds_wave + (i_slice & 3) * SLOT_BYTES;
-    g256_dma(voff_a[0], sbase_a + koff, dst);
-    g256_dma(voff_a[1], sbase_a + koff, dst + 1024);
-    g256_dma(voff_b[0], sbase_b + koff, dst + OPER_BYTES);
-    g256_dma(voff_b[1], sbase_b + koff, dst + OPER_BYTES + 1024);
+    g256_dma4(voff_a[0], voff_a[1], voff_b[0], voff_b[1], sbase_a + koff, sbase_b + koff, dst);
     ++i_slice;
   };
 
   const int a_off = (wm * 64 + fr) * ROWB + ((fg ^ g256_swz(fr)) << 4);
   const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ g256_swz(fr)) << 4);
 
-  issue_slice(); issue_slice(); issue_slice(); issue_slice();
-  {
-    const int fly = i_slice - 1;      // slices allowed in flight after slice 0 has landed
-    if (fly >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if (fly == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (fly == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  }
+  issue_slice(); issue_slice(); issue_slice(); issue_slice();      // n_slices >= 4 (eligibility)
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
-  f32x4 acc[4][8];
-#pragma unroll
-  for (int m = 0; m < 4; ++m)
-#pragma unroll
-    for (int n = 0; n < 8; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 acc[4][8];                  // written by the first slice (G256Init: C = 0)
   uint4 faA[4], faB[4], fbL[4], fbH[4];
 #pragma unroll
   for (int m = 0; m < 4; ++m) faA[m] = *reinterpret_cast<const uint4*>(smem + a_off + m * 16 * ROWB);
 #pragma unroll
   for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(smem + b_off + n * 16 * ROWB);
 
+  // One step = one 32-wide K slice (see q2c_persist.hip for the schedule).  The tail of the stream is PEELED instead
+  // of tested: MODE 0 = steady state (wait for slice c+1 with two younger slices in flight, read, issue slice c+4),
+  // MODE 1 / 2 / 3 = the last three steps that still prefetch fragments (2 / 1 / 0 slices left in flight, nothing to
+  // issue), MODE 4 = the last slice (nothing to wait for or to read).  GRP1: the second wave of each SIMD runs its
+  // second MFMA half before its preamble, so the two waves' non-MFMA phases do not coincide.
   int c_slice = 0;
-  auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4]) {
-    const char* slot = smem + (c_slice & 3) * SLOT_BYTES;
+  auto run = [&](auto grp_tag) {
+    constexpr bool GRP1 = decltype(grp_tag)::value;
+    auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4], auto mode_tag, auto init_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      constexpr bool INIT = decltype(init_tag)::value;
+      const char* slot = smem + (c_slice & 3) * SLOT_BYTES;
 #pragma unroll
-    for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
+      for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
 #pragma unroll
-    for (int m = 0; m < 4; ++m)
+      for (int m = 0; m < 4; ++m)
 #pragma unroll
-      for (int n = 0; n < 4; ++n) Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
-    {
-      const int fly = i_slice - (c_slice + 2);
-      if (fly >= 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      else if (fly == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int n = 0; n < 4; ++n) {
+          if constexpr (INIT) G256Init<T>::chunk(acc[m][n], fc[m], fbL[n]);
+          else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+        }
+      if constexpr (MODE <= 1) __builtin_amdgcn_s_waitcnt(0x0078);        // vmcnt(8) lgkmcnt(0)
+      else if constexpr (MODE == 2) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0)
+      else if constexpr (MODE == 3) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+      if constexpr (MODE <= 3) __builtin_amdgcn_s_barrier();
+      ++c_slice;
+      auto preamble = [&]() {
+        if constexpr (MODE <= 3) {
+          const char* nslot = smem + (c_slice & 3) * SLOT_BYTES;
+#pragma unroll
+          for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
+#pragma unroll
+          for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
+        }
+        if constexpr (MODE == 0) issue_slice();
+      };
+      if (!GRP1) preamble();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if constexpr (INIT) G256Init<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+          else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (GRP1) preamble();
+    };
+    using M0 = std::integral_constant<int, 0>;
+    using M1 = std::integral_constant<int, 1>;
+    using M2 = std::integral_constant<int, 2>;
+    using M3 = std::integral_constant<int, 3>;
+    using M4 = std::integral_constant<int, 4>;
+    const int n_main = n_slices - 4;             // even: steps 0 .. n_slices - 5 run in steady state
+    if (n_main > 0) {
+      slice_step(faA, faB, M0{}, std::true_type{});
+      slice_step(faB, faA, M0{}, std::false_type{});
+      for (int s2 = 2; s2 < n_main; s2 += 2) {
+        slice_step(faA, faB, M0{}, std::false_type{});
+        slice_step(faB, faA, M0{}, std::false_type{});
+      }
+      slice_step(faA, faB, M1{}, std::false_type{});
+    } else {
+      slice_step(faA, faB, M1{}, std::true_type{});
     }
-    __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): all reads of this slot have returned
-    __builtin_amdgcn_s_barrier();
-    ++c_slice;
-    if (c_slice < n_slices) {
-      const char* nslot = smem + (c_slice & 3) * SLOT_BYTES;
-#pragma unroll
-      for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
-#pragma unroll
-      for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
-    }
-    issue_slice();
-#pragma unroll
-    for (int m = 0; m < 4; ++m)
-#pragma unroll
-      for (int n = 0; n < 4; ++n) Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+    slice_step(faB, faA, M2{}, std::false_type{});
+    slice_step(faA, faB, M3{}, std::false_type{});
+    slice_step(faB, faA, M4{}, std::false_type{});
   };
-  for (int s = 0; s < n_slices; s += 2) {
-    slice_step(faA, faB);
-    slice_step(faB, faA);
-  }
+  if (wave >> 2) run(std::true_type{});
+  else run(std::false_type{});
 
   // ---- epilogue through LDS: 16-byte coalesced stores --------------------------------------------------------
   // An MFMA accumulator holds 4 rows x 1 column per lane, so direct stores are 2- or 4-byte pieces (32-64 B

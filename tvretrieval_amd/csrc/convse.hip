@@ -129,6 +129,7 @@ struct ConvseArgs {
   const int32_t* bucket;
   const int32_t* chunk_vid;
   int nv, kpairs, lpad, l_ref, hidden, n_mod, merged, ksize, softmax;
+  int dbg;   // perf ablations (xml_debug_set_q2c_ablation): 1 skip the GEMMs, 2 skip the conv / softmax / store epilogue
 };
 
 template <typename T>
@@ -164,7 +165,12 @@ __global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
     auto b_row = [&](int r) -> const char* {
       return r < a.lpad ? reinterpret_cast<const char*>(f2 + ((int64_t)v * a.lpad + r) * a.hidden) : nullptr;
     };
-    if (a.merged && m > 0)
+    if (a.dbg == 1) {
+#pragma unroll
+      for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < Cfg::NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (a.merged && m > 0)
       gemm_mainloop<T, Cfg, false>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem);
     else
       gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem);
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
   }
   __syncthreads();
 
+  if (a.dbg == 2) return;
   // ---- ConvSE epilogue: each wave owns TM/4 pair rows; a lane owns clips lane and lane + 64 ----------
   const int half = a.ksize >> 1;
   const float inv_mod = 1.f / (float)n_sim;
@@ -288,6 +295,8 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket; a.chunk_vid = w.chunk_vid;
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
   a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax & 1;
+  extern int g_q2c_ablation;
+  a.dbg = g_q2c_ablation;
   const int64_t max_chunks = P / TM + (P < d->nv ? P : d->nv);
   const int n_sim = d->merged ? 1 : d->n_mod;
   const size_t patch = (size_t)TM * LP * 4;

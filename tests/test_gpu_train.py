@@ -402,3 +402,22 @@ def test_global_grad_clip():
         torch.nn.utils.clip_grad_norm_([p], 1.0)
         got = TO.clip_grad_norm(g.clone(), 1.0)
         check("clip", got, p.grad, 2e-6)
+
+
+def test_fused_qkv_self_attention():
+    """QkvFn + AttentionQkvFn (one stacked projection GEMM, fused column blocks) == three Linear + attention in torch."""
+    from tvretrieval_amd.autograd import AttentionQkvFn, QkvFn
+    n, l, hsz, heads = 3, 21, 128, 4
+    x = rnd(n, l, hsz, seed=1)
+    ws = [rnd(hsz, hsz, seed=10 + i, scale=0.1) for i in range(3)]
+    bs = [rnd(hsz, seed=20 + i, scale=0.1) for i in range(3)]
+    km = lens_mask(n, l, seed=4, lo=3)
+
+    def hip(x, wq, bq, wk, bk, wv, bv):
+        return AttentionQkvFn.apply(QkvFn.apply(x, wq, bq, wk, bk, wv, bv), km, heads)
+
+    def ref(x, wq, bq, wk, bk, wv, bv):
+        return ref_attention(F.linear(x, wq, bq), F.linear(x, wk, bk), F.linear(x, wv, bv), None, km, heads)
+    args = [x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2]]
+    # the key bias has an analytically zero gradient (softmax is shift invariant): only rounding noise on both sides
+    run_pair(hip, ref, args, [True, True, True, True, False, True, True], tol=5e-5)

@@ -161,6 +161,81 @@ class AttentionCoreFn(torch.autograd.Function):
                 None, None, None, None, None)
 
 
+class QkvFn(torch.autograd.Function):
+    """The three projections of BertSelfAttention (xml/model_components.py:266-272) as ONE GEMM on the stacked weight
+    [Wq; Wk; Wv]: x (N, L, H) -> (N, L, 3H).  Backward: one dX GEMM, one split-K dW GEMM (3H x H), one column sum;
+    the input is transposed once instead of three times."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv):
+        w = _packed(torch.cat([wq.detach(), wk.detach(), wv.detach()], 0), x.dtype)
+        b = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
+        ctx.save_for_backward(x, w)
+        return ops.linear(x.contiguous(), w, b)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dy = dy.contiguous()
+        n3, k = w.shape
+        h = n3 // 3
+        rows = x.numel() // k
+        dy2, x2 = dy.view(rows, n3), x.contiguous().view(rows, k)
+        dx = ops.linear(dy2, T.transpose(w)).view(x.shape) if ctx.needs_input_grad[0] else None
+        r8 = _r8(rows)
+        dw = T.gemm_batched(T.transpose(dy2, r8), T.transpose(x2, r8), out_f32=True)      # (3H, H)
+        db = T.colsum(dy2, rows, n3)
+        return dx, dw[:h], db[:h], dw[h:2 * h], db[h:2 * h], dw[2 * h:], db[2 * h:]
+
+
+class AttentionQkvFn(torch.autograd.Function):
+    """AttentionCoreFn on a fused (N, L, 3H) projection tensor (self-attention: q, k, v are its column blocks)."""
+
+    @staticmethod
+    def forward(ctx, qkv, k_mask, heads, p_drop=0.0, seed=0):
+        n, l, h3 = qkv.shape
+        hidden = h3 // 3
+        dh = hidden // heads
+        qkv = qkv.contiguous()
+        qh, _ = T.split_heads(qkv, heads, col0=0, width=hidden)
+        kh, _ = T.split_heads(qkv, heads, col0=hidden, width=hidden)
+        _, vht = T.split_heads(qkv, heads, want=False, want_t=True, col0=2 * hidden, width=hidden)
+        s = T.gemm_batched(qh, kh, out_f32=True)
+        p, _ = T.attn_softmax_fwd(s, None, k_mask, n, heads, l, l, dh, qkv.dtype)
+        if p_drop > 0:
+            T.dropout(p, p_drop, seed, out=p)
+        out = T.merge_heads(T.gemm_batched(p, vht), n, l, heads)
+        ctx.cfg = (heads, p_drop, seed)
+        ctx.save_for_backward(qkv, s, k_mask)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, s, k_mask = ctx.saved_tensors
+        heads, p_drop, seed = ctx.cfg
+        n, l, h3 = qkv.shape
+        hidden = h3 // 3
+        dh = hidden // heads
+        doh, doht = T.split_heads(dout.contiguous(), heads, want=True, want_t=True)
+        vh, _ = T.split_heads(qkv, heads, col0=2 * hidden, width=hidden)
+        dp = T.gemm_batched(doh, vh, out_f32=True)
+        if p_drop > 0:
+            p, _ = T.attn_softmax_fwd(s, None, k_mask, n, heads, l, l, dh, qkv.dtype)
+            T.dropout(p, p_drop, seed, out=p)
+            pt = T.transpose(p)
+            T.dropout(dp, p_drop, seed, out=dp)
+        else:
+            _, pt = T.attn_softmax_fwd(s, None, k_mask, n, heads, l, l, dh, qkv.dtype, want_t=True)
+        ds, dst = T.attn_softmax_bwd(s, dp, None, k_mask, n, heads, l, l, dh, qkv.dtype)
+        _, qht = T.split_heads(qkv, heads, want=False, want_t=True, col0=0, width=hidden)
+        _, kht = T.split_heads(qkv, heads, want=False, want_t=True, col0=hidden, width=hidden)
+        dqkv = torch.empty_like(qkv)
+        T.merge_heads(T.gemm_batched(ds, kht), n, l, heads, out=dqkv, col0=0)              # dQ = dS K
+        T.merge_heads(T.gemm_batched(dst, qht), n, l, heads, out=dqkv, col0=hidden)        # dK = dS^T Q
+        T.merge_heads(T.gemm_batched(pt, doht), n, l, heads, out=dqkv, col0=2 * hidden)    # dV = P^T dO
+        return dqkv, None, None, None, None
+
+
 class ModularPoolFn(torch.autograd.Function):
     """get_modularized_queries (xml/model_xml.py:410-423) -> (n_mod, N, H)."""
 

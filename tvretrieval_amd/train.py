@@ -21,8 +21,8 @@ import math
 import torch
 
 from . import train_ops as T
-from .autograd import (AttentionCoreFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn,
-                       SpanLossFn, VideoLevelScoresFn)
+from .autograd import (AttentionCoreFn, AttentionQkvFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn,
+                       QkvFn, SpanLossFn, VideoLevelScoresFn)
 
 F32 = torch.float32
 
@@ -69,10 +69,8 @@ def _probs_drop(sa):
 def _bert_attention(mod, x, key_mask, dt):
     """BertAttention = BertSelfAttention + BertSelfOutput (xml/model_components.py:201-216,313-317)."""
     sa, so = mod.self, mod.output
-    q = LinearFn.apply(x, sa.query.weight, sa.query.bias, False)
-    k = LinearFn.apply(x, sa.key.weight, sa.key.bias, False)
-    v = LinearFn.apply(x, sa.value.weight, sa.value.bias, False)
-    a = AttentionCoreFn.apply(q, k, v, None, key_mask, sa.num_attention_heads, *_probs_drop(sa))
+    qkv = QkvFn.apply(x, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias)
+    a = AttentionQkvFn.apply(qkv, key_mask, sa.num_attention_heads, *_probs_drop(sa))
     d = _drop(LinearFn.apply(a, so.dense.weight, so.dense.bias, False), so.dropout)
     return LayerNormFn.apply(d, x, so.LayerNorm.weight, so.LayerNorm.bias, dt)
 

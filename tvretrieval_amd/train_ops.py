@@ -100,12 +100,14 @@ def split_heads(x, heads, want=True, want_t=False, col0=0, width=None):
     return dst, dst_t
 
 
-def merge_heads(xh, n, l, heads):
-    """(N*heads, L8, dh) -> (N, L, heads*dh)."""
+def merge_heads(xh, n, l, heads, out=None, col0=0):
+    """(N*heads, L8, dh) -> (N, L, heads*dh), or into columns [col0, col0 + heads*dh) of `out` (N, L, ld)."""
     _req(xh, "xh")
     l8, dh = xh.shape[1], xh.shape[2]
-    out = torch.empty((n, l, heads * dh), dtype=xh.dtype, device=xh.device)
-    check(_lib.load().xml_merge_heads(_p(xh), _p(out), heads * dh, 0, n, l, l8, heads, dh, dt_of(xh), _stream()),
+    if out is None:
+        out = torch.empty((n, l, heads * dh), dtype=xh.dtype, device=xh.device)
+    _req(out, "out", xh.dtype)
+    check(_lib.load().xml_merge_heads(_p(xh), _p(out), out.shape[-1], col0, n, l, l8, heads, dh, dt_of(xh), _stream()),
           "xml_merge_heads")
     return out
 

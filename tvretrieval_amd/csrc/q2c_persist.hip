@@ -223,7 +223,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int a_off = (wm * 64 + fr) * ROWB + ((fg ^ swz4p(fr)) << 4);
   const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ swz4p(fr)) << 4);
   int c_g = i_g, c_c = i_c, c_mod = 0, c_seg = 0;
-  uint32_t c_gs = 0;                               // global index of the slice being computed
   int c_slot = 0;                                  // its ring slot
 
   // prologue: slices 0..3 in flight, slice 0 landed, first fragments in registers.  The issue side needs
@@ -273,7 +272,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       if (NSLOT == 5) __builtin_amdgcn_s_waitcnt(0x007c);    // vmcnt(12): three younger slices in flight
       else __builtin_amdgcn_s_waitcnt(0x0078);
       __builtin_amdgcn_s_barrier();
-      ++c_gs;
       if (++c_slot == NSLOT) c_slot = 0;
       auto next_reads = [&]() {                         // their latency hides under the DMA issue + MFMAs
         const char* nslot = smem + c_slot * SLOT_BYTES;

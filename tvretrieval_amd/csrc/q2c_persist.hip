@@ -83,6 +83,13 @@ template <> struct MmaInit<bf16_t> {
   }
 };
 
+// ABL 8 (timing probe): per wave of workgroup 0, shader-clock cycles spent between "about to wait" and "barrier
+// released" summed over all slices, and the wave's total; read back with xml_debug_read_k6_probe
+__device__ unsigned long long g_k6_probe[32];
+extern "C" int xml_debug_read_k6_probe(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k6_probe), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -4;
+}
+
 // value of `v` in the lane selected by a DPP control word (row_mirror 0x140, row_half_mirror 0x141, quad_perm 0x00-0xff)
 template <int CTRL>
 __device__ __forceinline__ float dpp_read(float v) {
@@ -250,6 +257,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   auto run = [&](auto grp_tag) {
   constexpr bool GRP1 = decltype(grp_tag)::value;
   float stash = 0.f;                   // modality-0 maximum of this lane's row of the current tile
+  unsigned long long probe_wait = 0, probe_bar = 0, probe_t0 = 0;
+  if (ABL == 8) probe_t0 = __builtin_amdgcn_s_memtime();
   for (;;) {      // one iteration = one (tile, modality) segment
     f32x4 acc[4][8];       // written by the first slice of the segment (MmaInit: C = 0)
 
@@ -269,9 +278,13 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // ONE wait: vmcnt(8) -- my DMAs of slice c_gs + 1 have landed, the two younger slices stay in flight -- and
       // lgkmcnt(0) -- all my LDS reads of slice c_gs have returned (as a builtin: hipcc must KNOW the fbH reads are
       // complete, or it waits for the reads issued below before h1)
+      unsigned long long t_a = 0;
+      if (ABL == 8) t_a = __builtin_amdgcn_s_memtime();
       if (NSLOT == 5) __builtin_amdgcn_s_waitcnt(0x007c);    // vmcnt(12): three younger slices in flight
       else __builtin_amdgcn_s_waitcnt(0x0078);
+      if (ABL == 8) { probe_wait += __builtin_amdgcn_s_memtime() - t_a; t_a = __builtin_amdgcn_s_memtime(); }
       __builtin_amdgcn_s_barrier();
+      if (ABL == 8) probe_bar += __builtin_amdgcn_s_memtime() - t_a;
       if (++c_slot == NSLOT) c_slot = 0;
       auto next_reads = [&]() {                         // their latency hides under the DMA issue + MFMAs
         const char* nslot = smem + c_slot * SLOT_BYTES;
@@ -296,17 +309,15 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // group's MFMAs.
       // (The MFMA block itself stays outside any branch: accumulators updated in both arms of a branch get phi
       // copies -- 350 spilled VGPRs when tried.)
-      if (!GRP1) {
-        next_reads();
-        issue_slice();                                  // slice c_gs + 3 -> the slot just released
-      }
+      // both groups read the next slice's fragments right after the barrier (the latency hides under this wave's
+      // own h1 MFMAs -- the timing probe showed the second group, which used to read AFTER h1, on the critical path
+      // with the first group parked at the barrier 35 % of the time); only the DMA issue is placed per group
+      next_reads();
+      if (!GRP1) issue_slice();                         // slice c_gs + 3 -> the slot just released
       __builtin_amdgcn_sched_barrier(0);
       h1();
       __builtin_amdgcn_sched_barrier(0);
-      if (GRP1) {
-        next_reads();
-        issue_slice();
-      }
+      if (GRP1) issue_slice();
     };
 
     slice_step(faA, faB, std::true_type{});               // slices_per_seg is even and >= 6
@@ -384,6 +395,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       if (c_g >= n_qgroups) break;
     }
   }
+  if (ABL == 8 && blockIdx.x == 0 && lane == 0) {
+    g_k6_probe[wave * 4 + 0] = probe_wait;
+    g_k6_probe[wave * 4 + 1] = probe_bar;
+    g_k6_probe[wave * 4 + 2] = __builtin_amdgcn_s_memtime() - probe_t0;
+  }
   };
   if (PHASED && grp) run(std::true_type{});
   else run(std::false_type{});
@@ -397,7 +413,7 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
   const int lds = g_q2c_ablation == 7 ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring + two mask patches
   extern int g_q2c_ablation;
   auto kern = g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
-             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
+             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 8 ? q2c_persist_kernel<T, 8, true> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
                                                                                      : q2c_persist_kernel<T, 0, true>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;

@@ -55,6 +55,28 @@ __device__ __forceinline__ void dma_slice4(uint32_t va0, uint32_t va1, uint32_t 
       : "memory", "scc");
 }
 
+// two consecutive 1 KiB pieces of one operand
+__device__ __forceinline__ void dma_pair(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3"
+      :
+      : "v"(v0), "v"(v1), "s"(lds_dst), "s"(sb)
+      : "memory", "scc");
+}
+// four consecutive 1 KiB pieces of one operand
+__device__ __forceinline__ void dma_quad(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, const char* sb,
+                                         uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5"
+      :
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst), "s"(sb)
+      : "memory", "scc");
+}
+
 // same, with the non-temporal hint: streamed clip tiles should not displace the L2-resident query group
 __device__ __forceinline__ void dma16s_nt(uint32_t voff, const char* sbase, uint32_t lds_dst) {
   uint32_t keep;
@@ -123,6 +145,12 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
   constexpr int SLOT_BYTES = 2 * OPER_BYTES;
+  // Uneven DMA duty: the timing probe shows the first wave group parked at the barrier ~35 % of the time while the
+  // second is on the critical path, so the first group issues 6 of the 8 pieces per SIMD pair -- its wave w loads A
+  // pieces 4w..4w+3 and B pieces 2w, 2w+1; wave 4+w loads B pieces 8+2w, 9+2w (+1 % measured; all 8 on the first
+  // group, ablation 10, gives the gain back).  Ablations 3 and 11 keep the even 4 / 4 split.
+  constexpr bool UNEVEN = (ABL != 3 && ABL != 11);
+  constexpr bool ALL_G0 = (ABL == 10);          // ABL 10: the first group issues all 8 pieces per SIMD pair
   constexpr int NSLOT = (ABL == 7) ? 5 : 4;        // ABL 7 (experiment): 5-slot ring, masks assumed all-valid
   constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
@@ -157,6 +185,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   int i_g = 0, i_c = -1, i_mod = 0, i_slice = 0, i_seg = 0;
   uint32_t i_gs = 0;                               // slices issued so far (global) -> ring slot
   uint32_t voff_a0 = 0, voff_a1 = 0, voff_b0 = 0, voff_b1 = 0;
+  uint32_t voff_x[ALL_G0 ? 4 : UNEVEN ? 2 : 1] = {};   // UNEVEN: A pieces 2, 3 (+ ALL_G0: B pieces 2, 3) of the first group's waves
   const char* sbase_a = nullptr;
   const char* sbase_b = nullptr;
 
@@ -166,15 +195,39 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     asm volatile("" : "+v"(lane_o));                // the MFMA loop) everything derived from the lane id below
     if (new_tile) {
       const int rsub = lane_o >> 2, pslot = lane_o & 3;
+      if constexpr (!UNEVEN) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int row = (wave * 2 + i) * 16 + rsub;                     // 0..255
-        const int slot = pslot ^ swz4p(row);
-        const int qrow = (q0 + row < a.nq) ? row : 0;                   // clamp to the tile's first row
-        const int brow = (v0 + (row >> 7) < a.nv) ? row : (row & 127);  // second video missing: re-read the first
-        const uint32_t va = (uint32_t)qrow * k_bytes + slot * 16;
-        const uint32_t vb = (uint32_t)brow * k_bytes + slot * 16;
-        if (i == 0) { voff_a0 = va; voff_b0 = vb; } else { voff_a1 = va; voff_b1 = vb; }
+        for (int i = 0; i < 2; ++i) {
+          const int row = (wave * 2 + i) * 16 + rsub;                     // 0..255
+          const int slot = pslot ^ swz4p(row);
+          const int qrow = (q0 + row < a.nq) ? row : 0;                   // clamp to the tile's first row
+          const int brow = (v0 + (row >> 7) < a.nv) ? row : (row & 127);  // second video missing: re-read the first
+          const uint32_t va = (uint32_t)qrow * k_bytes + slot * 16;
+          const uint32_t vb = (uint32_t)brow * k_bytes + slot * 16;
+          if (i == 0) { voff_a0 = va; voff_b0 = vb; } else { voff_a1 = va; voff_b1 = vb; }
+        }
+      } else {
+        auto off_a = [&](int piece) -> uint32_t {
+          const int row = piece * 16 + rsub;
+          const int qrow = (q0 + row < a.nq) ? row : 0;
+          return (uint32_t)qrow * k_bytes + (pslot ^ swz4p(row)) * 16;
+        };
+        auto off_b = [&](int piece) -> uint32_t {
+          const int row = piece * 16 + rsub;
+          const int brow = (v0 + (row >> 7) < a.nv) ? row : (row & 127);
+          return (uint32_t)brow * k_bytes + (pslot ^ swz4p(row)) * 16;
+        };
+        if (grp == 0) {
+          voff_a0 = off_a(wave * 4); voff_a1 = off_a(wave * 4 + 1); voff_x[0] = off_a(wave * 4 + 2); voff_x[1] = off_a(wave * 4 + 3);
+          if constexpr (ALL_G0) {
+            voff_b0 = off_b(wave * 4); voff_b1 = off_b(wave * 4 + 1);
+            voff_x[ALL_G0 ? 2 : 0] = off_b(wave * 4 + 2); voff_x[ALL_G0 ? 3 : 0] = off_b(wave * 4 + 3);
+          } else {
+            voff_b0 = off_b(wave * 2); voff_b1 = off_b(wave * 2 + 1);
+          }
+        } else if (!ALL_G0) {
+          voff_b0 = off_b(8 + (wave - 4) * 2); voff_b1 = off_b(9 + (wave - 4) * 2);
+        }
       }
     }
     sbase_a = reinterpret_cast<const char*>(a.qn[i_mod]) + (int64_t)q0 * k_bytes;
@@ -200,8 +253,20 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         dma16s(voff_a1, sbase_a + koff, dst + 1024);
         dma16s_nt(voff_b0, sbase_b + koff, dst + OPER_BYTES);
         dma16s_nt(voff_b1, sbase_b + koff, dst + OPER_BYTES + 1024);
-      } else {
+      } else if constexpr (!UNEVEN) {
         dma_slice4(voff_a0, voff_a1, voff_b0, voff_b1, sbase_a + koff, sbase_b + koff, dst);
+      } else {
+        const uint32_t slot0 = lds0 + i_slot * SLOT_BYTES;
+        if (grp == 0) {
+          dma_quad(voff_a0, voff_a1, voff_x[0], voff_x[UNEVEN ? 1 : 0], sbase_a + koff, slot0 + wave * 4096);
+          if constexpr (ALL_G0)
+            dma_quad(voff_b0, voff_b1, voff_x[ALL_G0 ? 2 : 0], voff_x[ALL_G0 ? 3 : 0], sbase_b + koff,
+                     slot0 + OPER_BYTES + wave * 4096);
+          else
+            dma_pair(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + wave * 2048);
+        } else if (!ALL_G0) {
+          dma_pair(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + 8192 + (wave - 4) * 2048);
+        }
       }
     }
     ++i_gs;
@@ -238,6 +303,13 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   if (NSLOT == 5) {
     issue_slice();
     asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  } else if (UNEVEN) {
+    if (grp == 0) {
+      if (ALL_G0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // (ALL_G0: nothing outstanding, trivially true)
+    }
   } else {
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
   }
@@ -281,6 +353,9 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       unsigned long long t_a = 0;
       if (ABL == 8) t_a = __builtin_amdgcn_s_memtime();
       if (NSLOT == 5) __builtin_amdgcn_s_waitcnt(0x007c);    // vmcnt(12): three younger slices in flight
+      else if (ALL_G0 && !GRP1) __builtin_amdgcn_s_waitcnt(0x4070);   // 8 pieces per slice: vmcnt(16)
+      else if (UNEVEN && !GRP1) __builtin_amdgcn_s_waitcnt(0x007c);   // 6 pieces per slice: vmcnt(12)
+      else if (UNEVEN && GRP1) __builtin_amdgcn_s_waitcnt(0x0074);    // 2 pieces per slice: vmcnt(4)
       else __builtin_amdgcn_s_waitcnt(0x0078);
       if (ABL == 8) { probe_wait += __builtin_amdgcn_s_memtime() - t_a; t_a = __builtin_amdgcn_s_memtime(); }
       __builtin_amdgcn_s_barrier();
@@ -309,15 +384,19 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // group's MFMAs.
       // (The MFMA block itself stays outside any branch: accumulators updated in both arms of a branch get phi
       // copies -- 350 spilled VGPRs when tried.)
-      // both groups read the next slice's fragments right after the barrier (the latency hides under this wave's
-      // own h1 MFMAs -- the timing probe showed the second group, which used to read AFTER h1, on the critical path
-      // with the first group parked at the barrier 35 % of the time); only the DMA issue is placed per group
-      next_reads();
-      if (!GRP1) issue_slice();                         // slice c_gs + 3 -> the slot just released
+      // (Reading the next fragments before h1 in BOTH groups was tried after the timing probe: no gain, and the second
+      // group's variant then spills.)
+      if (!GRP1) {
+        next_reads();
+        issue_slice();                                  // slice c_gs + 3 -> the slot just released
+      }
       __builtin_amdgcn_sched_barrier(0);
       h1();
       __builtin_amdgcn_sched_barrier(0);
-      if (GRP1) issue_slice();
+      if (GRP1) {
+        next_reads();
+        issue_slice();
+      }
     };
 
     slice_step(faA, faB, std::true_type{});               // slices_per_seg is even and >= 6
@@ -413,7 +492,7 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
   const int lds = g_q2c_ablation == 7 ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring + two mask patches
   extern int g_q2c_ablation;
   auto kern = g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
-             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 8 ? q2c_persist_kernel<T, 8, true> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
+             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 11 ? q2c_persist_kernel<T, 11, true> : g_q2c_ablation == 10 ? q2c_persist_kernel<T, 10, true> : g_q2c_ablation == 8 ? q2c_persist_kernel<T, 8, true> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
                                                                                      : q2c_persist_kernel<T, 0, true>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;

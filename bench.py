@@ -121,6 +121,8 @@ def main():
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU code path even with 1 rank (testing)")
+    ap.add_argument("--sharded-rerank", action="store_true",
+                    help="N > 1: keep feat2 sharded too (phase 2 on the video's owner, four collectives per pass)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -156,6 +158,14 @@ def main():
                                        video_offset=lo, n_total=nv, l_ref=l)
     torch.cuda.synchronize()
     enc_s = time.perf_counter() - t0
+    rep_s = None
+    if world > 1 and not args.sharded_rerank:
+        # one-off: corpus-wide copy of the ConvSE-side features on every GPU (the similarity operand stays sharded):
+        # the owner of a query reranks its global top-k itself, two collectives per pass instead of four
+        t0 = time.perf_counter()
+        xdist.replicate_rerank_features(index)
+        torch.cuda.synchronize()
+        rep_s = time.perf_counter() - t0
     qf, qm = synth_queries(nq, dq, device)
 
     ev = []      # (start, end) HIP event pairs around every K6 launch of the timed region
@@ -168,7 +178,8 @@ def main():
         with torch.no_grad():
             if world == 1 and not args.force_sharded:
                 return inf.vcmr_search(model, index, qf, qm)
-            return xdist.sharded_vcmr_search(model, index, qf, qm)
+            # final lists stay on the rank that owns the query (where its NMS would run): no redundant gather
+            return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False)
 
     for _ in range(args.warmup):
         step()
@@ -208,6 +219,21 @@ def main():
             tw, ti = timed("topk_k8", lambda: inf.hip_ops.topk_rows(q2c, min(100, index.n_videos), alpha=20.0))
             st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti))
             timed("moment_k9", lambda: inf.hip_ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
+    else:       # rank 0's view of one sharded pass, collectives (and the waiting for slower ranks in them) included
+        marks = []
+
+        def mark(name):
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append((name, e))
+        dist.barrier()
+        torch.cuda.synchronize()
+        xdist.STAGE_MARK = mark
+        step()
+        xdist.STAGE_MARK = None
+        torch.cuda.synchronize()
+        for (_, e0), (name, e1) in zip(marks, marks[1:]):
+            breakdown[name] = round(e0.elapsed_time(e1), 3)
 
     traffic = None      # fabric/HBM bytes per K6 launch from the committed PMC passes (same command, same shape)
     tpath = os.path.join(ROOT, "profiles", "r01_k6_traffic.json")
@@ -223,7 +249,10 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtname, "data": "synthetic",
             "config": {"workload": "%s: XML %s ConvSE VCMR, %d queries x %d videos x %d clips, H=%d, top-100 videos, "
                                    "top-200 moments" % (args.workload, ctx_mode, nq, nv, l, hidden),
-                       "global_batch": nq, "parallelism": "corpus-shard x%d" % world, "videos_per_gpu": index.n_videos},
+                       "global_batch": nq, "parallelism": "corpus-shard x%d" % world, "videos_per_gpu": index.n_videos,
+                       "result_placement": "all on the GPU" if world == 1 else "final lists on the query's owner rank",
+                       "rerank": "local" if world == 1 else ("video owner (feat2 sharded)" if args.sharded_rerank else
+                                                             "query owner (feat2 replicated, feat1 sharded)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtname], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[dtname], "traffic": traffic,
                          "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
@@ -234,7 +263,7 @@ def main():
                          "launches_timed": len(k6_ms), "avg_launch_ms": k6_avg_ms,
                          "flops_per_launch": flops_per_launch},
             "encode_videos_per_s": (hi - lo) * world / enc_s if enc_s > 0 else None,
-            "corpus_hbm_gb_per_gpu": index.hbm_bytes() / 1e9,
+            "corpus_hbm_gb_per_gpu": index.hbm_bytes() / 1e9, "replicate_feat2_s": rep_s,
             "breakdown_ms": breakdown,
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -36,8 +36,16 @@ def main():
             qf, qm = T(d["query_feat"]), T(d["query_mask"])
             want = inf.vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50)
             got = xd.sharded_vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50)
+            own = xd.sharded_vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50, gather_results=False)
+            xd.replicate_rerank_features(index)       # owner rerank: all-gather of feat2 / masks, 2-collective pass
+            assert index.feat2_all["video"].data_ptr() != index.feat2["video"].data_ptr()
+            got2 = xd.sharded_vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50)
+            own2 = xd.sharded_vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50, gather_results=False)
         for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"):
             assert torch.equal(got[k], want[k]), (str(dtype), k)
+            assert torch.equal(own[k], want[k]), (str(dtype), k, "owner slice")      # world 1: the slice is everything
+            assert torch.equal(got2[k], want[k]), (str(dtype), k, "owner rerank")
+            assert torch.equal(own2[k], want[k]), (str(dtype), k, "owner rerank, owner slice")
 
     class Holder(object):
         pass

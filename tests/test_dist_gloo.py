@@ -1,6 +1,7 @@
 """world_size-2 `gloo` tests of the corpus-sharded VCMR orchestration (tvretrieval_amd.dist) on CPU.
 The device kernels are replaced by tests/cpu_backend.py (oracle formulation); what is under test is the host
-logic: shard arithmetic, sharded query encoding, the exact two-phase all-gather merge."""
+logic: shard arithmetic, sharded query encoding, the exact two-phase merge partitioned by query owner
+(all-to-all + all-gather)."""
 import os
 import socket
 
@@ -52,15 +53,40 @@ def _worker(rank, world, port, name, kvid, nbefore, ret):
         index = _make_index(model, d, lo, hi, n_total, l_ref, bs=n_total)
         qf, qm = torch.from_numpy(d["query_feat"]), torch.from_numpy(d["query_mask"])
         out = xd.sharded_vcmr_search(model, index, qf, qm, max_vcmr_video=kvid, max_before_nms=nbefore, ops=CpuOps)
+        mine = xd.sharded_vcmr_search(model, index, qf, qm, max_vcmr_video=kvid, max_before_nms=nbefore, ops=CpuOps,
+                                      gather_results=False)      # final lists only for the queries this rank owns
+        q_lo, q_hi = mine["query_range"]
+        assert (q_lo, q_hi) == xd.query_slice(qf.shape[0], rank, world)[:2]
+        slice_ok = all(torch.equal(mine[k], out[k][q_lo:q_hi]) for k in ("flat_scores", "flat_indices")) and \
+            all(torch.equal(mine[k], out[k]) for k in ("top_scores", "top_indices"))
+        # owner rerank: corpus-wide feat2 copy, phase 2 on the query's owner (two collectives per pass)
+        xd.replicate_rerank_features(index)
+        assert index.feat2_all[index.modalities[0]].shape[0] == n_total
+        out2 = xd.sharded_vcmr_search(model, index, qf, qm, max_vcmr_video=kvid, max_before_nms=nbefore, ops=CpuOps)
+        mine2 = xd.sharded_vcmr_search(model, index, qf, qm, max_vcmr_video=kvid, max_before_nms=nbefore, ops=CpuOps,
+                                       gather_results=False)
+        slice_ok = slice_ok and mine2["query_range"] == (q_lo, q_hi) and \
+            all(torch.equal(mine2[k], out2[k][q_lo:q_hi])
+                for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"))
+        flags = [None] * world
+        dist.all_gather_object(flags, bool(slice_ok))
         if rank == 0:
             full = _make_index(model, d, 0, n_total, n_total, l_ref, bs=n_total)
             want = inf.vcmr_search(model, full, qf, qm, max_vcmr_video=kvid, max_before_nms=nbefore, ops=CpuOps)
-            ok = True
-            for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"):
-                same = torch.equal(out[k], want[k])
-                ok = ok and same
-                if not same:
-                    print(k, "differs", (out[k] != want[k]).sum().item())
+            ok = all(flags)
+            for tag, got in (("sharded rerank", out), ("owner rerank", out2)):
+                assert got["query_range"] == (0, qf.shape[0])
+                for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"):
+                    same = torch.equal(got[k], want[k])
+                    if not same and k.endswith("scores"):
+                        # the CPU stand-in's BLAS rounds differently for different batch shapes (the HIP kernels are
+                        # per-video / per-query and shape-independent: tests/test_gpu_dist.py asserts bit equality);
+                        # what is under test here is the merge logic
+                        same = torch.allclose(got[k], want[k], rtol=2e-5, atol=0)
+                    ok = ok and same
+                    if not same:
+                        print(tag, k, "differs", (got[k] != want[k]).sum().item(),
+                              (got[k].double() - want[k].double()).abs().max().item())
             # and the single-GPU path itself reproduces the reference's golden tail
             alpha, gk, mn, mx, gn = d["tail_params"]
             if int(gk) == kvid and int(gn) == nbefore:
@@ -74,11 +100,13 @@ def _worker(rank, world, port, name, kvid, nbefore, ret):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("name,kvid,nbefore", [("xml_video_sub_cross_h128", 5, 60), ("xml_video_sub_cross_h128", 7, 90),
-                                                ("xml_video_only_h256", 4, 40),
-                                                ("xml_video_sub_nocross_nomerge_h128", 3, 30)])
-def test_sharded_equals_single_gloo(name, kvid, nbefore):
-    world = 2
+@pytest.mark.parametrize("name,kvid,nbefore,world", [("xml_video_sub_cross_h128", 5, 60, 2),
+                                                      ("xml_video_sub_cross_h128", 7, 90, 2),
+                                                      ("xml_video_only_h256", 4, 40, 2),
+                                                      ("xml_video_sub_nocross_nomerge_h128", 3, 30, 2),
+                                                      ("xml_video_sub_cross_h128", 5, 60, 3),      # ragged query slices
+                                                      ("xml_video_only_h256", 4, 40, 4)])          # an empty slice
+def test_sharded_equals_single_gloo(name, kvid, nbefore, world):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
     port = _free_port()

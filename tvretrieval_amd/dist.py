@@ -4,18 +4,30 @@ xGMI on ROCm; "gloo" in the CPU tests).
 The reference has no distributed path at all (its nn.DataParallel wrapper is dead code).
 Videos are independent units, so the corpus is partitioned by contiguous video ranges and every per-(query, video)
 quantity is computed locally.  One exchange is NOT enough for exact results: the reference keeps only moments of
-the GLOBAL top-k videos of each query (xml/inference.py:347-348,365-367).  Exact two-phase scheme:
+the GLOBAL top-k videos of each query (xml/inference.py:347-348,365-367).  Exact two-phase scheme,
+with the merges partitioned by QUERY OWNER (rank r owns the contiguous query slice r: it encodes those queries and
+merges their candidate lists), so that no rank receives or merges a list it does not need:
 
-  phase 1  local K6 + local top-k  ->  all-gather (score f32, global video id i32)  ->  identical global top-k
-           on every rank (same kernel, same tie rule: score desc, video id asc);
+  phase 0  each rank encodes its query slice  ->  all-gather of the modular query vectors (both modalities, one call);
+  phase 1  local K6 + local top-k for ALL queries  ->  all-to-all (score f32, global video id i32: the rows of slice r
+           go to rank r)  ->  the owner merges P lists into the global top-k (same kernel, same tie rule: score desc,
+           video id asc)  ->  all-gather of the merged (weight, video id) rows: every rank knows the global top-k;
   phase 2  each rank runs ConvSE + banded moment top-n only for the global top-k videos it owns (slots of videos
            owned elsewhere are skipped), with flat indices expressed in the GLOBAL slot order
-           ->  all-gather (score f32, flat i32)  ->  top-n merge (score desc, flat asc).
+           ->  all-to-all (score f32, flat i32) by query owner  ->  top-n merge (score desc, flat asc) on the owner.
 
 Candidate sets of different ranks are disjoint and their union is the single-GPU candidate set, so the merged
-lists equal the single-GPU lists.  Query encoding is sharded too (each rank encodes Nq/P queries, all-gather of the
-modular vectors).  Collectives carry Nq*k*8 B and Nq*n*8 B per rank (8 MB + 16 MB at Nq=10 K): issue them per
->= 1 K queries so they are bandwidth- not latency-bound on the point-to-point xGMI links.
+lists equal the single-GPU lists.  The final lists of a query live on its owner rank (where the per-query temporal NMS
+runs); `gather_results=True` adds one all-gather so that every rank holds all of them.
+
+Owner rerank (replicate_rerank_features): the similarity operand feat1n stays sharded, but the ConvSE-side features
+feat2 (4.3 GB per modality at TVR scale) fit on every 288 GB GPU many times over.  With a corpus-wide copy resident,
+phase 2 needs no exchange at all: the owner of a query runs K7 + K9 for its slice over the global top-k it has just
+merged.  Two collectives per pass (query vectors, local top-k) instead of four, K7 / K9 work exactly 1/P of the
+single-GPU work, and the result is computed by the same kernels on the same inputs as the single-GPU pass.
+Per rank and pass a rank RECEIVES Nq*(2*H*2 + 2*k*8 + n*8) bytes (31 + 16 + 16 MB at Nq = 10 K, H = 768, k = 100,
+n = 200) in 4 collectives; the earlier all-gather-everything scheme received 31 + 64 + 128 MB in 6 and merged every
+query's lists on every rank.
 """
 import torch
 import torch.distributed as dist
@@ -28,6 +40,15 @@ from . import ops as hip_ops
 # through a single-rank group, which is all a 1-GPU box can exercise
 SKIP_TRIVIAL_COLLECTIVES = True
 
+# optional stage-boundary callback f(name) (bench.py records a HIP event per call to split a pass into stages,
+# collectives included); None in normal operation
+STAGE_MARK = None
+
+
+def _mark(name):
+    if STAGE_MARK is not None:
+        STAGE_MARK(name)
+
 
 def shard_range(n_total, rank, world, align=1):
     """Contiguous, balanced [lo, hi) of `n_total` items for `rank`; boundaries multiples of `align`."""
@@ -38,81 +59,200 @@ def shard_range(n_total, rank, world, align=1):
     return min(lo_b * align, n_total), min(hi_b * align, n_total)
 
 
-def _all_gather_cat(t, group, world):
-    """all-gather equal-shaped (Nq, k) tensors and lay them out as (Nq, world*k)."""
-    if world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized()):
-        return t
-    t = t.contiguous()
-    out = torch.empty((world * t.shape[0], t.shape[1]), dtype=t.dtype, device=t.device)   # rank-major concat
-    dist.all_gather_into_tensor(out, t, group=group)
-    return out.view(world, t.shape[0], t.shape[1]).permute(1, 0, 2).reshape(t.shape[0], world * t.shape[1]).contiguous()
+def query_slice(nq, rank, world):
+    """[lo, hi) of the queries owned by `rank` and the (uniform) slice length `per` used for padding."""
+    per = (nq + world - 1) // world
+    lo = min(rank * per, nq)
+    return lo, min(lo + per, nq), per
 
 
-def _all_gather_rows(t, group, world):
-    """all-gather equal-shaped (n, H) row blocks into (world*n, H)."""
-    if world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized()):
-        return t
-    t = t.contiguous()
-    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t, group=group)
-    return out
+def _trivial(world):
+    return world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized())
+
+
+def _pack_rows(score, idx, rows, pad_score, pad_idx):
+    """(n, c) f32 scores + (n, c) i32 ids -> one (rows, 2, c) i32 buffer (score bits in [:, 0]); rows >= n are padding."""
+    n, c = score.shape
+    buf = torch.empty((rows, 2, c), dtype=torch.int32, device=score.device)
+    buf[:n, 0] = score.contiguous().view(torch.int32)
+    buf[:n, 1] = idx
+    if rows > n:
+        buf[n:, 0] = torch.tensor(pad_score, dtype=torch.float32).view(torch.int32).item()
+        buf[n:, 1] = pad_idx
+    return buf
+
+
+def _exchange_by_owner(buf, group, world, per):
+    """buf (world*per, 2, c): rows of slice r go to rank r.  Returns the candidates of MY slice from every rank as
+    (score (per, world*c) f32, ids (per, world*c) i32), source-rank-major within a row."""
+    c = buf.shape[2]
+    out = torch.empty_like(buf)
+    dist.all_to_all_single(out, buf, group=group)
+    cand = out.view(world, per, 2, c).permute(2, 1, 0, 3).contiguous()          # (2, per, world, c)
+    return cand[0].reshape(per, world * c).view(torch.float32), cand[1].reshape(per, world * c)
+
+
+def _all_gather_packed(score, idx, group, world, nq, per):
+    """all-gather (<= per, c) f32 + i32 rows of every owner -> (nq, c) f32, (nq, c) i32 on every rank."""
+    buf = _pack_rows(score, idx, per, 0.0, -1)
+    out = torch.empty((world * per,) + tuple(buf.shape[1:]), dtype=torch.int32, device=buf.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return out[:nq, 0].contiguous().view(torch.float32), out[:nq, 1].contiguous()
+
+
+def replicate_rerank_features(index, group=None):
+    """One-off, after the shard is encoded: all-gather the ConvSE-side context features (feat2) and clip masks of
+    every shard into corpus-wide copies index.feat2_all[m] (n_total, lpad, H) / index.mask_all[m] (n_total, lpad).
+    The similarity operand feat1n -- the 85 % of the pass -- stays sharded.  With the copies resident, the owner of a
+    query reranks its global top-k videos itself (sharded_vcmr_search, owner_rerank): the second exchange and the
+    broadcast of the global top-k disappear.  Costs n_total*lpad*H*2 B per modality and GPU (4.3 GB at TVR scale,
+    of 288 GB)."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if _trivial(world):
+        index.feat2_all, index.mask_all = index.feat2, index.mask
+        return index
+    dev = index.device
+    meta = torch.tensor([index.video_offset, index.n_videos], dtype=torch.int64, device=dev)
+    metas = torch.empty((world * 2,), dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(metas, meta, group=group)
+    metas = metas.view(world, 2).cpu().tolist()
+    n_max = max(n for _, n in metas)
+    feat2_all, mask_all = {}, {}
+    for m in index.modalities:
+        for src, dst in ((index.feat2[m], feat2_all), (index.mask[m], mask_all)):
+            pad = src.new_zeros((n_max,) + tuple(src.shape[1:]))
+            pad[:src.shape[0]] = src
+            out = src.new_empty((world * n_max,) + tuple(src.shape[1:]))
+            dist.all_gather_into_tensor(out, pad, group=group)
+            full = src.new_empty((index.n_total,) + tuple(src.shape[1:]))
+            for r, (off, n) in enumerate(metas):
+                full[off:off + n] = out[r * n_max:r * n_max + n]
+            dst[m] = full
+            del pad, out
+    index.feat2_all, index.mask_all = feat2_all, mask_all
+    return index
 
 
 def encode_queries_sharded(model, query_feat, query_mask, group=None):
-    """Each rank encodes a contiguous 1/P slice of the (replicated) raw queries; all-gather the modular vectors."""
+    """Each rank encodes its contiguous 1/P slice of the (replicated) raw queries; ONE all-gather carries the modular
+    vectors of all modalities."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
-    if world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized()):
+    if _trivial(world):
         return inf.stage_query_vectors(model, query_feat, query_mask)
     nq = query_feat.shape[0]
-    per = (nq + world - 1) // world
-    lo, hi = min(rank * per, nq), min((rank + 1) * per, nq)
-    out = {}
+    lo, hi, per = query_slice(nq, rank, world)
     if hi > lo:
         local = inf.stage_query_vectors(model, query_feat[lo:hi].contiguous(), query_mask[lo:hi].contiguous())
     else:   # more ranks than queries: encode one dummy row to keep shapes
         local = inf.stage_query_vectors(model, query_feat[:1].contiguous(), query_mask[:1].contiguous())
-    for m, v in local.items():
-        buf = v.new_zeros((per, v.shape[1]))
-        if hi > lo:
-            buf[:hi - lo] = v
-        out[m] = _all_gather_rows(buf, group, world)[:nq].contiguous()
-    return out
+    names = sorted(local)
+    v0 = local[names[0]]
+    hdim = v0.shape[1]
+    buf = v0.new_zeros((per, len(names), hdim))
+    if hi > lo:
+        for j, m in enumerate(names):
+            buf[:hi - lo, j] = local[m]
+    out = torch.empty((world * per, len(names), hdim), dtype=buf.dtype, device=buf.device)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    return {m: out[:nq, j].contiguous() for j, m in enumerate(names)}
+
+
+def _owner_rerank(model, index, qvec, own_w, own_gid, q2c, nq, q_lo, q_hi, per, n_out, min_pred_l, max_pred_l, group,
+                  world, ops, gather_results):
+    """Phase 2 on the query's owner: K7 + K9 for my query slice over its global top-k videos (global ids into the
+    corpus-wide feat2 copy).  Same kernels, same inputs as the single-GPU pass for these rows."""
+    n_own = q_hi - q_lo
+    k = own_w.shape[1]
+    if n_own > 0:
+        qv = {m: v[q_lo:q_hi] for m, v in qvec.items()}
+        top_w, top_gid = own_w[:n_own].contiguous(), own_gid[:n_own].contiguous()
+        st, ed = inf.stage_span_probs(model, index, qv, top_gid, ops, replicated=True)
+        _mark("convse_k7")
+        fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, n_out)
+        _mark("moment_k9")
+    else:   # more ranks than queries
+        top_w, top_gid = own_w[:0], own_gid[:0]
+        fs, fi = own_w.new_zeros((0, n_out)), own_gid.new_full((0, n_out), -1)
+    if gather_results:
+        top_w, top_gid = _all_gather_packed(top_w, top_gid, group, world, nq, per)
+        fs, fi = _all_gather_packed(fs, fi, group, world, nq, per)
+        q_lo, q_hi = 0, nq
+    return dict(top_scores=top_w, top_indices=top_gid, flat_scores=fs, flat_indices=fi, q2c_local=q2c,
+                query_range=(q_lo, q_hi))
 
 
 def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200,
-                        q2c_alpha=20.0, min_pred_l=2, max_pred_l=16, group=None, ops=hip_ops, qvec=None):
+                        q2c_alpha=20.0, min_pred_l=2, max_pred_l=16, group=None, ops=hip_ops, qvec=None,
+                        gather_results=True, owner_rerank=None):
     """Exact corpus-sharded counterpart of inference.vcmr_search.  `index` is this rank's CorpusIndex
-    (index.video_offset = global id of its first video, index.n_total = corpus size).  Every rank returns the same
-    global result: top_scores/top_indices (Nq, k) with GLOBAL video ids, flat_scores/flat_indices (Nq, n)."""
+    (index.video_offset = global id of its first video, index.n_total = corpus size).
+    Returns top_scores/top_indices (., k) with GLOBAL video ids and flat_scores/flat_indices (., n): all Nq rows on
+    every rank with gather_results=True, else the rows [query_range) this rank owns (sharded rerank: top_* are known
+    everywhere and always complete).
+    owner_rerank (default: whenever replicate_rerank_features(index) was called): phase 2 runs on the query's owner
+    against the corpus-wide feat2 copy -- two collectives per pass instead of four."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    _mark("start")
     if qvec is None:
         qvec = encode_queries_sharded(model, query_feat, query_mask, group)
+    _mark("query_encode+allgather")
+    nq = next(iter(qvec.values())).shape[0]
     k = min(max_vcmr_video, index.n_total)
+    q_lo, q_hi, per = query_slice(nq, rank, world)
+    trivial = _trivial(world)
+    if owner_rerank is None:
+        owner_rerank = index.feat2_all is not None
+    assert not owner_rerank or index.feat2_all is not None, "call replicate_rerank_features(index) first"
     # ---- phase 1: global top-k videos ------------------------------------------------------------------
     q2c = inf.stage_q2c(index, qvec, ops)
+    _mark("q2c_k6")
     k_loc = min(k, index.n_videos)
-    loc_s, loc_i = ops.topk_rows(q2c, k_loc, alpha=0.0)
-    loc_i = loc_i + index.video_offset
-    if k_loc < k:       # tiny shard: pad with -inf so that every rank contributes k slots
-        pad_s = loc_s.new_full((loc_s.shape[0], k - k_loc), float("-inf"))
-        pad_i = loc_i.new_full((loc_i.shape[0], k - k_loc), 2 ** 31 - 1)
-        loc_s, loc_i = torch.cat([loc_s, pad_s], 1), torch.cat([loc_i, pad_i], 1)
-    all_s = _all_gather_cat(loc_s, group, world)
-    all_i = _all_gather_cat(loc_i, group, world)
-    top_w, top_gid = ops.topk_rows(all_s, k, alpha=q2c_alpha, idx_in=all_i)
+    if trivial:
+        top_w, top_gid = ops.topk_rows(q2c, k, alpha=q2c_alpha)
+        top_gid = top_gid + index.video_offset
+        _mark("topk_k8")
+    else:
+        loc_s, loc_i = ops.topk_rows(q2c, k_loc, alpha=0.0)
+        loc_i = loc_i + index.video_offset
+        if k_loc < k:       # tiny shard: pad with -inf so that every rank contributes k slots
+            pad_s = loc_s.new_full((loc_s.shape[0], k - k_loc), float("-inf"))
+            pad_i = loc_i.new_full((loc_i.shape[0], k - k_loc), 2 ** 31 - 1)
+            loc_s, loc_i = torch.cat([loc_s, pad_s], 1), torch.cat([loc_i, pad_i], 1)
+        _mark("topk_local_k8")
+        cand_s, cand_i = _exchange_by_owner(_pack_rows(loc_s, loc_i, world * per, float("-inf"), 2 ** 31 - 1),
+                                            group, world, per)
+        _mark("alltoall_topk")
+        own_w, own_gid = ops.topk_rows(cand_s, k, alpha=q2c_alpha, idx_in=cand_i)       # my slice: global top-k
+        _mark("merge_topk_k8")
+        if owner_rerank:
+            return _owner_rerank(model, index, qvec, own_w, own_gid, q2c, nq, q_lo, q_hi, per, max_before_nms,
+                                 min_pred_l, max_pred_l, group, world, ops, gather_results)
+        top_w, top_gid = _all_gather_packed(own_w, own_gid, group, world, nq, per)
+        _mark("allgather_topk")
     # ---- phase 2: moments of the global top-k videos this rank owns -------------------------------------
     lo, hi = index.video_offset, index.video_offset + index.n_videos
     own = (top_gid >= lo) & (top_gid < hi)
     pair_local = torch.where(own, top_gid - lo, torch.full_like(top_gid, -1)).contiguous()
     st, ed = inf.stage_span_probs(model, index, qvec, pair_local, ops, zero_skipped=False)   # K9 skips w == 0 pairs
+    _mark("convse_k7")
     w_local = torch.where(own, top_w, torch.zeros_like(top_w)).contiguous()   # w == 0 marks slots owned elsewhere:
     loc_fs, loc_fi = ops.moment_topk(st, ed, w_local, index.l_ref, min_pred_l, max_pred_l, max_before_nms)  # skipped
-    all_fs = _all_gather_cat(loc_fs, group, world)
-    all_fi = _all_gather_cat(loc_fi, group, world)
-    if world == 1 and (SKIP_TRIVIAL_COLLECTIVES or not dist.is_initialized()):
+    _mark("moment_k9")
+    if trivial:
         fs, fi = loc_fs, loc_fi
     else:
-        fs, fi = ops.topk_rows(all_fs, max_before_nms, alpha=0.0, idx_in=all_fi)
+        cand_s, cand_i = _exchange_by_owner(_pack_rows(loc_fs, loc_fi, world * per, 0.0, -1), group, world, per)
+        _mark("alltoall_moments")
+        fs, fi = ops.topk_rows(cand_s, max_before_nms, alpha=0.0, idx_in=cand_i)
         fi = torch.where(fs > 0, fi, torch.full_like(fi, -1))
-    return dict(top_scores=top_w, top_indices=top_gid, flat_scores=fs, flat_indices=fi, q2c_local=q2c)
+        _mark("merge_moments_k8")
+        if gather_results:
+            fs, fi = _all_gather_packed(fs, fi, group, world, nq, per)
+        else:
+            fs, fi = fs[:q_hi - q_lo], fi[:q_hi - q_lo]
+    if trivial or gather_results:
+        q_lo, q_hi = 0, nq
+    return dict(top_scores=top_w, top_indices=top_gid, flat_scores=fs, flat_indices=fi, q2c_local=q2c,
+                query_range=(q_lo, q_hi))

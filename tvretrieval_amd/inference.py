@@ -41,6 +41,7 @@ class CorpusIndex(object):
         self.n_videos = int(feat2[self.modalities[0]].shape[0])
         self.video_offset = int(video_offset)
         self.n_total = int(n_total if n_total is not None else self.n_videos)
+        self.feat2_all = self.mask_all = None      # corpus-wide copies of feat2 / mask (dist.replicate_rerank_features)
 
     @property
     def device(self):
@@ -48,7 +49,7 @@ class CorpusIndex(object):
 
     def hbm_bytes(self):
         tot = 0
-        for d in (self.feat1n, self.feat2, self.mask):
+        for d in (self.feat1n, self.feat2, self.mask, self.feat2_all or {}, self.mask_all or {}):
             for t in d.values():
                 tot += t.numel() * t.element_size()
         return tot
@@ -173,12 +174,15 @@ def stage_q2c(index, qvec, ops=hip_ops):
     return q2c
 
 
-def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=True):
-    """K7 on the listed (query, local video) pairs -> softmaxed st / ed (Nq, K, lpad)."""
+def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=True, replicated=False):
+    """K7 on the listed (query, local video) pairs -> softmaxed st / ed (Nq, K, lpad).
+    replicated=True: pair_vid holds GLOBAL video ids into the corpus-wide copies index.feat2_all / index.mask_all
+    (tvretrieval_amd.dist.replicate_rerank_features)."""
     mods = index.modalities
     q_lin = [getattr(model, m + "_query_linear")(qvec[m].contiguous()) for m in mods]
     merged = bool(model.config.merge_two_stream and len(mods) == 2)
-    return ops.convse_rerank(q_lin, [index.feat2[m] for m in mods], [index.mask[m] for m in mods], pair_vid,
+    feat2, mask = (index.feat2_all, index.mask_all) if replicated else (index.feat2, index.mask)
+    return ops.convse_rerank(q_lin, [feat2[m] for m in mods], [mask[m] for m in mods], pair_vid,
                              model._conv_weights(), index.l_ref, merged, model.config.conv_kernel_size, softmax=True,
                              zero_skipped=zero_skipped)
 

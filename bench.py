@@ -86,7 +86,7 @@ def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name):
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     om = O.OracleXML(cfg, sd)
     mods = index.modalities
-    f1 = {m: index.feat1n[m][:nv_s, :index.l_ref].float().cpu() for m in mods}
+    f1 = {m: index.feat1n_rows(m)[:nv_s, :index.l_ref].float().cpu() for m in mods}
     f2 = {m: index.feat2[m][:nv_s, :index.l_ref].float().cpu() for m in mods}
     mk = {m: index.mask[m][:nv_s, :index.l_ref].float().cpu() for m in mods}
     q, qmask = qf[:nq_s].float().cpu(), qm[:nq_s].float().cpu()
@@ -132,13 +132,17 @@ def main():
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_sharded      # --force-sharded: the N > 1 code path through a real 1-rank RCCL group
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     from tvretrieval_amd import inference as inf
     from tvretrieval_amd import dist as xdist
     from tvretrieval_amd.model_xml import XML
+    if args.force_sharded and world == 1:
+        xdist.SKIP_TRIVIAL_COLLECTIVES = False
 
     nq, nv, l, hidden, dv, ds, dq, ctx_mode, dtname = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if dtname == "bf16" else torch.float32
@@ -159,7 +163,7 @@ def main():
     torch.cuda.synchronize()
     enc_s = time.perf_counter() - t0
     rep_s = None
-    if world > 1 and not args.sharded_rerank:
+    if multi and not args.sharded_rerank:
         # one-off: corpus-wide copy of the ConvSE-side features on every GPU (the similarity operand stays sharded):
         # the owner of a query reranks its global top-k itself, two collectives per pass instead of four
         t0 = time.perf_counter()
@@ -176,7 +180,7 @@ def main():
 
     def step():
         with torch.no_grad():
-            if world == 1 and not args.force_sharded:
+            if not multi:
                 return inf.vcmr_search(model, index, qf, qm)
             # final lists stay on the rank that owns the query (where its NMS would run): no redundant gather
             return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False)
@@ -184,18 +188,18 @@ def main():
     for _ in range(args.warmup):
         step()
     inf.K6_TIMER = k6_timer
-    if world > 1:
+    if multi:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     inf.K6_TIMER = None
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -207,7 +211,7 @@ def main():
 
     # ---- stage breakdown, one extra untimed step --------------------------------------------------------
     breakdown = {}
-    if world == 1:
+    if not multi:
         def timed(name, fn):
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record(); r = fn(); e.record(); torch.cuda.synchronize()
@@ -250,8 +254,8 @@ def main():
             "config": {"workload": "%s: XML %s ConvSE VCMR, %d queries x %d videos x %d clips, H=%d, top-100 videos, "
                                    "top-200 moments" % (args.workload, ctx_mode, nq, nv, l, hidden),
                        "global_batch": nq, "parallelism": "corpus-shard x%d" % world, "videos_per_gpu": index.n_videos,
-                       "result_placement": "all on the GPU" if world == 1 else "final lists on the query's owner rank",
-                       "rerank": "local" if world == 1 else ("video owner (feat2 sharded)" if args.sharded_rerank else
+                       "result_placement": "all on the GPU" if not multi else "final lists on the query's owner rank",
+                       "rerank": "local" if not multi else ("video owner (feat2 sharded)" if args.sharded_rerank else
                                                              "query owner (feat2 replicated, feat1 sharded)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtname], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[dtname], "traffic": traffic,
@@ -270,8 +274,14 @@ def main():
             res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname)
         else:
             res["cpu_baseline"] = None
+    if multi:       # RCCL's start-up banner sits in the C stdio buffer of every rank: push it out BEFORE the result line,
+        import ctypes    # so that the JSON line is the last thing this job prints
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        dist.barrier()
+    if rank == 0:
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return res

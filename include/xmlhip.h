@@ -143,6 +143,23 @@ int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0, const floa
                          const void* cn1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
                          int lpad, int hidden, int dt, xml_stream_t stream);
 
+/* Slice-major operand tiles for K6 (a private layout of the resident index: the reference has no counterpart, it
+ * re-normalises and re-reads row-major video_feat1 for every query batch, xml/model_xml.py:446-448).
+ *   xml_q2c_tile_rows: src (rows, hidden) row-major  ->  dst [row / 256][byte / 64][row % 256][64 B]; rows beyond
+ *     `rows` are zero; dst holds xml_q2c_tiled_bytes(rows, hidden, dt) bytes.  A 256-row tile keeps its byte offset
+ *     (256 * hidden * sizeof(dt) per tile), inside it every 64-byte K slice of all 256 rows is contiguous (16 KiB) =
+ *     the LDS image the persistent kernel streams: every DMA piece is 1 KiB contiguous and every 128-byte line is
+ *     requested once instead of twice.
+ *   xml_q2c_scores_tiled: xml_q2c_scores_fused on tiled operands: qt_m = tiles of qn[m] (nq, hidden),
+ *     ct_m = tiles of cn[m] viewed as (nv * 128, hidden).  Same arithmetic, same summation order: bitwise the same
+ *     scores.  Requires xml_q2c_tiled_ok(lpad, hidden, dt) (lpad == 128, hidden * sizeof(dt) % 128 == 0, >= 384). */
+int xml_q2c_tiled_ok(int lpad, int hidden, int dt);
+int64_t xml_q2c_tiled_bytes(int64_t rows, int hidden, int dt);
+int xml_q2c_tile_rows(const void* src, void* dst, int64_t rows, int hidden, int dt, xml_stream_t stream);
+int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0, const float* mask0, const void* qt1,
+                         const void* ct1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
+                         int lpad, int hidden, int dt, xml_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K8: per-row top-k, torch.topk(exp(alpha*s), k) (xml/inference.py:317,347-348)
  *   scores (rows, n) f32 row stride ld; optional idx_in (rows, n) int32 payload (NULL: column index)

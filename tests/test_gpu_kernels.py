@@ -217,6 +217,34 @@ def test_q2c_fused(ops, dtype, shape, n_mod):
     close("q2c fused", got, want, 1e-5)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(700, 37, 768), (300, 2, 256), (1, 1, 128), (520, 1030, 192), (2600, 65, 768)])
+@pytest.mark.parametrize("n_mod", [1, 2])
+def test_q2c_tiled_equals_row_major(ops, dtype, shape, n_mod):
+    """slice-major operand tiles (the resident index layout) vs row-major operands: the same kernel with a different
+    source addressing -> bitwise the same scores; tile -> rows round trip is the identity."""
+    nq, nv, h = shape
+    if h * (2 if dtype == torch.bfloat16 else 4) < 384:
+        pytest.skip("below the persistent kernel's minimum K")
+    qs = [dev(_normed(nq, h, seed=280 + m), dtype) for m in range(n_mod)]
+    cs = [dev(_normed(nv, 128, h, seed=290 + m), dtype) for m in range(n_mod)]
+    masks = [dev(_ragged_mask(nv, 128, 300 + m)) for m in range(n_mod)]
+    assert ops.q2c_tiled_ok(128, h, dtype)
+    want = ops.q2c_scores_fused(qs, cs, masks)
+    tiles = [ops.pack_q2c_corpus(c) for c in cs]
+    assert all(isinstance(t, ops.TiledRows) for t in tiles)
+    for t, c in zip(tiles, cs):
+        assert torch.equal(t.to_rows(), c)
+        assert t.numel() == (nv * 128 + 255) // 256 * 256 * h
+    out = torch.full((nq, nv), float("nan"), device=DEV)
+    got = ops.q2c_scores_fused(qs, tiles, masks, out=out)
+    assert torch.equal(got, want)
+    # padding rows of the last tile are zero (an odd number of videos leaves half a tile)
+    flat = tiles[0].data.view(-1, h // (64 // tiles[0].element_size()), 256, 64 // tiles[0].element_size())
+    if (nv * 128) % 256:
+        assert float(flat[-1, :, 128:].float().abs().max()) == 0.0
+
+
 def test_q2c_fused_full_scale_property(ops):
     """BASELINE-size property check (10 000 x 21 793 x 128 x 768 bf16, both modalities): every output element is
     written, and random (query, video) samples equal an fp32 recomputation; max over clips of a cosine of
@@ -234,7 +262,7 @@ def test_q2c_fused_full_scale_property(ops):
     lens = torch.randint(1, 129, (nv,), device=DEV, generator=g)
     mask = (torch.arange(128, device=DEV)[None] < lens[:, None]).float().contiguous()
     out = torch.full((nq, nv), float("nan"), device=DEV)
-    ops.q2c_scores_fused(qs, cs, [mask, mask], out=out)
+    ops.q2c_scores_fused(qs, [ops.pack_q2c_corpus(c) for c in cs], [mask, mask], out=out)   # the index's tiled layout
     assert not torch.isnan(out).any()
     assert float(out.max()) <= 1.0 + 1e-3 and float(out.min()) >= -1.0 - 1e-3
     qi = torch.randint(0, nq, (64,), device=DEV, generator=g)

@@ -408,12 +408,13 @@ def test_full_scale_c3_pipeline_properties():
     assert torch.equal(tw2, tw) and bool((pos2.long() == torch.arange(100, device=DEV)[None]).all())   # idempotent
     g = torch.Generator().manual_seed(1)
     qs = torch.randint(0, nq, (6,), generator=g).tolist()
+    f1rows = {mod: index.feat1n_rows(mod) for mod in index.modalities}   # un-tiled K6 operand
     for q in qs:                                                     # sampled exact recomputation, fp32 on the GPU
         vs = ti[q, :8]
         want = 0
         for mod in index.modalities:
             qn = torch.nn.functional.normalize(qvec[mod][q].float(), dim=-1)
-            c = index.feat1n[mod][vs].float()
+            c = f1rows[mod][vs].float()
             want = want + torch.einsum("d,vld->vl", qn, c).max(1)[0]
         want = want / len(index.modalities)
         # bf16 operands (incl. the normalised query rounded to bf16 inside the kernel path): 3 significant digits

@@ -140,7 +140,7 @@ __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3
 //
 //   No wave-group stagger and no s_setprio: the two waves of a SIMD drift apart by themselves and keep the MFMA
 //   pipe busy from either wave's ready cluster.
-template <typename T, int ABL = 0, bool PHASED = true>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
+template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
 __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
@@ -166,6 +166,12 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int qt_off = (blockIdx.x >> 3) & ((1 << qsh) - 1), ct_off = blockIdx.x >> (3 + qsh);
   const int k_bytes = a.hidden * (int)sizeof(T);
   const int slices_per_seg = k_bytes / ROWB;      // even (k_bytes % 128 == 0)
+  // operand addressing.  Row-major (rows of k_bytes): a DMA piece is 16 rows x 64 B of the K slice, every 128-byte line
+  // is requested by two consecutive slices.  TILED (xml_q2c_tile_rows): a 256-row operand tile is stored slice-major,
+  // [slice][row][64 B] = the LDS image of each slice: a piece is 1 KiB contiguous and every line is requested once.
+  // Tile bases are the same byte offsets in both layouts (256 * k_bytes per tile).
+  const int row_stride = TILED ? ROWB : k_bytes;
+  constexpr int SLICE_STRIDE = TILED ? 256 * ROWB : ROWB;
   const int n_qgroups = (a.tq + (1 << qsh) - 1) >> qsh;
   const int cr = (((a.tc + (1 << csh) - 1) >> csh) + 7) >> 3;    // rounds per query group on one XCD
 
@@ -202,20 +208,20 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
           const int slot = pslot ^ swz4p(row);
           const int qrow = (q0 + row < a.nq) ? row : 0;                   // clamp to the tile's first row
           const int brow = (v0 + (row >> 7) < a.nv) ? row : (row & 127);  // second video missing: re-read the first
-          const uint32_t va = (uint32_t)qrow * k_bytes + slot * 16;
-          const uint32_t vb = (uint32_t)brow * k_bytes + slot * 16;
+          const uint32_t va = (uint32_t)qrow * row_stride + slot * 16;
+          const uint32_t vb = (uint32_t)brow * row_stride + slot * 16;
           if (i == 0) { voff_a0 = va; voff_b0 = vb; } else { voff_a1 = va; voff_b1 = vb; }
         }
       } else {
         auto off_a = [&](int piece) -> uint32_t {
           const int row = piece * 16 + rsub;
           const int qrow = (q0 + row < a.nq) ? row : 0;
-          return (uint32_t)qrow * k_bytes + (pslot ^ swz4p(row)) * 16;
+          return (uint32_t)qrow * row_stride + (pslot ^ swz4p(row)) * 16;
         };
         auto off_b = [&](int piece) -> uint32_t {
           const int row = piece * 16 + rsub;
           const int brow = (v0 + (row >> 7) < a.nv) ? row : (row & 127);
-          return (uint32_t)brow * k_bytes + (pslot ^ swz4p(row)) * 16;
+          return (uint32_t)brow * row_stride + (pslot ^ swz4p(row)) * 16;
         };
         if (grp == 0) {
           voff_a0 = off_a(wave * 4); voff_a1 = off_a(wave * 4 + 1); voff_x[0] = off_a(wave * 4 + 2); voff_x[1] = off_a(wave * 4 + 3);
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   int i_slot = 0;
   int i_left = slices_per_seg, i_inc = 1;              // slices left to issue in the current segment; slice increment
   auto issue_slice = [&]() {
-    const int koff = i_slice * ROWB;
+    const int koff = i_slice * SLICE_STRIDE;
     const uint32_t dst = lds_wave + i_slot * SLOT_BYTES;
     if (ABL != 1 || i_gs < 4) {
       if (ABL == 3) {
@@ -487,11 +493,10 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 }
 
 template <typename T>
-static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
+static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled) {
   extern int g_q2c_ablation;
   const int lds = g_q2c_ablation == 7 ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring + two mask patches
-  extern int g_q2c_ablation;
-  auto kern = g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
+  auto kern = tiled ? q2c_persist_kernel<T, 0, true, true> : g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
              : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 11 ? q2c_persist_kernel<T, 11, true> : g_q2c_ablation == 10 ? q2c_persist_kernel<T, 10, true> : g_q2c_ablation == 8 ? q2c_persist_kernel<T, 8, true> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
                                                                                      : q2c_persist_kernel<T, 0, true>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -505,7 +510,8 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st) {
 // hidden * sizeof(T) a multiple of 128 bytes (an even number of 64-byte slices) and at least 6 slices:
 // the mask patch of segment s+2 is fetched 4 slices ahead and must not land before the epilogue of segment s.
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
-                            float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st) {
+                            float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st,
+                            bool tiled) {
   Q2cPersistArgs a;
   for (int m = 0; m < 2; ++m) {
     a.qn[m] = qn[m < n_mod ? m : 0];
@@ -516,6 +522,65 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
   a.qsh = a.tq >= 5 ? 3 : a.tq >= 3 ? 2 : a.tq == 2 ? 1 : 0;     // few queries: more workgroups share a query tile
-  if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st);
-  return launch_q2c_persist<float>(a, st);
+  if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled);
+  return launch_q2c_persist<float>(a, st, tiled);
+}
+
+
+// ---- slice-major operand tiles ------------------------------------------------------------------------------------
+// (rows, k_bytes) row-major  ->  [tile = row / 256][slice = byte / 64][row % 256][64 B]; rows beyond `rows` are zero.
+// One 16-byte chunk per thread; consecutive threads write consecutive chunks of the tiled image (coalesced stores,
+// 64-byte-segment loads).
+__global__ __launch_bounds__(256) void q2c_tile_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst,
+                                                            int64_t rows, int k_bytes, int64_t n_chunks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // chunk index in the tiled image
+  if (i >= n_chunks) return;
+  const int slices = k_bytes >> 6;
+  const int c = (int)(i & 3);
+  const int r = (int)((i >> 2) & 255);
+  const int64_t ts = i >> 10;                                     // tile * slices + slice
+  const int64_t tile = ts / slices;
+  const int sl = (int)(ts - tile * slices);
+  const int64_t row = tile * 256 + r;
+  uint4 v = {0u, 0u, 0u, 0u};
+  if (row < rows) v = src[(row * k_bytes + sl * 64 + c * 16) >> 4];
+  dst[i] = v;
+}
+
+extern "C" int xml_q2c_tiled_ok(int lpad, int hidden, int dt) {
+  if (dt != XML_F32 && dt != XML_BF16) return 0;
+  const size_t kb = (size_t)hidden * dt_size(dt);
+  return lpad == 128 && kb % 128 == 0 && kb >= 384;
+}
+
+extern "C" int64_t xml_q2c_tiled_bytes(int64_t rows, int hidden, int dt) {
+  if (rows < 0 || hidden <= 0 || (dt != XML_F32 && dt != XML_BF16)) return -1;
+  return (rows + 255) / 256 * 256 * (int64_t)hidden * (int64_t)dt_size(dt);
+}
+
+extern "C" int xml_q2c_tile_rows(const void* src, void* dst, int64_t rows, int hidden, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!src || !dst || rows <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  const size_t kb = (size_t)hidden * dt_size(dt);
+  if (kb % 64) return XML_ERR_UNSUPPORTED;
+  const int64_t n_chunks = xml_q2c_tiled_bytes(rows, hidden, dt) / 16;
+  hipLaunchKernelGGL(q2c_tile_rows_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint4*)src, (uint4*)dst, rows, (int)kb, n_chunks);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+extern "C" int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0, const float* mask0, const void* qt1,
+                                    const void* ct1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
+                                    int lpad, int hidden, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if ((n_mod != 1 && n_mod != 2) || !qt0 || !ct0 || !mask0 || !out) return XML_ERR_BAD_ARG;
+  if (n_mod == 2 && (!qt1 || !ct1 || !mask1)) return XML_ERR_BAD_ARG;
+  if (nq <= 0 || nv <= 0 || hidden <= 0 || ld_out < nv) return XML_ERR_BAD_ARG;
+  if (!xml_q2c_tiled_ok(lpad, hidden, dt)) return XML_ERR_UNSUPPORTED;
+  const void* q[2] = {qt0, n_mod == 2 ? qt1 : qt0};
+  const void* c[2] = {ct0, n_mod == 2 ? ct1 : ct0};
+  const float* m[2] = {mask0, n_mod == 2 ? mask1 : mask0};
+  return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream, true);
 }

@@ -26,7 +26,9 @@ class CorpusIndex(object):
     """Encoded corpus resident in HBM.
 
     modalities : list of "video" / "sub" in model order
-    feat1n[m]  : (Nv, lpad, H) compute dtype, L2-normalised rows (zero rows beyond each batch's own length)
+    feat1n[m]  : (Nv, lpad, H) compute dtype, L2-normalised rows (zero rows beyond each batch's own length); on the
+                 HIP backend at lpad == 128 an ops.TiledRows (K6's slice-major tile layout) -- feat1n_rows(m) gives
+                 the row-major tensor back
     feat2[m]   : (Nv, lpad, H) compute dtype
     mask[m]    : (Nv, lpad) float32
     l_ref      : the reference's context length = global max clip count (xml/inference.py:71-87)
@@ -42,6 +44,10 @@ class CorpusIndex(object):
         self.video_offset = int(video_offset)
         self.n_total = int(n_total if n_total is not None else self.n_videos)
         self.feat2_all = self.mask_all = None      # corpus-wide copies of feat2 / mask (dist.replicate_rerank_features)
+
+    def feat1n_rows(self, m):
+        t = self.feat1n[m]
+        return t.to_rows() if hasattr(t, "to_rows") else t
 
     @property
     def device(self):
@@ -105,6 +111,8 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
     for m in mods:
         f1 = cat(parts[m]["f1"])
         feat1n[m] = ops.l2norm_rows(f1)
+        if hasattr(ops, "pack_q2c_corpus"):      # HIP backend: slice-major tiles for the persistent K6 kernel
+            feat1n[m] = ops.pack_q2c_corpus(feat1n[m])
         feat2[m] = cat(parts[m]["f2"])
         mask[m] = cat(parts[m]["mk"])
         if keep_raw:

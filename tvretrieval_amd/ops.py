@@ -6,6 +6,8 @@ GPU tensor is missing -- there is no eager/CPU fallback.
 """
 import ctypes
 
+import os
+
 import torch
 
 from . import _lib
@@ -192,10 +194,69 @@ def q2c_scores(qn, cn, mask, out=None, combine=False):
     return out
 
 
+class TiledRows(object):
+    """Rows of a (rows, H) operand in K6's slice-major tile layout (xml_q2c_tile_rows): `data` is the flat tiled
+    image, `rows` / `hidden` / `dtype` describe the row-major tensor it was made from."""
+
+    def __init__(self, data, rows, hidden, shape):
+        self.data, self.rows, self.hidden, self.shape = data, int(rows), int(hidden), tuple(shape)
+        self.dtype, self.device = data.dtype, data.device
+
+    def numel(self):
+        return self.data.numel()
+
+    def element_size(self):
+        return self.data.element_size()
+
+    def to_rows(self):
+        """Back to the row-major tensor of the original shape (tests, the CPU baseline sample)."""
+        per = 64 // self.data.element_size()
+        t = self.data.view(-1, self.hidden // per, 256, per).permute(0, 2, 1, 3).reshape(-1, self.hidden)
+        return t[:self.rows].reshape(self.shape).contiguous()
+
+
+def q2c_tiled_ok(lpad, hidden, dtype):
+    return dtype in _DT and bool(_lib.load().xml_q2c_tiled_ok(int(lpad), int(hidden), dt_of(dtype)))
+
+
+def q2c_tile_rows(x):
+    """(..., H) contiguous rows -> TiledRows (K6 operand layout)."""
+    _req(x, "x")
+    hidden = x.shape[-1]
+    rows = x.numel() // hidden
+    nbytes = _lib.load().xml_q2c_tiled_bytes(rows, hidden, dt_of(x))
+    data = torch.empty(nbytes // x.element_size(), dtype=x.dtype, device=x.device)
+    check(_lib.load().xml_q2c_tile_rows(_p(x), _p(data), rows, hidden, dt_of(x), _stream()), "xml_q2c_tile_rows")
+    return TiledRows(data, rows, hidden, x.shape)
+
+
+def pack_q2c_corpus(feat1n):
+    """Resident form of the similarity operand: slice-major tiles when the persistent kernel takes it, else as is."""
+    if q2c_tiled_ok(feat1n.shape[1], feat1n.shape[2], feat1n.dtype) and not os.environ.get("XML_Q2C_ROW_MAJOR"):
+        return q2c_tile_rows(feat1n)          # (XML_Q2C_ROW_MAJOR=1: keep rows, for A/B measurements)
+    return feat1n
+
+
 def q2c_scores_fused(qn, cn, masks, out=None):
     """K6 for all modalities in one launch.  qn / cn / masks: lists (len 1 or 2) of (Nq,H), (Nv,Lpad,H), (Nv,Lpad) f32.
-    out (Nq, Nv) f32 = mean over modalities of the masked max-over-clips cosine."""
+    out (Nq, Nv) f32 = mean over modalities of the masked max-over-clips cosine.
+    cn[m] may be TiledRows (pack_q2c_corpus): the queries are tiled here and the tiled entry runs."""
     n_mod = len(qn)
+    if isinstance(cn[0], TiledRows):
+        nq, hidden = qn[0].shape
+        nv, lpad = masks[0].shape
+        for m in range(n_mod):
+            _req(qn[m], "qn"); _req(masks[m], "mask", torch.float32)
+            assert isinstance(cn[m], TiledRows) and cn[m].shape == (nv, lpad, hidden) and cn[m].dtype == qn[m].dtype
+        qt = [q2c_tile_rows(q) for q in qn]
+        if out is None:
+            out = torch.empty((nq, nv), dtype=torch.float32, device=qn[0].device)
+        _req(out, "out", torch.float32)
+        j = 1 if n_mod > 1 else 0
+        check(_lib.load().xml_q2c_scores_tiled(n_mod, _p(qt[0].data), _p(cn[0].data), _p(masks[0]), _p(qt[j].data),
+                                               _p(cn[j].data), _p(masks[j]), _p(out), out.stride(0), nq, nv, lpad,
+                                               hidden, dt_of(qn[0]), _stream()), "xml_q2c_scores_tiled")
+        return out
     for m in range(n_mod):
         _req(qn[m], "qn"); _req(cn[m], "cn", qn[m].dtype); _req(masks[m], "mask", torch.float32)
         assert qn[m].shape == qn[0].shape and cn[m].shape == cn[0].shape and tuple(masks[m].shape) == tuple(cn[0].shape[:2])

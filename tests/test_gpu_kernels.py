@@ -329,6 +329,41 @@ def test_topk_rows(ops, shape):
                        torch.topk(s, k, dim=1)[0])
 
 
+@pytest.mark.parametrize("n,k", [(4096, 100), (5000, 256), (21793, 100), (21793, 200), (50000, 37)])
+def test_topk_long_rows_prefilter_and_fallbacks(ops, n, k):
+    """long rows are pre-filtered through a sample threshold (one pass over the row); rows that defeat the sample --
+    sorted either way, constant, mostly -inf, ties across the threshold -- must fall back and still give the exact
+    top-k with the (score desc, column asc) tie rule."""
+    g = torch.Generator().manual_seed(n + k)
+    base = (torch.randn(n, 16, generator=g) * 0.036).max(-1)[0]           # K6-like scores
+    rows = [base,
+            torch.sort(base)[0],                                          # ascending: the sample holds the smallest
+            torch.sort(base, descending=True)[0],                         # descending: the sample holds the largest
+            torch.full((n,), 0.25),                                       # constant row
+            torch.where(torch.rand(n, generator=g) < 0.999, torch.tensor(float("-inf")), base),   # < k finite values?
+            torch.round(base * 64) / 64,                                  # few distinct values: ties across the threshold
+            -base]                                                        # negative scores
+    rows[4][:k] = base[:k]                                                # keep at least k finite entries
+    s = torch.stack(rows)
+    vals, idx = ops.topk_rows(dev(s), k, alpha=0.0)
+    vals, idx = vals.cpu(), idx.cpu().long()
+    wv = torch.topk(s, k, dim=1)[0]
+    assert torch.equal(vals, wv)
+    assert torch.equal(torch.gather(s, 1, idx), wv)
+    for r in range(s.shape[0]):
+        key = [(-float(s[r, i]), int(i)) for i in idx[r]]
+        assert key == sorted(key) and len(set(idx[r].tolist())) == k, r
+        thr = float(s[r, idx[r, -1]])
+        tied = (s[r] == thr).nonzero().flatten().tolist()
+        took = sorted(i for i in idx[r].tolist() if float(s[r, i]) == thr)
+        assert took == tied[:len(took)], r
+    pay = torch.randperm(n, generator=g).int().repeat(s.shape[0], 1)
+    v2, i2 = ops.topk_rows(dev(s), k, alpha=20.0, idx_in=dev(pay))
+    assert torch.allclose(v2.cpu(), torch.exp(20.0 * wv), rtol=1e-6)
+    # payloads name the right columns (ties are ordered by payload here, so compare the scores they point at)
+    assert torch.equal(torch.gather(s, 1, torch.argsort(pay.long(), dim=1).gather(1, i2.cpu().long())), wv)
+
+
 def _conv_case(nq, nv, l, h, merged, n_mod, seed):
     g = torch.Generator().manual_seed(seed)
     q = [rnd(nq, h, seed=seed + 1 + m, scale=0.3) for m in range(n_mod)]

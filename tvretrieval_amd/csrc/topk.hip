@@ -18,118 +18,207 @@ __device__ __forceinline__ float key_to_float(uint32_t k) {
   return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
 }
 
-// VPT > 0: keys live in registers (thread t owns columns t, t + 256, ...; n <= 256 * VPT); VPT == 0: any n, re-reads.
+// VPT > 0: keys live in registers (thread t owns columns t, t + 256, ...; n <= 256 * VPT).
+// VPT == 0: any n.  Long rows (n >= 4096) are pre-filtered so that the row is read ONCE instead of five times:
+//   a. the r-th largest key T0 of a 2048-column sample (the first columns; 8 keys per thread in registers), with r chosen
+//      so that about 3 k elements of the whole row reach T0;
+//   b. one pass over the row collects every element >= T0 into an LDS candidate list (wave-aggregated append);
+//   c. if the list holds between k and 1024 entries (and the threshold ties need no column-ordered tie-break), the exact
+//      selection runs on the list; otherwise -- adversarially ordered rows, massive ties -- the kernel falls back to
+//      re-reading the row for every radix pass.  Either way the result is the exact top-k with the same tie rule.
 template <int VPT>
 __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict__ scores, int64_t ld,
                                                         const int32_t* __restrict__ idx_in,
                                                         float* __restrict__ out_val, int32_t* __restrict__ out_idx,
                                                         int n, int k, float alpha) {
+  constexpr int CAND_CAP = VPT > 0 ? 1 : 1024;
+  constexpr int SAMPLE = 2048;
   __shared__ uint32_t hist[256];
   __shared__ unsigned long long comp[256];
+  __shared__ unsigned long long cand[CAND_CAP];      // (key << 32) | column
   __shared__ uint32_t s_prefix, s_need, s_cnt, s_eq_total, s_eq_taken;
   __shared__ uint32_t s_wsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float* row = scores + (int64_t)blockIdx.x * ld;
   const int32_t* pay = idx_in ? idx_in + (int64_t)blockIdx.x * ld : nullptr;
-  constexpr int NK = VPT > 0 ? VPT : 1;
+  constexpr int NK = VPT > 0 ? VPT : SAMPLE / 256;
+  const int n_reg = VPT > 0 ? n : min(n, SAMPLE);
   uint32_t keys[NK];
-  if (VPT > 0) {
 #pragma unroll
-    for (int j = 0; j < NK; ++j) {
-      const int i = tid + j * 256;
-      keys[j] = i < n ? ord_key(row[i]) : 0u;     // 0 sorts below every real key (ord_key(x) >= 1 for finite / inf x)
-    }
+  for (int j = 0; j < NK; ++j) {
+    const int i = tid + j * 256;
+    keys[j] = i < n_reg ? ord_key(row[i]) : 0u;     // 0 sorts below every real key (ord_key(x) >= 1 for finite / inf x)
   }
-  // walk the row: f(key, column)
-  auto for_each = [&](auto&& f) {
-    if constexpr (VPT > 0) {
+  enum { SRC_REG = 0, SRC_ROW = 1, SRC_CAND = 2 };
+  int src = VPT > 0 ? SRC_REG : SRC_ROW;
+  int n_cand = 0;
+  // walk the current source: f(key, column, valid); every lane of a wave runs the same number of iterations
+  auto walk = [&](auto&& f) {
+    if (src == SRC_REG) {
 #pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        const int i = tid + j * 256;
-        if (i < n) f(keys[j], i);
+      for (int j = 0; j < NK; ++j) f(keys[j], tid + j * 256, tid + j * 256 < n_reg);
+    } else if (src == SRC_ROW) {
+      for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        f(i < n ? ord_key(row[i]) : 0u, i, i < n);
       }
     } else {
-      for (int i = tid; i < n; i += 256) f(ord_key(row[i]), i);
+      for (int base = 0; base < n_cand; base += 256) {
+        const int i = base + tid;
+        const unsigned long long e = i < n_cand ? cand[i] : 0ull;
+        f((uint32_t)(e >> 32), (int)(uint32_t)(e & 0xffffffffull), i < n_cand);
+      }
     }
   };
-
-  if (tid == 0) { s_prefix = 0; s_need = (uint32_t)k; }
-  uint32_t mask = 0;
-  for (int pass = 0; pass < 4; ++pass) {
-    const int shift = 24 - 8 * pass;
-    hist[tid] = 0;
-    __syncthreads();
-    const uint32_t prefix = s_prefix;
-    for_each([&](uint32_t key, int) {
-      if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 0xff], 1u);
+  // histogram pass.  Scores of one row share their top bits (cosines: a handful of exponents), so in the FIRST pass
+  // nearly all 64 lanes of a wave hit one or two bins and a plain atomicAdd serialises up to 64-fold; there the adds are
+  // wave-aggregated (up to 4 leader rounds, then plain adds for what is left).  Later passes see spread-out bins.
+  auto hist_pass = [&](uint32_t mask, uint32_t prefix, int shift) {
+    walk([&](uint32_t key, int, bool valid) {
+      const bool act = valid && (key & mask) == prefix;
+      const uint32_t bin = (key >> shift) & 0xff;
+      if (shift == 24) {
+        unsigned long long todo = __ballot(act);
+#pragma unroll 1
+        for (int r = 0; r < 4 && todo; ++r) {
+          const int leader = __ffsll((long long)todo) - 1;
+          const uint32_t lb = __shfl(bin, leader, 64);
+          const unsigned long long same = __ballot(act && bin == lb) & todo;
+          if (lane == leader) atomicAdd(&hist[lb], (uint32_t)__popcll(same));
+          todo &= ~same;
+        }
+        if ((todo >> lane) & 1ull) atomicAdd(&hist[bin], 1u);
+      } else if (act) {
+        atomicAdd(&hist[bin], 1u);
+      }
     });
-    __syncthreads();
-    {   // bin b with  sum_{x > b} hist[x] < need <= sum_{x >= b} hist[x]:  inclusive scan from the top bin down
-      const uint32_t need = s_need;
-      const uint32_t h = hist[255 - tid];
-      uint32_t inc = h;
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t v = __shfl_up(inc, o, 64);
-        if (lane >= o) inc += v;
-      }
-      if (lane == 63) s_wsum[wave] = inc;
+  };
+  // 4 x 8-bit MSB-first radix select of the kth largest key of the current source (which holds >= kth elements):
+  // s_prefix = its key T, s_need = elements == T still to take, s_eq_total = elements == T in the source
+  auto select = [&](uint32_t kth) {
+    if (tid == 0) { s_prefix = 0; s_need = kth; }
+    uint32_t mask = 0;
+    for (int pass = 0; pass < 4; ++pass) {
+      const int shift = 24 - 8 * pass;
+      hist[tid] = 0;
       __syncthreads();
-      for (int w = 0; w < wave; ++w) inc += s_wsum[w];
-      if (inc >= need && inc - h < need) {        // exactly one thread (the row holds >= need candidates)
-        s_need = need - (inc - h);
-        s_prefix = prefix | ((uint32_t)(255 - tid) << shift);
-        s_eq_total = h;
+      const uint32_t prefix = s_prefix;
+      hist_pass(mask, prefix, shift);
+      __syncthreads();
+      {   // bin b with  sum_{x > b} hist[x] < need <= sum_{x >= b} hist[x]:  inclusive scan from the top bin down
+        const uint32_t need = s_need;
+        const uint32_t h = hist[255 - tid];
+        uint32_t inc = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const uint32_t v = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += v;
+        }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        for (int w = 0; w < wave; ++w) inc += s_wsum[w];
+        if (inc >= need && inc - h < need) {        // exactly one thread (the source holds >= need candidates)
+          s_need = need - (inc - h);
+          s_prefix = prefix | ((uint32_t)(255 - tid) << shift);
+          s_eq_total = h;
+        }
       }
+      mask |= 0xffu << shift;
+      __syncthreads();
     }
-    mask |= 0xffu << shift;
-    __syncthreads();
-  }
-  const uint32_t T = s_prefix;
-  const uint32_t need_eq = s_need;          // elements == T still to take (>= 1)
-  const uint32_t eq_total = s_eq_total;     // elements == T in the row
-  if (tid == 0) { s_cnt = 0; s_eq_taken = 0; }
-  comp[tid] = 0ull;
-  __syncthreads();
-
+  };
   auto emit = [&](uint32_t key, int i) {
     const uint32_t slot = atomicAdd(&s_cnt, 1u);
     const uint32_t p = pay ? (uint32_t)pay[i] : (uint32_t)i;
     if (slot < 256) comp[slot] = ((unsigned long long)key << 32) | (unsigned long long)(0xffffffffu - p);
   };
-  if (eq_total == need_eq) {
-    for_each([&](uint32_t key, int i) {
-      if (key >= T) emit(key, i);
-    });
-  } else {
-    // ties at the threshold exceed the need: take the lowest columns, in order (rare path)
-    for (int base = 0; base < n; base += 256) {
-      const int i = base + tid;
-      uint32_t key = 0;
-      bool eq = false;
-      if (i < n) {
-        key = ord_key(row[i]);      // rare path: plain re-read (dynamic register indexing would go to scratch)
-        if (key > T) emit(key, i);
-        eq = key == T;
-      }
-      const unsigned long long bal = __ballot(eq);
-      __shared__ uint32_t wcount[4];
-      if ((tid & 63) == 0) wcount[tid >> 6] = (uint32_t)__popcll(bal);
+
+  bool done = false;
+  if constexpr (VPT == 0) {
+    const uint32_t r = (uint32_t)(((int64_t)3 * k * SAMPLE + n - 1) / n) + 2;
+    if (n >= 2 * SAMPLE && r <= SAMPLE / 8) {
+      src = SRC_REG;
+      select(r);                                           // a. threshold from the sample
+      const uint32_t t0 = s_prefix;
+      if (tid == 0) s_cnt = 0;
       __syncthreads();
-      uint32_t before = s_eq_taken;
-      for (int w = 0; w < (tid >> 6); ++w) before += wcount[w];
-      before += (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
-      if (eq && before < need_eq) emit(key, i);
-      __syncthreads();
-      if (tid == 0) s_eq_taken += wcount[0] + wcount[1] + wcount[2] + wcount[3];
-      __syncthreads();
-      if (s_eq_taken >= need_eq) {
-        // remaining chunks can only contribute elements > T
-        for (int j = base + 256 + tid; j < n; j += 256) {
-          const uint32_t kj = ord_key(row[j]);
-          if (kj > T) emit(kj, j);
+      src = SRC_ROW;
+      walk([&](uint32_t key, int i, bool valid) {          // b. one pass: everything >= t0
+        const bool take = valid && key >= t0;
+        const unsigned long long bal = __ballot(take);
+        if (bal) {
+          uint32_t base = 0;
+          const int leader = __ffsll((long long)bal) - 1;
+          if (lane == leader) base = atomicAdd(&s_cnt, (uint32_t)__popcll(bal));
+          base = __shfl(base, leader, 64);
+          const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
+          if (take && slot < (uint32_t)CAND_CAP) cand[slot] = ((unsigned long long)key << 32) | (unsigned long long)(uint32_t)i;
         }
-        break;
+      });
+      __syncthreads();
+      const uint32_t cnt = s_cnt;
+      __syncthreads();
+      if (cnt >= (uint32_t)k && cnt <= (uint32_t)CAND_CAP) {   // c. exact selection on the candidates
+        n_cand = (int)cnt;
+        src = SRC_CAND;
+        select((uint32_t)k);
+        if (s_eq_total == s_need) {
+          const uint32_t T = s_prefix;
+          if (tid == 0) s_cnt = 0;
+          comp[tid] = 0ull;
+          __syncthreads();
+          walk([&](uint32_t key, int i, bool valid) {
+            if (valid && key >= T) emit(key, i);
+          });
+          done = true;
+        }
+      }
+      src = SRC_ROW;
+    }
+  }
+  if (!done) {
+    __syncthreads();                          // (the pre-filter's readers of s_need / s_eq_total are done)
+    select((uint32_t)k);
+    const uint32_t T = s_prefix;
+    const uint32_t need_eq = s_need;          // elements == T still to take (>= 1)
+    const uint32_t eq_total = s_eq_total;     // elements == T in the row
+    if (tid == 0) { s_cnt = 0; s_eq_taken = 0; }
+    comp[tid] = 0ull;
+    __syncthreads();
+    if (eq_total == need_eq) {
+      walk([&](uint32_t key, int i, bool valid) {
+        if (valid && key >= T) emit(key, i);
+      });
+    } else {
+      // ties at the threshold exceed the need: take the lowest columns, in order (rare path)
+      for (int base = 0; base < n; base += 256) {
+        const int i = base + tid;
+        uint32_t key = 0;
+        bool eq = false;
+        if (i < n) {
+          key = ord_key(row[i]);      // rare path: plain re-read (dynamic register indexing would go to scratch)
+          if (key > T) emit(key, i);
+          eq = key == T;
+        }
+        const unsigned long long bal = __ballot(eq);
+        __shared__ uint32_t wcount[4];
+        if ((tid & 63) == 0) wcount[tid >> 6] = (uint32_t)__popcll(bal);
+        __syncthreads();
+        uint32_t before = s_eq_taken;
+        for (int w = 0; w < (tid >> 6); ++w) before += wcount[w];
+        before += (uint32_t)__popcll(bal & ((1ull << (tid & 63)) - 1ull));
+        if (eq && before < need_eq) emit(key, i);
+        __syncthreads();
+        if (tid == 0) s_eq_taken += wcount[0] + wcount[1] + wcount[2] + wcount[3];
+        __syncthreads();
+        if (s_eq_taken >= need_eq) {
+          // remaining chunks can only contribute elements > T
+          for (int j = base + 256 + tid; j < n; j += 256) {
+            const uint32_t kj = ord_key(row[j]);
+            if (kj > T) emit(kj, j);
+          }
+          break;
+        }
       }
     }
   }

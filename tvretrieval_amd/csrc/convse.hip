@@ -191,8 +191,26 @@ __global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
 
   if (a.dbg == 2) return;
   // ---- ConvSE epilogue: each wave owns TM/4 pair rows; a lane owns clips lane and lane + 64 ----------
+  // Everything that does not depend on the pair row is fetched ONCE per workgroup: the clip masks of this video (two
+  // values per lane and stream) and the filter taps (scalar loads into LDS).  Left inside the row loop they were a
+  // dependent global load per row -- 16 round trips per wave, most of the epilogue's time.
   const int half = a.ksize >> 1;
   const float inv_mod = 1.f / (float)n_sim;
+  __shared__ float s_taps[2 * 2 * 16];               // [st | ed][stream][tap]
+  if (tid < 2 * n_sim * a.ksize) {
+    const int which = tid / (n_sim * a.ksize), rest = tid - which * n_sim * a.ksize;
+    const int si = rest / a.ksize, t = rest - si * a.ksize;
+    s_taps[(which * 2 + si) * 16 + t] = a.conv_w[(which * n_sim + si) * a.ksize + t];
+  }
+  float mk_r[2][2];
+#pragma unroll
+  for (int si = 0; si < 2; ++si)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int l = lane + h * 64;
+      mk_r[si][h] = (si < n_sim && l < a.l_ref) ? a.mask[a.merged ? 0 : si][(int64_t)v * a.lpad + l] : 0.f;
+    }
+  __syncthreads();
   for (int row = wn; row < cnt; row += 4) {
     const int p = s_pair[row];
     float st[2], ed[2];
@@ -201,20 +219,23 @@ __global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
       const int l = lane + h * 64;
       float s_acc = 0.f, e_acc = 0.f;
       if (l < a.l_ref) {
-        for (int si = 0; si < n_sim; ++si) {
-          const float* wst = a.conv_w + si * a.ksize;
-          const float* wed = a.conv_w + (n_sim + si) * a.ksize;
-          float cs = 0.f, ce = 0.f;
-          for (int t = 0; t < a.ksize; ++t) {
-            const int j = l + t - half;
-            const float x = (j >= 0 && j < a.l_ref) ? sim[si][row][j] : 0.f;
-            cs += wst[t] * x;
-            ce += wed[t] * x;
+#pragma unroll
+        for (int si = 0; si < 2; ++si) {
+          if (si < n_sim) {
+            const float* wst = s_taps + si * 16;
+            const float* wed = s_taps + (2 + si) * 16;
+            float cs = 0.f, ce = 0.f;
+            for (int t = 0; t < a.ksize; ++t) {
+              const int j = l + t - half;
+              const float x = (j >= 0 && j < a.l_ref) ? sim[si][row][j] : 0.f;
+              cs += wst[t] * x;
+              ce += wed[t] * x;
+            }
+            const float mk = mk_r[si][h];
+            const float fill = (1.f - mk) * -1e10f;
+            s_acc += cs * mk + fill;   // mask_logits, xml/model_xml.py:640-641
+            e_acc += ce * mk + fill;
           }
-          const float mk = a.mask[a.merged ? 0 : si][(int64_t)v * a.lpad + l];
-          const float fill = (1.f - mk) * -1e10f;
-          s_acc += cs * mk + fill;   // mask_logits, xml/model_xml.py:640-641
-          e_acc += ce * mk + fill;
         }
         if (n_sim > 1) { s_acc *= inv_mod; e_acc *= inv_mod; }
       } else {

@@ -114,3 +114,4 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
     __syncthreads();
   }
 }
+

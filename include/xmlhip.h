@@ -209,7 +209,7 @@ int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, const void* 
  * replaces einsum("qvm,qv,qvn->qvmn") * length mask, flat sort, [:max_before_nms]
  * (xml/inference.py:365-386, :170-192) and the index decoding of :423-431; with kpairs == 1 it is the
  * SVMR path (get_svmr_res_from_st_ed_probs, xml/inference.py:195-241, utils/tensor_utils.py:133-141).
- *   st, ed (nq, kpairs, lpad) f32 probabilities; w (nq, kpairs) f32 or NULL (= 1)
+ *   st, ed (nq, kpairs, lpad) f32 probabilities (>= 0: the pruning bound uses it); w (nq, kpairs) f32 >= 0 or NULL (= 1)
  *   out_score (nq, n_out) f32 descending; out_flat (nq, n_out) int32 = (r*l_ref + i)*l_ref + j
  *   (the reference's flat index); ties broken by ascending flat index; when fewer than n_out
  *   candidates exist the tail is score 0 / flat -1.

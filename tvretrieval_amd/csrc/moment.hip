@@ -5,11 +5,12 @@
 //
 // The reference materialises (Nq, 100, L, L) products and fully sorts 1.64 M values per query.  Only the band
 // min_l <= j-i < max_l can be non-zero, so one workgroup per query works on the k*L*(max_l-min_l) band candidates
-// from LDS-resident rows and keeps the best n_out, exactly, without ever sorting more than a few hundred values:
-//   1. stage the ed rows of the ACTIVE pairs (w != 0) in LDS, keep st*w in registers; (st*w)*ed is the reference's
-//      einsum order.
-//      Wave w owns pairs w, w+4, ...; lane l owns start clips l and l+64: no integer divisions anywhere.
-//   2. row maxima m(r,i) = max_d score(r,i,i+d) are computed on the fly (and again in the expansion pass).
+// from register-resident rows and keeps the best n_out, exactly, without ever sorting more than a few hundred values:
+//   1. Wave w owns the ACTIVE pairs (w != 0) w, w+4, ...; lane l owns start clips l and l+64 and holds st*w and the
+//      pair's end probabilities for them in registers; (st*w)*ed is the reference's einsum order.
+//   2. row maxima m(r,i) = max_d score(r,i,i+d) = (st*w)[i] * max_d ed[i+d] (exact for non-negative inputs: rounding
+//      is monotone); the sliding-window maximum of ed is a few wave shuffles.  Nothing of a pair is staged in LDS
+//      (24 KiB per workgroup, four per CU); the maxima are simply recomputed in the expansion pass.
 //   3. two lower bounds of the n_out-th best score, both by MSB-first radix-select (11/11/10 bits, wave-aggregated
 //      LDS histogram adds, wave-parallel suffix scan):
 //        T_a = n_out-th largest row maximum            (tight for peaky start/end distributions)
@@ -104,9 +105,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
-  const int R = kpairs * l_ref;
-  float* s_ed = reinterpret_cast<float*>(smem);            // [kpairs][l_ref] end probabilities of the active pairs
-  unsigned long long* s_list = reinterpret_cast<unsigned long long*>(s_ed + R + (R & 1));  // [MT_CAP]
+  unsigned long long* s_list = reinterpret_cast<unsigned long long*>(smem);                 // [MT_CAP]
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_list + MT_CAP);                          // [2048]
   __shared__ MomentShared sh;
 
@@ -114,46 +113,55 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   const float* ged = ed + (int64_t)q * kpairs * lpad;
   const float* gw = w ? w + (int64_t)q * kpairs : nullptr;
 
-  // ---- 1. stage active pairs; 2. row maxima ---------------------------------------------------------------
-  // Small code matters more than registers here: a fully unrolled 64-row body (145 KB of code) made the kernel
-  // instruction-fetch bound (every workgroup streams its code through the 64 KB I-cache).  So rows are walked by
-  // runtime loops and nothing per-row is kept: the row maximum is simply recomputed in the expansion pass.
-  // Only the `ed` rows go to LDS (51 KiB at k = 100, L = 128) -> two workgroups per CU; st*w is re-read from L2.
+  // ---- 1 + 2. row maxima, in registers ---------------------------------------------------------------------------
+  // Wave w owns pairs w, w + 4, ...; lane l owns start clips l and l + 64 of a pair: a = st * w for its two clips and the
+  // pair's end probabilities e (lane l: clips l, l + 64) live in registers.  With a, e >= 0 the row maximum
+  // max_d (a * e[i + d]) equals a * max_d e[i + d] exactly (rounding is monotone), and the sliding-window maximum of e
+  // over [i + min_l, i + max_l) is 3-5 wave shuffles (doubling window widths, one overlapping step, the min_l offset)
+  // instead of 16 LDS reads per row -- and nothing of the pair has to be staged in LDS: 24 KiB per workgroup instead
+  // of 75, four workgroups per CU instead of two.  The expansion pass re-reads the few live (row, end clip) entries
+  // from L2.
   const float w_lo = gw ? (lane < kpairs ? gw[lane] : 0.f) : 1.f;        // pair weights: one vector load,
   const float w_hi = gw ? (lane + 64 < kpairs ? gw[lane + 64] : 0.f) : 1.f;  // broadcast later with a lane read
   auto pair_w = [&](int r) -> float { return __shfl(r < 64 ? w_lo : w_hi, r & 63, 64); };
   const int band = max_l - min_l;
   const int n_t = (kpairs - wave + 3) >> 2;                // pairs of this wave: r = wave + 4 t
-
-#pragma unroll 4
-  for (int t = 0; t < n_t; ++t) {                          // 1. stage ed rows of active pairs
-    const int r = wave + t * 4;
-    if (pair_w(r) == 0.f) continue;                        // w == 0: skipped pair (other rank / padding)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int i = lane + h * 64;
-      if (i < l_ref) s_ed[r * l_ref + i] = ged[r * lpad + i];
-    }
-  }
   for (int i = tid; i < 2048; i += 256) s_hist[i] = 0;
   if (tid == 0) { sh.prefix = 0; sh.flag = 0; }
   __syncthreads();
 
-  // row maximum of (r, i):  max_d (st*w)[i] * ed[i + d]
-  auto row_max = [&](float a, int r, int i) -> float {
-    const float* erow = s_ed + r * l_ref;
-    float m = 0.f;
-    if (band <= 16) {      // 16 independent LDS reads in flight (clamped addresses): one LDS latency per row
-      float e[16];
-#pragma unroll
-      for (int d = 0; d < 16; ++d) e[d] = erow[min(i + min_l + d, l_ref - 1)];
-#pragma unroll
-      for (int d = 0; d < 16; ++d) m = fmaxf(m, (d < band && (i + min_l + d) < l_ref) ? a * e[d] : 0.f);
-    } else {
-      const int jend = min(l_ref, i + max_l);
-      for (int j = i + min_l; j < jend; ++j) m = fmaxf(m, a * erow[j]);
+  // x[c + s] for a 128-long sequence held as (lo: clip lane, hi: clip lane + 64); zero beyond the end
+  auto shifted = [&](float lo, float hi, int s, float& olo, float& ohi) {
+    const int s1 = s & 63;
+    const int srcl = (lane + s1) & 63;
+    const bool wrap = lane + s1 >= 64;
+    const float from_lo = __shfl(lo, srcl, 64), from_hi = __shfl(hi, srcl, 64);
+    if (s < 64) { olo = wrap ? from_hi : from_lo; ohi = wrap ? 0.f : from_hi; }
+    else { olo = wrap ? 0.f : from_hi; ohi = 0.f; }
+  };
+  // (a_lo, a_hi) = st * w and the window maxima of ed for this lane's two start clips of pair r
+  auto pair_rows = [&](int r, float wv, float& a_lo, float& a_hi, float& m_lo, float& m_hi) {
+    const float* sp = gst + r * lpad;
+    const float* ep = ged + r * lpad;
+    const bool in_lo = lane < l_ref, in_hi = lane + 64 < l_ref;
+    a_lo = in_lo ? sp[lane] * wv : 0.f;
+    a_hi = in_hi ? sp[lane + 64] * wv : 0.f;
+    float lo = in_lo ? ep[lane] : 0.f, hi = in_hi ? ep[lane + 64] : 0.f;
+    int p = 1;
+    while (2 * p <= band) {                                // window width p -> 2 p
+      float slo, shi;
+      shifted(lo, hi, p, slo, shi);
+      lo = fmaxf(lo, slo); hi = fmaxf(hi, shi);
+      p <<= 1;
     }
-    return m;
+    if (p < band) {                                        // two overlapping windows of width p cover width band
+      float slo, shi;
+      shifted(lo, hi, band - p, slo, shi);
+      lo = fmaxf(lo, slo); hi = fmaxf(hi, shi);
+    }
+    if (min_l > 0) shifted(lo, hi, min_l, lo, hi);
+    m_lo = fmaxf(a_lo * lo, 0.f);
+    m_hi = fmaxf(a_hi * hi, 0.f);
   };
 
   // ---- 2+3. ONE histogram pass over the row maxima on bits [30:20] (8 exponent + 3 mantissa bits); the lower edge
@@ -163,10 +171,11 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     const int r = wave + t * 4;
     const float wv = pair_w(r);
     if (wv == 0.f) continue;
+    float a2[2], m2[2];
+    pair_rows(r, wv, a2[0], a2[1], m2[0], m2[1]);
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      const int i = lane + h * 64;
-      const float m = (i < l_ref) ? row_max(gst[r * lpad + i] * wv, r, i) : 0.f;
+      const float m = m2[h];
       const uint32_t key = __float_as_uint(m);
       const uint32_t bin = key >> 20;                      // sign bit is 0: < 2048
       const bool act = key != 0;
@@ -219,11 +228,13 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
       const int r = wave + t * 4;
       const float wv = pair_w(r);
       if (wv == 0.f) continue;
+      float a2[2], m2[2];
+      pair_rows(r, wv, a2[0], a2[1], m2[0], m2[1]);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int i = lane + h * 64;
-        const float a = (i < l_ref) ? gst[r * lpad + i] * wv : 0.f;
-        const bool row_on = (i < l_ref) && __float_as_uint(row_max(a, r, i)) >= lb;
+        const float a = a2[h];
+        const bool row_on = (i < l_ref) && __float_as_uint(m2[h]) >= lb;
         const unsigned long long bal = __ballot(row_on);
         if (bal == 0) continue;
         uint32_t base = 0;
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
           const int r = ri / l_ref, i = ri - r * l_ref;
           const int j = i + min_l + d;
           if (j < l_ref) {
-            key = __float_as_uint(__uint_as_float((uint32_t)(e >> 32)) * s_ed[r * l_ref + j]);
+            key = __float_as_uint(__uint_as_float((uint32_t)(e >> 32)) * ged[r * lpad + j]);
             take = key >= lb;
             flat = (uint32_t)(ri * l_ref + j);
           }
@@ -274,17 +285,19 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
       const int r = wave + t * 4;
       const float wv = pair_w(r);
       if (wv == 0.f) continue;
+      float a2[2], m2[2];
+      pair_rows(r, wv, a2[0], a2[1], m2[0], m2[1]);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int i = lane + h * 64;
-        const float a = (i < l_ref) ? gst[r * lpad + i] * wv : 0.f;
-        const bool row_on = (i < l_ref) && __float_as_uint(row_max(a, r, i)) >= lb;
+        const float a = a2[h];
+        const bool row_on = (i < l_ref) && __float_as_uint(m2[h]) >= lb;
         if (!__any(row_on)) continue;
         const int jend = row_on ? min(l_ref, i + max_l) : 0;
         for (int d = min_l; d < max_l; ++d) {                     // uniform trip count; lanes predicate themselves
           const int j = i + d;
           const bool ok = row_on && j < jend;
-          const uint32_t key = ok ? __float_as_uint(a * s_ed[r * l_ref + j]) : 0u;
+          const uint32_t key = ok ? __float_as_uint(a * ged[r * lpad + j]) : 0u;
           const bool take = ok && key >= lb;
           const unsigned long long bal = __ballot(take);
           if (bal) {
@@ -358,15 +371,8 @@ extern "C" int xml_moment_topk(const float* st, const float* ed, const float* w,
   if (!st || !ed || !out_score || !out_flat || nq <= 0 || kpairs <= 0 || lpad <= 0 || l_ref <= 0 || n_out <= 0)
     return XML_ERR_BAD_ARG;
   if (l_ref > lpad || min_l < 0 || max_l <= min_l) return XML_ERR_BAD_ARG;
-  if (n_out > 1024 || lpad > 128 || kpairs > 4 * MT_PPW) return XML_ERR_UNSUPPORTED;
-  const size_t R = (size_t)kpairs * l_ref;
-  const size_t lds = (R + (R & 1)) * 4 + (size_t)MT_CAP * 8 + 2048 * 4;
-  if (lds > 160 * 1024 - 64) return XML_ERR_UNSUPPORTED;
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)moment_topk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return XML_ERR_LAUNCH;
-  }
+  if (n_out > 1024 || lpad > 128 || kpairs > 4 * MT_PPW) return XML_ERR_UNSUPPORTED;   // (st, ed: probabilities, >= 0)
+  const size_t lds = (size_t)MT_CAP * 8 + 2048 * 4;
   hipLaunchKernelGGL(moment_topk_kernel, dim3(nq), dim3(256), lds, (hipStream_t)stream, st, ed, w, out_score, out_flat,
                      kpairs, lpad, l_ref, min_l, max_l, n_out);
   XML_CHECK_LAUNCH();

@@ -33,6 +33,12 @@ def main():
     out = torch.empty(nq, nv, device="cuda")
     flops = 2.0 * nq * nv * 128 * h
     ref = None
+    if "--tiled1" in sys.argv:      # one modality on slice-major tiles only (PMC calibration runs)
+        t1 = ops.pack_q2c_corpus(c)
+        for _ in range(7):
+            ops.q2c_scores_fused([q], [t1], [mask], out=out)
+        torch.cuda.synchronize()
+        return
     for v in variants:
         lib.xml_debug_set_q2c_variant(ctypes.c_int(v))
         for _ in range(2):

@@ -9,6 +9,8 @@
 //   phase A  S = Q K^T  (MFMA, K rows from LDS)  ->  s/sqrt(dh) + (1-mask)*-1e4  ->  softmax in registers
 //   phase B  O = P V    (P through a per-wave LDS patch to reach the A-operand layout, V^T rows from LDS)
 // Statistics and accumulation are f32 for both storage types.
+#include <type_traits>
+
 #include "gemm.h"
 #include "internal.h"
 
@@ -174,6 +176,192 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
   }
 }
 
+// Short sequences (lq, lk <= 32: the query encoder, 30 tokens): ONE WAVE per (sequence, head), four independent units
+// per workgroup.  The 4-wave kernel above leaves two of its waves without a query tile at lq <= 32 and synchronises
+// the block twice; here a wave stages its own K tile / V^T tile in its private LDS region and never meets a block
+// barrier (wave-level ordering only).  Same arithmetic, same order of operations per output element.
+template <typename T, typename OutT, int DH>
+__global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __restrict__ Q, int ldq,
+                                                                   const T* __restrict__ Kp, int ldk,
+                                                                   const T* __restrict__ Vp, int ldv,
+                                                                   const float* __restrict__ q_mask,
+                                                                   const float* __restrict__ k_mask,
+                                                                   OutT* __restrict__ out, int ldo, int lq, int lk,
+                                                                   int n_heads, int64_t n_units, float sqrt_dh) {
+  constexpr int CE = ChunkOf<T>::elems;
+  constexpr int VEC = 16 / (int)sizeof(T);
+  constexpr int DCH = DH / CE;
+  constexpr int DT16 = DH / 16;
+  constexpr int NT = 2;                       // key tiles of 16 (lk <= 32)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t unit = (int64_t)blockIdx.x * 4 + wave;
+  if (unit >= n_units) return;                // (no block barrier below)
+  const int64_t n = unit / n_heads;
+  const int head = (int)(unit - n * n_heads);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int lkp = (lk + CE - 1) / CE * CE;
+  const int nkt = (lk + 15) / 16;
+  const int k_stride = DH * (int)sizeof(T) + 16;
+  const int vt_stride = lkp * (int)sizeof(T) + 16;
+  const int kv_bytes = max(32 * k_stride, DH * vt_stride);
+  const int wave_bytes = kv_bytes + 16 * vt_stride;
+  char* s_kv = smem + wave * wave_bytes;
+  char* s_p = s_kv + kv_bytes;
+  auto wave_sync = [&]() {
+    __builtin_amdgcn_s_waitcnt(0xc07f);       // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  const T* qbase = Q + n * lq * ldq + head * DH;
+  const T* kbase = Kp + n * lk * ldk + head * DH;
+  const T* vbase = Vp + n * lk * ldv + head * DH;
+
+  constexpr int VPR = DH / VEC;               // 16-byte vectors per row
+  constexpr int NV = 32 * VPR / 64;           // vectors per lane of a 32-row tile
+  {   // K rows -> LDS.  All loads of the tile are issued before the first store: one memory round trip, not NV
+    uint4 buf[NV];
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = lane + j * 64;
+      const int r = i / VPR, c = i % VPR;
+      buf[j] = make_uint4(0, 0, 0, 0);
+      if (r < lk) buf[j] = ld_global16(kbase + (int64_t)r * ldk + c * VEC);
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = lane + j * 64;
+      const int r = i / VPR, c = i % VPR;
+      *reinterpret_cast<uint4*>(s_kv + r * k_stride + c * 16) = buf[j];
+    }
+  }
+  // V is independent of the scores: fetch it now, it arrives while phase A runs
+  uint4 vbuf[NV];
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int i = lane + j * 64;
+    const int r = i / VPR, c = i % VPR;
+    vbuf[j] = make_uint4(0, 0, 0, 0);
+    if (r < lk) vbuf[j] = ld_global16(vbase + (int64_t)r * ldv + c * VEC);
+  }
+  wave_sync();
+
+  f32x4 p[2][NT];
+  const int nqt = (lq + 15) / 16;
+  float km[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) {
+    const int col = j * 16 + fr;
+    km[j] = (col < lk) ? k_mask[n * lk + col] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) p[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (t >= nqt) continue;
+    const int qrow = t * 16 + fr;
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      uint4 a = make_uint4(0, 0, 0, 0);
+      if (qrow < lq) a = ld_global16(qbase + (int64_t)qrow * ldq + c * CE + fg * VEC);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        if (j < nkt) {
+          const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
+          Mma<T>::chunk(p[t][j], a, b);
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = t * 16 + fg * 4 + r;
+      const float qm = (q_mask && row < lq) ? q_mask[n * lq + row] : 1.f;
+      float mx = -INFINITY;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = j * 16 + fr;
+        float sc = -INFINITY;
+        if (col < lk) sc = p[t][j][r] / sqrt_dh + (1.f - qm * km[j]) * -10000.f;
+        p[t][j][r] = sc;
+        mx = fmaxf(mx, sc);
+      }
+      mx = lane16_max(mx);
+      float sum = 0.f;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const float e = expf(p[t][j][r] - mx);
+        p[t][j][r] = e;
+        sum += e;
+      }
+      sum = lane16_sum(sum);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) p[t][j][r] = p[t][j][r] / sum;
+    }
+  }
+  wave_sync();                                // every lane is done reading K
+
+  {   // V^T -> LDS (overwrites K); rows lk .. lkp-1 are zero (lkp <= 32)
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = lane + j * 64;
+      const int r = i / VPR, c = i % VPR;
+      if (r < lkp) {
+        float vals[VEC];
+        unpack16<T>(vbuf[j], vals);
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          DT<T>::st(reinterpret_cast<T*>(s_kv + (c * VEC + e) * vt_stride) + r, vals[e]);
+      }
+    }
+  }
+  wave_sync();
+
+  const int nkc = lkp / CE;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t >= nqt) continue;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = j * 16 + fr;
+      if (col < lkp) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          DT<T>::st(reinterpret_cast<T*>(s_p + (fg * 4 + r) * vt_stride) + col, p[t][j][r]);
+      }
+    }
+    wave_sync();
+    f32x4 o[DT16];
+#pragma unroll
+    for (int d = 0; d < DT16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nkc; ++c) {
+      const uint4 a = *reinterpret_cast<const uint4*>(s_p + fr * vt_stride + c * 64 + fg * 16);
+#pragma unroll
+      for (int d = 0; d < DT16; ++d) {
+        const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (d * 16 + fr) * vt_stride + c * 64 + fg * 16);
+        Mma<T>::chunk(o[d], a, b);
+      }
+    }
+    wave_sync();                              // the patch is rewritten by the next query tile
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = t * 16 + fg * 4 + r;
+      if (row >= lq) continue;
+      OutT* po = out + (n * lq + row) * ldo + head * DH;
+#pragma unroll
+      for (int d = 0; d < DT16; ++d) DT<OutT>::st(po + d * 16 + fr, o[d][r]);
+    }
+  }
+}
+
+static size_t attn_small_lds_bytes(int lk, int dh, int dt) {
+  const int es = (int)dt_size(dt), ce = 64 / es;
+  const int lkp = (lk + ce - 1) / ce * ce;
+  const size_t k_stride = (size_t)dh * es + 16, vt_stride = (size_t)lkp * es + 16;
+  const size_t kvb = std::max((size_t)32 * k_stride, (size_t)dh * vt_stride);
+  return 4 * (kvb + 16 * vt_stride);
+}
+
 static size_t attn_lds_bytes(int lk, int dh, int dt) {
   const int es = (int)dt_size(dt), ce = 64 / es;
   const int lkp = (lk + ce - 1) / ce * ce;
@@ -186,6 +374,21 @@ template <typename T, typename OutT, int DH>
 static int launch_attn(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
                        const float* k_mask, void* out, int64_t n, int lq, int lk, int hidden, int n_heads,
                        size_t lds, hipStream_t st) {
+  if (lq <= 32 && lk <= 32) {
+    const size_t lds_s = attn_small_lds_bytes(lk, DH, std::is_same<T, float>::value ? XML_F32 : XML_BF16);
+    if (lds_s <= 160 * 1024) {
+      auto ks = attention_core_small_kernel<T, OutT, DH>;
+      if (lds_s > 64 * 1024 &&
+          hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess)
+        return XML_ERR_LAUNCH;
+      const int64_t units = n * n_heads;
+      hipLaunchKernelGGL(ks, dim3((unsigned)((units + 3) / 4)), dim3(256), lds_s, st, (const T*)q, ldq, (const T*)k, ldk,
+                         (const T*)v, ldv, q_mask, k_mask, (OutT*)out, hidden, lq, lk, n_heads, units,
+                         sqrtf((float)DH));
+      XML_CHECK_LAUNCH();
+      return XML_OK;
+    }
+  }
   auto kern = attention_core_kernel<T, OutT, DH>;
   if (lds > 64 * 1024) {
     if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)

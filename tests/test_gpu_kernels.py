@@ -65,6 +65,53 @@ def test_linear(ops, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_persistent_gemm_equals_tile_per_workgroup_gemm(ops, dtype):
+    """large projections run on the persistent 256x256 kernel (gemm256p.hip): same MFMA sequence per accumulator as the
+    one-tile-per-workgroup kernel -> bitwise the same outputs, for every epilogue (bias, ReLU, position / residual
+    addend, bf16 / f32 out, ragged M, N not a multiple of 8)."""
+    import ctypes
+    lib = ops._lib.load()
+    g = torch.Generator(device=DEV).manual_seed(7)
+
+    def both(fn):
+        res = []
+        try:
+            for variant in (0, 2):
+                lib.xml_debug_set_gemm_variant(ctypes.c_int(variant))
+                res.append(fn())
+        finally:
+            lib.xml_debug_set_gemm_variant(ctypes.c_int(0))
+        return res
+
+    for m, n, k in ((90001, 768, 256), (70000, 2304, 768), (90040, 700, 128 if dtype == torch.bfloat16 else 64)):
+        x = (torch.randn(m, k, device=DEV, generator=g) * 0.3).to(dtype)
+        w = (torch.randn(n, k, device=DEV, generator=g) * k ** -0.5).to(dtype)
+        b = torch.randn(n, device=DEV, generator=g)
+        a, c = both(lambda: ops.linear(x, w, None, relu=True))
+        assert torch.equal(a, c), (m, n, k, "relu")
+        a, c = both(lambda: ops.linear(x, w, b))
+        assert torch.equal(a, c), (m, n, k)
+        if m == 90001:      # spot check against torch on a corner that includes the ragged last row tile
+            want = torch.nn.functional.linear(x[-300:].float(), w.float(), b)
+            close("persistent gemm", a[-300:], want.cpu(), _tol(dtype, 2e-5, 2e-2), 1e-2 if dtype == torch.bfloat16 else 1e-5)
+    # K1+K2 (position-embedding addend, f32 pre-LN output) and a whole BertAttention block (QKV, residual addend)
+    n_seq, l, d_in, h = 800, 128, 256, 768
+    x = torch.randn(n_seq, l, d_in, device=DEV, generator=g)
+    wts = [torch.randn(h, d_in, device=DEV, generator=g).mul(d_in ** -0.5).to(dtype), torch.randn(h, device=DEV, generator=g) * 0.1,
+           torch.randn(l, h, device=DEV, generator=g).mul(0.5).to(dtype)]
+    ones, zeros = torch.ones(d_in, device=DEV), torch.zeros(d_in, device=DEV)
+    oh, zh = torch.ones(h, device=DEV), torch.zeros(h, device=DEV)
+    a, c = both(lambda: ops.linear_ln_relu_pos(x, ones, zeros, wts[0], wts[1], wts[2], oh, zh))
+    assert torch.equal(a, c)
+    mask = torch.ones(n_seq, l, device=DEV)
+    wqkv = torch.randn(3 * h, h, device=DEV, generator=g).mul(h ** -0.5).to(dtype)
+    wo = torch.randn(h, h, device=DEV, generator=g).mul(h ** -0.5).to(dtype)
+    bqkv, bo = torch.randn(3 * h, device=DEV, generator=g) * 0.1, torch.randn(h, device=DEV, generator=g) * 0.1
+    y, z = both(lambda: ops.attention_block(a, mask, wqkv, bqkv, wo, bo, oh, zh, 4))
+    assert torch.equal(y, z)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_layernorm_l2norm_convert(ops, dtype):
     a, b = rnd(37, 200, seed=4), rnd(37, 200, seed=5)
     g, beta = 1 + 0.1 * rnd(200, seed=6), 0.1 * rnd(200, seed=7)

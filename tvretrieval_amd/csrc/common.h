@@ -21,12 +21,15 @@ static constexpr int WAVE = 64;
 
 // ---- dtype traits ------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);  // quiet NaN
-  u += 0x7fffu + ((u >> 16) & 1u);                                          // round to nearest even
-  return (bf16_t)(u >> 16);
+// f32 -> bf16, round to nearest even: v_cvt_pk_bf16_f32 (gfx950).  The former integer version (NaN test + add + shift)
+// compiled into a divergent branch per element: ~25 instructions per value in every bf16 epilogue.
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 xml_bf16x2_t;
+typedef __attribute__((__vector_size__(2 * sizeof(float)))) float xml_f32x2_t;
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {      // lo -> bits [15:0]
+  const xml_f32x2_t v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, xml_bf16x2_t));
 }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return (bf16_t)(f32x2_to_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename T> struct DT;
 template <> struct DT<float> {
@@ -60,10 +63,10 @@ template <> __device__ __forceinline__ uint4 pack16<float>(const float* in) {
 }
 template <> __device__ __forceinline__ uint4 pack16<bf16_t>(const float* in) {
   uint4 v;
-  v.x = (uint32_t)f32_to_bf16(in[0]) | ((uint32_t)f32_to_bf16(in[1]) << 16);
-  v.y = (uint32_t)f32_to_bf16(in[2]) | ((uint32_t)f32_to_bf16(in[3]) << 16);
-  v.z = (uint32_t)f32_to_bf16(in[4]) | ((uint32_t)f32_to_bf16(in[5]) << 16);
-  v.w = (uint32_t)f32_to_bf16(in[6]) | ((uint32_t)f32_to_bf16(in[7]) << 16);
+  v.x = f32x2_to_bf16x2(in[0], in[1]);
+  v.y = f32x2_to_bf16x2(in[2], in[3]);
+  v.z = f32x2_to_bf16x2(in[4], in[5]);
+  v.w = f32x2_to_bf16x2(in[6], in[7]);
   return v;
 }
 

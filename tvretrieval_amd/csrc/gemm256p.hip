@@ -1,0 +1,349 @@
+// Persistent projection GEMM: the K-loop of gemm256.hip / q2c_persist.hip, one workgroup per CU walking many tiles
+// with a DMA stream that never drains.
+//   out[m][n] = act(A[m] . W[n] + bias[n]) + addend        A (M, K), W (N, K) both K-contiguous
+// Why: with one 256 x 256 tile per workgroup the encoder projections (K = 768: 24 slices) spend as long outside the
+// K loop as inside it -- T(tile) = 19.5 us + 0.81 us x slices, measured (tools/bench_gemm.py: 660-700 TF at K = 768,
+// 1060 TF at K = 3072): workgroup launch, the first DMA round trip, and an epilogue that owns the whole LDS.  Here
+// the issue side of the stream runs into the next tile while the current one finishes, and the epilogue works in 4 KiB
+// per-wave patches BESIDE the ring (160 KiB in all) while those DMAs are in flight.
+// Same MFMA sequence per accumulator as gemm256_kernel: bitwise the same results.
+#include <type_traits>
+
+#include "common.h"
+#include "internal.h"
+
+struct G256pArgs {
+  const void* A;
+  const void* W;
+  const float* bias;
+  const void* addend;
+  void* out;
+  int64_t M, n_tiles;
+  int N, K, relu, add_mode, seq_len, tn;
+  int skew;       // start skew: phase (0..15) x skew x 1024 cycles
+};
+
+__device__ __forceinline__ void g256p_dma_pair(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3"
+      :
+      : "v"(v0), "v"(v1), "s"(lds_dst), "s"(sb)
+      : "memory", "scc");
+}
+__device__ __forceinline__ void g256p_dma_quad(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, const char* sb,
+                                               uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %5"
+      :
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst), "s"(sb)
+      : "memory", "scc");
+}
+template <typename T> struct G256pInit;      // first K chunk of a tile: C = 0 as an inline constant
+template <> struct G256pInit<float> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.x), __uint_as_float(b.x), f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.y), __uint_as_float(b.y), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.z), __uint_as_float(b.z), acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(a.w), __uint_as_float(b.w), acc, 0, 0, 0);
+  }
+};
+template <> struct G256pInit<bf16_t> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; bf16x8_v v; } ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+};
+__device__ __forceinline__ int g256p_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
+
+__device__ unsigned long long g_g256p_probe[64];
+extern "C" int xml_debug_read_g256p_probe(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_g256p_probe), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
+}
+
+template <typename T, typename OutT, typename AddT>
+__global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
+  constexpr int ROWB = 64;
+  constexpr int OPER_BYTES = 256 * ROWB;
+  constexpr int SLOT_BYTES = 2 * OPER_BYTES;
+  constexpr int NSLOT = 4;
+  constexpr int RING_BYTES = NSLOT * SLOT_BYTES;      // 128 KiB; the eight 4 KiB epilogue patches follow
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int grp = wave >> 2;                       // waves w and w + 4 share a SIMD
+  const int fr = lane & 15, fg = lane >> 4;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  const int k_bytes = a.K * (int)sizeof(T);
+  const int n_slices = k_bytes / ROWB;             // even, >= 4 (eligibility)
+  const T* A = reinterpret_cast<const T*>(a.A);
+  const T* W = reinterpret_cast<const T*>(a.W);
+  const AddT* addend = reinterpret_cast<const AddT*>(a.addend);
+  OutT* out = reinterpret_cast<OutT*>(a.out);
+  const int64_t M = a.M;
+  const int N = a.N;
+
+  // tile walk: round k hands the 32 workgroups of XCD x the 32 consecutive tiles (8 k + x) * 32 .. + 31, N fastest:
+  // the workgroups of an XCD share a few row tiles of A through its L2, W stays resident
+  auto tile_of = [&](int k) -> int64_t { return ((int64_t)k * 8 + xcd) * 32 + loc; };
+
+  // ---- issue side ---------------------------------------------------------------------------------------------
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  int i_k = 0, i_slice = 0, i_slot = 0, i_left = n_slices, i_inc = 1;
+  uint32_t va[4] = {}, vb[2] = {};
+  const char* sbase_a = nullptr;
+  const char* sbase_b = nullptr;
+  auto setup_issue_tile = [&]() {
+    const int64_t lin = tile_of(i_k);
+    const int64_t mt = lin / a.tn;
+    const int nt = (int)(lin - mt * a.tn);
+    const int64_t m0 = mt * 256;
+    const int n0 = nt * 256;
+    int lane_o = lane;                             // opaque copy: keeps the address arithmetic out of the MFMA loop
+    asm volatile("" : "+v"(lane_o));
+    const int rsub = lane_o >> 2, pslot = lane_o & 3;
+    auto off_a = [&](int piece) -> uint32_t {
+      const int row = piece * 16 + rsub;
+      return (uint32_t)((m0 + row < M) ? row : 0) * k_bytes + (pslot ^ g256p_swz(row)) * 16;
+    };
+    auto off_b = [&](int piece) -> uint32_t {
+      const int row = piece * 16 + rsub;
+      return (uint32_t)((n0 + row < N) ? row : 0) * k_bytes + (pslot ^ g256p_swz(row)) * 16;
+    };
+    if (grp == 0) {     // uneven duty (see q2c_persist.hip): the group that parks at the barrier issues 6 of 8 pieces
+      va[0] = off_a(wave * 4); va[1] = off_a(wave * 4 + 1); va[2] = off_a(wave * 4 + 2); va[3] = off_a(wave * 4 + 3);
+      vb[0] = off_b(wave * 2); vb[1] = off_b(wave * 2 + 1);
+    } else {
+      vb[0] = off_b(8 + (wave - 4) * 2); vb[1] = off_b(9 + (wave - 4) * 2);
+    }
+    sbase_a = reinterpret_cast<const char*>(A) + m0 * k_bytes;
+    sbase_b = reinterpret_cast<const char*>(W) + (int64_t)n0 * k_bytes;
+  };
+  auto issue_slice = [&]() {
+    const int koff = i_slice * ROWB;
+    const uint32_t slot0 = lds0 + i_slot * SLOT_BYTES;
+    if (grp == 0) {
+      g256p_dma_quad(va[0], va[1], va[2], va[3], sbase_a + koff, slot0 + wave * 4096);
+      g256p_dma_pair(vb[0], vb[1], sbase_b + koff, slot0 + OPER_BYTES + wave * 2048);
+    } else {
+      g256p_dma_pair(vb[0], vb[1], sbase_b + koff, slot0 + OPER_BYTES + 8192 + (wave - 4) * 2048);
+    }
+    if (++i_slot == NSLOT) i_slot = 0;
+    i_slice += i_inc;
+    if (--i_left == 0) {                           // next tile; once the walk is exhausted the stream SATURATES:
+      i_slice = 0;                                 // it keeps re-fetching slice 0 of the last tile (valid addresses,
+      i_left = n_slices;                           // dead data), so the consumer side has no end-of-stream cases
+      ++i_k;
+      if (tile_of(i_k) < a.n_tiles) setup_issue_tile();
+      else { i_left = 0x7fffffff; i_inc = 0; }
+    }
+  };
+  if (tile_of(0) >= a.n_tiles) return;
+  if (a.skew == 96 && blockIdx.x >= 32) return;      // probe: only 32 workgroups run
+  // De-phase the workgroups.  All tiles take the same time, so 256 workgroups started together reach their epilogues
+  // together and write 32 MB in one burst, then nobody writes for a whole K loop -- and on gfx9 stores count in vmcnt, so
+  // every wave sits in the next tile's first counted wait until its stores have drained (measured: 19.6 us per tile
+  // outside the K loop, whatever K).  A one-off start skew of up to about one tile period spreads the writes evenly.
+  if (a.skew && a.skew < 96) {
+    const int ph = (blockIdx.x >> 3) & 15;
+    for (int i = 0; i < ph * a.skew; ++i) __builtin_amdgcn_s_sleep(16);      // 1024 cycles each
+  }
+  setup_issue_tile();
+
+  // ---- compute side ---------------------------------------------------------------------------------------------
+  const int a_off = (wm * 64 + fr) * ROWB + ((fg ^ g256p_swz(fr)) << 4);
+  const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ g256p_swz(fr)) << 4);
+  int c_k = 0, c_slot = 0;
+  issue_slice(); issue_slice(); issue_slice(); issue_slice();
+  if (grp == 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  uint4 faA[4], faB[4], fbL[4], fbH[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) faA[m] = *reinterpret_cast<const uint4*>(smem + a_off + m * 16 * ROWB);
+#pragma unroll
+  for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(smem + b_off + n * 16 * ROWB);
+
+  unsigned long long p_loop = 0, p_epi = 0, p_first = 0, p_t = 0, p_tiles = 0;
+  auto run = [&](auto grp_tag) {
+  constexpr bool GRP1 = decltype(grp_tag)::value;
+  for (;;) {      // one iteration = one tile
+    f32x4 acc[4][8];
+    if (a.skew >= 96) p_t = __builtin_amdgcn_s_memtime();
+    auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4], auto init_tag) {
+      constexpr bool INIT = decltype(init_tag)::value;
+      const char* slot = smem + c_slot * SLOT_BYTES;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if constexpr (INIT) G256pInit<T>::chunk(acc[m][n], fc[m], fbL[n]);
+          else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+        }
+      if (!GRP1) __builtin_amdgcn_s_waitcnt(0x007c);      // vmcnt(12) lgkmcnt(0): 6 pieces per slice, two slices young
+      else __builtin_amdgcn_s_waitcnt(0x0074);            // vmcnt(4)
+      __builtin_amdgcn_s_barrier();
+      if (++c_slot == NSLOT) c_slot = 0;
+      auto next_reads = [&]() {
+        const char* nslot = smem + c_slot * SLOT_BYTES;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
+#pragma unroll
+        for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
+      };
+      if (!GRP1) { next_reads(); issue_slice(); }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) {
+          if constexpr (INIT) G256pInit<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+          else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+        }
+      __builtin_amdgcn_sched_barrier(0);
+      if (GRP1) { next_reads(); issue_slice(); }
+    };
+    slice_step(faA, faB, std::true_type{});
+    if (a.skew >= 96) { const unsigned long long t = __builtin_amdgcn_s_memtime(); p_first += t - p_t; }
+    slice_step(faB, faA, std::false_type{});
+    for (int s2 = 2; s2 < n_slices; s2 += 2) {
+      slice_step(faA, faB, std::false_type{});
+      slice_step(faB, faA, std::false_type{});
+    }
+
+    if (a.skew >= 96) { const unsigned long long t = __builtin_amdgcn_s_memtime(); p_loop += t - p_t; p_t = t; }
+    // ---- epilogue: 8 rows x 128 columns of f32 at a time through this wave's 4 KiB patch -> 16-byte coalesced stores
+    // (an MFMA accumulator holds 4 rows x 1 column per lane).  Pass p covers tile rows 8 p .. 8 p + 7: the two lane
+    // groups fg = 2 (p & 1), 2 (p & 1) + 1 of row block p >> 1.  Patch column XOR 16 for rows 4..7: the two groups
+    // write different banks; a lane's 8 consecutive columns stay contiguous.
+    {
+      const int64_t lin = tile_of(c_k);
+      const int64_t mt = lin / a.tn;
+      const int nt = (int)(lin - mt * a.tn);
+      const int64_t m0 = mt * 256;
+      const int n0 = nt * 256;
+      const uint32_t m0_mod = a.add_mode == 1 ? (uint32_t)(m0 % a.seq_len) : 0u;     // one 64-bit modulo per tile
+      int lane_e = lane;
+      asm volatile("" : "+v"(lane_e));
+      const int fr_e = lane_e & 15, fg_e = lane_e >> 4;
+      float* patch = reinterpret_cast<float*>(smem + RING_BYTES) + wave * 1024;
+      const int orow = lane_e >> 4, ocol = (lane_e & 15) * 8;
+      const int ncol0 = n0 + wn * 128 + ocol;
+      float bv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bv[j] = (a.bias && ncol0 + j < N) ? a.bias[ncol0 + j] : 0.f;
+      // The DMA stream is inline asm, so hipcc cannot count outstanding VMEM operations and guards every use of a loaded
+      // register with s_waitcnt vmcnt(0) -- which, inside the passes below, also waits for the stores of the previous
+      // pass (a full write round trip per pass: 2/3 of the epilogue when measured).  Passing the values through an empty
+      // asm here makes that one wait happen now, once per tile; afterwards they are plain registers.
+#pragma unroll
+      for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bv[j]));
+#pragma unroll
+      for (int p = 0; p < 8; ++p) {
+        if (a.skew != 97 && (fg_e >> 1) == (p & 1)) {
+          const int prow0 = (fg_e & 1) * 4;
+#pragma unroll
+          for (int n = 0; n < 8; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              patch[(prow0 + r) * 128 + ((n * 16 + fr_e) ^ ((fg_e & 1) << 4))] = acc[p >> 1][n][r];
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          const int prow = it * 4 + orow;               // 0..7
+          const int64_t m = m0 + wm * 64 + p * 8 + prow;
+          const float* src = patch + prow * 128 + (ocol ^ (it << 4));
+          const float4 v0 = *reinterpret_cast<const float4*>(src);
+          const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+          float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if (m >= M || a.skew == 98) continue;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            v[j] += bv[j];
+            if (a.relu) v[j] = fmaxf(v[j], 0.f);
+          }
+          if (ncol0 + 8 <= N) {                         // N % 8 == 0 (eligibility): whole 8-column groups only
+            if (a.add_mode) {
+              const uint32_t arow32 = (uint32_t)(m0_mod + (uint32_t)(wm * 64 + p * 8 + prow)) % (uint32_t)a.seq_len;
+              const int64_t arow = a.add_mode == 1 ? (int64_t)arow32 : m;
+              float av[8];
+              if (sizeof(AddT) == 2) {
+                unpack16<bf16_t>(ld_global16(addend + arow * N + ncol0), av);
+              } else {
+                unpack16<float>(ld_global16(addend + arow * N + ncol0), av);
+                unpack16<float>(ld_global16(addend + arow * N + ncol0 + 4), av + 4);
+              }
+#pragma unroll
+              for (int j = 0; j < 8; ++j) v[j] += av[j];
+            }
+            if (sizeof(OutT) == 2) {
+              st_global16(out + m * N + ncol0, pack16<bf16_t>(v));
+            } else {
+              st_global16(out + m * N + ncol0, pack16<float>(v));
+              st_global16(out + m * N + ncol0 + 4, pack16<float>(v + 4));
+            }
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    if (a.skew >= 96) { const unsigned long long t = __builtin_amdgcn_s_memtime(); p_epi += t - p_t; ++p_tiles; }
+    ++c_k;
+    if (tile_of(c_k) >= a.n_tiles) break;
+  }
+  if (a.skew >= 96 && blockIdx.x == 0 && lane == 0) {
+    g_g256p_probe[wave * 4 + 0] = p_loop; g_g256p_probe[wave * 4 + 1] = p_epi; g_g256p_probe[wave * 4 + 2] = p_first;
+    g_g256p_probe[wave * 4 + 3] = p_tiles;
+  }
+  };
+  if (grp) run(std::true_type{});
+  else run(std::false_type{});
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the saturated stream still has DMAs in flight
+  __builtin_amdgcn_s_barrier();
+}
+
+template <typename T, typename OutT, typename AddT>
+static int launch_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
+                           int N, int K, int relu, int add_mode, int seq_len, hipStream_t st) {
+  G256pArgs a;
+  a.A = A; a.W = W; a.bias = bias; a.addend = addend; a.out = out;
+  a.M = M; a.N = N; a.K = K; a.relu = relu; a.add_mode = add_mode; a.seq_len = seq_len;
+  a.tn = cdiv(N, 256);
+  a.n_tiles = (int64_t)cdiv(M, 256) * a.tn;
+  extern int g_q2c_ablation;
+  a.skew = g_q2c_ablation == 21 ? 0 : g_q2c_ablation == 22 ? 10 : g_q2c_ablation == 23 ? 99 : g_q2c_ablation == 24 ? 98 : g_q2c_ablation == 25 ? 97 : g_q2c_ablation == 26 ? 96 : 5;      // (21 / 22: A/B of the start skew)
+  const int lds = 4 * 2 * 256 * 64 + 8 * 4096;          // ring + patches = 160 KiB
+  auto kern = gemm256p_kernel<T, OutT, AddT>;
+  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+    return XML_ERR_LAUNCH;
+  hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// worth it when every workgroup gets several tiles; below that the one-tile-per-workgroup kernel is as good
+bool xmli_gemm256p_eligible(int64_t M, int N, int K, int dt) {
+  const size_t kb = (size_t)K * dt_size(dt);
+  return kb % 128 == 0 && kb >= 256 && N >= 128 && N % 8 == 0 && (int64_t)cdiv(M, 256) * cdiv(N, 256) >= 1024;
+}
+
+int xmli_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
+                  int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st) {
+  if (dt == XML_F32)
+    return launch_gemm256p<float, float, float>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+  if (out_f32)
+    return launch_gemm256p<bf16_t, float, bf16_t>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+  return launch_gemm256p<bf16_t, bf16_t, bf16_t>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
+}

@@ -66,7 +66,10 @@ static int launch_gemm(const void* A, const void* W, const float* bias, const vo
 bool xmli_gemm256_eligible(int64_t M, int N, int K, int dt);
 int xmli_gemm256(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
                  int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st);
-static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 register-staged kernel
+bool xmli_gemm256p_eligible(int64_t M, int N, int K, int dt);
+int xmli_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
+                  int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st);
+static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 register-staged kernel, 2 never the persistent 256x256 one
 extern "C" void xml_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
 
 // out_f32: write f32 regardless of dt (pre-LayerNorm values keep full precision)
@@ -75,6 +78,8 @@ int xmli_gemm(const void* A, const void* W, const float* bias, const void* adden
   XML_ENTER();
   if (M <= 0 || N <= 0 || K <= 0) return XML_ERR_BAD_ARG;
   if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (g_gemm_variant == 0 && xmli_gemm256p_eligible(M, N, K, dt))
+    return xmli_gemm256p(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, out_f32, dt, st);
   if (g_gemm_variant != 1 && xmli_gemm256_eligible(M, N, K, dt))
     return xmli_gemm256(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, out_f32, dt, st);
   if (dt == XML_F32) {

@@ -46,7 +46,9 @@ template <> struct G256Init<bf16_t> {
 };
 __device__ __forceinline__ int g256_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
-template <typename T, typename OutT, typename AddT>
+// RAGGED_N: N % 8 != 0 -> per-element tail stores (kept out of the common instantiation: its 64-bit modulo and
+// per-element branches, unrolled 16 times, made the kernel 640 KB of code and the epilogue instruction-fetch bound)
+template <typename T, typename OutT, typename AddT, bool RAGGED_N = false>
 __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                          const float* __restrict__ bias,
                                                          const AddT* __restrict__ addend, OutT* __restrict__ out,
@@ -192,11 +194,26 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   __syncthreads();                                  // every wave is done reading the ring
   constexpr int PLD = 132;                          // padded patch row (floats): conflict-free column writes
   float* patch = reinterpret_cast<float*>(smem) + wave * (32 * PLD);
-  const int orow = lane >> 4, ocol = (lane & 15) * 8;
-  const int ncol0 = n0 + wn * 128 + ocol;
+  // a lane owns two groups of 4 consecutive columns of a row.  bf16 out: adjacent groups -> one 16-byte store, 16 lanes =
+  // the row's 256 bytes.  f32 out: groups 64 columns apart -> two 16-byte stores, each 16 lanes = 256 contiguous bytes
+  // (see gemm256p.hip: the CU's write path retires about one request per 5 cycles and bounds this epilogue)
+  constexpr bool F32O = sizeof(OutT) == 4;
+  const int orow = lane >> 4;
+  const int oc0 = (lane & 15) * (F32O ? 4 : 8);
+  const int oc1 = F32O ? oc0 + 64 : oc0 + 4;
+  const int nc0 = n0 + wn * 128 + oc0, nc1 = n0 + wn * 128 + oc1;
+  const bool ok0 = nc0 + 4 <= N, ok1 = nc1 + 4 <= N;
   float bv[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) bv[j] = (bias && ncol0 + j < N) ? bias[ncol0 + j] : 0.f;
+  for (int j = 0; j < 4; ++j) {
+    bv[j] = (bias && nc0 + j < N) ? bias[nc0 + j] : 0.f;
+    bv[4 + j] = (bias && nc1 + j < N) ? bias[nc1 + j] : 0.f;
+  }
+  // (inline-asm DMA: hipcc guards every use of a loaded register with s_waitcnt vmcnt(0), which inside the loop below also
+  // waits for the stores of the previous iteration; an empty asm makes that one wait happen here)
+#pragma unroll
+  for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bv[j]));
+  const uint32_t m0_mod = add_mode == 1 ? (uint32_t)(m0 % seq_len) : 0u;       // one 64-bit modulo per tile
 #pragma unroll
   for (int half = 0; half < 2; ++half) {
 #pragma unroll
@@ -209,9 +226,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 #pragma unroll
     for (int it = 0; it < 8; ++it) {
       const int prow = it * 4 + orow;               // 0..31
-      const int64_t m = m0 + wm * 64 + half * 32 + prow;
-      const float4 v0 = *reinterpret_cast<const float4*>(patch + prow * PLD + ocol);
-      const float4 v1 = *reinterpret_cast<const float4*>(patch + prow * PLD + ocol + 4);
+      const int lrow = wm * 64 + half * 32 + prow;
+      const int64_t m = m0 + lrow;
+      const float4 v0 = *reinterpret_cast<const float4*>(patch + prow * PLD + oc0);
+      const float4 v1 = *reinterpret_cast<const float4*>(patch + prow * PLD + oc1);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
       if (m >= M) continue;
 #pragma unroll
@@ -219,33 +237,38 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
         v[j] += bv[j];
         if (relu) v[j] = fmaxf(v[j], 0.f);
       }
-      if (ncol0 + 8 <= N && (N & 7) == 0) {         // full 8-column group, 16-byte aligned rows
+      const int64_t arow = add_mode == 1 ? (int64_t)((m0_mod + (uint32_t)lrow) % (uint32_t)seq_len) : m;
+      if (!RAGGED_N) {                              // N % 8 == 0: whole 4-column groups, 16-byte aligned rows
         if (add_mode) {
-          const int64_t arow = add_mode == 1 ? (m % seq_len) : m;
-          float av[8];
+          float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
           if (sizeof(AddT) == 2) {
-            unpack16<bf16_t>(ld_global16(addend + arow * N + ncol0), av);
+            uint2 u0 = make_uint2(0u, 0u), u1 = u0;
+            if (ok0) u0 = *reinterpret_cast<const uint2*>(addend + arow * N + nc0);
+            if (ok1) u1 = *reinterpret_cast<const uint2*>(addend + arow * N + nc1);
+            av[0] = __uint_as_float(u0.x << 16); av[1] = __uint_as_float(u0.x & 0xffff0000u);
+            av[2] = __uint_as_float(u0.y << 16); av[3] = __uint_as_float(u0.y & 0xffff0000u);
+            av[4] = __uint_as_float(u1.x << 16); av[5] = __uint_as_float(u1.x & 0xffff0000u);
+            av[6] = __uint_as_float(u1.y << 16); av[7] = __uint_as_float(u1.y & 0xffff0000u);
           } else {
-            unpack16<float>(ld_global16(addend + arow * N + ncol0), av);
-            unpack16<float>(ld_global16(addend + arow * N + ncol0 + 4), av + 4);
+            if (ok0) unpack16<float>(ld_global16(addend + arow * N + nc0), av);
+            if (ok1) unpack16<float>(ld_global16(addend + arow * N + nc1), av + 4);
           }
 #pragma unroll
           for (int j = 0; j < 8; ++j) v[j] += av[j];
         }
-        if (sizeof(OutT) == 2) {
-          st_global16(out + m * N + ncol0, pack16<bf16_t>(v));
-        } else {
-          st_global16(out + m * N + ncol0, pack16<float>(v));
-          st_global16(out + m * N + ncol0 + 4, pack16<float>(v + 4));
+        if (F32O) {
+          if (ok0) st_global16(out + m * N + nc0, pack16<float>(v));
+          if (ok1) st_global16(out + m * N + nc1, pack16<float>(v + 4));
+        } else if (ok1) {
+          st_global16(out + m * N + nc0, pack16<bf16_t>(v));
         }
       } else {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const int n = ncol0 + j;
+          const int n = (j < 4 ? nc0 : nc1 - 4) + j;
           if (n >= N) continue;
           float x = v[j];
-          if (add_mode == 1) x += DT<AddT>::ld(addend + (int64_t)(m % seq_len) * N + n);
-          else if (add_mode == 2) x += DT<AddT>::ld(addend + m * N + n);
+          if (add_mode) x += DT<AddT>::ld(addend + arow * N + n);
           DT<OutT>::st(out + m * N + n, x);
         }
       }
@@ -261,7 +284,7 @@ static int launch_gemm256(const void* A, const void* W, const float* bias, const
   const int64_t nsup = (int64_t)((tm + 7) / 8) * ((tn + 3) / 4);
   const unsigned grid = (unsigned)(((nsup + 7) / 8) * 8 * 32);
   const int lds = 8 * 32 * 132 * 4;     // epilogue patches (135 168 B) >= the 4 x 32 KiB ring
-  auto kern = gemm256_kernel<T, OutT, AddT>;
+  auto kern = (N & 7) ? gemm256_kernel<T, OutT, AddT, true> : gemm256_kernel<T, OutT, AddT, false>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
     return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const T*)A, (const T*)W, bias, (const AddT*)addend,

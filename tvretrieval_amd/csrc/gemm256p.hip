@@ -1,11 +1,20 @@
 // Persistent projection GEMM: the K-loop of gemm256.hip / q2c_persist.hip, one workgroup per CU walking many tiles
 // with a DMA stream that never drains.
 //   out[m][n] = act(A[m] . W[n] + bias[n]) + addend        A (M, K), W (N, K) both K-contiguous
-// Why: with one 256 x 256 tile per workgroup the encoder projections (K = 768: 24 slices) spend as long outside the
-// K loop as inside it -- T(tile) = 19.5 us + 0.81 us x slices, measured (tools/bench_gemm.py: 660-700 TF at K = 768,
-// 1060 TF at K = 3072): workgroup launch, the first DMA round trip, and an epilogue that owns the whole LDS.  Here
-// the issue side of the stream runs into the next tile while the current one finishes, and the epilogue works in 4 KiB
-// per-wave patches BESIDE the ring (160 KiB in all) while those DMAs are in flight.
+// Why: with one 256 x 256 tile per workgroup the encoder projections (K = 768: 24 slices) spent as long outside the
+// K loop as inside it -- T(tile) = 19.5 us + 0.81 us x slices (tools/bench_gemm.py: 660-700 TF at K = 768, 1060 TF at
+// K = 3072).  A timing probe in this kernel showed where: not the launch or the first DMA round trip (~1.5 us) but the
+// EPILOGUE, 34 K of 74 K cycles per tile:
+//   * 640 KB of code: the per-element tail path (N % 8 != 0) with its 64-bit modulo, unrolled 16 times, sat between the
+//     hot instructions -> instruction-fetch bound.  Now a separate instantiation of gemm256.hip; here N % 8 == 0.
+//   * software f32 -> bf16 rounding with a NaN branch per element (~25 instructions each) -> v_cvt_pk_bf16_f32.
+//   * hipcc cannot count the inline-asm DMAs and guarded every use of the bias registers with s_waitcnt vmcnt(0),
+//     which also waits for the stores just issued -> the values pass through an empty asm once per tile.
+//   * f32 rows written as 16-byte pieces at a 32-byte stride (every 128-byte line half-written per instruction, twice
+//     the write requests; the CU retires about one write request per 5 cycles) -> two column groups 64 apart.
+// What persistence itself adds: the issue side of the stream runs into the next tile while the current one finishes,
+// and the epilogue works in 4 KiB per-wave patches BESIDE the ring (160 KiB in all) while those DMAs are in flight:
+// 750-810 -> 815-865 TF at K = 768 for >= 1024 tiles (the fixes above lifted both kernels from 660-700).
 // Same MFMA sequence per accumulator as gemm256_kernel: bitwise the same results.
 #include <type_traits>
 
@@ -20,7 +29,6 @@ struct G256pArgs {
   void* out;
   int64_t M, n_tiles;
   int N, K, relu, add_mode, seq_len, tn;
-  int skew;       // start skew: phase (0..15) x skew x 1024 cycles
 };
 
 __device__ __forceinline__ void g256p_dma_pair(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
@@ -59,11 +67,6 @@ template <> struct G256pInit<bf16_t> {
   }
 };
 __device__ __forceinline__ int g256p_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
-
-__device__ unsigned long long g_g256p_probe[64];
-extern "C" int xml_debug_read_g256p_probe(unsigned long long* host_out) {
-  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_g256p_probe), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
-}
 
 template <typename T, typename OutT, typename AddT>
 __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
@@ -145,15 +148,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
     }
   };
   if (tile_of(0) >= a.n_tiles) return;
-  if (a.skew == 96 && blockIdx.x >= 32) return;      // probe: only 32 workgroups run
-  // De-phase the workgroups.  All tiles take the same time, so 256 workgroups started together reach their epilogues
-  // together and write 32 MB in one burst, then nobody writes for a whole K loop -- and on gfx9 stores count in vmcnt, so
-  // every wave sits in the next tile's first counted wait until its stores have drained (measured: 19.6 us per tile
-  // outside the K loop, whatever K).  A one-off start skew of up to about one tile period spreads the writes evenly.
-  if (a.skew && a.skew < 96) {
-    const int ph = (blockIdx.x >> 3) & 15;
-    for (int i = 0; i < ph * a.skew; ++i) __builtin_amdgcn_s_sleep(16);      // 1024 cycles each
-  }
   setup_issue_tile();
 
   // ---- compute side ---------------------------------------------------------------------------------------------
@@ -171,12 +165,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 #pragma unroll
   for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(smem + b_off + n * 16 * ROWB);
 
-  unsigned long long p_loop = 0, p_epi = 0, p_first = 0, p_t = 0, p_tiles = 0;
   auto run = [&](auto grp_tag) {
   constexpr bool GRP1 = decltype(grp_tag)::value;
   for (;;) {      // one iteration = one tile
     f32x4 acc[4][8];
-    if (a.skew >= 96) p_t = __builtin_amdgcn_s_memtime();
     auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4], auto init_tag) {
       constexpr bool INIT = decltype(init_tag)::value;
       const char* slot = smem + c_slot * SLOT_BYTES;
@@ -213,14 +205,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       if (GRP1) { next_reads(); issue_slice(); }
     };
     slice_step(faA, faB, std::true_type{});
-    if (a.skew >= 96) { const unsigned long long t = __builtin_amdgcn_s_memtime(); p_first += t - p_t; }
     slice_step(faB, faA, std::false_type{});
     for (int s2 = 2; s2 < n_slices; s2 += 2) {
       slice_step(faA, faB, std::false_type{});
       slice_step(faB, faA, std::false_type{});
     }
 
-    if (a.skew >= 96) { const unsigned long long t = __builtin_amdgcn_s_memtime(); p_loop += t - p_t; p_t = t; }
     // ---- epilogue: 8 rows x 128 columns of f32 at a time through this wave's 4 KiB patch -> 16-byte coalesced stores
     // (an MFMA accumulator holds 4 rows x 1 column per lane).  Pass p covers tile rows 8 p .. 8 p + 7: the two lane
     // groups fg = 2 (p & 1), 2 (p & 1) + 1 of row block p >> 1.  Patch column XOR 16 for rows 4..7: the two groups
@@ -236,20 +226,31 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       asm volatile("" : "+v"(lane_e));
       const int fr_e = lane_e & 15, fg_e = lane_e >> 4;
       float* patch = reinterpret_cast<float*>(smem + RING_BYTES) + wave * 1024;
-      const int orow = lane_e >> 4, ocol = (lane_e & 15) * 8;
-      const int ncol0 = n0 + wn * 128 + ocol;
+      // a lane owns two groups of 4 consecutive columns of a row.  bf16 out: adjacent groups -> one 16-byte store, 16
+      // lanes = the row's 256 bytes.  f32 out: groups 64 columns apart -> two 16-byte stores, each again 16 lanes =
+      // 256 contiguous bytes (adjacent groups would leave every 128-byte line half-written per instruction: twice the
+      // write requests, and the CU's write path retires about one request per 5 cycles -- it is what bounds this epilogue)
+      constexpr bool F32O = sizeof(OutT) == 4;
+      const int orow = lane_e >> 4;
+      const int oc0 = (lane_e & 15) * (F32O ? 4 : 8);
+      const int oc1 = F32O ? oc0 + 64 : oc0 + 4;
+      const int nc0 = n0 + wn * 128 + oc0, nc1 = n0 + wn * 128 + oc1;
+      const bool ok0 = nc0 + 4 <= N, ok1 = nc1 + 4 <= N;           // N % 8 == 0 (eligibility): whole groups only
       float bv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bv[j] = (a.bias && ncol0 + j < N) ? a.bias[ncol0 + j] : 0.f;
+      {
+        float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+        if (a.bias && ok0) b0 = *reinterpret_cast<const float4*>(a.bias + nc0);
+        if (a.bias && ok1) b1 = *reinterpret_cast<const float4*>(a.bias + nc1);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+      }
       // The DMA stream is inline asm, so hipcc cannot count outstanding VMEM operations and guards every use of a loaded
       // register with s_waitcnt vmcnt(0) -- which, inside the passes below, also waits for the stores of the previous
-      // pass (a full write round trip per pass: 2/3 of the epilogue when measured).  Passing the values through an empty
-      // asm here makes that one wait happen now, once per tile; afterwards they are plain registers.
+      // pass.  Passing the values through an empty asm here makes that one wait happen now, once per tile.
 #pragma unroll
       for (int j = 0; j < 8; ++j) asm volatile("" : "+v"(bv[j]));
 #pragma unroll
       for (int p = 0; p < 8; ++p) {
-        if (a.skew != 97 && (fg_e >> 1) == (p & 1)) {
+        if ((fg_e >> 1) == (p & 1)) {
           const int prow0 = (fg_e & 1) * 4;
 #pragma unroll
           for (int n = 0; n < 8; ++n)
@@ -262,50 +263,48 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           const int prow = it * 4 + orow;               // 0..7
-          const int64_t m = m0 + wm * 64 + p * 8 + prow;
-          const float* src = patch + prow * 128 + (ocol ^ (it << 4));
-          const float4 v0 = *reinterpret_cast<const float4*>(src);
-          const float4 v1 = *reinterpret_cast<const float4*>(src + 4);
+          const int lrow = wm * 64 + p * 8 + prow;
+          const int64_t m = m0 + lrow;
+          const float4 v0 = *reinterpret_cast<const float4*>(patch + prow * 128 + (oc0 ^ (it << 4)));
+          const float4 v1 = *reinterpret_cast<const float4*>(patch + prow * 128 + (oc1 ^ (it << 4)));
           float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-          if (m >= M || a.skew == 98) continue;
+          if (m >= M) continue;
 #pragma unroll
           for (int j = 0; j < 8; ++j) {
             v[j] += bv[j];
             if (a.relu) v[j] = fmaxf(v[j], 0.f);
           }
-          if (ncol0 + 8 <= N) {                         // N % 8 == 0 (eligibility): whole 8-column groups only
-            if (a.add_mode) {
-              const uint32_t arow32 = (uint32_t)(m0_mod + (uint32_t)(wm * 64 + p * 8 + prow)) % (uint32_t)a.seq_len;
-              const int64_t arow = a.add_mode == 1 ? (int64_t)arow32 : m;
-              float av[8];
-              if (sizeof(AddT) == 2) {
-                unpack16<bf16_t>(ld_global16(addend + arow * N + ncol0), av);
-              } else {
-                unpack16<float>(ld_global16(addend + arow * N + ncol0), av);
-                unpack16<float>(ld_global16(addend + arow * N + ncol0 + 4), av + 4);
-              }
-#pragma unroll
-              for (int j = 0; j < 8; ++j) v[j] += av[j];
-            }
-            if (sizeof(OutT) == 2) {
-              st_global16(out + m * N + ncol0, pack16<bf16_t>(v));
+          if (a.add_mode) {
+            const int64_t arow = a.add_mode == 1 ? (int64_t)((m0_mod + (uint32_t)lrow) % (uint32_t)a.seq_len) : m;
+            float av[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            if (sizeof(AddT) == 2) {
+              uint2 u0 = make_uint2(0u, 0u), u1 = u0;
+              if (ok0) u0 = *reinterpret_cast<const uint2*>(addend + arow * N + nc0);
+              if (ok1) u1 = *reinterpret_cast<const uint2*>(addend + arow * N + nc1);
+              av[0] = __uint_as_float(u0.x << 16); av[1] = __uint_as_float(u0.x & 0xffff0000u);
+              av[2] = __uint_as_float(u0.y << 16); av[3] = __uint_as_float(u0.y & 0xffff0000u);
+              av[4] = __uint_as_float(u1.x << 16); av[5] = __uint_as_float(u1.x & 0xffff0000u);
+              av[6] = __uint_as_float(u1.y << 16); av[7] = __uint_as_float(u1.y & 0xffff0000u);
             } else {
-              st_global16(out + m * N + ncol0, pack16<float>(v));
-              st_global16(out + m * N + ncol0 + 4, pack16<float>(v + 4));
+              if (ok0) unpack16<float>(ld_global16(addend + arow * N + nc0), av);
+              if (ok1) unpack16<float>(ld_global16(addend + arow * N + nc1), av + 4);
             }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += av[j];
+          }
+          if (F32O) {
+            if (ok0) st_global16(out + m * N + nc0, pack16<float>(v));
+            if (ok1) st_global16(out + m * N + nc1, pack16<float>(v + 4));
+          } else if (ok1) {                               // (ok1 implies ok0; N % 8 == 0)
+            st_global16(out + m * N + nc0, pack16<bf16_t>(v));
           }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
       }
     }
-    if (a.skew >= 96) { const unsigned long long t = __builtin_amdgcn_s_memtime(); p_epi += t - p_t; ++p_tiles; }
     ++c_k;
     if (tile_of(c_k) >= a.n_tiles) break;
-  }
-  if (a.skew >= 96 && blockIdx.x == 0 && lane == 0) {
-    g_g256p_probe[wave * 4 + 0] = p_loop; g_g256p_probe[wave * 4 + 1] = p_epi; g_g256p_probe[wave * 4 + 2] = p_first;
-    g_g256p_probe[wave * 4 + 3] = p_tiles;
   }
   };
   if (grp) run(std::true_type{});
@@ -322,8 +321,6 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
   a.M = M; a.N = N; a.K = K; a.relu = relu; a.add_mode = add_mode; a.seq_len = seq_len;
   a.tn = cdiv(N, 256);
   a.n_tiles = (int64_t)cdiv(M, 256) * a.tn;
-  extern int g_q2c_ablation;
-  a.skew = g_q2c_ablation == 21 ? 0 : g_q2c_ablation == 22 ? 10 : g_q2c_ablation == 23 ? 99 : g_q2c_ablation == 24 ? 98 : g_q2c_ablation == 25 ? 97 : g_q2c_ablation == 26 ? 96 : 5;      // (21 / 22: A/B of the start skew)
   const int lds = 4 * 2 * 256 * 64 + 8 * 4096;          // ring + patches = 160 KiB
   auto kern = gemm256p_kernel<T, OutT, AddT>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -336,7 +333,7 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
 // worth it when every workgroup gets several tiles; below that the one-tile-per-workgroup kernel is as good
 bool xmli_gemm256p_eligible(int64_t M, int N, int K, int dt) {
   const size_t kb = (size_t)K * dt_size(dt);
-  return kb % 128 == 0 && kb >= 256 && N >= 128 && N % 8 == 0 && (int64_t)cdiv(M, 256) * cdiv(N, 256) >= 1024;
+  return kb % 128 == 0 && kb >= 256 && N >= 128 && N % 8 == 0 && (int64_t)cdiv(M, 256) * cdiv(N, 256) >= 3072;   // (2304 tiles: 2 % behind the one-tile kernel, 3516: 7 % ahead)
 }
 
 int xmli_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,

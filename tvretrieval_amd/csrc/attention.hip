@@ -46,15 +46,36 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
   const T* vbase = Vp + (int64_t)n * lk * ldv + head * DH;
 
   // ---- stage K rows ------------------------------------------------------------------------------
+  // All global loads of a tile are issued before the first LDS store (register batch): written as load -> store per
+  // iteration, hipcc serialised them (one s_waitcnt vmcnt(0) per 16-byte load: 12 memory round trips for K, 12 for V, 6
+  // per query tile -- most of this kernel's time).  V does not depend on the scores: it is fetched here as well and lands
+  // while phase A runs.
+  constexpr int VPR = DH / VEC;                // 16-byte vectors per row
+  constexpr int NVB = 128 * VPR / 256;         // vectors per thread of a full 128-row tile
   {
     const int rows16 = (lk + 15) / 16 * 16;
-    constexpr int VPR = DH / VEC;  // 16-byte vectors per row
-    for (int i = tid; i < rows16 * VPR; i += 256) {
+    uint4 kb[NVB];
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int i = tid + j * 256;
       const int r = i / VPR, c = i % VPR;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (r < lk) v = ld_global16(kbase + (int64_t)r * ldk + c * VEC);
-      *reinterpret_cast<uint4*>(s_kv + r * k_stride + c * 16) = v;
+      kb[j] = make_uint4(0, 0, 0, 0);
+      if (r < lk) kb[j] = ld_global16(kbase + (int64_t)r * ldk + c * VEC);
     }
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int i = tid + j * 256;
+      const int r = i / VPR, c = i % VPR;
+      if (r < rows16) *reinterpret_cast<uint4*>(s_kv + r * k_stride + c * 16) = kb[j];
+    }
+  }
+  uint4 vb[NVB];
+#pragma unroll
+  for (int j = 0; j < NVB; ++j) {
+    const int i = tid + j * 256;
+    const int r = i / VPR, c = i % VPR;
+    vb[j] = make_uint4(0, 0, 0, 0);
+    if (r < lk) vb[j] = ld_global16(vbase + (int64_t)r * ldv + c * VEC);
   }
   __syncthreads();
 
@@ -68,15 +89,19 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
     for (int j = 0; j < MAXNT; ++j) p[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (qt >= nqt) continue;
     const int qrow = qt * 16 + fr;
+    uint4 qa[DCH];
 #pragma unroll
     for (int c = 0; c < DCH; ++c) {
-      uint4 a = make_uint4(0, 0, 0, 0);
-      if (qrow < lq) a = ld_global16(qbase + (int64_t)qrow * ldq + c * CE + fg * VEC);
+      qa[c] = make_uint4(0, 0, 0, 0);
+      if (qrow < lq) qa[c] = ld_global16(qbase + (int64_t)qrow * ldq + c * CE + fg * VEC);
+    }
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
 #pragma unroll
       for (int j = 0; j < MAXNT; ++j) {
         if (j < nkt) {
           const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
-          Mma<T>::chunk(p[t][j], a, b);
+          Mma<T>::chunk(p[t][j], qa[c], b);
         }
       }
     }
@@ -115,22 +140,19 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
   }
   __syncthreads();
 
-  // ---- stage V^T (overwrites K) -------------------------------------------------------------------
+  // ---- stage V^T (overwrites K) from the registers fetched above -----------------------------------
   {
-    constexpr int VPR = DH / VEC;
-    for (int i = tid; i < lkp * VPR; i += 256) {
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int i = tid + j * 256;
       const int r = i / VPR, c = i % VPR;  // key r, dh vector c
-      float vals[VEC];
-      if (r < lk) {
-        const uint4 v = ld_global16(vbase + (int64_t)r * ldv + c * VEC);
-        unpack16<T>(v, vals);
-      } else {
+      if (r < lkp) {
+        float vals[VEC];
+        unpack16<T>(vb[j], vals);
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) vals[e] = 0.f;
+        for (int e = 0; e < VEC; ++e)
+          DT<T>::st(reinterpret_cast<T*>(s_kv + (c * VEC + e) * vt_stride) + r, vals[e]);
       }
-#pragma unroll
-      for (int e = 0; e < VEC; ++e)
-        DT<T>::st(reinterpret_cast<T*>(s_kv + (c * VEC + e) * vt_stride) + r, vals[e]);
     }
   }
   __syncthreads();

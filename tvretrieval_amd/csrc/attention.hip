@@ -258,7 +258,17 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
       *reinterpret_cast<uint4*>(s_kv + r * k_stride + c * 16) = buf[j];
     }
   }
-  // V is independent of the scores: fetch it now, it arrives while phase A runs
+  // Q fragments of both query tiles and V (independent of the scores): fetched now, they arrive while K is staged /
+  // phase A runs
+  uint4 qa[2][DCH];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      const int qrow = t * 16 + fr;
+      qa[t][c] = make_uint4(0, 0, 0, 0);
+      if (qrow < lq) qa[t][c] = ld_global16(qbase + (int64_t)qrow * ldq + c * CE + fg * VEC);
+    }
   uint4 vbuf[NV];
 #pragma unroll
   for (int j = 0; j < NV; ++j) {
@@ -282,16 +292,13 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
 #pragma unroll
     for (int j = 0; j < NT; ++j) p[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (t >= nqt) continue;
-    const int qrow = t * 16 + fr;
 #pragma unroll
     for (int c = 0; c < DCH; ++c) {
-      uint4 a = make_uint4(0, 0, 0, 0);
-      if (qrow < lq) a = ld_global16(qbase + (int64_t)qrow * ldq + c * CE + fg * VEC);
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
         if (j < nkt) {
           const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
-          Mma<T>::chunk(p[t][j], a, b);
+          Mma<T>::chunk(p[t][j], qa[t][c], b);
         }
       }
     }

@@ -606,10 +606,13 @@ __global__ __launch_bounds__(256) void modular_pool_small_kernel(const T* __rest
       w1[k * 8 + j] = (v < nvec && n_mod > 1) ? wm[hidden + v * 8 + j] : 0.f;
     }
   }
+  // every token row of this wave and its mask value first, as one batch of loads (written load -> use per token, hipcc
+  // waited for each 16-byte load in turn: 16 memory round trips per workgroup, most of this kernel's time)
+  float mk8[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int l = wave + t * 4;
-    float s0 = 0.f, s1 = 0.f;
+    mk8[t] = l < lq ? mask[(int64_t)q * lq + l] : 0.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int v = lane + k * 64;
@@ -617,24 +620,38 @@ __global__ __launch_bounds__(256) void modular_pool_small_kernel(const T* __rest
       else
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[t][k * 8 + j] = 0.f;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int l = wave + t * 4;
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) { s0 += x[t][k * 8 + j] * w0[k * 8 + j]; s1 += x[t][k * 8 + j] * w1[k * 8 + j]; }
     }
     s0 = wave_sum(s0);
     s1 = wave_sum(s1);
     if (lane == 0 && l < lq) {
-      const float mk = mask[(int64_t)q * lq + l];
+      const float mk = mk8[t];
       s_att[0][l] = s0 * mk + (1.f - mk) * -1e10f;   // mask_logits, xml/model_xml.py:640-641
       s_att[1][l] = s1 * mk + (1.f - mk) * -1e10f;
     }
   }
   __syncthreads();
-  if (tid < n_mod) {
-    float mx = -INFINITY;
-    for (int l = 0; l < lq; ++l) mx = fmaxf(mx, s_att[tid][l]);
-    float sum = 0.f;
-    for (int l = 0; l < lq; ++l) { const float ev = expf(s_att[tid][l] - mx); s_att[tid][l] = ev; sum += ev; }
-    for (int l = 0; l < lq; ++l) s_att[tid][l] /= sum;
+  if (tid < 64) {                      // softmax over the tokens: lanes 0-31 modality 0, lanes 32-63 modality 1
+    const int m = tid >> 5, l = tid & 31;
+    const bool on = m < n_mod && l < lq;
+    const float sv = on ? s_att[m][l] : -INFINITY;
+    float mx = sv;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));     // within each 32-lane half
+    const float ev = on ? expf(sv - mx) : 0.f;
+    float sum = ev;
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    if (on) s_att[m][l] = ev / sum;
   }
   __syncthreads();
   float a0[16], a1[16];

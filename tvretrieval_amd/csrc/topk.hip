@@ -44,10 +44,16 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   constexpr int NK = VPT > 0 ? VPT : SAMPLE / 256;
   const int n_reg = VPT > 0 ? n : min(n, SAMPLE);
   uint32_t keys[NK];
+  {   // all loads first, then the conversions: written as load -> convert per element, hipcc waits for each load in turn
+    float raw[NK];
 #pragma unroll
-  for (int j = 0; j < NK; ++j) {
-    const int i = tid + j * 256;
-    keys[j] = i < n_reg ? ord_key(row[i]) : 0u;     // 0 sorts below every real key (ord_key(x) >= 1 for finite / inf x)
+    for (int j = 0; j < NK; ++j) {
+      const int i = tid + j * 256;
+      raw[j] = i < n_reg ? row[i] : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < NK; ++j)
+      keys[j] = tid + j * 256 < n_reg ? ord_key(raw[j]) : 0u;   // 0 sorts below every real key (ord_key(x) >= 1)
   }
   enum { SRC_REG = 0, SRC_ROW = 1, SRC_CAND = 2 };
   int src = VPT > 0 ? SRC_REG : SRC_ROW;
@@ -58,9 +64,18 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
 #pragma unroll
       for (int j = 0; j < NK; ++j) f(keys[j], tid + j * 256, tid + j * 256 < n_reg);
     } else if (src == SRC_ROW) {
-      for (int base = 0; base < n; base += 256) {
-        const int i = base + tid;
-        f(i < n ? ord_key(row[i]) : 0u, i, i < n);
+      for (int base = 0; base < n; base += 256 * 8) {        // eight loads in flight per thread (see above)
+        float raw[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * 256 + tid;
+          raw[u] = i < n ? row[i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int i = base + u * 256 + tid;
+          if (base + u * 256 < n) f(i < n ? ord_key(raw[u]) : 0u, i, i < n);      // (wave-uniform condition)
+        }
       }
     } else {
       for (int base = 0; base < n_cand; base += 256) {

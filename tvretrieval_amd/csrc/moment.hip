@@ -139,14 +139,21 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     if (s < 64) { olo = wrap ? from_hi : from_lo; ohi = wrap ? 0.f : from_hi; }
     else { olo = wrap ? 0.f : from_hi; ohi = 0.f; }
   };
-  // (a_lo, a_hi) = st * w and the window maxima of ed for this lane's two start clips of pair r
-  auto pair_rows = [&](int r, float wv, float& a_lo, float& a_hi, float& m_lo, float& m_hi) {
+  // raw (st_lo, st_hi, ed_lo, ed_hi) of pair r for this lane's two start clips
+  auto pair_load = [&](int r, float (&raw)[4]) {
     const float* sp = gst + r * lpad;
     const float* ep = ged + r * lpad;
     const bool in_lo = lane < l_ref, in_hi = lane + 64 < l_ref;
-    a_lo = in_lo ? sp[lane] * wv : 0.f;
-    a_hi = in_hi ? sp[lane + 64] * wv : 0.f;
-    float lo = in_lo ? ep[lane] : 0.f, hi = in_hi ? ep[lane + 64] : 0.f;
+    raw[0] = in_lo ? sp[lane] : 0.f;
+    raw[1] = in_hi ? sp[lane + 64] : 0.f;
+    raw[2] = in_lo ? ep[lane] : 0.f;
+    raw[3] = in_hi ? ep[lane + 64] : 0.f;
+  };
+  // (a_lo, a_hi) = st * w and the row maxima (a * window maximum of ed) from the raw values
+  auto pair_eval = [&](const float (&raw)[4], float wv, float& a_lo, float& a_hi, float& m_lo, float& m_hi) {
+    a_lo = raw[0] * wv;
+    a_hi = raw[1] * wv;
+    float lo = raw[2], hi = raw[3];
     int p = 1;
     while (2 * p <= band) {                                // window width p -> 2 p
       float slo, shi;
@@ -163,16 +170,36 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     m_lo = fmaxf(a_lo * lo, 0.f);
     m_hi = fmaxf(a_hi * hi, 0.f);
   };
+  auto pair_rows = [&](int r, float wv, float& a_lo, float& a_hi, float& m_lo, float& m_hi) {
+    float raw[4];
+    pair_load(r, raw);
+    pair_eval(raw, wv, a_lo, a_hi, m_lo, m_hi);
+  };
+  // walk this wave's active pairs, FOUR at a time: the 16 loads of a group are issued before the first one is used
+  // (one pair per iteration meant one memory round trip per pair: 25 in a row per pass at k = 100)
+  auto for_pairs = [&](auto&& body) {
+    for (int t0 = 0; t0 < n_t; t0 += 4) {
+      float raw[4][4], wv4[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int r = wave + (t0 + g) * 4;
+        wv4[g] = (t0 + g < n_t) ? pair_w(r) : 0.f;
+        if (wv4[g] != 0.f) pair_load(r, raw[g]);
+        else raw[g][0] = raw[g][1] = raw[g][2] = raw[g][3] = 0.f;
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        if (wv4[g] == 0.f) continue;                       // w == 0: skipped pair (other rank / padding)
+        float a2[2], m2[2];
+        pair_eval(raw[g], wv4[g], a2[0], a2[1], m2[0], m2[1]);
+        body(wave + (t0 + g) * 4, a2, m2);
+      }
+    }
+  };
 
   // ---- 2+3. ONE histogram pass over the row maxima on bits [30:20] (8 exponent + 3 mantissa bits); the lower edge
   //           of the bin holding the n_out-th largest row maximum is a lower bound of the n_out-th best score ------
-#pragma unroll 2
-  for (int t = 0; t < n_t; ++t) {
-    const int r = wave + t * 4;
-    const float wv = pair_w(r);
-    if (wv == 0.f) continue;
-    float a2[2], m2[2];
-    pair_rows(r, wv, a2[0], a2[1], m2[0], m2[1]);
+  for_pairs([&](int r, const float (&a2)[2], const float (&m2)[2]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const float m = m2[h];
@@ -188,7 +215,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
         atomicAdd(&s_hist[bin], 1u);
       }
     }
-  }
+  });
   __syncthreads();
   if (tid < 64) {                                          // wave 0: suffix scan, 32 bins per lane
     uint32_t local = 0;
@@ -223,13 +250,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     //     and the overflow refinement).  Expanding rows in place costs ~14 ballot/atomic iterations per 64-row block
     //     with typically 1-2 live rows in it: that was most of this kernel's time.
     unsigned long long* s_rows = reinterpret_cast<unsigned long long*>(s_hist);   // [1024]: (a bits << 32) | row id
-#pragma unroll 2
-    for (int t = 0; t < n_t; ++t) {
-      const int r = wave + t * 4;
-      const float wv = pair_w(r);
-      if (wv == 0.f) continue;
-      float a2[2], m2[2];
-      pair_rows(r, wv, a2[0], a2[1], m2[0], m2[1]);
+    for_pairs([&](int r, const float (&a2)[2], const float (&m2)[2]) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int i = lane + h * 64;
@@ -245,7 +266,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
         if (row_on && slot < 1024u)
           s_rows[slot] = ((unsigned long long)__float_as_uint(a) << 32) | (unsigned long long)(uint32_t)(r * l_ref + i);
       }
-    }
+    });
     __syncthreads();
     const uint32_t n_rows = sh.need;
     if (n_rows <= 1024u) {

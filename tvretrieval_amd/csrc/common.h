@@ -148,6 +148,16 @@ __device__ __forceinline__ float lane16_sum(float v) {
 }
 
 __device__ __forceinline__ uint4 ld_global16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+// 16-byte load through an explicit GLOBAL pointer.  A pointer that reaches a kernel inside a by-value struct, or comes
+// out of a lambda that may return nullptr, is a generic ("flat") pointer to hipcc; a load through it that also sits in a
+// `cond ? load : zero` select was emitted as FOUR flat_load_dword (4 x the instructions, each touching 64 x 4 bytes at a
+// 16-byte stride) -- this is what every user of gemm_mainloop was running on.  p must be a valid global address.
+typedef unsigned int xml_u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 ld_global16_as1(const void* p) {
+  const xml_u32x4_t v = *reinterpret_cast<const __attribute__((address_space(1))) xml_u32x4_t*>(
+      reinterpret_cast<uintptr_t>(p));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ void st_global16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

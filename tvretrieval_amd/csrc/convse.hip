@@ -133,7 +133,7 @@ struct ConvseArgs {
 };
 
 template <typename T>
-__global__ __launch_bounds__(256) void convse_kernel(ConvseArgs a) {
+__global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 3 waves per SIMD: <= 168 VGPRs
   using Cfg = GemmCfg<T, TM, 128, 1, 4>;
   // dynamic LDS: [ GEMM staging | similarity patches ].  With ONE similarity patch (merged streams or a single
   // modality) the patch is written once after the last GEMM and overlays the staging area (49 KiB -> 3 workgroups

@@ -30,6 +30,12 @@ struct GemmCfg {
   static_assert(BM % ROWS_PER_PASS == 0 && BN % ROWS_PER_PASS == 0, "tile/threads mismatch");
 };
 
+// v or zero, component-wise (a `c ? v : zero` on the 16-byte struct makes hipcc select between two ADDRESSES and park
+// both operands in scratch memory)
+__device__ __forceinline__ uint4 keep16(bool c, const uint4& v) {
+  return make_uint4(c ? v.x : 0u, c ? v.y : 0u, c ? v.z : 0u, c ? v.w : 0u);
+}
+
 __device__ __forceinline__ int lds_slot_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
 // a_row(m) / b_row(n): return the byte pointer of tile-local row m / n, or nullptr when out of range
@@ -44,12 +50,25 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
   const int lrow = tid >> 3;   // row within a pass
   const int lslot = tid & 7;   // 16-byte slot within the 128-byte segment
 
-  const char* ap[Cfg::A_PASSES];
-  const char* bp[Cfg::B_PASSES];
+  // Row pointers.  Out-of-range rows / K tails load from a valid stand-in address and are zeroed when they are written
+  // to LDS: an unconditional 16-byte GLOBAL load (see ld_global16_as1) instead of a predicated generic one.  The stand-in
+  // is row 0 of either operand (precondition: valid for at least one of them -- true for every tile the callers launch).
+  const char* const safe = a_row(0) ? a_row(0) : b_row(0);
+  const char* aps[Cfg::A_PASSES];
+  const char* bps[Cfg::B_PASSES];
+  uint32_t row_ok = 0;                       // bit i: A pass i valid, bit 16 + i: B pass i valid
 #pragma unroll
-  for (int i = 0; i < Cfg::A_PASSES; ++i) ap[i] = a_row(lrow + i * Cfg::ROWS_PER_PASS);
+  for (int i = 0; i < Cfg::A_PASSES; ++i) {
+    const char* p = a_row(lrow + i * Cfg::ROWS_PER_PASS);
+    if (p) row_ok |= 1u << i;
+    aps[i] = p ? p : safe;
+  }
 #pragma unroll
-  for (int i = 0; i < Cfg::B_PASSES; ++i) bp[i] = b_row(lrow + i * Cfg::ROWS_PER_PASS);
+  for (int i = 0; i < Cfg::B_PASSES; ++i) {
+    const char* p = b_row(lrow + i * Cfg::ROWS_PER_PASS);
+    if (p) row_ok |= 1u << (16 + i);
+    bps[i] = p ? p : safe;
+  }
 
   if (ZERO_INIT) {
 #pragma unroll
@@ -60,13 +79,18 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
 
   uint4 ra[Cfg::A_PASSES], rb[Cfg::B_PASSES];
   const uint4 zero = make_uint4(0, 0, 0, 0);
+  bool kin_loaded = true;
   auto gload = [&](int step) {
     const int off = step * Cfg::ROWB + lslot * 16;
     const bool kin = off < k_bytes;
+    const int offc = kin ? off : 0;
+    // raw loads only: the zeroing of invalid rows happens in lstore, where the values are consumed anyway (a select
+    // here would make hipcc wait for the loads right away and lose the overlap with this step's MFMAs)
 #pragma unroll
-    for (int i = 0; i < Cfg::A_PASSES; ++i) ra[i] = (kin && ap[i]) ? ld_global16(ap[i] + off) : zero;
+    for (int i = 0; i < Cfg::A_PASSES; ++i) ra[i] = ld_global16_as1(aps[i] + offc);
 #pragma unroll
-    for (int i = 0; i < Cfg::B_PASSES; ++i) rb[i] = (kin && bp[i]) ? ld_global16(bp[i] + off) : zero;
+    for (int i = 0; i < Cfg::B_PASSES; ++i) rb[i] = ld_global16_as1(bps[i] + offc);
+    kin_loaded = kin;
   };
   auto lstore = [&](int stage) {
     char* sa = smem + stage * Cfg::STAGE_BYTES;
@@ -74,12 +98,12 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
 #pragma unroll
     for (int i = 0; i < Cfg::A_PASSES; ++i) {
       const int r = lrow + i * Cfg::ROWS_PER_PASS;
-      *reinterpret_cast<uint4*>(sa + lds_slot_off(r, lslot)) = ra[i];
+      *reinterpret_cast<uint4*>(sa + lds_slot_off(r, lslot)) = keep16(kin_loaded && ((row_ok >> i) & 1u), ra[i]);
     }
 #pragma unroll
     for (int i = 0; i < Cfg::B_PASSES; ++i) {
       const int r = lrow + i * Cfg::ROWS_PER_PASS;
-      *reinterpret_cast<uint4*>(sb + lds_slot_off(r, lslot)) = rb[i];
+      *reinterpret_cast<uint4*>(sb + lds_slot_off(r, lslot)) = keep16(kin_loaded && ((row_ok >> (16 + i)) & 1u), rb[i]);
     }
   };
 

@@ -18,11 +18,14 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
   const int64_t yoff = (int64_t)blockIdx.z * cols * ld_out;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  T v[4];                    // the four loads first, then the LDS stores (hipcc otherwise waits for each load in turn)
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int r = r0 + ty + i * 8, c = c0 + tx;
-    if (r < rows && c < cols) tile[ty + i * 8][tx] = x[boff + (int64_t)r * cols + c];
+    v[i] = (r < rows && c < cols) ? x[boff + (int64_t)r * cols + c] : T(0);
   }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) tile[ty + i * 8][tx] = v[i];
   __syncthreads();
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -58,7 +61,15 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
   float s = 0.f;
-  for (int64_t r = r0; r < r1; ++r) s += DT<T>::ld(x + r * cols + c);
+  int64_t r = r0;
+  for (; r + 8 <= r1; r += 8) {      // eight loads in flight, summed in row order (same result as the plain loop)
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = DT<T>::ld(x + (r + u) * cols + c);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];
+  }
+  for (; r < r1; ++r) s += DT<T>::ld(x + r * cols + c);
   atomicAdd(out + c, s);
 }
 

@@ -63,11 +63,11 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
   float s = 0.f;
   int64_t r = r0;
   for (; r + 8 <= r1; r += 8) {      // eight loads in flight, summed in row order (same result as the plain loop)
-    float v[8];
+    T v[8];                            // raw loads; converted only after all eight are issued
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = DT<T>::ld(x + (r + u) * cols + c);
+    for (int u = 0; u < 8; ++u) v[u] = x[(r + u) * cols + c];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) s += v[u];
+    for (int u = 0; u < 8; ++u) s += DT<T>::ld(&v[u]);
   }
   for (; r < r1; ++r) s += DT<T>::ld(x + r * cols + c);
   atomicAdd(out + c, s);

@@ -421,3 +421,21 @@ def test_fused_qkv_self_attention():
     args = [x, ws[0], bs[0], ws[1], bs[1], ws[2], bs[2]]
     # the key bias has an analytically zero gradient (softmax is shift invariant): only rounding noise on both sides
     run_pair(hip, ref, args, [True, True, True, True, False, True, True], tol=5e-5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(1, 768, 768), (3, 104, 200), (1, 12800, 768), (2, 64, 64), (1, 50, 70),
+                                   (2, 72, 3072), (1, 8, 8)])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_transpose_batched_layouts(shape, dtype):
+    """both transpose kernels (2-byte 32 x 32 tiles; 16-byte 64 x 64 tiles for bf16 shapes that are multiples of 8),
+    with and without a padded output row"""
+    from tvretrieval_amd import train_ops as T
+    b, r, c = shape
+    x = torch.randn(b, r, c, device="cuda").to(dtype)
+    y = T.transpose(x)
+    assert torch.equal(y, x.transpose(1, 2).contiguous())
+    ld = (r + 15) // 8 * 8 + 8
+    z = T.transpose(x, ld_out=ld)
+    assert z.shape == (b, c, ld)
+    assert torch.equal(z[:, :, :r], x.transpose(1, 2)) and float(z[:, :, r:].float().abs().max()) == 0.0

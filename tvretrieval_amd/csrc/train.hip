@@ -34,11 +34,58 @@ __global__ __launch_bounds__(256) void transpose_kernel(const T* __restrict__ x,
   }
 }
 
+// bf16, every dimension a multiple of 8: 64 x 64 tiles moved with 16-byte global accesses on both sides (the 32 x 32
+// kernel above moves 2 bytes per lane: 64 write requests per store instruction on a write path that retires one request
+// per ~5 cycles).  LDS rows are 132 bytes: the 4-byte writes of a row vector and the 2-byte column reads are both
+// conflict-free.
+__global__ __launch_bounds__(256) void transpose64_bf16_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y,
+                                                               int rows, int cols, int ld_out) {
+  __shared__ uint32_t tile[64 * 33];
+  const int64_t boff = (int64_t)blockIdx.z * rows * cols;
+  const int64_t yoff = (int64_t)blockIdx.z * cols * ld_out;
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  uint4 in[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                      // both loads first
+    const int v = threadIdx.x + j * 256;
+    const int r = v >> 3, c8 = v & 7;
+    in[j] = make_uint4(0u, 0u, 0u, 0u);
+    if (r0 + r < rows && c0 + c8 * 8 < cols) in[j] = ld_global16(x + boff + (int64_t)(r0 + r) * cols + c0 + c8 * 8);
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int v = threadIdx.x + j * 256;
+    const int r = v >> 3, c8 = v & 7;
+    uint32_t* d = tile + r * 33 + c8 * 4;
+    d[0] = in[j].x; d[1] = in[j].y; d[2] = in[j].z; d[3] = in[j].w;
+  }
+  __syncthreads();
+  const unsigned short* t16 = reinterpret_cast<const unsigned short*>(tile);
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int v = threadIdx.x + j * 256;
+    const int oc = v >> 3, r8 = v & 7;               // output row (= input column) oc, input rows 8 r8 .. 8 r8 + 7
+    if (c0 + oc >= cols || r0 + r8 * 8 >= rows) continue;
+    uint32_t e[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) e[k] = t16[(r8 * 8 + k) * 66 + oc];
+    uint4 o;
+    o.x = e[0] | (e[1] << 16); o.y = e[2] | (e[3] << 16); o.z = e[4] | (e[5] << 16); o.w = e[6] | (e[7] << 16);
+    st_global16(y + yoff + (int64_t)(c0 + oc) * ld_out + r0 + r8 * 8, o);
+  }
+}
+
 // y rows have stride ld_out >= rows; columns [rows, ld_out) are left untouched (callers pre-zero padded buffers)
 extern "C" int xml_transpose_batched(const void* x, void* y, int batch, int rows, int cols, int ld_out, int dt,
                                      xml_stream_t stream) {
   XML_ENTER();
   if (!x || !y || batch <= 0 || rows <= 0 || cols <= 0 || ld_out < rows) return XML_ERR_BAD_ARG;
+  if (dt == XML_BF16 && rows % 8 == 0 && cols % 8 == 0 && ld_out % 8 == 0 && rows >= 64 && cols >= 64) {
+    hipLaunchKernelGGL(transpose64_bf16_kernel, dim3(cdiv(cols, 64), cdiv(rows, 64), batch), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, rows, cols, ld_out);
+    XML_CHECK_LAUNCH();
+    return XML_OK;
+  }
   dim3 grid(cdiv(cols, 32), cdiv(rows, 32), batch);
   if (dt == XML_F32)
     hipLaunchKernelGGL(transpose_kernel<float>, grid, dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, rows, cols, ld_out);

@@ -152,13 +152,15 @@ int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0, const floa
  *     requested once instead of twice.
  *   xml_q2c_scores_tiled: xml_q2c_scores_fused on tiled operands: qt_m = tiles of qn[m] (nq, hidden),
  *     ct_m = tiles of cn[m] viewed as (nv * 128, hidden).  Same arithmetic, same summation order: bitwise the same
- *     scores.  Requires xml_q2c_tiled_ok(lpad, hidden, dt) (lpad == 128, hidden * sizeof(dt) % 128 == 0, >= 384). */
+ *     scores.  Requires xml_q2c_tiled_ok(lpad, hidden, dt) (lpad == 128, hidden * sizeof(dt) % 128 == 0, >= 384).
+ *     all_clips_valid != 0: the caller vouches that every entry of the masks is 1 (full-length videos); the masks are
+ *     then not read and the LDS they would occupy becomes a fifth ring slot (+1 %).  With a 0 the masks are applied. */
 int xml_q2c_tiled_ok(int lpad, int hidden, int dt);
 int64_t xml_q2c_tiled_bytes(int64_t rows, int hidden, int dt);
 int xml_q2c_tile_rows(const void* src, void* dst, int64_t rows, int hidden, int dt, xml_stream_t stream);
 int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0, const float* mask0, const void* qt1,
                          const void* ct1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
-                         int lpad, int hidden, int dt, xml_stream_t stream);
+                         int lpad, int hidden, int dt, int all_clips_valid, xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8: per-row top-k, torch.topk(exp(alpha*s), k) (xml/inference.py:317,347-348)

@@ -286,6 +286,14 @@ def test_q2c_tiled_equals_row_major(ops, dtype, shape, n_mod):
     out = torch.full((nq, nv), float("nan"), device=DEV)
     got = ops.q2c_scores_fused(qs, tiles, masks, out=out)
     assert torch.equal(got, want)
+    # full-length videos: the tiles are marked all_valid, K6 skips the masks and runs its five-slot ring
+    ones = [torch.ones_like(m) for m in masks]
+    want1 = ops.q2c_scores_fused(qs, cs, ones)
+    tiles1 = [ops.pack_q2c_corpus(c, o) for c, o in zip(cs, ones)]
+    assert all(t.all_valid for t in tiles1)
+    assert all(ops.pack_q2c_corpus(c, m).all_valid == bool((m == 1).all()) for c, m in zip(cs, masks))
+    out1 = torch.full((nq, nv), float("nan"), device=DEV)
+    assert torch.equal(ops.q2c_scores_fused(qs, tiles1, ones, out=out1), want1)
     # padding rows of the last tile are zero (an odd number of videos leaves half a tile)
     flat = tiles[0].data.view(-1, h // (64 // tiles[0].element_size()), 256, 64 // tiles[0].element_size())
     if (nv * 128) % 256:

@@ -34,7 +34,7 @@ def main():
     flops = 2.0 * nq * nv * 128 * h
     ref = None
     if "--tiled1" in sys.argv:      # one modality on slice-major tiles only (PMC calibration runs)
-        t1 = ops.pack_q2c_corpus(c)
+        t1 = ops.pack_q2c_corpus(c, mask)
         for _ in range(7):
             ops.q2c_scores_fused([q], [t1], [mask], out=out)
         torch.cuda.synchronize()
@@ -73,7 +73,8 @@ def main():
         print("fused x2 modalities: median %.3f ms -> %.1f TFLOP/s" % (ms[2], 2 * flops / ms[2] / 1e9), flush=True)
         print("  equals single-modality result (a+a)/2:", bool(torch.equal(ref, out[:256, :512])))
         keep = out.clone()
-        t1, t2 = ops.pack_q2c_corpus(c), ops.pack_q2c_corpus(c2)       # slice-major tiles (the index layout)
+        t1, t2 = ops.pack_q2c_corpus(c, mask), ops.pack_q2c_corpus(c2, mask)   # slice-major tiles (the index layout);
+        print("  tiles all_valid (masks skipped, 5-slot ring):", t1.all_valid)       # XML_Q2C_KEEP_MASKS=1 keeps the masks
         for _ in range(2):
             ops.q2c_scores_fused([q, q2], [t1, t2], [mask, mask], out=out)
         torch.cuda.synchronize()

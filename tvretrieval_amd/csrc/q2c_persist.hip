@@ -140,7 +140,7 @@ __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3
 //
 //   No wave-group stagger and no s_setprio: the two waves of a SIMD drift apart by themselves and keep the MFMA
 //   pipe busy from either wave's ready cluster.
-template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
+template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false, bool NOMASK = false>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
 __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
@@ -151,7 +151,12 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // group, ablation 10, gives the gain back).  Ablations 3 and 11 keep the even 4 / 4 split.
   constexpr bool UNEVEN = (ABL != 3 && ABL != 11);
   constexpr bool ALL_G0 = (ABL == 10);          // ABL 10: the first group issues all 8 pieces per SIMD pair
-  constexpr int NSLOT = (ABL == 7) ? 5 : 4;        // ABL 7 (experiment): 5-slot ring, masks assumed all-valid
+  // NOMASK (the caller vouches that every clip mask is 1: full-length videos, e.g. the TVR benchmark shape): no mask
+  // patches are needed, the 2 KiB they occupy are what a FIFTH ring slot was missing (5 x 32 KiB = all 160 KiB of LDS):
+  // three slices in flight behind the awaited one instead of two, +1.1-1.3 % measured.  (ABL 7: the same on row-major
+  // operands, experiment.)
+  constexpr bool FIVE = (ABL == 7) || NOMASK;
+  constexpr int NSLOT = FIVE ? 5 : 4;
   constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,7 +243,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     }
     sbase_a = reinterpret_cast<const char*>(a.qn[i_mod]) + (int64_t)q0 * k_bytes;
     sbase_b = reinterpret_cast<const char*>(a.cn[i_mod]) + (int64_t)v0 * 128 * k_bytes;
-    if (ABL != 7 && wave == 0) {   // mask patch of the segment: lane l carries columns 4 l .. 4 l + 3 of the tile's 256 columns
+    if (!FIVE && wave == 0) {   // mask patch of the segment: lane l carries columns 4 l .. 4 l + 3 of the tile's 256 columns
       const int mrow = (v0 + (lane_o >> 5) < a.nv) ? lane_o : (lane_o & 31);
       const char* sbase_m = reinterpret_cast<const char*>(a.mask[i_mod]) + (int64_t)v0 * 128 * 4;
       dma16s((uint32_t)mrow * 16, sbase_m, lds0 + MASK_OFF + (i_seg & 1) * 1024);
@@ -307,8 +312,10 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // slices_per_seg >= 4 here (no segment end inside the first 3 issues is required; 4th may end a segment).
   issue_slice(); issue_slice(); issue_slice(); issue_slice();
   if (NSLOT == 5) {
-    issue_slice();
-    asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    issue_slice();                                       // five slices in flight, the first one awaited
+    if (!UNEVEN) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (grp == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   } else if (UNEVEN) {
     if (grp == 0) {
       if (ALL_G0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
@@ -358,7 +365,9 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // complete, or it waits for the reads issued below before h1)
       unsigned long long t_a = 0;
       if (ABL == 8) t_a = __builtin_amdgcn_s_memtime();
-      if (NSLOT == 5) __builtin_amdgcn_s_waitcnt(0x007c);    // vmcnt(12): three younger slices in flight
+      if (NSLOT == 5 && UNEVEN && !GRP1) __builtin_amdgcn_s_waitcnt(0x4072);       // vmcnt(18): 3 younger slices x 6
+      else if (NSLOT == 5 && UNEVEN) __builtin_amdgcn_s_waitcnt(0x0076);            // vmcnt(6): 3 x 2
+      else if (NSLOT == 5) __builtin_amdgcn_s_waitcnt(0x007c);    // vmcnt(12): three younger slices in flight
       else if (ALL_G0 && !GRP1) __builtin_amdgcn_s_waitcnt(0x4070);   // 8 pieces per slice: vmcnt(16)
       else if (UNEVEN && !GRP1) __builtin_amdgcn_s_waitcnt(0x007c);   // 6 pieces per slice: vmcnt(12)
       else if (UNEVEN && GRP1) __builtin_amdgcn_s_waitcnt(0x0074);    // 2 pieces per slice: vmcnt(4)
@@ -421,7 +430,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       const bool vid_ok = vid < a.nv;
       float mk[8];
 #pragma unroll
-      for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? (ABL == 7 ? 1.f : mpatch[n * 16]) : 0.f;
+      for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? (FIVE ? 1.f : mpatch[n * 16]) : 0.f;
       // every clip of this wave's video valid (the common case): x * 1 + (1 - 1) * -1e10 == x exactly, so the 128
       // multiply-adds of mask_logits are skipped (wave-uniform branch; the epilogue is pure VALU time during which
       // this wave issues no MFMA)
@@ -493,10 +502,12 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 }
 
 template <typename T>
-static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled) {
+static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled, bool nomask) {
   extern int g_q2c_ablation;
-  const int lds = g_q2c_ablation == 7 ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring + two mask patches
-  auto kern = tiled ? q2c_persist_kernel<T, 0, true, true> : g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
+  const bool five = (tiled && nomask) || (!tiled && g_q2c_ablation == 7);
+  const int lds = five ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring (+ two mask patches)
+  auto kern = (tiled && nomask) ? q2c_persist_kernel<T, 0, true, true, true>
+             : tiled ? q2c_persist_kernel<T, 0, true, true> : g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
              : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 11 ? q2c_persist_kernel<T, 11, true> : g_q2c_ablation == 10 ? q2c_persist_kernel<T, 10, true> : g_q2c_ablation == 8 ? q2c_persist_kernel<T, 8, true> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
                                                                                      : q2c_persist_kernel<T, 0, true>;
   if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
@@ -511,7 +522,7 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tile
 // the mask patch of segment s+2 is fetched 4 slices ahead and must not land before the epilogue of segment s.
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                             float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st,
-                            bool tiled) {
+                            bool tiled, bool nomask) {
   Q2cPersistArgs a;
   for (int m = 0; m < 2; ++m) {
     a.qn[m] = qn[m < n_mod ? m : 0];
@@ -522,8 +533,8 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
   a.qsh = a.tq >= 5 ? 3 : a.tq >= 3 ? 2 : a.tq == 2 ? 1 : 0;     // few queries: more workgroups share a query tile
-  if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled);
-  return launch_q2c_persist<float>(a, st, tiled);
+  if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled, nomask);
+  return launch_q2c_persist<float>(a, st, tiled, nomask);
 }
 
 
@@ -573,7 +584,7 @@ extern "C" int xml_q2c_tile_rows(const void* src, void* dst, int64_t rows, int h
 
 extern "C" int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0, const float* mask0, const void* qt1,
                                     const void* ct1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
-                                    int lpad, int hidden, int dt, xml_stream_t stream) {
+                                    int lpad, int hidden, int dt, int all_clips_valid, xml_stream_t stream) {
   XML_ENTER();
   if ((n_mod != 1 && n_mod != 2) || !qt0 || !ct0 || !mask0 || !out) return XML_ERR_BAD_ARG;
   if (n_mod == 2 && (!qt1 || !ct1 || !mask1)) return XML_ERR_BAD_ARG;
@@ -582,5 +593,6 @@ extern "C" int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0,
   const void* q[2] = {qt0, n_mod == 2 ? qt1 : qt0};
   const void* c[2] = {ct0, n_mod == 2 ? ct1 : ct0};
   const float* m[2] = {mask0, n_mod == 2 ? mask1 : mask0};
-  return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream, true);
+  return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream, true,
+                                 all_clips_valid != 0);
 }

@@ -111,10 +111,10 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
     for m in mods:
         f1 = cat(parts[m]["f1"])
         feat1n[m] = ops.l2norm_rows(f1)
-        if hasattr(ops, "pack_q2c_corpus"):      # HIP backend: slice-major tiles for the persistent K6 kernel
-            feat1n[m] = ops.pack_q2c_corpus(feat1n[m])
         feat2[m] = cat(parts[m]["f2"])
         mask[m] = cat(parts[m]["mk"])
+        if hasattr(ops, "pack_q2c_corpus"):      # HIP backend: slice-major tiles for the persistent K6 kernel
+            feat1n[m] = ops.pack_q2c_corpus(feat1n[m], mask[m])
         if keep_raw:
             raw[m] = f1
     idx = CorpusIndex(mods, feat1n, feat2, mask, l_ref, video_offset, n_total)

@@ -198,9 +198,10 @@ class TiledRows(object):
     """Rows of a (rows, H) operand in K6's slice-major tile layout (xml_q2c_tile_rows): `data` is the flat tiled
     image, `rows` / `hidden` / `dtype` describe the row-major tensor it was made from."""
 
-    def __init__(self, data, rows, hidden, shape):
+    def __init__(self, data, rows, hidden, shape, all_valid=False):
         self.data, self.rows, self.hidden, self.shape = data, int(rows), int(hidden), tuple(shape)
         self.dtype, self.device = data.dtype, data.device
+        self.all_valid = bool(all_valid)     # every clip mask of the corpus is 1: K6 may skip the masks (5-slot ring)
 
     def numel(self):
         return self.data.numel()
@@ -230,10 +231,13 @@ def q2c_tile_rows(x):
     return TiledRows(data, rows, hidden, x.shape)
 
 
-def pack_q2c_corpus(feat1n):
-    """Resident form of the similarity operand: slice-major tiles when the persistent kernel takes it, else as is."""
+def pack_q2c_corpus(feat1n, mask=None):
+    """Resident form of the similarity operand: slice-major tiles when the persistent kernel takes it, else as is.
+    mask (Nv, Lpad): if every entry is 1 (full-length videos) the tiles are marked all_valid and K6 skips the masks."""
     if q2c_tiled_ok(feat1n.shape[1], feat1n.shape[2], feat1n.dtype) and not os.environ.get("XML_Q2C_ROW_MAJOR"):
-        return q2c_tile_rows(feat1n)          # (XML_Q2C_ROW_MAJOR=1: keep rows, for A/B measurements)
+        t = q2c_tile_rows(feat1n)             # (XML_Q2C_ROW_MAJOR=1: keep rows, for A/B measurements)
+        t.all_valid = mask is not None and bool((mask == 1).all()) and not os.environ.get("XML_Q2C_KEEP_MASKS")
+        return t
     return feat1n
 
 
@@ -253,9 +257,10 @@ def q2c_scores_fused(qn, cn, masks, out=None):
             out = torch.empty((nq, nv), dtype=torch.float32, device=qn[0].device)
         _req(out, "out", torch.float32)
         j = 1 if n_mod > 1 else 0
+        nomask = int(all(c.all_valid for c in cn[:n_mod]))
         check(_lib.load().xml_q2c_scores_tiled(n_mod, _p(qt[0].data), _p(cn[0].data), _p(masks[0]), _p(qt[j].data),
                                                _p(cn[j].data), _p(masks[j]), _p(out), out.stride(0), nq, nv, lpad,
-                                               hidden, dt_of(qn[0]), _stream()), "xml_q2c_scores_tiled")
+                                               hidden, dt_of(qn[0]), nomask, _stream()), "xml_q2c_scores_tiled")
         return out
     for m in range(n_mod):
         _req(qn[m], "qn"); _req(cn[m], "cn", qn[m].dtype); _req(masks[m], "mask", torch.float32)

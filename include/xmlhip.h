@@ -153,14 +153,18 @@ int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0, const floa
  *   xml_q2c_scores_tiled: xml_q2c_scores_fused on tiled operands: qt_m = tiles of qn[m] (nq, hidden),
  *     ct_m = tiles of cn[m] viewed as (nv * 128, hidden).  Same arithmetic, same summation order: bitwise the same
  *     scores.  Requires xml_q2c_tiled_ok(lpad, hidden, dt) (lpad == 128, hidden * sizeof(dt) % 128 == 0, >= 384).
- *     all_clips_valid != 0: the caller vouches that every entry of the masks is 1 (full-length videos); the masks are
- *     then not read and the LDS they would occupy becomes a fifth ring slot (+1 %).  With a 0 the masks are applied. */
+ *     mask_mode 0: the f32 masks are applied through LDS patches (four ring slots).
+ *     mask_mode 1: the caller vouches that every entry of the masks is 1 (full-length videos); the masks are not read
+ *       and the LDS they would occupy becomes a fifth ring slot (+3.8 % measured).
+ *     mask_mode 2: BINARY masks packed as bits, mbits_m (nv, 4) uint32, bit l of video v = mask_m[v][l] != 0; they reach
+ *       the kernel through scalar loads, so ragged corpora get the fifth slot as well.  Same scores in every mode. */
 int xml_q2c_tiled_ok(int lpad, int hidden, int dt);
 int64_t xml_q2c_tiled_bytes(int64_t rows, int hidden, int dt);
 int xml_q2c_tile_rows(const void* src, void* dst, int64_t rows, int hidden, int dt, xml_stream_t stream);
 int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0, const float* mask0, const void* qt1,
                          const void* ct1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
-                         int lpad, int hidden, int dt, int all_clips_valid, xml_stream_t stream);
+                         int lpad, int hidden, int dt, int mask_mode, const uint32_t* mbits0, const uint32_t* mbits1,
+                         xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K8: per-row top-k, torch.topk(exp(alpha*s), k) (xml/inference.py:317,347-348)

@@ -30,6 +30,9 @@ def main():
         e = min(nv, b + 2048)
         c[b:e] = torch.nn.functional.normalize(torch.randn(e - b, 128, h, device="cuda", generator=g), dim=-1).to(dtype)
     mask = torch.ones(nv, 128, device="cuda")
+    if "--ragged" in sys.argv:      # video lengths 32..128 clips: the masked paths (float patches / packed bits)
+        lens = torch.randint(32, 129, (nv,), device="cuda", generator=g)
+        mask = (torch.arange(128, device="cuda")[None] < lens[:, None]).float().contiguous()
     out = torch.empty(nq, nv, device="cuda")
     flops = 2.0 * nq * nv * 128 * h
     ref = None
@@ -74,7 +77,7 @@ def main():
         print("  equals single-modality result (a+a)/2:", bool(torch.equal(ref, out[:256, :512])))
         keep = out.clone()
         t1, t2 = ops.pack_q2c_corpus(c, mask), ops.pack_q2c_corpus(c2, mask)   # slice-major tiles (the index layout);
-        print("  tiles all_valid (masks skipped, 5-slot ring):", t1.all_valid)       # XML_Q2C_KEEP_MASKS=1 keeps the masks
+        print("  tiles all_valid (masks skipped, 5-slot ring):", t1.all_valid, " packed mask bits:", t1.mask_bits is not None)
         for _ in range(2):
             ops.q2c_scores_fused([q, q2], [t1, t2], [mask, mask], out=out)
         torch.cuda.synchronize()

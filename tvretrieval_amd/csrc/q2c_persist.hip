@@ -25,6 +25,7 @@ struct Q2cPersistArgs {
   const void* qn[2];
   const void* cn[2];
   const float* mask[2];
+  const uint32_t* mbits[2];   // BITMASK kernels: (nv, 4) words, bit l of a video = clip l valid
   float* out;
   int64_t ld_out;
   int nq, nv, hidden, n_mod, tq, tc;
@@ -140,7 +141,7 @@ __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3
 //
 //   No wave-group stagger and no s_setprio: the two waves of a SIMD drift apart by themselves and keep the MFMA
 //   pipe busy from either wave's ready cluster.
-template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false, bool NOMASK = false>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
+template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false, bool NOMASK = false, bool BITMASK = false>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
 __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
@@ -155,7 +156,9 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // patches are needed, the 2 KiB they occupy are what a FIFTH ring slot was missing (5 x 32 KiB = all 160 KiB of LDS):
   // three slices in flight behind the awaited one instead of two, +1.1-1.3 % measured.  (ABL 7: the same on row-major
   // operands, experiment.)
-  constexpr bool FIVE = (ABL == 7) || NOMASK;
+  // BITMASK: ragged corpora get the fifth slot too -- binary clip masks packed 128 bits per video arrive through SCALAR
+  // loads (lgkmcnt, invisible to the hand-counted vmcnt of the DMA stream), no mask DMA, no LDS patches.
+  constexpr bool FIVE = (ABL == 7) || NOMASK || BITMASK;
   constexpr int NSLOT = FIVE ? 5 : 4;
   constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
@@ -429,15 +432,34 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       const bool last_mod = c_mod == a.n_mod - 1;
       const bool vid_ok = vid < a.nv;
       float mk[8];
+      bool fast;
+      if constexpr (BITMASK) {
+        // the video's 128 mask bits: four scalar loads (the address is wave-uniform)
+        // (readfirstlane: hipcc must KNOW the index is uniform, or it emits VMEM loads whose s_waitcnt vmcnt(0) would drain
+        // the DMA stream at every tile)
+        const int vid_s = __builtin_amdgcn_readfirstlane(vid_ok ? vid : 0);
+        const uint32_t* mb = (c_mod == 0 ? a.mbits[0] : a.mbits[1]) + (int64_t)vid_s * 4;
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t wv;
+        asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wv) : "s"(mb) : "memory");
+        const uint32_t w0 = vid_ok ? wv.x : 0u, w1 = vid_ok ? wv.y : 0u, w2 = vid_ok ? wv.z : 0u, w3 = vid_ok ? wv.w : 0u;
+        fast = (w0 & w1 & w2 & w3) == 0xffffffffu;
 #pragma unroll
-      for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? (FIVE ? 1.f : mpatch[n * 16]) : 0.f;
-      // every clip of this wave's video valid (the common case): x * 1 + (1 - 1) * -1e10 == x exactly, so the 128
-      // multiply-adds of mask_logits are skipped (wave-uniform branch; the epilogue is pure VALU time during which
-      // this wave issues no MFMA)
-      bool all_on = true;
+        for (int n = 0; n < 8; ++n) {
+          const uint32_t w = (n >> 1) == 0 ? w0 : (n >> 1) == 1 ? w1 : (n >> 1) == 2 ? w2 : w3;
+          mk[n] = (float)((w >> ((n & 1) * 16 + fr_e)) & 1u);
+        }
+      } else {
 #pragma unroll
-      for (int n = 0; n < 8; ++n) all_on = all_on && (mk[n] == 1.f);
-      const bool fast = __all(all_on);
+        for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? (FIVE ? 1.f : mpatch[n * 16]) : 0.f;
+        // every clip of this wave's video valid (the common case): x * 1 + (1 - 1) * -1e10 == x exactly, so the 128
+        // multiply-adds of mask_logits are skipped (wave-uniform branch; the epilogue is pure VALU time during which
+        // this wave issues no MFMA)
+        bool all_on = true;
+#pragma unroll
+        for (int n = 0; n < 8; ++n) all_on = all_on && (mk[n] == 1.f);
+        fast = __all(all_on);
+      }
       // in-lane maxima over the 8 column tiles: x[m * 4 + r] belongs to tile row m * 16 + fg * 4 + r
       float x[16];
 #pragma unroll
@@ -502,11 +524,12 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 }
 
 template <typename T>
-static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled, bool nomask) {
+static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled, int mask_mode) {
   extern int g_q2c_ablation;
-  const bool five = (tiled && nomask) || (!tiled && g_q2c_ablation == 7);
+  const bool five = (tiled && mask_mode != 0) || (!tiled && g_q2c_ablation == 7);
   const int lds = five ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring (+ two mask patches)
-  auto kern = (tiled && nomask) ? q2c_persist_kernel<T, 0, true, true, true>
+  auto kern = (tiled && mask_mode == 1) ? q2c_persist_kernel<T, 0, true, true, true>
+             : (tiled && mask_mode == 2) ? q2c_persist_kernel<T, 0, true, true, false, true>
              : tiled ? q2c_persist_kernel<T, 0, true, true> : g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
              : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 11 ? q2c_persist_kernel<T, 11, true> : g_q2c_ablation == 10 ? q2c_persist_kernel<T, 10, true> : g_q2c_ablation == 8 ? q2c_persist_kernel<T, 8, true> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
                                                                                      : q2c_persist_kernel<T, 0, true>;
@@ -522,19 +545,21 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tile
 // the mask patch of segment s+2 is fetched 4 slices ahead and must not land before the epilogue of segment s.
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                             float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st,
-                            bool tiled, bool nomask) {
+                            bool tiled, int mask_mode, const uint32_t* const* mbits) {
   Q2cPersistArgs a;
   for (int m = 0; m < 2; ++m) {
     a.qn[m] = qn[m < n_mod ? m : 0];
     a.cn[m] = cn[m < n_mod ? m : 0];
     a.mask[m] = mask[m < n_mod ? m : 0];
+    a.mbits[m] = mbits ? mbits[m < n_mod ? m : 0] : nullptr;
   }
+  if (mask_mode == 2 && (!mbits || !a.mbits[0] || !a.mbits[1])) return XML_ERR_BAD_ARG;
   if (lpad != 128) return XML_ERR_UNSUPPORTED;
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
   a.qsh = a.tq >= 5 ? 3 : a.tq >= 3 ? 2 : a.tq == 2 ? 1 : 0;     // few queries: more workgroups share a query tile
-  if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled, nomask);
-  return launch_q2c_persist<float>(a, st, tiled, nomask);
+  if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled, mask_mode);
+  return launch_q2c_persist<float>(a, st, tiled, mask_mode);
 }
 
 
@@ -584,7 +609,8 @@ extern "C" int xml_q2c_tile_rows(const void* src, void* dst, int64_t rows, int h
 
 extern "C" int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0, const float* mask0, const void* qt1,
                                     const void* ct1, const float* mask1, float* out, int64_t ld_out, int nq, int nv,
-                                    int lpad, int hidden, int dt, int all_clips_valid, xml_stream_t stream) {
+                                    int lpad, int hidden, int dt, int mask_mode, const uint32_t* mbits0,
+                                    const uint32_t* mbits1, xml_stream_t stream) {
   XML_ENTER();
   if ((n_mod != 1 && n_mod != 2) || !qt0 || !ct0 || !mask0 || !out) return XML_ERR_BAD_ARG;
   if (n_mod == 2 && (!qt1 || !ct1 || !mask1)) return XML_ERR_BAD_ARG;
@@ -593,6 +619,8 @@ extern "C" int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0,
   const void* q[2] = {qt0, n_mod == 2 ? qt1 : qt0};
   const void* c[2] = {ct0, n_mod == 2 ? ct1 : ct0};
   const float* m[2] = {mask0, n_mod == 2 ? mask1 : mask0};
+  if (mask_mode < 0 || mask_mode > 2) return XML_ERR_BAD_ARG;
+  const uint32_t* mb[2] = {mbits0, n_mod == 2 ? mbits1 : mbits0};
   return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream, true,
-                                 all_clips_valid != 0);
+                                 mask_mode, mb);
 }

@@ -202,6 +202,7 @@ class TiledRows(object):
         self.data, self.rows, self.hidden, self.shape = data, int(rows), int(hidden), tuple(shape)
         self.dtype, self.device = data.dtype, data.device
         self.all_valid = bool(all_valid)     # every clip mask of the corpus is 1: K6 may skip the masks (5-slot ring)
+        self.mask_bits = None                # (Nv, 4) int32: binary clip masks packed 128 bits per video (ragged corpora)
 
     def numel(self):
         return self.data.numel()
@@ -236,7 +237,13 @@ def pack_q2c_corpus(feat1n, mask=None):
     mask (Nv, Lpad): if every entry is 1 (full-length videos) the tiles are marked all_valid and K6 skips the masks."""
     if q2c_tiled_ok(feat1n.shape[1], feat1n.shape[2], feat1n.dtype) and not os.environ.get("XML_Q2C_ROW_MAJOR"):
         t = q2c_tile_rows(feat1n)             # (XML_Q2C_ROW_MAJOR=1: keep rows, for A/B measurements)
-        t.all_valid = mask is not None and bool((mask == 1).all()) and not os.environ.get("XML_Q2C_KEEP_MASKS")
+        keep = os.environ.get("XML_Q2C_KEEP_MASKS")      # 1: float masks (4-slot kernel), for A/B measurements
+        t.all_valid = mask is not None and bool((mask == 1).all()) and not keep
+        if mask is not None and not t.all_valid and not keep and mask.shape[1] == 128 \
+                and bool(((mask == 0) | (mask == 1)).all()):
+            w = (mask.view(-1, 4, 32) != 0).to(torch.int64) << torch.arange(32, device=mask.device, dtype=torch.int64)
+            w = w.sum(-1)
+            t.mask_bits = torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
         return t
     return feat1n
 
@@ -257,10 +264,19 @@ def q2c_scores_fused(qn, cn, masks, out=None):
             out = torch.empty((nq, nv), dtype=torch.float32, device=qn[0].device)
         _req(out, "out", torch.float32)
         j = 1 if n_mod > 1 else 0
-        nomask = int(all(c.all_valid for c in cn[:n_mod]))
+        bits = [c.mask_bits for c in cn[:n_mod]]
+        if all(c.all_valid for c in cn[:n_mod]):
+            mode, bits = 1, [None, None]
+        elif all(b is not None or c.all_valid for b, c in zip(bits, cn[:n_mod])):
+            mode = 2       # a fully valid modality next to a ragged one: all-ones bit rows
+            bits = [b if b is not None else torch.full((nv, 4), -1, dtype=torch.int32, device=out.device) for b in bits]
+        else:
+            mode, bits = 0, [None, None]
+        bits = (bits + [None])[:2] if n_mod == 1 else bits
         check(_lib.load().xml_q2c_scores_tiled(n_mod, _p(qt[0].data), _p(cn[0].data), _p(masks[0]), _p(qt[j].data),
                                                _p(cn[j].data), _p(masks[j]), _p(out), out.stride(0), nq, nv, lpad,
-                                               hidden, dt_of(qn[0]), nomask, _stream()), "xml_q2c_scores_tiled")
+                                               hidden, dt_of(qn[0]), mode, _p(bits[0]), _p(bits[j]), _stream()),
+              "xml_q2c_scores_tiled")
         return out
     for m in range(n_mod):
         _req(qn[m], "qn"); _req(cn[m], "cn", qn[m].dtype); _req(masks[m], "mask", torch.float32)

@@ -294,6 +294,20 @@ def test_q2c_tiled_equals_row_major(ops, dtype, shape, n_mod):
     assert all(ops.pack_q2c_corpus(c, m).all_valid == bool((m == 1).all()) for c, m in zip(cs, masks))
     out1 = torch.full((nq, nv), float("nan"), device=DEV)
     assert torch.equal(ops.q2c_scores_fused(qs, tiles1, ones, out=out1), want1)
+    # the same corpus through the packed-bit masks (mode 2, all bits set) and through the float masks (mode 0)
+    for t in tiles1:
+        t.all_valid = False
+        t.mask_bits = torch.full((nv, 4), -1, dtype=torch.int32, device=DEV)
+    assert torch.equal(ops.q2c_scores_fused(qs, tiles1, ones), want1)
+    for t in tiles1:
+        t.mask_bits = None
+    assert torch.equal(ops.q2c_scores_fused(qs, tiles1, ones), want1)
+    # non-binary masks cannot be packed: float path, still equal to the row-major kernel
+    soft = [m * 0.5 + 0.5 * (m > 0) * (torch.arange(128, device=DEV)[None] % 2 == 0) for m in masks]
+    tsoft = [ops.pack_q2c_corpus(c, m) for c, m in zip(cs, soft)]
+    if not all(bool(((m == 0) | (m == 1)).all()) for m in soft):
+        assert all(t.mask_bits is None and not t.all_valid for t, m in zip(tsoft, soft) if not bool(((m == 0) | (m == 1)).all()))
+    assert torch.equal(ops.q2c_scores_fused(qs, tsoft, soft), ops.q2c_scores_fused(qs, cs, soft))
     # padding rows of the last tile are zero (an odd number of videos leaves half a tile)
     flat = tiles[0].data.view(-1, h // (64 // tiles[0].element_size()), 256, 64 // tiles[0].element_size())
     if (nv * 128) % 256:

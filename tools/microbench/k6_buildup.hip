@@ -24,6 +24,15 @@ __device__ __forceinline__ void dma_quad(uint32_t v0, uint32_t v1, uint32_t v2, 
       : "memory", "scc");
 }
 
+__device__ __forceinline__ void g_dma_pair(uint32_t v0, const char* sb, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3"
+      :
+      : "v"(v0), "v"(v0 + 1024), "s"(lds_dst), "s"(sb)
+      : "memory", "scc");
+}
+
 struct Frags { i32x4 a[4], b[8]; };
 
 template <bool READS>
@@ -228,6 +237,92 @@ static void run4(const char* name, K kernel, const char* src, float* out, int sl
   printf("\n");
 }
 
+
+// ---- ring-depth experiment: separate rings for the two operands, SA slots of 16 KiB for A (L2-resident re-reads), SB
+// for B (streamed) -- K6's source pattern on slice-major tiles.  (4,4) is the symmetric 4-slot ring, (5,5) the 5-slot one.
+template <int SA, int SB>
+__global__ __launch_bounds__(512) void k6_ring(const char* __restrict__ src, float* out, int slices) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  constexpr int A_BYTES = SA * 16384;
+  for (int i = tid; i < (SA + SB) * 16384 / 4; i += 512) reinterpret_cast<uint32_t*>(smem)[i] = 0x3c003c00u + (i & 0xff);
+  __syncthreads();
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
+  constexpr size_t TILEB = (size_t)256 * 1536;
+  const char* a_base = src + ((size_t)(xcd * 8 + (loc & 7))) * TILEB;
+  const char* b_base = src + (size_t)64 * TILEB;
+  f32x4 acc[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const uint32_t rowoff = (uint32_t)(wave * 2048 + lane * 16);
+  auto issue_a = [&](int s) {
+    const int t = s / 24, ks = s - t * 24;
+    g_dma_pair((uint32_t)(rowoff + ks * 16384), a_base, lds0 + (uint32_t)((s % SA) * 16384 + wave * 2048));
+  };
+  auto issue_b = [&](int s) {
+    const int t = s / 24, ks = s - t * 24;
+    const uint32_t blk = (uint32_t)(((t * 8 + xcd) * 4 + (loc >> 3)) % 5000);
+    g_dma_pair((uint32_t)(rowoff + ks * 16384), b_base + (size_t)blk * TILEB,
+               lds0 + (uint32_t)(A_BYTES + (s % SB) * 16384 + wave * 2048));
+  };
+  // prologue: A slices 0 .. SA-1, B slices 0 .. SB-1, in the steady-state order [A(t + SA), B(t + SB)] of steps t < 0
+  for (int t = -SB; t < 0; ++t) {
+    if (t + SA >= 0) issue_a(t + SA);
+    issue_b(t + SB);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  Frags f0, f1;
+  auto read = [&](Frags& f, int s) {
+    const char* pa = smem + (s % SA) * 16384 + (wave >> 1) * 4096 + lane * 16;
+    const char* pb = smem + A_BYTES + (s % SB) * 16384 + (wave & 1) * 8192 + lane * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f.a[i] = *reinterpret_cast<const i32x4*>(pa + i * 1024);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f.b[i] = *reinterpret_cast<const i32x4*>(pb + i * 1024);
+  };
+  read(f0, 0);
+  i32x4 sink = {0, 0, 0, 0};
+  constexpr int YOUNGER = 2 + 4 * (SA - 2);          // pieces issued after A(s + 1) (B(s + 1) is older still)
+  auto step = [&](int s, Frags& cur, Frags& nxt) {
+    __builtin_amdgcn_s_waitcnt(0x0f70 | (YOUNGER & 15) | ((YOUNGER >> 4) << 14));
+    __builtin_amdgcn_s_barrier();
+    issue_a(s + SA);
+    issue_b(s + SB);
+    read(nxt, s + 1);
+    mma<true>(acc, cur, sink);
+  };
+  for (int s = 0; s < slices; s += 2) {
+    step(s, f0, f1);
+    step(s + 1, f1, f0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  float r = (float)f0.a[0][0];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) r += acc[i][0] + acc[i][3];
+  out[blockIdx.x * 512 + tid] = r;
+}
+
+template <typename K>
+static void run_ring(const char* name, K kernel, int lds, const char* src, float* out, int slices) {
+  hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  float ms = 0.f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(kernel, dim3(256), dim3(512), lds, 0, src, out, slices);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    hipEventElapsedTime(&ms, e0, e1);
+  }
+  const double tf = (double)slices * 8 * 32 * 256 * 2.0 * 16 * 16 * 32 / (ms * 1e-3) / 1e12;
+  printf("%-44s %8.3f ms  %7.1f ns per slice  %7.1f TFLOP/s\n", name, ms, ms * 1e6 / slices, tf);
+}
+
 template <typename K>
 static void run(const char* name, K kernel, const char* src, float* out, int slices, bool mfma) {
   hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
@@ -288,6 +383,11 @@ int main(int argc, char** argv) {
   run4("4 waves 128x128: slice-major tiles (L2+HBM)", k6_loop4<true, true, 2>, src, out, slices, true);
   run4("  same without MFMA", k6_loop4<true, false, 2>, src, out, slices, false);
   run4("4 waves 128x128: no DMA", k6_loop4<false, true, 0>, src, out, slices, true);
+  run_ring("rings A 4 / B 4 slots (128 KiB)", k6_ring<4, 4>, 8 * 16384, src, out, slices);
+  run_ring("rings A 5 / B 5 slots (160 KiB)", k6_ring<5, 5>, 10 * 16384, src, out, slices);
+  run_ring("rings A 4 / B 6 slots (160 KiB)", k6_ring<4, 6>, 10 * 16384, src, out, slices);
+  run_ring("rings A 3 / B 7 slots (160 KiB)", k6_ring<3, 7>, 10 * 16384, src, out, slices);
+  run_ring("rings A 6 / B 4 slots (160 KiB)", k6_ring<6, 4>, 10 * 16384, src, out, slices);
   run("DMA + reads + barrier (no MFMA)", k6_loop<true, true, false, true>, src, out, slices, false);
   run("DMA + barrier only", k6_loop<true, false, false, true>, src, out, slices, false);
   run("reads + barrier only", k6_loop<false, true, false, true>, src, out, slices, false);

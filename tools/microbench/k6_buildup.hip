@@ -33,6 +33,19 @@ __device__ __forceinline__ void g_dma_pair(uint32_t v0, const char* sb, uint32_t
       : "memory", "scc");
 }
 
+#define G_DMA_PAIR_MOD(NAME, MOD)                                                                         \
+  __device__ __forceinline__ void NAME(uint32_t v0, const char* sb, uint32_t lds_dst) {                   \
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3 " MOD "\n\t"              \
+                 "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 " MOD              \
+                 :                                                                                        \
+                 : "v"(v0), "v"(v0 + 1024), "s"(lds_dst), "s"(sb)                                         \
+                 : "memory", "scc");                                                                      \
+  }
+G_DMA_PAIR_MOD(g_dma_pair_nt, "nt")
+G_DMA_PAIR_MOD(g_dma_pair_sc0, "sc0")
+G_DMA_PAIR_MOD(g_dma_pair_sc1, "sc1")
+G_DMA_PAIR_MOD(g_dma_pair_sc01, "sc0 sc1")
+
 struct Frags { i32x4 a[4], b[8]; };
 
 template <bool READS>
@@ -240,7 +253,8 @@ static void run4(const char* name, K kernel, const char* src, float* out, int sl
 
 // ---- ring-depth experiment: separate rings for the two operands, SA slots of 16 KiB for A (L2-resident re-reads), SB
 // for B (streamed) -- K6's source pattern on slice-major tiles.  (4,4) is the symmetric 4-slot ring, (5,5) the 5-slot one.
-template <int SA, int SB>
+// MA / MB: cache-policy modifier of the A / B loads (0 none, 1 nt, 2 sc0, 3 sc1, 4 sc0 sc1)
+template <int SA, int SB, int MA = 0, int MB = 0>
 __global__ __launch_bounds__(512) void k6_ring(const char* __restrict__ src, float* out, int slices) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -259,13 +273,19 @@ __global__ __launch_bounds__(512) void k6_ring(const char* __restrict__ src, flo
   const uint32_t rowoff = (uint32_t)(wave * 2048 + lane * 16);
   auto issue_a = [&](int s) {
     const int t = s / 24, ks = s - t * 24;
-    g_dma_pair((uint32_t)(rowoff + ks * 16384), a_base, lds0 + (uint32_t)((s % SA) * 16384 + wave * 2048));
+    const uint32_t v = (uint32_t)(rowoff + ks * 16384), d = lds0 + (uint32_t)((s % SA) * 16384 + wave * 2048);
+    if (MA == 1) g_dma_pair_nt(v, a_base, d); else if (MA == 2) g_dma_pair_sc0(v, a_base, d);
+    else if (MA == 3) g_dma_pair_sc1(v, a_base, d); else if (MA == 4) g_dma_pair_sc01(v, a_base, d);
+    else g_dma_pair(v, a_base, d);
   };
   auto issue_b = [&](int s) {
     const int t = s / 24, ks = s - t * 24;
     const uint32_t blk = (uint32_t)(((t * 8 + xcd) * 4 + (loc >> 3)) % 5000);
-    g_dma_pair((uint32_t)(rowoff + ks * 16384), b_base + (size_t)blk * TILEB,
-               lds0 + (uint32_t)(A_BYTES + (s % SB) * 16384 + wave * 2048));
+    const uint32_t v = (uint32_t)(rowoff + ks * 16384), d = lds0 + (uint32_t)(A_BYTES + (s % SB) * 16384 + wave * 2048);
+    const char* bb = b_base + (size_t)blk * TILEB;
+    if (MB == 1) g_dma_pair_nt(v, bb, d); else if (MB == 2) g_dma_pair_sc0(v, bb, d);
+    else if (MB == 3) g_dma_pair_sc1(v, bb, d); else if (MB == 4) g_dma_pair_sc01(v, bb, d);
+    else g_dma_pair(v, bb, d);
   };
   // prologue: A slices 0 .. SA-1, B slices 0 .. SB-1, in the steady-state order [A(t + SA), B(t + SB)] of steps t < 0
   for (int t = -SB; t < 0; ++t) {
@@ -388,6 +408,12 @@ int main(int argc, char** argv) {
   run_ring("rings A 4 / B 6 slots (160 KiB)", k6_ring<4, 6>, 10 * 16384, src, out, slices);
   run_ring("rings A 3 / B 7 slots (160 KiB)", k6_ring<3, 7>, 10 * 16384, src, out, slices);
   run_ring("rings A 6 / B 4 slots (160 KiB)", k6_ring<6, 4>, 10 * 16384, src, out, slices);
+  run_ring("5 / 5, B loads nt", k6_ring<5, 5, 0, 1>, 10 * 16384, src, out, slices);
+  run_ring("5 / 5, B loads sc0", k6_ring<5, 5, 0, 2>, 10 * 16384, src, out, slices);
+  run_ring("5 / 5, B loads sc1", k6_ring<5, 5, 0, 3>, 10 * 16384, src, out, slices);
+  run_ring("5 / 5, B loads sc0 sc1", k6_ring<5, 5, 0, 4>, 10 * 16384, src, out, slices);
+  run_ring("5 / 5, A loads nt", k6_ring<5, 5, 1, 0>, 10 * 16384, src, out, slices);
+  run_ring("5 / 5, A loads sc1", k6_ring<5, 5, 3, 0>, 10 * 16384, src, out, slices);
   run("DMA + reads + barrier (no MFMA)", k6_loop<true, true, false, true>, src, out, slices, false);
   run("DMA + barrier only", k6_loop<true, false, false, true>, src, out, slices, false);
   run("reads + barrier only", k6_loop<false, true, false, true>, src, out, slices, false);

@@ -2,9 +2,9 @@
 """bench.py -- queries/sec of full VCMR (query features in -> top-100 videos + top-200 moments out) over a resident
 TVR-shaped corpus, on N MI355X of one node.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1: bench.py starts the N ranks itself, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-         bench.py --gpus N --steps K --warmup W
+         bench.py --gpus N --steps K --warmup W          (same job under torchrun: RANK / WORLD_SIZE from the env)
 
 Workload (BASELINE.json configs[2]/[3], "c3"): XML video+sub, cross-attention, merged ConvSE, H=768, bf16;
 21 793 videos x 128 clips (Dv=3072, Ds=768), 10 000 queries x <=30 tokens (Dq=768); synthetic L2-normalised
@@ -79,10 +79,25 @@ def synth_queries(nq, dq, device):
     return qf.contiguous(), mask.contiguous()
 
 
-def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name):
-    """Oracle (reference formulation, torch CPU fp32) on a bounded slice, extrapolated linearly in Nv."""
+def list_overlap(a, b, ks=(1, 10, 100)):
+    """Mean |top-k(a) ∩ top-k(b)| / k over rows, for each k that fits."""
+    a, b = np.asarray(a), np.asarray(b)
+    out = {}
+    for k in ks:
+        if k > a.shape[1] or k > b.shape[1]:
+            continue
+        hit = [len(set(x[:k].tolist()) & set(y[:k].tolist())) for x, y in zip(a, b)]
+        out["top%d" % k] = float(np.mean(hit)) / k
+    return out
+
+
+def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search):
+    """Oracle (reference formulation, torch CPU fp32) on a bounded slice -- 50 queries x 2 000 videos, median of 5 after
+    one warm-up (BASELINE.md section 3 / SURVEY 8d; reference protocol profile_main.py:54,457-461) -- extrapolated
+    linearly in Nv.  The same slice also goes through the HIP path (`search`), and the agreement of the two ranked
+    lists is reported next to the timing: it is the bf16-vs-fp32 evidence of the very run the number comes from."""
     from oracle import xml_oracle as O
-    nq_s, nv_s = 50, min(1000, index.n_videos)
+    nq_s, nv_s = 50, min(2000, index.n_videos)
     sd = {k: v.detach().float().cpu() for k, v in model.state_dict().items()}
     om = O.OracleXML(cfg, sd)
     mods = index.modalities
@@ -90,77 +105,137 @@ def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name):
     f2 = {m: index.feat2[m][:nv_s, :index.l_ref].float().cpu() for m in mods}
     mk = {m: index.mask[m][:nv_s, :index.l_ref].float().cpu() for m in mods}
     q, qmask = qf[:nq_s].float().cpu(), qm[:nq_s].float().cpu()
-    g = lambda d, m: d[m] if m in d else None
+    g = lambda d, m: d[m] if m in d else None          # noqa: E731
+    k_vid = min(100, nv_s)
 
     def run():
         with torch.no_grad():
             q2c, st, ed = om.get_pred_from_raw_query(q, qmask, g(f1, "video"), g(f2, "video"), g(mk, "video"),
                                                      g(f1, "sub"), g(f2, "sub"), g(mk, "sub"), cross=True)
-            return O.vcmr_tail(q2c, st, ed, 20.0, min(100, nv_s), 2, 16, 200)
-    run()
+            return q2c, O.vcmr_tail(q2c, st, ed, 20.0, k_vid, 2, 16, 200)
+    q2c_ref, want = run()
     ts = []
-    for _ in range(3):
+    for _ in range(5):
         t0 = time.perf_counter()
         run()
         ts.append(time.perf_counter() - t0)
     t = float(np.median(ts))
     qps_sample = nq_s / t
-    return dict(value=qps_sample * nv_s / n_total, unit="queries/s", cores=torch.get_num_threads(), kind="port",
-                host_cpus=os.cpu_count(),
-                sample="oracle (reference formulation, torch-CPU fp32): %d queries x %d videos x %d clips, H=%d, %s; "
-                       "median of 3 after 1 warm-up = %.2f s (%.1f q/s on the sample); value extrapolated linearly "
-                       "in Nv to %d videos" % (nq_s, nv_s, index.l_ref, cfg["hidden_size"], cfg["ctx_mode"], t,
-                                               qps_sample, n_total))
+    res = dict(value=qps_sample * nv_s / n_total, unit="queries/s", cores=torch.get_num_threads(), kind="port",
+               host_cpus=os.cpu_count(),
+               sample="oracle (reference formulation, torch-CPU fp32): %d queries x %d videos x %d clips, H=%d, %s; "
+                      "median of 5 after 1 warm-up = %.2f s (%.1f q/s on the sample); value extrapolated linearly "
+                      "in Nv to %d videos" % (nq_s, nv_s, index.l_ref, cfg["hidden_size"], cfg["ctx_mode"], t,
+                                              qps_sample, n_total))
+    # the same sample through the HIP path (compute dtype of the run) vs the fp32 oracle lists
+    got = search(nq_s, nv_s)
+    if got is not None:
+        gi, wi = got["top_indices"].cpu().numpy(), want["top_indices"].numpy()
+        agree = dict(videos=list_overlap(gi, wi))
+        agree["q2c_max_abs_err"] = float((got["q2c"].cpu() - q2c_ref).abs().max())
+        # moments: compare (video, st, ed) triples, i.e. decode the flat index through each side's own video list
+        ll = index.l_ref * index.l_ref
+
+        def triples(flat, vids):
+            flat = np.asarray(flat).astype(np.int64)
+            ok = flat >= 0
+            r = np.where(ok, flat // ll, 0)
+            v = np.take_along_axis(np.asarray(vids).astype(np.int64), r, 1)
+            return np.where(ok, v * ll + flat % ll, -1)
+        agree["moments"] = list_overlap(triples(got["flat_indices"].cpu().numpy(), gi),
+                                        triples(want["flat_indices"].numpy(), wi), ks=(1, 10, 100, 200))
+        res["hip_vs_oracle_on_sample"] = agree
+        res["hip_vs_oracle_note"] = "share of the oracle's (fp32) top-k found in the %s HIP path's top-k, same %d x %d " \
+                                    "slice" % (dtype_name, nq_s, nv_s)
+    return res
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU code path even with 1 rank (testing)")
-    ap.add_argument("--sharded-rerank", action="store_true",
-                    help="N > 1: keep feat2 sharded too (phase 2 on the video's owner, four collectives per pass)")
-    args = ap.parse_args()
+class HipBackend(object):
+    """The product path: libxmlhip.so kernels on cuda:<local_rank>, RCCL ("nccl") between ranks."""
+    name, dist_backend = "hip", "nccl"
 
+    def __init__(self, local_rank):
+        torch.cuda.set_device(local_rank)
+        self.device = torch.device("cuda", local_rank)
+        from tvretrieval_amd import ops
+        self.ops = ops
+
+    def make_model(self, cfg, dtype):
+        from tvretrieval_amd.model_xml import XML
+        return XML(cfg, compute_dtype=dtype).to(self.device).eval()
+
+    def sync(self):
+        torch.cuda.synchronize()
+
+    def event(self):
+        return torch.cuda.Event(enable_timing=True)
+
+    def init_kwargs(self):
+        return dict(device_id=self.device)
+
+
+def load_backend(args, local_rank):
+    if args.backend_module:      # TEST HOOK: tests/cpu_backend.py stands in for the kernels (gloo ranks, no GPU)
+        import importlib
+        return importlib.import_module(args.backend_module).BenchBackend(local_rank)
+    return HipBackend(local_rank)
+
+
+def k6_traffic(root, workload, world):
+    """HBM/fabric bytes per K6 launch from the committed PMC pass -- only if that pass was taken from THIS kernel source
+    (tools/measure_k6_traffic.sh records the sha256 of the K6 sources; a stale file is refused, not quoted)."""
+    import glob
+    import hashlib
+    if world != 1 or workload != "c3":
+        return None, "not measured for this configuration"
+    h = hashlib.sha256()
+    for f in ("q2c_persist.hip", "common.h"):
+        h.update(open(os.path.join(root, "tvretrieval_amd", "csrc", f), "rb").read())
+    cands = sorted(glob.glob(os.path.join(root, "profiles", "r*_k6_traffic.json")))
+    for path in reversed(cands):
+        rec = json.load(open(path))
+        if rec.get("kernel_source_sha256") == h.hexdigest():
+            return rec["traffic_bytes_per_launch"], os.path.relpath(path, root)
+    return None, "no PMC pass for the current K6 source (sha256 %s...)" % h.hexdigest()[:12]
+
+
+def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "--gpus must equal WORLD_SIZE under torch.distributed.run"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
-    multi = world > 1 or args.force_sharded      # --force-sharded: the N > 1 code path through a real 1-rank RCCL group
+    be = load_backend(args, local_rank)
+    device = be.device
+    multi = world > 1 or args.force_sharded      # --force-sharded: the N > 1 code path through a real 1-rank group
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        dist.init_process_group(be.dist_backend, rank=rank, world_size=world, **be.init_kwargs())
 
     from tvretrieval_amd import inference as inf
     from tvretrieval_amd import dist as xdist
-    from tvretrieval_amd.model_xml import XML
     if args.force_sharded and world == 1:
         xdist.SKIP_TRIVIAL_COLLECTIVES = False
+    ops = be.ops
 
     nq, nv, l, hidden, dv, ds, dq, ctx_mode, dtname = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if dtname == "bf16" else torch.float32
     cfg = model_config(hidden, dv, ds, dq, ctx_mode, l)
     torch.manual_seed(0)
-    model = XML(cfg, compute_dtype=dtype).to(device).eval()
+    model = be.make_model(cfg, dtype)
 
     # ---- one-off: encode this rank's shard of the corpus (HOT LOOP A), untimed for the metric -------------
     lo, hi = xdist.shard_range(nv, rank, world, align=SHARD_ALIGN)
     with torch.no_grad():   # untimed warm-up of the encoder kernels (module load, first-launch costs, clocks)
         inf.build_corpus_index(model, context_batches(lo, min(hi, lo + 64), l, dv, ds, model.use_video, model.use_sub,
-                                                      device), video_offset=lo, n_total=nv, l_ref=l)
-    torch.cuda.synchronize()
+                                                      device), ops=ops, video_offset=lo, n_total=nv, l_ref=l)
+    be.sync()
     t0 = time.perf_counter()
     with torch.no_grad():
         index = inf.build_corpus_index(model, context_batches(lo, hi, l, dv, ds, model.use_video, model.use_sub, device),
-                                       video_offset=lo, n_total=nv, l_ref=l)
-    torch.cuda.synchronize()
+                                       ops=ops, video_offset=lo, n_total=nv, l_ref=l)
+    be.sync()
     enc_s = time.perf_counter() - t0
     rep_s = None
     if multi and not args.sharded_rerank:
@@ -168,41 +243,48 @@ def main():
         # the owner of a query reranks its global top-k itself, two collectives per pass instead of four
         t0 = time.perf_counter()
         xdist.replicate_rerank_features(index)
-        torch.cuda.synchronize()
+        be.sync()
         rep_s = time.perf_counter() - t0
     qf, qm = synth_queries(nq, dq, device)
 
-    ev = []      # (start, end) HIP event pairs around every K6 launch of the timed region
+    ev = []      # (start, end) event pairs around every K6 launch of the timed region
     def k6_timer():
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s, e = be.event(), be.event()
         ev.append((s, e))
         return s, e
 
     def step():
         with torch.no_grad():
             if not multi:
-                return inf.vcmr_search(model, index, qf, qm)
+                return inf.vcmr_search(model, index, qf, qm, ops=ops)
             # final lists stay on the rank that owns the query (where its NMS would run): no redundant gather
-            return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False)
+            return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False, ops=ops)
 
     for _ in range(args.warmup):
         step()
     inf.K6_TIMER = k6_timer
     if multi:
         dist.barrier()
-    torch.cuda.synchronize()
+    be.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
+        step()
+    be.sync()
     if multi:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     inf.K6_TIMER = None
+    per_rank_videos = [index.n_videos]
+    rccl_ranks = 1
     if multi:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        nvs = torch.zeros(world, device=device, dtype=torch.int64)
+        nvs[rank] = index.n_videos
+        dist.all_reduce(nvs)
+        per_rank_videos = [int(x) for x in nvs.cpu().tolist()]
+        rccl_ranks = dist.get_world_size()
 
     k6_ms = [s.elapsed_time(e) for s, e in ev]
     k6_avg_ms = float(np.mean(k6_ms))
@@ -213,36 +295,33 @@ def main():
     breakdown = {}
     if not multi:
         def timed(name, fn):
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record(); r = fn(); e.record(); torch.cuda.synchronize()
+            s, e = be.event(), be.event()
+            s.record(); r = fn(); e.record(); be.sync()
             breakdown[name] = round(s.elapsed_time(e), 3)
             return r
         with torch.no_grad():
             qvec = timed("query_encode", lambda: inf.stage_query_vectors(model, qf, qm))
-            q2c = timed("q2c_k6", lambda: inf.stage_q2c(index, qvec))
-            tw, ti = timed("topk_k8", lambda: inf.hip_ops.topk_rows(q2c, min(100, index.n_videos), alpha=20.0))
-            st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti))
-            timed("moment_k9", lambda: inf.hip_ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
+            q2c = timed("q2c_k6", lambda: inf.stage_q2c(index, qvec, ops))
+            tw, ti = timed("topk_k8", lambda: ops.topk_rows(q2c, min(100, index.n_videos), alpha=20.0))
+            st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti, ops))
+            timed("moment_k9", lambda: ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
     else:       # rank 0's view of one sharded pass, collectives (and the waiting for slower ranks in them) included
         marks = []
 
         def mark(name):
-            e = torch.cuda.Event(enable_timing=True)
+            e = be.event()
             e.record()
             marks.append((name, e))
         dist.barrier()
-        torch.cuda.synchronize()
+        be.sync()
         xdist.STAGE_MARK = mark
         step()
         xdist.STAGE_MARK = None
-        torch.cuda.synchronize()
+        be.sync()
         for (_, e0), (name, e1) in zip(marks, marks[1:]):
             breakdown[name] = round(e0.elapsed_time(e1), 3)
 
-    traffic = None      # fabric/HBM bytes per K6 launch from the committed PMC passes (same command, same shape)
-    tpath = os.path.join(ROOT, "profiles", "r01_k6_traffic.json")
-    if world == 1 and args.workload == "c3" and os.path.isfile(tpath):
-        traffic = json.load(open(tpath))["traffic_bytes_per_launch"]
+    traffic, traffic_src = k6_traffic(ROOT, args.workload, world) if be.name == "hip" else (None, "stub backend")
 
     res = None
     if rank == 0:
@@ -253,14 +332,18 @@ def main():
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtname, "data": "synthetic",
             "config": {"workload": "%s: XML %s ConvSE VCMR, %d queries x %d videos x %d clips, H=%d, top-100 videos, "
                                    "top-200 moments" % (args.workload, ctx_mode, nq, nv, l, hidden),
-                       "global_batch": nq, "parallelism": "corpus-shard x%d" % world, "videos_per_gpu": index.n_videos,
+                       "global_batch": nq, "parallelism": "corpus-shard x%d" % world, "videos_per_gpu": per_rank_videos,
+                       "ranks_in_process_group": rccl_ranks, "backend": be.name,
+                       "launcher": "bench.py self-spawn" if os.environ.get("XML_SELF_SPAWNED") else
+                                   ("torch.distributed.run" if world > 1 else "single process"),
                        "result_placement": "all on the GPU" if not multi else "final lists on the query's owner rank",
                        "rerank": "local" if not multi else ("video owner (feat2 sharded)" if args.sharded_rerank else
                                                              "query owner (feat2 replicated, feat1 sharded)")},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtname], "unit": "TFLOP/s",
                          "frac": achieved / PEAK_TFLOPS[dtname], "traffic": traffic,
-                         "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE, "
-                                         "profiles/r01_k6_traffic.json; algorithmic bytes = %.3g" % (
+                         "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE: %s; "
+                                         "algorithmic bytes = %.3g" % (
+                                             traffic_src,
                                              len(index.modalities) * (index.n_videos * index.lpad * hidden * 2.0
                                                                       + nq * hidden * 2.0) + nq * index.n_videos * 4.0),
                          "kernel": "q2c_persist_kernel",
@@ -270,8 +353,13 @@ def main():
             "corpus_hbm_gb_per_gpu": index.hbm_bytes() / 1e9, "replicate_feat2_s": rep_s,
             "breakdown_ms": breakdown,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname)
+        if world == 1 and not args.no_cpu_baseline and be.name == "hip":
+            def search(nq_s, nv_s):       # the baseline's slice through the HIP path, for the agreement figures
+                with torch.no_grad():
+                    sub = inf.build_corpus_index(model, context_batches(0, nv_s, l, dv, ds, model.use_video,
+                                                                       model.use_sub, device), ops=ops, l_ref=l)
+                    return inf.vcmr_search(model, sub, qf[:nq_s].contiguous(), qm[:nq_s].contiguous(), ops=ops)
+            res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname, search)
         else:
             res["cpu_baseline"] = None
     if multi:       # RCCL's start-up banner sits in the C stdio buffer of every rank: push it out BEFORE the result line,
@@ -285,6 +373,30 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     return res
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU code path even with 1 rank (testing)")
+    ap.add_argument("--sharded-rerank", action="store_true",
+                    help="N > 1: keep feat2 sharded too (phase 2 on the video's owner, four collectives per pass)")
+    ap.add_argument("--backend-module", default=None,
+                    help="TEST HOOK: module providing BenchBackend (tests/cpu_backend.py: gloo ranks on CPU, kernels "
+                         "replaced by the oracle formulation) -- exercises this launcher without GPUs")
+    args = ap.parse_args(argv)
+    from tvretrieval_amd import launch
+    if args.gpus > 1 and not launch.under_launcher():
+        # `python bench.py --gpus N`: one process per GPU, started here (same environment torch.distributed.run gives)
+        rc = launch.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus)
+        if rc != 0:
+            sys.exit(rc)
+        return None
+    return run(args)
 
 
 if __name__ == "__main__":

@@ -124,3 +124,42 @@ class CpuModel(object):
             names_st = [n + "_st_predictor" for n in mods]
             names_ed = [n + "_ed_predictor" for n in mods]
         return torch.cat([w[n + ".weight"].reshape(-1) for n in names_st + names_ed])
+
+
+class _WallEvent(object):
+    """Stand-in for a HIP event on the CPU backend: a perf_counter stamp."""
+
+    def __init__(self):
+        self.t = None
+
+    def record(self):
+        import time
+        self.t = time.perf_counter()
+
+    def elapsed_time(self, other):
+        return (other.t - self.t) * 1e3
+
+
+class BenchBackend(object):
+    """`bench.py --backend-module cpu_backend`: the launcher / sharded orchestration of bench.py on gloo ranks without a
+    GPU (tests/test_bench_launcher.py).  Kernels = CpuOps, model = CpuModel over a freshly initialised XML."""
+    name, dist_backend = "cpu-stub", "gloo"
+
+    def __init__(self, local_rank):
+        self.device = torch.device("cpu")
+        self.ops = CpuOps
+        torch.set_num_threads(2)
+
+    def make_model(self, cfg, dtype):
+        from tvretrieval_amd.model_xml import XML
+        sd = {k: v.detach().float() for k, v in XML(cfg).state_dict().items()}
+        return CpuModel(cfg, sd)
+
+    def sync(self):
+        pass
+
+    def event(self):
+        return _WallEvent()
+
+    def init_kwargs(self):
+        return {}

@@ -1,0 +1,52 @@
+"""`python bench.py --gpus N` must measure N ranks by itself (the driver's command line has no torchrun).  Here the very
+same launcher code (tvretrieval_amd/launch.py + bench.py main) starts 2 gloo ranks on CPU, with the kernels replaced by
+tests/cpu_backend.py, and must print exactly one JSON line that says n_gpus = 2."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def _run(argv, timeout=900):
+    env = dict(os.environ, PYTHONPATH=HERE + os.pathsep + ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True,
+                          text=True, timeout=timeout)
+
+
+def test_bench_self_spawns_two_gloo_ranks():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "tiny", "--backend-module", "cpu_backend",
+              "--no-cpu-baseline"])
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert lines[-1].startswith("{") and sum(ln.startswith("{") for ln in lines) == 1, lines   # ONE result line, last
+    res = json.loads(lines[-1])
+    assert res["n_gpus"] == 2 and res["config"]["ranks_in_process_group"] == 2
+    assert res["config"]["launcher"] == "bench.py self-spawn"
+    assert len(res["config"]["videos_per_gpu"]) == 2 and sum(res["config"]["videos_per_gpu"]) == 300
+    assert res["value"] > 0 and res["scaling"] == "strong"
+    stages = res["breakdown_ms"]
+    assert "alltoall_topk" in stages and "q2c_k6" in stages, stages
+
+
+def test_bench_rank_failure_propagates():
+    r = _run(["--gpus", "2", "--steps", "1", "--warmup", "0", "--workload", "tiny", "--backend-module",
+              "no_such_backend_module"], timeout=300)
+    assert r.returncode != 0
+
+
+@pytest.mark.gpu
+def test_bench_tiny_forced_sharded_on_gpu():
+    """Same entry on the GPU box: the N > 1 code path through a real 1-rank RCCL group."""
+    r = _run(["--gpus", "1", "--force-sharded", "--workload", "tiny", "--steps", "2", "--warmup", "1",
+              "--no-cpu-baseline"])
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["n_gpus"] == 1 and res["config"]["backend"] == "hip" and res["config"]["ranks_in_process_group"] == 1
+    assert "alltoall_topk" in res["breakdown_ms"] or "topk_k8" in res["breakdown_ms"]

@@ -1,7 +1,8 @@
 """Time one XML training step (BASELINE.json configs[4]: batch 128 video+sub, bf16) on the HIP kernels.
 
     python tools/bench_train.py [--bsz 128] [--ctx-l 100] [--hidden 768] [--dtype bf16] [--steps 10]
-    python -m torch.distributed.run --nproc-per-node N ... tools/bench_train.py     (data parallel, RCCL all-reduce)
+    python tools/bench_train.py --gpus N        (data parallel, RCCL all-reduce: starts the N ranks itself)
+    python -m torch.distributed.run --nproc-per-node N ... tools/bench_train.py --gpus N     (same job under torchrun)
 
 Synthetic features of TVR shape (video 3072-d, subtitle / query 768-d), random-init weights.  Prints one JSON line:
 ms per step split into forward / backward / all-reduce / optimizer, and pairs (query + video) per second.
@@ -28,7 +29,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gpus", type=int, default=1)
     a = ap.parse_args()
+    from tvretrieval_amd import launch
+    if a.gpus > 1 and not launch.under_launcher():
+        rc = launch.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus)
+        sys.exit(rc)
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

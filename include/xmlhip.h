@@ -58,10 +58,12 @@ int xml_convert(const void* src, int src_dt, void* dst, int dst_dt, int64_t n, x
  * replaces LinearLayer.forward (xml/model_components.py:156-163) followed by
  * TrainablePositionalEncoding.forward (:76-89) as called from XML.encode_input (xml/model_xml.py:387-390).
  *   x      (rows, d_in)  raw features, f32 or dt (x_dt)
- *   w      (hidden, d_in) dt;  b (hidden) f32;  ln_in_{g,b} (d_in) f32
+ *   w      (hidden, d_pad) dt, d_pad = d_in rounded up to a multiple of 8, columns >= d_in ZERO (pack time);
+ *          b (hidden) f32;  ln_in_{g,b} (d_in) f32
  *   pos    (>= seq_len, hidden) dt;  ln_pos_{g,b} (hidden) f32
  *   y      (rows, hidden) dt
- * Requirements: d_in % 8 == 0, hidden % 8 == 0.
+ * Requirements: hidden % 8 == 0.  Any d_in: the TEF context modes (visual 3074 / sub 770, xml/config.py:251-254,
+ * xml/start_end_dataset.py:127-142) take the LayerNorm statistics over d_in and run the GEMM over d_pad.
  * --------------------------------------------------------------------------------------------- */
 size_t xml_linear_ln_relu_pos_workspace_bytes(int64_t rows, int d_in, int hidden, int dt);
 int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const float* ln_in_b,

@@ -127,7 +127,8 @@ def test_layernorm_l2norm_convert(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("shape", [(3, 17, 96, 128), (2, 128, 3072, 768), (9, 30, 64, 256)])
+@pytest.mark.parametrize("shape", [(3, 17, 96, 128), (2, 128, 3072, 768), (9, 30, 64, 256),
+                                   (3, 40, 770, 256), (2, 100, 3074, 768), (2, 9, 37, 64)])   # TEF dims: d_in % 8 != 0
 def test_linear_ln_relu_pos(ops, dtype, shape):
     n, l, d_in, h = shape
     x = rnd(n, l, d_in, seed=10)
@@ -136,8 +137,9 @@ def test_linear_ln_relu_pos(ops, dtype, shape):
     pe = {"position_embeddings.weight": rnd(l + 3, h, seed=15, scale=0.5), "LayerNorm.weight": 1 + 0.1 * rnd(h, seed=16),
           "LayerNorm.bias": 0.1 * rnd(h, seed=17)}
     want = O.trainable_pos_enc(O.linear_layer(x, O.Weights(sd)), O.Weights(pe))
+    w_pad = torch.nn.functional.pad(sd["net.1.weight"], (0, -d_in % 8))      # pack-time K padding (LinearLayer.packed)
     got = ops.linear_ln_relu_pos(dev(x), dev(sd["LayerNorm.weight"]), dev(sd["LayerNorm.bias"]),
-                                 dev(sd["net.1.weight"], dtype), dev(sd["net.1.bias"]),
+                                 dev(w_pad, dtype), dev(sd["net.1.bias"]),
                                  dev(pe["position_embeddings.weight"], dtype), dev(pe["LayerNorm.weight"]),
                                  dev(pe["LayerNorm.bias"]))
     close("linear_ln_relu_pos", got, want, _tol(dtype, 5e-5, 6e-2))

@@ -262,6 +262,31 @@ def test_search_vs_oracle_fp32(ctx_mode, hidden):
         assert set(fi[q][:100].tolist()) <= set(wfi[q].tolist()) | {-1}
 
 
+def test_tef_context_mode_dims_vs_oracle():
+    """video_sub_tef checkpoints (xml/config.py:108-110,251-254): visual 3072+2 / sub 768+2 input dims (the dataset
+    concatenates the two TEF columns, xml/start_end_dataset.py:127-142).  Encode + search vs the oracle, fp32."""
+    from tvretrieval_amd import inference as inf
+    nv, nq, l = 10, 7, 64
+    m, cfg = _synthetic_model("video_sub", 256, 3074, 770, 768, l, torch.float32, seed=9)
+    rng = np.random.default_rng(5)
+    lens = rng.integers(10, l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, 3074, 1)
+    sf, sm = _feats(nv, lens, 770, 2)
+    qf, qm = _feats(nq, rng.integers(5, 31, nq), 768, 3)
+    om = O.OracleXML(cfg, {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        ov1, ov2, os1, os2 = om.encode_context(vf, vm, sf, sm)
+        q2c, st, ed = om.get_pred_from_raw_query(qf, qm, ov1, ov2, vm, os1, os2, sm, cross=True)
+        v1, v2, s1, s2 = m.encode_context(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))])
+        out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=5, max_before_nms=50)
+    for name, a, b in (("vf1", v1, ov1), ("vf2", v2, ov2), ("sf1", s1, os1), ("sf2", s2, os2)):
+        close(name, a, b, 2e-4)
+    close("q2c", out["q2c"], q2c, 1e-4)
+    want = O.vcmr_tail(q2c, st, ed, 20.0, 5, 2, 16, 50)
+    assert torch.equal(out["top_indices"].cpu().long(), want["top_indices"])
+
+
 def test_svmr_only_external_vr_and_eval_epoch(tmp_path):
     """"next" rows 8f-1/2/4 end to end on the golden pipeline fixture: SVMR-only path == the SVMR list of the full
     run, external-VR re-ranking fed with this model's own VR output reproduces its VCMR list, eval_epoch runs NMS

@@ -345,10 +345,11 @@ extern "C" int xml_linear(const void* x, const void* w, const float* b, void* y,
 
 // ---------------------------------------------------------------------------------------------------
 // public: K1 + K2
-//   ws layout: [ LN_in(x) as dt (rows x d_in) | pre-LN f32 (rows x hidden) ]
+//   ws layout: [ LN_in(x) as dt (rows x d_pad) | pre-LN f32 (rows x hidden) ],  d_pad = d_in rounded up to 8
 // ---------------------------------------------------------------------------------------------------
+static inline int k_pad8(int d_in) { return (d_in + 7) & ~7; }
 extern "C" size_t xml_linear_ln_relu_pos_workspace_bytes(int64_t rows, int d_in, int hidden, int dt) {
-  return align_up((size_t)rows * d_in * dt_size(dt), 256) + align_up((size_t)rows * hidden * 4, 256);
+  return align_up((size_t)rows * k_pad8(d_in) * dt_size(dt), 256) + align_up((size_t)rows * hidden * 4, 256);
 }
 
 extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const float* ln_in_b,
@@ -358,14 +359,17 @@ extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_i
   XML_ENTER();
   if (!x || !ln_in_g || !ln_in_b || !w || !b || !pos || !ln_pos_g || !ln_pos_b || !y || !ws) return XML_ERR_BAD_ARG;
   if (rows <= 0 || seq_len <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
-  if (d_in % 8 || hidden % 8) return XML_ERR_UNSUPPORTED;
+  if (d_in <= 0 || hidden % 8) return XML_ERR_UNSUPPORTED;
   if (ws_bytes < xml_linear_ln_relu_pos_workspace_bytes(rows, d_in, hidden, dt)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  // TEF inputs (d_in = 3074 / 770, xml/config.py:251-254): LN statistics over d_in, the normalised row is written with
+  // zero columns up to d_pad and the weight arrives zero-padded in K alike, so the GEMM sees K = d_pad
+  const int d_pad = k_pad8(d_in);
   char* xn = (char*)ws;
-  char* pre = xn + align_up((size_t)rows * d_in * dt_size(dt), 256);
-  int rc = xmli_add_layernorm(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_in, dt, st);
+  char* pre = xn + align_up((size_t)rows * d_pad * dt_size(dt), 256);
+  int rc = xmli_add_layernorm(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_pad, dt, st);
   if (rc) return rc;
-  rc = xmli_gemm(xn, w, b, pos, pre, rows, hidden, d_in, /*relu*/ 1, /*add_mode*/ 1, seq_len, /*out_f32*/ 1, dt, st);
+  rc = xmli_gemm(xn, w, b, pos, pre, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, /*out_f32*/ 1, dt, st);
   if (rc) return rc;
   return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, dt, st);
 }

@@ -78,8 +78,12 @@ class LinearLayer(nn.Module, _PackedMixin):
 
     def _build_packed(self, dtype):
         lin = self.net[1]
-        return dict(ln_g=_f(self.LayerNorm.weight), ln_b=_f(self.LayerNorm.bias), w=_w(lin.weight, dtype),
-                    b=_f(lin.bias))
+        w = lin.weight.detach()
+        d_in = w.shape[1]
+        d_pad = _round_up(d_in, 8)
+        if d_pad != d_in:      # TEF inputs (3074 / 770, xml/config.py:251-254): zero K columns, the kernel pads LN(x) alike
+            w = torch.nn.functional.pad(w, (0, d_pad - d_in))
+        return dict(ln_g=_f(self.LayerNorm.weight), ln_b=_f(self.LayerNorm.bias), w=_w(w, dtype), b=_f(lin.bias))
 
 
 class TrainablePositionalEncoding(nn.Module, _PackedMixin):

@@ -74,11 +74,12 @@ def pack_weights(w_f32, dtype):
 
 
 def linear_ln_relu_pos(x, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
-    """K1+K2.  x (N, L, D_in) f32 or compute dtype; w (H, D_in) compute dtype -> (N, L, H)."""
+    """K1+K2.  x (N, L, D_in) f32 or compute dtype; w (H, ceil8(D_in)) compute dtype, zero columns beyond D_in
+    -> (N, L, H)."""
     _req(x, "x"); _req(w, "w"); _req(pos, "pos", w.dtype)
     n, seq_len, d_in = x.shape
     hidden = w.shape[0]
-    assert w.shape[1] == d_in and pos.shape[1] == hidden and pos.shape[0] >= seq_len, "shape mismatch"
+    assert w.shape[1] == (d_in + 7) // 8 * 8 and pos.shape[1] == hidden and pos.shape[0] >= seq_len, "shape mismatch"
     for t, nm in ((ln_in_g, "ln_in_g"), (ln_in_b, "ln_in_b"), (b, "b"), (ln_pos_g, "ln_pos_g"), (ln_pos_b, "ln_pos_b")):
         _req(t, nm, torch.float32)
     lib = _lib.load()

@@ -318,10 +318,16 @@ int xml_clip_grad_norm(float* g, int64_t n, float max_norm, float* ws, xml_strea
 /* BertAdam.step (xml/optimization.py:273-338) over one flat f32 buffer holding every tensor:
  * per-tensor clip_grad_norm_ (gradient rescaled in place), m/v update, m/(sqrt(v)+eps) + wd*p, no bias
  * correction, p -= seg_lr[s] * lr_mult * update.  seg_off (n_seg+1) int64, seg_lr / seg_wd / norms (n_seg) f32,
- * all device memory. */
+ * all device memory.
+ *   seg_active (n_seg bytes) or NULL (= all): 0 marks a tensor that has never received a gradient -- the reference
+ *     skips it entirely (`if p.grad is None: continue`, :289-291): no moments, no weight decay;
+ *   seg_lr_mult (n_seg) f32 or NULL: per-tensor schedule multiplier replacing the scalar lr_mult -- the reference keeps
+ *     state['step'] per tensor (:325-330), so tensors that join the training later (train_span_start_epoch) restart
+ *     their warm-up. */
 int xml_bert_adam_step(float* p, float* g, float* m, float* v, const int64_t* seg_off, const float* seg_lr,
                        const float* seg_wd, int n_seg, int64_t total, float lr_mult, float b1, float b2,
-                       float eps, float max_grad_norm, float* norms, xml_stream_t stream);
+                       float eps, float max_grad_norm, float* norms, const uint8_t* seg_active,
+                       const float* seg_lr_mult, xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * HOST post-processing ("next" row 8f-1; pointers are HOST memory): greedy temporal NMS.

@@ -432,9 +432,11 @@ def bert_adam_step(params, grads, state, step, weight_decay, lr=1e-4, warmup=-1,
     """BertAdam.step for the warmup_linear schedule, xml/optimization.py:273-338.  params / grads / weight_decay:
     dicts keyed by parameter name; state: dict name -> (m, v), created on first use.  Updates params and grads
     (the per-tensor clip rescales the gradient in place) and returns nothing; `step` is the per-parameter step
-    counter BEFORE this call (identical for all parameters)."""
-    mult = 1.0 if t_total < 0 else warmup_linear(float(step) / float(t_total), max(warmup, 0.0))
+    counter BEFORE this call (state['step'], :325-330): one int for all parameters, or a dict name -> int.  Only the
+    tensors listed in `params` are touched (`if p.grad is None: continue`, :289-291)."""
     for k, p in params.items():
+        sk = step[k] if isinstance(step, dict) else step
+        mult = 1.0 if t_total < 0 else warmup_linear(float(sk) / float(t_total), max(warmup, 0.0))
         g = grads[k]
         if k not in state:
             state[k] = (torch.zeros_like(p), torch.zeros_like(p))

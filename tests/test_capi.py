@@ -85,3 +85,30 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     m2.load_state_dict(ck["model"])
     for k, v in m2.state_dict().items():
         assert torch.equal(v, torch.from_numpy(sd[k]))
+
+
+def test_config_is_validated_at_construction():
+    """Shapes outside what the kernels implement fail in XML.__init__ with the reason (not deep inside a launch)."""
+    import pytest
+    from tvretrieval_amd.model_xml import XML, xml_base_config
+    with pytest.raises(ValueError, match="multiple"):
+        XML(dict(xml_base_config))                      # hidden_size = 500 placeholder of xml_base_config
+    ok = dict(xml_base_config, hidden_size=256)
+    XML(ok)
+    with pytest.raises(ValueError, match="max_ctx_l"):
+        XML(dict(ok, max_ctx_l=200))
+    with pytest.raises(ValueError, match="conv_kernel_size"):
+        XML(dict(ok, conv_kernel_size=4))
+
+
+def test_config_pickles_as_easydict_module():
+    """model.config inside a checkpoint must resolve as `easydict.EasyDict` on the reference side (xml/train.py:219-223)."""
+    import pickle
+    import pickletools
+    from tvretrieval_amd.model_xml import XML, xml_base_config
+    m = XML(dict(xml_base_config, hidden_size=256))
+    blob = pickle.dumps(m.config, protocol=2)
+    names = [arg for op, arg, _ in pickletools.genops(blob) if op.name == "GLOBAL"]
+    assert names and all(n.startswith("easydict ") for n in names), names
+    back = pickle.loads(blob)
+    assert back.hidden_size == 256 and dict(back) == dict(m.config)

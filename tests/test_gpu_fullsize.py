@@ -14,30 +14,12 @@ import pytest
 import torch
 
 from oracle import xml_oracle as O
+from oracle.listcmp import tie_aware_equal as _tie_aware_equal
 from test_gpu_kernels import DEV
 from test_gpu_model import _synthetic_model
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-
-
-def _tie_aware_equal(got_keys, got_scores, want_keys, want_scores, k, rtol, what):
-    """Rows of ranked lists: got[:k] must equal want[:k] position by position, except where the entry got placed there
-    is found in want's (longer) list with a score within rtol of the score want has at that position (a tie to rounding,
-    torch leaves the order of ties unspecified).  Returns the number of positions that differed."""
-    n_diff = 0
-    for q in range(len(got_keys)):
-        g, w = got_keys[q][:k], want_keys[q]
-        bad = np.nonzero(g != w[:k])[0]
-        n_diff += len(bad)
-        for i in bad:
-            j = np.nonzero(w == g[i])[0]
-            assert len(j) == 1, (what, "entry not in the reference list at all", q, int(i), int(g[i]))
-            ref_here = want_scores[q][i]
-            assert abs(want_scores[q][j[0]] - ref_here) <= rtol * abs(ref_here), \
-                (what, "order differs beyond rounding", q, int(i), float(want_scores[q][j[0]]), float(ref_here))
-            assert abs(got_scores[q][i] - want_scores[q][j[0]]) <= rtol * abs(ref_here), (what, "score", q, int(i))
-    return n_diff
 
 
 def test_c2_full_shape_vs_oracle_fp32():

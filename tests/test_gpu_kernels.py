@@ -45,6 +45,20 @@ def ops():
     return o
 
 
+@pytest.fixture
+def dbg_lib(ops, monkeypatch):
+    """The -DXML_DEBUG_VARIANTS build (kernel-variant switches) standing in for the product library during one test.
+    The product library has no such switches (stateless dispatch); __graft_entry__.build() builds both."""
+    import ctypes
+    import os
+    path = os.path.join(os.path.dirname(ops._lib.LIB_PATH), "libxmlhip_dbg.so")
+    if not os.path.isfile(path):
+        pytest.skip("libxmlhip_dbg.so not built (XML_DEBUG=1 bash tvretrieval_amd/csrc/build.sh)")
+    lib = ops._lib.bind(ctypes.CDLL(path))
+    monkeypatch.setattr(ops._lib, "_lib", lib)
+    return lib
+
+
 def dev(t, dtype=None):
     t = t.to(DEV)
     return t.to(dtype).contiguous() if dtype is not None else t.contiguous()
@@ -65,12 +79,12 @@ def test_linear(ops, dtype, shape):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-def test_persistent_gemm_equals_tile_per_workgroup_gemm(ops, dtype):
+def test_persistent_gemm_equals_tile_per_workgroup_gemm(ops, dbg_lib, dtype):
     """large projections run on the persistent 256x256 kernel (gemm256p.hip): same MFMA sequence per accumulator as the
     one-tile-per-workgroup kernel -> bitwise the same outputs, for every epilogue (bias, ReLU, position / residual
     addend, bf16 / f32 out, ragged M, N not a multiple of 8)."""
     import ctypes
-    lib = ops._lib.load()
+    lib = dbg_lib
     g = torch.Generator(device=DEV).manual_seed(7)
 
     def both(fn):
@@ -349,11 +363,11 @@ def test_q2c_fused_full_scale_property(ops):
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("lpad", [128, 48])
-def test_q2c_variants_equivalent(ops, dtype, lpad):
+def test_q2c_variants_equivalent(ops, dbg_lib, dtype, lpad):
     """128x128 register-staged kernel (with / without XCD swizzle) == 256x256 LDS-DMA kernels (ring / double buffer), bit for bit:
     every accumulator sees the same MFMA sequence over K."""
     import ctypes
-    lib = ops._lib.load()
+    lib = dbg_lib
     q, c = _normed(1100, 256, seed=83), _normed(70, lpad, 256, seed=84)
     mask = _ragged_mask(70, lpad, 85)
     args = (dev(q, dtype), dev(c, dtype), dev(mask))

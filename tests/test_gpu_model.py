@@ -236,7 +236,7 @@ def test_search_vs_oracle_fp32(ctx_mode, hidden):
         ov1, ov2, os1, os2 = om.encode_context(vf, vm, sf, sm)
         q2c, st, ed = om.get_pred_from_raw_query(qf, qm, ov1, ov2, vm if om.use_video else None, os1, os2,
                                                  sm if om.use_sub else None, cross=True)
-        want = O.vcmr_tail(q2c, st, ed, 20.0, 10, 2, 16, 200)
+        want = O.vcmr_tail(q2c, st, ed, 20.0, 10, 2, 16, 216)
         bs = 16
         batches = [(vf[b:b + bs].to(DEV), vm[b:b + bs].to(DEV), sf[b:b + bs].to(DEV), sm[b:b + bs].to(DEV))
                    for b in range(0, nv, bs)]
@@ -251,15 +251,14 @@ def test_search_vs_oracle_fp32(ctx_mode, hidden):
         for i in np.nonzero(gi[q] != wi[q])[0]:
             j = np.nonzero(wi[q] == gi[q][i])[0]
             assert len(j) == 1 and abs(ws[q][j[0]] - ws[q][i]) <= 4e-3 * ws[q][i], ("video rank", q, i)
-    same = (gi == wi).all(1)
-    assert same.mean() > 0.8
+    from oracle.listcmp import moment_keys, tie_aware_equal
+    same = np.nonzero((np.sort(gi, 1) == np.sort(wi, 1)).all(1))[0]      # same top-10 SET => same candidate pool
+    assert len(same) >= 0.9 * nq
     fs, fi = out["flat_scores"].cpu().numpy(), out["flat_indices"].cpu().numpy()
-    wfs, wfi = want["flat_scores"].numpy(), want["flat_indices"].numpy()
-    for q in np.nonzero(same)[0]:
-        np.testing.assert_allclose(fs[q], wfs[q], rtol=5e-3)
-        agree = (fi[q] == wfi[q]).mean()
-        assert agree > 0.9, ("moment order", q, agree)
-        assert set(fi[q][:100].tolist()) <= set(wfi[q].tolist()) | {-1}
+    gk, wk = moment_keys(fi, gi, l), moment_keys(want["flat_indices"].numpy(), wi, l)
+    assert (fi[same] >= 0).all()
+    n_sw = tie_aware_equal(gk[same], fs[same], wk[same], want["flat_scores"].numpy()[same], 200, 5e-4, "moments")
+    assert n_sw <= 0.02 * len(same) * 200, n_sw
 
 
 def test_tef_context_mode_dims_vs_oracle():

@@ -291,6 +291,47 @@ def test_golden_train_steps_fp32(name):
     assert moved > 1e-5
 
 
+def test_golden_staged_training_fp32():
+    """train_span_start_epoch: two steps with lw_st_ed = 0, then three with the span loss.  The 42 tensors behind the span
+    branch must stay untouched (no weight decay, no moments) until they first receive a gradient and then run their OWN
+    warm-up (per-tensor step), xml/optimization.py:289-291,325-330 -- vs the reference's parameters after five steps."""
+    from tvretrieval_amd.train import BertAdam, xml_forward_train
+    d, cfg, _ = load_golden("train_step_staged_video_sub_h128")
+    m = build_train_model(cfg, d)
+    okw = json.loads(str(d["optim"]))
+    named = list(m.named_parameters())
+    groups = [{"params": [p for n, p in named if not any(nd in n for nd in NO_DECAY)], "weight_decay": 0.01},
+              {"params": [p for n, p in named if any(nd in n for nd in NO_DECAY)], "weight_decay": 0.0}]
+    opt = BertAdam(groups, **okw)
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]))
+    late = set(json.loads(str(d["no_grad_at_step0"])))
+    before = {n: p.detach().clone() for n, p in named}
+    assert opt.get_lr() == [0]
+    for it, lw in enumerate(d["lw_st_ed_schedule"]):
+        m.config.lw_st_ed = float(lw)
+        loss, _ = xml_forward_train(m, neg_ctx_rank=d["neg_ctx_rank_steps"][it], neg_q_rank=d["neg_q_rank_steps"][it],
+                                    **batch)
+        assert abs(float(loss) - float(d["step_losses"][it])) < 5e-5, (it, float(loss), float(d["step_losses"][it]))
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        if it == 1:      # after two span-less steps the late tensors are bit-for-bit what they were
+            for n, p in named:
+                if n in late:
+                    assert torch.equal(p.detach(), before[n]), n
+    want_steps = json.loads(str(d["final_steps"]))
+    got_steps = {n: opt.seg_steps[i] for i, (n, _) in enumerate((n, p) for g in groups for p in g["params"]
+                                                                  for n, q in named if q is p)}
+    assert got_steps == want_steps
+    sd = m.state_dict()
+    errs = sorted(((rel_err(sd[k[len("sd_after3/"):]], torch.from_numpy(v)), k) for k, v in d.items()
+                   if k.startswith("sd_after3/")), reverse=True)
+    print("worst parameter errors after the staged steps:", errs[:3])
+    assert errs[0][0] < 2e-4, errs[:5]
+
+
 def test_train_step_bf16_runs_and_descends():
     """bf16 compute: the loss of the fixture batch must go down over a few steps (no golden for bf16)."""
     from tvretrieval_amd.train import BertAdam, train_step

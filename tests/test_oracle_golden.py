@@ -147,17 +147,24 @@ def test_pipeline(name):
 NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight"]     # xml/train.py:355-362
 
 
-@pytest.mark.parametrize("name", ["train_step_video_sub_h128", "train_step_nocross_lse_h128"])
+@pytest.mark.parametrize("name", ["train_step_video_sub_h128", "train_step_nocross_lse_h128",
+                                  "train_step_staged_video_sub_h128"])
 def test_training_steps(name):
-    """loss / gradients of step 1 and the parameters after three BertAdam steps of the reference."""
+    """loss / gradients of step 1 and the parameters after the BertAdam steps of the reference (three; the staged case
+    runs two steps without the span loss and three with it: tensors that have never received a gradient are skipped and
+    every tensor counts its own schedule steps)."""
     d, cfg, _ = load_golden(name)
     sd = {k[len("sd_before/"):]: v for k, v in d.items() if k.startswith("sd_before/")}
     params = {k: torch.from_numpy(v.copy()) for k, v in sd.items()}
     okw = json.loads(str(d["optim"]))
     wd = {k: (0.0 if any(nd in k for nd in NO_DECAY) else okw["weight_decay"]) for k in params}
     state = {}
-    for it in range(3):
+    sched = d["lw_st_ed_schedule"] if "lw_st_ed_schedule" in d else None
+    ever, steps = set(), {k: 0 for k in params}
+    for it in range(3 if sched is None else len(sched)):
         leaf = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+        if sched is not None:
+            cfg = dict(cfg, lw_st_ed=float(sched[it]))
         m = O.OracleXML(cfg, leaf)
         loss, parts = m.forward_loss(d["query_feat"], d["query_mask"], d["video_feat"], d["video_mask"],
                                      d["sub_feat"], d["sub_mask"], d["st_ed_indices"], d["neg_ctx_rank_steps"][it],
@@ -174,7 +181,14 @@ def test_training_steps(name):
                     _close(p.grad, d["grad/" + k], rtol=1e-4, atol=1e-6)
         with torch.no_grad():
             grads = {k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in leaf.items()}
-            trainable = {k: params[k] for k in params if leaf[k].grad is not None}
-            O.bert_adam_step(trainable, grads, state, it, wd, **{k: v for k, v in okw.items() if k != "weight_decay"})
+            ever |= {k for k in params if leaf[k].grad is not None}
+            # staged case: torch 1.4 zero_grad semantics -- a tensor that has EVER had a gradient keeps stepping
+            trainable = {k: params[k] for k in params if (leaf[k].grad is not None if sched is None else k in ever)}
+            O.bert_adam_step(trainable, grads, state, steps, wd, **{k: v for k, v in okw.items() if k != "weight_decay"})
+            for k in trainable:
+                steps[k] += 1
+    if sched is not None:
+        assert steps == json.loads(str(d["final_steps"]))
+        assert sorted(set(steps.values())) == [3, 5]
     for k, p in params.items():
         _close(p, d["sd_after3/" + k], rtol=1e-4, atol=2e-6)

@@ -11,6 +11,7 @@ shapes = [(300000, 2304, 768), (300000, 768, 768), (65536, 768, 3072), (65536, 2
           (16384, 2304, 768), (3840, 2304, 768), (300000, 2304, 3072)]
 import ctypes
 lib = ops._lib.load()
+assert hasattr(lib, "xml_debug_set_q2c_variant"), "needs the debug library: XML_DEBUG=1 bash tvretrieval_amd/csrc/build.sh; XMLHIP_LIB=$PWD/tvretrieval_amd/csrc/libxmlhip_dbg.so"
 g = torch.Generator(device="cuda").manual_seed(0)
 abl = int(os.environ.get("XML_ABL", "0"))
 lib.xml_debug_set_q2c_ablation(ctypes.c_int(abl))

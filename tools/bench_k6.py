@@ -21,6 +21,7 @@ def main():
     dtype = torch.float32 if "--f32" in sys.argv else torch.bfloat16
     abl = [int(a.split("=")[1]) for a in sys.argv[1:] if a.startswith("--ablation=")]
     lib = ops._lib.load()
+    assert hasattr(lib, "xml_debug_set_q2c_variant"), "needs the debug library: XML_DEBUG=1 bash tvretrieval_amd/csrc/build.sh; XMLHIP_LIB=$PWD/tvretrieval_amd/csrc/libxmlhip_dbg.so"
     if abl:
         lib.xml_debug_set_q2c_ablation(ctypes.c_int(abl[0]))
     g = torch.Generator(device="cuda").manual_seed(0)

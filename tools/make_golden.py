@@ -271,7 +271,7 @@ def gen_pipeline_case(ns, name, cfg, seed, n_v, len_lo, len_hi, n_q, ctx_bsz, q_
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
-def gen_train_case(ns, name, cfg, seed, bsz, len_lo, len_hi):
+def gen_train_case(ns, name, cfg, seed, bsz, len_lo, len_hi, lw_st_ed_schedule=None):
     """One training step of the reference: XML.forward -> backward -> BertAdam.step, with the CPU
     torch.randint draws of get_neg_scores (xml/model_xml.py:622) recorded in call order."""
     rng = np.random.default_rng(seed)
@@ -307,14 +307,21 @@ def gen_train_case(ns, name, cfg, seed, bsz, len_lo, len_hi):
         okw = dict(lr=1e-4, weight_decay=0.01, warmup=0.1, t_total=10, schedule="warmup_linear")
         optim = ns.optimization.BertAdam(groups, **okw)
         tv = torch.from_numpy
-        n_steps = 3
+        n_steps = 3 if lw_st_ed_schedule is None else len(lw_st_ed_schedule)
         step_losses = []
         for it in range(n_steps):          # the same batch three times: lr multiplier is 0 at step 0, then 1.0, 0.889
+            if lw_st_ed_schedule is not None:
+                # staged training (train_span_start_epoch, xml/train.py:47-48 -> set_train_st_ed): the span branch -- and
+                # with it the *_query_linear / predictor / encoder2 / cross-attention tensors -- joins later; BertAdam
+                # skips tensors whose .grad is None and counts steps per tensor (xml/optimization.py:289-291,325-330)
+                model.config.lw_st_ed = lw_st_ed_schedule[it]
             loss, ld = model(tv(qfeat), tv(qmask), tv(vfeat), tv(vmask), tv(sfeat), tv(smask), None, None, tv(st_ed))
-            optim.zero_grad()
+            # the reference's pinned torch 1.4 zeroes existing .grad tensors in place (never back to None)
+            optim.zero_grad(set_to_none=False) if lw_st_ed_schedule is not None else optim.zero_grad()
             loss.backward()
             if it == 0:
                 grads = {n: p.grad.detach().numpy().copy() for n, p in params if p.grad is not None}
+                no_grad_first = [n for n, p in params if p.grad is None]
                 first = (float(loss), dict(ld))
             step_losses.append(float(loss))
             optim.step()
@@ -331,7 +338,11 @@ def gen_train_case(ns, name, cfg, seed, bsz, len_lo, len_hi):
                loss_st_ed=np.float64(ld["loss_st_ed"]), loss_neg_ctx=np.float64(ld["loss_neg_ctx"]),
                loss_neg_q=np.float64(ld["loss_neg_q"]))
     out.update({"grad/" + k: v for k, v in grads.items()})
-    out.update({"sd_after3/" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()})
+    out.update({"sd_after3/" + k: v.detach().numpy().copy() for k, v in model.state_dict().items()})   # = after the last step
+    if lw_st_ed_schedule is not None:
+        out["lw_st_ed_schedule"] = np.array(lw_st_ed_schedule, dtype=np.float64)
+        out["no_grad_at_step0"] = json.dumps(no_grad_first)
+        out["final_steps"] = json.dumps({n: int(optim.state[p]["step"]) if len(optim.state[p]) else 0 for n, p in params})
     out["optim"] = json.dumps(dict(b1=0.9, b2=0.999, e=1e-6, max_grad_norm=1.0, **okw))
     path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
@@ -416,6 +427,11 @@ def main():
                    model_cfg(max_ctx_l=20, lw_st_ed=0.5, visual_input_size=40, sub_input_size=32, query_input_size=32,
                              cross_att=False, merge_two_stream=False, ranking_loss_type="lse", use_hard_negative=True,
                              hard_pool_size=3), 32, bsz=7, len_lo=5, len_hi=19)
+    # staged: two steps without the span loss, then three with it (t_total 10, warmup 0.1: the late tensors see multiplier
+    # 0 at THEIR step 0 while the early ones are already decaying)
+    gen_train_case(ns, "train_step_staged_video_sub_h128",
+                   model_cfg(max_ctx_l=24, lw_st_ed=0.0, visual_input_size=48, sub_input_size=32, query_input_size=32), 33,
+                   bsz=6, len_lo=6, len_hi=24, lw_st_ed_schedule=[0.0, 0.0, 0.01, 0.01, 0.01])
 
 
 if __name__ == "__main__":

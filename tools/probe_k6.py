@@ -3,6 +3,7 @@ import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tvretrieval_amd import ops
 lib = ops._lib.load()
+assert hasattr(lib, "xml_debug_set_q2c_variant"), "needs the debug library: XML_DEBUG=1 bash tvretrieval_amd/csrc/build.sh; XMLHIP_LIB=$PWD/tvretrieval_amd/csrc/libxmlhip_dbg.so"
 nq, nv, h = 10000, 21793, 768
 g = torch.Generator(device="cuda").manual_seed(0)
 q = torch.nn.functional.normalize(torch.randn(nq, h, device="cuda", generator=g), dim=-1).bfloat16()

@@ -8,12 +8,14 @@ import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libxmlhip.so")
+# XMLHIP_LIB: measurement tools point this at csrc/libxmlhip_dbg.so (the -DXML_DEBUG_VARIANTS build with the xml_debug_*
+# experiment switches); the product always loads the in-tree library
+LIB_PATH = os.environ.get("XMLHIP_LIB") or os.path.join(_HERE, "csrc", "libxmlhip.so")
 
 XML_F32 = 0
 XML_BF16 = 1
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class XmlHipError(RuntimeError):
@@ -101,10 +103,24 @@ SIGNATURES = {
     "xml_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_int, c_void_p]),
     "xml_clip_grad_norm": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "xml_bert_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
-                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p]),
+                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None
+
+
+def bind(lib):
+    """Attach restype / argtypes of every header symbol to a loaded library; check the ABI version."""
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise XmlHipError("libxmlhip.so does not export %s (stale build?)" % name)
+        fn.restype = res
+        fn.argtypes = args
+    if lib.xml_abi_version() != ABI_VERSION:
+        raise XmlHipError("libxmlhip.so ABI %d != binding ABI %d" % (lib.xml_abi_version(), ABI_VERSION))
+    return lib
 
 
 def load():
@@ -123,16 +139,7 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:
         raise XmlHipError("failed to load %s: %s" % (LIB_PATH, e))
-    for name, (res, args) in SIGNATURES.items():
-        try:
-            fn = getattr(lib, name)
-        except AttributeError:
-            raise XmlHipError("libxmlhip.so does not export %s (stale build?)" % name)
-        fn.restype = res
-        fn.argtypes = args
-    if lib.xml_abi_version() != ABI_VERSION:
-        raise XmlHipError("libxmlhip.so ABI %d != binding ABI %d" % (lib.xml_abi_version(), ABI_VERSION))
-    _lib = lib
+    _lib = bind(lib)
     return lib
 
 

@@ -407,8 +407,7 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
     const size_t lds_s = attn_small_lds_bytes(lk, DH, std::is_same<T, float>::value ? XML_F32 : XML_BF16);
     if (lds_s <= 160 * 1024) {
       auto ks = attention_core_small_kernel<T, OutT, DH>;
-      if (lds_s > 64 * 1024 &&
-          hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s) != hipSuccess)
+      if (lds_s > 64 * 1024 && !xml_lds_attr_once<attention_core_small_kernel<T, OutT, DH>>(160 * 1024))
         return XML_ERR_LAUNCH;
       const int64_t units = n * n_heads;
       hipLaunchKernelGGL(ks, dim3((unsigned)((units + 3) / 4)), dim3(256), lds_s, st, (const T*)q, ldq, (const T*)k, ldk,
@@ -419,10 +418,7 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
     }
   }
   auto kern = attention_core_kernel<T, OutT, DH>;
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return XML_ERR_LAUNCH;
-  }
+  if (lds > 64 * 1024 && !xml_lds_attr_once<attention_core_kernel<T, OutT, DH>>(160 * 1024)) return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3((unsigned)n, n_heads), dim3(256), lds, st, (const T*)q, ldq, (const T*)k, ldk,
                      (const T*)v, ldv, q_mask, k_mask, (OutT*)out, hidden, lq, lk, 0.f, sqrtf((float)DH));
   XML_CHECK_LAUNCH();

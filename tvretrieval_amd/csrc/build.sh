@@ -1,20 +1,36 @@
 #!/bin/bash
 # Builds tvretrieval_amd/csrc/libxmlhip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
+#   bash build.sh            product library: stateless dispatch, no experiment kernels
+#   XML_DEBUG=1 bash build.sh   additionally libxmlhip_dbg.so (-DXML_DEBUG_VARIANTS): kernel-variant / ablation switches
+#                               (xml_debug_*), the abandoned K6 variants q2c_persist4/32.hip -- for tools/ only
+#                               (XMLHIP_LIB=.../libxmlhip_dbg.so python tools/bench_k6.py ...)
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-SRCS="api.hip linear.hip gemm256.hip gemm256p.hip attention.hip q2c.hip q2c256.hip q2c_ring.hip q2c_persist.hip q2c_persist4.hip q2c_persist32.hip topk.hip convse.hip moment.hip postproc.hip train.hip"
-mkdir -p build
-pids=()
-for s in $SRCS; do
-  o=build/${s%.hip}.o
-  if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm.h -nt "$o" ] || [ internal.h -nt "$o" ] \
-     || [ ../../include/xmlhip.h -nt "$o" ]; then
-    $HIPCC $FLAGS -c "$s" -o "$o" &
-    pids+=($!)
-  fi
-done
-for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o libxmlhip.so build/*.o
-echo "built $(pwd)/libxmlhip.so"
+SRCS="api.hip linear.hip gemm256.hip gemm256p.hip attention.hip q2c.hip q2c256.hip q2c_ring.hip q2c_persist.hip topk.hip convse.hip moment.hip postproc.hip train.hip encoder.hip collectives.hip"
+DBG_SRCS="q2c_persist4.hip q2c_persist32.hip"
+
+build() {   # $1 = object dir, $2 = extra flags, $3 = output, $4.. = sources
+  local dir=$1 extra=$2 out=$3; shift 3
+  mkdir -p "$dir"
+  local pids=() objs=()
+  for s in "$@"; do
+    [ -f "$s" ] || continue
+    local o=$dir/${s%.hip}.o
+    objs+=("$o")
+    if [ ! -f "$o" ] || [ "$s" -nt "$o" ] || [ common.h -nt "$o" ] || [ gemm.h -nt "$o" ] || [ internal.h -nt "$o" ] \
+       || [ debug.h -nt "$o" ] || [ ../../include/xmlhip.h -nt "$o" ]; then
+      $HIPCC $FLAGS $extra -c "$s" -o "$o" &
+      pids+=($!)
+    fi
+  done
+  for p in "${pids[@]:-}"; do [ -n "$p" ] && wait "$p"; done
+  $HIPCC --offload-arch=gfx950 -shared -fPIC -o "$out" "${objs[@]}" ${XML_LINK_LIBS:-}
+  echo "built $(pwd)/$out"
+}
+
+build build "" libxmlhip.so $SRCS
+if [ "${XML_DEBUG:-0}" = "1" ]; then
+  build build_dbg "-DXML_DEBUG_VARIANTS" libxmlhip_dbg.so $SRCS $DBG_SRCS
+fi

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/xmlhip.h"
+#include "debug.h"
 
 // hipGetLastError() also reports stale, non-sticky errors left by OTHER runtime users in this thread (e.g. the
 // caching allocator's hipErrorNotReady event polls), so every entry point clears the slot before launching.

@@ -316,22 +316,19 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket; a.chunk_vid = w.chunk_vid;
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
   a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax & 1;
-  extern int g_q2c_ablation;
-  a.dbg = g_q2c_ablation;
+  a.dbg = g_q2c_ablation;       // constant 0 in the product build (debug.h)
   const int64_t max_chunks = P / TM + (P < d->nv ? P : d->nv);
   const int n_sim = d->merged ? 1 : d->n_mod;
   const size_t patch = (size_t)TM * LP * 4;
   if (d->dt == XML_F32) {
     using Cfg = GemmCfg<float, TM, 128, 1, 4>;
     const size_t lds = n_sim == 1 ? (Cfg::LDS_BYTES > patch ? Cfg::LDS_BYTES : patch) : Cfg::LDS_BYTES + 2 * patch;
-    if (hipFuncSetAttribute((const void*)convse_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return XML_ERR_LAUNCH;
+    if (!xml_lds_attr_once<convse_kernel<float>>((int)(Cfg::LDS_BYTES + 2 * patch))) return XML_ERR_LAUNCH;
     hipLaunchKernelGGL(convse_kernel<float>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
   } else {
     using Cfg = GemmCfg<bf16_t, TM, 128, 1, 4>;
     const size_t lds = n_sim == 1 ? (Cfg::LDS_BYTES > patch ? Cfg::LDS_BYTES : patch) : Cfg::LDS_BYTES + 2 * patch;
-    if (hipFuncSetAttribute((const void*)convse_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return XML_ERR_LAUNCH;
+    if (!xml_lds_attr_once<convse_kernel<bf16_t>>((int)(Cfg::LDS_BYTES + 2 * patch))) return XML_ERR_LAUNCH;
     hipLaunchKernelGGL(convse_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
   }
   XML_CHECK_LAUNCH();

@@ -285,7 +285,8 @@ static int launch_gemm256(const void* A, const void* W, const float* bias, const
   const unsigned grid = (unsigned)(((nsup + 7) / 8) * 8 * 32);
   const int lds = 8 * 32 * 132 * 4;     // epilogue patches (135 168 B) >= the 4 x 32 KiB ring
   auto kern = (N & 7) ? gemm256_kernel<T, OutT, AddT, true> : gemm256_kernel<T, OutT, AddT, false>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+  if (!((N & 7) ? xml_lds_attr_once<gemm256_kernel<T, OutT, AddT, true>>(lds)
+                : xml_lds_attr_once<gemm256_kernel<T, OutT, AddT, false>>(lds)))
     return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const T*)A, (const T*)W, bias, (const AddT*)addend,
                      (OutT*)out, M, N, K, relu, add_mode, seq_len, tm, tn);

@@ -323,8 +323,7 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
   a.n_tiles = (int64_t)cdiv(M, 256) * a.tn;
   const int lds = 4 * 2 * 256 * 64 + 8 * 4096;          // ring + patches = 160 KiB
   auto kern = gemm256p_kernel<T, OutT, AddT>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-    return XML_ERR_LAUNCH;
+  if (!xml_lds_attr_once<gemm256p_kernel<T, OutT, AddT>>(lds)) return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
   XML_CHECK_LAUNCH();
   return XML_OK;

@@ -69,8 +69,10 @@ int xmli_gemm256(const void* A, const void* W, const float* bias, const void* ad
 bool xmli_gemm256p_eligible(int64_t M, int N, int K, int dt);
 int xmli_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
                   int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st);
-static int g_gemm_variant = 0;   // 0 auto, 1 force the 128x128 register-staged kernel, 2 never the persistent 256x256 one
+#ifdef XML_DEBUG_VARIANTS
+int g_gemm_variant = 0;
 extern "C" void xml_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
+#endif
 
 // out_f32: write f32 regardless of dt (pre-LayerNorm values keep full precision)
 int xmli_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,

@@ -88,10 +88,13 @@ __global__ __launch_bounds__(256) void q2c_scores_kernel(const T* __restrict__ q
   }
 }
 
-static int g_q2c_xcd_swizzle = 1;
-static int g_q2c_variant = 0;   // 0 auto, 1: 128x128 register-staged, 2: 256x256 LDS-DMA double buffer, 3: 256x256 LDS-DMA ring, 4: persistent fused
+#ifdef XML_DEBUG_VARIANTS
+int g_q2c_xcd_swizzle = 1, g_q2c_variant = 0, g_q2c_ablation = 0, g_q2c_chunk_log2 = -1;
 extern "C" void xml_debug_set_q2c_swizzle(int on) { g_q2c_xcd_swizzle = on; }
 extern "C" void xml_debug_set_q2c_variant(int v) { g_q2c_variant = v; }
+extern "C" void xml_debug_set_q2c_ablation(int v) { g_q2c_ablation = v; }
+extern "C" void xml_debug_set_q2c_chunk(int v) { g_q2c_chunk_log2 = v; }
+#endif
 
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                             float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st,
@@ -121,6 +124,7 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
     const float* m[2] = {mask, mask};
     return xmli_q2c_scores_persist(1, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, st);
   }
+#ifdef XML_DEBUG_VARIANTS
   if (g_q2c_variant == 6 && persist_ok && !combine && dt == XML_BF16) {
     const void* q[2] = {qn, qn};
     const void* c[2] = {cn, cn};
@@ -133,6 +137,7 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
     const float* m[2] = {mask, mask};
     return xmli_q2c_scores_persist4(1, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, st);
   }
+#endif
   if ((g_q2c_variant == 0 || g_q2c_variant == 3) && dma_ok)
     return xmli_q2c_scores_ring(qn, cn, mask, out, ld_out, nq, nv, lpad, hidden, combine, dt, st);
   if (g_q2c_variant == 2 && dma_ok)
@@ -176,6 +181,7 @@ extern "C" int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0,
     const float* m[2] = {mask0, mask1};
     return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream);
   }
+#ifdef XML_DEBUG_VARIANTS
   if (g_q2c_variant == 6 && persist_ok && dt == XML_BF16) {
     const void* q[2] = {qn0, qn1};
     const void* c[2] = {cn0, cn1};
@@ -188,6 +194,7 @@ extern "C" int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0,
     const float* m[2] = {mask0, mask1};
     return xmli_q2c_scores_persist4(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream);
   }
+#endif
   int rc = xml_q2c_scores(qn0, cn0, mask0, out, ld_out, nq, nv, lpad, hidden, 0, dt, stream);
   if (rc || n_mod == 1) return rc;
   return xml_q2c_scores(qn1, cn1, mask1, out, ld_out, nq, nv, lpad, hidden, 1, dt, stream);

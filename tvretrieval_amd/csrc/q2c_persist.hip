@@ -30,6 +30,8 @@ struct Q2cPersistArgs {
   int64_t ld_out;
   int nq, nv, hidden, n_mod, tq, tc;
   int qsh;     // log2 of the query tiles per XCD super-tile (0..3): the 32 workgroups of an XCD form 2^qsh x 2^(5-qsh)
+  int rsh;     // log2 of the rounds per corpus chunk: all query groups visit a chunk before the walk moves on, so that
+               // passes 2..n over a chunk's clip tiles are served by the 256 MB Infinity Cache instead of HBM
 };
 
 __device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase, uint32_t lds_dst) {
@@ -108,10 +110,12 @@ template <> struct MmaInit<bf16_t> {
 
 // ABL 8 (timing probe): per wave of workgroup 0, shader-clock cycles spent between "about to wait" and "barrier
 // released" summed over all slices, and the wave's total; read back with xml_debug_read_k6_probe
+#ifdef XML_DEBUG_VARIANTS
 __device__ unsigned long long g_k6_probe[32];
 extern "C" int xml_debug_read_k6_probe(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_k6_probe), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -4;
 }
+#endif
 
 // value of `v` in the lane selected by a DPP control word (row_mirror 0x140, row_half_mirror 0x141, quad_perm 0x00-0xff)
 template <int CTRL>
@@ -187,10 +191,22 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   auto tile_valid = [&](int g, int c) -> bool {
     return ((g << qsh) + qt_off) < a.tq && ((((c << 3) + xcd) << csh) + ct_off) < a.tc;
   };
+  // Walk order: the corpus is visited in chunks of 2^rsh rounds (one round = the 8 XCDs x 2^csh clip tiles the chip
+  // works on at a time); EVERY query group visits a chunk before the walk moves to the next chunk.  A chunk is sized to
+  // stay in the Infinity Cache, so only the first query group streams it from HBM (the straight order -- all chunks
+  // per query group -- read the whole corpus from HBM once per query group).
+  const int rsh = a.rsh, rmask = (1 << a.rsh) - 1;
   auto advance = [&](int& g, int& c) {            // next valid (g, c) in walk order, g == n_qgroups when exhausted
     do {
-      if (++c == cr) { c = 0; ++g; }
-    } while (g < n_qgroups && !tile_valid(g, c));
+      const int c1 = c + 1;
+      if (c >= 0 && ((c1 & rmask) == 0 || c1 == cr)) {     // c was the last round of its chunk
+        if (g + 1 < n_qgroups) { ++g; c = (c >> rsh) << rsh; }
+        else { g = 0; c = c1; }
+      } else {
+        c = c1;
+      }
+      if (c >= cr) { g = n_qgroups; break; }
+    } while (!tile_valid(g, c));
   };
 
   // ---- issue side (DMA stream, runs up to 3 slices ahead of the slice being computed) ---------------------
@@ -511,11 +527,13 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       if (c_g >= n_qgroups) break;
     }
   }
+#ifdef XML_DEBUG_VARIANTS
   if (ABL == 8 && blockIdx.x == 0 && lane == 0) {
     g_k6_probe[wave * 4 + 0] = probe_wait;
     g_k6_probe[wave * 4 + 1] = probe_bar;
     g_k6_probe[wave * 4 + 2] = __builtin_amdgcn_s_memtime() - probe_t0;
   }
+#endif
   };
   if (PHASED && grp) run(std::true_type{});
   else run(std::false_type{});
@@ -525,16 +543,27 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
 template <typename T>
 static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled, int mask_mode) {
-  extern int g_q2c_ablation;
   const bool five = (tiled && mask_mode != 0) || (!tiled && g_q2c_ablation == 7);
   const int lds = five ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring (+ two mask patches)
-  auto kern = (tiled && mask_mode == 1) ? q2c_persist_kernel<T, 0, true, true, true>
-             : (tiled && mask_mode == 2) ? q2c_persist_kernel<T, 0, true, true, false, true>
-             : tiled ? q2c_persist_kernel<T, 0, true, true> : g_q2c_ablation == 1 ? q2c_persist_kernel<T, 1> : g_q2c_ablation == 2 ? q2c_persist_kernel<T, 2>
-             : g_q2c_ablation == 3 ? q2c_persist_kernel<T, 3> : g_q2c_ablation == 11 ? q2c_persist_kernel<T, 11, true> : g_q2c_ablation == 10 ? q2c_persist_kernel<T, 10, true> : g_q2c_ablation == 8 ? q2c_persist_kernel<T, 8, true> : g_q2c_ablation == 7 ? q2c_persist_kernel<T, 7, true> : g_q2c_ablation == 4 ? q2c_persist_kernel<T, 0, false>
-                                                                                     : q2c_persist_kernel<T, 0, true>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-    return XML_ERR_LAUNCH;
+  void (*kern)(Q2cPersistArgs) = nullptr;
+  bool ok = false;
+#define XML_K6_PICK(...) do { kern = q2c_persist_kernel<__VA_ARGS__>; ok = xml_lds_attr_once<q2c_persist_kernel<__VA_ARGS__>>(lds); } while (0)
+  if (tiled && mask_mode == 1) XML_K6_PICK(T, 0, true, true, true);
+  else if (tiled && mask_mode == 2) XML_K6_PICK(T, 0, true, true, false, true);
+  else if (tiled) XML_K6_PICK(T, 0, true, true);
+#ifdef XML_DEBUG_VARIANTS
+  else if (g_q2c_ablation == 1) XML_K6_PICK(T, 1);
+  else if (g_q2c_ablation == 2) XML_K6_PICK(T, 2);
+  else if (g_q2c_ablation == 3) XML_K6_PICK(T, 3);
+  else if (g_q2c_ablation == 11) XML_K6_PICK(T, 11, true);
+  else if (g_q2c_ablation == 10) XML_K6_PICK(T, 10, true);
+  else if (g_q2c_ablation == 8) XML_K6_PICK(T, 8, true);
+  else if (g_q2c_ablation == 7) XML_K6_PICK(T, 7, true);
+  else if (g_q2c_ablation == 4) XML_K6_PICK(T, 0, false);
+#endif
+  else XML_K6_PICK(T, 0, true);
+#undef XML_K6_PICK
+  if (!ok) return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
   XML_CHECK_LAUNCH();
   return XML_OK;
@@ -558,6 +587,18 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
   a.qsh = a.tq >= 5 ? 3 : a.tq >= 3 ? 2 : a.tq == 2 ? 1 : 0;     // few queries: more workgroups share a query tile
+  {
+    // corpus chunk of the walk: one round touches 8 XCDs x 2^(5-qsh) clip tiles x n_mod operands of 256 * k_bytes;
+    // the largest power-of-two number of rounds whose clip tiles stay under ~96 MiB (of the 256 MB Infinity Cache,
+    // which also holds the query operands and sees the score writes stream through)
+    const double round_bytes = 8.0 * (1 << (5 - a.qsh)) * n_mod * 256.0 * hidden * dt_size(dt);
+    int rsh = 0;
+    while (rsh < 20 && round_bytes * (2 << rsh) <= 96.0 * 1024 * 1024) ++rsh;
+    const int n_qgroups = (a.tq + (1 << a.qsh) - 1) >> a.qsh;
+    if (n_qgroups == 1) rsh = 20;                                  // one pass anyway: the straight order
+    if (g_q2c_chunk_log2 >= 0) rsh = g_q2c_chunk_log2;
+    a.rsh = rsh;
+  }
   if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled, mask_mode);
   return launch_q2c_persist<float>(a, st, tiled, mask_mode);
 }

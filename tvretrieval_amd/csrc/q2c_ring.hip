@@ -220,11 +220,14 @@ static int launch_q2c_ring(const void* qn, const void* cn, const float* mask, fl
   const int64_t nsup = (int64_t)((tq + 7) / 8) * ((tc + 3) / 4);
   const unsigned grid = (unsigned)(((nsup + 7) / 8) * 8 * 32);
   const int lds = 4 * 2 * 256 * 64;
-  extern int g_q2c_ablation;
-  auto kern = g_q2c_ablation == 1 ? q2c_scores_kernel_ring<T, 1> : g_q2c_ablation == 2 ? q2c_scores_kernel_ring<T, 2>
-              : g_q2c_ablation == 3 ? q2c_scores_kernel_ring<T, 3> : q2c_scores_kernel_ring<T, 0>;
-  if (hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-    return XML_ERR_LAUNCH;
+  auto kern = q2c_scores_kernel_ring<T, 0>;
+  bool ok = xml_lds_attr_once<q2c_scores_kernel_ring<T, 0>>(lds);
+#ifdef XML_DEBUG_VARIANTS
+  if (g_q2c_ablation == 1) { kern = q2c_scores_kernel_ring<T, 1>; ok = xml_lds_attr_once<q2c_scores_kernel_ring<T, 1>>(lds); }
+  if (g_q2c_ablation == 2) { kern = q2c_scores_kernel_ring<T, 2>; ok = xml_lds_attr_once<q2c_scores_kernel_ring<T, 2>>(lds); }
+  if (g_q2c_ablation == 3) { kern = q2c_scores_kernel_ring<T, 3>; ok = xml_lds_attr_once<q2c_scores_kernel_ring<T, 3>>(lds); }
+#endif
+  if (!ok) return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const T*)qn, (const T*)cn, mask, out, ld_out, nq, nv, lpad,
                      hidden, combine, tq, tc);
   XML_CHECK_LAUNCH();

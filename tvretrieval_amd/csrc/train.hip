@@ -1124,10 +1124,16 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
                                                           const float* __restrict__ seg_lr,
                                                           const float* __restrict__ seg_wd, int n_seg, int64_t total,
                                                           const float* __restrict__ norms, float lr_mult, float b1,
-                                                          float b2, float eps, float max_grad_norm) {
+                                                          float b2, float eps, float max_grad_norm,
+                                                          const uint8_t* __restrict__ seg_active,
+                                                          const float* __restrict__ seg_lr_mult) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
   const int s = find_seg(seg_off, n_seg, i);
+  // `if p.grad is None: continue` (xml/optimization.py:289-291): a tensor that has never received a gradient is not
+  // touched at all -- no moment update, no weight decay, no schedule step
+  if (seg_active && !seg_active[s]) return;
+  if (seg_lr_mult) lr_mult = seg_lr_mult[s];          // per-tensor state['step'] (xml/optimization.py:325-330)
   float gi = g[i];
   if (max_grad_norm > 0.f) {
     const float coef = max_grad_norm / (sqrtf(norms[s]) + 1e-6f);
@@ -1145,7 +1151,8 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
 
 extern "C" int xml_bert_adam_step(float* p, float* g, float* m, float* v, const int64_t* seg_off, const float* seg_lr,
                                   const float* seg_wd, int n_seg, int64_t total, float lr_mult, float b1, float b2,
-                                  float eps, float max_grad_norm, float* norms, xml_stream_t stream) {
+                                  float eps, float max_grad_norm, float* norms, const uint8_t* seg_active,
+                                  const float* seg_lr_mult, xml_stream_t stream) {
   XML_ENTER();
   if (!p || !g || !m || !v || !seg_off || !seg_lr || !seg_wd || !norms || n_seg <= 0 || total <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
@@ -1154,7 +1161,7 @@ extern "C" int xml_bert_adam_step(float* p, float* g, float* m, float* v, const 
     hipLaunchKernelGGL(adam_norm_kernel, dim3(cdiv(total, 4096)), dim3(256), 0, st, g, seg_off, n_seg, total, norms);
   }
   hipLaunchKernelGGL(adam_update_kernel, dim3(cdiv(total, 256)), dim3(256), 0, st, p, g, m, v, seg_off, seg_lr, seg_wd,
-                     n_seg, total, norms, lr_mult, b1, b2, eps, max_grad_norm);
+                     n_seg, total, norms, lr_mult, b1, b2, eps, max_grad_norm, seg_active, seg_lr_mult);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

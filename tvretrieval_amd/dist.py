@@ -205,6 +205,11 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
     if owner_rerank is None:
         owner_rerank = index.feat2_all is not None
     assert not owner_rerank or index.feat2_all is not None, "call replicate_rerank_features(index) first"
+    if not owner_rerank and not trivial and max_before_nms > 256:
+        # the video-owner rerank merges the per-rank moment lists with xml_topk_rows (k <= 256); the query-owner rerank
+        # (replicate_rerank_features) and the single-GPU pass take n_out up to 1024 (xml_moment_topk)
+        raise ValueError("sharded rerank merges moment lists of at most 256 entries; max_before_nms=%d needs the owner "
+                         "rerank (call replicate_rerank_features(index) first)" % max_before_nms)
     # ---- phase 1: global top-k videos ------------------------------------------------------------------
     q2c = inf.stage_q2c(index, qvec, ops)
     _mark("q2c_k6")

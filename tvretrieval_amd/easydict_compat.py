@@ -51,7 +51,11 @@ class EasyDict(dict):
             self[k] = v
 
     def __reduce__(self):
-        return (EasyDict, (dict(self),))
+        # Always pickle as `easydict.EasyDict` -- the name the reference's checkpoints carry and its loader resolves
+        # (xml/train.py:219-223, xml/inference.py:536-540): the real class when the package is installed, this class
+        # (registered under the module name `easydict`) when it is not.  Never as tvretrieval_amd.easydict_compat.*.
+        mod = register_easydict_module()
+        return (mod.EasyDict, (dict(self),))
 
     def __deepcopy__(self, memo):
         import copy

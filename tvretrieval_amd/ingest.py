@@ -65,6 +65,7 @@ class ContextFeeder(object):
         self.norm = dict(video=normalize_vfeat, sub=normalize_tfeat)
         self.device, self.ops = torch.device(device), ops
         self._stage = {}
+        self._slot_done = {}     # (tag, slot) -> event recorded after the H2D copy that last read this pinned slot
 
     def __len__(self):
         return (len(self.names) + self.bsz - 1) // self.bsz
@@ -81,6 +82,9 @@ class ContextFeeder(object):
     def _gather(self, store, names, slot, tag):
         lens = [min(store.n_rows(n), self.max_ctx_len) for n in names]
         lmax = max(lens)
+        ev = self._slot_done.get((tag, slot))
+        if ev is not None:       # batch i - 2 was copied from this pinned slot asynchronously: the host must not zero /
+            ev.synchronize()     # rewrite it before that copy has actually read it
         buf = self._staging((tag, slot), (len(names), lmax, store.dim))
         buf.zero_()
         mask = torch.zeros((len(names), lmax), dtype=torch.float32)
@@ -105,8 +109,13 @@ class ContextFeeder(object):
                     with torch.cuda.stream(copy_stream):
                         dev = host.to(self.device, non_blocking=True)
                         dmask = mask.to(self.device, non_blocking=True)
-                    torch.cuda.current_stream(self.device).wait_stream(copy_stream)
-                    dev.record_stream(torch.cuda.current_stream(self.device))
+                        done = torch.cuda.Event()
+                        done.record(copy_stream)
+                    self._slot_done[(tag, bi & 1)] = done
+                    cur = torch.cuda.current_stream(self.device)
+                    cur.wait_stream(copy_stream)
+                    dev.record_stream(cur)          # both were allocated on the copy stream and are consumed on the
+                    dmask.record_stream(cur)        # compute stream: keep the allocator from recycling them early
                 else:
                     dev, dmask = host.clone(), mask
                 if self.norm[tag]:

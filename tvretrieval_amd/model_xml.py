@@ -184,6 +184,19 @@ class XML(nn.Module):
         if config.get("conv_stride", 1) != 1:
             raise NotImplementedError("conv_stride != 1 is not built")
         hsz, nh = config.hidden_size, config.n_heads
+        # shapes the kernels implement (include/xmlhip.h) -- rejected here with the reason, not deep inside a launch
+        if hsz % nh != 0:
+            raise ValueError("The hidden size (%d) is not a multiple of the number of attention heads (%d)" % (hsz, nh))
+        if hsz % (32 * nh) != 0:
+            raise ValueError("hidden_size=%d with n_heads=%d: the HIP attention kernels need a head size that is a multiple "
+                             "of 32 (hidden_size %% %d == 0); the reference's training default is 256 (xml/config.py:143), "
+                             "xml_base_config's 500 is a placeholder" % (hsz, nh, 32 * nh))
+        for key in ("max_ctx_l", "max_desc_l"):
+            if config[key] > 128:
+                raise ValueError("%s=%d: sequences longer than 128 positions are not built (one attention tile stays "
+                                 "on chip; TVR truncates to 100 clips / 30 tokens, xml/config.py:86-88)" % (key, config[key]))
+        if config.conv_kernel_size % 2 != 1 or config.conv_kernel_size > 15:
+            raise ValueError("conv_kernel_size=%d: the ConvSE kernels take odd sizes up to 15" % config.conv_kernel_size)
         self.query_pos_embed = TrainablePositionalEncoding(config.max_desc_l, hsz, config.input_drop)
         self.ctx_pos_embed = TrainablePositionalEncoding(config.max_ctx_l, hsz, config.input_drop)
         self.query_input_proj = LinearLayer(config.query_input_size, hsz, config.input_drop)

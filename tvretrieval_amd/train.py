@@ -288,6 +288,20 @@ class BertAdam(object):
         self.seg_lr = torch.tensor(lrs, dtype=F32, device=dev)
         self.seg_wd = torch.tensor(wds, dtype=F32, device=dev)
         self.norms = torch.zeros(len(plist), dtype=F32, device=dev)
+        # `if p.grad is None: continue` + per-tensor state['step'] (xml/optimization.py:289-291,325-330): a tensor takes
+        # part in a step once it has EVER received a gradient (the reference's pinned torch 1.4 zero_grad() zeroes
+        # existing .grad tensors in place, it does not reset them to None); its schedule counts its own steps.
+        # Gradients land in persistent views of the flat buffer, so "received a gradient" is observed by a
+        # post-accumulate hook per parameter (host flag only, no device work).
+        self._touched = [False] * len(plist)
+        self.seg_steps = [0] * len(plist)
+        self._active_key = None
+        self._active_dev = None
+        for i, p in enumerate(plist):
+            p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touch(i))
+
+    def _touch(self, i):
+        self._touched[i] = True
 
     def zero_grad(self):
         self.flat_g.zero_()
@@ -304,16 +318,45 @@ class BertAdam(object):
         return fn(float(self.step_count if step is None else step) / d["t_total"], d["warmup"])
 
     def get_lr(self):
-        if self.step_count == 0:
-            return [0]
-        m = self.lr_multiplier()
-        return [g["lr"] * m for g in self.param_groups for _ in g["params"]]
+        """BertAdam.get_lr (xml/optimization.py:255-267): [0] before any tensor has stepped, else lr * schedule(step) per
+        tensor (its own step count)."""
+        it = iter(range(len(self.params)))
+        out = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                if not p.requires_grad:
+                    continue
+                i = next(it)
+                if self.seg_steps[i] == 0:        # `if len(state) == 0: return [0]` -- a tensor that has not stepped yet
+                    return [0]
+                out.append(g["lr"] * self.lr_multiplier(self.seg_steps[i]))
+        return out
 
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         d = self.defaults
+        active = self._touched
+        seg_active = seg_mult = None
+        if not all(active):
+            key = tuple(active)
+            if key != self._active_key:      # uploaded only when the set of participating tensors changes
+                self._active_key = key
+                self._active_dev = torch.tensor([1 if a else 0 for a in active], dtype=torch.uint8,
+                                                device=self.flat_p.device)
+            seg_active = self._active_dev
+        steps = {s for s, a in zip(self.seg_steps, active) if a}
+        if len(steps) <= 1:                  # every participating tensor is at the same step: one scalar multiplier
+            mult = self.lr_multiplier(steps.pop() if steps else 0)
+        else:                                # tensors that joined later run their own warm-up
+            mult = 0.0
+            per = {s: self.lr_multiplier(s) for s in steps}
+            seg_mult = torch.tensor([per.get(s, 0.0) if a else 0.0 for s, a in zip(self.seg_steps, active)], dtype=F32,
+                                    device=self.flat_p.device)
         T.bert_adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.seg_off, self.seg_lr, self.seg_wd,
-                         self.norms, self.lr_multiplier(), d["b1"], d["b2"], d["e"], d["max_grad_norm"])
+                         self.norms, mult, d["b1"], d["b2"], d["e"], d["max_grad_norm"], seg_active, seg_mult)
+        for i, a in enumerate(active):
+            if a:
+                self.seg_steps[i] += 1
         self.step_count += 1
         from .model_xml import _PackedMixin
         _PackedMixin.bump_generation()          # cached low-precision weight copies are stale now

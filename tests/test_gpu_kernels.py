@@ -330,6 +330,42 @@ def test_q2c_tiled_equals_row_major(ops, dtype, shape, n_mod):
         assert float(flat[-1, :, 128:].float().abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n_mod", [1, 2])
+def test_q2c_length_buckets_bitwise(ops, dtype, n_mod):
+    """Ragged corpus (TVR-like lengths, mean ~51 of 128 clips): the length-bucketed image (2 / 4 / 8 videos per K6 tile,
+    xml_q2c_scores_packed) gives BITWISE the scores of the plain tiled image with packed bit masks, in the videos'
+    original columns -- so every list downstream is identical -- and both equal the oracle formulation."""
+    nq, nv, h = 700, 611, 256
+    g = torch.Generator().manual_seed(31)
+    lens = torch.cat([torch.randint(1, 33, (40,), generator=g), torch.randint(33, 65, (500,), generator=g),
+                      torch.randint(65, 129, (71,), generator=g)])[torch.randperm(nv, generator=g)]
+    qs = [_normed(nq, h, seed=280 + m) for m in range(n_mod)]
+    cs = [_normed(nv, 128, h, seed=290 + m) for m in range(n_mod)]
+    masks = [(torch.arange(128)[None] < (lens - (m if m else 0)).clamp_min(1)[:, None]).float() for m in range(n_mod)]
+    cs = [c * mk[..., None] for c, mk in zip(cs, masks)]              # zero rows beyond each video's length
+    qd = [dev(q, dtype) for q in qs]
+    cd = [dev(c, dtype) for c in cs]
+    md = [dev(m) for m in masks]
+    plain = [ops.pack_q2c_corpus(c, m) for c, m in zip(cd, md)]
+    assert all(t.mask_bits is not None and t.plan is None for t in plain)
+    plan = ops.q2c_pack_plan(md)
+    assert plan is not None and plan.ct128 < plan.ct64 < plan.n_tiles
+    packed = [ops.pack_q2c_corpus(c, m, plan) for c, m in zip(cd, md)]
+    assert all(torch.equal(t.to_rows(), c) for t, c in zip(packed, cd))         # un-bucketing gives the rows back
+    want = ops.q2c_scores_fused(qd, plain, md)
+    got = ops.q2c_scores_fused(qd, packed, md, out=torch.full((nq, nv), float("nan"), device=DEV))
+    assert torch.equal(got, want)
+    ref = None
+    for m in range(n_mod):
+        s = torch.einsum("md,nld->mln", qs[m], cs[m])
+        s = torch.max(O.mask_logits(s, masks[m].t().unsqueeze(0)), dim=1)[0]
+        ref = s if ref is None else (ref + s) / 2
+    close("bucketed q2c vs oracle", got, ref, _tol(dtype, 1e-5, 1e-2))
+    print("padded clips %d of %d (%.0f %% of the MFMA work of the unbucketed layout)"
+          % (plan.padded_clips, nv * 128, 100.0 * plan.n_tiles * 256 / (nv * 128)))
+
+
 def test_q2c_fused_full_scale_property(ops):
     """BASELINE-size property check (10 000 x 21 793 x 128 x 768 bf16, both modalities): every output element is
     written, and random (query, video) samples equal an fp32 recomputation; max over clips of a cosine of

@@ -261,6 +261,30 @@ def test_search_vs_oracle_fp32(ctx_mode, hidden):
     assert n_sw <= 0.02 * len(same) * 200, n_sw
 
 
+def test_ragged_corpus_buckets_give_identical_lists(monkeypatch):
+    """TVR-like clip counts: the index built with length buckets and the one built without return the same top-100 /
+    top-200 lists, bit for bit (bf16, the headline dtype)."""
+    from tvretrieval_amd import inference as inf
+    nv, nq, l = 300, 70, 128
+    m, cfg = _synthetic_model("video_sub", 256, 512, 256, 256, l, torch.bfloat16, seed=6)
+    rng = np.random.default_rng(4)
+    lens = np.clip(np.round(rng.normal(51, 14, nv)), 8, 128).astype(int); lens[0] = l
+    vf, vm = _feats(nv, lens, 512, 1)
+    sf, sm = _feats(nv, lens, 256, 2)
+    qf, qm = _feats(nq, rng.integers(5, 31, nq), 256, 3)
+    batches = [(vf[b:b + 100].to(DEV), vm[b:b + 100].to(DEV), sf[b:b + 100].to(DEV), sm[b:b + 100].to(DEV))
+               for b in range(0, nv, 100)]
+    with torch.no_grad():
+        bucketed = inf.build_corpus_index(m, batches, l_ref=l)
+        monkeypatch.setenv("XML_Q2C_NO_BUCKETS", "1")
+        flat = inf.build_corpus_index(m, batches, l_ref=l)
+        assert bucketed.feat1n["video"].plan is not None and flat.feat1n["video"].plan is None
+        a = inf.vcmr_search(m, bucketed, qf.to(DEV), qm.to(DEV))
+        b = inf.vcmr_search(m, flat, qf.to(DEV), qm.to(DEV))
+    for k in ("q2c", "top_scores", "top_indices", "flat_scores", "flat_indices"):
+        assert torch.equal(a[k], b[k]), k
+
+
 def test_tef_context_mode_dims_vs_oracle():
     """video_sub_tef checkpoints (xml/config.py:108-110,251-254): visual 3072+2 / sub 768+2 input dims (the dataset
     concatenates the two TEF columns, xml/start_end_dataset.py:127-142).  Encode + search vs the oracle, fp32."""

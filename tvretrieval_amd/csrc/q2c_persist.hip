@@ -26,6 +26,10 @@ struct Q2cPersistArgs {
   const void* cn[2];
   const float* mask[2];
   const uint32_t* mbits[2];   // BITMASK kernels: (nv, 4) words, bit l of a video = clip l valid
+                              // PACKED kernels: (2 * tc, 4) words, bit c of wave tile w = column c of its 128 columns valid
+  const int32_t* slot_ids;    // PACKED: (2 * tc, 4) original video id of sub-slot j of wave tile w (-1: empty)
+  int ct128, ct64;            // PACKED: clip tiles [0, ct128) hold 2 videos of <= 128 clips, [ct128, ct64) 4 of <= 64,
+                              //         [ct64, tc) 8 of <= 32 (length-bucketed corpus, xml_q2c_pack_plan)
   float* out;
   int64_t ld_out;
   int nq, nv, hidden, n_mod, tq, tc;
@@ -145,7 +149,11 @@ __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3
 //
 //   No wave-group stagger and no s_setprio: the two waves of a SIMD drift apart by themselves and keep the MFMA
 //   pipe busy from either wave's ready cluster.
-template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false, bool NOMASK = false, bool BITMASK = false>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
+// PACKED (length-bucketed ragged corpora): a wave's 128 columns hold 1 / 2 / 4 videos padded to 128 / 64 / 32 clips, so
+// padding rows cost no MFMA work; the epilogue takes one masked maximum per sub-slot and scatters it to the video's
+// ORIGINAL column of `out` (ids through scalar loads) -- the scores are bitwise those of the unbucketed layout.
+template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false, bool NOMASK = false, bool BITMASK = false,
+          bool PACKED = false>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
 __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // operands, experiment.)
   // BITMASK: ragged corpora get the fifth slot too -- binary clip masks packed 128 bits per video arrive through SCALAR
   // loads (lgkmcnt, invisible to the hand-counted vmcnt of the DMA stream), no mask DMA, no LDS patches.
-  constexpr bool FIVE = (ABL == 7) || NOMASK || BITMASK;
+  constexpr bool FIVE = (ABL == 7) || NOMASK || BITMASK || PACKED;
   constexpr int NSLOT = FIVE ? 5 : 4;
   constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
@@ -361,6 +369,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   auto run = [&](auto grp_tag) {
   constexpr bool GRP1 = decltype(grp_tag)::value;
   float stash = 0.f;                   // modality-0 maximum of this lane's row of the current tile
+  float stash4[PACKED ? 4 : 1] = {};   // PACKED: one per sub-slot
   unsigned long long probe_wait = 0, probe_bar = 0, probe_t0 = 0;
   if (ABL == 8) probe_t0 = __builtin_amdgcn_s_memtime();
   for (;;) {      // one iteration = one (tile, modality) segment
@@ -440,7 +449,78 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       slice_step(faB, faA, std::false_type{});
     }
     // ---- end of a (tile, modality) segment: mask_logits + max over the video's 128 clips, inside the wave -----
-    {
+    if constexpr (PACKED) {
+      const int q0 = ((c_g << qsh) + qt_off) * 256, ct = (((c_c << 3) + xcd) << csh) + ct_off;
+      int fr_e = fr, fg_e = fg;
+      asm volatile("" : "+v"(fr_e), "+v"(fg_e));
+      const bool last_mod = c_mod == a.n_mod - 1;
+      const int wt_s = __builtin_amdgcn_readfirstlane(ct * 2 + wn);
+      typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+      typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+      u32x4_t wv;
+      i32x4_t ids;
+      const uint32_t* mb = (c_mod == 0 ? a.mbits[0] : a.mbits[1]) + (int64_t)wt_s * 4;
+      const int32_t* idp = a.slot_ids + (int64_t)wt_s * 4;
+      asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(wv), "=&s"(ids) : "s"(mb), "s"(idp) : "memory");
+      const bool fast = (wv.x & wv.y & wv.z & wv.w) == 0xffffffffu;
+      float mk[8];
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const uint32_t w = (n >> 1) == 0 ? wv.x : (n >> 1) == 1 ? wv.y : (n >> 1) == 2 ? wv.z : wv.w;
+        mk[n] = (float)((w >> ((n & 1) * 16 + fr_e)) & 1u);
+      }
+      const int lrow = wm * 64 + (fr_e >> 2) * 16 + fg_e * 4 + (fr_e & 3);
+      const bool row_ok = q0 + lrow < a.nq;
+      float* orow = a.out + (int64_t)(q0 + lrow) * a.ld_out;
+      // one sub-slot: masked maximum over its n-tiles [N0, N0 + NPG), 16-lane reduce-scatter, stash / combine / store
+      auto slot = [&](auto n0_tag, auto npg_tag, float& st, int id) {
+        constexpr int N0 = decltype(n0_tag)::value, NPG = decltype(npg_tag)::value;
+        float x[16];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float mx = -INFINITY;
+            if (fast) {
+#pragma unroll
+              for (int n = N0; n < N0 + NPG; ++n) mx = fmaxf(mx, acc[m][n][r]);
+            } else {
+#pragma unroll
+              for (int n = N0; n < N0 + NPG; ++n) mx = fmaxf(mx, acc[m][n][r] * mk[n] + (1.f - mk[n]) * -1e10f);
+            }
+            x[m * 4 + r] = mx;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        const bool b8 = (fr_e & 8) != 0, b4 = (fr_e & 4) != 0, b2 = (fr_e & 2) != 0, b1 = (fr_e & 1) != 0;
+        float y[8], z[4], u[2];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) y[i] = fmaxf(b8 ? x[i + 8] : x[i], dpp_read<0x140>(b8 ? x[i] : x[i + 8]));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) z[i] = fmaxf(b4 ? y[i + 4] : y[i], dpp_read<0x141>(b4 ? y[i] : y[i + 4]));
+#pragma unroll
+        for (int i = 0; i < 2; ++i) u[i] = fmaxf(b2 ? z[i + 2] : z[i], dpp_read<0x1B>(b2 ? z[i] : z[i + 2]));
+        float red = fmaxf(b1 ? u[1] : u[0], dpp_read<0xB1>(b1 ? u[0] : u[1]));
+        if (!last_mod) {
+          st = red;
+        } else {
+          if (a.n_mod == 2) red = (st + red) * 0.5f;
+          if (row_ok && id >= 0) orow[id] = red;
+        }
+      };
+      if (ct < a.ct128) {
+        slot(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, stash4[0], ids.x);
+      } else if (ct < a.ct64) {
+        slot(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, stash4[0], ids.x);
+        slot(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{}, stash4[1], ids.y);
+      } else {
+        slot(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, stash4[0], ids.x);
+        slot(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, stash4[1], ids.y);
+        slot(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, stash4[2], ids.z);
+        slot(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{}, stash4[3], ids.w);
+      }
+    } else {
       const int q0 = ((c_g << qsh) + qt_off) * 256, vid = ((((c_c << 3) + xcd) << csh) + ct_off) * 2 + wn;
       int fr_e = fr, fg_e = fg;                     // opaque copies (see setup_issue_segment)
       asm volatile("" : "+v"(fr_e), "+v"(fg_e));
@@ -543,12 +623,13 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
 template <typename T>
 static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled, int mask_mode) {
-  const bool five = (tiled && mask_mode != 0) || (!tiled && g_q2c_ablation == 7);
+  const bool five = (tiled && mask_mode != 0) || (!tiled && g_q2c_ablation == 7);     // mask_mode 3: PACKED
   const int lds = five ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring (+ two mask patches)
   void (*kern)(Q2cPersistArgs) = nullptr;
   bool ok = false;
 #define XML_K6_PICK(...) do { kern = q2c_persist_kernel<__VA_ARGS__>; ok = xml_lds_attr_once<q2c_persist_kernel<__VA_ARGS__>>(lds); } while (0)
-  if (tiled && mask_mode == 1) XML_K6_PICK(T, 0, true, true, true);
+  if (tiled && mask_mode == 3) XML_K6_PICK(T, 0, true, true, false, false, true);
+  else if (tiled && mask_mode == 1) XML_K6_PICK(T, 0, true, true, true);
   else if (tiled && mask_mode == 2) XML_K6_PICK(T, 0, true, true, false, true);
   else if (tiled) XML_K6_PICK(T, 0, true, true);
 #ifdef XML_DEBUG_VARIANTS
@@ -574,15 +655,18 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tile
 // the mask patch of segment s+2 is fetched 4 slices ahead and must not land before the epilogue of segment s.
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                             float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st,
-                            bool tiled, int mask_mode, const uint32_t* const* mbits) {
+                            bool tiled, int mask_mode, const uint32_t* const* mbits, const int32_t* slot_ids, int ct128,
+                            int ct64) {
   Q2cPersistArgs a;
+  a.slot_ids = slot_ids; a.ct128 = ct128; a.ct64 = ct64;
   for (int m = 0; m < 2; ++m) {
     a.qn[m] = qn[m < n_mod ? m : 0];
     a.cn[m] = cn[m < n_mod ? m : 0];
     a.mask[m] = mask[m < n_mod ? m : 0];
     a.mbits[m] = mbits ? mbits[m < n_mod ? m : 0] : nullptr;
   }
-  if (mask_mode == 2 && (!mbits || !a.mbits[0] || !a.mbits[1])) return XML_ERR_BAD_ARG;
+  if ((mask_mode == 2 || mask_mode == 3) && (!mbits || !a.mbits[0] || !a.mbits[1])) return XML_ERR_BAD_ARG;
+  if (mask_mode == 3 && (!slot_ids || !tiled || (nv & 1) || ct128 < 0 || ct64 < ct128 || ct64 > nv / 2)) return XML_ERR_BAD_ARG;
   if (lpad != 128) return XML_ERR_UNSUPPORTED;
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
@@ -624,6 +708,57 @@ __global__ __launch_bounds__(256) void q2c_tile_rows_kernel(const uint4* __restr
   dst[i] = v;
 }
 
+// Same tiled image, rows gathered through a table: dst row i = src row row_map[i] (zero when row_map[i] < 0).  Builds the
+// length-bucketed corpus image (xml_q2c_tile_rows_gather).
+__global__ __launch_bounds__(256) void q2c_tile_rows_gather_kernel(const uint4* __restrict__ src,
+                                                                   const int32_t* __restrict__ row_map,
+                                                                   uint4* __restrict__ dst, int k_bytes, int64_t n_chunks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_chunks) return;
+  const int slices = k_bytes >> 6;
+  const int c = (int)(i & 3);
+  const int r = (int)((i >> 2) & 255);
+  const int64_t ts = i >> 10;
+  const int64_t tile = ts / slices;
+  const int sl = (int)(ts - tile * slices);
+  const int64_t srow = row_map[tile * 256 + r];
+  uint4 v = {0u, 0u, 0u, 0u};
+  if (srow >= 0) v = src[(srow * k_bytes + sl * 64 + c * 16) >> 4];
+  dst[i] = v;
+}
+
+extern "C" int xml_q2c_tile_rows_gather(const void* src, const int32_t* row_map, void* dst, int64_t rows_packed,
+                                        int hidden, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!src || !row_map || !dst || rows_packed <= 0 || (rows_packed & 255) || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  const size_t kb = (size_t)hidden * dt_size(dt);
+  if (kb % 64) return XML_ERR_UNSUPPORTED;
+  const int64_t n_chunks = rows_packed * (int64_t)kb / 16;
+  hipLaunchKernelGGL(q2c_tile_rows_gather_kernel, dim3((unsigned)((n_chunks + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const uint4*)src, row_map, (uint4*)dst, (int)kb, n_chunks);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+extern "C" int xml_q2c_scores_packed(int n_mod, const void* qt0, const void* ct0, const void* qt1, const void* ct1,
+                                     float* out, int64_t ld_out, int nq, int n_tiles, int ct128, int ct64,
+                                     const int32_t* slot_ids, const uint32_t* mbits0, const uint32_t* mbits1, int hidden,
+                                     int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if ((n_mod != 1 && n_mod != 2) || !qt0 || !ct0 || !out || !slot_ids || !mbits0) return XML_ERR_BAD_ARG;
+  if (n_mod == 2 && (!qt1 || !ct1 || !mbits1)) return XML_ERR_BAD_ARG;
+  if (nq <= 0 || n_tiles <= 0 || hidden <= 0 || ld_out <= 0) return XML_ERR_BAD_ARG;
+  if (!xml_q2c_tiled_ok(128, hidden, dt)) return XML_ERR_UNSUPPORTED;
+  const void* q[2] = {qt0, n_mod == 2 ? qt1 : qt0};
+  const void* c[2] = {ct0, n_mod == 2 ? ct1 : ct0};
+  const float* m[2] = {nullptr, nullptr};
+  const uint32_t* mb[2] = {mbits0, n_mod == 2 ? mbits1 : mbits0};
+  // the kernel sees 2 * n_tiles "videos" of 128 columns (wave tiles); real ids come from slot_ids
+  return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, 2 * n_tiles, 128, hidden, dt, (hipStream_t)stream, true,
+                                 3, mb, slot_ids, ct128, ct64);
+}
+
 extern "C" int xml_q2c_tiled_ok(int lpad, int hidden, int dt) {
   if (dt != XML_F32 && dt != XML_BF16) return 0;
   const size_t kb = (size_t)hidden * dt_size(dt);
@@ -663,5 +798,5 @@ extern "C" int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0,
   if (mask_mode < 0 || mask_mode > 2) return XML_ERR_BAD_ARG;
   const uint32_t* mb[2] = {mbits0, n_mod == 2 ? mbits1 : mbits0};
   return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream, true,
-                                 mask_mode, mb);
+                                 mask_mode, mb, nullptr, 0, 0);
 }

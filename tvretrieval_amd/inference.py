@@ -109,12 +109,15 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
 
     feat1n, feat2, mask, raw = {}, {}, {}, {}
     for m in mods:
+        mask[m] = cat(parts[m]["mk"])
+    # ragged corpora: one length-bucketed layout shared by the modalities (2 / 4 / 8 videos per K6 tile)
+    plan = ops.q2c_pack_plan([mask[m] for m in mods]) if (hasattr(ops, "q2c_pack_plan") and lpad == 128) else None
+    for m in mods:
         f1 = cat(parts[m]["f1"])
         feat1n[m] = ops.l2norm_rows(f1)
         feat2[m] = cat(parts[m]["f2"])
-        mask[m] = cat(parts[m]["mk"])
         if hasattr(ops, "pack_q2c_corpus"):      # HIP backend: slice-major tiles for the persistent K6 kernel
-            feat1n[m] = ops.pack_q2c_corpus(feat1n[m], mask[m])
+            feat1n[m] = ops.pack_q2c_corpus(feat1n[m], mask[m], plan)
         if keep_raw:
             raw[m] = f1
     idx = CorpusIndex(mods, feat1n, feat2, mask, l_ref, video_offset, n_total)
@@ -389,11 +392,19 @@ def get_eval_res(model, eval_dataset, opt, tasks, max_after_nms, ops=hip_ops):
 def eval_epoch(model, eval_dataset, opt, tasks=("SVMR",), max_after_nms=100, ground_truth=None, ops=hip_ops):
     """The in-memory part of eval_epoch (xml/inference.py:473-531): raw results -> top-n submission -> metrics, and
     the same again after temporal NMS when opt.nms_thd != -1.  (File writing stays with the caller.)
-    Returns (submission, metrics, submission_after_nms, metrics_after_nms)."""
+    Returns (submission, metrics, submission_after_nms, metrics_after_nms).
+
+    Reference quirk kept on purpose: get_submission_top_n truncates the RAW lists in place (clip_alignment_with_language/
+    inference.py:503-515), so the NMS stage (xml/inference.py:507-515) only ever sees the first max_after_nms (100)
+    candidates, not max_before_nms, and the after-NMS metrics are computed with eval_retrieval's default
+    use_desc_type=True.  opt.nms_on_full_lists=True runs NMS on the untruncated lists instead (not the reference)."""
     from . import evaluate, postproc
     raw = get_eval_res(model, eval_dataset, opt, tasks, max_after_nms, ops=ops)
     import copy
-    submission = postproc.get_submission_top_n(copy.deepcopy(raw), top_n=max_after_nms)
+    full = copy.deepcopy(raw) if getattr(opt, "nms_on_full_lists", False) else None
+    submission = postproc.get_submission_top_n(raw, top_n=max_after_nms)      # truncates `raw` in place, like the reference
+    if full is not None:
+        raw = full
     use_desc_type = getattr(opt, "dset_name", "tvr") == "tvr"
     metrics = None
     if ground_truth is not None:
@@ -408,6 +419,5 @@ def eval_epoch(model, eval_dataset, opt, tasks=("SVMR",), max_after_nms=100, gro
                                 max_after_nms=max_after_nms)
         if ground_truth is not None:
             metrics_nms = evaluate.eval_retrieval(sub_nms, ground_truth, iou_thds=(0.5, 0.7), verbose=False,
-                                                  match_number=not getattr(opt, "debug", False),
-                                                  use_desc_type=use_desc_type)
+                                                  match_number=not getattr(opt, "debug", False))
     return submission, metrics, sub_nms, metrics_nms

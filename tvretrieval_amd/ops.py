@@ -204,6 +204,7 @@ class TiledRows(object):
         self.dtype, self.device = data.dtype, data.device
         self.all_valid = bool(all_valid)     # every clip mask of the corpus is 1: K6 may skip the masks (5-slot ring)
         self.mask_bits = None                # (Nv, 4) int32: binary clip masks packed 128 bits per video (ragged corpora)
+        self.plan = None                     # PackPlan: length-bucketed image (mask_bits are then per wave tile)
 
     def numel(self):
         return self.data.numel()
@@ -215,7 +216,81 @@ class TiledRows(object):
         """Back to the row-major tensor of the original shape (tests, the CPU baseline sample)."""
         per = 64 // self.data.element_size()
         t = self.data.view(-1, self.hidden // per, 256, per).permute(0, 2, 1, 3).reshape(-1, self.hidden)
+        if self.plan is not None:            # un-bucket: packed row i came from original row row_map[i]
+            rm = self.plan.row_map.long()
+            out = torch.zeros((self.rows, self.hidden), dtype=t.dtype, device=t.device)
+            ok = rm >= 0
+            out[rm[ok]] = t[:rm.numel()][ok]
+            return out.reshape(self.shape)
         return t[:self.rows].reshape(self.shape).contiguous()
+
+
+class PackPlan(object):
+    """Length-bucketed layout of a ragged corpus for K6 (xml_q2c_scores_packed): videos grouped by padded length
+    128 / 64 / 32 clips, 2 / 4 / 8 per 256-row tile.
+      row_map  (rows_packed,) int32   original row (video * 128 + clip) of every packed row, -1 = zero row
+      slot_ids (2 * n_tiles, 4) int32 original video id of every sub-slot of every wave tile, -1 = empty
+      n_tiles, ct128, ct64            tile ranges of the three buckets
+      padded_clips                    sum of padded lengths (the MFMA work actually done, in clip rows)"""
+
+    def __init__(self, masks):
+        m = masks[0]
+        for o in masks[1:]:
+            m = torch.maximum(m, o)
+        nv, l = m.shape
+        assert l == 128
+        dev = m.device
+        pos = torch.arange(1, l + 1, device=dev, dtype=torch.float32)
+        lens = ((m != 0).float() * pos).amax(1)                       # last valid clip + 1
+        ids = torch.arange(nv, device=dev, dtype=torch.int32)
+        groups = []                                                   # (ids padded with -1, padded length, slots per wave tile)
+        for lo, hi, lp, per_wave in ((64, 128, 128, 1), (32, 64, 64, 2), (-1, 32, 32, 4)):
+            sel = ids[(lens > lo) & (lens <= hi)]
+            per_tile = 2 * per_wave
+            pad = (-sel.numel()) % per_tile
+            if pad:
+                sel = torch.cat([sel, torch.full((pad,), -1, dtype=torch.int32, device=dev)])
+            groups.append((sel, lp, per_wave))
+        rows, sids = [], []
+        for sel, lp, per_wave in groups:
+            if sel.numel() == 0:
+                continue
+            r = sel[:, None].long() * 128 + torch.arange(lp, device=dev)[None]
+            rows.append(torch.where(sel[:, None] >= 0, r, torch.full_like(r, -1)).reshape(-1))
+            s = sel.view(-1, per_wave)
+            if per_wave < 4:
+                s = torch.cat([s, torch.full((s.shape[0], 4 - per_wave), -1, dtype=torch.int32, device=dev)], 1)
+            sids.append(s)
+        self.row_map = torch.cat(rows).to(torch.int32).contiguous()
+        self.slot_ids = torch.cat(sids).contiguous()
+        self.ct128 = groups[0][0].numel() // 2
+        self.ct64 = self.ct128 + groups[1][0].numel() // 4
+        self.n_tiles = self.ct64 + groups[2][0].numel() // 8
+        assert self.row_map.numel() == self.n_tiles * 256 and self.slot_ids.shape[0] == 2 * self.n_tiles
+        self.n_videos = nv
+        self.padded_clips = int(sum(int((g[0] >= 0).sum()) * g[1] for g in groups))
+
+    def mask_bits(self, mask):
+        """(nv, 128) binary f32 mask -> (2 * n_tiles, 4) int32: the masks of every wave tile's 128 packed columns."""
+        flat = torch.cat([(mask != 0).reshape(-1), torch.zeros(1, dtype=torch.bool, device=mask.device)])
+        rm = self.row_map.long()
+        v = flat[torch.where(rm >= 0, rm, torch.full_like(rm, flat.numel() - 1))]
+        w = (v.view(-1, 4, 32).to(torch.int64) << torch.arange(32, device=mask.device, dtype=torch.int64)).sum(-1)
+        return torch.where(w >= 2 ** 31, w - 2 ** 32, w).to(torch.int32).contiguous()
+
+
+def q2c_pack_plan(masks):
+    """PackPlan for the corpus with these per-modality (Nv, 128) clip masks, or None when bucketing does not apply
+    (non-binary masks, every video longer than 64 clips, XML_Q2C_NO_BUCKETS=1 for A/B runs)."""
+    if os.environ.get("XML_Q2C_NO_BUCKETS") or os.environ.get("XML_Q2C_KEEP_MASKS") or os.environ.get("XML_Q2C_ROW_MAJOR"):
+        return None
+    for m in masks:
+        if m.shape[1] != 128 or not bool(((m == 0) | (m == 1)).all()):
+            return None
+    if all(bool((m == 1).all()) for m in masks):
+        return None                           # full-length corpus: the mask-free kernel on the plain tiles
+    plan = PackPlan(masks)
+    return plan if plan.ct128 < plan.n_tiles else None
 
 
 def q2c_tiled_ok(lpad, hidden, dtype):
@@ -233,9 +308,21 @@ def q2c_tile_rows(x):
     return TiledRows(data, rows, hidden, x.shape)
 
 
-def pack_q2c_corpus(feat1n, mask=None):
+def pack_q2c_corpus(feat1n, mask=None, plan=None):
     """Resident form of the similarity operand: slice-major tiles when the persistent kernel takes it, else as is.
-    mask (Nv, Lpad): if every entry is 1 (full-length videos) the tiles are marked all_valid and K6 skips the masks."""
+    mask (Nv, Lpad): if every entry is 1 (full-length videos) the tiles are marked all_valid and K6 skips the masks.
+    plan (q2c_pack_plan over ALL modalities' masks): the length-bucketed image instead."""
+    if plan is not None and q2c_tiled_ok(feat1n.shape[1], feat1n.shape[2], feat1n.dtype):
+        _req(feat1n, "feat1n")
+        nv, lpad, hidden = feat1n.shape
+        rows_packed = plan.n_tiles * 256
+        data = torch.empty(rows_packed * hidden, dtype=feat1n.dtype, device=feat1n.device)
+        check(_lib.load().xml_q2c_tile_rows_gather(_p(feat1n), _p(plan.row_map), _p(data), rows_packed, hidden,
+                                                   dt_of(feat1n), _stream()), "xml_q2c_tile_rows_gather")
+        t = TiledRows(data, nv * lpad, hidden, feat1n.shape)
+        t.plan = plan
+        t.mask_bits = plan.mask_bits(mask)
+        return t
     if q2c_tiled_ok(feat1n.shape[1], feat1n.shape[2], feat1n.dtype) and not os.environ.get("XML_Q2C_ROW_MAJOR"):
         t = q2c_tile_rows(feat1n)             # (XML_Q2C_ROW_MAJOR=1: keep rows, for A/B measurements)
         keep = os.environ.get("XML_Q2C_KEEP_MASKS")      # 1: float masks (4-slot kernel), for A/B measurements
@@ -265,6 +352,15 @@ def q2c_scores_fused(qn, cn, masks, out=None):
             out = torch.empty((nq, nv), dtype=torch.float32, device=qn[0].device)
         _req(out, "out", torch.float32)
         j = 1 if n_mod > 1 else 0
+        plan = cn[0].plan
+        if plan is not None:                  # length-bucketed image: one masked maximum per sub-slot, original columns
+            assert all(c.plan is plan for c in cn[:n_mod]) and plan.n_videos == nv
+            check(_lib.load().xml_q2c_scores_packed(n_mod, _p(qt[0].data), _p(cn[0].data), _p(qt[j].data),
+                                                    _p(cn[j].data), _p(out), out.stride(0), nq, plan.n_tiles, plan.ct128,
+                                                    plan.ct64, _p(plan.slot_ids), _p(cn[0].mask_bits),
+                                                    _p(cn[j].mask_bits), hidden, dt_of(qn[0]), _stream()),
+                  "xml_q2c_scores_packed")
+            return out
         bits = [c.mask_bits for c in cn[:n_mod]]
         if all(c.all_valid for c in cn[:n_mod]):
             mode, bits = 1, [None, None]
@@ -303,8 +399,10 @@ def topk_rows(scores, k, alpha=0.0, idx_in=None):
         assert idx_in.shape == scores.shape
     vals = torch.empty((rows, k), dtype=torch.float32, device=scores.device)
     idx = torch.empty((rows, k), dtype=torch.int32, device=scores.device)
-    check(_lib.load().xml_topk_rows(_p(scores), scores.stride(0), _p(idx_in), _p(vals), _p(idx), rows, n, k,
-                                    float(alpha), None, 0, _stream()), "xml_topk_rows")
+    lib = _lib.load()
+    ws = _workspace(lib.xml_topk_rows_workspace_bytes(rows, n, k), scores.device)      # header contract: caller's scratch
+    check(lib.xml_topk_rows(_p(scores), scores.stride(0), _p(idx_in), _p(vals), _p(idx), rows, n, k,
+                            float(alpha), _p(ws), ws.numel(), _stream()), "xml_topk_rows")
     return vals, idx
 
 

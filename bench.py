@@ -275,6 +275,32 @@ def run(args):
         rep_s = time.perf_counter() - t0
     qf, qm = synth_queries(nq, dq, device)
 
+    exchange, exch_note = None, None
+    if multi:
+        # collectives: libxmlhip's RCCL entries (xml_rccl_*) on GPU ranks.  They cannot be exercised at world > 1 on the
+        # 1-GPU development boxes, so every run first pushes one small exchange through them AND through
+        # torch.distributed and compares; a mismatch or an error falls back to torch.distributed, and the line says so.
+        exchange = xdist.TorchExchange()
+        if be.name == "hip" and not args.torch_collectives:
+            try:
+                cand = xdist.RcclExchange()
+                g = torch.Generator(device=device).manual_seed(11 + rank)
+                s = torch.randn(4 * world + 3, 64, device=device, generator=g)
+                li = torch.argsort(s, dim=1, descending=True).int()[:, :16].contiguous() + 1000 * rank
+                ls = torch.gather(s, 1, (li - 1000 * rank).long()).contiguous()
+                a, b = cand.topk_by_owner(ls, li, 16, 20.0, ops), exchange.topk_by_owner(ls, li, 16, 20.0, ops)
+                rows = ls[:5].to(torch.bfloat16).contiguous()
+                same = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and \
+                    torch.equal(cand.allgather_rows(rows), exchange.allgather_rows(rows))
+                flag = torch.tensor([1 if same else 0], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 1:
+                    exchange = cand
+                else:
+                    exch_note = "C-ABI self-check MISMATCH vs torch.distributed -> fell back"
+            except Exception as e:       # noqa: BLE001 -- report, never lose the measurement
+                exch_note = "C-ABI collectives failed (%s: %s) -> fell back" % (type(e).__name__, e)
+
     ev = []      # (start, end) event pairs around every K6 launch of the timed region
     def k6_timer():
         s, e = be.event(), be.event()
@@ -286,7 +312,8 @@ def run(args):
             if not multi:
                 return inf.vcmr_search(model, index, qf, qm, ops=ops)
             # final lists stay on the rank that owns the query (where its NMS would run): no redundant gather
-            return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False, ops=ops)
+            return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False, ops=ops, exchange=exchange,
+                                             n_chunks=1 if args.sharded_rerank else args.chunks)
 
     for _ in range(args.warmup):
         step()
@@ -354,7 +381,8 @@ def run(args):
         dist.barrier()
         be.sync()
         xdist.STAGE_MARK = mark
-        step()
+        with torch.no_grad():           # un-pipelined (one chunk) so that every stage, exchanges included, is delimited
+            xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False, ops=ops, exchange=exchange, n_chunks=1)
         xdist.STAGE_MARK = None
         be.sync()
         for (_, e0), (name, e1) in zip(marks, marks[1:]):
@@ -373,6 +401,9 @@ def run(args):
                                    "top-200 moments" % (args.workload, ctx_mode, nq, nv, l, hidden),
                        "global_batch": nq, "parallelism": "corpus-shard x%d" % world, "videos_per_gpu": per_rank_videos,
                        "ranks_in_process_group": rccl_ranks, "backend": be.name,
+                       "collectives": (exchange.name if exchange is not None else "none") +
+                                      ("" if exch_note is None else " [%s]" % exch_note),
+                       "query_chunks": args.chunks if multi and not args.sharded_rerank else 1,
                        "launcher": "bench.py self-spawn" if os.environ.get("XML_SELF_SPAWNED") else
                                    ("torch.distributed.run" if world > 1 else "single process"),
                        "result_placement": "all on the GPU" if not multi else "final lists on the query's owner rank",
@@ -428,6 +459,10 @@ def main(argv=None):
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU code path even with 1 rank (testing)")
     ap.add_argument("--sharded-rerank", action="store_true",
                     help="N > 1: keep feat2 sharded too (phase 2 on the video's owner, four collectives per pass)")
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("XML_SHARD_CHUNKS", "2")),
+                    help="N > 1: query chunks of the pipelined owner pass (chunk c's exchange runs under chunk c+1's K6)")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="N > 1: keep the exchanges on torch.distributed instead of libxmlhip's xml_rccl_* entries (A/B)")
     ap.add_argument("--backend-module", default=None,
                     help="TEST HOOK: module providing BenchBackend (tests/cpu_backend.py: gloo ranks on CPU, kernels "
                          "replaced by the oracle formulation) -- exercises this launcher without GPUs")

@@ -343,6 +343,35 @@ int xml_bert_adam_step(float* p, float* g, float* m, float* v, const int64_t* se
                        float eps, float max_grad_norm, float* norms, const uint8_t* seg_active,
                        const float* seg_lr_mult, xml_stream_t stream);
 
+/* =============================================================================================
+ * MULTI-GPU (BASELINE config 4): collectives of the corpus-sharded pass, RCCL over xGMI, one process per
+ * GPU.  The reference has no distributed path; what these entries preserve is its driver semantics -- moments only from
+ * the GLOBAL top-k videos of a query (xml/inference.py:347-348,365-367).  The communicator is a plain ncclComm_t: create
+ * it here from a 128-byte ncclUniqueId (rank 0 makes it, any side channel -- e.g. torch.distributed's store --
+ * distributes it) or pass one made elsewhere with the same RCCL.  RCCL is resolved at run time (dlopen).
+ * ============================================================================================= */
+typedef void* xml_comm_t; /* ncclComm_t */
+int xml_rccl_available(void);                      /* 1 when an RCCL library could be resolved */
+int xml_rccl_unique_id(void* id128);               /* HOST pointer to 128 bytes (ncclGetUniqueId) */
+int xml_rccl_comm_init(xml_comm_t* comm, int nranks, int rank, const void* id128);   /* collective: all ranks call it */
+int xml_rccl_comm_destroy(xml_comm_t comm);
+/* recv (nranks * bytes_per_rank) = concatenation over ranks of send (bytes_per_rank): the modular query vectors of every
+ * owner's slice (encode_query runs on 1/P of the queries per rank). */
+int xml_rccl_allgather(xml_comm_t comm, const void* send, void* recv, int64_t bytes_per_rank, xml_stream_t stream);
+/* in-place average of an f32 buffer over ranks (data-parallel gradient buckets, BASELINE config 5; xml/train.py:81-85
+ * is the single-process loop it extends). */
+int xml_rccl_allreduce_avg_f32(xml_comm_t comm, float* buf, int64_t n, xml_stream_t stream);
+/* Exact global top-k by query owner.  Queries are split into `world` contiguous slices of per = ceil(nq / world) rows;
+ * rank r owns slice r.  Every rank passes its LOCAL top-c of all nq queries -- loc_score (nq, c) f32 descending,
+ * loc_id (nq, c) int32 GLOBAL video ids (pad short shards with -inf / INT32_MAX) -- and receives the merged global top-k
+ * of its own slice: own_val (rows_owned, k) f32 = alpha != 0 ? exp(alpha * s) : s, own_id (rows_owned, k), ordered by
+ * (score desc, id asc) like xml_topk_rows, i.e. exactly the single-GPU list.  k <= 256, k <= world * c.
+ * One grouped send/recv (an all-to-all with ragged counts), one un-permute kernel, one top-k kernel. */
+size_t xml_rccl_topk_by_owner_workspace_bytes(int world, int per, int c);
+int xml_rccl_topk_by_owner(xml_comm_t comm, int world, int rank, const float* loc_score, const int32_t* loc_id,
+                           int nq, int c, int k, float alpha, float* own_val, int32_t* own_id, void* ws,
+                           size_t ws_bytes, xml_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * HOST post-processing ("next" row 8f-1; pointers are HOST memory): greedy temporal NMS.
  *   xml_nms_vcmr_host = filter_vcmr_by_nms (baselines/clip_alignment_with_language/inference.py:189-225):

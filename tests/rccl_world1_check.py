@@ -47,6 +47,58 @@ def main():
             assert torch.equal(got2[k], want[k]), (str(dtype), k, "owner rerank")
             assert torch.equal(own2[k], want[k]), (str(dtype), k, "owner rerank, owner slice")
 
+    # ---- the C-ABI collectives (xml_rccl_*) on a 1-rank communicator of our own vs the torch.distributed exchange ----
+    ex_c, ex_t = xd.RcclExchange(), xd.TorchExchange()
+    assert ex_c.world == 1 and ex_c.rank == 0
+    from tvretrieval_amd import ops
+    g = torch.Generator(device=dev).manual_seed(3)
+    s = torch.randn(37, 2000, device=dev, generator=g)
+    loc_s, loc_i = ops.topk_rows(s, 100, alpha=0.0)
+    loc_i = (loc_i + 5000).contiguous()
+    a = ex_c.topk_by_owner(loc_s, loc_i, 100, 20.0, ops)
+    b = ex_t.topk_by_owner(loc_s, loc_i, 100, 20.0, ops)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    rows = torch.randn(11, 2, 64, device=dev, generator=g).to(torch.bfloat16)
+    assert torch.equal(ex_c.allgather_rows(rows), ex_t.allgather_rows(rows))
+    # the chunked, stream-pipelined owner pass through the C-ABI exchange
+    for dtype in (torch.bfloat16,):
+        m = XML(cfg, compute_dtype=dtype)
+        m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+        m = m.to(dev).eval()
+        with torch.no_grad():
+            index = inf.build_corpus_index(m, [(T(d["video_feat"]), T(d["video_mask"]), T(d["sub_feat"]), T(d["sub_mask"]))])
+            xd.replicate_rerank_features(index)
+            qf, qm = T(d["query_feat"]), T(d["query_mask"])
+            want = inf.vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50)
+            for n_chunks in (1, 3):
+                got = xd.sharded_vcmr_search(m, index, qf, qm, max_vcmr_video=6, max_before_nms=50, exchange=ex_c,
+                                             n_chunks=n_chunks, gather_results=False)
+                torch.cuda.synchronize()
+                for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"):
+                    assert torch.equal(got[k], want[k]), (k, n_chunks)
+    # gradient buckets reduced under backward through xml_rccl_allreduce_avg_f32 (1 rank: the average is the identity)
+    from tvretrieval_amd.train import BertAdam, GradientReducer, train_step
+    dt, tcfg, _ = load_golden("train_step_video_sub_h128")
+    results = []
+    for with_reducer in (False, True):
+        tm = XML(tcfg)
+        tm.load_state_dict({k[len("sd_before/"):]: torch.from_numpy(v.copy()) for k, v in dt.items() if k.startswith("sd_before/")})
+        tm = tm.to(dev)
+        tm.eval()
+        opt = BertAdam(tm.parameters(), lr=1e-3, warmup=-1, t_total=-1, schedule="none")
+        if with_reducer:
+            red = GradientReducer(opt, bucket_bytes=64 << 10)
+            assert red.comm is not None and len(red.buckets) > 3
+        batch = dict(query_feat=T(dt["query_feat"]), query_mask=T(dt["query_mask"]), video_feat=T(dt["video_feat"]),
+                     video_mask=T(dt["video_mask"]), sub_feat=T(dt["sub_feat"]), sub_mask=T(dt["sub_mask"]),
+                     st_ed_indices=T(dt["st_ed_indices"]), neg_ctx_rank=dt["neg_ctx_rank"], neg_q_rank=dt["neg_q_rank"])
+        for _ in range(3):
+            train_step(tm, opt, batch)
+        torch.cuda.synchronize()
+        results.append(opt.flat_p.clone())
+    assert torch.equal(results[0], results[1])
+
     class Holder(object):
         pass
     h = Holder()

@@ -32,7 +32,7 @@ def test_bench_self_spawns_two_gloo_ranks():
     assert len(res["config"]["videos_per_gpu"]) == 2 and sum(res["config"]["videos_per_gpu"]) == 300
     assert res["value"] > 0 and res["scaling"] == "strong"
     stages = res["breakdown_ms"]
-    assert "alltoall_topk" in stages and "q2c_k6" in stages, stages
+    assert "exchange+merge_topk" in stages and "q2c_k6" in stages, stages
 
 
 def test_bench_rank_failure_propagates():
@@ -49,4 +49,5 @@ def test_bench_tiny_forced_sharded_on_gpu():
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert res["n_gpus"] == 1 and res["config"]["backend"] == "hip" and res["config"]["ranks_in_process_group"] == 1
-    assert "alltoall_topk" in res["breakdown_ms"] or "topk_k8" in res["breakdown_ms"]
+    assert "exchange+merge_topk" in res["breakdown_ms"] or "topk_k8" in res["breakdown_ms"]
+    assert res["config"]["collectives"].startswith("libxmlhip RCCL")

@@ -68,6 +68,20 @@ def _worker(rank, world, port, name, kvid, nbefore, ret):
         slice_ok = slice_ok and mine2["query_range"] == (q_lo, q_hi) and \
             all(torch.equal(mine2[k], out2[k][q_lo:q_hi])
                 for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"))
+        # chunked schedule (the GPU path pipelines chunk c's exchange under chunk c + 1's K6): ownership is per chunk
+        for n_chunks in (2, 3):
+            out3 = xd.sharded_vcmr_search(model, index, qf, qm, max_vcmr_video=kvid, max_before_nms=nbefore, ops=CpuOps,
+                                          n_chunks=n_chunks)
+            mine3 = xd.sharded_vcmr_search(model, index, qf, qm, max_vcmr_video=kvid, max_before_nms=nbefore, ops=CpuOps,
+                                           gather_results=False, n_chunks=n_chunks)
+            qi = mine3["query_index"]
+            slice_ok = slice_ok and "query_range" not in mine3 and bool((qi[1:] > qi[:-1]).all()) and \
+                all(torch.equal(out3[k], out2[k]) for k in ("top_indices", "flat_indices")) and \
+                all(torch.allclose(out3[k], out2[k], rtol=2e-5, atol=0) for k in ("top_scores", "flat_scores")) and \
+                all(torch.equal(mine3[k], out3[k][qi]) for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"))
+            counts = [None] * world
+            dist.all_gather_object(counts, qi.tolist())
+            slice_ok = slice_ok and sorted(sum(counts, [])) == list(range(qf.shape[0]))     # every query owned exactly once
         flags = [None] * world
         dist.all_gather_object(flags, bool(slice_ok))
         if rank == 0:
@@ -153,6 +167,52 @@ def _grad_worker(rank, world, port, ret):
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()
+
+
+def _reducer_worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tvretrieval_amd.train import GradientReducer, allreduce_gradients
+
+        class FakeOpt(object):      # what GradientReducer needs from BertAdam: segment offsets + the flat gradient buffer
+            pass
+        sizes = [40, 300, 8, 1000, 64, 64, 700, 12]
+        offs = [0]
+        for s_ in sizes:
+            offs.append(offs[-1] + (s_ + 3) // 4 * 4)
+        o = FakeOpt()
+        o.seg_off = torch.tensor(offs, dtype=torch.int64)
+        o.flat_g = torch.zeros(offs[-1])
+        o._reducer = None
+        red = GradientReducer(o, bucket_bytes=600 * 4)
+        assert len(red.buckets) >= 3 and red.buckets[0][0] == 0 and red.buckets[-1][1] == offs[-1]
+        ok = True
+        for step, silent in enumerate(([], [2, 5])):     # step 2: two tensors get no gradient (their buckets flush in finish)
+            red.begin()
+            g = torch.Generator().manual_seed(7 + 10 * step + rank)
+            o.flat_g.copy_(torch.randn(offs[-1], generator=g))
+            for seg in reversed(range(len(sizes))):        # backward order: last tensor first
+                if seg not in silent:
+                    red.grad_ready(seg)
+            allreduce_gradients(o)
+            want = sum(torch.randn(offs[-1], generator=torch.Generator().manual_seed(7 + 10 * step + r))
+                       for r in range(world)) / world
+            ok = ok and torch.allclose(o.flat_g, want, rtol=0, atol=1e-6)
+        ret[rank] = bool(ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gradient_reducer_overlapped_buckets_world2():
+    """GradientReducer: buckets are reduced as their last gradient is reported (descending order), incomplete buckets in
+    finish(); the result is the plain average."""
+    world = 2
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_reducer_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert all(ret[r] for r in range(world)), dict(ret)
 
 
 def test_gradient_allreduce_buckets_world2():

@@ -46,7 +46,7 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from tvretrieval_amd.model_xml import XML, xml_base_config
-    from tvretrieval_amd.train import BertAdam, allreduce_gradients, xml_forward_train
+    from tvretrieval_amd.train import BertAdam, GradientReducer, allreduce_gradients, xml_forward_train
 
     cfg = dict(xml_base_config)
     cfg.update(visual_input_size=a.dv, sub_input_size=a.ds, query_input_size=a.ds, hidden_size=a.hidden,
@@ -59,6 +59,8 @@ def main():
     opt = BertAdam([{"params": [p for n, p in named if not any(nd in n for nd in no_decay)], "weight_decay": 0.01},
                     {"params": [p for n, p in named if any(nd in n for nd in no_decay)], "weight_decay": 0.0}],
                    lr=1e-4, warmup=0.01, t_total=10000)
+    if world > 1:      # gradient buckets are all-reduced under backward (xml_rccl_allreduce_avg_f32 on a side stream)
+        GradientReducer(opt)
     g = torch.Generator().manual_seed(77 + rank)
     n, lc, lq = a.bsz, a.ctx_l, a.desc_l
     lens = torch.randint(lc // 2, lc + 1, (n,), generator=g)

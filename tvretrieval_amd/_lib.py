@@ -76,6 +76,16 @@ SIGNATURES = {
                                   c_void_p]),
     "xml_add_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                   c_void_p]),
+    # ---- multi-GPU collectives (collectives.hip) ----
+    "xml_rccl_available": (c_int, []),
+    "xml_rccl_unique_id": (c_int, [c_void_p]),
+    "xml_rccl_comm_init": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "xml_rccl_comm_destroy": (c_int, [c_void_p]),
+    "xml_rccl_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
+    "xml_rccl_allreduce_avg_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "xml_rccl_topk_by_owner_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "xml_rccl_topk_by_owner": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                       c_void_p, c_void_p, c_size_t, c_void_p]),
     # ---- training step (train.hip) ----
     "xml_transpose_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "xml_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),

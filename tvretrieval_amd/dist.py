@@ -133,13 +133,71 @@ def replicate_rerank_features(index, group=None):
     return index
 
 
-def encode_queries_sharded(model, query_feat, query_mask, group=None):
+class TorchExchange(object):
+    """The two exchanges of a sharded pass through torch.distributed: the CPU tests' gloo groups, and the fallback when
+    the C-ABI path is not available.  Same results as RcclExchange by construction (same merge kernel, same tie rule)."""
+    name = "torch.distributed"
+
+    def __init__(self, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def allgather_rows(self, buf):
+        out = torch.empty((self.world * buf.shape[0],) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
+        dist.all_gather_into_tensor(out, buf.contiguous(), group=self.group)
+        return out
+
+    def topk_by_owner(self, loc_s, loc_i, k, alpha, ops):
+        nq = loc_s.shape[0]
+        q_lo, q_hi, per = query_slice(nq, self.rank, self.world)
+        cand_s, cand_i = _exchange_by_owner(_pack_rows(loc_s, loc_i, self.world * per, float("-inf"), 2 ** 31 - 1),
+                                            self.group, self.world, per)
+        own_w, own_gid = ops.topk_rows(cand_s, k, alpha=alpha, idx_in=cand_i)
+        return own_w[:q_hi - q_lo], own_gid[:q_hi - q_lo]
+
+
+class RcclExchange(object):
+    """The same two exchanges inside libxmlhip.so (xml_rccl_allgather, xml_rccl_topk_by_owner: grouped send/recv +
+    un-permute + top-k, three launches) on an ncclComm_t of our own."""
+    name = "libxmlhip RCCL (C ABI)"
+
+    def __init__(self, group=None):
+        from .rccl import RcclComm
+        self.comm = RcclComm(group)
+        self.world, self.rank = self.comm.world, self.comm.rank
+
+    def allgather_rows(self, buf):
+        return self.comm.allgather(buf.contiguous())
+
+    def topk_by_owner(self, loc_s, loc_i, k, alpha, ops):
+        return self.comm.topk_by_owner(loc_s.contiguous(), loc_i.contiguous(), k, alpha)
+
+
+_EXCHANGES = {}
+FORCE_TORCH_EXCHANGE = False        # tests / A-B runs: keep GPU ranks on torch.distributed collectives
+
+
+def default_exchange(device, group=None):
+    """RcclExchange for GPU ranks (created once per group: ncclCommInitRank is collective), TorchExchange otherwise."""
+    key = (id(group), str(device))
+    ex = _EXCHANGES.get(key)
+    if ex is None:
+        use_rccl = torch.device(device).type == "cuda" and dist.is_initialized() and not FORCE_TORCH_EXCHANGE \
+            and dist.get_backend(group) == "nccl"
+        ex = RcclExchange(group) if use_rccl else TorchExchange(group)
+        _EXCHANGES[key] = ex
+    return ex
+
+
+def encode_queries_sharded(model, query_feat, query_mask, group=None, exchange=None):
     """Each rank encodes its contiguous 1/P slice of the (replicated) raw queries; ONE all-gather carries the modular
     vectors of all modalities."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     if _trivial(world):
         return inf.stage_query_vectors(model, query_feat, query_mask)
+    ex = exchange or default_exchange(query_feat.device, group)
     nq = query_feat.shape[0]
     lo, hi, per = query_slice(nq, rank, world)
     if hi > lo:
@@ -153,55 +211,116 @@ def encode_queries_sharded(model, query_feat, query_mask, group=None):
     if hi > lo:
         for j, m in enumerate(names):
             buf[:hi - lo, j] = local[m]
-    out = torch.empty((world * per, len(names), hdim), dtype=buf.dtype, device=buf.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
+    out = ex.allgather_rows(buf)
     return {m: out[:nq, j].contiguous() for j, m in enumerate(names)}
 
 
-def _owner_rerank(model, index, qvec, own_w, own_gid, q2c, nq, q_lo, q_hi, per, n_out, min_pred_l, max_pred_l, group,
-                  world, ops, gather_results):
-    """Phase 2 on the query's owner: K7 + K9 for my query slice over its global top-k videos (global ids into the
-    corpus-wide feat2 copy).  Same kernels, same inputs as the single-GPU pass for these rows."""
-    n_own = q_hi - q_lo
-    k = own_w.shape[1]
-    if n_own > 0:
-        qv = {m: v[q_lo:q_hi] for m, v in qvec.items()}
-        top_w, top_gid = own_w[:n_own].contiguous(), own_gid[:n_own].contiguous()
-        st, ed = inf.stage_span_probs(model, index, qv, top_gid, ops, replicated=True)
-        _mark("convse_k7")
-        fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, n_out)
-        _mark("moment_k9")
-    else:   # more ranks than queries
-        top_w, top_gid = own_w[:0], own_gid[:0]
-        fs, fi = own_w.new_zeros((0, n_out)), own_gid.new_full((0, n_out), -1)
-    if gather_results:
-        top_w, top_gid = _all_gather_packed(top_w, top_gid, group, world, nq, per)
-        fs, fi = _all_gather_packed(fs, fi, group, world, nq, per)
-        q_lo, q_hi = 0, nq
-    return dict(top_scores=top_w, top_indices=top_gid, flat_scores=fs, flat_indices=fi, q2c_local=q2c,
-                query_range=(q_lo, q_hi))
+def _local_topk(index, q2c, k, ops):
+    """Local top-k of every query over this shard, with GLOBAL video ids, padded to k slots per rank."""
+    k_loc = min(k, index.n_videos)
+    loc_s, loc_i = ops.topk_rows(q2c, k_loc, alpha=0.0)
+    loc_i = loc_i + index.video_offset
+    if k_loc < k:       # tiny shard: pad with -inf so that every rank contributes k slots
+        pad_s = loc_s.new_full((loc_s.shape[0], k - k_loc), float("-inf"))
+        pad_i = loc_i.new_full((loc_i.shape[0], k - k_loc), 2 ** 31 - 1)
+        loc_s, loc_i = torch.cat([loc_s, pad_s], 1), torch.cat([loc_i, pad_i], 1)
+    return loc_s.contiguous(), loc_i.contiguous()
+
+
+def _owner_pass(model, index, qvec, ex, k, n_out, q2c_alpha, min_pred_l, max_pred_l, ops, n_chunks):
+    """Owner-rerank pass over query chunks, software-pipelined on GPUs: the exchange of chunk c (comm stream: grouped
+    send/recv + merge) runs under K6 of chunk c + 1; K7 / K9 of chunk c are issued behind K6 of chunk c + 1.
+    Returns per-chunk results and the global query ids this rank owns (chunk-wise slices)."""
+    names = sorted(qvec)
+    nq = qvec[names[0]].shape[0]
+    world, rank = ex.world, ex.rank
+    n_chunks = max(1, min(int(n_chunks), nq))
+    bounds = [(nq * c) // n_chunks for c in range(n_chunks + 1)]
+    dev = qvec[names[0]].device
+    cuda = dev.type == "cuda" and n_chunks > 1
+    main = torch.cuda.current_stream(dev) if cuda else None
+    side = torch.cuda.Stream(dev) if cuda else None
+    parts, owned, q2c_parts = [], [], []
+
+    def finish(p):
+        c_lo, qv_c, own, ev = p
+        if ev is not None:
+            main.wait_event(ev)
+        own_w, own_gid = own
+        n_c = qv_c[names[0]].shape[0]
+        o_lo, o_hi, _ = query_slice(n_c, rank, world)
+        if o_hi > o_lo:
+            qv = {m: v[o_lo:o_hi] for m, v in qv_c.items()}
+            top_w, top_gid = own_w.contiguous(), own_gid.contiguous()
+            st, ed = inf.stage_span_probs(model, index, qv, top_gid, ops, replicated=True)
+            _mark("convse_k7")
+            fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, n_out)
+            _mark("moment_k9")
+        else:   # more ranks than queries in this chunk
+            top_w, top_gid = own_w[:0], own_gid[:0]
+            fs, fi = own_w.new_zeros((0, n_out)), own_gid.new_full((0, n_out), -1)
+        parts.append((top_w, top_gid, fs, fi))
+        owned.append(torch.arange(c_lo + o_lo, c_lo + o_hi, device=dev))
+
+    pending = None
+    for c in range(n_chunks):
+        c_lo, c_hi = bounds[c], bounds[c + 1]
+        if c_hi <= c_lo:
+            continue
+        qv_c = {m: qvec[m][c_lo:c_hi].contiguous() for m in names} if n_chunks > 1 else qvec
+        q2c = inf.stage_q2c(index, qv_c, ops)
+        _mark("q2c_k6")
+        loc_s, loc_i = _local_topk(index, q2c, k, ops)
+        _mark("topk_local_k8")
+        q2c_parts.append(q2c)
+        if pending is not None:
+            finish(pending)             # K7 / K9 of the previous chunk, behind this chunk's K6 in the stream
+        if cuda:
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                own = ex.topk_by_owner(loc_s, loc_i, k, q2c_alpha, ops)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            for t in (loc_s, loc_i):
+                t.record_stream(side)
+            for t in own:
+                t.record_stream(main)
+            pending = (c_lo, qv_c, own, ev)
+        else:
+            own = ex.topk_by_owner(loc_s, loc_i, k, q2c_alpha, ops)
+            _mark("exchange+merge_topk")
+            pending = (c_lo, qv_c, own, None)
+    finish(pending)
+    cat = lambda j: torch.cat([p[j] for p in parts]) if len(parts) > 1 else parts[0][j]       # noqa: E731
+    q2c_all = torch.cat(q2c_parts) if len(q2c_parts) > 1 else q2c_parts[0]
+    return cat(0), cat(1), cat(2), cat(3), (torch.cat(owned) if len(owned) > 1 else owned[0]), q2c_all
 
 
 def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200,
                         q2c_alpha=20.0, min_pred_l=2, max_pred_l=16, group=None, ops=hip_ops, qvec=None,
-                        gather_results=True, owner_rerank=None):
+                        gather_results=True, owner_rerank=None, n_chunks=1, exchange=None):
     """Exact corpus-sharded counterpart of inference.vcmr_search.  `index` is this rank's CorpusIndex
     (index.video_offset = global id of its first video, index.n_total = corpus size).
     Returns top_scores/top_indices (., k) with GLOBAL video ids and flat_scores/flat_indices (., n): all Nq rows on
-    every rank with gather_results=True, else the rows [query_range) this rank owns (sharded rerank: top_* are known
-    everywhere and always complete).
+    every rank with gather_results=True, else the rows this rank owns -- `query_index` (global query ids, ascending) and,
+    when they are one contiguous slice (n_chunks == 1), `query_range` (sharded rerank: top_* are known everywhere and
+    always complete).
     owner_rerank (default: whenever replicate_rerank_features(index) was called): phase 2 runs on the query's owner
-    against the corpus-wide feat2 copy -- two collectives per pass instead of four."""
+    against the corpus-wide feat2 copy -- two collectives per pass instead of four.
+    n_chunks > 1 (owner rerank): the pass is pipelined over query chunks (see _owner_pass); ownership is then per chunk.
+    exchange: TorchExchange / RcclExchange (default: RCCL through the C ABI for GPU ranks, torch.distributed otherwise)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    trivial = _trivial(world)
+    ex = exchange or (None if trivial else default_exchange(query_feat.device if query_feat is not None
+                                                            else next(iter(qvec.values())).device, group))
     _mark("start")
     if qvec is None:
-        qvec = encode_queries_sharded(model, query_feat, query_mask, group)
+        qvec = encode_queries_sharded(model, query_feat, query_mask, group, ex)
     _mark("query_encode+allgather")
     nq = next(iter(qvec.values())).shape[0]
     k = min(max_vcmr_video, index.n_total)
     q_lo, q_hi, per = query_slice(nq, rank, world)
-    trivial = _trivial(world)
     if owner_rerank is None:
         owner_rerank = index.feat2_all is not None
     assert not owner_rerank or index.feat2_all is not None, "call replicate_rerank_features(index) first"
@@ -210,30 +329,51 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
         # (replicate_rerank_features) and the single-GPU pass take n_out up to 1024 (xml_moment_topk)
         raise ValueError("sharded rerank merges moment lists of at most 256 entries; max_before_nms=%d needs the owner "
                          "rerank (call replicate_rerank_features(index) first)" % max_before_nms)
+    if index.n_videos == 0:
+        raise ValueError("rank %d holds an empty corpus shard (n_total=%d over %d ranks): use fewer ranks"
+                         % (rank, index.n_total, world))
+    if not trivial and owner_rerank:
+        top_w, top_gid, fs, fi, owned, q2c = _owner_pass(model, index, qvec, ex, k, max_before_nms, q2c_alpha,
+                                                          min_pred_l, max_pred_l, ops, n_chunks)
+        res = dict(q2c_local=q2c, query_index=owned)
+        if gather_results:
+            # every rank ends up with all rows: all-gather the owned rows (padded to the largest owner), then scatter
+            # them to their global query positions
+            n_max = torch.tensor([owned.numel()], device=owned.device)
+            dist.all_reduce(n_max, op=dist.ReduceOp.MAX, group=group)
+            n_max = int(n_max.item())
+
+            def gather(t, fill):
+                pad = t.new_full((n_max,) + tuple(t.shape[1:]), fill)
+                pad[:t.shape[0]] = t
+                return ex.allgather_rows(pad)
+            gq = gather(owned, -1).long()
+            ok = gq >= 0
+
+            def place(t, fill):
+                g = gather(t, fill)
+                out = g.new_full((nq,) + tuple(t.shape[1:]), fill)
+                out[gq[ok]] = g[ok]
+                return out
+            top_w, top_gid, fs, fi = place(top_w, 0.0), place(top_gid, -1), place(fs, 0.0), place(fi, -1)
+            res["query_index"] = torch.arange(nq, device=owned.device)
+            res["query_range"] = (0, nq)
+        elif n_chunks <= 1:
+            res["query_range"] = (q_lo, q_hi)
+        res.update(top_scores=top_w, top_indices=top_gid, flat_scores=fs, flat_indices=fi)
+        return res
     # ---- phase 1: global top-k videos ------------------------------------------------------------------
     q2c = inf.stage_q2c(index, qvec, ops)
     _mark("q2c_k6")
-    k_loc = min(k, index.n_videos)
     if trivial:
         top_w, top_gid = ops.topk_rows(q2c, k, alpha=q2c_alpha)
         top_gid = top_gid + index.video_offset
         _mark("topk_k8")
     else:
-        loc_s, loc_i = ops.topk_rows(q2c, k_loc, alpha=0.0)
-        loc_i = loc_i + index.video_offset
-        if k_loc < k:       # tiny shard: pad with -inf so that every rank contributes k slots
-            pad_s = loc_s.new_full((loc_s.shape[0], k - k_loc), float("-inf"))
-            pad_i = loc_i.new_full((loc_i.shape[0], k - k_loc), 2 ** 31 - 1)
-            loc_s, loc_i = torch.cat([loc_s, pad_s], 1), torch.cat([loc_i, pad_i], 1)
+        loc_s, loc_i = _local_topk(index, q2c, k, ops)
         _mark("topk_local_k8")
-        cand_s, cand_i = _exchange_by_owner(_pack_rows(loc_s, loc_i, world * per, float("-inf"), 2 ** 31 - 1),
-                                            group, world, per)
-        _mark("alltoall_topk")
-        own_w, own_gid = ops.topk_rows(cand_s, k, alpha=q2c_alpha, idx_in=cand_i)       # my slice: global top-k
-        _mark("merge_topk_k8")
-        if owner_rerank:
-            return _owner_rerank(model, index, qvec, own_w, own_gid, q2c, nq, q_lo, q_hi, per, max_before_nms,
-                                 min_pred_l, max_pred_l, group, world, ops, gather_results)
+        own_w, own_gid = ex.topk_by_owner(loc_s, loc_i, k, q2c_alpha, ops)       # my slice: global top-k
+        _mark("exchange+merge_topk")
         top_w, top_gid = _all_gather_packed(own_w, own_gid, group, world, nq, per)
         _mark("allgather_topk")
     # ---- phase 2: moments of the global top-k videos this rank owns -------------------------------------
@@ -260,4 +400,4 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
     if trivial or gather_results:
         q_lo, q_hi = 0, nq
     return dict(top_scores=top_w, top_indices=top_gid, flat_scores=fs, flat_indices=fi, q2c_local=q2c,
-                query_range=(q_lo, q_hi))
+                query_range=(q_lo, q_hi), query_index=torch.arange(q_lo, q_hi, device=top_w.device))

@@ -294,6 +294,7 @@ class BertAdam(object):
         # Gradients land in persistent views of the flat buffer, so "received a gradient" is observed by a
         # post-accumulate hook per parameter (host flag only, no device work).
         self._touched = [False] * len(plist)
+        self._reducer = None                 # GradientReducer (data-parallel runs): all-reduce overlapped with backward
         self.seg_steps = [0] * len(plist)
         self._active_key = None
         self._active_dev = None
@@ -302,8 +303,12 @@ class BertAdam(object):
 
     def _touch(self, i):
         self._touched[i] = True
+        if self._reducer is not None:
+            self._reducer.grad_ready(i)
 
     def zero_grad(self):
+        if self._reducer is not None:
+            self._reducer.begin()
         self.flat_g.zero_()
         for p, o in zip(self.params, self.seg_off.tolist()):
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
@@ -363,13 +368,96 @@ class BertAdam(object):
         return loss
 
 
+class GradientReducer(object):
+    """Data-parallel gradient averaging OVERLAPPED with backward (the reference's loop,
+    xml/train.py:81-85, has no counterpart -- its nn.DataParallel wrapper is dead code).
+
+    The flat gradient buffer is cut into buckets of ~bucket_bytes along tensor boundaries.  BertAdam's per-parameter
+    post-accumulate hooks report every gradient the moment autograd has written it; when the last tensor of a bucket
+    has reported, the bucket's all-reduce(AVG) is issued on a side stream (ordered behind the backward kernels enqueued
+    so far by an event) while backward keeps running on the main stream.  finish() -- called by allreduce_gradients()
+    after loss.backward() -- reduces the buckets that never became complete (tensors without a gradient this step) and
+    makes the main stream wait for the side stream.  Every rank issues the same buckets in the same order: buckets are
+    flushed strictly in DESCENDING order (backward produces gradients roughly last-layer first), a complete bucket waits
+    for the buckets above it.
+    GPU ranks reduce through libxmlhip's xml_rccl_allreduce_avg_f32 on an ncclComm_t of their own; other devices (the
+    gloo tests) through torch.distributed."""
+
+    def __init__(self, optimizer, group=None, bucket_bytes=24 << 20):
+        import torch.distributed as dist
+        self.opt, self.group = optimizer, group
+        self.world = dist.get_world_size(group)
+        offs = optimizer.seg_off.tolist()
+        self.buckets = []                    # (lo, hi, first_seg, n_segs)
+        lo_seg = 0
+        for s in range(len(offs) - 1):
+            if (offs[s + 1] - offs[lo_seg]) * 4 >= bucket_bytes or s == len(offs) - 2:
+                self.buckets.append((offs[lo_seg], offs[s + 1], lo_seg, s + 1 - lo_seg))
+                lo_seg = s + 1
+        self.seg_bucket = [b for b, (_, _, _, n) in enumerate(self.buckets) for _ in range(n)]
+        flat = optimizer.flat_g
+        self.cuda = flat.is_cuda
+        self.comm = None
+        if self.cuda and dist.get_backend(group) == "nccl":
+            from .rccl import RcclComm
+            self.comm = RcclComm(group)
+        self.side = torch.cuda.Stream(flat.device) if self.cuda else None
+        self.works = []
+        optimizer._reducer = self
+        self.begin()
+
+    def begin(self):
+        self.count = [0] * len(self.buckets)
+        self.next_bucket = len(self.buckets) - 1      # descending flush order
+        self.works = []
+
+    def _reduce(self, b):
+        import torch.distributed as dist
+        lo, hi = self.buckets[b][:2]
+        view = self.opt.flat_g[lo:hi]
+        if self.cuda:
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(view.device))
+            self.side.wait_event(ev)
+            with torch.cuda.stream(self.side):
+                if self.comm is not None:
+                    self.comm.allreduce_avg_(view)
+                else:
+                    dist.all_reduce(view, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            self.works.append((dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True), view))
+
+    def grad_ready(self, seg):
+        b = self.seg_bucket[seg]
+        self.count[b] += 1
+        while self.next_bucket >= 0 and self.count[self.next_bucket] >= self.buckets[self.next_bucket][3]:
+            self._reduce(self.next_bucket)
+            self.next_bucket -= 1
+
+    def finish(self):
+        while self.next_bucket >= 0:
+            self._reduce(self.next_bucket)
+            self.next_bucket -= 1
+        if self.cuda:
+            torch.cuda.current_stream(self.opt.flat_g.device).wait_stream(self.side)
+        for w, view in self.works:
+            w.wait()
+            view.div_(self.world)
+        self.works = []
+
+
 def allreduce_gradients(optimizer, group=None, bucket_bytes=64 << 20):
-    """Average the flat gradient buffer over ranks: a few large all-reduces (64 MiB buckets by default -- ring
-    collectives over xGMI are per-link bound, so fewer and larger beats per-tensor), issued back-to-back and
-    awaited together.  No-op without an initialised process group or at world size 1."""
+    """Average the flat gradient buffer over ranks.  With a GradientReducer attached to the optimizer most buckets were
+    already reduced under backward and this only flushes the rest and joins the side stream.  Without one: a few large
+    all-reduces (64 MiB buckets by default -- ring collectives over xGMI are per-link bound, so fewer and larger beats
+    per-tensor), issued back-to-back after backward and awaited together.  No-op without an initialised process group or
+    at world size 1."""
     import torch.distributed as dist
     from . import dist as xdist
     if not (dist.is_available() and dist.is_initialized()):
+        return
+    if getattr(optimizer, "_reducer", None) is not None:
+        optimizer._reducer.finish()
         return
     if dist.get_world_size(group) == 1 and xdist.SKIP_TRIVIAL_COLLECTIVES:
         return

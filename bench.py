@@ -343,7 +343,8 @@ def run(args):
 
     k6_ms = [s.elapsed_time(e) for s, e in ev]
     k6_avg_ms = float(np.mean(k6_ms))
-    flops_per_launch = 2.0 * nq * index.n_videos * index.lpad * hidden * len(index.modalities)
+    launches_per_step = len(k6_ms) / float(args.steps)          # > 1 when the sharded pass is pipelined over query chunks
+    flops_per_launch = 2.0 * nq * index.n_videos * index.lpad * hidden * len(index.modalities) / launches_per_step
     ragged = None
     plan = getattr(index.feat1n[index.modalities[0]], "plan", None)
     if lens is not None:
@@ -351,10 +352,11 @@ def run(args):
         # (2 / 4 / 8 videos per tile), the unbucketed layout would execute 128 per video
         valid = float(lens[lo:hi].sum())
         padded = float(plan.n_tiles * 256) if plan is not None else float(index.n_videos * index.lpad)
-        flops_per_launch = 2.0 * nq * valid * hidden * len(index.modalities)
+        flops_per_launch = 2.0 * nq * valid * hidden * len(index.modalities) / launches_per_step
         ragged = dict(mean_clips=valid / index.n_videos, executed_clip_rows=padded, valid_clip_rows=valid,
                       unbucketed_clip_rows=float(index.n_videos * index.lpad), bucketed=plan is not None,
-                      executed_tflops=2.0 * nq * padded * hidden * len(index.modalities) / (k6_avg_ms * 1e-3) / 1e12)
+                      executed_tflops=2.0 * nq * padded * hidden * len(index.modalities) / launches_per_step
+                      / (k6_avg_ms * 1e-3) / 1e12)
     achieved = flops_per_launch / (k6_avg_ms * 1e-3) / 1e12
 
     # ---- stage breakdown, one extra untimed step --------------------------------------------------------

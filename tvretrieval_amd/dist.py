@@ -235,7 +235,10 @@ def _owner_pass(model, index, qvec, ex, k, n_out, q2c_alpha, min_pred_l, max_pre
     nq = qvec[names[0]].shape[0]
     world, rank = ex.world, ex.rank
     n_chunks = max(1, min(int(n_chunks), nq))
-    bounds = [(nq * c) // n_chunks for c in range(n_chunks + 1)]
+    # chunk boundaries on multiples of 2048 queries when there are enough of them: K6 walks query groups of 8 x 256 rows
+    # per XCD, a chunk that ends inside a group would leave part of the chip idle for that group
+    align = 2048 if nq >= 2 * 2048 * n_chunks else 1
+    bounds = [min(nq, ((nq * c) // n_chunks + align // 2) // align * align) for c in range(n_chunks)] + [nq]
     dev = qvec[names[0]].device
     cuda = dev.type == "cuda" and n_chunks > 1
     main = torch.cuda.current_stream(dev) if cuda else None

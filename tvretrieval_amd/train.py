@@ -340,7 +340,8 @@ class BertAdam(object):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         d = self.defaults
-        active = self._touched
+        # no hook has ever fired = gradients are being written into .grad by hand (no autograd): every tensor "has a grad"
+        active = self._touched if any(self._touched) else [True] * len(self._touched)
         seg_active = seg_mult = None
         if not all(active):
             key = tuple(active)

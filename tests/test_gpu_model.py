@@ -387,10 +387,45 @@ def test_c1_single_query_single_video_svmr():
     ws, wf = want[0, :, 2], (want[0, :, 0] * l + want[0, :, 1]).astype(np.int64)
     n = int((ws > 0).sum())
     assert n > 100 and (gf[n:] == -1).all()
-    np.testing.assert_allclose(gs[:n], ws[:n], rtol=5e-3)
-    assert (gf[:n] == wf[:n]).mean() > 0.9
+    from oracle.listcmp import tie_aware_equal
+    tie_aware_equal(gf[None, :n], gs[None, :n], wf[None, :n], ws[None, :n], n, 2e-4, "SVMR moments")
     # VCMR over a one-video corpus ranks the same spans (weight exp(20 s) is a common factor)
-    assert (out["flat_indices"].cpu().numpy()[0][:n] == gf[:n]).mean() > 0.95
+    vf_ = out["flat_indices"].cpu().numpy()[0][:n]
+    tie_aware_equal(vf_[None], out["flat_scores"].cpu().numpy()[0][None, :n] / float(out["top_scores"][0, 0]),
+                    wf[None, :n], ws[None, :n], n, 2e-4, "VCMR over one video")
+
+
+def test_short_corpus_zero_score_tail_is_dropped():
+    """The one output-shape difference at the boundary, pinned: the reference sorts the WHOLE (k, L, L) product tensor and
+    always returns max_before_nms rows (xml/inference.py:381-386); when fewer candidates pass the length mask the tail is
+    padding -- rows of score exactly 0 at masked (st, ed) positions, in an order torch.sort leaves unspecified.  The HIP
+    path returns the positive-score prefix and marks the rest flat = -1 / score 0 (the drivers drop those rows), so the
+    lists are identical up to that meaningless tail."""
+    from tvretrieval_amd import inference as inf
+    nv, nq, l = 2, 3, 16                      # 2 videos x 16 clips: at most 2 * sum_{i} min(14, 16 - i - 2) candidates
+    m, cfg = _synthetic_model("video_sub", 128, 64, 64, 64, l, torch.float32, seed=4)
+    vf, vm = _feats(nv, [16, 9], 64, 1)
+    sf, sm = _feats(nv, [16, 9], 64, 2)
+    qf, qm = _feats(nq, [5, 9, 12], 64, 3)
+    om = O.OracleXML(cfg, {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        v1, v2, s1, s2 = om.encode_context(vf, vm, sf, sm)
+        q2c, st, ed = om.get_pred_from_raw_query(qf, qm, v1, v2, vm, s1, s2, sm, cross=True)
+        want = O.vcmr_tail(q2c, st, ed, 20.0, 2, 2, 16, 200)
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))])
+        out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=2, max_before_nms=200)
+    ws, wf = want["flat_scores"].numpy(), want["flat_indices"].numpy()
+    gs, gf = out["flat_scores"].cpu().numpy(), out["flat_indices"].cpu().numpy()
+    assert ws.shape == (nq, 200) == gs.shape
+    from oracle.listcmp import moment_keys, tie_aware_equal
+    for q in range(nq):
+        n = int((ws[q] > 0).sum())
+        assert 0 < n < 200                                            # the reference's list HAS a padding tail here
+        assert (ws[q][n:] == 0).all()                                 # ... of exact zeros
+        assert (gf[q][n:] == -1).all() and (gs[q][n:] == 0).all()     # ours: marked empty
+        gk = moment_keys(gf[q:q + 1, :n], out["top_indices"].cpu().numpy()[q:q + 1], l)
+        wk = moment_keys(wf[q:q + 1, :n], want["top_indices"].numpy()[q:q + 1], l)
+        tie_aware_equal(gk, gs[q:q + 1, :n], wk, ws[q:q + 1, :n], n, 2e-4, "positive-score prefix")
 
 
 def test_hip_graph_replay_equals_eager():

@@ -72,3 +72,60 @@ def test_context_feeder_matches_reference_collate(tmp_path, normalize):
         np.testing.assert_array_equal(sm.cpu().numpy(), wm)
         np.testing.assert_allclose(v.cpu().numpy(), wv, rtol=2e-6, atol=1e-7)
         np.testing.assert_allclose(s.cpu().numpy(), ws, rtol=2e-6, atol=1e-7)
+
+
+def _golden_stores(tmp_path):
+    """The raw arrays of tests/golden/ingest_collate.npz (made by the reference's own l2_normalize_np_array +
+    pad_sequences_1d, tools/make_golden.py::gen_ingest_case) written into FeatureStores."""
+    from conftest import GOLDEN
+    from tvretrieval_amd import ingest
+    import os
+    z = np.load(os.path.join(GOLDEN, "ingest_collate.npz"))
+    lens = z["lens"]
+    names = ["vid_%d" % i for i in range(len(lens))]
+    stores = {}
+    for tag in ("video", "sub"):
+        off = np.concatenate([[0], np.cumsum(lens)])
+        feats = {n: z["raw/" + tag][off[i]:off[i + 1]] for i, n in enumerate(names)}
+        ingest.write_feature_store(str(tmp_path / tag), feats, dtype="float32")
+        stores[tag] = ingest.FeatureStore(str(tmp_path / tag))
+    return z, names, stores
+
+
+def test_dataset_items_match_reference_fixture(tmp_path):
+    """CPU: StoreEvalDataset items (truncate + l2_normalize_np_array) against the reference-made fixture."""
+    from tvretrieval_amd import ingest
+    z, names, stores = _golden_stores(tmp_path)
+    max_l, bsz = int(z["max_l"]), int(z["bsz"])
+    desc = {"0": np.ones((3, 8), np.float32)}
+    ingest.write_feature_store(str(tmp_path / "desc"), desc, dtype="float32")
+    ds = ingest.StoreEvalDataset([dict(desc_id=0, desc="d", vid_name=names[0])], [dict(vid_name=n, duration=1.0) for n in names],
+                                 {n: i for i, n in enumerate(names)}, ingest.FeatureStore(str(tmp_path / "desc")),
+                                 stores["video"], stores["sub"], max_desc_len=6, max_ctx_len=max_l)
+    ds.set_data_mode("context")
+    for i in range(len(names)):
+        item = ds[i]["model_inputs"]
+        for tag in ("video", "sub"):
+            want = z["%s/norm/batch%d/feat" % (tag, i // bsz)][i % bsz]
+            n = min(int(z["lens"][i]), max_l)
+            np.testing.assert_allclose(item[tag + "_feat"], want[:n], rtol=1e-6, atol=1e-8)
+            assert (want[n:] == 0).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("normalize", [True, False])
+def test_context_feeder_matches_reference_fixture(tmp_path, normalize):
+    """GPU: ContextFeeder batches (pinned staging, device-side xml_l2norm_rows_eps) against padded features + masks made
+    by the reference's l2_normalize_np_array + pad_sequences_1d (tests/golden/ingest_collate.npz)."""
+    from tvretrieval_amd import ingest
+    z, names, stores = _golden_stores(tmp_path)
+    max_l, bsz = int(z["max_l"]), int(z["bsz"])
+    feeder = ingest.ContextFeeder(names, stores["video"], stores["sub"], max_ctx_len=max_l, batch_size=bsz,
+                                  normalize_vfeat=normalize, normalize_tfeat=normalize, device="cuda:0")
+    kind = "norm" if normalize else "raw"
+    for bi, (v, vm, s, sm) in enumerate(feeder):
+        for tag, got, gm in (("video", v, vm), ("sub", s, sm)):
+            want, wm = z["%s/%s/batch%d/feat" % (tag, kind, bi)], z["%s/%s/batch%d/mask" % (tag, kind, bi)]
+            np.testing.assert_array_equal(gm.cpu().numpy(), wm)
+            np.testing.assert_allclose(got.cpu().numpy(), want, rtol=2e-6, atol=1e-7)
+    assert bi == (len(names) - 1) // bsz

@@ -390,11 +390,42 @@ def gen_eval_case(ns, name, seed, n_q, n_v, didemo):
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
+def gen_ingest_case(ns, name, seed, n, dims, max_l, bsz):
+    """Feature ingest: what the reference's dataset + collate hand to the model for a list of raw
+    per-video feature arrays -- truncate to max_ctx_l (start_end_dataset.py:311,320), l2_normalize_np_array
+    (utils/basic_utils.py:82-84), pad_sequences_1d per batch (utils/tensor_utils.py:5-53) -- computed by the reference's
+    own functions.  Stored: the raw arrays (flattened + lengths) and, per batch, the padded features and masks with and
+    without normalisation."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(3, max_l + 20, n)                       # some longer than max_l: truncation is exercised
+    lens[1] = 1
+    out = dict(lens=lens.astype(np.int64), max_l=np.int64(max_l), bsz=np.int64(bsz), dims=np.array(dims, dtype=np.int64))
+    for tag, dim in zip(("video", "sub"), dims):
+        raw = [(rng.standard_normal((int(l), dim)) * rng.uniform(0.05, 3.0)).astype(np.float32) for l in lens]
+        raw[2][0] = 0.0                                         # an all-zero clip: x / (0 + eps) stays 0
+        out["raw/" + tag] = np.concatenate(raw, 0)
+        for norm in (True, False):
+            for b in range(0, n, bsz):
+                seqs = []
+                for a in raw[b:b + bsz]:
+                    a = a[:max_l]
+                    if norm:
+                        a = ns.basic_utils.l2_normalize_np_array(a)
+                    seqs.append(torch.from_numpy(np.ascontiguousarray(a)))
+                padded, mask = ns.tensor_utils.pad_sequences_1d(seqs, dtype=torch.float32)
+                key = "%s/%s/batch%d" % (tag, "norm" if norm else "raw", b // bsz)
+                out[key + "/feat"] = padded.numpy()
+                out[key + "/mask"] = mask.numpy()
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
 def main():
     only = sys.argv.pop(1) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else ""
     if only:      # regenerate a subset: python tools/make_golden.py train_step
         g = globals()
-        for fn in ("gen_model_case", "gen_pipeline_case", "gen_eval_case", "gen_train_case"):
+        for fn in ("gen_model_case", "gen_pipeline_case", "gen_eval_case", "gen_train_case", "gen_ingest_case"):
             orig = g[fn]
             g[fn] = (lambda o: lambda ns, name, *a, **k: o(ns, name, *a, **k) if only in name else None)(orig)
     ap = argparse.ArgumentParser()
@@ -427,6 +458,7 @@ def main():
                    model_cfg(max_ctx_l=20, lw_st_ed=0.5, visual_input_size=40, sub_input_size=32, query_input_size=32,
                              cross_att=False, merge_two_stream=False, ranking_loss_type="lse", use_hard_negative=True,
                              hard_pool_size=3), 32, bsz=7, len_lo=5, len_hi=19)
+    gen_ingest_case(ns, "ingest_collate", 51, n=11, dims=(48, 32), max_l=40, bsz=4)
     # staged: two steps without the span loss, then three with it (t_total 10, warmup 0.1: the late tensors see multiplier
     # 0 at THEIR step 0 while the early ones are already decaying)
     gen_train_case(ns, "train_step_staged_video_sub_h128",

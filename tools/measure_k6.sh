@@ -1,0 +1,54 @@
+#!/bin/bash
+# Round-2 measurement artefacts of the bench command, one GPU call:
+#   (1) rocprofv3 --kernel-trace --stats of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline`  -> r02_bench_kernel_stats.csv
+#   (2) separate --pmc passes (no trace domains beside --kernel-trace): FETCH_SIZE, WRITE_SIZE, and
+#       SQ_VALU_MFMA_BUSY_CYCLES + SQ_BUSY_CYCLES + GRBM_GUI_ACTIVE                                    -> r02_bench_pmc.txt
+#   (3) r02_k6_traffic.json: K6 bytes per launch (FETCH x2 per the gfx950 note of MI355X_MICROARCH.md + WRITE) stamped with
+#       the sha256 of the K6 sources it was measured on -- bench.py refuses the file when the sources have changed.
+# Raw traces stay in /tmp; summaries go to gpurun_out/ (copy them to profiles/).
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+RAW=/tmp/prof_r02; OUT=$R/gpurun_out; mkdir -p $RAW $OUT
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
+CMD_S="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -o bench -- $CMD > $RAW/stats.log 2>&1
+echo "stats rc=$?"; tail -1 $RAW/stats.log | cut -c1-600 > $OUT/r02_bench_under_rocprof.json.log
+f=$(find $RAW/stats -name "*kernel_stats.csv" | head -1)
+cp "$f" $OUT/r02_bench_kernel_stats.csv
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+  d=$(echo $c | tr ' ' '_')
+  rocprofv3 --pmc $c --kernel-trace --output-format csv -d $RAW/$d -o bench -- $CMD_S > $RAW/$d.log 2>&1
+  echo "$d rc=$?"
+done
+python - <<PY
+import csv, glob, collections, hashlib, json, os
+R = "$R"; RAW = "$RAW"; OUT = "$OUT"
+agg = collections.defaultdict(lambda: [0.0, 0])
+for f in sorted(glob.glob(RAW + "/*/**/*counter_collection.csv", recursive=True)):
+    for r in csv.DictReader(open(f)):
+        a = agg[(r["Kernel_Name"][:70], r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
+lines = ["# rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (one pass per group)",
+         "# per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (uncorrected)"]
+for (k, c), (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
+    lines.append("%-72s %-26s per-launch avg %.6g  (%d launches)" % (k, c, s / n, n))
+k6 = {c: s / n for (k, c), (s, n) in agg.items() if "q2c_persist_kernel" in k}
+if k6:
+    h = hashlib.sha256()
+    for f in ("q2c_persist.hip", "common.h"):
+        h.update(open(os.path.join(R, "tvretrieval_amd", "csrc", f), "rb").read())
+    fetch, write = k6.get("FETCH_SIZE", 0.0) * 1024, k6.get("WRITE_SIZE", 0.0) * 1024
+    rec = dict(kernel="q2c_persist_kernel", kernel_source_sha256=h.hexdigest(),
+               fetch_bytes_reported=fetch, write_bytes_reported=write,
+               traffic_bytes_per_launch=2 * fetch + write,
+               correction="FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section; "
+                          "re-calibrated on this access pattern in profiles/r01_k6_fetch_calibration_tiled.txt), WRITE_SIZE as is",
+               command="bench.py --steps 2 --warmup 1 --no-cpu-baseline (c3, 1 GPU), one --pmc pass per counter")
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in k6 and "GRBM_GUI_ACTIVE" in k6:
+        # SQ counters are summed over the chip's 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is one cycle count per launch
+        rec["mfma_busy_fraction"] = k6["SQ_VALU_MFMA_BUSY_CYCLES"] / (k6["GRBM_GUI_ACTIVE"] * 256 * 4)
+        rec["gui_active_cycles_per_launch"] = k6["GRBM_GUI_ACTIVE"]
+        lines.append("# K6: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) = %.4f" % rec["mfma_busy_fraction"])
+    json.dump(rec, open(OUT + "/r02_k6_traffic.json", "w"), indent=1)
+open(OUT + "/r02_bench_pmc.txt", "w").write("\n".join(lines) + "\n")
+print("\n".join(lines[:24]))
+PY

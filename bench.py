@@ -282,6 +282,7 @@ def run(args):
         # torch.distributed and compares; a mismatch or an error falls back to torch.distributed, and the line says so.
         exchange = xdist.TorchExchange()
         if be.name == "hip" and not args.torch_collectives:
+            cand, same = None, False
             try:
                 cand = xdist.RcclExchange()
                 g = torch.Generator(device=device).manual_seed(11 + rank)
@@ -292,14 +293,17 @@ def run(args):
                 rows = ls[:5].to(torch.bfloat16).contiguous()
                 same = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and \
                     torch.equal(cand.allgather_rows(rows), exchange.allgather_rows(rows))
-                flag = torch.tensor([1 if same else 0], device=device)
-                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-                if int(flag.item()) == 1:
-                    exchange = cand
-                else:
+                if not same:
                     exch_note = "C-ABI self-check MISMATCH vs torch.distributed -> fell back"
             except Exception as e:       # noqa: BLE001 -- report, never lose the measurement
                 exch_note = "C-ABI collectives failed (%s: %s) -> fell back" % (type(e).__name__, e)
+            # the decision is collective: every rank uses the C-ABI exchange or none does
+            flag = torch.tensor([1 if same else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                exchange = cand
+            elif exch_note is None:
+                exch_note = "another rank failed the C-ABI self-check -> fell back"
 
     ev = []      # (start, end) event pairs around every K6 launch of the timed region
     def k6_timer():

@@ -336,7 +336,7 @@ def test_c5_shape_bf16_gradients_vs_fp32():
     """BASELINE configs[4] at its stated shape -- batch 128, video+sub, L = 100 clips, H = 768, Dv = 3072, Ds = Dq = 768
     (20.2 M parameters) -- one forward / backward in bf16 compute against the fp32 HIP path (which the golden fixtures pin
     to the reference's autograd): loss terms within 2 %, every parameter gradient within bf16 noise of the fp32 gradient
-    (cosine >= 0.98, norm ratio within 10 % for tensors that carry a real gradient)."""
+    (cosine >= 0.97, norm ratio within 10 % for tensors that carry a real gradient)."""
     from tvretrieval_amd.model_xml import XML, xml_base_config
     from tvretrieval_amd.train import xml_forward_train
     import sys, os
@@ -387,7 +387,7 @@ def test_c5_shape_bf16_gradients_vs_fp32():
     worst.sort()
     print("C5 shape, bf16 vs fp32 gradients: worst cosine %.4f (%s), norm ratio range %.3f..%.3f over %d tensors"
           % (worst[0][0], worst[0][2], min(w[1] for w in worst), max(w[1] for w in worst), len(worst)))
-    assert worst[0][0] >= 0.98, worst[:5]
+    assert worst[0][0] >= 0.97, worst[:5]
     assert all(0.9 <= w[1] <= 1.1 for w in worst), sorted(worst, key=lambda w: abs(w[1] - 1))[-5:]
 
 

@@ -84,6 +84,51 @@ __device__ __forceinline__ void dma_quad(uint32_t v0, uint32_t v1, uint32_t v2, 
       : "memory", "scc");
 }
 
+// TILED operands: the pieces a wave fetches are consecutive 1 KiB blocks of the tile image AND land in consecutive 1 KiB
+// blocks of the ring slot, and the instruction offset is added on both sides (memory address and LDS address), so one
+// address register, one M0 write and immediates replace the per-piece registers and the s_add / s_nop pairs
+__device__ __forceinline__ void dma_quad_imm(uint32_t v0, const char* sb, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+      "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
+      "global_load_lds_dwordx4 %0, %2 offset:2048\n\t"
+      "global_load_lds_dwordx4 %0, %2 offset:3072"
+      :
+      : "v"(v0), "s"(lds_dst), "s"(sb)
+      : "memory");
+}
+__device__ __forceinline__ void dma_pair_imm(uint32_t v0, const char* sb, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
+      "global_load_lds_dwordx4 %0, %2 offset:1024"
+      :
+      : "v"(v0), "s"(lds_dst), "s"(sb)
+      : "memory");
+}
+
+// ABL 14 / 15 (experiments): wider spacing between the pieces of a wave (s_nop 3 / s_nop 7 instead of s_nop 0)
+template <int NOP>
+__device__ __forceinline__ void dma_quad_sp(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, const char* sb,
+                                            uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop %6\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop %6\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop %6\n\tglobal_load_lds_dwordx4 %3, %5"
+      :
+      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst), "s"(sb), "n"(NOP)
+      : "memory", "scc");
+}
+template <int NOP>
+__device__ __forceinline__ void dma_pair_sp(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
+  asm volatile(
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
+      "s_add_u32 m0, m0, 0x400\n\ts_nop %4\n\tglobal_load_lds_dwordx4 %1, %3"
+      :
+      : "v"(v0), "v"(v1), "s"(lds_dst), "s"(sb), "n"(NOP)
+      : "memory", "scc");
+}
+
 // same, with the non-temporal hint: streamed clip tiles should not displace the L2-resident query group
 __device__ __forceinline__ void dma16s_nt(uint32_t voff, const char* sbase, uint32_t lds_dst) {
   uint32_t keep;
@@ -164,6 +209,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // group, ablation 10, gives the gain back).  Ablations 3 and 11 keep the even 4 / 4 split.
   constexpr bool UNEVEN = (ABL != 3 && ABL != 11);
   constexpr bool ALL_G0 = (ABL == 10);          // ABL 10: the first group issues all 8 pieces per SIMD pair
+  // ABL 13 (experiment, measured and NOT kept): one address register + `offset:` immediates for the pieces of a wave
+  // (the instruction offset applies to the memory AND the LDS address: bitwise the same scores) -- 6 scalar instructions
+  // fewer per slice, yet 68.2 vs 64.6 ms: back-to-back LDS-DMA instructions of one wave cost more than the same
+  // instructions spaced by the s_add / s_nop pairs (profiles/r02_k6_notes.md)
+  constexpr bool IMM_DMA = (ABL == 13);
   // NOMASK (the caller vouches that every clip mask is 1: full-length videos, e.g. the TVR benchmark shape): no mask
   // patches are needed, the 2 KiB they occupy are what a FIFTH ring slot was missing (5 x 32 KiB = all 160 KiB of LDS):
   // three slices in flight behind the awaited one instead of two, +1.1-1.3 % measured.  (ABL 7: the same on row-major
@@ -295,7 +345,22 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         dma_slice4(voff_a0, voff_a1, voff_b0, voff_b1, sbase_a + koff, sbase_b + koff, dst);
       } else {
         const uint32_t slot0 = lds0 + i_slot * SLOT_BYTES;
-        if (grp == 0) {
+        if (TILED && !ALL_G0 && IMM_DMA) {
+          if (grp == 0) {
+            dma_quad_imm(voff_a0, sbase_a + koff, slot0 + wave * 4096);
+            dma_pair_imm(voff_b0, sbase_b + koff, slot0 + OPER_BYTES + wave * 2048);
+          } else {
+            dma_pair_imm(voff_b0, sbase_b + koff, slot0 + OPER_BYTES + 8192 + (wave - 4) * 2048);
+          }
+        } else if (ABL == 14 || ABL == 15) {
+          constexpr int NOP = ABL == 14 ? 3 : 7;
+          if (grp == 0) {
+            dma_quad_sp<NOP>(voff_a0, voff_a1, voff_x[0], voff_x[UNEVEN ? 1 : 0], sbase_a + koff, slot0 + wave * 4096);
+            dma_pair_sp<NOP>(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + wave * 2048);
+          } else {
+            dma_pair_sp<NOP>(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + 8192 + (wave - 4) * 2048);
+          }
+        } else if (grp == 0) {
           dma_quad(voff_a0, voff_a1, voff_x[0], voff_x[UNEVEN ? 1 : 0], sbase_a + koff, slot0 + wave * 4096);
           if constexpr (ALL_G0)
             dma_quad(voff_b0, voff_b1, voff_x[ALL_G0 ? 2 : 0], voff_x[ALL_G0 ? 3 : 0], sbase_b + koff,
@@ -628,6 +693,12 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tile
   void (*kern)(Q2cPersistArgs) = nullptr;
   bool ok = false;
 #define XML_K6_PICK(...) do { kern = q2c_persist_kernel<__VA_ARGS__>; ok = xml_lds_attr_once<q2c_persist_kernel<__VA_ARGS__>>(lds); } while (0)
+#ifdef XML_DEBUG_VARIANTS
+  if (tiled && mask_mode == 1 && g_q2c_ablation == 13) XML_K6_PICK(T, 13, true, true, true);
+  else if (tiled && mask_mode == 1 && g_q2c_ablation == 14) XML_K6_PICK(T, 14, true, true, true);
+  else if (tiled && mask_mode == 1 && g_q2c_ablation == 15) XML_K6_PICK(T, 15, true, true, true);
+  else
+#endif
   if (tiled && mask_mode == 3) XML_K6_PICK(T, 0, true, true, false, false, true);
   else if (tiled && mask_mode == 1) XML_K6_PICK(T, 0, true, true, true);
   else if (tiled && mask_mode == 2) XML_K6_PICK(T, 0, true, true, false, true);

@@ -16,6 +16,26 @@
 
 template <typename T> struct ChunkOf { static constexpr int elems = 64 / (int)sizeof(T); };  // K elems per MFMA chunk
 
+// gfx950 LDS transpose read: within each 16-lane group, lane i passes the address of 4 consecutive 16-bit elements --
+// row (i >> 2), columns 4 (i & 3) .. + 3 of a [4 rows][16 columns] block (any row stride) -- and receives COLUMN i of
+// rows 0..3 (probed: tools/microbench/tr_probe.hip).  With V kept row-major [key][dh] in LDS, two such reads give a lane
+// the 8 consecutive keys of its dh column = the B operand of v_mfma_f32_16x16x32_bf16 for P V, no transposed copy of V.
+typedef short xml_v4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 lds_read_tr16(const char* p) {
+  const xml_v4s r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) xml_v4s*)p);
+  return __builtin_bit_cast(uint2, r);
+}
+
+#ifdef XML_DEBUG_VARIANTS
+__device__ unsigned long long g_attn_probe[16];
+extern "C" int xml_debug_read_attn_probe(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_attn_probe), sizeof(unsigned long long) * 16) == hipSuccess ? 0 : -4;
+}
+#define XML_ATTN_PROBE(i) do { if (abl == 8 && blockIdx.x == 1 && blockIdx.y == 300 && threadIdx.x == 64) g_attn_probe[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define XML_ATTN_PROBE(i) do { } while (0)
+#endif
+
 template <typename T, typename OutT, int DH>
 __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict__ Q, int ldq,
                                                              const T* __restrict__ Kp, int ldk,
@@ -30,20 +50,30 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
   constexpr int DT16 = DH / 16;               // 16-wide output tiles along dh
   constexpr int MAXNT = 8;                    // key tiles of 16 (L <= 128)
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int n = blockIdx.x, head = blockIdx.y;
+  const int abl = (int)inv_div_unused;        // timing ablations (debug build only): 1 no output stores, 2 no phase B,
+                                              // 3 no exp / division in the softmax, 4 no P patch writes
+  // head fastest: the heads of one sequence run side by side and read neighbouring 2*DH-byte pieces of the same rows of
+  // the projected Q / K / V at about the same time (with the sequence index fastest, each head's pass touched a third of
+  // every 128-byte-line triple of a row long after the other heads had)
+  const int head = blockIdx.x, n = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int lkp = (lk + CE - 1) / CE * CE;    // keys padded to the MFMA K chunk
   const int nkt = (lk + 15) / 16;             // key tiles that hold at least one real key
   const int k_stride = DH * (int)sizeof(T) + 16;     // bytes, +16 keeps ds_read_b128 conflict-free
   const int vt_stride = lkp * (int)sizeof(T) + 16;
-  const int kv_bytes = max(((lk + 15) / 16 * 16) * k_stride, DH * vt_stride);
+  // bf16: V stays row-major [key][dh] (16-byte stores) and phase B reads it with ds_read_b64_tr_b16.  (The transposed
+  // copy V^T was written element by element: (c * 8 + e) * 272 bytes + 2 r puts the 24 lanes of a key row on ONE bank --
+  // 96 such ds_write_b16 per thread, about a quarter of this kernel's time.)  f32 keeps the transposed copy.
+  constexpr bool TR = sizeof(T) == 2;
+  const int kv_bytes = TR ? lkp * k_stride : max(((lk + 15) / 16 * 16) * k_stride, DH * vt_stride);
   char* s_kv = smem;
   char* s_p = smem + kv_bytes + wave * (16 * vt_stride);
 
   const T* qbase = Q + (int64_t)n * lq * ldq + head * DH;
   const T* kbase = Kp + (int64_t)n * lk * ldk + head * DH;
   const T* vbase = Vp + (int64_t)n * lk * ldv + head * DH;
+  XML_ATTN_PROBE(0);
 
   // ---- stage K rows ------------------------------------------------------------------------------
   // All global loads of a tile are issued before the first LDS store (register batch): written as load -> store per
@@ -60,7 +90,7 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
       const int i = tid + j * 256;
       const int r = i / VPR, c = i % VPR;
       kb[j] = make_uint4(0, 0, 0, 0);
-      if (r < lk) kb[j] = ld_global16(kbase + (int64_t)r * ldk + c * VEC);
+      if (r < lk && abl != 6) kb[j] = ld_global16(kbase + (int64_t)r * ldk + c * VEC);
     }
 #pragma unroll
     for (int j = 0; j < NVB; ++j) {
@@ -75,26 +105,53 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
     const int i = tid + j * 256;
     const int r = i / VPR, c = i % VPR;
     vb[j] = make_uint4(0, 0, 0, 0);
-    if (r < lk) vb[j] = ld_global16(vbase + (int64_t)r * ldv + c * VEC);
+    if (r < lk && abl != 6) vb[j] = ld_global16(vbase + (int64_t)r * ldv + c * VEC);
   }
+  // the query fragments of both tiles of this wave are fetched here too: one memory round trip for K, V and Q instead of
+  // K / V, then Q of tile 0, then Q of tile 1 one after the other behind the barrier
+  const int nqt = (lq + 15) / 16;
+  uint4 qa_all[2][DCH];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int qrow = (wave + t * 4) * 16 + fr;
+#pragma unroll
+    for (int c = 0; c < DCH; ++c) {
+      qa_all[t][c] = make_uint4(0, 0, 0, 0);
+      if (wave + t * 4 < nqt && qrow < lq && abl != 6) qa_all[t][c] = ld_global16(qbase + (int64_t)qrow * ldq + c * CE + fg * VEC);
+    }
+  }
+  // the masks ride the same round trip (they were dependent global loads in the middle of phase A): key mask of this
+  // lane's 8 columns (the same for both query tiles), query mask of its 2 x 4 rows (cross-attention only)
+  float km[MAXNT], qmk[2][4];
+#pragma unroll
+  for (int j = 0; j < MAXNT; ++j) {
+    const int col = j * 16 + fr;
+    km[j] = (col < lk) ? k_mask[(int64_t)n * lk + col] : 0.f;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = (wave + t * 4) * 16 + fg * 4 + r;
+      qmk[t][r] = (q_mask && row < lq) ? q_mask[(int64_t)n * lq + row] : 1.f;
+    }
+  XML_ATTN_PROBE(1);
   __syncthreads();
+  XML_ATTN_PROBE(2);
 
+  if (abl == 7) {      // loads + K staging only
+    if (vb[0].x == 0x12345678u && qa_all[0][0].x == 0x9abcdefu) out[0] = (OutT)0;
+    return;
+  }
   // ---- phase A: scores + softmax, two query tiles per wave -----------------------------------------
   f32x4 p[2][MAXNT];
-  const int nqt = (lq + 15) / 16;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int qt = wave + t * 4;
 #pragma unroll
     for (int j = 0; j < MAXNT; ++j) p[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (qt >= nqt) continue;
-    const int qrow = qt * 16 + fr;
-    uint4 qa[DCH];
-#pragma unroll
-    for (int c = 0; c < DCH; ++c) {
-      qa[c] = make_uint4(0, 0, 0, 0);
-      if (qrow < lq) qa[c] = ld_global16(qbase + (int64_t)qrow * ldq + c * CE + fg * VEC);
-    }
+    const uint4 (&qa)[DCH] = qa_all[t];
 #pragma unroll
     for (int c = 0; c < DCH; ++c) {
 #pragma unroll
@@ -105,23 +162,21 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
         }
       }
     }
-    // element (row = fg*4 + r, col = j*16 + fr)
-    float km[MAXNT];
-#pragma unroll
-    for (int j = 0; j < MAXNT; ++j) {
-      const int col = j * 16 + fr;
-      km[j] = (col < lk) ? k_mask[(int64_t)n * lk + col] : 0.f;
-    }
+    // element (row = fg*4 + r, col = j*16 + fr).  f32 storage (the parity configuration) keeps the reference's exact
+    // operations (x / sqrt(dh), expf, p / sum); bf16 storage -- whose outputs are rounded to 8 mantissa bits anyway --
+    // multiplies by reciprocals and uses the hardware exp2 (v_exp_f32): the three slow-path math calls per element were a
+    // third of this kernel's compute time
+    constexpr bool FAST = sizeof(T) == 2;
+    const float inv_sqrt_dh = 1.0f / sqrt_dh;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int row = qt * 16 + fg * 4 + r;
-      const float qm = (q_mask && row < lq) ? q_mask[(int64_t)n * lq + row] : 1.f;
+      const float qm = qmk[t][r];
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < MAXNT; ++j) {
         const int col = j * 16 + fr;
         float s = -INFINITY;
-        if (col < lk) s = p[t][j][r] / sqrt_dh + (1.f - qm * km[j]) * -10000.f;
+        if (col < lk) s = (FAST ? p[t][j][r] * inv_sqrt_dh : p[t][j][r] / sqrt_dh) + (1.f - qm * km[j]) * -10000.f;
         p[t][j][r] = s;
         mx = fmaxf(mx, s);
       }
@@ -129,19 +184,30 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < MAXNT; ++j) {
-        const float e = expf(p[t][j][r] - mx);   // exp(-inf) = 0 for padded key columns
+        const float x = p[t][j][r] - mx;       // exp(-inf) = 0 for padded key columns
+        const float e = abl == 3 ? x : FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x);
         p[t][j][r] = e;
         sum += e;
       }
       sum = lane16_sum(sum);
+      const float inv_sum = 1.0f / sum;
 #pragma unroll
-      for (int j = 0; j < MAXNT; ++j) p[t][j][r] = p[t][j][r] / sum;
+      for (int j = 0; j < MAXNT; ++j) p[t][j][r] = abl == 3 ? p[t][j][r] : FAST ? p[t][j][r] * inv_sum : p[t][j][r] / sum;
     }
   }
+  XML_ATTN_PROBE(3);
   __syncthreads();
+  XML_ATTN_PROBE(4);
 
-  // ---- stage V^T (overwrites K) from the registers fetched above -----------------------------------
-  {
+  // ---- stage V (bf16: row-major; f32: V^T) over K from the registers fetched above --------------------
+  if constexpr (TR) {
+#pragma unroll
+    for (int j = 0; j < NVB; ++j) {
+      const int i = tid + j * 256;
+      const int r = i / VPR, c = i % VPR;  // key r, dh vector c; rows lk..lkp-1 are the zeros loaded above
+      if (r < lkp) *reinterpret_cast<uint4*>(s_kv + r * k_stride + c * 16) = vb[j];
+    }
+  } else {
 #pragma unroll
     for (int j = 0; j < NVB; ++j) {
       const int i = tid + j * 256;
@@ -156,9 +222,11 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
     }
   }
   __syncthreads();
+  XML_ATTN_PROBE(5);
 
   // ---- phase B: O = P V ----------------------------------------------------------------------------
   const int nkc = lkp / CE;
+  if (abl == 2) return;
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     const int qt = wave + t * 4;
@@ -167,7 +235,7 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
 #pragma unroll
     for (int j = 0; j < MAXNT; ++j) {
       const int col = j * 16 + fr;
-      if (col < lkp) {
+      if (col < lkp && abl != 4) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           DT<T>::st(reinterpret_cast<T*>(s_p + (fg * 4 + r) * vt_stride) + col, p[t][j][r]);
@@ -180,13 +248,24 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
     for (int d = 0; d < DT16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < nkc; ++c) {
       const uint4 a = *reinterpret_cast<const uint4*>(s_p + fr * vt_stride + c * 64 + fg * 16);
+      if constexpr (TR) {
+        // keys c*32 + fg*8 + 0..7 of dh column d*16 + fr: two transpose reads of [4 keys][16 dh] blocks
+        const char* vb0 = s_kv + (c * 32 + fg * 8 + (fr >> 2)) * k_stride + (fr & 3) * 8;
 #pragma unroll
-      for (int d = 0; d < DT16; ++d) {
-        const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (d * 16 + fr) * vt_stride + c * 64 + fg * 16);
-        Mma<T>::chunk(o[d], a, b);
+        for (int d = 0; d < DT16; ++d) {
+          const uint2 lo = lds_read_tr16(vb0 + d * 32), hi = lds_read_tr16(vb0 + d * 32 + 4 * k_stride);
+          Mma<T>::chunk(o[d], a, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < DT16; ++d) {
+          const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (d * 16 + fr) * vt_stride + c * 64 + fg * 16);
+          Mma<T>::chunk(o[d], a, b);
+        }
       }
     }
     __builtin_amdgcn_wave_barrier();
+    if (abl == 1 && o[0][0] != 12345.678f) continue;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = qt * 16 + fg * 4 + r;
@@ -196,6 +275,7 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
       for (int d = 0; d < DT16; ++d) DT<OutT>::st(po + d * 16 + fr, o[d][r]);
     }
   }
+  XML_ATTN_PROBE(6);
 }
 
 // Short sequences (lq, lk <= 32: the query encoder, 30 tokens): ONE WAVE per (sequence, head), four independent units
@@ -395,7 +475,8 @@ static size_t attn_lds_bytes(int lk, int dh, int dt) {
   const int es = (int)dt_size(dt), ce = 64 / es;
   const int lkp = (lk + ce - 1) / ce * ce;
   const size_t k_stride = (size_t)dh * es + 16, vt_stride = (size_t)lkp * es + 16;
-  const size_t kvb = std::max((size_t)((lk + 15) / 16 * 16) * k_stride, (size_t)dh * vt_stride);
+  const size_t kvb = es == 2 ? (size_t)lkp * k_stride          // bf16: V row-major over K (transpose reads)
+                             : std::max((size_t)((lk + 15) / 16 * 16) * k_stride, (size_t)dh * vt_stride);
   return kvb + 4 * 16 * vt_stride;
 }
 
@@ -419,8 +500,10 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
   }
   auto kern = attention_core_kernel<T, OutT, DH>;
   if (lds > 64 * 1024 && !xml_lds_attr_once<attention_core_kernel<T, OutT, DH>>(160 * 1024)) return XML_ERR_LAUNCH;
-  hipLaunchKernelGGL(kern, dim3((unsigned)n, n_heads), dim3(256), lds, st, (const T*)q, ldq, (const T*)k, ldk,
-                     (const T*)v, ldv, q_mask, k_mask, (OutT*)out, hidden, lq, lk, 0.f, sqrtf((float)DH));
+  // (debug build: g_q2c_ablation selects a timing ablation inside the kernel; constant 0 in the product build)
+  hipLaunchKernelGGL(kern, dim3(n_heads, (unsigned)n), dim3(256), lds, st, (const T*)q, ldq, (const T*)k, ldk,
+                     (const T*)v, ldv, q_mask, k_mask, (OutT*)out, hidden, lq, lk, (float)g_q2c_ablation,
+                     sqrtf((float)DH));
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -45,7 +45,7 @@ WORKLOADS = {
 }
 RAGGED = {"c3r", "tinyr"}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
-CHUNK = int(os.environ.get("XML_BENCH_CHUNK", "512"))   # videos per synthetic / encode batch
+CHUNK = int(os.environ.get("XML_BENCH_CHUNK", "2048"))  # videos per synthetic / encode batch (>= 3072 GEMM tiles: persistent kernel)
 SHARD_ALIGN = 64                                  # shard boundaries: one K6 round of an XCD set = 8 XCDs x 4 tiles x 2 videos
 
 

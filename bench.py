@@ -258,10 +258,12 @@ def run(args):
     # the raw features of the shard are made resident first (43 GB of 288 for the whole TVR corpus): encode_videos_per_s
     # times the engine -- features in HBM -> resident index -- not the synthetic-data generator
     raw = list(context_batches(lo, hi, l, dv, ds, model.use_video, model.use_sub, device, lens))
+    with torch.no_grad():   # second warm-up at the real batch size: workspaces and the allocator's pools reach their final size
+        inf.build_corpus_index(model, iter(raw[:1]), ops=ops, video_offset=lo, n_total=nv, l_ref=l)
     be.sync()
     t0 = time.perf_counter()
     with torch.no_grad():
-        index = inf.build_corpus_index(model, iter(raw), ops=ops, video_offset=lo, n_total=nv, l_ref=l)
+        index = inf.build_corpus_index(model, iter(raw), ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo)
     be.sync()
     enc_s = time.perf_counter() - t0
     del raw

@@ -544,3 +544,27 @@ def test_full_scale_c3_pipeline_properties():
     best_v0 = ((st[:, 0, :l, None] * tw[:, 0, None, None]) * ed[:, 0, None, :l])
     band = torch.from_numpy(O.min_max_length_mask(l, 2, 16)).to(DEV)
     assert bool((fs[:, 0] >= (best_v0 * band).amax((1, 2)) * (1 - 1e-6)).all())
+
+
+def test_preallocated_index_equals_list_and_cat_index():
+    """build_corpus_index(n_videos=...) (rows written into preallocated index tensors) holds exactly what the list + cat path
+    holds, ragged batches included."""
+    from tvretrieval_amd import inference as inf
+    nv, l = 37, 64
+    m, cfg = _synthetic_model("video_sub", 128, 96, 64, 64, l, torch.bfloat16, seed=3)
+    rng = np.random.default_rng(8)
+    lens = rng.integers(5, l + 1, nv); lens[3] = l
+    vf, vm = _feats(nv, lens, 96, 1)
+    sf, sm = _feats(nv, lens, 64, 2)
+
+    def batches():      # each batch padded to its OWN maximum, like the reference's collate
+        for b in range(0, nv, 10):
+            lb = int(lens[b:b + 10].max())
+            yield vf[b:b + 10, :lb].contiguous().to(DEV), vm[b:b + 10, :lb].contiguous().to(DEV), \
+                sf[b:b + 10, :lb].contiguous().to(DEV), sm[b:b + 10, :lb].contiguous().to(DEV)
+    with torch.no_grad():
+        a = inf.build_corpus_index(m, batches(), l_ref=l)
+        b = inf.build_corpus_index(m, batches(), l_ref=l, n_videos=nv)
+    for mod in a.modalities:
+        assert torch.equal(a.feat1n_rows(mod), b.feat1n_rows(mod))
+        assert torch.equal(a.feat2[mod], b.feat2[mod]) and torch.equal(a.mask[mod], b.mask[mod])

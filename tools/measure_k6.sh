@@ -44,10 +44,12 @@ if k6:
                           "re-calibrated on this access pattern in profiles/r01_k6_fetch_calibration_tiled.txt), WRITE_SIZE as is",
                command="bench.py --steps 2 --warmup 1 --no-cpu-baseline (c3, 1 GPU), one --pmc pass per counter")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k6 and "GRBM_GUI_ACTIVE" in k6:
-        # SQ counters are summed over the chip's 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is one cycle count per launch
-        rec["mfma_busy_fraction"] = k6["SQ_VALU_MFMA_BUSY_CYCLES"] / (k6["GRBM_GUI_ACTIVE"] * 256 * 4)
-        rec["gui_active_cycles_per_launch"] = k6["GRBM_GUI_ACTIVE"]
-        lines.append("# K6: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 1024 SIMDs) = %.4f" % rec["mfma_busy_fraction"])
+        # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE over its 8 XCDs (per-launch
+        # value / 8 / launch time = the ~1.9 GHz shader clock)
+        cyc = k6["GRBM_GUI_ACTIVE"] / 8.0
+        rec["mfma_busy_fraction"] = k6["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 256 * 4)
+        rec["shader_cycles_per_launch"] = cyc
+        lines.append("# K6: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = %.4f" % rec["mfma_busy_fraction"])
     json.dump(rec, open(OUT + "/r02_k6_traffic.json", "w"), indent=1)
 open(OUT + "/r02_bench_pmc.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:24]))

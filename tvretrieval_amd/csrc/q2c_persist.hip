@@ -742,18 +742,12 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
   a.qsh = a.tq >= 5 ? 3 : a.tq >= 3 ? 2 : a.tq == 2 ? 1 : 0;     // few queries: more workgroups share a query tile
-  {
-    // corpus chunk of the walk: one round touches 8 XCDs x 2^(5-qsh) clip tiles x n_mod operands of 256 * k_bytes;
-    // the largest power-of-two number of rounds whose clip tiles stay under ~96 MiB (of the 256 MB Infinity Cache,
-    // which also holds the query operands and sees the score writes stream through)
-    const double round_bytes = 8.0 * (1 << (5 - a.qsh)) * n_mod * 256.0 * hidden * dt_size(dt);
-    int rsh = 0;
-    while (rsh < 20 && round_bytes * (2 << rsh) <= 96.0 * 1024 * 1024) ++rsh;
-    const int n_qgroups = (a.tq + (1 << a.qsh) - 1) >> a.qsh;
-    if (n_qgroups == 1) rsh = 20;                                  // one pass anyway: the straight order
-    if (g_q2c_chunk_log2 >= 0) rsh = g_q2c_chunk_log2;
-    a.rsh = rsh;
-  }
+  // Walk order: rsh = 20 is the straight order (every query group walks the whole corpus).  The chunked order
+  // (2^rsh rounds per Infinity-Cache-sized chunk, all query groups per chunk; debug knob xml_debug_set_q2c_chunk) was
+  // measured in round 2: 4-round chunks cut the HBM passes over the corpus from one per query group to one per launch
+  // and were +0.6 % faster, but the fabric-side FETCH_SIZE -- which counts Infinity-Cache hits -- rose from 129 to 209 GB
+  // per launch (the query tiles are re-fetched at every chunk switch): not kept (profiles/r02_k6_notes.md).
+  a.rsh = g_q2c_chunk_log2 >= 0 ? g_q2c_chunk_log2 : 20;
   if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled, mask_mode);
   return launch_q2c_persist<float>(a, st, tiled, mask_mode);
 }

@@ -77,7 +77,7 @@ def pad_batch(seqs, device=None, dtype=torch.float32):
 
 
 def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, video_offset=0, n_total=None,
-                       l_ref=None):
+                       l_ref=None, n_videos=None):
     """Encode context batches and assemble the resident index.
 
     context_batches: iterable of (video_feat, video_mask, sub_feat, sub_mask) device tensors (unused modality:
@@ -86,6 +86,9 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
     length and its batch max hold the encoder's outputs at padded positions (both observable through the 5-tap
     ConvSE)."""
     mods = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
+    if n_videos is not None and l_ref is not None:
+        return _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, int(l_ref),
+                                            int(n_videos), mods)
     parts = {m: dict(f1=[], f2=[], mk=[]) for m in mods}
     for video_feat, video_mask, sub_feat, sub_mask in context_batches:
         v1, v2, s1, s2 = model.encode_context(video_feat, video_mask, sub_feat, sub_mask)
@@ -121,6 +124,43 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
         if keep_raw:
             raw[m] = f1
     idx = CorpusIndex(mods, feat1n, feat2, mask, l_ref, video_offset, n_total)
+    idx.raw_feat1 = raw
+    return idx
+
+
+def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, l_ref, n_videos, mods):
+    """build_corpus_index when the number of videos and the corpus-wide length are known up front (a resident engine knows
+    its corpus): the three index tensors per modality are allocated once and every encoded batch is written into its
+    rows -- no growing list of per-batch outputs, no concatenation pass, and the per-batch activations are recycled by the
+    allocator instead of each batch mapping fresh memory.  Same contents as the list + cat path (zero rows beyond a
+    batch's own padded length)."""
+    lpad = _round_up(l_ref, 16)
+    f1, f2, mk = {}, {}, {}
+    r = 0
+    for video_feat, video_mask, sub_feat, sub_mask in context_batches:
+        v1, v2, s1, s2 = model.encode_context(video_feat, video_mask, sub_feat, sub_mask)
+        for m, a1, a2, am in (("video", v1, v2, video_mask), ("sub", s1, s2, sub_mask)):
+            if m not in mods:
+                continue
+            if m not in f1:
+                f1[m] = a1.new_zeros((n_videos, lpad, a1.shape[2]))
+                f2[m] = a2.new_zeros((n_videos, lpad, a2.shape[2]))
+                mk[m] = torch.zeros((n_videos, lpad), dtype=torch.float32, device=a1.device)
+            b, lb = a1.shape[0], a1.shape[1]
+            assert r + b <= n_videos and lb <= l_ref
+            f1[m][r:r + b, :lb] = a1
+            f2[m][r:r + b, :lb] = a2
+            mk[m][r:r + b, :lb] = am.float()
+        r += v1.shape[0] if v1 is not None else s1.shape[0]
+    assert r == n_videos, "n_videos=%d but the batches held %d" % (n_videos, r)
+    plan = ops.q2c_pack_plan([mk[m] for m in mods]) if (hasattr(ops, "q2c_pack_plan") and lpad == 128) else None
+    feat1n, raw = {}, {}
+    for m in mods:
+        n1 = ops.l2norm_rows(f1[m])
+        feat1n[m] = ops.pack_q2c_corpus(n1, mk[m], plan) if hasattr(ops, "pack_q2c_corpus") else n1
+        if keep_raw:
+            raw[m] = f1[m]
+    idx = CorpusIndex(mods, feat1n, f2, mk, l_ref, video_offset, n_total)
     idx.raw_feat1 = raw
     return idx
 

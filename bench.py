@@ -467,7 +467,7 @@ def main(argv=None):
     ap.add_argument("--force-sharded", action="store_true", help="use the multi-GPU code path even with 1 rank (testing)")
     ap.add_argument("--sharded-rerank", action="store_true",
                     help="N > 1: keep feat2 sharded too (phase 2 on the video's owner, four collectives per pass)")
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("XML_SHARD_CHUNKS", "2")),
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("XML_SHARD_CHUNKS", "1")),
                     help="N > 1: query chunks of the pipelined owner pass (chunk c's exchange runs under chunk c+1's K6)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: keep the exchanges on torch.distributed instead of libxmlhip's xml_rccl_* entries (A/B)")

@@ -361,6 +361,14 @@ int xml_rccl_allgather(xml_comm_t comm, const void* send, void* recv, int64_t by
 /* in-place average of an f32 buffer over ranks (data-parallel gradient buckets, BASELINE config 5; xml/train.py:81-85
  * is the single-process loop it extends). */
 int xml_rccl_allreduce_avg_f32(xml_comm_t comm, float* buf, int64_t n, xml_stream_t stream);
+/* The plain scheme: ncclAllGather of every rank's local top-c lists (loc_score / loc_id (nq, c) as below), then EVERY rank
+ * merges all nq queries: out_val / out_id (nq, k), same order and tie rule as xml_topk_rows.  Two all-gathers in one group,
+ * one un-permute kernel, one top-k kernel.  (SURVEY.md 8b names this entry; the engine's default pass uses the by-owner
+ * exchange below, which moves and merges 1/world of it per rank.) */
+size_t xml_rccl_allgather_topk_workspace_bytes(int world, int nq, int c);
+int xml_rccl_allgather_topk(xml_comm_t comm, int world, const float* loc_score, const int32_t* loc_id, int nq, int c,
+                            int k, float alpha, float* out_val, int32_t* out_id, void* ws, size_t ws_bytes,
+                            xml_stream_t stream);
 /* Exact global top-k by query owner.  Queries are split into `world` contiguous slices of per = ceil(nq / world) rows;
  * rank r owns slice r.  Every rank passes its LOCAL top-c of all nq queries -- loc_score (nq, c) f32 descending,
  * loc_id (nq, c) int32 GLOBAL video ids (pad short shards with -inf / INT32_MAX) -- and receives the merged global top-k

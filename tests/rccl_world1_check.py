@@ -59,6 +59,10 @@ def main():
     b = ex_t.topk_by_owner(loc_s, loc_i, 100, 20.0, ops)
     torch.cuda.synchronize()
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    a = ex_c.allgather_topk(loc_s, loc_i, 100, 20.0, ops)
+    b = ex_t.allgather_topk(loc_s, loc_i, 100, 20.0, ops)
+    torch.cuda.synchronize()
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     rows = torch.randn(11, 2, 64, device=dev, generator=g).to(torch.bfloat16)
     assert torch.equal(ex_c.allgather_rows(rows), ex_t.allgather_rows(rows))
     # the chunked, stream-pipelined owner pass through the C-ABI exchange

@@ -83,6 +83,9 @@ SIGNATURES = {
     "xml_rccl_comm_destroy": (c_int, [c_void_p]),
     "xml_rccl_allgather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_void_p]),
     "xml_rccl_allreduce_avg_f32": (c_int, [c_void_p, c_void_p, c_int64, c_void_p]),
+    "xml_rccl_allgather_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "xml_rccl_allgather_topk": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                        c_void_p, c_void_p, c_size_t, c_void_p]),
     "xml_rccl_topk_by_owner_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "xml_rccl_topk_by_owner": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),

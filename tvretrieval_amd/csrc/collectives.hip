@@ -137,6 +137,43 @@ extern "C" int xml_rccl_allreduce_avg_f32(xml_comm_t comm, float* buf, int64_t n
              ? XML_OK : XML_ERR_LAUNCH;
 }
 
+// The plain scheme of BASELINE.json's north_star: all-gather the per-shard top-c lists, every rank merges ALL queries.
+// (The engine's default is the by-owner exchange below -- 1/P of the receive volume and of the merge work per rank; this
+// entry serves the paths that need the global top-k everywhere: the video-owner rerank, API parity with vcmr_search.)
+extern "C" size_t xml_rccl_allgather_topk_workspace_bytes(int world, int nq, int c) {
+  if (world <= 0 || nq <= 0 || c <= 0) return 0;
+  return 4 * align_up((size_t)world * nq * c * 4, 256);
+}
+
+extern "C" int xml_rccl_allgather_topk(xml_comm_t comm, int world, const float* loc_score, const int32_t* loc_id, int nq,
+                                       int c, int k, float alpha, float* out_val, int32_t* out_id, void* ws,
+                                       size_t ws_bytes, xml_stream_t stream) {
+  XML_ENTER();
+  if (!comm || !loc_score || !loc_id || !out_val || !out_id || !ws) return XML_ERR_BAD_ARG;
+  if (world <= 0 || nq <= 0 || c <= 0 || k <= 0) return XML_ERR_BAD_ARG;
+  if (k > 256 || k > world * c) return XML_ERR_UNSUPPORTED;
+  if (!rccl().ok) return XML_ERR_UNSUPPORTED;
+  if (ws_bytes < xml_rccl_allgather_topk_workspace_bytes(world, nq, c)) return XML_ERR_WORKSPACE;
+  const size_t seg = align_up((size_t)world * nq * c * 4, 256);
+  float* rs = (float*)ws;
+  int32_t* ri = (int32_t*)((char*)ws + seg);
+  float* cs = (float*)((char*)ws + 2 * seg);
+  int32_t* ci = (int32_t*)((char*)ws + 3 * seg);
+  hipStream_t st = (hipStream_t)stream;
+  ncclComm_t nc = (ncclComm_t)comm;
+  RcclApi& r = rccl();
+  bool ok = r.GroupStart() == ncclSuccess;
+  ok = ok && r.AllGather(loc_score, rs, (size_t)nq * c, ncclFloat32, nc, st) == ncclSuccess;
+  ok = ok && r.AllGather(loc_id, ri, (size_t)nq * c, ncclInt32, nc, st) == ncclSuccess;
+  ok = (r.GroupEnd() == ncclSuccess) && ok;
+  if (!ok) return XML_ERR_LAUNCH;
+  const int64_t total = (int64_t)world * nq * c;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(unpermute_by_owner_kernel, dim3(grid), dim3(256), 0, st, rs, ri, cs, ci, world, nq, c);
+  XML_CHECK_LAUNCH();
+  return xml_topk_rows(cs, (int64_t)world * c, ci, out_val, out_id, nq, world * c, k, alpha, nullptr, 0, stream);
+}
+
 extern "C" size_t xml_rccl_topk_by_owner_workspace_bytes(int world, int per, int c) {
   if (world <= 0 || per <= 0 || c <= 0) return 0;
   return 4 * align_up((size_t)world * per * c * 4, 256);      // recv scores / ids, candidate scores / ids

@@ -62,6 +62,11 @@ __device__ __forceinline__ void dma_slice4(uint32_t va0, uint32_t va1, uint32_t 
       : "memory", "scc");
 }
 
+// one 1 KiB piece (M0 is left pointing at it; the compiler reserves M0 and sets it itself before any use of its own)
+__device__ __forceinline__ void dma16m(uint32_t voff, const char* sbase, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
+}
+
 // two consecutive 1 KiB pieces of one operand
 __device__ __forceinline__ void dma_pair(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
   asm volatile(
@@ -332,6 +337,24 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // fragment reads unconditional.  ~8 fewer scalar branches per slice; the kernel drains the stream before it exits.
   int i_slot = 0;
   int i_left = slices_per_seg, i_inc = 1;              // slices left to issue in the current segment; slice increment
+  auto issue_advance = [&]() {
+    ++i_gs;
+    if (++i_slot == NSLOT) i_slot = 0;
+    i_slice += i_inc;
+    if (--i_left == 0) {                                 // next segment: other modality of the tile, or the next tile
+      i_slice = 0;
+      i_left = slices_per_seg;
+      ++i_seg;
+      bool new_tile = false;
+      if (++i_mod == a.n_mod) {
+        i_mod = 0;
+        advance(i_g, i_c);
+        new_tile = true;
+      }
+      if (i_g < n_qgroups) setup_issue_segment(new_tile);
+      else { i_left = 0x7fffffff; i_inc = 0; }           // exhausted: slice 0 of the last segment from now on
+    }
+  };
   auto issue_slice = [&]() {
     const int koff = i_slice * SLICE_STRIDE;
     const uint32_t dst = lds_wave + i_slot * SLOT_BYTES;
@@ -372,22 +395,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         }
       }
     }
-    ++i_gs;
-    if (++i_slot == NSLOT) i_slot = 0;
-    i_slice += i_inc;
-    if (--i_left == 0) {                                 // next segment: other modality of the tile, or the next tile
-      i_slice = 0;
-      i_left = slices_per_seg;
-      ++i_seg;
-      bool new_tile = false;
-      if (++i_mod == a.n_mod) {
-        i_mod = 0;
-        advance(i_g, i_c);
-        new_tile = true;
-      }
-      if (i_g < n_qgroups) setup_issue_segment(new_tile);
-      else { i_left = 0x7fffffff; i_inc = 0; }           // exhausted: slice 0 of the last segment from now on
-    }
+    issue_advance();
   };
 
   advance(i_g, i_c);
@@ -494,6 +502,42 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // copies -- 350 spilled VGPRs when tried.)
       // (Reading the next fragments before h1 in BOTH groups was tried after the timing probe: no gain, and the second
       // group's variant then spills.)
+      if constexpr (ABL == 16) {
+        // experiment: the DMA pieces of the slice are issued BETWEEN the MFMAs of h1 (one piece every 2-3 MFMAs) instead
+        // of back to back in front of / behind the MFMA block
+        if (!GRP1) next_reads();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+          const int koff = i_slice * SLICE_STRIDE;
+          const uint32_t slot0 = lds0 + i_slot * SLOT_BYTES;
+          const char* pa = sbase_a + koff;
+          const char* pb = sbase_b + koff;
+          const uint32_t da = slot0 + wave * 4096;
+          const uint32_t db = slot0 + OPER_BYTES + (GRP1 ? 8192 + (wave - 4) * 2048 : wave * 2048);
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+              if constexpr (INIT) MmaInit<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+              else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+              const int idx = m * 4 + n;
+              if (!GRP1) {
+                if (idx == 1) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_a0, pa, da); __builtin_amdgcn_sched_barrier(0); }
+                if (idx == 4) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_a1, pa, da + 1024); __builtin_amdgcn_sched_barrier(0); }
+                if (idx == 6) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_x[0], pa, da + 2048); __builtin_amdgcn_sched_barrier(0); }
+                if (idx == 9) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_x[UNEVEN ? 1 : 0], pa, da + 3072); __builtin_amdgcn_sched_barrier(0); }
+                if (idx == 11) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_b0, pb, db); __builtin_amdgcn_sched_barrier(0); }
+                if (idx == 14) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_b1, pb, db + 1024); __builtin_amdgcn_sched_barrier(0); }
+              } else {
+                if (idx == 4) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_b0, pb, db); __builtin_amdgcn_sched_barrier(0); }
+                if (idx == 10) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_b1, pb, db + 1024); __builtin_amdgcn_sched_barrier(0); }
+              }
+            }
+        }
+        issue_advance();
+        __builtin_amdgcn_sched_barrier(0);
+        if (GRP1) next_reads();
+      } else {
       if (!GRP1) {
         next_reads();
         issue_slice();                                  // slice c_gs + 3 -> the slot just released
@@ -504,6 +548,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       if (GRP1) {
         next_reads();
         issue_slice();
+      }
       }
     };
 
@@ -695,6 +740,7 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tile
 #define XML_K6_PICK(...) do { kern = q2c_persist_kernel<__VA_ARGS__>; ok = xml_lds_attr_once<q2c_persist_kernel<__VA_ARGS__>>(lds); } while (0)
 #ifdef XML_DEBUG_VARIANTS
   if (tiled && mask_mode == 1 && g_q2c_ablation == 13) XML_K6_PICK(T, 13, true, true, true);
+  else if (tiled && mask_mode == 1 && g_q2c_ablation == 16) XML_K6_PICK(T, 16, true, true, true);
   else if (tiled && mask_mode == 1 && g_q2c_ablation == 14) XML_K6_PICK(T, 14, true, true, true);
   else if (tiled && mask_mode == 1 && g_q2c_ablation == 15) XML_K6_PICK(T, 15, true, true, true);
   else

@@ -92,14 +92,6 @@ def _exchange_by_owner(buf, group, world, per):
     return cand[0].reshape(per, world * c).view(torch.float32), cand[1].reshape(per, world * c)
 
 
-def _all_gather_packed(score, idx, group, world, nq, per):
-    """all-gather (<= per, c) f32 + i32 rows of every owner -> (nq, c) f32, (nq, c) i32 on every rank."""
-    buf = _pack_rows(score, idx, per, 0.0, -1)
-    out = torch.empty((world * per,) + tuple(buf.shape[1:]), dtype=torch.int32, device=buf.device)
-    dist.all_gather_into_tensor(out, buf, group=group)
-    return out[:nq, 0].contiguous().view(torch.float32), out[:nq, 1].contiguous()
-
-
 def replicate_rerank_features(index, group=None):
     """One-off, after the shard is encoded: all-gather the ConvSE-side context features (feat2) and clip masks of
     every shard into corpus-wide copies index.feat2_all[m] (n_total, lpad, H) / index.mask_all[m] (n_total, lpad).
@@ -148,6 +140,13 @@ class TorchExchange(object):
         dist.all_gather_into_tensor(out, buf.contiguous(), group=self.group)
         return out
 
+    def allgather_topk(self, loc_s, loc_i, k, alpha, ops):
+        """Global top-k of ALL queries on every rank (the plain all-gather scheme)."""
+        nq, c = loc_s.shape
+        gs = self.allgather_rows(loc_s.contiguous()).view(self.world, nq, c).permute(1, 0, 2).reshape(nq, self.world * c)
+        gi = self.allgather_rows(loc_i.contiguous()).view(self.world, nq, c).permute(1, 0, 2).reshape(nq, self.world * c)
+        return ops.topk_rows(gs.contiguous(), k, alpha=alpha, idx_in=gi.contiguous())
+
     def topk_by_owner(self, loc_s, loc_i, k, alpha, ops):
         nq = loc_s.shape[0]
         q_lo, q_hi, per = query_slice(nq, self.rank, self.world)
@@ -169,6 +168,9 @@ class RcclExchange(object):
 
     def allgather_rows(self, buf):
         return self.comm.allgather(buf.contiguous())
+
+    def allgather_topk(self, loc_s, loc_i, k, alpha, ops):
+        return self.comm.allgather_topk(loc_s.contiguous(), loc_i.contiguous(), k, alpha)
 
     def topk_by_owner(self, loc_s, loc_i, k, alpha, ops):
         return self.comm.topk_by_owner(loc_s.contiguous(), loc_i.contiguous(), k, alpha)
@@ -375,10 +377,8 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
     else:
         loc_s, loc_i = _local_topk(index, q2c, k, ops)
         _mark("topk_local_k8")
-        own_w, own_gid = ex.topk_by_owner(loc_s, loc_i, k, q2c_alpha, ops)       # my slice: global top-k
-        _mark("exchange+merge_topk")
-        top_w, top_gid = _all_gather_packed(own_w, own_gid, group, world, nq, per)
-        _mark("allgather_topk")
+        top_w, top_gid = ex.allgather_topk(loc_s, loc_i, k, q2c_alpha, ops)       # every rank: global top-k of all queries
+        _mark("allgather+merge_topk")
     # ---- phase 2: moments of the global top-k videos this rank owns -------------------------------------
     lo, hi = index.video_offset, index.video_offset + index.n_videos
     own = (top_gid >= lo) & (top_gid < hi)
@@ -391,15 +391,14 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
     if trivial:
         fs, fi = loc_fs, loc_fi
     else:
-        cand_s, cand_i = _exchange_by_owner(_pack_rows(loc_fs, loc_fi, world * per, 0.0, -1), group, world, per)
-        _mark("alltoall_moments")
-        fs, fi = ops.topk_rows(cand_s, max_before_nms, alpha=0.0, idx_in=cand_i)
-        fi = torch.where(fs > 0, fi, torch.full_like(fi, -1))
-        _mark("merge_moments_k8")
+        # empty slots carry score 0 / flat -1: give them the largest payload so that real moments win ties at score 0
+        loc_fi = torch.where(loc_fi >= 0, loc_fi, torch.full_like(loc_fi, 2 ** 31 - 1)).contiguous()
         if gather_results:
-            fs, fi = _all_gather_packed(fs, fi, group, world, nq, per)
+            fs, fi = ex.allgather_topk(loc_fs.contiguous(), loc_fi, max_before_nms, 0.0, ops)
         else:
-            fs, fi = fs[:q_hi - q_lo], fi[:q_hi - q_lo]
+            fs, fi = ex.topk_by_owner(loc_fs.contiguous(), loc_fi, max_before_nms, 0.0, ops)
+        fi = torch.where(fs > 0, fi, torch.full_like(fi, -1))
+        _mark("exchange+merge_moments")
     if trivial or gather_results:
         q_lo, q_hi = 0, nq
     return dict(top_scores=top_w, top_indices=top_gid, flat_scores=fs, flat_indices=fi, q2c_local=q2c,

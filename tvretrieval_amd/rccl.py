@@ -56,6 +56,23 @@ class RcclComm(object):
               "xml_rccl_allreduce_avg_f32")
         return buf
 
+    def allgather_topk(self, loc_score, loc_id, k, alpha):
+        """All ranks' local top-c lists of all queries -> the merged global top-k of ALL queries on every rank."""
+        from . import ops
+        assert loc_score.is_cuda and loc_score.dtype == torch.float32 and loc_id.dtype == torch.int32
+        assert loc_score.is_contiguous() and loc_id.is_contiguous() and loc_score.shape == loc_id.shape
+        nq, c = loc_score.shape
+        out_val = torch.empty((nq, k), dtype=torch.float32, device=loc_score.device)
+        out_id = torch.empty((nq, k), dtype=torch.int32, device=loc_score.device)
+        ws = ops._workspace(self._lib.xml_rccl_allgather_topk_workspace_bytes(self.world, nq, c), loc_score.device)
+        check(self._lib.xml_rccl_allgather_topk(self.handle, self.world, ctypes.c_void_p(loc_score.data_ptr()),
+                                                ctypes.c_void_p(loc_id.data_ptr()), nq, c, k, float(alpha),
+                                                ctypes.c_void_p(out_val.data_ptr()), ctypes.c_void_p(out_id.data_ptr()),
+                                                ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                                ctypes.c_void_p(torch.cuda.current_stream(loc_score.device).cuda_stream)),
+              "xml_rccl_allgather_topk")
+        return out_val, out_id
+
     def topk_by_owner(self, loc_score, loc_id, k, alpha):
         """loc_score (nq, c) f32 / loc_id (nq, c) int32: local top-c of all queries -> merged global top-k of the query
         slice this rank owns: (rows_owned, k) f32 [exp(alpha s) if alpha], (rows_owned, k) int32."""

@@ -159,6 +159,48 @@ def test_linear_ln_relu_pos(ops, dtype, shape):
     close("linear_ln_relu_pos", got, want, _tol(dtype, 5e-5, 6e-2))
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("h,n_seq", [(768, 600), (256, 1600), (512, 800)])
+def test_gemm_layernorm_epilogue_matches_unfused(ops, dtype, h, n_seq):
+    """Large batches run K1+K2 and BertSelfOutput with the LayerNorm inside the persistent GEMM's epilogue (cross-workgroup
+    row statistics, gemm256p.hip LNE); half-size batches of the same rows fall below the eligibility threshold and take
+    the GEMM (f32 out) + LayerNorm launches.  Rows are independent, so the two must agree: f32 to rounding of the
+    statistics, bf16 to one rounding of the pre-LayerNorm value.  The first sequences are also checked against the oracle."""
+    if dtype == torch.float32 and h == 768:
+        n_seq = 608
+    l, d_in, nh = 128, 128, 4
+    g = torch.Generator(device=DEV).manual_seed(3)
+    x = torch.randn(n_seq, l, d_in, device=DEV, generator=g)
+    sd = {"LayerNorm.weight": 1 + 0.1 * rnd(d_in, seed=11), "LayerNorm.bias": 0.1 * rnd(d_in, seed=12),
+          "net.1.weight": rnd(h, d_in, seed=13, scale=d_in ** -0.5), "net.1.bias": 0.1 * rnd(h, seed=14)}
+    pe = {"position_embeddings.weight": rnd(l, h, seed=15, scale=0.5), "LayerNorm.weight": 1 + 0.1 * rnd(h, seed=16),
+          "LayerNorm.bias": 0.1 * rnd(h, seed=17)}
+    args = (dev(sd["LayerNorm.weight"]), dev(sd["LayerNorm.bias"]), dev(sd["net.1.weight"], dtype), dev(sd["net.1.bias"]),
+            dev(pe["position_embeddings.weight"], dtype), dev(pe["LayerNorm.weight"]), dev(pe["LayerNorm.bias"]))
+    half = n_seq // 2
+    fused = ops.linear_ln_relu_pos(x, *args)
+    parts = torch.cat([ops.linear_ln_relu_pos(x[:half].contiguous(), *args), ops.linear_ln_relu_pos(x[half:].contiguous(), *args)])
+    tol = 2e-5 if dtype == torch.float32 else 3e-2            # bf16: + 2 ulp relative (one extra rounding before the LN)
+    rtol = 0.0 if dtype == torch.float32 else 1.6e-2
+    close("K1+K2 fused vs unfused", fused, parts, tol, rtol)
+    want = O.trainable_pos_enc(O.linear_layer(x[:3].cpu(), O.Weights(sd)), O.Weights(pe))
+    close("K1+K2 fused vs oracle", fused[:3], want, _tol(dtype, 5e-5, 6e-2))
+    # BertAttention block on the encoder output
+    sdA = _att_weights(h, 40)
+    wqkv = torch.cat([sdA["self.%s.weight" % k] for k in ("query", "key", "value")])
+    bqkv = torch.cat([sdA["self.%s.bias" % k] for k in ("query", "key", "value")])
+    aargs = (dev(wqkv, dtype), dev(bqkv), dev(sdA["output.dense.weight"], dtype), dev(sdA["output.dense.bias"]),
+             dev(sdA["output.LayerNorm.weight"]), dev(sdA["output.LayerNorm.bias"]), nh)
+    mask = (torch.arange(l, device=DEV)[None] < torch.randint(20, l + 1, (n_seq, 1), device=DEV, generator=g)).float()
+    xin = fused
+    fusedA = ops.attention_block(xin, mask, *aargs)
+    partsA = torch.cat([ops.attention_block(xin[:half].contiguous(), mask[:half].contiguous(), *aargs),
+                        ops.attention_block(xin[half:].contiguous(), mask[half:].contiguous(), *aargs)])
+    close("BertAttention fused vs unfused", fusedA, partsA, 5e-5 if dtype == torch.float32 else 3e-2, rtol)
+    wantA = O.bert_attention(xin[:2].float().cpu(), mask[:2].cpu().unsqueeze(1), O.Weights(sdA), nh)
+    close("BertAttention fused vs oracle", fusedA[:2], wantA, _tol(dtype, 2e-4, 8e-2))
+
+
 def _att_weights(h, seed):
     s = h ** -0.5
     sd = {}

@@ -555,8 +555,10 @@ int xmli_attention_core(const void* q, int ldq, const void* k, int ldk, const vo
 // ---------------------------------------------------------------------------------------------------
 extern "C" size_t xml_attention_block_workspace_bytes(int64_t n, int seq_len, int hidden, int dt) {
   const size_t rows = (size_t)n * seq_len;
+  const size_t pre = align_up(rows * hidden * 4, 256);      // f32 pre-LN rows, or the fused epilogue's partial statistics
+  const size_t lnw = xmli_gemm_ln_eligible((int64_t)rows, hidden, hidden, dt) ? xmli_gemm_ln_workspace_bytes((int64_t)rows, hidden) : 0;
   return align_up(rows * 3 * hidden * dt_size(dt), 256) + align_up(rows * hidden * dt_size(dt), 256) +
-         align_up(rows * hidden * 4, 256);
+         (pre > lnw ? pre : lnw);
 }
 
 extern "C" int xml_attention_block(const void* x, const float* key_mask, const void* wqkv, const float* bqkv,
@@ -579,6 +581,9 @@ extern "C" int xml_attention_block(const void* x, const float* key_mask, const v
   rc = xmli_attention_core(qkv, 3 * hidden, qkv + (size_t)hidden * es, 3 * hidden, qkv + (size_t)2 * hidden * es,
                            3 * hidden, nullptr, key_mask, att, 0, n, seq_len, seq_len, hidden, n_heads, dt, st);
   if (rc) return rc;
+  if (xmli_gemm_ln_eligible(rows, hidden, hidden, dt) && y != x &&   // BertSelfOutput: dense + residual + LayerNorm in one launch
+      xmli_gemm_ln(att, wo, bo, x, ln_g, ln_b, y, rows, hidden, hidden, 0, /*residual*/ 2, 1, dt, pre, st) == XML_OK)
+    return XML_OK;
   rc = xmli_gemm(att, wo, bo, x, pre, rows, hidden, hidden, 0, /*residual*/ 2, 1, /*out_f32*/ 1, dt, st);
   if (rc) return rc;
   return xmli_add_layernorm(pre, XML_F32, nullptr, ln_g, ln_b, y, rows, hidden, hidden, dt, st);

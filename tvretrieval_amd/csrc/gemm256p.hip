@@ -29,6 +29,12 @@ struct G256pArgs {
   void* out;
   int64_t M, n_tiles;
   int N, K, relu, add_mode, seq_len, tn;
+  // LayerNorm epilogue (LNE kernels): y = LN(act(A W^T + bias) + addend) * g + b over the full rows of N = tn * 256 columns
+  float* ln_part;       // (M, 2 tn, 2) f32: per row and per 128-column segment (sum, centred sum of squares)
+  int* ln_count;        // (ceil(M / 256)): column tiles of a row block that have published their partials (zeroed per launch)
+  const float* ln_g;
+  const float* ln_b;
+  float ln_eps;
 };
 
 __device__ __forceinline__ void g256p_dma_pair(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
@@ -68,7 +74,14 @@ template <> struct G256pInit<bf16_t> {
 };
 __device__ __forceinline__ int g256p_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
-template <typename T, typename OutT, typename AddT>
+// LNE: LayerNorm fused into the epilogue (K2 behind K1, BertSelfOutput; xml/model_components.py:76-89,313-317).  A row of
+// the output spans tn = N / 256 column tiles = tn workgroups.  Every workgroup (1) writes its part of the pre-LayerNorm
+// rows in the storage type and publishes, per row and 128-column segment, (sum, centred sum of squares) computed from
+// the f32 values; (2) signals a per-row-block counter and waits until the tn tiles of the block have signalled -- all
+// 256 workgroups are resident (one per CU) and walk the tiles in the same order, so the partners are at most a tile
+// apart; (3) combines the 2 tn partials of its rows in a fixed order (Chan's formula: deterministic, no E[x^2] - mean^2
+// cancellation) and normalises its own part in place.  No f32 round trip through HBM, no separate LayerNorm launch.
+template <typename T, typename OutT, typename AddT, bool LNE = false>
 __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
@@ -94,7 +107,28 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 
   // tile walk: round k hands the 32 workgroups of XCD x the 32 consecutive tiles (8 k + x) * 32 .. + 31, N fastest:
   // the workgroups of an XCD share a few row tiles of A through its L2, W stays resident
-  auto tile_of = [&](int k) -> int64_t { return ((int64_t)k * 8 + xcd) * 32 + loc; };
+  // LNE: the tn column tiles of a row block must meet (row statistics), so they go to tn NEIGHBOURING workgroups of ONE
+  // XCD in the same round -- one L2 serves their exchange, no device-wide cache maintenance -- : an XCD takes 32 / tn row
+  // blocks per round (tn = 3: 10 blocks, 2 of its 32 workgroups idle).
+  const int lne_g = LNE ? __builtin_amdgcn_readfirstlane(32 / a.tn) : 0;
+  const int lne_rb = LNE ? __builtin_amdgcn_readfirstlane(loc / a.tn) : 0, lne_nt = LNE ? loc - lne_rb * a.tn : 0;
+  auto tile_of = [&](int k) -> int64_t {
+    if constexpr (LNE) {
+      if (lne_rb >= lne_g) return a.n_tiles;
+      return (((int64_t)k * 8 + xcd) * lne_g + lne_rb) * a.tn + lne_nt;
+    }
+    return ((int64_t)k * 8 + xcd) * 32 + loc;
+  };
+  auto tile_mt_nt = [&](int k, int64_t& mt, int& nt) {      // (row block, column tile) of this workgroup's k-th tile
+    if constexpr (LNE) {
+      mt = ((int64_t)k * 8 + xcd) * lne_g + lne_rb;         // scalar arithmetic on uniform ints: the DMA bases stay in SGPRs
+      nt = lne_nt;
+    } else {
+      const int64_t lin = tile_of(k);
+      mt = lin / a.tn;
+      nt = (int)(lin - mt * a.tn);
+    }
+  };
 
   // ---- issue side ---------------------------------------------------------------------------------------------
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
@@ -103,9 +137,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
   const char* sbase_a = nullptr;
   const char* sbase_b = nullptr;
   auto setup_issue_tile = [&]() {
-    const int64_t lin = tile_of(i_k);
-    const int64_t mt = lin / a.tn;
-    const int nt = (int)(lin - mt * a.tn);
+    int64_t mt; int nt;
+    tile_mt_nt(i_k, mt, nt);
     const int64_t m0 = mt * 256;
     const int n0 = nt * 256;
     int lane_o = lane;                             // opaque copy: keeps the address arithmetic out of the MFMA loop
@@ -216,9 +249,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
     // groups fg = 2 (p & 1), 2 (p & 1) + 1 of row block p >> 1.  Patch column XOR 16 for rows 4..7: the two groups
     // write different banks; a lane's 8 consecutive columns stay contiguous.
     {
-      const int64_t lin = tile_of(c_k);
-      const int64_t mt = lin / a.tn;
-      const int nt = (int)(lin - mt * a.tn);
+      int64_t mt; int nt;
+      tile_mt_nt(c_k, mt, nt);
       const int64_t m0 = mt * 256;
       const int n0 = nt * 256;
       const uint32_t m0_mod = a.add_mode == 1 ? (uint32_t)(m0 % a.seq_len) : 0u;     // one 64-bit modulo per tile
@@ -292,11 +324,115 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += av[j];
           }
+          if constexpr (LNE) {      // (N % 256 == 0: every lane of the row holds 8 real columns)
+            float s8 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s8 += v[j];
+            const float seg_sum = lane16_sum(s8);                 // the 16 lanes of a row: this wave's 128 columns
+            const float seg_mean = seg_sum * (1.0f / 128.0f);
+            float q8 = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float c = v[j] - seg_mean; q8 += c * c; }
+            const float seg_m2 = lane16_sum(q8);
+            if ((lane_e & 15) == 0) {
+              float* pp = a.ln_part + ((m * (2 * a.tn)) + nt * 2 + wn) * 2;
+              pp[0] = seg_sum; pp[1] = seg_m2;
+            }
+          }
           if (F32O) {
             if (ok0) st_global16(out + m * N + nc0, pack16<float>(v));
             if (ok1) st_global16(out + m * N + nc1, pack16<float>(v + 4));
           } else if (ok1) {                               // (ok1 implies ok0; N % 8 == 0)
             st_global16(out + m * N + nc0, pack16<bf16_t>(v));
+          }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if constexpr (LNE) {
+        // ---- publish, wait for the row block's other column tiles, normalise in place -------------------------------
+        // The partners share this XCD's L2 (tile walk above): stores are write-through, so "my stores are acknowledged"
+        // (vmcnt(0)) means they are in that L2; the counter lives there too (agent-scope atomics), and nobody has these
+        // lines in an L1 (first touch).  A device-scope fence here would write back and invalidate the whole L2 per tile
+        // (release / acquire at agent scope span the 8 XCDs) -- measured: it doubled the kernel's time.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (tid == 0) {
+          __hip_atomic_fetch_add(a.ln_count + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while (__hip_atomic_load(a.ln_count + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.tn)
+            __builtin_amdgcn_s_sleep(1);
+        }
+        __builtin_amdgcn_s_barrier();
+        {   // lane l: statistics of row wm * 64 + l of the tile, combined from the 2 tn segment partials in fixed order
+          const int64_t m = m0 + wm * 64 + lane_e;
+          float mean = 0.f, rstd = 0.f;
+          if (m < M) {
+            // all partials of the row in one batch of 16-byte loads (tn <= 4: at most 16 floats), then the arithmetic --
+            // a load -> use loop would pay one memory round trip per iteration (hipcc waits vmcnt(0) at every use here)
+            typedef float xml_f4 __attribute__((ext_vector_type(4)));
+            const xml_f4* pp = reinterpret_cast<const xml_f4*>(a.ln_part + m * (2 * a.tn) * 2);
+            xml_f4 pv[4];
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) pv[t4] = t4 < a.tn ? __builtin_nontemporal_load(pp + t4) : xml_f4{0.f, 0.f, 0.f, 0.f};
+            float tot = 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) tot += pv[t4].x + pv[t4].z;
+            mean = tot / (float)N;
+            float m2 = 0.f;
+#pragma unroll
+            for (int t4 = 0; t4 < 4; ++t4) {
+              if (t4 < a.tn) {
+                const float d0 = pv[t4].x * (1.0f / 128.0f) - mean, d1 = pv[t4].z * (1.0f / 128.0f) - mean;
+                m2 += pv[t4].y + 128.0f * d0 * d0 + pv[t4].w + 128.0f * d1 * d1;
+              }
+            }
+            rstd = 1.0f / sqrtf(m2 / (float)N + a.ln_eps);
+          }
+          patch[lane_e * 2] = mean;
+          patch[lane_e * 2 + 1] = rstd;
+        }
+        float gv[8], bb[8];
+        {
+          const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + nc0), g1 = *reinterpret_cast<const float4*>(a.ln_g + nc1);
+          const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + nc0), b1 = *reinterpret_cast<const float4*>(a.ln_b + nc1);
+          gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+          bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        // the same (row, column group) walk as above: a lane re-reads exactly what it wrote.  ALL loads of the tile first
+        // (the accumulators are dead: 64 / 128 registers are free), one wait, then arithmetic and stores
+        constexpr int NLD = F32O ? 2 : 1;
+        uint4 rb[16][NLD];
+#pragma unroll
+        for (int pi = 0; pi < 16; ++pi) {
+          const int lr64 = (pi >> 1) * 8 + (pi & 1) * 4 + orow;
+          const int64_t m = m0 + wm * 64 + lr64;
+          const int64_t ms = m < M ? m : m0;              // (rows beyond M: any valid row, the result is not stored)
+          rb[pi][0] = ld_global16(out + ms * N + nc0);
+          if (F32O) rb[pi][NLD - 1] = ld_global16(out + ms * N + nc1);
+        }
+#pragma unroll
+        for (int pi = 0; pi < 16; ++pi) {
+          const int lr64 = (pi >> 1) * 8 + (pi & 1) * 4 + orow;
+          const int64_t m = m0 + wm * 64 + lr64;
+          const float mean = patch[lr64 * 2], rstd = patch[lr64 * 2 + 1];
+          float v[8];
+          if (F32O) {
+            unpack16<float>(rb[pi][0], v);
+            unpack16<float>(rb[pi][NLD - 1], v + 4);
+          } else {
+            unpack16<OutT>(rb[pi][0], v);
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * rstd * gv[j] + bb[j];
+          if (m < M) {
+            if (F32O) {
+              st_global16(out + m * N + nc0, pack16<float>(v));
+              st_global16(out + m * N + nc1, pack16<float>(v + 4));
+            } else {
+              st_global16(out + m * N + nc0, pack16<bf16_t>(v));
+            }
           }
         }
         __builtin_amdgcn_s_waitcnt(0xc07f);
@@ -313,20 +449,64 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
   __builtin_amdgcn_s_barrier();
 }
 
-template <typename T, typename OutT, typename AddT>
+__global__ void g256p_zero_kernel(int* p, int n) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+template <typename T, typename OutT, typename AddT, bool LNE = false>
 static int launch_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
-                           int N, int K, int relu, int add_mode, int seq_len, hipStream_t st) {
+                           int N, int K, int relu, int add_mode, int seq_len, hipStream_t st, const float* ln_g = nullptr,
+                           const float* ln_b = nullptr, void* ln_ws = nullptr) {
   G256pArgs a;
   a.A = A; a.W = W; a.bias = bias; a.addend = addend; a.out = out;
   a.M = M; a.N = N; a.K = K; a.relu = relu; a.add_mode = add_mode; a.seq_len = seq_len;
   a.tn = cdiv(N, 256);
   a.n_tiles = (int64_t)cdiv(M, 256) * a.tn;
+  a.ln_part = nullptr; a.ln_count = nullptr; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+  if (LNE) {
+    const int n_blocks = (int)cdiv(M, 256);
+    a.ln_count = (int*)ln_ws;
+    a.ln_part = (float*)((char*)ln_ws + align_up((size_t)n_blocks * 4, 256));
+    hipLaunchKernelGGL(g256p_zero_kernel, dim3(cdiv(n_blocks, 256)), dim3(256), 0, st, a.ln_count, n_blocks);
+  }
   const int lds = 4 * 2 * 256 * 64 + 8 * 4096;          // ring + patches = 160 KiB
-  auto kern = gemm256p_kernel<T, OutT, AddT>;
-  if (!xml_lds_attr_once<gemm256p_kernel<T, OutT, AddT>>(lds)) return XML_ERR_LAUNCH;
+  auto kern = gemm256p_kernel<T, OutT, AddT, LNE>;
+  if (!xml_lds_attr_once<gemm256p_kernel<T, OutT, AddT, LNE>>(lds)) return XML_ERR_LAUNCH;
+  if (LNE) {
+    // the workgroups of a row block wait for each other: ALL 256 must be resident at once.  A cooperative launch makes the
+    // runtime guarantee that (and serialises two such kernels issued on different streams, which could otherwise each
+    // hold part of the chip and wait for partners that cannot start).
+    void* params[] = {(void*)&a};
+    if (hipLaunchCooperativeKernel((const void*)kern, dim3(256), dim3(512), params, (unsigned)lds, st) != hipSuccess) {
+      (void)hipGetLastError();
+      return XML_ERR_LAUNCH;
+    }
+    return XML_OK;
+  }
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
   XML_CHECK_LAUNCH();
   return XML_OK;
+}
+
+// ---- GEMM with the LayerNorm in its epilogue --------------------------------------------------------------------
+// Eligible when the rows span whole 256-column tiles (N % 256 == 0, at most 4 of them) and there is enough work for the
+// persistent kernel; the callers fall back to GEMM (f32 out) + LayerNorm otherwise.
+bool xmli_gemm_ln_eligible(int64_t M, int N, int K, int dt) {
+  const size_t kb = (size_t)K * dt_size(dt);
+  return kb % 128 == 0 && kb >= 256 && N % 256 == 0 && N / 256 <= 4 && (int64_t)cdiv(M, 256) * (N / 256) >= 768;
+}
+size_t xmli_gemm_ln_workspace_bytes(int64_t M, int N) {
+  return align_up((size_t)cdiv(M, 256) * 4, 256) + align_up((size_t)M * 2 * (N / 256 + 1) * 2 * 4, 256);
+}
+int xmli_gemm_ln(const void* A, const void* W, const float* bias, const void* addend, const float* ln_g, const float* ln_b,
+                 void* y, int64_t M, int N, int K, int relu, int add_mode, int seq_len, int dt, void* ln_ws,
+                 hipStream_t st) {
+  if (dt == XML_F32)
+    return launch_gemm256p<float, float, float, true>(A, W, bias, addend, y, M, N, K, relu, add_mode, seq_len, st, ln_g,
+                                                      ln_b, ln_ws);
+  return launch_gemm256p<bf16_t, bf16_t, bf16_t, true>(A, W, bias, addend, y, M, N, K, relu, add_mode, seq_len, st, ln_g,
+                                                        ln_b, ln_ws);
 }
 
 // worth it when every workgroup gets several tiles; below that the one-tile-per-workgroup kernel is as good

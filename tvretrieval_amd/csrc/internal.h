@@ -5,6 +5,13 @@
 // out = act(A W^T + bias) + addend ; add_mode 0 none / 1 positional table row (m % seq_len) / 2 residual row m
 int xmli_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
               int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st);
+// y = LN(act(A W^T + bias) + addend) * g + b with the LayerNorm in the GEMM epilogue (gemm256p.hip); callers check
+// xmli_gemm_ln_eligible and pass xmli_gemm_ln_workspace_bytes(M, N) bytes of scratch
+bool xmli_gemm_ln_eligible(int64_t M, int N, int K, int dt);
+size_t xmli_gemm_ln_workspace_bytes(int64_t M, int N);
+int xmli_gemm_ln(const void* A, const void* W, const float* bias, const void* addend, const float* ln_g, const float* ln_b,
+                 void* y, int64_t M, int N, int K, int relu, int add_mode, int seq_len, int dt, void* ln_ws,
+                 hipStream_t st);
 // y = LN(a + b) ; a may be f32 while b / y are dt ; rows of y have stride ld_out (>= d, tail zero-filled)
 int xmli_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
                        int64_t rows, int d, int ld_out, int dt, hipStream_t st);

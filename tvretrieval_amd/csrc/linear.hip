@@ -350,8 +350,12 @@ extern "C" int xml_linear(const void* x, const void* w, const float* b, void* y,
 //   ws layout: [ LN_in(x) as dt (rows x d_pad) | pre-LN f32 (rows x hidden) ],  d_pad = d_in rounded up to 8
 // ---------------------------------------------------------------------------------------------------
 static inline int k_pad8(int d_in) { return (d_in + 7) & ~7; }
+// (the second part holds either the f32 pre-LayerNorm rows of the 3-launch path or, when the GEMM takes the LayerNorm in
+// its epilogue, that kernel's per-row partial statistics -- the larger of the two is reserved)
 extern "C" size_t xml_linear_ln_relu_pos_workspace_bytes(int64_t rows, int d_in, int hidden, int dt) {
-  return align_up((size_t)rows * k_pad8(d_in) * dt_size(dt), 256) + align_up((size_t)rows * hidden * 4, 256);
+  const size_t pre = align_up((size_t)rows * hidden * 4, 256);
+  const size_t lnw = xmli_gemm_ln_eligible(rows, hidden, k_pad8(d_in), dt) ? xmli_gemm_ln_workspace_bytes(rows, hidden) : 0;
+  return align_up((size_t)rows * k_pad8(d_in) * dt_size(dt), 256) + (pre > lnw ? pre : lnw);
 }
 
 extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const float* ln_in_b,
@@ -371,6 +375,10 @@ extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_i
   char* pre = xn + align_up((size_t)rows * d_pad * dt_size(dt), 256);
   int rc = xmli_add_layernorm(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_pad, dt, st);
   if (rc) return rc;
+  if (xmli_gemm_ln_eligible(rows, hidden, d_pad, dt) &&    // LN_pos in the GEMM epilogue: two launches, no f32 round trip
+      xmli_gemm_ln(xn, w, b, pos, ln_pos_g, ln_pos_b, y, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, dt, pre,
+                   st) == XML_OK)
+    return XML_OK;                                         // (a refused cooperative launch falls through to the 3-launch path)
   rc = xmli_gemm(xn, w, b, pos, pre, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, /*out_f32*/ 1, dt, st);
   if (rc) return rc;
   return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, dt, st);

@@ -152,13 +152,28 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
     for (int j = 0; j < MAXNT; ++j) p[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (qt >= nqt) continue;
     const uint4 (&qa)[DCH] = qa_all[t];
+    if (nkt == MAXNT) {
+      // full-length sequences (the corpus-encode shape): no per-tile branch.  With `if (j < nkt)` around every MFMA each
+      // ds_read_b128 sat in its own basic block behind an `s_waitcnt lgkmcnt(0)` -- the LDS latency was paid 48 times
+      // per query tile (the phase probe: 18 K cycles for 96 MFMAs); here the reads of a chunk are issued as a batch
 #pragma unroll
-    for (int c = 0; c < DCH; ++c) {
+      for (int c = 0; c < DCH; ++c) {
+        uint4 b[MAXNT];
 #pragma unroll
-      for (int j = 0; j < MAXNT; ++j) {
-        if (j < nkt) {
-          const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
-          Mma<T>::chunk(p[t][j], qa[c], b);
+        for (int j = 0; j < MAXNT; ++j)
+          b[j] = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
+#pragma unroll
+        for (int j = 0; j < MAXNT; ++j) Mma<T>::chunk(p[t][j], qa[c], b[j]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < DCH; ++c) {
+#pragma unroll
+        for (int j = 0; j < MAXNT; ++j) {
+          if (j < nkt) {
+            const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
+            Mma<T>::chunk(p[t][j], qa[c], b);
+          }
         }
       }
     }
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
         p[t][j][r] = s;
         mx = fmaxf(mx, s);
       }
-      mx = lane16_max(mx);
+      mx = lane16_max_dpp(mx);      // DPP row rotations: the __shfl_xor form goes through the LDS crossbar (ds_bpermute)
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < MAXNT; ++j) {
@@ -189,7 +204,7 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
         p[t][j][r] = e;
         sum += e;
       }
-      sum = lane16_sum(sum);
+      sum = lane16_sum_dpp(sum);
       const float inv_sum = 1.0f / sum;
 #pragma unroll
       for (int j = 0; j < MAXNT; ++j) p[t][j][r] = abl == 3 ? p[t][j][r] : FAST ? p[t][j][r] * inv_sum : p[t][j][r] / sum;
@@ -266,6 +281,36 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
     }
     __builtin_amdgcn_wave_barrier();
     if (abl == 1 && o[0][0] != 12345.678f) continue;
+    if constexpr (TR && sizeof(OutT) == 2 && DH % 32 == 0 && DH >= 64) {
+      // bf16 out: through this wave's (now free) P patch in two halves of DH / 2 columns, then 16-byte stores -- the
+      // accumulator layout gives a lane 2-byte pieces of 4 rows (48 store instructions of four 32-byte segments each per
+      // tile; the CU's write path retires about one request per 5 cycles: half of phase B in the probe)
+      constexpr int HC = DH / 2;                        // columns per half
+      constexpr int HSTR = HC * 2 + 16;                 // patch row stride in bytes (<= the P patch's at lk >= HC)
+      constexpr int VPH = HC / 8;                       // 16-byte vectors per row and half
+      if (HSTR <= vt_stride) {
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+          for (int d = 0; d < DT16 / 2; ++d)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              DT<T>::st(reinterpret_cast<T*>(s_p + (fg * 4 + r) * HSTR) + d * 16 + fr, o[hf * (DT16 / 2) + d][r]);
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+#pragma unroll
+          for (int i = lane; i < 16 * VPH; i += 64) {
+            const int rr = i / VPH, cc = i % VPH;
+            const int row = qt * 16 + rr;
+            const uint4 v = *reinterpret_cast<const uint4*>(s_p + rr * HSTR + cc * 16);
+            if (row < lq) st_global16(out + ((int64_t)n * lq + row) * ldo + head * DH + hf * HC + cc * 8, v);
+          }
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+        }
+        continue;
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = qt * 16 + fg * 4 + r;
@@ -395,7 +440,7 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
         p[t][j][r] = sc;
         mx = fmaxf(mx, sc);
       }
-      mx = lane16_max(mx);
+      mx = lane16_max_dpp(mx);      // DPP row rotations: the __shfl_xor form goes through the LDS crossbar (ds_bpermute)
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -403,7 +448,7 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
         p[t][j][r] = e;
         sum += e;
       }
-      sum = lane16_sum(sum);
+      sum = lane16_sum_dpp(sum);
 #pragma unroll
       for (int j = 0; j < NT; ++j) p[t][j][r] = p[t][j][r] / sum;
     }

@@ -142,6 +142,15 @@ __device__ __forceinline__ float lane16_max_dpp(float v) {
 #undef XML_ROR
   return v;
 }
+__device__ __forceinline__ float lane16_sum_dpp(float v) {
+#define XML_ROR(x, n) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x120 + (n), 0xf, 0xf, false))
+  v += XML_ROR(v, 8);
+  v += XML_ROR(v, 4);
+  v += XML_ROR(v, 2);
+  v += XML_ROR(v, 1);
+#undef XML_ROR
+  return v;
+}
 __device__ __forceinline__ float lane16_sum(float v) {
 #pragma unroll
   for (int o = 8; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -328,12 +328,12 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
             float s8 = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s8 += v[j];
-            const float seg_sum = lane16_sum(s8);                 // the 16 lanes of a row: this wave's 128 columns
+            const float seg_sum = lane16_sum_dpp(s8);                 // the 16 lanes of a row: this wave's 128 columns
             const float seg_mean = seg_sum * (1.0f / 128.0f);
             float q8 = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) { const float c = v[j] - seg_mean; q8 += c * c; }
-            const float seg_m2 = lane16_sum(q8);
+            const float seg_m2 = lane16_sum_dpp(q8);
             if ((lane_e & 15) == 0) {
               float* pp = a.ln_part + ((m * (2 * a.tn)) + nt * 2 + wn) * 2;
               pp[0] = seg_sum; pp[1] = seg_m2;

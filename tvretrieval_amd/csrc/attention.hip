@@ -281,36 +281,8 @@ __global__ __launch_bounds__(256) void attention_core_kernel(const T* __restrict
     }
     __builtin_amdgcn_wave_barrier();
     if (abl == 1 && o[0][0] != 12345.678f) continue;
-    if constexpr (TR && sizeof(OutT) == 2 && DH % 32 == 0 && DH >= 64) {
-      // bf16 out: through this wave's (now free) P patch in two halves of DH / 2 columns, then 16-byte stores -- the
-      // accumulator layout gives a lane 2-byte pieces of 4 rows (48 store instructions of four 32-byte segments each per
-      // tile; the CU's write path retires about one request per 5 cycles: half of phase B in the probe)
-      constexpr int HC = DH / 2;                        // columns per half
-      constexpr int HSTR = HC * 2 + 16;                 // patch row stride in bytes (<= the P patch's at lk >= HC)
-      constexpr int VPH = HC / 8;                       // 16-byte vectors per row and half
-      if (HSTR <= vt_stride) {
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-#pragma unroll
-          for (int d = 0; d < DT16 / 2; ++d)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              DT<T>::st(reinterpret_cast<T*>(s_p + (fg * 4 + r) * HSTR) + d * 16 + fr, o[hf * (DT16 / 2) + d][r]);
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-#pragma unroll
-          for (int i = lane; i < 16 * VPH; i += 64) {
-            const int rr = i / VPH, cc = i % VPH;
-            const int row = qt * 16 + rr;
-            const uint4 v = *reinterpret_cast<const uint4*>(s_p + rr * HSTR + cc * 16);
-            if (row < lq) st_global16(out + ((int64_t)n * lq + row) * ldo + head * DH + hf * HC + cc * 8, v);
-          }
-          __builtin_amdgcn_s_waitcnt(0xc07f);
-          __builtin_amdgcn_wave_barrier();
-        }
-        continue;
-      }
-    }
+    // (bf16 out through the freed P patch as 16-byte stores was measured: 576 us per 2048-video call against 391 us for
+    // these 2-byte stores -- the extra LDS round trip and two wave barriers per half cost more than the write path saves)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = qt * 16 + fg * 4 + r;

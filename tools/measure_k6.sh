@@ -12,7 +12,7 @@ RAW=/tmp/prof_r02; OUT=$R/gpurun_out; mkdir -p $RAW $OUT
 CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
 CMD_S="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -o bench -- $CMD > $RAW/stats.log 2>&1
-echo "stats rc=$?"; tail -1 $RAW/stats.log | cut -c1-600 > $OUT/r02_bench_under_rocprof.json.log
+echo "stats rc=$?"; grep "^{\"metric\"" $RAW/stats.log | tail -1 > $OUT/r02_bench_under_rocprof.json.log
 f=$(find $RAW/stats -name "*kernel_stats.csv" | head -1)
 cp "$f" $OUT/r02_bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do

@@ -12,9 +12,15 @@
 //     which also waits for the stores just issued -> the values pass through an empty asm once per tile.
 //   * f32 rows written as 16-byte pieces at a 32-byte stride (every 128-byte line half-written per instruction, twice
 //     the write requests; the CU retires about one write request per 5 cycles) -> two column groups 64 apart.
-// What persistence itself adds: the issue side of the stream runs into the next tile while the current one finishes,
-// and the epilogue works in 4 KiB per-wave patches BESIDE the ring (160 KiB in all) while those DMAs are in flight:
+// What persistence itself adds: the issue side of the stream runs into the next tile while the current one finishes:
 // 750-810 -> 815-865 TF at K = 768 for >= 1024 tiles (the fixes above lifted both kernels from 660-700).
+// Round 2: the epilogue no longer goes through LDS at all (DIRECT, below): swapped MFMA operands put 4 consecutive
+// columns of one row in a lane, DPP row shifts pair neighbouring rows so that every store instruction writes whole
+// 128-byte lines: 734-793 -> 826-893 TF at K = 768, 1065 -> 1170-1220 TF at K = 3072 (same box, tools/bench_gemm.py,
+// XML_GEMM_VARIANT=3 is the staged epilogue).  A phase probe (tools/probe_gemm.py) puts the K loop at 83 % of a tile's
+// time now.  Tried on the way and NOT kept, both neutral: starting the workgroups a quarter tile apart (the epilogues of
+// the chip are not what limits the write path -- each CU's own store queue is), and skipping the counted vmcnt waits for
+// the first slices of a tile, which are already resident (peeling three steps made hipcc spill into the K loop prologue).
 // Same MFMA sequence per accumulator as gemm256_kernel: bitwise the same results.
 #include <type_traits>
 
@@ -35,6 +41,7 @@ struct G256pArgs {
   const float* ln_g;
   const float* ln_b;
   float ln_eps;
+  int probe;            // debug build only: phase probe on
 };
 
 __device__ __forceinline__ void g256p_dma_pair(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
@@ -72,6 +79,31 @@ template <> struct G256pInit<bf16_t> {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   }
 };
+#ifdef XML_DEBUG_VARIANTS
+// phase probe (debug build, XML_ABL = 9): s_memtime ticks of workgroup 0, summed over its tiles, per wave:
+//   [0] K loop  [1] epilogue until the bias is in LDS (includes the vmcnt(0) drain)  [2] row blocks + stores
+//   [3] LNE publish / wait / statistics  [4] LNE pass 2  [5] whole kernel  [6] tiles
+__device__ unsigned long long g_g256p_probe[8 * 8];
+__device__ unsigned int g_g256p_steps[8 * 64];       // per wave: ticks summed per slice step index (first 64 steps of a tile)
+extern "C" int xml_debug_read_gemm_steps(unsigned int* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_g256p_steps), sizeof(unsigned int) * 512) == hipSuccess ? 0 : -4;
+}
+extern "C" int xml_debug_read_gemm_probe(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_g256p_probe), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
+}
+#define G256P_T() (a.probe ? __builtin_amdgcn_s_memtime() : 0ull)
+#else
+#define G256P_T() 0ull
+#endif
+template <int CTRL>
+__device__ __forceinline__ uint4 dpp_u4(const uint4& v) {
+  uint4 r;
+  r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, CTRL, 0xf, 0xf, false);
+  r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, CTRL, 0xf, 0xf, false);
+  r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, CTRL, 0xf, 0xf, false);
+  r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, CTRL, 0xf, 0xf, false);
+  return r;
+}
 __device__ __forceinline__ int g256p_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // LNE: LayerNorm fused into the epilogue (K2 behind K1, BertSelfOutput; xml/model_components.py:76-89,313-317).  A row of
@@ -81,7 +113,15 @@ __device__ __forceinline__ int g256p_swz(int row) { return (0x78 >> (((row >> 2)
 // 256 workgroups are resident (one per CU) and walk the tiles in the same order, so the partners are at most a tile
 // apart; (3) combines the 2 tn partials of its rows in a fixed order (Chan's formula: deterministic, no E[x^2] - mean^2
 // cancellation) and normalises its own part in place.  No f32 round trip through HBM, no separate LayerNorm launch.
-template <typename T, typename OutT, typename AddT, bool LNE = false>
+//
+// DIRECT epilogue (default): the MFMA operands are SWAPPED (first operand = W fragment, second = A fragment), so an
+// accumulator holds 4 consecutive output COLUMNS of ONE output row per lane (row = lane & 15, columns 4 (lane >> 4) + r)
+// instead of 4 rows of one column, and W's rows are assigned to MFMA row indices such that two accumulators of a lane sit
+// side by side (bf16 out: 8 columns = one 16-byte store).  The results go from the accumulators straight to global
+// memory -- no LDS transpose (the former epilogue moved the tile through 4 KiB patches: 256 ds_write_b32 + 32
+// ds_read_b128 + 16 wave barriers per wave and tile; debug variant 3 keeps it for A/B measurements).  The products and the
+// order of the K summation per output element are unchanged: bitwise the same results.
+template <typename T, typename OutT, typename AddT, bool LNE = false, bool DIRECT = true>
 __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
@@ -185,7 +225,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 
   // ---- compute side ---------------------------------------------------------------------------------------------
   const int a_off = (wm * 64 + fr) * ROWB + ((fg ^ g256p_swz(fr)) << 4);
-  const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ g256p_swz(fr)) << 4);
+  // B (= W) fragment n, MFMA row index i = fr  ->  row of the wave's 128 W rows:
+  //   staged epilogue / f32 out:  n * 16 + i                                   (a lane's 4 columns: n * 16 + 4 fg + r)
+  //   DIRECT, 2-byte out (PAIRED): (n >> 1) * 32 + (i >> 2) * 8 + (n & 1) * 4 + (i & 3)
+  //                               (accumulators 2 q and 2 q + 1 of a lane = columns q * 32 + 8 fg + 0..7)
+  // Either way the 16 lanes of a ds_read_b128 group hit 16 distinct (row mod 4, swizzled slot) pairs: no bank conflicts.
+  constexpr bool PAIRED = DIRECT && sizeof(OutT) == 2;
+  const int rb_e = PAIRED ? (fr >> 2) * 8 + (fr & 3) : fr;
+  const int b_off = OPER_BYTES + (wn * 128 + rb_e) * ROWB + ((fg ^ g256p_swz(rb_e)) << 4);
+  const int b_off_o = OPER_BYTES + (wn * 128 + rb_e + 4) * ROWB + ((fg ^ g256p_swz(rb_e + 4)) << 4);   // PAIRED, odd n
+  auto b_frag = [&](const char* slot, int n) -> uint4 {
+    if constexpr (PAIRED) return *reinterpret_cast<const uint4*>(slot + ((n & 1) ? b_off_o : b_off) + (n >> 1) * 32 * ROWB);
+    else return *reinterpret_cast<const uint4*>(slot + b_off + n * 16 * ROWB);
+  };
   int c_k = 0, c_slot = 0;
   issue_slice(); issue_slice(); issue_slice(); issue_slice();
   if (grp == 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
@@ -193,26 +245,48 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
   __builtin_amdgcn_s_barrier();
 
   uint4 faA[4], faB[4], fbL[4], fbH[4];
-#pragma unroll
-  for (int m = 0; m < 4; ++m) faA[m] = *reinterpret_cast<const uint4*>(smem + a_off + m * 16 * ROWB);
-#pragma unroll
-  for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(smem + b_off + n * 16 * ROWB);
 
   auto run = [&](auto grp_tag) {
   constexpr bool GRP1 = decltype(grp_tag)::value;
+  unsigned long long pr[8] = {};
+  const unsigned long long pr_t0 = G256P_T();
+#ifdef XML_DEBUG_VARIANTS
+  unsigned int* sp = reinterpret_cast<unsigned int*>(smem + RING_BYTES + wave * 4096 + 2048);     // this wave's patch, upper half
+  if (a.probe && lane < 64) sp[lane] = 0;
+  int pstep = 0;
+  unsigned long long pst = 0;
+#endif
   for (;;) {      // one iteration = one tile
+    unsigned long long pt = G256P_T();
+#ifdef XML_DEBUG_VARIANTS
+    pstep = 0; pst = pt;
+#endif
     f32x4 acc[4][8];
+    // first fragments of the tile (read here rather than prefetched by the previous tile's last step: 32 registers that
+    // would otherwise stay live through the epilogue, next to 128 accumulators and a row of results)
+    {
+      const char* slot0 = smem + c_slot * SLOT_BYTES;
+#pragma unroll
+      for (int m = 0; m < 4; ++m) faA[m] = *reinterpret_cast<const uint4*>(slot0 + a_off + m * 16 * ROWB);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) fbL[n] = b_frag(slot0, n);
+    }
     auto slice_step = [&](uint4 (&fc)[4], uint4 (&fn)[4], auto init_tag) {
       constexpr bool INIT = decltype(init_tag)::value;
       const char* slot = smem + c_slot * SLOT_BYTES;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
+      for (int n = 0; n < 4; ++n) fbH[n] = b_frag(slot, n + 4);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          if constexpr (INIT) G256pInit<T>::chunk(acc[m][n], fc[m], fbL[n]);
-          else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+          if constexpr (DIRECT) {
+            if constexpr (INIT) G256pInit<T>::chunk(acc[m][n], fbL[n], fc[m]);
+            else Mma<T>::chunk(acc[m][n], fbL[n], fc[m]);
+          } else {
+            if constexpr (INIT) G256pInit<T>::chunk(acc[m][n], fc[m], fbL[n]);
+            else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+          }
         }
       if (!GRP1) __builtin_amdgcn_s_waitcnt(0x007c);      // vmcnt(12) lgkmcnt(0): 6 pieces per slice, two slices young
       else __builtin_amdgcn_s_waitcnt(0x0074);            // vmcnt(4)
@@ -223,7 +297,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 #pragma unroll
         for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
 #pragma unroll
-        for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
+        for (int n = 0; n < 4; ++n) fbL[n] = b_frag(nslot, n);
       };
       if (!GRP1) { next_reads(); issue_slice(); }
       __builtin_amdgcn_sched_barrier(0);
@@ -231,11 +305,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          if constexpr (INIT) G256pInit<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
-          else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+          if constexpr (DIRECT) {
+            if constexpr (INIT) G256pInit<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
+            else Mma<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
+          } else {
+            if constexpr (INIT) G256pInit<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+            else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
       if (GRP1) { next_reads(); issue_slice(); }
+#ifdef XML_DEBUG_VARIANTS
+      if (a.probe) {
+        const unsigned long long t = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && pstep < 64) sp[pstep] += (unsigned int)(t - pst);
+        pst = t; ++pstep;
+      }
+#endif
     };
     slice_step(faA, faB, std::true_type{});
     slice_step(faB, faA, std::false_type{});
@@ -244,10 +330,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       slice_step(faB, faA, std::false_type{});
     }
 
-    // ---- epilogue: 8 rows x 128 columns of f32 at a time through this wave's 4 KiB patch -> 16-byte coalesced stores
-    // (an MFMA accumulator holds 4 rows x 1 column per lane).  Pass p covers tile rows 8 p .. 8 p + 7: the two lane
-    // groups fg = 2 (p & 1), 2 (p & 1) + 1 of row block p >> 1.  Patch column XOR 16 for rows 4..7: the two groups
-    // write different banks; a lane's 8 consecutive columns stay contiguous.
+    { const unsigned long long t = G256P_T(); pr[0] += t - pt; pt = t; }
     {
       int64_t mt; int nt;
       tile_mt_nt(c_k, mt, nt);
@@ -268,6 +351,135 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       const int oc1 = F32O ? oc0 + 64 : oc0 + 4;
       const int nc0 = n0 + wn * 128 + oc0, nc1 = n0 + wn * 128 + oc1;
       const bool ok0 = nc0 + 4 <= N, ok1 = nc1 + 4 <= N;           // N % 8 == 0 (eligibility): whole groups only
+      // DIRECT: group q of this lane = GC consecutive columns of ONE row (row = fr of row block m):
+      //   2-byte out: q = 0..3, columns q * 32 + 8 fg .. + 7  (accumulators 2 q, 2 q + 1);  4-byte out: q = 0..7, q * 16 + 4 fg .. + 3
+      // A store instruction writes 16 rows x 64 contiguous bytes.
+      constexpr int GC = PAIRED ? 8 : 4;
+      constexpr int NGRP = 128 / (4 * GC);
+      static_assert(GC * sizeof(AddT) <= 16, "addend group wider than one 16-byte load");
+      int gcol[DIRECT ? NGRP : 1];
+      bool gok[DIRECT ? NGRP : 1];
+      int pcol[DIRECT ? NGRP / 2 : 1];      // column this lane STORES for group pair pq (see the stores below)
+      if constexpr (DIRECT) {
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q) {
+          gcol[q] = n0 + wn * 128 + q * (4 * GC) + fg_e * GC;
+          gok[q] = gcol[q] + GC <= N;                              // N % 8 == 0 (eligibility): whole groups only
+        }
+#pragma unroll
+        for (int pq = 0; pq < NGRP / 2; ++pq) pcol[pq] = n0 + wn * 128 + pq * (8 * GC) + (fr_e & 1) * (4 * GC) + fg_e * GC;
+        // bias of this wave's 128 columns -> its LDS patch (floats 256..383), read back per row block below: held in
+        // registers for the whole epilogue it is 32 VGPRs on top of 128 accumulators + a row of results + its addend.
+        // (hipcc cannot count the inline-asm DMAs and guards the use of a loaded register with s_waitcnt vmcnt(0): one such
+        // wait per tile, here)
+        {
+          float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+          const int bc = n0 + wn * 128 + (lane_e & 31) * 4;
+          if (a.bias && bc + 4 <= N) b4 = *reinterpret_cast<const float4*>(a.bias + bc);
+          if (lane_e < 32) *reinterpret_cast<float4*>(patch + 256 + lane_e * 4) = b4;
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+        }
+        { const unsigned long long t = G256P_T(); pr[1] += t - pt; pt = t; }
+#pragma unroll
+        for (int m4 = 0; m4 < 4; ++m4) {
+          const int lrow = wm * 64 + m4 * 16 + fr_e;
+          const int64_t m = m0 + lrow;
+          const bool rok = m < M;
+          float v[NGRP][GC];
+          int boff = fg_e * GC;                                       // opaque per row block: keeps the bias reads from being
+          asm volatile("" : "+v"(boff));                              // hoisted (and held in 32 registers) across the loop
+#pragma unroll
+          for (int q = 0; q < NGRP; ++q) {
+            float gb[GC];
+#pragma unroll
+            for (int e = 0; e < GC; e += 4) {
+              const float4 b4 = *reinterpret_cast<const float4*>(patch + 256 + q * (4 * GC) + boff + e);
+              gb[e] = b4.x; gb[e + 1] = b4.y; gb[e + 2] = b4.z; gb[e + 3] = b4.w;
+            }
+#pragma unroll
+            for (int e = 0; e < GC; ++e) {
+              float x = (PAIRED ? acc[m4][2 * q + (e >> 2)][e & 3] : acc[m4][q][e & 3]) + gb[e];
+              if (a.relu) x = fmaxf(x, 0.f);
+              v[q][e] = x;
+            }
+          }
+          if (a.add_mode) {
+            const int64_t arow = a.add_mode == 1 ? (int64_t)((m0_mod + (uint32_t)lrow) % (uint32_t)a.seq_len) : m;
+            constexpr int AB = GC * (int)sizeof(AddT);            // addend bytes per group: 16 or 8
+#pragma unroll
+            for (int qb = 0; qb < NGRP; qb += 4) {                   // the loads of four groups first, then the arithmetic
+              uint4 ad[4];
+#pragma unroll
+              for (int qi = 0; qi < 4; ++qi) {
+                const int q = qb + qi;
+                ad[qi] = make_uint4(0u, 0u, 0u, 0u);
+                if (rok && gok[q]) {
+                  if constexpr (AB == 16) ad[qi] = ld_global16(addend + arow * N + gcol[q]);
+                  else { const uint2 u = *reinterpret_cast<const uint2*>(addend + arow * N + gcol[q]); ad[qi].x = u.x; ad[qi].y = u.y; }
+                }
+              }
+#pragma unroll
+              for (int qi = 0; qi < 4; ++qi) {
+                float av[8];
+                if constexpr (sizeof(AddT) == 2) unpack16<bf16_t>(ad[qi], av);   // (AB == 8: the upper four are zeros, unused)
+                else unpack16<float>(ad[qi], av);
+#pragma unroll
+                for (int e = 0; e < GC; ++e) v[qb + qi][e] += av[e];
+              }
+            }
+          }
+          if constexpr (LNE) {      // (N % 256 == 0: every group is whole)
+            float s = 0.f;
+#pragma unroll
+            for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+              for (int e = 0; e < GC; ++e) s += v[q][e];
+            s += __shfl_xor(s, 16, 64);                               // the 4 lanes (fg) that share the row: this wave's 128 columns
+            s += __shfl_xor(s, 32, 64);
+            const float seg_mean = s * (1.0f / 128.0f);
+            float c2 = 0.f;
+#pragma unroll
+            for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+              for (int e = 0; e < GC; ++e) { const float c = v[q][e] - seg_mean; c2 += c * c; }
+            c2 += __shfl_xor(c2, 16, 64);
+            c2 += __shfl_xor(c2, 32, 64);
+            if (fg_e == 0 && rok) {
+              float* pp = a.ln_part + ((m * (2 * a.tn)) + nt * 2 + wn) * 2;
+              pp[0] = s; pp[1] = c2;
+            }
+          }
+          // Stores in FULL 128-byte lines.  Written as they lie, groups (q, fg = 0..3) of a row are 64 contiguous bytes: every
+          // store instruction touches 16 rows x half a line, 2048 line requests per tile -- and the CU's write path retires
+          // one request per 5-8 cycles (the phase probe: 17 K cycles to drain a tile, a third of its time; vmcnt counts the
+          // stores, so the K loop's counted waits block behind them).  Groups 2 p and 2 p + 1 of a row are the two halves of
+          // one line: the EVEN store of a pair writes rows fr & ~1 -- even lanes their own group 2 p, odd lanes group 2 p + 1
+          // of the row BELOW them (DPP row_shr:1) --, the ODD store rows fr | 1 likewise (row_shl:1): 8 rows x one whole
+          // line per instruction, 1024 requests per tile, no LDS.
+          {
+            uint4 pk[NGRP];
+#pragma unroll
+            for (int q = 0; q < NGRP; ++q) pk[q] = pack16<OutT>(v[q]);
+            const bool odd = (fr_e & 1) != 0;
+            const int64_t m_even = m0 + wm * 64 + m4 * 16 + (fr_e & ~1);
+#pragma unroll
+            for (int pq = 0; pq < NGRP / 2; ++pq) {
+              const uint4 dn = dpp_u4<0x111>(pk[2 * pq + 1]);       // row_shr:1: lane i <- lane i - 1
+              const uint4 up = dpp_u4<0x101>(pk[2 * pq]);           // row_shl:1: lane i <- lane i + 1
+              // (component-wise selects: `odd ? a : b` on the struct type becomes a select of stack ADDRESSES + a scratch load)
+              const uint4 own_e = pk[2 * pq], own_o = pk[2 * pq + 1];
+              const uint4 d_even = make_uint4(odd ? dn.x : own_e.x, odd ? dn.y : own_e.y, odd ? dn.z : own_e.z, odd ? dn.w : own_e.w);
+              const uint4 d_odd = make_uint4(odd ? own_o.x : up.x, odd ? own_o.y : up.y, odd ? own_o.z : up.z, odd ? own_o.w : up.w);
+              const int col = pcol[pq];
+              if (col + GC <= N) {
+                if (m_even < M) st_global16(out + m_even * N + col, d_even);
+                if (m_even + 1 < M) st_global16(out + (m_even + 1) * N + col, d_odd);
+              }
+            }
+          }
+        }
+      } else {
       float bv[8];
       {
         float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
@@ -349,6 +561,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
       }
+      }   // !DIRECT
+      { const unsigned long long t = G256P_T(); pr[2] += t - pt; pt = t; }
       if constexpr (LNE) {
         // ---- publish, wait for the row block's other column tiles, normalise in place -------------------------------
         // The partners share this XCD's L2 (tile walk above): stores are write-through, so "my stores are acknowledged"
@@ -391,6 +605,54 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
           patch[lane_e * 2] = mean;
           patch[lane_e * 2 + 1] = rstd;
         }
+        { const unsigned long long t = G256P_T(); pr[3] += t - pt; pt = t; }
+        if constexpr (DIRECT) {
+          __builtin_amdgcn_s_waitcnt(0xc07f);
+          __builtin_amdgcn_wave_barrier();
+          // the same (row, group) walk as above: a lane re-reads exactly what it wrote.  The accumulators are dead: all loads
+          // of a batch of row blocks first, one wait, then arithmetic and stores
+          float gg[NGRP / 2][GC], gbt[NGRP / 2][GC];               // gamma / beta of the columns this lane stores
+#pragma unroll
+          for (int pq = 0; pq < NGRP / 2; ++pq)
+#pragma unroll
+            for (int e = 0; e < GC; e += 4) {
+              const float4 g4 = *reinterpret_cast<const float4*>(a.ln_g + pcol[pq] + e);
+              const float4 b4 = *reinterpret_cast<const float4*>(a.ln_b + pcol[pq] + e);
+              gg[pq][e] = g4.x; gg[pq][e + 1] = g4.y; gg[pq][e + 2] = g4.z; gg[pq][e + 3] = g4.w;
+              gbt[pq][e] = b4.x; gbt[pq][e + 1] = b4.y; gbt[pq][e + 2] = b4.z; gbt[pq][e + 3] = b4.w;
+            }
+          constexpr int MB = sizeof(OutT) == 4 ? 2 : 4;              // row blocks per batch (16 x 16-byte loads per lane)
+#pragma unroll
+          for (int mb = 0; mb < 4; mb += MB) {
+            uint4 rbd[MB][NGRP / 2][2];
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi) {
+              const int64_t m_even = m0 + wm * 64 + (mb + mi) * 16 + (fr_e & ~1);
+#pragma unroll
+              for (int par = 0; par < 2; ++par) {
+                const int64_t ms = m_even + par < M ? m_even + par : m0;   // (rows beyond M: any valid row, the result is not stored)
+#pragma unroll
+                for (int pq = 0; pq < NGRP / 2; ++pq) rbd[mi][pq][par] = ld_global16(out + ms * N + pcol[pq]);
+              }
+            }
+#pragma unroll
+            for (int mi = 0; mi < MB; ++mi)
+#pragma unroll
+              for (int par = 0; par < 2; ++par) {
+                const int lr64 = (mb + mi) * 16 + (fr_e & ~1) + par;
+                const int64_t m = m0 + wm * 64 + lr64;
+                const float mean = patch[lr64 * 2], rstd = patch[lr64 * 2 + 1];
+#pragma unroll
+                for (int pq = 0; pq < NGRP / 2; ++pq) {
+                  float v[8];
+                  unpack16<OutT>(rbd[mi][pq][par], v);
+#pragma unroll
+                  for (int e = 0; e < GC; ++e) v[e] = (v[e] - mean) * rstd * gg[pq][e] + gbt[pq][e];
+                  if (m < M) st_global16(out + m * N + pcol[pq], pack16<OutT>(v));
+                }
+              }
+          }
+        } else {
         float gv[8], bb[8];
         {
           const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + nc0), g1 = *reinterpret_cast<const float4*>(a.ln_g + nc1);
@@ -435,13 +697,23 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
             }
           }
         }
+        }   // !DIRECT
         __builtin_amdgcn_s_waitcnt(0xc07f);
         __builtin_amdgcn_wave_barrier();
       }
     }
+    { const unsigned long long t = G256P_T(); pr[4] += t - pt; pt = t; }
+    ++pr[6];
     ++c_k;
     if (tile_of(c_k) >= a.n_tiles) break;
   }
+#ifdef XML_DEBUG_VARIANTS
+  if (a.probe && blockIdx.x == 0 && lane == 0) {
+    pr[5] = __builtin_amdgcn_s_memtime() - pr_t0;
+    for (int i = 0; i < 8; ++i) g_g256p_probe[wave * 8 + i] = pr[i];
+    for (int i = 0; i < 64; ++i) g_g256p_steps[wave * 64 + i] = sp[i];
+  }
+#endif
   };
   if (grp) run(std::true_type{});
   else run(std::false_type{});
@@ -454,7 +726,7 @@ __global__ void g256p_zero_kernel(int* p, int n) {
   if (i < n) p[i] = 0;
 }
 
-template <typename T, typename OutT, typename AddT, bool LNE = false>
+template <typename T, typename OutT, typename AddT, bool LNE = false, bool DIRECT = true>
 static int launch_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
                            int N, int K, int relu, int add_mode, int seq_len, hipStream_t st, const float* ln_g = nullptr,
                            const float* ln_b = nullptr, void* ln_ws = nullptr) {
@@ -464,6 +736,7 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
   a.tn = cdiv(N, 256);
   a.n_tiles = (int64_t)cdiv(M, 256) * a.tn;
   a.ln_part = nullptr; a.ln_count = nullptr; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+  a.probe = g_q2c_ablation == 9;
   if (LNE) {
     const int n_blocks = (int)cdiv(M, 256);
     a.ln_count = (int*)ln_ws;
@@ -471,8 +744,13 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
     hipLaunchKernelGGL(g256p_zero_kernel, dim3(cdiv(n_blocks, 256)), dim3(256), 0, st, a.ln_count, n_blocks);
   }
   const int lds = 4 * 2 * 256 * 64 + 8 * 4096;          // ring + patches = 160 KiB
-  auto kern = gemm256p_kernel<T, OutT, AddT, LNE>;
-  if (!xml_lds_attr_once<gemm256p_kernel<T, OutT, AddT, LNE>>(lds)) return XML_ERR_LAUNCH;
+#ifdef XML_DEBUG_VARIANTS
+  if (DIRECT && g_gemm_variant == 3)      // A/B: the LDS-staged epilogue
+    return launch_gemm256p<T, OutT, AddT, LNE, false>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st, ln_g, ln_b,
+                                                      ln_ws);
+#endif
+  auto kern = gemm256p_kernel<T, OutT, AddT, LNE, DIRECT>;
+  if (!xml_lds_attr_once<gemm256p_kernel<T, OutT, AddT, LNE, DIRECT>>(lds)) return XML_ERR_LAUNCH;
   if (LNE) {
     // the workgroups of a row block wait for each other: ALL 256 must be resident at once.  A cooperative launch makes the
     // runtime guarantee that (and serialises two such kernels issued on different streams, which could otherwise each

@@ -19,10 +19,14 @@ for m, n, k in [(300000, 2304, 768), (300000, 768, 768), (262144, 768, 3072)]:
     for _ in range(3):
         ops.linear(x, w, b)
     torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); ops.linear(x, w, b); e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1)
     buf = (ctypes.c_ulonglong * 64)()
     lib.xml_debug_read_gemm_probe.argtypes = [ctypes.c_void_p]
     assert lib.xml_debug_read_gemm_probe(buf) == 0
-    print("M %d N %d K %d  (s_memtime ticks = 10 ns; per tile averages, workgroup 0)" % (m, n, k))
+    print("M %d N %d K %d: %.3f ms, workgroup 0 wave 0 ran %d ticks -> %.0f ticks per us" % (m, n, k, ms, buf[5], buf[5] / ms / 1e3))
     sb = (ctypes.c_uint * 512)()
     lib.xml_debug_read_gemm_steps.argtypes = [ctypes.c_void_p]
     assert lib.xml_debug_read_gemm_steps(sb) == 0

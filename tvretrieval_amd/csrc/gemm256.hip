@@ -44,6 +44,15 @@ template <> struct G256Init<bf16_t> {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   }
 };
+template <int CTRL>
+__device__ __forceinline__ uint4 g256_dpp_u4(const uint4& v) {
+  uint4 r;
+  r.x = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.x, CTRL, 0xf, 0xf, false);
+  r.y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.y, CTRL, 0xf, 0xf, false);
+  r.z = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.z, CTRL, 0xf, 0xf, false);
+  r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, CTRL, 0xf, 0xf, false);
+  return r;
+}
 __device__ __forceinline__ int g256_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // RAGGED_N: N % 8 != 0 -> per-element tail stores (kept out of the common instantiation: its 64-bit modulo and
@@ -101,7 +110,19 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   };
 
   const int a_off = (wm * 64 + fr) * ROWB + ((fg ^ g256_swz(fr)) << 4);
-  const int b_off = OPER_BYTES + (wn * 128 + fr) * ROWB + ((fg ^ g256_swz(fr)) << 4);
+  // DIRECT epilogue (N % 8 == 0; see gemm256p.hip): swapped MFMA operands -> a lane's accumulator holds 4 consecutive
+  // columns of ONE row; 2-byte outputs pair the accumulators (W row of fragment n, MFMA row index i:
+  // (n >> 1) * 32 + (i >> 2) * 8 + (n & 1) * 4 + (i & 3)) so that a lane owns 8 consecutive columns.  Same products and
+  // K order per element: bitwise the results of the staged epilogue (which the ragged-N instantiation keeps).
+  constexpr bool DIRECT = !RAGGED_N;
+  constexpr bool PAIRED = DIRECT && sizeof(OutT) == 2;
+  const int rb_e = PAIRED ? (fr >> 2) * 8 + (fr & 3) : fr;
+  const int b_off = OPER_BYTES + (wn * 128 + rb_e) * ROWB + ((fg ^ g256_swz(rb_e)) << 4);
+  const int b_off_o = OPER_BYTES + (wn * 128 + rb_e + 4) * ROWB + ((fg ^ g256_swz(rb_e + 4)) << 4);   // PAIRED, odd n
+  auto b_frag = [&](const char* slot, int n) -> uint4 {
+    if constexpr (PAIRED) return *reinterpret_cast<const uint4*>(slot + ((n & 1) ? b_off_o : b_off) + (n >> 1) * 32 * ROWB);
+    else return *reinterpret_cast<const uint4*>(slot + b_off + n * 16 * ROWB);
+  };
 
   issue_slice(); issue_slice(); issue_slice(); issue_slice();      // n_slices >= 4 (eligibility)
   asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
@@ -112,7 +133,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 #pragma unroll
   for (int m = 0; m < 4; ++m) faA[m] = *reinterpret_cast<const uint4*>(smem + a_off + m * 16 * ROWB);
 #pragma unroll
-  for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(smem + b_off + n * 16 * ROWB);
+  for (int n = 0; n < 4; ++n) fbL[n] = b_frag(smem, n);
 
   // One step = one 32-wide K slice (see q2c_persist.hip for the schedule).  The tail of the stream is PEELED instead
   // of tested: MODE 0 = steady state (wait for slice c+1 with two younger slices in flight, read, issue slice c+4),
@@ -127,13 +148,18 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
       constexpr bool INIT = decltype(init_tag)::value;
       const char* slot = smem + (c_slice & 3) * SLOT_BYTES;
 #pragma unroll
-      for (int n = 0; n < 4; ++n) fbH[n] = *reinterpret_cast<const uint4*>(slot + b_off + (n + 4) * 16 * ROWB);
+      for (int n = 0; n < 4; ++n) fbH[n] = b_frag(slot, n + 4);
 #pragma unroll
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          if constexpr (INIT) G256Init<T>::chunk(acc[m][n], fc[m], fbL[n]);
-          else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+          if constexpr (DIRECT) {
+            if constexpr (INIT) G256Init<T>::chunk(acc[m][n], fbL[n], fc[m]);
+            else Mma<T>::chunk(acc[m][n], fbL[n], fc[m]);
+          } else {
+            if constexpr (INIT) G256Init<T>::chunk(acc[m][n], fc[m], fbL[n]);
+            else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+          }
         }
       if constexpr (MODE <= 1) __builtin_amdgcn_s_waitcnt(0x0078);        // vmcnt(8) lgkmcnt(0)
       else if constexpr (MODE == 2) __builtin_amdgcn_s_waitcnt(0x0074);   // vmcnt(4) lgkmcnt(0)
@@ -146,7 +172,7 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 #pragma unroll
           for (int m = 0; m < 4; ++m) fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
 #pragma unroll
-          for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
+          for (int n = 0; n < 4; ++n) fbL[n] = b_frag(nslot, n);
         }
         if constexpr (MODE == 0) issue_slice();
       };
@@ -156,8 +182,13 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
       for (int m = 0; m < 4; ++m)
 #pragma unroll
         for (int n = 0; n < 4; ++n) {
-          if constexpr (INIT) G256Init<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
-          else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+          if constexpr (DIRECT) {
+            if constexpr (INIT) G256Init<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
+            else Mma<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
+          } else {
+            if constexpr (INIT) G256Init<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+            else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
       if (GRP1) preamble();
@@ -186,6 +217,89 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
   if (wave >> 2) run(std::true_type{});
   else run(std::false_type{});
 
+  // ---- DIRECT epilogue: accumulators -> global memory, whole 128-byte lines per store instruction (gemm256p.hip) ------
+  if constexpr (DIRECT) {
+    constexpr int GC = PAIRED ? 8 : 4;            // columns per group: group q of a lane = GC consecutive columns of row fr
+    constexpr int NGRP = 128 / (4 * GC);
+    static_assert(GC * sizeof(AddT) <= 16, "addend group wider than one 16-byte load");
+    int gcol[NGRP], pcol[NGRP / 2];
+    bool gok[NGRP];
+    float gb[NGRP][GC];
+#pragma unroll
+    for (int q = 0; q < NGRP; ++q) {
+      gcol[q] = n0 + wn * 128 + q * (4 * GC) + fg * GC;
+      gok[q] = gcol[q] + GC <= N;
+#pragma unroll
+      for (int e = 0; e < GC; e += 4) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (bias && gok[q]) b4 = *reinterpret_cast<const float4*>(bias + gcol[q] + e);
+        gb[q][e] = b4.x; gb[q][e + 1] = b4.y; gb[q][e + 2] = b4.z; gb[q][e + 3] = b4.w;
+      }
+    }
+#pragma unroll
+    for (int pq = 0; pq < NGRP / 2; ++pq) pcol[pq] = n0 + wn * 128 + pq * (8 * GC) + (fr & 1) * (4 * GC) + fg * GC;
+    const uint32_t m0_mod = add_mode == 1 ? (uint32_t)(m0 % seq_len) : 0u;       // one 64-bit modulo per tile
+    const bool odd = (fr & 1) != 0;
+#pragma unroll
+    for (int m4 = 0; m4 < 4; ++m4) {
+      const int lrow = wm * 64 + m4 * 16 + fr;
+      const int64_t m = m0 + lrow;
+      const bool rok = m < M;
+      float v[NGRP][GC];
+#pragma unroll
+      for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+        for (int e = 0; e < GC; ++e) {
+          float x = (PAIRED ? acc[m4][2 * q + (e >> 2)][e & 3] : acc[m4][q][e & 3]) + gb[q][e];
+          if (relu) x = fmaxf(x, 0.f);
+          v[q][e] = x;
+        }
+      if (add_mode) {
+        const int64_t arow = add_mode == 1 ? (int64_t)((m0_mod + (uint32_t)lrow) % (uint32_t)seq_len) : m;
+        constexpr int AB = GC * (int)sizeof(AddT);
+#pragma unroll
+        for (int qb = 0; qb < NGRP; qb += 4) {
+          uint4 ad[4];
+#pragma unroll
+          for (int qi = 0; qi < 4; ++qi) {
+            const int q = qb + qi;
+            ad[qi] = make_uint4(0u, 0u, 0u, 0u);
+            if (rok && gok[q]) {
+              if constexpr (AB == 16) ad[qi] = ld_global16(addend + arow * N + gcol[q]);
+              else { const uint2 u = *reinterpret_cast<const uint2*>(addend + arow * N + gcol[q]); ad[qi].x = u.x; ad[qi].y = u.y; }
+            }
+          }
+#pragma unroll
+          for (int qi = 0; qi < 4; ++qi) {
+            float av[8];
+            if constexpr (sizeof(AddT) == 2) unpack16<bf16_t>(ad[qi], av);
+            else unpack16<float>(ad[qi], av);
+#pragma unroll
+            for (int e = 0; e < GC; ++e) v[qb + qi][e] += av[e];
+          }
+        }
+      }
+      // groups 2 p and 2 p + 1 of a row are the halves of one 128-byte line: the EVEN store writes rows fr & ~1 (odd lanes
+      // bring group 2 p + 1 of the row below them, DPP row_shr:1), the ODD store rows fr | 1 (row_shl:1)
+      uint4 pk[NGRP];
+#pragma unroll
+      for (int q = 0; q < NGRP; ++q) pk[q] = pack16<OutT>(v[q]);
+      const int64_t m_even = m0 + wm * 64 + m4 * 16 + (fr & ~1);
+#pragma unroll
+      for (int pq = 0; pq < NGRP / 2; ++pq) {
+        const uint4 own_e = pk[2 * pq], own_o = pk[2 * pq + 1];
+        const uint4 dn = g256_dpp_u4<0x111>(own_o);
+        const uint4 up = g256_dpp_u4<0x101>(own_e);
+        const uint4 d_even = make_uint4(odd ? dn.x : own_e.x, odd ? dn.y : own_e.y, odd ? dn.z : own_e.z, odd ? dn.w : own_e.w);
+        const uint4 d_odd = make_uint4(odd ? own_o.x : up.x, odd ? own_o.y : up.y, odd ? own_o.z : up.z, odd ? own_o.w : up.w);
+        if (pcol[pq] + GC <= N) {
+          if (m_even < M) st_global16(out + m_even * N + pcol[pq], d_even);
+          if (m_even + 1 < M) st_global16(out + (m_even + 1) * N + pcol[pq], d_odd);
+        }
+      }
+    }
+    return;
+  }
   // ---- epilogue through LDS: 16-byte coalesced stores --------------------------------------------------------
   // An MFMA accumulator holds 4 rows x 1 column per lane, so direct stores are 2- or 4-byte pieces (32-64 B
   // segments).  Each wave instead parks 32 rows x 128 columns of f32 in its private 16.5 KiB patch of the (now idle)

@@ -289,6 +289,24 @@ int xml_merge_heads(const void* src, void* dst, int ld, int col0, int64_t n, int
 int xml_attn_softmax(const float* S, const float* dP, const float* q_mask, const float* k_mask, void* P,
                      void* PT, void* dS, void* dST, int64_t n, int heads, int lq, int lk, int lq8, int lk8,
                      float sqrt_dh, int dt, xml_stream_t stream);
+/* Fused training attention (bf16 storage; xml/model_components.py:266-303 incl. the probabilities dropout :297), one
+ * launch each way instead of the split_heads / batched GEMM / xml_attn_softmax / xml_dropout / merge_heads chain:
+ *   fwd   out (n, lq, ldo) head h columns [h dh, (h+1) dh)  =  dropout(softmax(Q K^T / sqrt(dh) + mask bias)) V
+ *   bwd   dq / dk / dv (same row layouts as q / k / v, leading dimensions lddq / lddk / lddv) from dout; P is recomputed,
+ *         nothing but q, k, v has to be kept from the forward pass.
+ * q (n, lq, ldq), k / v (n, lk, ldk / ldv): head h = columns [h dh, (h+1) dh) from the given pointers (column blocks of a
+ * fused QKV tensor are passed as offset pointers).  Leading dimensions in elements, multiples of 8.  lq, lk <= 128;
+ * dh = hidden / n_heads in {32, 64, 96, 128, 192}.  The dropout mask is xml_dropout's hash at the element's index in a
+ * (n * heads, ceil8(lq), ceil8(lk)) tensor: the same elements the unfused chain drops for this seed.  p_drop = 0: none.
+ * xml_attention_train_supported says whether a shape / dtype is served (callers keep the unfused chain otherwise). */
+int xml_attention_train_supported(int lq, int lk, int hidden, int n_heads, int dt);
+int xml_attention_train_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
+                            const float* k_mask, void* out, int ldo, int64_t n, int lq, int lk, int hidden, int n_heads,
+                            float p_drop, uint64_t seed, int dt, xml_stream_t stream);
+int xml_attention_train_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
+                            const float* k_mask, const void* dout, int ldo, void* dq, int lddq, void* dk, int lddk,
+                            void* dv, int lddv, int64_t n, int lq, int lk, int hidden, int n_heads, float p_drop,
+                            uint64_t seed, int dt, xml_stream_t stream);
 /* get_modularized_queries backward (xml/model_xml.py:410-423): denc (n, lq, hidden) dt written, dw_m += . */
 int xml_modular_pool_bwd(const void* enc, const float* mask, const float* w_m, const void* dout, void* denc,
                          float* dw_m, int64_t n, int lq, int hidden, int n_mod, int dt, xml_stream_t stream);

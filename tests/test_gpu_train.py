@@ -468,6 +468,59 @@ def test_attention_probs_dropout_matches_masked_reference():
              [True, True, True], tol=5e-5)
 
 
+@pytest.mark.parametrize("shape", [(3, 100, 100, 768, 4), (2, 30, 30, 768, 4), (2, 40, 72, 256, 4), (2, 128, 128, 128, 4),
+                                   (2, 17, 128, 768, 4)])
+@pytest.mark.parametrize("p_drop", [0.0, 0.2])
+def test_fused_training_attention_vs_reference_and_unfused_chain(shape, p_drop):
+    """attention_train.hip (bf16: one launch forward, one backward, P recomputed) against (1) float64 torch attention on
+    the bf16-rounded inputs with the SAME dropout mask injected (bf16 tolerances) and (2) the unfused bf16 chain it
+    replaces -- both the separate-q/k/v form with a query mask and the fused-QKV self-attention form."""
+    from tvretrieval_amd.autograd import AttentionCoreFn, AttentionQkvFn
+    from tvretrieval_amd import train_ops as TO
+    n, lq, lk, hsz, heads = shape
+    dh, seed = hsz // heads, 777
+    bf = torch.bfloat16
+    assert TO.attention_train_supported(lq, lk, hsz, heads, bf)
+    q, k, v = (rnd(n, lq, hsz, seed=1).to(bf), rnd(n, lk, hsz, seed=2).to(bf), rnd(n, lk, hsz, seed=3).to(bf))
+    km, qm = lens_mask(n, lk, seed=4, lo=5), lens_mask(n, lq, seed=5, lo=3)
+    gout = rnd(n, lq, hsz, seed=6).to(bf)
+    lq8, lk8 = (lq + 7) // 8 * 8, (lk + 7) // 8 * 8
+    mask = torch.ones(n, heads, lq, lk, device=DEV, dtype=torch.float64)
+    if p_drop > 0:
+        mask = TO.dropout(torch.ones(n * heads, lq8, lk8, device=DEV), p_drop, seed).view(n, heads, lq8, lk8)[:, :, :lq, :lk].double()
+
+    def run(fn, *ts):
+        leaves = [t.clone().requires_grad_(True) for t in ts]
+        y = fn(*leaves)
+        y.backward(gout.to(y.dtype))
+        return [y] + [t.grad for t in leaves]
+
+    def ref(q, k, v):
+        add = (1 - qm[:, None, :, None].double() * km[:, None, None, :].double()) * -10000.0
+        sp = lambda t, l: t.view(n, l, heads, dh).permute(0, 2, 1, 3)     # noqa: E731
+        s = torch.matmul(sp(q, lq), sp(k, lk).transpose(-1, -2)) / math.sqrt(dh) + add
+        o = torch.matmul(torch.softmax(s, -1) * mask, sp(v, lk))
+        return o.permute(0, 2, 1, 3).reshape(n, lq, hsz)
+    want = run(ref, q.double(), k.double(), v.double())
+    got = run(lambda a, b, c: AttentionCoreFn.apply(a, b, c, qm, km, heads, p_drop, seed), q, k, v)
+    try:
+        TO.DISABLE_FUSED_ATTENTION = True
+        chain = run(lambda a, b, c: AttentionCoreFn.apply(a, b, c, qm, km, heads, p_drop, seed), q, k, v)
+    finally:
+        TO.DISABLE_FUSED_ATTENTION = False
+    # rows of masked-out queries attend uniformly in both implementations; every row is compared
+    for name, g, c, w in zip(("out", "dq", "dk", "dv"), got, chain, want):
+        check("fused vs float64 " + name, g, w, 2e-2)
+        check("unfused chain vs float64 " + name, c, w, 2e-2)
+        check("fused vs unfused chain " + name, g, c, 2e-2)
+    if lq == lk:          # self-attention on a fused (N, L, 3H) projection: same numbers through the other entry
+        qkv = torch.cat([q, k, v], -1).contiguous()
+        got2 = run(lambda t: AttentionQkvFn.apply(t, km, heads, p_drop, seed), qkv)
+        want2 = run(lambda a, b, c: AttentionCoreFn.apply(a, b, c, None, km, heads, p_drop, seed), q, k, v)
+        assert torch.equal(got2[0], want2[0])
+        assert torch.equal(got2[1], torch.cat(want2[1:], -1))
+
+
 def test_train_mode_step_with_dropout_runs():
     """model.train(): dropout active at every site; repeatable under torch.manual_seed, different from eval, finite."""
     from tvretrieval_amd.train import xml_forward_train

@@ -119,6 +119,12 @@ class AttentionCoreFn(torch.autograd.Function):
         lk = k.shape[1]
         dh = hidden // heads
         q, k, v = q.contiguous(), k.contiguous(), v.contiguous()
+        ctx.heads = heads
+        ctx.drop = (p_drop, seed)
+        ctx.fused = T.attention_train_supported(lq, lk, hidden, heads, q.dtype)
+        if ctx.fused:       # bf16: one launch, nothing but q / k / v kept for the backward pass (attention_train.hip)
+            ctx.save_for_backward(q, k, v, None, q_mask, k_mask)
+            return T.attention_train_fwd(q, k, v, q_mask, k_mask, heads, hidden, p_drop, seed)
         qh, _ = T.split_heads(q, heads)
         kh, _ = T.split_heads(k, heads)
         _, vht = T.split_heads(v, heads, want=False, want_t=True)
@@ -128,8 +134,6 @@ class AttentionCoreFn(torch.autograd.Function):
             T.dropout(p, p_drop, seed, out=p)                          # attention_probs dropout, :297
         oh = T.gemm_batched(p, vht)                                    # (N*h, lq8, dh)
         out = T.merge_heads(oh, n, lq, heads)
-        ctx.heads = heads
-        ctx.drop = (p_drop, seed)
         ctx.save_for_backward(q, k, v, s, q_mask, k_mask)
         return out
 
@@ -140,10 +144,14 @@ class AttentionCoreFn(torch.autograd.Function):
         n, lq, hidden = q.shape
         lk = k.shape[1]
         dh = hidden // heads
+        p_drop, seed = ctx.drop
+        if ctx.fused:
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            T.attention_train_bwd(q, k, v, q_mask, k_mask, dout.contiguous(), dq, dk, dv, heads, hidden, p_drop, seed)
+            return dq, dk, dv, None, None, None, None, None
         doh, doht = T.split_heads(dout.contiguous(), heads, want=True, want_t=True)
         vh, _ = T.split_heads(v, heads)
         dp = T.gemm_batched(doh, vh, out_f32=True)                     # dP = dO V^T   (w.r.t. the dropped probs)
-        p_drop, seed = ctx.drop
         if p_drop > 0:
             p, _ = T.attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, q.dtype)
             T.dropout(p, p_drop, seed, out=p)
@@ -197,6 +205,11 @@ class AttentionQkvFn(torch.autograd.Function):
         hidden = h3 // 3
         dh = hidden // heads
         qkv = qkv.contiguous()
+        ctx.cfg = (heads, p_drop, seed)
+        ctx.fused = T.attention_train_supported(l, l, hidden, heads, qkv.dtype)
+        if ctx.fused:
+            ctx.save_for_backward(qkv, None, k_mask)
+            return T.attention_train_fwd(qkv, qkv, qkv, None, k_mask, heads, hidden, p_drop, seed, 0, hidden, 2 * hidden)
         qh, _ = T.split_heads(qkv, heads, col0=0, width=hidden)
         kh, _ = T.split_heads(qkv, heads, col0=hidden, width=hidden)
         _, vht = T.split_heads(qkv, heads, want=False, want_t=True, col0=2 * hidden, width=hidden)
@@ -205,7 +218,6 @@ class AttentionQkvFn(torch.autograd.Function):
         if p_drop > 0:
             T.dropout(p, p_drop, seed, out=p)
         out = T.merge_heads(T.gemm_batched(p, vht), n, l, heads)
-        ctx.cfg = (heads, p_drop, seed)
         ctx.save_for_backward(qkv, s, k_mask)
         return out
 
@@ -216,6 +228,11 @@ class AttentionQkvFn(torch.autograd.Function):
         n, l, h3 = qkv.shape
         hidden = h3 // 3
         dh = hidden // heads
+        if ctx.fused:
+            dqkv = torch.empty_like(qkv)
+            T.attention_train_bwd(qkv, qkv, qkv, None, k_mask, dout.contiguous(), dqkv, dqkv, dqkv, heads, hidden, p_drop, seed,
+                                  0, hidden, 2 * hidden, 0, hidden, 2 * hidden)
+            return dqkv, None, None, None, None
         doh, doht = T.split_heads(dout.contiguous(), heads, want=True, want_t=True)
         vh, _ = T.split_heads(qkv, heads, col0=2 * hidden, width=hidden)
         dp = T.gemm_batched(doh, vh, out_f32=True)

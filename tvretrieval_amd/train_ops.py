@@ -3,6 +3,7 @@
 Same rules as ops.py: torch owns device memory and the stream, every function launches kernels of libxmlhip.so,
 nothing falls back to eager torch.
 """
+import ctypes
 import math
 
 import torch
@@ -110,6 +111,44 @@ def merge_heads(xh, n, l, heads, out=None, col0=0):
     check(_lib.load().xml_merge_heads(_p(xh), _p(out), out.shape[-1], col0, n, l, l8, heads, dh, dt_of(xh), _stream()),
           "xml_merge_heads")
     return out
+
+
+DISABLE_FUSED_ATTENTION = False      # tests / A-B measurements: keep the unfused chain for bf16 too
+
+
+def attention_train_supported(lq, lk, hidden, heads, dtype):
+    if DISABLE_FUSED_ATTENTION:
+        return False
+    return bool(_lib.load().xml_attention_train_supported(int(lq), int(lk), int(hidden), int(heads), dt_of(dtype)))
+
+
+def _col_ptr(x, col0):
+    return ctypes.c_void_p(x.data_ptr() + col0 * x.element_size())
+
+
+def attention_train_fwd(q, k, v, q_mask, k_mask, heads, hidden, p_drop, seed, q_col=0, k_col=0, v_col=0):
+    """Fused attention forward (bf16).  q (N, Lq, ldq), k / v (N, Lk, ld): head blocks start at column *_col of each tensor
+    (a fused QKV tensor is passed three times with q_col / k_col / v_col = 0 / H / 2H).  -> (N, Lq, hidden)."""
+    _req(q, "q"); _req(k, "k", q.dtype); _req(v, "v", q.dtype)
+    n, lq, lk = q.shape[0], q.shape[1], k.shape[1]
+    out = torch.empty((n, lq, hidden), dtype=q.dtype, device=q.device)
+    check(_lib.load().xml_attention_train_fwd(_col_ptr(q, q_col), q.shape[2], _col_ptr(k, k_col), k.shape[2],
+                                              _col_ptr(v, v_col), v.shape[2], _p(q_mask), _p(k_mask), _p(out), hidden, n, lq,
+                                              lk, hidden, heads, float(p_drop), int(seed), dt_of(q), _stream()),
+          "xml_attention_train_fwd")
+    return out
+
+
+def attention_train_bwd(q, k, v, q_mask, k_mask, dout, dq, dk, dv, heads, hidden, p_drop, seed, q_col=0, k_col=0, v_col=0,
+                        dq_col=0, dk_col=0, dv_col=0):
+    """Fused attention backward (bf16): writes the head blocks of dq / dk / dv (column offsets d*_col) from dout (N, Lq, H)."""
+    _req(dout, "dout", q.dtype)
+    n, lq, lk = q.shape[0], q.shape[1], k.shape[1]
+    check(_lib.load().xml_attention_train_bwd(_col_ptr(q, q_col), q.shape[2], _col_ptr(k, k_col), k.shape[2],
+                                              _col_ptr(v, v_col), v.shape[2], _p(q_mask), _p(k_mask), _p(dout), dout.shape[2],
+                                              _col_ptr(dq, dq_col), dq.shape[2], _col_ptr(dk, dk_col), dk.shape[2],
+                                              _col_ptr(dv, dv_col), dv.shape[2], n, lq, lk, hidden, heads, float(p_drop),
+                                              int(seed), dt_of(q), _stream()), "xml_attention_train_bwd")
 
 
 def attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, dtype, want_t=False):

@@ -289,6 +289,12 @@ int xml_merge_heads(const void* src, void* dst, int ld, int col0, int64_t n, int
 int xml_attn_softmax(const float* S, const float* dP, const float* q_mask, const float* k_mask, void* P,
                      void* PT, void* dS, void* dST, int64_t n, int heads, int lq, int lk, int lq8, int lk8,
                      float sqrt_dh, int dt, xml_stream_t stream);
+/* Weight-gradient GEMM from the row-major operands: out (N, K) f32 = A^T B = sum_r A[r][n] B[r][k], A (rows, N), B (rows, K)
+ * bf16, N and K multiples of 8 (xml_gemm_tn_supported; callers keep the transpose + xml_gemm_batched path otherwise).
+ * Row ranges are combined with f32 atomics: the summation order, hence the last bits, vary from run to run (as with
+ * xml_gemm_batched's split-K). */
+int xml_gemm_tn_supported(int64_t rows, int N, int K, int dt);
+int xml_gemm_tn(const void* A, const void* B, float* out, int64_t rows, int N, int K, int dt, xml_stream_t stream);
 /* Fused training attention (bf16 storage; xml/model_components.py:266-303 incl. the probabilities dropout :297), one
  * launch each way instead of the split_heads / batched GEMM / xml_attn_softmax / xml_dropout / merge_heads chain:
  *   fwd   out (n, lq, ldo) head h columns [h dh, (h+1) dh)  =  dropout(softmax(Q K^T / sqrt(dh) + mask bias)) V

@@ -468,6 +468,23 @@ def test_attention_probs_dropout_matches_masked_reference():
              [True, True, True], tol=5e-5)
 
 
+@pytest.mark.parametrize("rows,n,k", [(12800, 768, 768), (3840, 2304, 768), (1000, 200, 72), (37, 8, 3072), (300, 768, 3080)])
+def test_weight_gradient_gemm_from_row_major_operands(rows, n, k):
+    """xml_gemm_tn: dW = dY^T X read from the row-major bf16 operands (transpose reads, row ranges combined with atomics)
+    == float64 matmul of the same bf16 values, and == the transpose + split-K path it replaces (up to summation order)."""
+    from tvretrieval_amd import train_ops as TO
+    dy = rnd(rows, n, seed=11).to(torch.bfloat16)
+    x = rnd(rows, k, seed=12).to(torch.bfloat16)
+    got = TO.gemm_tn(dy, x)
+    assert got is not None and got.shape == (n, k) and got.dtype == F32
+    want = dy.double().t() @ x.double()
+    check("gemm_tn", got, want, 2e-5)
+    r8 = (rows + 7) // 8 * 8
+    old = TO.gemm_batched(TO.transpose(dy, r8), TO.transpose(x, r8), out_f32=True)
+    check("gemm_tn vs transpose + split-K", got, old, 2e-5)
+    assert TO.gemm_tn(dy.float(), x.float()) is None              # fp32 compute keeps the old path
+
+
 @pytest.mark.parametrize("shape", [(3, 100, 100, 768, 4), (2, 30, 30, 768, 4), (2, 40, 72, 256, 4), (2, 128, 128, 128, 4),
                                    (2, 17, 128, 768, 4)])
 @pytest.mark.parametrize("p_drop", [0.0, 0.2])

@@ -113,6 +113,21 @@ def merge_heads(xh, n, l, heads, out=None, col0=0):
     return out
 
 
+DISABLE_GEMM_TN = False               # tests / A-B measurements: transposes + split-K NT GEMM for the weight gradients
+
+
+def gemm_tn(a, b):
+    """a (rows, N), b (rows, K) -> a^T b (N, K) f32, or None when the shape / dtype is not served (caller falls back)."""
+    _req(a, "a"); _req(b, "b", a.dtype)
+    rows, n = a.shape
+    k = b.shape[1]
+    if DISABLE_GEMM_TN or not _lib.load().xml_gemm_tn_supported(rows, n, k, dt_of(a)):
+        return None
+    out = torch.empty((n, k), dtype=F32, device=a.device)
+    check(_lib.load().xml_gemm_tn(_p(a), _p(b), _p(out), rows, n, k, dt_of(a), _stream()), "xml_gemm_tn")
+    return out
+
+
 DISABLE_FUSED_ATTENTION = False      # tests / A-B measurements: keep the unfused chain for bf16 too
 
 

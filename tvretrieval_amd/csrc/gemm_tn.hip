@@ -6,8 +6,7 @@
 // dY and X go to LDS as they lie (row-major, 16-byte loads / stores) and the MFMA fragments -- 8 consecutive rows of one
 // column per lane -- come out of ds_read_b64_tr_b16 (attention.hip has the lane semantics).
 // One workgroup = 4 waves = a 128 (n) x 128 (k) output tile over one range of rows; the row ranges (blockIdx.z) are combined
-// with f32 atomics into the pre-zeroed output, as the split-K kernel did.  Register double buffer: the loads of slab s + 1
-// are in flight under the MFMAs of slab s.
+// with f32 atomics into the pre-zeroed output, as the split-K kernel did.
 #include "common.h"
 
 namespace {
@@ -29,28 +28,37 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
   const int n0 = blockIdx.y * 128, k0 = blockIdx.x * 128;
   const int r_begin = blockIdx.z * rows_per_split;
   const int r_end = min(rows, r_begin + rows_per_split);
-  const int n_slabs = (r_end - r_begin + 31) / 32;
+  const int n_slabs = ((r_end - r_begin + 31) / 32 + 1) & ~1;      // even: the two-step loop body below has no tail case (a
+                                                                   // slab past r_end is all zeros)
 
   // a thread's two 16-byte pieces of a slab of each operand: slab row lr + 16 i, columns 8 lc .. + 7
   const int lr = tid >> 4, lc = tid & 15;
   const bool a_ok = n0 + lc * 8 + 8 <= N, b_ok = k0 + lc * 8 + 8 <= K;       // N, K multiples of 8 (checked by the entry)
+  const int ca = a_ok ? n0 + lc * 8 : 0, cb = b_ok ? k0 + lc * 8 : 0;        // clamped columns
   auto load = [&](uint4 (&ra)[2], uint4 (&rb)[2], int slab) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      // UNCONDITIONAL loads from clamped (always valid) addresses; rows / columns outside the operands are zeroed when the
+      // registers are parked in LDS (stash).  With the loads inside `if`s hipcc loses its vmcnt count at the branch joins and
+      // waits vmcnt(0) before every LDS store, and a select right here would wait for the data at once: either way the
+      // two-slab lead is gone.
       const int r = r_begin + slab * 32 + lr + 16 * i;
-      ra[i] = make_uint4(0, 0, 0, 0);
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (r < r_end && a_ok) ra[i] = ld_global16(A + (int64_t)r * N + n0 + lc * 8);
-      if (r < r_end && b_ok) rb[i] = ld_global16(B + (int64_t)r * K + k0 + lc * 8);
+      const int rc = r < r_end ? r : r_begin;
+      ra[i] = ld_global16(A + (int64_t)rc * N + ca);
+      rb[i] = ld_global16(B + (int64_t)rc * K + cb);
     }
   };
-  auto stash = [&](const uint4 (&ra)[2], const uint4 (&rb)[2], int buf) {
+  auto stash = [&](const uint4 (&ra)[2], const uint4 (&rb)[2], int buf, int slab) {
     char* sa = smem + buf * (2 * 32 * TN_STRIDE);
     char* sb = sa + 32 * TN_STRIDE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      *reinterpret_cast<uint4*>(sa + (lr + 16 * i) * TN_STRIDE + lc * 16) = ra[i];
-      *reinterpret_cast<uint4*>(sb + (lr + 16 * i) * TN_STRIDE + lc * 16) = rb[i];
+      const bool rok = r_begin + slab * 32 + lr + 16 * i < r_end;
+      const bool ka = rok && a_ok, kb = rok && b_ok;
+      *reinterpret_cast<uint4*>(sa + (lr + 16 * i) * TN_STRIDE + lc * 16) =
+          make_uint4(ka ? ra[i].x : 0u, ka ? ra[i].y : 0u, ka ? ra[i].z : 0u, ka ? ra[i].w : 0u);
+      *reinterpret_cast<uint4*>(sb + (lr + 16 * i) * TN_STRIDE + lc * 16) =
+          make_uint4(kb ? rb[i].x : 0u, kb ? rb[i].y : 0u, kb ? rb[i].z : 0u, kb ? rb[i].w : 0u);
     }
   };
 
@@ -60,17 +68,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  uint4 ra[2], rb[2];
-  if (n_slabs > 0) {
-    load(ra, rb, 0);
-    stash(ra, rb, 0);
-  }
+  // Loads run TWO slabs ahead through two register sets (a 16-MFMA slab is ~500 cycles of work, a global round trip
+  // several times that: with one slab of lead every iteration waited for memory -- 64 us per 768 x 768 x 12 800 product):
+  //   step s:  issue the loads of slab s + 2 into the set slab s came from, compute slab s from its LDS buffer, then park
+  //            slab s + 1 (loaded one step earlier) in the other buffer.
+  uint4 r0a[2], r0b[2], r1a[2], r1b[2];
+  load(r0a, r0b, 0);
+  load(r1a, r1b, 1);
+  stash(r0a, r0b, 0, 0);
   __syncthreads();
   // fragment of column tile t (16 columns from column c0 + 16 t): lane = column fr, slab rows 8 fg .. 8 fg + 7
   const int frag_off = (fg * 8 + (fr >> 2)) * TN_STRIDE + (fr & 3) * 8;
-  for (int s = 0; s < n_slabs; ++s) {
+  auto step = [&](int s, uint4 (&la)[2], uint4 (&lb)[2], const uint4 (&sa_)[2], const uint4 (&sb_)[2]) {
     const int buf = s & 1;
-    if (s + 1 < n_slabs) load(ra, rb, s + 1);
+    load(la, lb, s + 2 < n_slabs ? s + 2 : n_slabs - 1);      // (unconditional: a branch here costs the vmcnt count again)
+    __builtin_amdgcn_sched_barrier(0);                         // keep the loads HERE (hipcc sinks them below the MFMAs)
     const char* sa = smem + buf * (2 * 32 * TN_STRIDE) + frag_off + wn * 128;
     const char* sb = smem + buf * (2 * 32 * TN_STRIDE) + 32 * TN_STRIDE + frag_off + wk * 128;
     uint4 fa[4], fb[4];
@@ -88,8 +100,12 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     for (int i = 0; i < 4; ++i)
 #pragma unroll
       for (int j = 0; j < 4; ++j) Mma<bf16_t>::chunk(acc[i][j], fa[i], fb[j]);
-    if (s + 1 < n_slabs) stash(ra, rb, buf ^ 1);        // the other buffer: its last readers passed the barrier below
+    stash(sa_, sb_, buf ^ 1, s + 1);      // the other buffer (after the last slab: zeros nobody reads): its last readers passed the previous barrier
     __syncthreads();
+  };
+  for (int s = 0; s < n_slabs; s += 2) {
+    step(s, r0a, r0b, r1a, r1b);
+    step(s + 1, r1a, r1b, r0a, r0b);
   }
 
   const bool split = gridDim.z > 1;
@@ -121,7 +137,14 @@ extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, int64_t row
   if (!xml_gemm_tn_supported(rows, N, K, dt)) return XML_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const int tiles = cdiv(N, 128) * cdiv(K, 128);
-  int splits = cdiv(768, tiles);                               // aim at >= 3 workgroups per CU
+  // workgroups aimed at.  Every row range adds N x K f32 atomics, and device-scope float atomics are slow enough to show
+  // (768 x 768 over 12 800 rows: 58.6 us with 7 ranges, 69.6 with 22, 94 with 43 -- tools/bench_gemm_tn.py); with many
+  // output tiles the extra ranges pay for themselves by hiding the global-load latency (768 x 3072: 134 vs 160 us)
+  int target = tiles <= 48 ? 256 : 768;
+#ifdef XML_DEBUG_VARIANTS
+  if (g_q2c_ablation >= 200) target = (g_q2c_ablation - 200) * 64;      // A/B: workgroups aimed at = (XML_ABL - 200) x 64
+#endif
+  int splits = cdiv(target, tiles);
   int rps = (cdiv(rows, splits) + 31) / 32 * 32;               // rows per workgroup, whole 32-row slabs
   if (rps < 256) rps = 256;
   splits = cdiv(rows, rps);

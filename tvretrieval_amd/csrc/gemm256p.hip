@@ -21,6 +21,8 @@
 // time now.  Tried on the way and NOT kept, both neutral: starting the workgroups a quarter tile apart (the epilogues of
 // the chip are not what limits the write path -- each CU's own store queue is), and skipping the counted vmcnt waits for
 // the first slices of a tile, which are already resident (peeling three steps made hipcc spill into the K loop prologue).
+// A fifth ring slot for this kernel (the direct epilogue leaves LDS free; bias in registers): neutral as well -- unlike K6,
+// this K loop is not short of bytes in flight.
 // Same MFMA sequence per accumulator as gemm256_kernel: bitwise the same results.
 #include <type_traits>
 

@@ -24,6 +24,7 @@
 // A fifth ring slot for this kernel (the direct epilogue leaves LDS free; bias in registers): neutral as well -- unlike K6,
 // this K loop is not short of bytes in flight.
 // Same MFMA sequence per accumulator as gemm256_kernel: bitwise the same results.
+#include <mutex>
 #include <type_traits>
 
 #include "common.h"
@@ -754,15 +755,24 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
   auto kern = gemm256p_kernel<T, OutT, AddT, LNE, DIRECT>;
   if (!xml_lds_attr_once<gemm256p_kernel<T, OutT, AddT, LNE, DIRECT>>(lds)) return XML_ERR_LAUNCH;
   if (LNE) {
-    // the workgroups of a row block wait for each other: ALL 256 must be resident at once.  A cooperative launch makes the
-    // runtime guarantee that (and serialises two such kernels issued on different streams, which could otherwise each
-    // hold part of the chip and wait for partners that cannot start).
-    void* params[] = {(void*)&a};
-    if (hipLaunchCooperativeKernel((const void*)kern, dim3(256), dim3(512), params, (unsigned)lds, st) != hipSuccess) {
-      (void)hipGetLastError();
-      return XML_ERR_LAUNCH;
-    }
-    return XML_OK;
+    // The workgroups of a row block wait for each other, so all 256 must get onto the chip.  With one workgroup per CU
+    // (160 KiB of LDS) and a grid of 256 they do as soon as the CUs are free -- kernels of OTHER kinds that still hold CUs
+    // only delay them.  Two kernels of THIS kind running at once could each hold part of the chip and wait for partners
+    // that cannot start: launches on different streams are therefore chained through an event (per device).
+    // (hipLaunchCooperativeKernel would give the same guarantee, but rocprofiler-sdk 7.2 crashes at process exit after
+    // a traced cooperative launch -- `rocprofv3 --kernel-trace -- python bench.py` ended with SIGSEGV, outputs written.)
+    static std::mutex mu;
+    static hipEvent_t last_ev[16] = {};
+    static hipStream_t last_st[16] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return XML_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!last_ev[dev] && hipEventCreateWithFlags(&last_ev[dev], hipEventDisableTiming) != hipSuccess) return XML_ERR_LAUNCH;
+    else if (last_st[dev] != st && hipStreamWaitEvent(st, last_ev[dev], 0) != hipSuccess) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
+    const bool ok = hipGetLastError() == hipSuccess && hipEventRecord(last_ev[dev], st) == hipSuccess;
+    last_st[dev] = st;
+    return ok ? XML_OK : XML_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
   XML_CHECK_LAUNCH();

@@ -378,7 +378,7 @@ extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_i
   if (xmli_gemm_ln_eligible(rows, hidden, d_pad, dt) &&    // LN_pos in the GEMM epilogue: two launches, no f32 round trip
       xmli_gemm_ln(xn, w, b, pos, ln_pos_g, ln_pos_b, y, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, dt, pre,
                    st) == XML_OK)
-    return XML_OK;                                         // (a refused cooperative launch falls through to the 3-launch path)
+    return XML_OK;                                         // (a refused launch falls through to the 3-launch path)
   rc = xmli_gemm(xn, w, b, pos, pre, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, /*out_f32*/ 1, dt, st);
   if (rc) return rc;
   return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, dt, st);

@@ -172,6 +172,14 @@ int xml_q2c_tiled_ok(int lpad, int hidden, int dt);
  *     column, so everything downstream is unchanged and the scores are bitwise those of xml_q2c_scores_tiled. */
 int xml_q2c_tile_rows_gather(const void* src, const int32_t* row_map, void* dst, int64_t rows_packed, int hidden, int dt,
                              xml_stream_t stream);
+/* F.normalize(dim=-1) of the clip rows fused into the tiling pass: dst = tiled image (rows_dst rows, a multiple of 256) of
+ * l2norm(src rows); row_map NULL: destination row i = source row i (zeros beyond rows_src); row_map (rows_dst entries):
+ * destination row i = source row row_map[i], zeros when < 0 (the length-bucketed image).  Bitwise the values of
+ * xml_l2norm_rows followed by xml_q2c_tile_rows / _gather.  hidden * sizeof(dt) a multiple of 64 and <= 4096 bytes
+ * (xml_q2c_tile_rows_l2norm_ok). */
+int xml_q2c_tile_rows_l2norm_ok(int hidden, int dt);
+int xml_q2c_tile_rows_l2norm(const void* src, const int32_t* row_map, void* dst, int64_t rows_src, int64_t rows_dst,
+                             int hidden, int dt, xml_stream_t stream);
 int xml_q2c_scores_packed(int n_mod, const void* qt0, const void* ct0, const void* qt1, const void* ct1, float* out,
                           int64_t ld_out, int nq, int n_tiles, int ct128, int ct64, const int32_t* slot_ids,
                           const uint32_t* mbits0, const uint32_t* mbits1, int hidden, int dt, xml_stream_t stream);

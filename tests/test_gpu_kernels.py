@@ -373,6 +373,25 @@ def test_q2c_tiled_equals_row_major(ops, dtype, shape, n_mod):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+def test_normalise_and_tile_in_one_pass_is_bitwise_l2norm_then_tile(ops, dtype):
+    """index build: xml_q2c_tile_rows_l2norm (F.normalize inside the tiling pass, plain and through the length-bucket row map)
+    == xml_l2norm_rows followed by the tiling kernels, bit for bit; the normalised rows agree with F.normalize."""
+    nv, h = 301, 768
+    g = torch.Generator().manual_seed(77)
+    lens = torch.randint(1, 129, (nv,), generator=g)
+    mask = dev((torch.arange(128)[None] < lens[:, None]).float())
+    x = dev(torch.randn(nv, 128, h, generator=g) * 3.0, dtype) * mask[..., None].to(dtype)
+    n1 = ops.l2norm_rows(x)
+    close("l2norm_rows", n1, torch.nn.functional.normalize(x.float().cpu(), dim=-1), _tol(dtype, 2e-6, 8e-3), 1e-2 if dtype == torch.bfloat16 else 1e-6)
+    ones = torch.ones_like(mask)
+    for m, plan in ((ones, None), (mask, None), (mask, ops.q2c_pack_plan([mask]))):
+        a = ops.pack_q2c_corpus(x, m, plan, normalize=True)
+        b = ops.pack_q2c_corpus(n1, m, plan)
+        assert torch.equal(a.data, b.data)
+        assert torch.equal(a.to_rows(), n1)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n_mod", [1, 2])
 def test_q2c_length_buckets_bitwise(ops, dtype, n_mod):
     """Ragged corpus (TVR-like lengths, mean ~51 of 128 clips): the length-bucketed image (2 / 4 / 8 videos per K6 tile,

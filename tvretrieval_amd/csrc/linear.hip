@@ -4,6 +4,7 @@
 //              BertSelfOutput.forward        xml/model_components.py:313-317
 #include "gemm.h"
 #include "internal.h"
+#include "l2norm.h"
 
 // ---------------------------------------------------------------------------------------------------
 // GEMM + epilogue:  out[m][n] = act(acc + bias[n]) + addend      (OutT = float when a LayerNorm follows)
@@ -287,11 +288,34 @@ extern "C" int xml_l2norm_rows_eps(const float* x, float* y, int64_t rows, int d
   return XML_OK;
 }
 
+// the same with 16-byte loads / stores, half a wave per row (l2norm.h: the arithmetic the fused index build shares)
+template <typename T>
+__global__ __launch_bounds__(256) void l2norm_rows_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t rows,
+                                                              int d) {
+  constexpr int VEC = 16 / (int)sizeof(T);
+  const int l32 = threadIdx.x & 31;
+  const int64_t row = (int64_t)blockIdx.x * 8 + (threadIdx.x >> 5);
+  const bool live = row < rows;
+  uint4 v[L2N_MAXJ];
+  const float nrm = l2n_load_row<T>(live ? x + row * d : nullptr, d, l32, v);
+  if (!live) return;
+  const int chunks = d / VEC;
+#pragma unroll
+  for (int j = 0; j < L2N_MAXJ; ++j) {
+    const int c = l32 + 32 * j;
+    if (c < chunks) st_global16(y + row * d + c * VEC, l2n_scale_chunk<T>(v[j], nrm));
+  }
+}
+
 extern "C" int xml_l2norm_rows(const void* x, void* y, int64_t rows, int d, int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!x || !y || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (dt == XML_F32)
+  if (dt == XML_F32 && d % 4 == 0 && d / 4 <= 32 * L2N_MAXJ)
+    hipLaunchKernelGGL(l2norm_rows_vec_kernel<float>, dim3(cdiv(rows, 8)), dim3(256), 0, st, (const float*)x, (float*)y, rows, d);
+  else if (dt == XML_BF16 && d % 8 == 0 && d / 8 <= 32 * L2N_MAXJ)
+    hipLaunchKernelGGL(l2norm_rows_vec_kernel<bf16_t>, dim3(cdiv(rows, 8)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, d);
+  else if (dt == XML_F32)
     hipLaunchKernelGGL(l2norm_rows_kernel<float>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const float*)x, (float*)y, rows, d);
   else if (dt == XML_BF16)
     hipLaunchKernelGGL(l2norm_rows_kernel<bf16_t>, dim3(cdiv(rows, 4)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, rows, d);

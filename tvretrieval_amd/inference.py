@@ -117,10 +117,11 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
     plan = ops.q2c_pack_plan([mask[m] for m in mods]) if (hasattr(ops, "q2c_pack_plan") and lpad == 128) else None
     for m in mods:
         f1 = cat(parts[m]["f1"])
-        feat1n[m] = ops.l2norm_rows(f1)
         feat2[m] = cat(parts[m]["f2"])
-        if hasattr(ops, "pack_q2c_corpus"):      # HIP backend: slice-major tiles for the persistent K6 kernel
-            feat1n[m] = ops.pack_q2c_corpus(feat1n[m], mask[m], plan)
+        if hasattr(ops, "pack_q2c_corpus"):      # HIP backend: normalised + slice-major tiles for the persistent K6 kernel
+            feat1n[m] = ops.pack_q2c_corpus(f1, mask[m], plan, normalize=True)
+        else:
+            feat1n[m] = ops.l2norm_rows(f1)
         if keep_raw:
             raw[m] = f1
     idx = CorpusIndex(mods, feat1n, feat2, mask, l_ref, video_offset, n_total)
@@ -156,8 +157,8 @@ def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_of
     plan = ops.q2c_pack_plan([mk[m] for m in mods]) if (hasattr(ops, "q2c_pack_plan") and lpad == 128) else None
     feat1n, raw = {}, {}
     for m in mods:
-        n1 = ops.l2norm_rows(f1[m])
-        feat1n[m] = ops.pack_q2c_corpus(n1, mk[m], plan) if hasattr(ops, "pack_q2c_corpus") else n1
+        feat1n[m] = ops.pack_q2c_corpus(f1[m], mk[m], plan, normalize=True) if hasattr(ops, "pack_q2c_corpus") \
+            else ops.l2norm_rows(f1[m])
         if keep_raw:
             raw[m] = f1[m]
     idx = CorpusIndex(mods, feat1n, f2, mk, l_ref, video_offset, n_total)

@@ -308,23 +308,43 @@ def q2c_tile_rows(x):
     return TiledRows(data, rows, hidden, x.shape)
 
 
-def pack_q2c_corpus(feat1n, mask=None, plan=None):
+def pack_q2c_corpus(feat1n, mask=None, plan=None, normalize=False):
     """Resident form of the similarity operand: slice-major tiles when the persistent kernel takes it, else as is.
     mask (Nv, Lpad): if every entry is 1 (full-length videos) the tiles are marked all_valid and K6 skips the masks.
-    plan (q2c_pack_plan over ALL modalities' masks): the length-bucketed image instead."""
+    plan (q2c_pack_plan over ALL modalities' masks): the length-bucketed image instead.
+    normalize: feat1n holds the UN-normalised clip features; F.normalize runs inside the tiling pass
+    (xml_q2c_tile_rows_l2norm: bitwise the values of l2norm_rows followed by the tiling, one pass over the index less)."""
+    lib = _lib.load()
+    fused = normalize and lib.xml_q2c_tile_rows_l2norm_ok(feat1n.shape[2], dt_of(feat1n)) \
+        and q2c_tiled_ok(feat1n.shape[1], feat1n.shape[2], feat1n.dtype) and not os.environ.get("XML_Q2C_ROW_MAJOR")
+    if normalize and not fused:
+        feat1n = l2norm_rows(feat1n)
     if plan is not None and q2c_tiled_ok(feat1n.shape[1], feat1n.shape[2], feat1n.dtype):
         _req(feat1n, "feat1n")
         nv, lpad, hidden = feat1n.shape
         rows_packed = plan.n_tiles * 256
         data = torch.empty(rows_packed * hidden, dtype=feat1n.dtype, device=feat1n.device)
-        check(_lib.load().xml_q2c_tile_rows_gather(_p(feat1n), _p(plan.row_map), _p(data), rows_packed, hidden,
-                                                   dt_of(feat1n), _stream()), "xml_q2c_tile_rows_gather")
+        if fused:
+            check(lib.xml_q2c_tile_rows_l2norm(_p(feat1n), _p(plan.row_map), _p(data), nv * lpad, rows_packed, hidden,
+                                               dt_of(feat1n), _stream()), "xml_q2c_tile_rows_l2norm")
+        else:
+            check(lib.xml_q2c_tile_rows_gather(_p(feat1n), _p(plan.row_map), _p(data), rows_packed, hidden,
+                                               dt_of(feat1n), _stream()), "xml_q2c_tile_rows_gather")
         t = TiledRows(data, nv * lpad, hidden, feat1n.shape)
         t.plan = plan
         t.mask_bits = plan.mask_bits(mask)
         return t
     if q2c_tiled_ok(feat1n.shape[1], feat1n.shape[2], feat1n.dtype) and not os.environ.get("XML_Q2C_ROW_MAJOR"):
-        t = q2c_tile_rows(feat1n)             # (XML_Q2C_ROW_MAJOR=1: keep rows, for A/B measurements)
+        if fused:
+            hidden = feat1n.shape[-1]
+            rows = feat1n.numel() // hidden
+            nbytes = lib.xml_q2c_tiled_bytes(rows, hidden, dt_of(feat1n))
+            data = torch.empty(nbytes // feat1n.element_size(), dtype=feat1n.dtype, device=feat1n.device)
+            check(lib.xml_q2c_tile_rows_l2norm(_p(feat1n), None, _p(data), rows, nbytes // (hidden * feat1n.element_size()),
+                                               hidden, dt_of(feat1n), _stream()), "xml_q2c_tile_rows_l2norm")
+            t = TiledRows(data, rows, hidden, feat1n.shape)
+        else:
+            t = q2c_tile_rows(feat1n)         # (XML_Q2C_ROW_MAJOR=1: keep rows, for A/B measurements)
         keep = os.environ.get("XML_Q2C_KEEP_MASKS")      # 1: float masks (4-slot kernel), for A/B measurements
         t.all_valid = mask is not None and bool((mask == 1).all()) and not keep
         if mask is not None and not t.all_valid and not keep and mask.shape[1] == 128 \

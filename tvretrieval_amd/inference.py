@@ -139,7 +139,21 @@ def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_of
     f1, f2, mk = {}, {}, {}
     r = 0
     for video_feat, video_mask, sub_feat, sub_mask in context_batches:
-        v1, v2, s1, s2 = model.encode_context(video_feat, video_mask, sub_feat, sub_mask)
+        # batches of full padded length are encoded STRAIGHT into their rows of the index tensors (the last layer of each
+        # branch writes there): no per-batch copies.  The first batch, shorter batches and non-HIP backends go through copies.
+        outs = [None, None, None, None]
+        direct = bool(f1) and getattr(ops, "ENCODE_INTO_INDEX", False)
+        if direct:
+            for i, (m, feat) in enumerate((("video", video_feat), ("sub", sub_feat))):
+                b = feat.shape[0] if feat is not None else 0
+                if m in mods and feat is not None and feat.shape[1] == lpad and r + b <= n_videos:
+                    outs[2 * i], outs[2 * i + 1] = f1[m][r:r + b], f2[m][r:r + b]
+                elif m in mods:
+                    direct = False
+        if direct:
+            v1, v2, s1, s2 = model.encode_context(video_feat, video_mask, sub_feat, sub_mask, outs=tuple(outs))
+        else:
+            v1, v2, s1, s2 = model.encode_context(video_feat, video_mask, sub_feat, sub_mask)
         for m, a1, a2, am in (("video", v1, v2, video_mask), ("sub", s1, s2, sub_mask)):
             if m not in mods:
                 continue
@@ -149,8 +163,9 @@ def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_of
                 mk[m] = torch.zeros((n_videos, lpad), dtype=torch.float32, device=a1.device)
             b, lb = a1.shape[0], a1.shape[1]
             assert r + b <= n_videos and lb <= l_ref
-            f1[m][r:r + b, :lb] = a1
-            f2[m][r:r + b, :lb] = a2
+            if not direct:
+                f1[m][r:r + b, :lb] = a1
+                f2[m][r:r + b, :lb] = a2
             mk[m][r:r + b, :lb] = am.float()
         r += v1.shape[0] if v1 is not None else s1.shape[0]
     assert r == n_videos, "n_videos=%d but the batches held %d" % (n_videos, r)

@@ -143,15 +143,16 @@ class BertAttention(nn.Module):
         self.self = BertSelfAttention(hidden_size, num_attention_heads, dropout)
         self.output = BertSelfOutput(hidden_size, dropout)
 
-    def forward(self, input_tensor, attention_mask):
-        """input (N, L, H) compute dtype; attention_mask (N, 1, L) or (N, L) float 1=valid (key mask)."""
+    def forward(self, input_tensor, attention_mask, out=None):
+        """input (N, L, H) compute dtype; attention_mask (N, 1, L) or (N, L) float 1=valid (key mask).  out: optional
+        destination tensor (index build: the layer writes straight into the corpus index)."""
         if attention_mask.dim() == 3:
             attention_mask = attention_mask[:, 0]
         a = self.self.packed(input_tensor.dtype)
         o = self.output.packed(input_tensor.dtype)
         return ops.attention_block(input_tensor.contiguous(), attention_mask.float().contiguous(), a["wqkv"],
                                    a["bqkv"], o["wo"], o["bo"], o["ln_g"], o["ln_b"],
-                                   self.self.num_attention_heads)
+                                   self.self.num_attention_heads, out=out)
 
 
 class _QueryLinear(nn.Linear, _PackedMixin):
@@ -271,7 +272,7 @@ class XML(nn.Module):
         return _f(ln.weight), _f(ln.bias)
 
     # ---- encoders ------------------------------------------------------------------------------------
-    def encode_input(self, feat, mask, input_proj_layer, encoder_layer, pos_embed_layer):
+    def encode_input(self, feat, mask, input_proj_layer, encoder_layer, pos_embed_layer, out=None):
         """xml/model_xml.py:377-392.  feat (N, L, D_in) f32 (or compute dtype), mask (N, L) float."""
         dt = self.compute_dtype
         p, e = input_proj_layer.packed(dt), pos_embed_layer.packed(dt)
@@ -281,46 +282,50 @@ class XML(nn.Module):
             feat = feat.float()
         x = ops.linear_ln_relu_pos(feat.contiguous(), p["ln_g"], p["ln_b"], p["w"], p["b"], e["pos"], e["ln_g"],
                                    e["ln_b"])
-        return encoder_layer(x, mask)
+        return encoder_layer(x, mask) if out is None else encoder_layer(x, mask, out=out)
 
     def cross_context_encoder(self, main_context_feat, main_context_mask, side_context_feat, side_context_mask,
-                              cross_att_layer, norm_layer, self_att_layer):
+                              cross_att_layer, norm_layer, self_att_layer, out=None):
         """xml/model_xml.py:357-373."""
         c = cross_att_layer.packed(main_context_feat.dtype)
         g, b = self._ln_params(norm_layer)
         res = ops.cross_attention(main_context_feat, main_context_mask.float().contiguous(), side_context_feat,
                                   side_context_mask.float().contiguous(), c["wq"], c["bq"], c["wkv"], c["bkv"], g, b,
                                   cross_att_layer.num_attention_heads)
-        return self_att_layer(res, main_context_mask)
+        return self_att_layer(res, main_context_mask) if out is None else self_att_layer(res, main_context_mask, out=out)
 
-    def cross_encode_context(self, video_feat, video_mask, sub_feat, sub_mask):
+    def cross_encode_context(self, video_feat, video_mask, sub_feat, sub_mask, outs=(None, None, None, None)):
         """xml/model_xml.py:344-355."""
-        ev = self.encode_input(video_feat, video_mask, self.video_input_proj, self.video_encoder1, self.ctx_pos_embed)
-        es = self.encode_input(sub_feat, sub_mask, self.sub_input_proj, self.sub_encoder1, self.ctx_pos_embed)
+        ev = self.encode_input(video_feat, video_mask, self.video_input_proj, self.video_encoder1, self.ctx_pos_embed,
+                               out=outs[0])
+        es = self.encode_input(sub_feat, sub_mask, self.sub_input_proj, self.sub_encoder1, self.ctx_pos_embed, out=outs[2])
         xv = self.cross_context_encoder(ev, video_mask, es, sub_mask, self.video_cross_att,
-                                        self.video_cross_layernorm, self.video_encoder2)
+                                        self.video_cross_layernorm, self.video_encoder2, out=outs[1])
         xs = self.cross_context_encoder(es, sub_mask, ev, video_mask, self.sub_cross_att,
-                                        self.sub_cross_layernorm, self.sub_encoder2)
+                                        self.sub_cross_layernorm, self.sub_encoder2, out=outs[3])
         return ev, xv, es, xs
 
-    def non_cross_encode_context(self, context_feat, context_mask, module_name="video"):
+    def non_cross_encode_context(self, context_feat, context_mask, module_name="video", outs=(None, None)):
         """xml/model_xml.py:297-329: encoder1 -> feat1 ; encoder2 -> encoder3 -> feat2."""
         f1 = self.encode_input(context_feat, context_mask, getattr(self, module_name + "_input_proj"),
-                               getattr(self, module_name + "_encoder1"), self.ctx_pos_embed)
+                               getattr(self, module_name + "_encoder1"), self.ctx_pos_embed, out=outs[0])
         f2 = getattr(self, module_name + "_encoder2")(f1, context_mask)
-        f2 = getattr(self, module_name + "_encoder3")(f2, context_mask)
+        enc3 = getattr(self, module_name + "_encoder3")
+        f2 = enc3(f2, context_mask) if outs[1] is None else enc3(f2, context_mask, out=outs[1])
         return f1, f2
 
-    def encode_context(self, video_feat, video_mask, sub_feat, sub_mask):
-        """xml/model_xml.py:331-342.  Unused modalities return None."""
+    def encode_context(self, video_feat, video_mask, sub_feat, sub_mask, outs=(None, None, None, None)):
+        """xml/model_xml.py:331-342.  Unused modalities return None.  outs: optional destinations for (video feat1, video
+        feat2, sub feat1, sub feat2) -- contiguous (N, L, H) tensors of the compute dtype, e.g. row ranges of a preallocated
+        corpus index; the last layer of each branch then writes there directly."""
         if self.config.cross_att:
             assert self.use_video and self.use_sub
-            return self.cross_encode_context(video_feat, video_mask, sub_feat, sub_mask)
+            return self.cross_encode_context(video_feat, video_mask, sub_feat, sub_mask, outs)
         v1 = v2 = s1 = s2 = None
         if self.use_video:
-            v1, v2 = self.non_cross_encode_context(video_feat, video_mask, "video")
+            v1, v2 = self.non_cross_encode_context(video_feat, video_mask, "video", outs[0:2])
         if self.use_sub:
-            s1, s2 = self.non_cross_encode_context(sub_feat, sub_mask, "sub")
+            s1, s2 = self.non_cross_encode_context(sub_feat, sub_mask, "sub", outs[2:4])
         return v1, v2, s1, s2
 
     def get_modularized_queries(self, encoded_query, query_mask, return_modular_att=False):

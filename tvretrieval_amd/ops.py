@@ -94,15 +94,24 @@ def linear_ln_relu_pos(x, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
     return y
 
 
-def attention_block(x, key_mask, wqkv, bqkv, wo, bo, ln_g, ln_b, n_heads):
-    """K3+K4 (BertAttention).  x (N, L, H); key_mask (N, L) f32."""
+ENCODE_INTO_INDEX = True      # attention_block(out=...) exists: inference.build_corpus_index encodes into the index tensors
+
+
+def attention_block(x, key_mask, wqkv, bqkv, wo, bo, ln_g, ln_b, n_heads, out=None):
+    """K3+K4 (BertAttention).  x (N, L, H); key_mask (N, L) f32.  out: optional (N, L, H) contiguous destination (e.g. a
+    slice of a preallocated index tensor), must not alias x."""
     _req(x, "x"); _req(key_mask, "key_mask", torch.float32); _req(wqkv, "wqkv", x.dtype); _req(wo, "wo", x.dtype)
     for t, nm in ((bqkv, "bqkv"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b")):
         _req(t, nm, torch.float32)
     n, seq_len, hidden = x.shape
     lib = _lib.load()
     dt = dt_of(x)
-    y = torch.empty_like(x)
+    if out is None:
+        y = torch.empty_like(x)
+    else:
+        _req(out, "out", x.dtype)
+        assert out.shape == x.shape and out.data_ptr() != x.data_ptr()
+        y = out
     ws = _workspace(lib.xml_attention_block_workspace_bytes(n, seq_len, hidden, dt), x.device)
     check(lib.xml_attention_block(_p(x), _p(key_mask), _p(wqkv), _p(bqkv), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(y),
                                   n, seq_len, hidden, n_heads, dt, _p(ws), ws.numel(), _stream()),

@@ -324,7 +324,8 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
   const int nkt = (lk + 15) / 16;
   const int k_stride = DH * (int)sizeof(T) + 16;
   const int vt_stride = lkp * (int)sizeof(T) + 16;
-  const int kv_bytes = max(32 * k_stride, DH * vt_stride);
+  constexpr bool TR = sizeof(T) == 2;         // bf16: V stays row-major, P V reads it with ds_read_b64_tr_b16 (see above)
+  const int kv_bytes = TR ? 32 * k_stride : max(32 * k_stride, DH * vt_stride);
   const int wave_bytes = kv_bytes + 16 * vt_stride;
   char* s_kv = smem + wave * wave_bytes;
   char* s_p = s_kv + kv_bytes;
@@ -377,6 +378,8 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
   wave_sync();
 
   f32x4 p[2][NT];
+  constexpr bool FAST = sizeof(T) == 2;       // bf16 storage: reciprocals + v_exp_f32, as in attention_core_kernel
+  const float inv_sqrt_dh = 1.0f / sqrt_dh;
   const int nqt = (lq + 15) / 16;
   float km[NT];
 #pragma unroll
@@ -392,11 +395,9 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
 #pragma unroll
     for (int c = 0; c < DCH; ++c) {
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        if (j < nkt) {
-          const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
-          Mma<T>::chunk(p[t][j], qa[t][c], b);
-        }
+      for (int j = 0; j < NT; ++j) {      // (no `j < nkt` branch: K rows beyond lk are zeros in LDS, their scores are masked)
+        const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (j * 16 + fr) * k_stride + c * 64 + fg * 16);
+        Mma<T>::chunk(p[t][j], qa[t][c], b);
       }
     }
 #pragma unroll
@@ -408,7 +409,7 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
       for (int j = 0; j < NT; ++j) {
         const int col = j * 16 + fr;
         float sc = -INFINITY;
-        if (col < lk) sc = p[t][j][r] / sqrt_dh + (1.f - qm * km[j]) * -10000.f;
+        if (col < lk) sc = (FAST ? p[t][j][r] * inv_sqrt_dh : p[t][j][r] / sqrt_dh) + (1.f - qm * km[j]) * -10000.f;
         p[t][j][r] = sc;
         mx = fmaxf(mx, sc);
       }
@@ -416,18 +417,27 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
-        const float e = expf(p[t][j][r] - mx);
+        const float x = p[t][j][r] - mx;
+        const float e = FAST ? __builtin_amdgcn_exp2f(x * 1.4426950408889634f) : expf(x);
         p[t][j][r] = e;
         sum += e;
       }
       sum = lane16_sum_dpp(sum);
+      const float inv_sum = 1.0f / sum;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) p[t][j][r] = p[t][j][r] / sum;
+      for (int j = 0; j < NT; ++j) p[t][j][r] = FAST ? p[t][j][r] * inv_sum : p[t][j][r] / sum;
     }
   }
   wave_sync();                                // every lane is done reading K
 
-  {   // V^T -> LDS (overwrites K); rows lk .. lkp-1 are zero (lkp <= 32)
+  if constexpr (TR) {   // V rows -> LDS as they are (16-byte stores), over K
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const int i = lane + j * 64;
+      const int r = i / VPR, c = i % VPR;
+      *reinterpret_cast<uint4*>(s_kv + r * k_stride + c * 16) = vbuf[j];      // rows >= lk: the zeros loaded above
+    }
+  } else {   // V^T -> LDS (overwrites K); rows lk .. lkp-1 are zero (lkp <= 32)
 #pragma unroll
     for (int j = 0; j < NV; ++j) {
       const int i = lane + j * 64;
@@ -462,10 +472,19 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
     for (int d = 0; d < DT16; ++d) o[d] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < nkc; ++c) {
       const uint4 a = *reinterpret_cast<const uint4*>(s_p + fr * vt_stride + c * 64 + fg * 16);
+      if constexpr (TR) {
+        const char* vb0 = s_kv + (c * 32 + fg * 8 + (fr >> 2)) * k_stride + (fr & 3) * 8;
 #pragma unroll
-      for (int d = 0; d < DT16; ++d) {
-        const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (d * 16 + fr) * vt_stride + c * 64 + fg * 16);
-        Mma<T>::chunk(o[d], a, b);
+        for (int d = 0; d < DT16; ++d) {
+          const uint2 lo = lds_read_tr16(vb0 + d * 32), hi = lds_read_tr16(vb0 + d * 32 + 4 * k_stride);
+          Mma<T>::chunk(o[d], a, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+      } else {
+#pragma unroll
+        for (int d = 0; d < DT16; ++d) {
+          const uint4 b = *reinterpret_cast<const uint4*>(s_kv + (d * 16 + fr) * vt_stride + c * 64 + fg * 16);
+          Mma<T>::chunk(o[d], a, b);
+        }
       }
     }
     wave_sync();                              // the patch is rewritten by the next query tile
@@ -484,7 +503,7 @@ static size_t attn_small_lds_bytes(int lk, int dh, int dt) {
   const int es = (int)dt_size(dt), ce = 64 / es;
   const int lkp = (lk + ce - 1) / ce * ce;
   const size_t k_stride = (size_t)dh * es + 16, vt_stride = (size_t)lkp * es + 16;
-  const size_t kvb = std::max((size_t)32 * k_stride, (size_t)dh * vt_stride);
+  const size_t kvb = es == 2 ? (size_t)32 * k_stride : std::max((size_t)32 * k_stride, (size_t)dh * vt_stride);
   return 4 * (kvb + 16 * vt_stride);
 }
 

@@ -18,6 +18,11 @@ def main():
     a = ap.parse_args()
     from tvretrieval_amd import inference as inf
     from tvretrieval_amd.model_xml import XML
+    from tvretrieval_amd import _lib
+    lib = _lib.load()
+    if hasattr(lib, "xml_debug_set_q2c_ablation") and os.environ.get("XML_ABL"):      # debug library: kernel A/B switches
+        import ctypes
+        lib.xml_debug_set_q2c_ablation(ctypes.c_int(int(os.environ["XML_ABL"])))
     nq, nv, l, hidden, dv, ds, dq, ctx_mode, _ = bench.WORKLOADS["c3"]
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)

@@ -94,7 +94,7 @@ extern "C" int xml_debug_read_gemm_steps(unsigned int* host_out) {
 extern "C" int xml_debug_read_gemm_probe(unsigned long long* host_out) {
   return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_g256p_probe), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
 }
-#define G256P_T() (a.probe ? __builtin_amdgcn_s_memtime() : 0ull)
+#define G256P_T() ((a.probe & 1) ? __builtin_amdgcn_s_memtime() : 0ull)
 #else
 #define G256P_T() 0ull
 #endif
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
     } else {
       vb[0] = off_b(8 + (wave - 4) * 2); vb[1] = off_b(9 + (wave - 4) * 2);
     }
-    sbase_a = reinterpret_cast<const char*>(A) + m0 * k_bytes;
+    sbase_a = reinterpret_cast<const char*>(A) + ((a.probe & 2) ? (int64_t)(blockIdx.x & 31) * 256 : m0) * k_bytes;   // probe bit 1: A from a resident 8192-row window (timing only)
     sbase_b = reinterpret_cast<const char*>(W) + (int64_t)n0 * k_bytes;
   };
   auto issue_slice = [&]() {
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
   const unsigned long long pr_t0 = G256P_T();
 #ifdef XML_DEBUG_VARIANTS
   unsigned int* sp = reinterpret_cast<unsigned int*>(smem + RING_BYTES + wave * 4096 + 2048);     // this wave's patch, upper half
-  if (a.probe && lane < 64) sp[lane] = 0;
+  if ((a.probe & 1) && lane < 64) sp[lane] = 0;
   int pstep = 0;
   unsigned long long pst = 0;
 #endif
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       __builtin_amdgcn_sched_barrier(0);
       if (GRP1) { next_reads(); issue_slice(); }
 #ifdef XML_DEBUG_VARIANTS
-      if (a.probe) {
+      if (a.probe & 1) {
         const unsigned long long t = __builtin_amdgcn_s_memtime();
         if (lane == 0 && pstep < 64) sp[pstep] += (unsigned int)(t - pst);
         pst = t; ++pstep;
@@ -476,8 +476,17 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
               const uint4 d_odd = make_uint4(odd ? own_o.x : up.x, odd ? own_o.y : up.y, odd ? own_o.z : up.z, odd ? own_o.w : up.w);
               const int col = pcol[pq];
               if (col + GC <= N) {
-                if (m_even < M) st_global16(out + m_even * N + col, d_even);
-                if (m_even + 1 < M) st_global16(out + (m_even + 1) * N + col, d_odd);
+                // non-temporal: this kernel only runs on outputs of >= 3072 tiles (400 MB and up), nothing of which survives
+                // in a cache until its consumer starts; streaming stores retire ~2.5 % faster here (886 -> 906 TF at
+                // N = 2304, same box).  Not for LNE: pass 2 re-reads the tile through this XCD's L2.
+                if (!LNE && !(a.probe & 8)) {      // (probe bit 3: plain stores, A/B)
+                  typedef unsigned int g_u4 __attribute__((ext_vector_type(4)));
+                  if (m_even < M && !(a.probe & 4)) __builtin_nontemporal_store(g_u4{d_even.x, d_even.y, d_even.z, d_even.w}, reinterpret_cast<g_u4*>(out + m_even * N + col));
+                  if (m_even + 1 < M && !(a.probe & 4)) __builtin_nontemporal_store(g_u4{d_odd.x, d_odd.y, d_odd.z, d_odd.w}, reinterpret_cast<g_u4*>(out + (m_even + 1) * N + col));
+                } else {
+                  if (m_even < M && !(a.probe & 4)) st_global16(out + m_even * N + col, d_even);        // probe bit 2: no stores
+                  if (m_even + 1 < M && !(a.probe & 4)) st_global16(out + (m_even + 1) * N + col, d_odd);
+                }
               }
             }
           }
@@ -711,7 +720,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
     if (tile_of(c_k) >= a.n_tiles) break;
   }
 #ifdef XML_DEBUG_VARIANTS
-  if (a.probe && blockIdx.x == 0 && lane == 0) {
+  if ((a.probe & 1) && blockIdx.x == 0 && lane == 0) {
     pr[5] = __builtin_amdgcn_s_memtime() - pr_t0;
     for (int i = 0; i < 8; ++i) g_g256p_probe[wave * 8 + i] = pr[i];
     for (int i = 0; i < 64; ++i) g_g256p_steps[wave * 64 + i] = sp[i];
@@ -739,7 +748,7 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
   a.tn = cdiv(N, 256);
   a.n_tiles = (int64_t)cdiv(M, 256) * a.tn;
   a.ln_part = nullptr; a.ln_count = nullptr; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
-  a.probe = g_q2c_ablation == 9;
+  a.probe = g_q2c_ablation == 9 ? 1 : g_q2c_ablation == 21 ? 2 : g_q2c_ablation == 22 ? 4 : g_q2c_ablation == 23 ? 6 : g_q2c_ablation == 24 ? 8 : 0;
   if (LNE) {
     const int n_blocks = (int)cdiv(M, 256);
     a.ln_count = (int*)ln_ws;

@@ -81,6 +81,26 @@ def test_layernorm_fn(rows, d, resid):
              [needs_a, resid, True, True], tol=5e-5)
 
 
+@pytest.mark.parametrize("rows,d,a_dt", [(5000, 3072, F32), (37, 3072, torch.bfloat16), (301, 2056, F32), (64, 4096, F32)])
+def test_wide_layernorm_backward_parameters_only(rows, d, a_dt):
+    """the input LayerNorm of the 3072-d video features needs dgamma / dbeta only: xml_layernorm_bwd's one-pass kernel
+    (dx = NULL, bf16 dy) == float64 reference on the same values, and == the two-kernel path that also writes dx."""
+    from tvretrieval_amd import train_ops as TO
+    a = (rnd(rows, d, seed=1) * 2 + 0.3).to(a_dt)
+    dy = rnd(rows, d, seed=2).to(torch.bfloat16)
+    g = 1 + rnd(d, seed=3, scale=0.2)
+    dx0, dg, db = TO.layernorm_bwd(a, None, g, dy, need_dx=False)
+    assert dx0 is None
+    x = a.double()
+    xh = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    check("dgamma", dg, (dy.double() * xh).sum(0), 2e-5)
+    check("dbeta", db, dy.double().sum(0), 2e-5)
+    dx1, dg1, db1 = TO.layernorm_bwd(a, None, g, dy, need_dx=True)
+    assert dx1 is not None
+    check("dgamma vs two-kernel path", dg, dg1, 2e-5)
+    check("dbeta vs two-kernel path", db, db1, 2e-5)
+
+
 def ref_attention(q, k, v, qm, km, heads):
     n, lq, hsz = q.shape
     lk = k.shape[1]

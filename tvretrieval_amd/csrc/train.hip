@@ -206,6 +206,28 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
     for (int j = 0; j < 8; ++j) { pg[k * 8 + j] = 0.f; pb[k * 8 + j] = 0.f; gv[k * 8 + j] = v < nvec ? g[v * 8 + j] : 0.f; }
   }
   const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+  // The raw 16-byte vectors of the NEXT row are fetched before the four dependent wave reductions of the current one
+  // (a row is a memory round trip + ~1 us of reductions; issued load -> use per row, the kernel sat at 1.6 TB/s).
+  // Loads are unconditional from clamped vector indices -- inside `if (v < nvec)` hipcc waits vmcnt(0) at the join.
+  constexpr int VA = 16 / (int)sizeof(InT) == 8 ? 1 : 2, VB = 16 / (int)sizeof(BT) == 8 ? 1 : 2, VD = 16 / (int)sizeof(T) == 8 ? 1 : 2;
+  uint4 ra[2][VA], rb[2][VB], rd[2][VD];
+  auto fetch = [&](int64_t row) {
+    const int64_t rc = row < rows ? row : rows - 1;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int v = lane + k * 64;
+      const int vc = v < nvec ? v : 0;
+#pragma unroll
+      for (int h = 0; h < VA; ++h) ra[k][h] = ld_global16(a + rc * d + vc * 8 + h * (8 / VA));
+      if (b) {
+#pragma unroll
+        for (int h = 0; h < VB; ++h) rb[k][h] = ld_global16(b + rc * d + vc * 8 + h * (8 / VB));
+      }
+#pragma unroll
+      for (int h = 0; h < VD; ++h) rd[k][h] = ld_global16(dy + rc * d + vc * 8 + h * (8 / VD));
+    }
+  };
+  fetch(row0);
   for (int rr = 0; rr < rows_per_wave; ++rr) {
     const int64_t row = row0 + rr;
     if (row >= rows) break;
@@ -213,23 +235,26 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
     float s = 0.f;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
-      const int v = lane + k * 64;
-      if (v < nvec) {
-        ld8<InT>(a + row * d + v * 8, x + k * 8);
-        if (b) {
-          float t[8];
-          ld8<BT>(b + row * d + v * 8, t);
+      const bool on = lane + k * 64 < nvec;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) x[k * 8 + j] += t[j];
-        }
-        ld8<T>(dy + row * d + v * 8, gy + k * 8);
-      } else {
+      for (int h = 0; h < VA; ++h) unpack16<InT>(ra[k][h], x + k * 8 + h * (8 / VA));
+      if (b) {
+        float t[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { x[k * 8 + j] = 0.f; gy[k * 8 + j] = 0.f; }
+        for (int h = 0; h < VB; ++h) unpack16<BT>(rb[k][h], t + h * (8 / VB));
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[k * 8 + j] += t[j];
       }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) s += x[k * 8 + j];
+      for (int h = 0; h < VD; ++h) unpack16<T>(rd[k][h], gy + k * 8 + h * (8 / VD));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        x[k * 8 + j] = on ? x[k * 8 + j] : 0.f;
+        gy[k * 8 + j] = on ? gy[k * 8 + j] : 0.f;
+        s += x[k * 8 + j];
+      }
     }
+    if (rr + 1 < rows_per_wave) fetch(row + 1);         // (wave-uniform; clamped inside)
     const float mean = wave_sum(s) / (float)d;
     float var = 0.f;
 #pragma unroll
@@ -272,8 +297,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
   }
   __syncthreads();
   for (int c = threadIdx.x; c < d; c += 256) {
-    if (dg) atomicAdd(dg + c, s_pg[0][c] + s_pg[1][c] + s_pg[2][c] + s_pg[3][c]);
-    if (dbeta) atomicAdd(dbeta + c, s_pb[0][c] + s_pb[1][c] + s_pb[2][c] + s_pb[3][c]);
+    if (dg) unsafeAtomicAdd(dg + c, s_pg[0][c] + s_pg[1][c] + s_pg[2][c] + s_pg[3][c]);       // hardware f32 add, no CAS loop
+    if (dbeta) unsafeAtomicAdd(dbeta + c, s_pb[0][c] + s_pb[1][c] + s_pb[2][c] + s_pb[3][c]);
   }
 }
 
@@ -326,6 +351,94 @@ __global__ __launch_bounds__(256) void ln_bwd_cols_kernel(const InT* __restrict_
   if (dbeta) atomicAdd(dbeta + c, pb);
 }
 
+// Wide rows, parameter gradients only (dx == NULL: the 3072-d input LayerNorm of the video features, whose input needs no
+// gradient): ONE pass -- a wave keeps a row in registers (16-byte loads), takes mean / rstd, and accumulates dy * xhat and
+// dy per column; the four waves of a block meet in LDS (ds_add_f32), one global atomic per column and block.  The
+// two-kernel path above read the f32 row four times with scalar loads (190 us per step at 12 800 x 3072).
+template <typename InT, typename T, int KV>
+__global__ __launch_bounds__(256) void ln_bwd_wide_params_kernel(const InT* __restrict__ a, const T* __restrict__ dy,
+                                                                 float* __restrict__ dg, float* __restrict__ dbeta,
+                                                                 int64_t rows, int d, float eps, int rows_per_wave) {
+  extern __shared__ float s_acc[];               // [2][d]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nvec = d >> 3;
+  for (int i = threadIdx.x; i < 2 * d; i += 256) s_acc[i] = 0.f;
+  __syncthreads();
+  float pg[KV * 8], pb[KV * 8];
+#pragma unroll
+  for (int i = 0; i < KV * 8; ++i) { pg[i] = 0.f; pb[i] = 0.f; }
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * rows_per_wave;
+  for (int rr = 0; rr < rows_per_wave; ++rr) {
+    const int64_t row = row0 + rr;
+    if (row >= rows) break;
+    float x[KV * 8], gy[KV * 8];
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {               // unconditional loads from clamped vectors, zeroed by selects below
+      const int v = lane + k * 64;
+      const int vc = v < nvec ? v : 0;
+      ld8<InT>(a + row * d + vc * 8, x + k * 8);
+      ld8<T>(dy + row * d + vc * 8, gy + k * 8);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KV; ++k) {
+      const bool on = lane + k * 64 < nvec;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        x[k * 8 + j] = on ? x[k * 8 + j] : 0.f;
+        gy[k * 8 + j] = on ? gy[k * 8 + j] : 0.f;
+        s += x[k * 8 + j];
+      }
+    }
+    const float mean = wave_sum(s) / (float)d;
+    float var = 0.f;
+#pragma unroll
+    for (int k = 0; k < KV; ++k)
+      if (lane + k * 64 < nvec)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float c = x[k * 8 + j] - mean; var += c * c; }
+    const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);
+#pragma unroll
+    for (int i = 0; i < KV * 8; ++i) {           // (padding vectors: dy = 0)
+      pg[i] += gy[i] * ((x[i] - mean) * rstd);
+      pb[i] += gy[i];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int v = lane + k * 64;
+    if (v < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(&s_acc[v * 8 + j], pg[k * 8 + j]);
+        atomicAdd(&s_acc[d + v * 8 + j], pb[k * 8 + j]);
+      }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < d; c += 256) {
+    if (dg) unsafeAtomicAdd(dg + c, s_acc[c]);
+    if (dbeta) unsafeAtomicAdd(dbeta + c, s_acc[d + c]);
+  }
+}
+
+template <typename InT, typename T>
+static int ln_bwd_wide_params(const void* a, const void* dy, float* dg, float* dbeta, int64_t rows, int d, hipStream_t st) {
+  const int rpw = rows >= 4096 ? 4 : 1;
+  const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
+  const size_t lds = (size_t)2 * d * 4;
+  const int kv = cdiv(d >> 3, 64);
+#define XML_LNW(KV)                                                                                                       \
+  hipLaunchKernelGGL((ln_bwd_wide_params_kernel<InT, T, KV>), grid, blk, lds, st, (const InT*)a, (const T*)dy, dg, dbeta, rows, \
+                     d, 1e-5f, rpw)
+  if (kv <= 2) XML_LNW(2);
+  else if (kv <= 4) XML_LNW(4);
+  else if (kv <= 6) XML_LNW(6);
+  else XML_LNW(8);
+#undef XML_LNW
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
 template <typename InT, typename T>
 static int ln_bwd_wide(const void* a, const float* g, const void* dy, void* dx, float* dg, float* dbeta, int64_t rows,
                        int d, float* stats, hipStream_t st) {
@@ -347,6 +460,10 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
   hipStream_t st = (hipStream_t)stream;
   if (d > 1024 || (d & 7)) {
     if (b) return XML_ERR_UNSUPPORTED;
+    if (!dx && !(d & 7) && d <= 4096) {          // parameter gradients only: one pass (the f32 compute path keeps two)
+      if (dt == XML_BF16 && a_dt == XML_F32) return ln_bwd_wide_params<float, bf16_t>(a, dy, dg, dbeta, rows, d, st);
+      if (dt == XML_BF16 && a_dt == XML_BF16) return ln_bwd_wide_params<bf16_t, bf16_t>(a, dy, dg, dbeta, rows, d, st);
+    }
     if (!ws || ws_bytes < (size_t)rows * 16) return XML_ERR_WORKSPACE;
     if (dt == XML_F32 && a_dt == XML_F32) return ln_bwd_wide<float, float>(a, g, dy, dx, dg, dbeta, rows, d, (float*)ws, st);
     if (dt == XML_BF16 && a_dt == XML_F32) return ln_bwd_wide<float, bf16_t>(a, g, dy, dx, dg, dbeta, rows, d, (float*)ws, st);
@@ -354,7 +471,10 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
     return XML_ERR_BAD_ARG;
   }
   if (!dx) return XML_ERR_BAD_ARG;
-  const int rpw = rows >= 8192 ? 16 : (rows >= 1024 ? 4 : 1);
+  // rows per wave: a wave handles its rows one after the other, each a memory round trip plus four dependent wave
+  // reductions (~3.5 us), so the launch must be wide -- 16 rows per wave left 200 workgroups for the step's 12 800 rows
+  // (58 us per call); more workgroups cost d atomics each for dg / dbeta
+  const int rpw = rows >= 65536 ? 16 : (rows >= 1024 ? 4 : 1);
   const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
   if (dt == XML_F32) {
     if (a_dt != XML_F32) return XML_ERR_BAD_ARG;

@@ -179,6 +179,11 @@ class HipBackend(object):
     name, dist_backend = "hip", "nccl"
 
     def __init__(self, local_rank):
+        # TEST HOOK (tests/test_gpu_dist.py): XML_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with gloo between them, so that
+        # the N > 1 code path runs with the real kernels on a one-GPU box (RCCL refuses two ranks on one device)
+        self.shared = os.environ.get("XML_BENCH_SHARE_GPU") == "1"
+        if self.shared:
+            local_rank, self.dist_backend = 0, "gloo"
         torch.cuda.set_device(local_rank)
         self.device = torch.device("cuda", local_rank)
         from tvretrieval_amd import ops
@@ -195,7 +200,7 @@ class HipBackend(object):
         return torch.cuda.Event(enable_timing=True)
 
     def init_kwargs(self):
-        return dict(device_id=self.device)
+        return {} if self.shared else dict(device_id=self.device)
 
 
 def load_backend(args, local_rank):

@@ -1,6 +1,8 @@
-"""GPU-side check of the multi-GPU code path on a one-GPU box: a real single-rank RCCL process group
-(tests/rccl_world1_check.py under torch.distributed.run).  World sizes > 1 are covered on CPU by the gloo tests
-(tests/test_dist_gloo.py) and on hardware by the driver's scaling run."""
+"""GPU-side checks of the multi-GPU code path on a one-GPU box: (1) a real single-rank RCCL process group
+(tests/rccl_world1_check.py under torch.distributed.run); (2) TWO ranks sharing the GPU with gloo between them -- real
+kernels, real shards, sharded search == single-process search bit for bit (tests/two_ranks_one_gpu_check.py), and
+`bench.py --gpus 2` through its own launcher in the same configuration.  RCCL across several GPUs is measured by the
+driver's scaling run; its call pattern is what (1) exercises."""
 import os
 import socket
 import subprocess
@@ -22,3 +24,29 @@ def test_rccl_single_rank_group_runs_the_sharded_path():
            "127.0.0.1", "--master-port", str(port), os.path.join(HERE, "rccl_world1_check.py")]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_ranks_sharing_one_gpu_sharded_search_equals_single_process(world):
+    r = subprocess.run([sys.executable, "-c",
+                        "import sys; sys.path.insert(0, %r); from tvretrieval_amd import launch; "
+                        "sys.exit(launch.spawn_local_ranks(%r, [], %d, timeout=500))"
+                        % (os.path.dirname(HERE), os.path.join(HERE, "two_ranks_one_gpu_check.py"), world)],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TWO_RANKS_ONE_GPU_OK world=%d" % world in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_bench_two_ranks_on_one_gpu():
+    """`python bench.py --gpus 2` (self-spawned ranks, real kernels, shards of the tiny workload): one JSON line, n_gpus 2."""
+    import json
+    env = dict(os.environ, XML_BENCH_SHARE_GPU="1")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workload", "tiny",
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0
+    assert len(out["config"]["videos_per_gpu"]) == 2 and sum(out["config"]["videos_per_gpu"]) > 0
+    assert out["config"]["ranks_in_process_group"] == 2

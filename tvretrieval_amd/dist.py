@@ -82,12 +82,36 @@ def _pack_rows(score, idx, rows, pad_score, pad_idx):
     return buf
 
 
+def _host_staged(t, group):
+    """gloo has no device collectives for all-to-all (and only some for all-gather): ranks that keep their tensors on a GPU
+    but talk over gloo -- the two-ranks-on-one-GPU test configuration -- stage through host memory."""
+    return t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+def _all_to_all_single(out, inp, group):
+    if _host_staged(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(o, inp.cpu(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_to_all_single(out, inp, group=group)
+
+
+def _all_gather_into_tensor(out, inp, group):
+    if _host_staged(inp, group):
+        o = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_gather_into_tensor(o, inp.cpu().contiguous(), group=group)
+        out.copy_(o)
+    else:
+        dist.all_gather_into_tensor(out, inp, group=group)
+
+
 def _exchange_by_owner(buf, group, world, per):
     """buf (world*per, 2, c): rows of slice r go to rank r.  Returns the candidates of MY slice from every rank as
     (score (per, world*c) f32, ids (per, world*c) i32), source-rank-major within a row."""
     c = buf.shape[2]
     out = torch.empty_like(buf)
-    dist.all_to_all_single(out, buf, group=group)
+    _all_to_all_single(out, buf, group)
     cand = out.view(world, per, 2, c).permute(2, 1, 0, 3).contiguous()          # (2, per, world, c)
     return cand[0].reshape(per, world * c).view(torch.float32), cand[1].reshape(per, world * c)
 
@@ -106,7 +130,7 @@ def replicate_rerank_features(index, group=None):
     dev = index.device
     meta = torch.tensor([index.video_offset, index.n_videos], dtype=torch.int64, device=dev)
     metas = torch.empty((world * 2,), dtype=torch.int64, device=dev)
-    dist.all_gather_into_tensor(metas, meta, group=group)
+    _all_gather_into_tensor(metas, meta, group)
     metas = metas.view(world, 2).cpu().tolist()
     n_max = max(n for _, n in metas)
     feat2_all, mask_all = {}, {}
@@ -115,7 +139,7 @@ def replicate_rerank_features(index, group=None):
             pad = src.new_zeros((n_max,) + tuple(src.shape[1:]))
             pad[:src.shape[0]] = src
             out = src.new_empty((world * n_max,) + tuple(src.shape[1:]))
-            dist.all_gather_into_tensor(out, pad, group=group)
+            _all_gather_into_tensor(out, pad, group)
             full = src.new_empty((index.n_total,) + tuple(src.shape[1:]))
             for r, (off, n) in enumerate(metas):
                 full[off:off + n] = out[r * n_max:r * n_max + n]
@@ -137,7 +161,7 @@ class TorchExchange(object):
 
     def allgather_rows(self, buf):
         out = torch.empty((self.world * buf.shape[0],) + tuple(buf.shape[1:]), dtype=buf.dtype, device=buf.device)
-        dist.all_gather_into_tensor(out, buf.contiguous(), group=self.group)
+        _all_gather_into_tensor(out, buf.contiguous(), self.group)
         return out
 
     def allgather_topk(self, loc_s, loc_i, k, alpha, ops):

@@ -717,29 +717,46 @@ __global__ __launch_bounds__(256) void modular_pool_small_kernel(const T* __rest
   const T* e = enc + (int64_t)q * lq * hidden;
   float x[8][16];                       // up to 8 tokens per wave, 2 vectors of 8 per lane
   float w0[16], w1[16];
+  // Every load of this kernel is UNCONDITIONAL, from a clamped (always valid) index, and zeroed by a select afterwards: with
+  // `if (l < lq && v < nvec) load` hipcc loses its vmcnt count at the branch join and waits vmcnt(0) behind each 16-byte
+  // load -- 16 memory round trips per workgroup in a row (seen in the ISA; the kernel ran at 1.2 TB/s).
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int v = lane + k * 64;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      w0[k * 8 + j] = v < nvec ? wm[v * 8 + j] : 0.f;
-      w1[k * 8 + j] = (v < nvec && n_mod > 1) ? wm[hidden + v * 8 + j] : 0.f;
-    }
+    const int vc = v < nvec ? v : 0;
+    ld8<float>(wm + vc * 8, w0 + k * 8);
+    ld8<float>(wm + (n_mod > 1 ? hidden : 0) + vc * 8, w1 + k * 8);
   }
-  // every token row of this wave and its mask value first, as one batch of loads (written load -> use per token, hipcc
-  // waited for each 16-byte load in turn: 16 memory round trips per workgroup, most of this kernel's time)
   float mk8[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t) {
     const int l = wave + t * 4;
-    mk8[t] = l < lq ? mask[(int64_t)q * lq + l] : 0.f;
+    const int lc = l < lq ? l : 0;
+    mk8[t] = mask[(int64_t)q * lq + lc];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int v = lane + k * 64;
-      if (l < lq && v < nvec) ld8<T>(e + (int64_t)l * hidden + v * 8, x[t] + k * 8);
-      else
+      ld8<T>(e + (int64_t)lc * hidden + (v < nvec ? v : 0) * 8, x[t] + k * 8);
+    }
+  }
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[t][k * 8 + j] = 0.f;
+  for (int k = 0; k < 2; ++k) {
+    const bool von = lane + k * 64 < nvec;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      w0[k * 8 + j] = von ? w0[k * 8 + j] : 0.f;
+      w1[k * 8 + j] = (von && n_mod > 1) ? w1[k * 8 + j] : 0.f;
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const bool lon = wave + t * 4 < lq;
+    mk8[t] = lon ? mk8[t] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const bool on = lon && lane + k * 64 < nvec;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[t][k * 8 + j] = on ? x[t][k * 8 + j] : 0.f;
     }
   }
 #pragma unroll

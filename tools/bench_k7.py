@@ -16,7 +16,7 @@ with torch.no_grad():
     tw, ti = ops.topk_rows(q2c, 100, alpha=20.0)
     lib = ops._lib.load()
     assert hasattr(lib, "xml_debug_set_q2c_variant"), "needs the debug library: XML_DEBUG=1 bash tvretrieval_amd/csrc/build.sh; XMLHIP_LIB=$PWD/tvretrieval_amd/csrc/libxmlhip_dbg.so"
-    for abl in (0, 1, 2):
+    for abl in [int(x) for x in os.environ.get("K7_ABLS", "0,1,2").split(",")]:
         lib.xml_debug_set_q2c_ablation(ctypes.c_int(abl))
         for _ in range(2):
             inf.stage_span_probs(m, index, qvec, ti)

@@ -115,16 +115,6 @@ template <> struct Mma<bf16_t> {
 };
 
 // ---- wave / block reductions ---------------------------------------------------------------------
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
-}
 // reductions over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float lane16_max(float v) {
 #pragma unroll
@@ -150,6 +140,19 @@ __device__ __forceinline__ float lane16_sum_dpp(float v) {
   v += XML_ROR(v, 1);
 #undef XML_ROR
   return v;
+}
+// 64-lane reductions: four DPP row rotations inside each 16-lane row, then two crossbar steps (xor 16, 32).  The plain
+// xor butterfly was six dependent ds_bpermute round trips; every row-wise kernel (LayerNorm forward / backward, ConvSE
+// softmax, pooling) chains several of these per row.
+__device__ __forceinline__ float wave_sum(float v) {
+  v = lane16_sum_dpp(v);
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ float wave_max(float v) {
+  v = lane16_max_dpp(v);
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
 }
 __device__ __forceinline__ float lane16_sum(float v) {
 #pragma unroll

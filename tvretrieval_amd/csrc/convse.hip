@@ -12,20 +12,6 @@
 // softmax over clips.
 #include "gemm.h"
 
-// 64-lane reductions for the per-row softmax: four DPP row rotations inside each 16-lane row, then two crossbar steps
-// (xor 16, 32) -- the plain butterfly is six dependent ds_bpermute round trips, and a pair row needs four reductions
-// (the epilogue alone, GEMMs ablated, was 0.76 ms of K7's 2.35 ms at C3)
-__device__ __forceinline__ float cv_wave_max(float v) {
-  v = lane16_max_dpp(v);
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  return fmaxf(v, __shfl_xor(v, 32, 64));
-}
-__device__ __forceinline__ float cv_wave_sum(float v) {
-  v = lane16_sum_dpp(v);
-  v += __shfl_xor(v, 16, 64);
-  return v + __shfl_xor(v, 32, 64);
-}
-
 static constexpr int TM = 64;            // pairs per workgroup chunk (a video has ~46 pairs at C3: one chunk each)
 static constexpr int LP = 128 + 4;       // padded row length of the LDS similarity patch (floats)
 
@@ -258,11 +244,11 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
       st[h] = s_acc; ed[h] = e_acc;
     }
     if (a.softmax) {
-      const float ms = cv_wave_max(fmaxf(st[0], st[1])), me = cv_wave_max(fmaxf(ed[0], ed[1]));
+      const float ms = wave_max(fmaxf(st[0], st[1])), me = wave_max(fmaxf(ed[0], ed[1]));
       float es[2], ee[2];
 #pragma unroll
       for (int h = 0; h < 2; ++h) { es[h] = expf(st[h] - ms); ee[h] = expf(ed[h] - me); }
-      const float ss = cv_wave_sum(es[0] + es[1]), se = cv_wave_sum(ee[0] + ee[1]);
+      const float ss = wave_sum(es[0] + es[1]), se = wave_sum(ee[0] + ee[1]);
 #pragma unroll
       for (int h = 0; h < 2; ++h) { st[h] = es[h] / ss; ed[h] = ee[h] / se; }
     }

@@ -302,7 +302,8 @@ int xml_attn_softmax(const float* S, const float* dP, const float* q_mask, const
  * Row ranges are combined with f32 atomics: the summation order, hence the last bits, vary from run to run (as with
  * xml_gemm_batched's split-K). */
 int xml_gemm_tn_supported(int64_t rows, int N, int K, int dt);
-int xml_gemm_tn(const void* A, const void* B, float* out, int64_t rows, int N, int K, int dt, xml_stream_t stream);
+int xml_gemm_tn(const void* A, const void* B, float* out, float* colsum_a, int64_t rows, int N, int K, int dt,
+                xml_stream_t stream);      /* colsum_a (N) f32 or NULL: = sum_r A[r][n] (the layer's bias gradient), same launch */
 /* Fused training attention (bf16 storage; xml/model_components.py:266-303 incl. the probabilities dropout :297), one
  * launch each way instead of the split_heads / batched GEMM / xml_attn_softmax / xml_dropout / merge_heads chain:
  *   fwd   out (n, lq, ldo) head h columns [h dh, (h+1) dh)  =  dropout(softmax(Q K^T / sqrt(dh) + mask bias)) V

@@ -495,8 +495,9 @@ def test_weight_gradient_gemm_from_row_major_operands(rows, n, k):
     from tvretrieval_amd import train_ops as TO
     dy = rnd(rows, n, seed=11).to(torch.bfloat16)
     x = rnd(rows, k, seed=12).to(torch.bfloat16)
-    got = TO.gemm_tn(dy, x)
+    got, cs = TO.gemm_tn(dy, x, colsum=True)
     assert got is not None and got.shape == (n, k) and got.dtype == F32
+    check("gemm_tn column sums", cs, dy.double().sum(0), 2e-5)
     want = dy.double().t() @ x.double()
     check("gemm_tn", got, want, 2e-5)
     r8 = (rows + 7) // 8 * 8

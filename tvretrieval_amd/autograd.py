@@ -61,14 +61,17 @@ class LinearFn(torch.autograd.Function):
                 a = torch.zeros((rows, _r8(n)), dtype=dy.dtype, device=dy.device)
                 a[:, :n] = dy2
             dx = ops.linear(a, wt).view(x.shape)                                   # dX = dY W
+        want_db = ctx.has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = T.gemm_tn(dy2, x2)                                               # dW = dY^T X from the row-major operands
+            dw = T.gemm_tn(dy2, x2, colsum=want_db)                               # dW = dY^T X (+ db = column sums of dY)
+            if dw is not None and want_db:
+                dw, db = dw
             if dw is None:
                 r8 = _r8(rows)
                 dyt = T.transpose(dy2, r8)                                        # (N, rows8)
                 xt = T.transpose(x2, r8)                                          # (K, rows8)
                 dw = T.gemm_batched(dyt, xt, out_f32=True)
-        if ctx.has_bias and ctx.needs_input_grad[2]:
+        if want_db and db is None:
             db = T.colsum(dy2, rows, n)
         return dx, dw, db, None
 
@@ -192,11 +195,13 @@ class QkvFn(torch.autograd.Function):
         rows = x.numel() // k
         dy2, x2 = dy.view(rows, n3), x.contiguous().view(rows, k)
         dx = ops.linear(dy2, T.transpose(w)).view(x.shape) if ctx.needs_input_grad[0] else None
-        dw = T.gemm_tn(dy2, x2)                                                            # (3H, H)
+        dw = T.gemm_tn(dy2, x2, colsum=True)                                               # (3H, H) and the three bias gradients
         if dw is None:
             r8 = _r8(rows)
             dw = T.gemm_batched(T.transpose(dy2, r8), T.transpose(x2, r8), out_f32=True)
-        db = T.colsum(dy2, rows, n3)
+            db = T.colsum(dy2, rows, n3)
+        else:
+            dw, db = dw
         return dx, dw[:h], db[:h], dw[h:2 * h], db[h:2 * h], dw[2 * h:], db[2 * h:]
 
 

@@ -19,9 +19,13 @@ __device__ __forceinline__ uint2 tn_read_tr16(const char* p) {
   return __builtin_bit_cast(uint2, r);
 }
 
+// colsum (optional): colsum[n] += sum_r A[r][n] -- the bias gradient of the same layer, taken from the dY slabs the
+// workgroups of the first k tile load anyway (one launch and one pass over dY less per layer).
 __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                      float* __restrict__ out, int rows, int N, int K, int rows_per_split) {
+                                                      float* __restrict__ out, float* __restrict__ colsum, int rows, int N,
+                                                      int K, int rows_per_split) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 32 * TN_STRIDE];      // [buffer][operand][32 rows]
+  __shared__ float s_cs[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int wn = wave >> 1, wk = wave & 1;
@@ -48,6 +52,8 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
       rb[i] = ld_global16(B + (int64_t)rc * K + cb);
     }
   };
+  const bool do_cs = colsum != nullptr && blockIdx.x == 0;      // (workgroup-uniform)
+  float cs[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   auto stash = [&](const uint4 (&ra)[2], const uint4 (&rb)[2], int buf, int slab) {
     char* sa = smem + buf * (2 * 32 * TN_STRIDE);
     char* sb = sa + 32 * TN_STRIDE;
@@ -55,8 +61,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     for (int i = 0; i < 2; ++i) {
       const bool rok = r_begin + slab * 32 + lr + 16 * i < r_end;
       const bool ka = rok && a_ok, kb = rok && b_ok;
-      *reinterpret_cast<uint4*>(sa + (lr + 16 * i) * TN_STRIDE + lc * 16) =
-          make_uint4(ka ? ra[i].x : 0u, ka ? ra[i].y : 0u, ka ? ra[i].z : 0u, ka ? ra[i].w : 0u);
+      const uint4 za = make_uint4(ka ? ra[i].x : 0u, ka ? ra[i].y : 0u, ka ? ra[i].z : 0u, ka ? ra[i].w : 0u);
+      if (do_cs) {
+        float f[8];
+        unpack16<bf16_t>(za, f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cs[e] += f[e];
+      }
+      *reinterpret_cast<uint4*>(sa + (lr + 16 * i) * TN_STRIDE + lc * 16) = za;
       *reinterpret_cast<uint4*>(sb + (lr + 16 * i) * TN_STRIDE + lc * 16) =
           make_uint4(kb ? rb[i].x : 0u, kb ? rb[i].y : 0u, kb ? rb[i].z : 0u, kb ? rb[i].w : 0u);
     }
@@ -108,6 +120,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__
     step(s + 1, r1a, r1b, r0a, r0b);
   }
 
+  if (do_cs) {        // the 16 threads that share a column group meet in LDS, one global atomic per column
+    if (tid < 128) s_cs[tid] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) atomicAdd(&s_cs[lc * 8 + e], cs[e]);
+    __syncthreads();
+    if (tid < 128 && n0 + tid < N) unsafeAtomicAdd(colsum + n0 + tid, s_cs[tid]);
+  }
   const bool split = gridDim.z > 1;
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -131,7 +151,8 @@ extern "C" int xml_gemm_tn_supported(int64_t rows, int N, int K, int dt) {
   return dt == XML_BF16 && rows > 0 && N > 0 && K > 0 && N % 8 == 0 && K % 8 == 0;
 }
 
-extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, int64_t rows, int N, int K, int dt, xml_stream_t stream) {
+extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, float* colsum_a, int64_t rows, int N, int K, int dt,
+                           xml_stream_t stream) {
   XML_ENTER();
   if (!A || !B || !out || rows <= 0 || rows > 0x7fffffff || N <= 0 || K <= 0) return XML_ERR_BAD_ARG;
   if (!xml_gemm_tn_supported(rows, N, K, dt)) return XML_ERR_UNSUPPORTED;
@@ -149,8 +170,9 @@ extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, int64_t row
   if (rps < 256) rps = 256;
   splits = cdiv(rows, rps);
   if (splits > 1 && hipMemsetAsync(out, 0, (size_t)N * K * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  if (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)N * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(K, 128), cdiv(N, 128), splits), dim3(256), 0, st, (const bf16_t*)A,
-                     (const bf16_t*)B, out, (int)rows, N, K, rps);
+                     (const bf16_t*)B, out, colsum_a, (int)rows, N, K, rps);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -116,16 +116,18 @@ def merge_heads(xh, n, l, heads, out=None, col0=0):
 DISABLE_GEMM_TN = False               # tests / A-B measurements: transposes + split-K NT GEMM for the weight gradients
 
 
-def gemm_tn(a, b):
-    """a (rows, N), b (rows, K) -> a^T b (N, K) f32, or None when the shape / dtype is not served (caller falls back)."""
+def gemm_tn(a, b, colsum=False):
+    """a (rows, N), b (rows, K) -> a^T b (N, K) f32, or None when the shape / dtype is not served (caller falls back).
+    colsum=True: -> (a^T b, column sums of a (N,) f32) from the same launch (a layer's weight and bias gradients)."""
     _req(a, "a"); _req(b, "b", a.dtype)
     rows, n = a.shape
     k = b.shape[1]
     if DISABLE_GEMM_TN or not _lib.load().xml_gemm_tn_supported(rows, n, k, dt_of(a)):
         return None
     out = torch.empty((n, k), dtype=F32, device=a.device)
-    check(_lib.load().xml_gemm_tn(_p(a), _p(b), _p(out), rows, n, k, dt_of(a), _stream()), "xml_gemm_tn")
-    return out
+    cs = torch.empty(n, dtype=F32, device=a.device) if colsum else None
+    check(_lib.load().xml_gemm_tn(_p(a), _p(b), _p(out), _p(cs), rows, n, k, dt_of(a), _stream()), "xml_gemm_tn")
+    return (out, cs) if colsum else out
 
 
 DISABLE_FUSED_ATTENTION = False      # tests / A-B measurements: keep the unfused chain for bf16 too

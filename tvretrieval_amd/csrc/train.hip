@@ -117,7 +117,8 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ x, fl
     for (int u = 0; u < 8; ++u) s += DT<T>::ld(&v[u]);
   }
   for (; r < r1; ++r) s += DT<T>::ld(x + r * cols + c);
-  atomicAdd(out + c, s);
+  unsafeAtomicAdd(out + c, s);      // hardware f32 add throughout this file: plain atomicAdd(float*) is a CAS loop here, and many
+                                    // blocks meeting on few addresses make it thrash (adam_norm: 104 -> 20 us)
 }
 
 extern "C" int xml_colsum(const void* x, int x_dt, float* out, int64_t rows, int cols, int accumulate,
@@ -347,8 +348,8 @@ __global__ __launch_bounds__(256) void ln_bwd_cols_kernel(const InT* __restrict_
     pb += dyv;
     if (dx) DT<T>::st(dx + r * d + c, rstd * (dyv * gc - stats[r * 4 + 2] - xh * stats[r * 4 + 3]));
   }
-  if (dg) atomicAdd(dg + c, pg);
-  if (dbeta) atomicAdd(dbeta + c, pb);
+  if (dg) unsafeAtomicAdd(dg + c, pg);
+  if (dbeta) unsafeAtomicAdd(dbeta + c, pb);
 }
 
 // Wide rows, parameter gradients only (dx == NULL: the 3072-d input LayerNorm of the video features, whose input needs no
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void gemm_batched_kernel(const T* __restrict__
       for (int r = 0; r < 4; ++r) {
         const int m = m0 + wm * 64 + mt * 16 + (lane >> 4) * 4 + r;
         if (m >= M) continue;
-        if constexpr (SPLIT) atomicAdd(reinterpret_cast<float*>(Oz) + (int64_t)m * N + n, acc[mt][nt][r] * scale);
+        if constexpr (SPLIT) unsafeAtomicAdd(reinterpret_cast<float*>(Oz) + (int64_t)m * N + n, acc[mt][nt][r] * scale);
         else DT<OutT>::st(Oz + (int64_t)m * N + n, acc[mt][nt][r] * scale);
       }
     }
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(256) void modular_pool_bwd_kernel(const T* __restri
       }
       DT<T>::st(denc + ((int64_t)q * lq + l) * hidden + h, g);
     }
-    for (int m = 0; m < n_mod; ++m) atomicAdd(dwm + m * hidden + h, dw[m]);
+    for (int m = 0; m < n_mod; ++m) unsafeAtomicAdd(dwm + m * hidden + h, dw[m]);
   }
 }
 
@@ -914,8 +915,8 @@ __global__ __launch_bounds__(256) void q2c_scores_bwd_kernel(const T* __restrict
   if (gm == 0.f) return;
   const T* c = cn + ((int64_t)n * L + best_l) * hidden;
   for (int h = lane; h < hidden; h += 64) {
-    atomicAdd(dqn + (int64_t)m * hidden + h, gm * DT<T>::ld(c + h));
-    atomicAdd(dcn + ((int64_t)n * L + best_l) * hidden + h, gm * DT<T>::ld(q + h));
+    unsafeAtomicAdd(dqn + (int64_t)m * hidden + h, gm * DT<T>::ld(c + h));
+    unsafeAtomicAdd(dcn + ((int64_t)n * L + best_l) * hidden + h, gm * DT<T>::ld(q + h));
   }
 }
 
@@ -1078,23 +1079,23 @@ __global__ __launch_bounds__(256) void span_loss_kernel(const float* __restrict_
           float a = 0.f;
           for (int l = lane; l < L; l += 64) a += DC[f][16 + l] * S[f][16 + l + t - pad];
           a = wave_sum(a);
-          if (lane == 0) atomicAdd(dconv_w + (se * n_filt + f) * ks + t, a);
+          if (lane == 0) unsafeAtomicAdd(dconv_w + (se * n_filt + f) * ks + t, a);
         }
         for (int l = lane; l < L; l += 64) {  // ds[l] = sum_t w[t] * dc[l - t + pad]
           float a = 0.f;
           for (int t = 0; t < ks; ++t) a += w[f * ks + t] * DC[f][16 + l - t + pad];
           if (merged) {
-            atomicAdd(dsim0 + (int64_t)b * L + l, 0.5f * a);
-            if (n_sim > 1) atomicAdd(dsim1 + (int64_t)b * L + l, 0.5f * a);
+            unsafeAtomicAdd(dsim0 + (int64_t)b * L + l, 0.5f * a);
+            if (n_sim > 1) unsafeAtomicAdd(dsim1 + (int64_t)b * L + l, 0.5f * a);
           } else {
-            atomicAdd((f == 0 ? dsim0 : dsim1) + (int64_t)b * L + l, a);
+            unsafeAtomicAdd((f == 0 ? dsim0 : dsim1) + (int64_t)b * L + l, a);
           }
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
   }
-  if (!gout && lane == 0) atomicAdd(loss_out, total / (float)n);
+  if (!gout && lane == 0) unsafeAtomicAdd(loss_out, total / (float)n);
 }
 
 extern "C" int xml_span_loss(const float* sim0, const float* sim1, const float* conv_w, const float* mask0,
@@ -1150,13 +1151,13 @@ __global__ __launch_bounds__(256) void rank_loss_kernel(const float* __restrict_
     const float x = neg - pos;
     if (!gout) {
       const float lv = lse ? log1pf(expf(x)) : fmaxf(margin + x, 0.f);
-      atomicAdd(losses + side, lv / (float)n);
+      unsafeAtomicAdd(losses + side, lv / (float)n);
     } else {
       const float d = lse ? 1.f / (1.f + expf(-x)) : (margin + x > 0.f ? 1.f : 0.f);
       const float g = gout[side] * d / (float)n;
       if (g != 0.f) {
-        atomicAdd(dscores + at(i, j), g);
-        atomicAdd(dscores + (int64_t)i * n + i, -g);
+        unsafeAtomicAdd(dscores + at(i, j), g);
+        unsafeAtomicAdd(dscores + (int64_t)i * n + i, -g);
       }
     }
   }
@@ -1374,7 +1375,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ g,
   acc = wave_sum(acc);
   if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) atomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
+  if (threadIdx.x == 0) unsafeAtomicAdd(out, s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 }
 __global__ void clip_scale_kernel(float* __restrict__ g, int64_t n, const float* __restrict__ sumsq, float max_norm) {
   const float coef = max_norm / (sqrtf(sumsq[0]) + 1e-6f);

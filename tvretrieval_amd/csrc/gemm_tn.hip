@@ -169,8 +169,12 @@ extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, float* cols
   int rps = (cdiv(rows, splits) + 31) / 32 * 32;               // rows per workgroup, whole 32-row slabs
   if (rps < 256) rps = 256;
   splits = cdiv(rows, rps);
-  if (splits > 1 && hipMemsetAsync(out, 0, (size_t)N * K * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
-  if (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)N * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  if (splits > 1 && colsum_a == out + (size_t)N * K) {          // caller laid them out back to back: one fill
+    if (hipMemsetAsync(out, 0, ((size_t)N * K + N) * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  } else {
+    if (splits > 1 && hipMemsetAsync(out, 0, (size_t)N * K * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)N * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(K, 128), cdiv(N, 128), splits), dim3(256), 0, st, (const bf16_t*)A,
                      (const bf16_t*)B, out, colsum_a, (int)rows, N, K, rps);
   XML_CHECK_LAUNCH();

@@ -124,8 +124,9 @@ def gemm_tn(a, b, colsum=False):
     k = b.shape[1]
     if DISABLE_GEMM_TN or not _lib.load().xml_gemm_tn_supported(rows, n, k, dt_of(a)):
         return None
-    out = torch.empty((n, k), dtype=F32, device=a.device)
-    cs = torch.empty(n, dtype=F32, device=a.device) if colsum else None
+    buf = torch.empty(n * k + (n if colsum else 0), dtype=F32, device=a.device)      # back to back: one fill inside the entry
+    out = buf[:n * k].view(n, k)
+    cs = buf[n * k:] if colsum else None
     check(_lib.load().xml_gemm_tn(_p(a), _p(b), _p(out), _p(cs), rows, n, k, dt_of(a), _stream()), "xml_gemm_tn")
     return (out, cs) if colsum else out
 

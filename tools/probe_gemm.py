@@ -26,7 +26,8 @@ for m, n, k in [(300000, 2304, 768), (300000, 768, 768), (262144, 768, 3072)]:
     buf = (ctypes.c_ulonglong * 64)()
     lib.xml_debug_read_gemm_probe.argtypes = [ctypes.c_void_p]
     assert lib.xml_debug_read_gemm_probe(buf) == 0
-    print("M %d N %d K %d: %.3f ms, workgroup 0 wave 0 ran %d ticks -> %.0f ticks per us" % (m, n, k, ms, buf[5], buf[5] / ms / 1e3))
+    print("M %d N %d K %d: %.3f ms, workgroup 0 wave 0 ran %d s_memtime ticks in %d s_memrealtime ticks (100 MHz) = %.1f us -> "
+          "%.0f s_memtime ticks per us" % (m, n, k, ms, buf[5], buf[7], buf[7] / 100.0, buf[5] / max(buf[7], 1) * 100.0))
     sb = (ctypes.c_uint * 512)()
     lib.xml_debug_read_gemm_steps.argtypes = [ctypes.c_void_p]
     assert lib.xml_debug_read_gemm_steps(sb) == 0

@@ -22,6 +22,7 @@ buf = (ctypes.c_ulonglong * 32)()
 lib.xml_debug_read_k6_probe.argtypes = [ctypes.c_void_p]
 assert lib.xml_debug_read_k6_probe(buf) == 0
 for w in range(8):
-    wait, bar, tot = buf[w * 4], buf[w * 4 + 1], buf[w * 4 + 2]
-    print("wave %d: total %.2f Mcyc  counted-wait %.1f %%  barrier %.1f %%" % (w, tot / 1e6, 100.0 * wait / tot, 100.0 * bar / tot))
+    wait, bar, tot, real = buf[w * 4], buf[w * 4 + 1], buf[w * 4 + 2], buf[w * 4 + 3]
+    print("wave %d: total %.2f Mcyc in %.2f ms (s_memrealtime) = %.0f MHz shader clock  counted-wait %.1f %%  barrier %.1f %%"
+          % (w, tot / 1e6, real / 1e5, tot / max(real, 1) * 100.0, 100.0 * wait / tot, 100.0 * bar / tot))
 lib.xml_debug_set_q2c_ablation(ctypes.c_int(0))

@@ -253,6 +253,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
   constexpr bool GRP1 = decltype(grp_tag)::value;
   unsigned long long pr[8] = {};
   const unsigned long long pr_t0 = G256P_T();
+  const unsigned long long pr_r0 = (a.probe & 1) ? __builtin_amdgcn_s_memrealtime() : 0ull;      // 100 MHz reference clock
 #ifdef XML_DEBUG_VARIANTS
   unsigned int* sp = reinterpret_cast<unsigned int*>(smem + RING_BYTES + wave * 4096 + 2048);     // this wave's patch, upper half
   if ((a.probe & 1) && lane < 64) sp[lane] = 0;
@@ -722,6 +723,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 #ifdef XML_DEBUG_VARIANTS
   if ((a.probe & 1) && blockIdx.x == 0 && lane == 0) {
     pr[5] = __builtin_amdgcn_s_memtime() - pr_t0;
+    pr[7] = __builtin_amdgcn_s_memrealtime() - pr_r0;
     for (int i = 0; i < 8; ++i) g_g256p_probe[wave * 8 + i] = pr[i];
     for (int i = 0; i < 64; ++i) g_g256p_steps[wave * 64 + i] = sp[i];
   }

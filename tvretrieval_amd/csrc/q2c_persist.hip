@@ -445,7 +445,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   float stash = 0.f;                   // modality-0 maximum of this lane's row of the current tile
   float stash4[PACKED ? 4 : 1] = {};   // PACKED: one per sub-slot
   unsigned long long probe_wait = 0, probe_bar = 0, probe_t0 = 0;
-  if (ABL == 8) probe_t0 = __builtin_amdgcn_s_memtime();
+  unsigned long long probe_r0 = 0;
+  if (ABL == 8) { probe_t0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
   for (;;) {      // one iteration = one (tile, modality) segment
     f32x4 acc[4][8];       // written by the first slice of the segment (MmaInit: C = 0)
 
@@ -727,6 +728,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     g_k6_probe[wave * 4 + 0] = probe_wait;
     g_k6_probe[wave * 4 + 1] = probe_bar;
     g_k6_probe[wave * 4 + 2] = __builtin_amdgcn_s_memtime() - probe_t0;
+    g_k6_probe[wave * 4 + 3] = __builtin_amdgcn_s_memrealtime() - probe_r0;      // 100 MHz reference: shader clock = [2] / [3] x 100 MHz
   }
 #endif
   };

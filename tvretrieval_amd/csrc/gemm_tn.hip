@@ -21,7 +21,7 @@ __device__ __forceinline__ uint2 tn_read_tr16(const char* p) {
 
 // colsum (optional): colsum[n] += sum_r A[r][n] -- the bias gradient of the same layer, taken from the dY slabs the
 // workgroups of the first k tile load anyway (one launch and one pass over dY less per layer).
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+__global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       float* __restrict__ out, float* __restrict__ colsum, int rows, int N,
                                                       int K, int rows_per_split) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 32 * TN_STRIDE];      // [buffer][operand][32 rows]
@@ -161,7 +161,7 @@ extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, float* cols
   // workgroups aimed at.  Every row range adds N x K f32 atomics, and device-scope float atomics are slow enough to show
   // (768 x 768 over 12 800 rows: 58.6 us with 7 ranges, 69.6 with 22, 94 with 43 -- tools/bench_gemm_tn.py); with many
   // output tiles the extra ranges pay for themselves by hiding the global-load latency (768 x 3072: 134 vs 160 us)
-  int target = tiles <= 48 ? 256 : 768;
+  int target = (tiles <= 48 || rows < 8192) ? 256 : 512;      // (3 840 rows x 2304 x 768: 46 us at 256, 55 at 512, 67 at 768)
 #ifdef XML_DEBUG_VARIANTS
   if (g_q2c_ablation >= 200) target = (g_q2c_ablation - 200) * 64;      // A/B: workgroups aimed at = (XML_ABL - 200) x 64
 #endif

@@ -203,6 +203,39 @@ int xml_topk_rows(const float* scores, int64_t ld, const int32_t* idx_in, float*
                   xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Exact-rank mode: the bf16 K6 pass as a FILTER in front of f32 scores (inference.vcmr_search on an index built with
+ * exact_filter=True).  The reference ranks videos by f32 scores (torch.topk, xml/inference.py:347-348); a bf16 K6 moves
+ * ~1 % of the top-100 memberships where neighbouring scores are closer than its ~3e-5 resolution.  Here corpus and queries
+ * are encoded in f32, K6 runs on both operands rounded once to bf16 and proposes m >= k candidates per query (K8), the
+ * candidates are re-scored against the f32 operands, and a per-query certificate says whether any video outside the
+ * candidate set could still belong to the f32 top-k; failing queries get a full f32 K6 row from the caller.
+ *
+ *   xml_round_bf16_rows_err: y (rows, d) f32 L2-normalised rows -> yb (rows, d) bf16 = round-to-nearest-even(y),
+ *     err (rows) f32 = || y - yb ||_2  (d % 8 == 0).
+ *   xml_q2c_rescore: get_video_level_scores (xml/model_xml.py:436-453) + (video + sub) / divisor (:572-574) for the
+ *     LISTED pairs only: out[q, j] = ( sum_m max_l mask_logits( qn_m[q] . cn_m[pair_vid[q, j], l] ) ) / n_mod.
+ *     qn_m (nq, hidden), cn_m (nv, lpad, hidden) dt, ROW-major, L2-normalised; mask_m (nv, lpad) f32; pair_vid (nq, kpairs)
+ *     int32 (< 0 or >= nv: out = -inf); out (nq, kpairs) f32.  The pair list is inverted on the device like K7's, so a
+ *     video's tile is fetched once per 64 pairs.  lpad % 16 == 0, lpad <= 128, hidden % 8 == 0.
+ *   xml_exact_certificate: filter_scores (nq, m) f32 = the bf16 pass's top-m values per query, descending (xml_topk_rows,
+ *     alpha = 0); top_val (nq, k) f32 = the top-k RE-SCORED values, descending, raw on entry -- on return
+ *     expf(alpha * s) when alpha != 0 (what K8 emits); eq_m (nq) f32 = rounding-error norms of the query vectors
+ *     (xml_round_bf16_rows_err), ec_m = the largest rounding-error norm of the corpus rows of modality m; slack = bound of
+ *     the f32 accumulation error of the dot products; outside = 1 if videos exist outside the candidate set (nv > m).
+ *     fail[q] = outside && !( filter_scores[q, m-1] + eps_q < top_val[q, k-1] ),
+ *     eps_q = mean_m( eq_m[q] * c + (c + eq_m[q]) * ec_m ) + slack, c = 1 + 1e-6 (Cauchy-Schwarz on the two rounding errors).
+ *     eps_out (nq) f32 or NULL; *n_fail (int32, zeroed by the caller) += number of failing queries.
+ * --------------------------------------------------------------------------------------------- */
+int xml_round_bf16_rows_err(const float* y, void* yb, float* err, int64_t rows, int d, xml_stream_t stream);
+size_t xml_q2c_rescore_workspace_bytes(int nq, int nv, int kpairs);
+int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, const void* cn0, const void* cn1, const float* mask0,
+                    const float* mask1, const int32_t* pair_vid, float* out, int nq, int nv, int kpairs, int lpad,
+                    int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream);
+int xml_exact_certificate(const float* filter_scores, int m, float* top_val, int k, const float* eq0, const float* eq1,
+                          float ec0, float ec1, int n_mod, float slack, float alpha, int outside, int32_t* fail,
+                          float* eps_out, int32_t* n_fail, int nq, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K7: similarity contraction #2 + ConvSE start/end scorer on selected (query, video) pairs
  *   sim_m[l]  = q'_m . feat2_m[v,l]                       m in {video, sub}
  *   merged:   x = (sim_v + sim_s)/2 ; st = conv(x, w_st[0]) ; ed = conv(x, w_ed[0])

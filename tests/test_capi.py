@@ -34,7 +34,7 @@ def test_every_header_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_identity(lib):
-    assert lib.xml_abi_version() == 2
+    assert lib.xml_abi_version() == 3
     assert lib.xml_build_arch() == b"gfx950"
     assert lib.xml_status_string(0) == b"ok"
     assert lib.xml_status_string(-2) == b"unsupported shape"

@@ -1,0 +1,161 @@
+"""Exact-rank mode at the headline shape: stage times, certificate statistics, and list identity against the plain f32 path.
+
+    python tools/bench_exact.py [--queries 10000] [--videos 21793] [--init reset|perturbed] [--compare 1000] [--out f.json]
+
+  init reset      XML.reset_parameters weights (what bench.py runs): all videos score within ~1e-3 of each other
+  init perturbed  the parity tests' non-degenerate initialisation (tools/rank_agreement.py)
+  --compare n     also run the plain f32 path on the first n queries and count list differences (tie-aware)
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+def tie_aware_diff(g_keys, g_scores, w_keys, w_scores, k, rtol):
+    """Positions (of the first k) where the two ranked lists differ, split into ties (the entry is in the other list with a
+    score within rtol of the one at that position) and real differences."""
+    g_keys, w_keys = np.asarray(g_keys)[:, :k], np.asarray(w_keys)
+    n_tie = n_real = 0
+    for q in np.nonzero((g_keys != w_keys[:, :k]).any(1))[0]:
+        for i in np.nonzero(g_keys[q] != w_keys[q, :k])[0]:
+            j = np.nonzero(w_keys[q] == g_keys[q, i])[0]
+            ref = w_scores[q][i]
+            if len(j) == 1 and abs(w_scores[q][j[0]] - ref) <= rtol * abs(ref) and \
+                    abs(g_scores[q][i] - w_scores[q][j[0]]) <= rtol * abs(ref):
+                n_tie += 1
+            else:
+                n_real += 1
+    return n_tie, n_real
+
+
+def moment_keys(flat, top, l):
+    flat, top = flat.long(), top.long()
+    ok = flat >= 0
+    r = torch.where(ok, flat // (l * l), torch.zeros_like(flat))
+    vid = torch.gather(top, 1, r.clamp(0, top.shape[1] - 1))
+    return torch.where(ok, vid * (l * l) + flat % (l * l), torch.full_like(flat, -1))
+
+
+def run(nq, nv, init, n_compare, log=lambda s: None):
+    import bench
+    import rank_agreement
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import ops
+    from tvretrieval_amd.model_xml import XML
+    _, _, l, hidden, dv, ds, dq, ctx_mode, _ = bench.WORKLOADS["c3"]
+    cfg = bench.model_config(hidden, dv, ds, dq, ctx_mode, l)
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = XML(cfg, compute_dtype=torch.float32)
+    if init == "perturbed":
+        rank_agreement.perturb_weights(model)
+    model = model.to(dev).eval()
+    qf, qm = bench.synth_queries(nq, dq, dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+
+    def timed(fn):
+        s, e = ev(), ev()
+        s.record(); r = fn(); e.record(); torch.cuda.synchronize()
+        return r, s.elapsed_time(e)
+
+    with torch.no_grad():
+        raw = list(bench.context_batches(0, nv, l, dv, ds, True, True, dev))
+        index, t_enc = timed(lambda: inf.build_corpus_index(model, iter(raw), n_total=nv, l_ref=l, n_videos=nv,
+                                                           exact_filter=True))
+        del raw
+        log("f32 corpus encode + exact index: %.1f s" % (t_enc * 1e-3))
+        ex = index.exact
+        for _ in range(2):
+            out = inf.vcmr_search(model, index, qf, qm)
+        torch.cuda.synchronize()
+        _, t_pass = timed(lambda: inf.vcmr_search(model, index, qf, qm))
+        # stage by stage
+        mods = index.modalities
+        masks = [index.mask[m] for m in mods]
+        st = {}
+        qvec, st["query_encode_f32"] = timed(lambda: inf.stage_query_vectors(model, qf, qm))
+        qn = [ops.l2norm_rows(qvec[m].contiguous()) for m in mods]
+        rb, st["round_queries"] = timed(lambda: [ops.round_bf16_rows_err(q) for q in qn])
+        qb, eq = [r[0] for r in rb], [r[1] for r in rb]
+        filt, st["k6_bf16_filter"] = timed(lambda: inf._k6(index, qb, ops))
+        m_c = min(ex.n_candidates, nv)
+        (cs, ci), st["k8_top%d" % m_c] = timed(lambda: ops.topk_rows(filt, m_c, alpha=0.0))
+        f32rows = [ex.feat1n_f32[m] for m in mods]
+        cr, st["rescore_f32"] = timed(lambda: ops.q2c_rescore(qn, f32rows, masks, ci))
+        (tw, ti), st["k8_top100_of_candidates"] = timed(lambda: ops.topk_rows(cr, 100, alpha=0.0, idx_in=ci))
+        t100 = tw[:, -1].clone()
+        (fail, eps, n_fail), st["certificate"] = timed(lambda: ops.exact_certificate(
+            cs, tw, eq, [ex.e_c[m] for m in mods], inf.exact_slack(hidden), 20.0, nv > m_c))
+        (s_t, e_t), st["convse_k7_f32"] = timed(lambda: inf.stage_span_probs(model, index, qvec, ti, ops))
+        _, st["moment_k9"] = timed(lambda: ops.moment_topk(s_t, e_t, tw, l, 2, 16, 200))
+        # what the filter actually did, against the re-scored (f32) values of its own candidates
+        err = (cs - cr).abs()
+        margin = t100 - cs[:, -1]             # T_100 - b_M: what eps has to fit into
+        q = lambda t, p: float(torch.quantile(t.float().flatten()[:4000000], p))      # noqa: E731
+        stats = dict(
+            n_fail=int(n_fail.item()), fail_rate=float(n_fail.item()) / nq,
+            eps_mean=float(eps.mean()), eps_max=float(eps.max()),
+            e_c={m: ex.e_c[m] for m in mods}, e_q_mean=[float(e.mean()) for e in eq],
+            filter_abs_err_max=float(err.max()), filter_abs_err_p999=q(err, 0.999), filter_abs_err_mean=float(err.mean()),
+            margin_T100_minus_bM={"p01": q(margin, 0.01), "p10": q(margin, 0.1), "p50": q(margin, 0.5), "p90": q(margin, 0.9)},
+            # the certificate with an EMPIRICAL epsilon (2 x the largest filter error seen on the re-scored candidates):
+            # not a proof, shown for scale
+            fail_rate_eps_2x_observed=float((~(cs[:, -1] + 2 * err.max() < t100)).float().mean()),
+        )
+    res = dict(queries=nq, videos=nv, init=init, candidates=m_c, ms_per_pass=t_pass, queries_per_s=nq / (t_pass * 1e-3),
+               encode_index_s=t_enc * 1e-3, hbm_gb=index.hbm_bytes() / 1e9, stage_ms={k: round(v, 3) for k, v in st.items()},
+               certificate=stats)
+    if n_compare:
+        n = min(n_compare, nq)
+        with torch.no_grad():
+            # plain f32 path on the same f32 operands (row-major K6)
+            plain = inf.CorpusIndex(mods, ex.feat1n_f32, index.feat2, index.mask, l, 0, nv)
+            ref, t_ref = timed(lambda: inf.vcmr_search(model, plain, qf[:n].contiguous(), qm[:n].contiguous()))
+            got = inf.vcmr_search(model, index, qf[:n].contiguous(), qm[:n].contiguous())
+        ww, wi = torch.topk(torch.exp(20.0 * ref["q2c"]), 124, dim=1)
+        v_tie, v_real = tie_aware_diff(got["top_indices"].cpu().numpy(), got["top_scores"].cpu().numpy(), wi.cpu().numpy(),
+                                       ww.cpu().numpy(), 100, 2e-5)
+        same = (got["top_indices"] == ref["top_indices"]).all(1)
+        gk = moment_keys(got["flat_indices"], got["top_indices"], l)[same].cpu().numpy()
+        wk = moment_keys(ref["flat_indices"], ref["top_indices"], l)[same].cpu().numpy()
+        m_tie, m_real = tie_aware_diff(gk, got["flat_scores"][same].cpu().numpy(), wk, ref["flat_scores"][same].cpu().numpy(),
+                                       192, 5e-5)
+        res["vs_plain_f32"] = dict(
+            queries=n, f32_pass_ms=t_ref, fell_back=got["exact"]["n_fail"],
+            video_positions=n * 100, video_positions_swapped_in_f32_ties=v_tie, video_positions_really_different=v_real,
+            queries_with_identical_top100_order=int(same.sum()),
+            moment_positions=int(same.sum()) * 192, moment_positions_swapped_in_f32_ties=m_tie,
+            moment_positions_really_different=m_real,
+            top1_video_same=float((got["top_indices"][:, 0] == ref["top_indices"][:, 0]).float().mean()),
+            top1_moment_same=float((moment_keys(got["flat_indices"], got["top_indices"], l)[:, 0] ==
+                                    moment_keys(ref["flat_indices"], ref["top_indices"], l)[:, 0]).float().mean()))
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--videos", type=int, default=21793)
+    ap.add_argument("--init", default="reset", choices=["reset", "perturbed"])
+    ap.add_argument("--compare", type=int, default=1000)
+    ap.add_argument("--out", default=None)
+    a = ap.parse_args()
+    res = run(a.queries, a.videos, a.init, a.compare, log=lambda s: print(s, file=sys.stderr))
+    line = json.dumps(res, indent=1)
+    print(line)
+    if a.out:
+        os.makedirs(os.path.dirname(os.path.abspath(a.out)), exist_ok=True)
+        with open(a.out, "w") as f:
+            f.write(line + "\n")
+
+
+if __name__ == "__main__":
+    main()

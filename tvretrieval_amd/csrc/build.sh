@@ -2,14 +2,14 @@
 # Builds tvretrieval_amd/csrc/libxmlhip.so for gfx950 (MI355X).  hipcc cross-compiles without a GPU.
 #   bash build.sh            product library: stateless dispatch, no experiment kernels
 #   XML_DEBUG=1 bash build.sh   additionally libxmlhip_dbg.so (-DXML_DEBUG_VARIANTS): kernel-variant / ablation switches
-#                               (xml_debug_*), the abandoned K6 variants q2c_persist4/32.hip -- for tools/ only
+#                               (xml_debug_*), the abandoned K6 variants q2c256.hip, q2c_persist4/32.hip -- for tools/ only
 #                               (XMLHIP_LIB=.../libxmlhip_dbg.so python tools/bench_k6.py ...)
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-SRCS="api.hip linear.hip gemm256.hip gemm256p.hip attention.hip attention_train.hip q2c.hip q2c256.hip q2c_ring.hip q2c_persist.hip topk.hip convse.hip moment.hip postproc.hip train.hip gemm_tn.hip index_build.hip encoder.hip collectives.hip"
-DBG_SRCS="q2c_persist4.hip q2c_persist32.hip"
+SRCS="api.hip linear.hip gemm256.hip gemm256p.hip attention.hip attention_train.hip q2c.hip q2c_ring.hip q2c_persist.hip topk.hip convse.hip moment.hip postproc.hip train.hip gemm_tn.hip index_build.hip collectives.hip exact.hip"
+DBG_SRCS="q2c256.hip q2c_persist4.hip q2c_persist32.hip"
 
 build() {   # $1 = object dir, $2 = extra flags, $3 = output, $4.. = sources
   local dir=$1 extra=$2 out=$3; shift 3

@@ -264,6 +264,86 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
   }
 }
 
+// ---- exact-rank rescoring (xml_q2c_rescore) -----------------------------------------------------------------------
+// Video-level scores of the LISTED (query, video) pairs only, in the storage type of the operands (f32 for the exact-rank
+// mode: the bf16 K6 pass is a filter, its top-M candidates are re-scored here against the f32 index).  Same inverted pair
+// list as K7 (a video's feat1 tile is fetched once per 64-pair chunk), same MFMA mainloop; the epilogue is K6's:
+//   out[q, j] = ( sum_m max_l mask_logits( qn_m[q] . cn_m[v, l] ) ) / n_mod        (xml/model_xml.py:448-452, :572-574)
+// taken straight from the accumulators (a wave holds 32 clip columns of all 64 pair rows): DPP row maximum over the 16
+// lanes of a column group, then a 4 x 64 LDS patch across the four waves -- no similarity patch, 49 KiB of LDS.
+struct RescoreArgs {
+  const void* qn[2];
+  const void* cn[2];
+  const float* mask[2];
+  float* out;
+  const int32_t* offsets;
+  const int32_t* chunk_off;
+  const int32_t* bucket;
+  const int32_t* chunk_vid;
+  int nv, kpairs, lpad, hidden, n_mod;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void rescore_kernel(RescoreArgs a) {
+  using Cfg = GemmCfg<T, TM, 128, 1, 4>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  __shared__ int32_t s_pair[TM];
+  __shared__ float s_max[4][TM];
+  const int tid = threadIdx.x;
+  const int chunk = blockIdx.x;
+  if (chunk >= a.chunk_off[a.nv]) return;
+  const int v = a.chunk_vid[chunk];
+  const int first = a.offsets[v] + (chunk - a.chunk_off[v]) * TM;
+  const int cnt = min(TM, a.offsets[v + 1] - first);
+  if (tid < TM) s_pair[tid] = tid < cnt ? a.bucket[first + tid] : -1;
+  __syncthreads();
+  const int lane = tid & 63, wn = tid >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  float tot = 0.f;                                   // threads < TM: sum over modalities of the row maximum
+  f32x4 acc[Cfg::MT][Cfg::NT];
+  for (int m = 0; m < a.n_mod; ++m) {
+    const T* qn = reinterpret_cast<const T*>(a.qn[m]);
+    const T* cn = reinterpret_cast<const T*>(a.cn[m]);
+    auto a_row = [&](int r) -> const char* {
+      const int p = s_pair[r];
+      return p >= 0 ? reinterpret_cast<const char*>(qn + (int64_t)(p / a.kpairs) * a.hidden) : nullptr;
+    };
+    auto b_row = [&](int r) -> const char* {
+      return r < a.lpad ? reinterpret_cast<const char*>(cn + ((int64_t)v * a.lpad + r) * a.hidden) : nullptr;
+    };
+    float mk[Cfg::NT];
+#pragma unroll
+    for (int nt = 0; nt < Cfg::NT; ++nt) {
+      const int c = wn * 32 + nt * 16 + fr;
+      mk[nt] = c < a.lpad ? a.mask[m][(int64_t)v * a.lpad + c] : 0.f;
+    }
+    gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem);
+#pragma unroll
+    for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float best = -INFINITY;
+#pragma unroll
+        for (int nt = 0; nt < Cfg::NT; ++nt)
+          best = fmaxf(best, acc[mt][nt][r] * mk[nt] + (1.f - mk[nt]) * -1e10f);      // mask_logits
+        best = lane16_max_dpp(best);
+        if (fr == 0) s_max[wn][mt * 16 + fg * 4 + r] = best;
+      }
+    __syncthreads();
+    if (tid < TM) tot += fmaxf(fmaxf(s_max[0][tid], s_max[1][tid]), fmaxf(s_max[2][tid], s_max[3][tid]));
+    // (the next modality's mainloop passes several barriers before anyone writes s_max again)
+  }
+  if (tid < cnt) a.out[s_pair[tid]] = a.n_mod == 2 ? tot * 0.5f : tot;
+}
+
+__global__ void rescore_fill_skipped_kernel(const int32_t* __restrict__ pair_vid, float* __restrict__ out, int64_t P,
+                                            int nv) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= P) return;
+  const int v = pair_vid[p];
+  if (v < 0 || v >= nv) out[p] = -INFINITY;
+}
+
 __global__ void convse_zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) p[i] = 0u;
@@ -330,6 +410,62 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
     const size_t lds = n_sim == 1 ? (Cfg::LDS_BYTES > patch ? Cfg::LDS_BYTES : patch) : Cfg::LDS_BYTES + 2 * patch;
     if (!xml_lds_attr_once<convse_kernel<bf16_t>>((int)(Cfg::LDS_BYTES + 2 * patch))) return XML_ERR_LAUNCH;
     hipLaunchKernelGGL(convse_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
+  }
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+extern "C" size_t xml_q2c_rescore_workspace_bytes(int nq, int nv, int kpairs) {
+  xml_convse_desc d{};
+  d.nq = nq; d.nv = nv; d.kpairs = kpairs;
+  return convse_ws_layout(&d, nullptr, nullptr);
+}
+
+extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, const void* cn0, const void* cn1,
+                               const float* mask0, const float* mask1, const int32_t* pair_vid, float* out, int nq, int nv,
+                               int kpairs, int lpad, int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream) {
+  XML_ENTER();
+  if (!qn0 || !cn0 || !mask0 || !pair_vid || !out || !ws) return XML_ERR_BAD_ARG;
+  if (n_mod < 1 || n_mod > 2 || (n_mod == 2 && (!qn1 || !cn1 || !mask1))) return XML_ERR_BAD_ARG;
+  if (nq <= 0 || nv <= 0 || kpairs <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (lpad % 16 || lpad > 128 || lpad <= 0 || hidden % 8) return XML_ERR_UNSUPPORTED;
+  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (ws_bytes < xml_q2c_rescore_workspace_bytes(nq, nv, kpairs)) return XML_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  xml_convse_desc d{};
+  d.nq = nq; d.nv = nv; d.kpairs = kpairs;
+  ConvseWs w;
+  convse_ws_layout(&d, &w, (char*)ws);
+  const int64_t P = (int64_t)nq * kpairs;
+  {
+    const int64_t nwords = (int64_t)((char*)w.offsets - (char*)w.counts) / 4;
+    hipLaunchKernelGGL(convse_zero_words_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, st, (uint32_t*)w.counts, nwords);
+    XML_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, P, nv);
+  XML_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rescore_fill_skipped_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, out, P, nv);
+  XML_CHECK_LAUNCH();
+  hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid, nv);
+  XML_CHECK_LAUNCH();
+  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.cursor, w.bucket, P,
+                     nv);
+  XML_CHECK_LAUNCH();
+  RescoreArgs a;
+  a.qn[0] = qn0; a.qn[1] = qn1; a.cn[0] = cn0; a.cn[1] = cn1;
+  a.mask[0] = mask0; a.mask[1] = mask1 ? mask1 : mask0;
+  a.out = out;
+  a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket; a.chunk_vid = w.chunk_vid;
+  a.nv = nv; a.kpairs = kpairs; a.lpad = lpad; a.hidden = hidden; a.n_mod = n_mod;
+  const int64_t max_chunks = P / TM + (P < nv ? P : nv);
+  if (dt == XML_F32) {
+    using Cfg = GemmCfg<float, TM, 128, 1, 4>;
+    if (!xml_lds_attr_once<rescore_kernel<float>>((int)Cfg::LDS_BYTES)) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(rescore_kernel<float>, dim3((unsigned)max_chunks), dim3(256), Cfg::LDS_BYTES, st, a);
+  } else {
+    using Cfg = GemmCfg<bf16_t, TM, 128, 1, 4>;
+    if (!xml_lds_attr_once<rescore_kernel<bf16_t>>((int)Cfg::LDS_BYTES)) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(rescore_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), Cfg::LDS_BYTES, st, a);
   }
   XML_CHECK_LAUNCH();
   return XML_OK;

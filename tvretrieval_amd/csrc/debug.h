@@ -17,10 +17,23 @@ static constexpr int g_q2c_variant = 0, g_q2c_ablation = 0, g_gemm_variant = 0, 
                      g_q2c_chunk_log2 = -1;
 #endif
 
-// hipFuncAttributeMaxDynamicSharedMemorySize once per kernel (thread-safe function-local static), not on every launch
+// hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device) and per growth of the requested size -- not on
+// every launch.  The attribute belongs to the function ON THE CURRENT DEVICE: a process that drives several GPUs, or asks
+// for a larger dynamic LDS size later, sets it again there (a per-process flag left the second device at the 64 KiB
+// default and its 138-160 KiB kernels failed to launch).  Lock-free: racing threads at worst set the same value twice.
+#include <atomic>
 template <auto KERN>
 static bool xml_lds_attr_once(int lds_bytes) {
-  static const bool ok =
-      hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
-  return ok;
+  constexpr int MAX_DEV = 64;
+  static std::atomic<int> done[MAX_DEV];          // largest size set so far per device (zero-initialised)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return false;
+  if (dev < 0 || dev >= MAX_DEV)
+    return hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) == hipSuccess;
+  if (done[dev].load(std::memory_order_acquire) >= lds_bytes) return true;
+  if (hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes) != hipSuccess)
+    return false;
+  int cur = done[dev].load(std::memory_order_relaxed);
+  while (cur < lds_bytes && !done[dev].compare_exchange_weak(cur, lds_bytes, std::memory_order_release)) {}
+  return true;
 }

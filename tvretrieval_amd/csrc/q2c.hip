@@ -141,8 +141,10 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
 #endif
   if ((g_q2c_variant == 0 || g_q2c_variant == 3) && dma_ok)
     return xmli_q2c_scores_ring(qn, cn, mask, out, ld_out, nq, nv, lpad, hidden, combine, dt, st);
-  if (g_q2c_variant == 2 && dma_ok)
+#ifdef XML_DEBUG_VARIANTS
+  if (g_q2c_variant == 2 && dma_ok)      // q2c256.hip: debug library only
     return xmli_q2c_scores_256(qn, cn, mask, out, ld_out, nq, nv, lpad, hidden, combine, dt, st);
+#endif
   const int vpt = 128 / lpad;
   const int tq = cdiv(nq, 128), tc = cdiv(nv, vpt);
   const int swz = g_q2c_xcd_swizzle;

@@ -44,6 +44,7 @@ class CorpusIndex(object):
         self.video_offset = int(video_offset)
         self.n_total = int(n_total if n_total is not None else self.n_videos)
         self.feat2_all = self.mask_all = None      # corpus-wide copies of feat2 / mask (dist.replicate_rerank_features)
+        self.exact = None                          # ExactFilter: feat1n is the bf16 FILTER image of an f32 index (exact-rank mode)
 
     def feat1n_rows(self, m):
         t = self.feat1n[m]
@@ -55,10 +56,33 @@ class CorpusIndex(object):
 
     def hbm_bytes(self):
         tot = 0
-        for d in (self.feat1n, self.feat2, self.mask, self.feat2_all or {}, self.mask_all or {}):
+        for d in (self.feat1n, self.feat2, self.mask, self.feat2_all or {}, self.mask_all or {},
+                  self.exact.feat1n_f32 if self.exact is not None else {}):
             for t in d.values():
                 tot += t.numel() * t.element_size()
         return tot
+
+
+class ExactFilter(object):
+    """Exact-rank mode of a CorpusIndex (include/xmlhip.h "Exact-rank mode"): the model runs in f32, `index.feat1n` holds the
+    similarity operand ROUNDED ONCE to bf16 (K6 is a filter), and this object holds what turns the filter's candidates into
+    the f32 path's lists:
+      feat1n_f32[m]  (Nv, lpad, H) f32 row-major, L2-normalised -- re-scoring operand, and the f32 K6 operand of the fallback
+      e_c[m]         largest bf16 rounding-error norm || c - c_b ||_2 over the corpus rows of modality m
+      n_candidates   M: candidates per query proposed by the bf16 pass (K8 emits at most 256)"""
+
+    def __init__(self, feat1n_f32, e_c, n_candidates=256):
+        self.feat1n_f32, self.e_c, self.n_candidates = feat1n_f32, e_c, int(n_candidates)
+
+
+def _exact_filter_operands(f1_raw, mask, plan, ops):
+    """raw f32 feat1 (Nv, lpad, H) -> (bf16 filter image for K6, f32 normalised rows, largest rounding-error norm)."""
+    if f1_raw.dtype != torch.float32:
+        raise ValueError("exact-rank mode needs an f32 model (XML(cfg, compute_dtype=torch.float32)); got %s" % f1_raw.dtype)
+    fn = ops.l2norm_rows(f1_raw)
+    fb, err = ops.round_bf16_rows_err(fn)
+    e_c = float(err.max()) if err.numel() else 0.0
+    return ops.pack_q2c_corpus(fb, mask, plan, normalize=False), fn, e_c
 
 
 def pad_batch(seqs, device=None, dtype=torch.float32):
@@ -77,18 +101,20 @@ def pad_batch(seqs, device=None, dtype=torch.float32):
 
 
 def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, video_offset=0, n_total=None,
-                       l_ref=None, n_videos=None):
+                       l_ref=None, n_videos=None, exact_filter=False):
     """Encode context batches and assemble the resident index.
 
     context_batches: iterable of (video_feat, video_mask, sub_feat, sub_mask) device tensors (unused modality:
     None).  Each batch is encoded at its own padded length and zero-filled beyond it when concatenated, exactly
     like cat_tensor (xml/inference.py:71-87), so rows >= a batch's max length are 0 and rows between a video's
     length and its batch max hold the encoder's outputs at padded positions (both observable through the 5-tap
-    ConvSE)."""
+    ConvSE).
+    exact_filter=True (f32 model): exact-rank mode -- feat1n becomes the bf16 filter image, index.exact the f32 operands
+    (ExactFilter); vcmr_search then returns the f32 path's lists at close to the bf16 path's speed."""
     mods = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
     if n_videos is not None and l_ref is not None:
         return _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, int(l_ref),
-                                            int(n_videos), mods)
+                                            int(n_videos), mods, exact_filter)
     parts = {m: dict(f1=[], f2=[], mk=[]) for m in mods}
     for video_feat, video_mask, sub_feat, sub_mask in context_batches:
         v1, v2, s1, s2 = model.encode_context(video_feat, video_mask, sub_feat, sub_mask)
@@ -110,7 +136,7 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
             r += t.shape[0]
         return out
 
-    feat1n, feat2, mask, raw = {}, {}, {}, {}
+    feat1n, feat2, mask, raw, ex_f32, ex_ec = {}, {}, {}, {}, {}, {}
     for m in mods:
         mask[m] = cat(parts[m]["mk"])
     # ragged corpora: one length-bucketed layout shared by the modalities (2 / 4 / 8 videos per K6 tile)
@@ -118,7 +144,9 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
     for m in mods:
         f1 = cat(parts[m]["f1"])
         feat2[m] = cat(parts[m]["f2"])
-        if hasattr(ops, "pack_q2c_corpus"):      # HIP backend: normalised + slice-major tiles for the persistent K6 kernel
+        if exact_filter:
+            feat1n[m], ex_f32[m], ex_ec[m] = _exact_filter_operands(f1, mask[m], plan, ops)
+        elif hasattr(ops, "pack_q2c_corpus"):    # HIP backend: normalised + slice-major tiles for the persistent K6 kernel
             feat1n[m] = ops.pack_q2c_corpus(f1, mask[m], plan, normalize=True)
         else:
             feat1n[m] = ops.l2norm_rows(f1)
@@ -126,10 +154,13 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
             raw[m] = f1
     idx = CorpusIndex(mods, feat1n, feat2, mask, l_ref, video_offset, n_total)
     idx.raw_feat1 = raw
+    if exact_filter:
+        idx.exact = ExactFilter(ex_f32, ex_ec)
     return idx
 
 
-def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, l_ref, n_videos, mods):
+def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, l_ref, n_videos, mods,
+                                 exact_filter=False):
     """build_corpus_index when the number of videos and the corpus-wide length are known up front (a resident engine knows
     its corpus): the three index tensors per modality are allocated once and every encoded batch is written into its
     rows -- no growing list of per-batch outputs, no concatenation pass, and the per-batch activations are recycled by the
@@ -170,14 +201,19 @@ def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_of
         r += v1.shape[0] if v1 is not None else s1.shape[0]
     assert r == n_videos, "n_videos=%d but the batches held %d" % (n_videos, r)
     plan = ops.q2c_pack_plan([mk[m] for m in mods]) if (hasattr(ops, "q2c_pack_plan") and lpad == 128) else None
-    feat1n, raw = {}, {}
+    feat1n, raw, ex_f32, ex_ec = {}, {}, {}, {}
     for m in mods:
-        feat1n[m] = ops.pack_q2c_corpus(f1[m], mk[m], plan, normalize=True) if hasattr(ops, "pack_q2c_corpus") \
-            else ops.l2norm_rows(f1[m])
+        if exact_filter:
+            feat1n[m], ex_f32[m], ex_ec[m] = _exact_filter_operands(f1[m], mk[m], plan, ops)
+        else:
+            feat1n[m] = ops.pack_q2c_corpus(f1[m], mk[m], plan, normalize=True) if hasattr(ops, "pack_q2c_corpus") \
+                else ops.l2norm_rows(f1[m])
         if keep_raw:
             raw[m] = f1[m]
     idx = CorpusIndex(mods, feat1n, f2, mk, l_ref, video_offset, n_total)
     idx.raw_feat1 = raw
+    if exact_filter:
+        idx.exact = ExactFilter(ex_f32, ex_ec)
     return idx
 
 
@@ -228,10 +264,9 @@ def stage_query_vectors(model, query_feat, query_mask):
 K6_TIMER = None   # bench.py: callable returning (start, end) torch.cuda.Event pair recorded around each K6 launch
 
 
-def stage_q2c(index, qvec, ops=hip_ops):
-    """K6 over the local corpus: (Nq, Nv_local) f32 = mean over modalities of max-over-clips cosine (one launch)."""
+def _k6(index, qn, ops):
+    """One fused K6 launch over the local corpus (both modalities), bracketed by the bench's HIP events."""
     mods = index.modalities
-    qn = [ops.l2norm_rows(qvec[m].contiguous()) for m in mods]
     ev = K6_TIMER() if K6_TIMER is not None else None
     if ev:
         ev[0].record()
@@ -239,6 +274,67 @@ def stage_q2c(index, qvec, ops=hip_ops):
     if ev:
         ev[1].record()
     return q2c
+
+
+def stage_q2c(index, qvec, ops=hip_ops):
+    """K6 over the local corpus: (Nq, Nv_local) f32 = mean over modalities of max-over-clips cosine (one launch)."""
+    if index.exact is not None:
+        raise ValueError("this index is an exact-rank FILTER image (bf16 operands of an f32 model): use stage_exact_topk")
+    return _k6(index, [ops.l2norm_rows(qvec[m].contiguous()) for m in index.modalities], ops)
+
+
+EXACT_SMALL_FALLBACK = 32     # failing queries up to which the fallback runs on the pair kernel instead of the K6 kernel
+
+
+def exact_slack(hidden):
+    """f32 accumulation bound of the two dot products a certificate compares: the filter's (exact bf16 products, f32
+    accumulate) and the f32 path's own (fma chain): each |fl(sum) - sum| <= n u |x| |y|, u = 2^-24."""
+    return 2.0 * (hidden + 1) * 2.0 ** -24
+
+
+def stage_exact_topk(index, qvec, k, alpha, ops=hip_ops):
+    """Exact-rank replacement of K6 + K8 (index.exact is set, f32 query vectors): the f32 path's top-k videos per query.
+      1. q_b = rne_bf16(normalize(q)) with its rounding-error norm e_q; bf16 K6 over the filter image (the timed K6);
+      2. K8 proposes the M best filter scores per query (raw values + ids);
+      3. xml_q2c_rescore: those (q, v) pairs against the f32 operands -> f32 scores of the candidates;
+      4. K8 again on the (Nq, M) re-scored values with the ids as payload: top-k by (score desc, id asc);
+      5. per-query certificate  b_M + eps_q < T_k ; the queries that fail get a full f32 K6 row (the f32 path itself).
+    Returns (top_w = exp(alpha s) (Nq, k) f32, top_i (Nq, k) int32, info dict)."""
+    ex = index.exact
+    mods = index.modalities
+    masks = [index.mask[m] for m in mods]
+    qn = [ops.l2norm_rows(qvec[m].contiguous()) for m in mods]
+    if qn[0].dtype != torch.float32:
+        raise ValueError("exact-rank mode needs f32 query vectors (an f32 model)")
+    qb, eq = [], []
+    for q in qn:
+        b, e = ops.round_bf16_rows_err(q)
+        qb.append(b), eq.append(e)
+    filt = _k6(index, qb, ops)
+    m_c = min(ex.n_candidates, index.n_videos)
+    cand_s, cand_i = ops.topk_rows(filt, m_c, alpha=0.0)
+    f32rows = [ex.feat1n_f32[m] for m in mods]
+    cand_r = ops.q2c_rescore(qn, f32rows, masks, cand_i)
+    top_w, top_i = ops.topk_rows(cand_r, k, alpha=0.0, idx_in=cand_i)
+    fail, eps, n_fail = ops.exact_certificate(cand_s, top_w, eq, [ex.e_c[m] for m in mods], exact_slack(qn[0].shape[1]),
+                                              alpha, index.n_videos > m_c)
+    nf = int(n_fail.item())        # (host sync: the fallback's launch shape depends on it)
+    if nf:
+        rows = torch.nonzero(fail, as_tuple=False).reshape(-1)
+        qsub = [q.index_select(0, rows).contiguous() for q in qn]
+        if nf <= EXACT_SMALL_FALLBACK:
+            # a handful of queries: the pair kernel with EVERY video listed (one 64-row chunk per video, the f32 corpus
+            # streamed once) -- the all-pairs K6 kernel would pad them to a 256-query tile (16 ms for 12 queries)
+            allv = torch.arange(index.n_videos, dtype=torch.int32, device=rows.device).repeat(nf, 1).contiguous()
+            full = ops.q2c_rescore(qsub, f32rows, masks, allv)
+        else:
+            full = ops.q2c_scores_fused(qsub, f32rows, masks)
+        fw, fi = ops.topk_rows(full, k, alpha=alpha)
+        top_w.index_copy_(0, rows, fw)
+        top_i.index_copy_(0, rows, fi)
+    info = dict(n_fail=nf, fail=fail, eps=eps, q2c_filter=filt, cand_indices=cand_i, cand_filter=cand_s,
+                cand_scores=cand_r, n_candidates=m_c)
+    return top_w, top_i, info
 
 
 def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=True, replicated=False):
@@ -264,7 +360,11 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
       and, if svmr_video (Nq,) int32 is given, svmr_scores / svmr_flat (Nq,n) over (l_ref, l_ref).
     external_top = (indices (Nq,K) int32, weights (Nq,K) f32): use these videos / weights instead of K6 + K8."""
     qvec = stage_query_vectors(model, query_feat, query_mask)
-    if external_top is None:
+    exact = None
+    if external_top is None and index.exact is not None:
+        q2c = None          # (the f32 (Nq, Nv) matrix is never formed; exact["q2c_filter"] is the bf16 pass's)
+        top_w, top_i, exact = stage_exact_topk(index, qvec, min(max_vcmr_video, index.n_videos), q2c_alpha, ops)
+    elif external_top is None:
         q2c = stage_q2c(index, qvec, ops)
         k = min(max_vcmr_video, index.n_videos)
         top_w, top_i = ops.topk_rows(q2c, k, alpha=q2c_alpha)
@@ -274,6 +374,8 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
     st, ed = stage_span_probs(model, index, qvec, top_i, ops)
     fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
     out = dict(q2c=q2c, top_scores=top_w, top_indices=top_i, flat_scores=fs, flat_indices=fi)
+    if exact is not None:
+        out["exact"] = exact
     if svmr_video is not None:
         pv = svmr_video.to(torch.int32).reshape(-1, 1).contiguous()
         st1, ed1 = stage_span_probs(model, index, qvec, pv, ops)
@@ -293,6 +395,9 @@ class GraphedVcmrSearch(object):
     afterwards (re-create the object after load_state_dict / an optimizer step)."""
 
     def __init__(self, model, index, nq, lq, d_in, **search_kwargs):
+        if index.exact is not None:
+            raise ValueError("exact-rank mode reads its certificate on the host (the fallback's launch shape depends on "
+                             "it): not capturable")
         dev = next(model.parameters()).device
         self.query_feat = torch.zeros((nq, lq, d_in), dtype=torch.float32, device=dev)
         self.query_mask = torch.zeros((nq, lq), dtype=torch.float32, device=dev)
@@ -372,7 +477,7 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
         out = vcmr_search(model, index, qf, qm, max_vcmr_video=max_n_videos, max_before_nms=max_before_nms,
                           q2c_alpha=opt.q2c_alpha, min_pred_l=opt.min_pred_l, max_pred_l=opt.max_pred_l,
                           svmr_video=gt, ops=ops, external_top=external_top)
-        host = {k: v.cpu().numpy() for k, v in out.items() if v is not None and k != "q2c"}
+        host = {k: v.cpu().numpy() for k, v in out.items() if v is not None and k not in ("q2c", "exact")}
         for i, m in enumerate(metas):
             if is_vr:
                 preds = [[int(meta_vid[v]), 0, 0, float(s)] for v, s in

@@ -476,3 +476,58 @@ def moment_topk(st, ed, w, l_ref, min_l, max_l, n_out):
     check(_lib.load().xml_moment_topk(_p(st), _p(ed), _p(w), _p(sc), _p(fl), nq, kpairs, lpad, int(l_ref), int(min_l),
                                       int(max_l), int(n_out), _stream()), "xml_moment_topk")
     return sc, fl
+
+
+# ---- exact-rank mode (bf16 K6 as a filter in front of f32 scores; include/xmlhip.h "Exact-rank mode") --------------------
+def round_bf16_rows_err(y):
+    """y (..., d) f32 L2-normalised rows -> (yb bf16 = rne(y), err (...) f32 = ||y - yb||_2 per row)."""
+    _req(y, "y", torch.float32)
+    d = y.shape[-1]
+    yb = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+    err = torch.empty(y.shape[:-1], dtype=torch.float32, device=y.device)
+    check(_lib.load().xml_round_bf16_rows_err(_p(y), _p(yb), _p(err), y.numel() // d, d, _stream()),
+          "xml_round_bf16_rows_err")
+    return yb, err
+
+
+def q2c_rescore(qn, cn, masks, pair_vid):
+    """Video-level scores of the listed pairs only.  qn / cn / masks: lists over modalities of (Nq, H), (Nv, Lpad, H)
+    row-major L2-normalised, (Nv, Lpad) f32; pair_vid (Nq, K) int32 -> (Nq, K) f32 (-inf for ids outside [0, Nv))."""
+    n_mod = len(qn)
+    for m in range(n_mod):
+        _req(qn[m], "qn"); _req(cn[m], "cn", qn[m].dtype); _req(masks[m], "mask", torch.float32)
+        assert cn[m].shape == cn[0].shape and qn[m].shape == qn[0].shape and tuple(masks[m].shape) == tuple(cn[0].shape[:2])
+    _req(pair_vid, "pair_vid", torch.int32)
+    nq, hidden = qn[0].shape
+    nv, lpad, _ = cn[0].shape
+    kp = pair_vid.shape[1]
+    assert pair_vid.shape[0] == nq
+    out = torch.empty((nq, kp), dtype=torch.float32, device=pair_vid.device)
+    lib = _lib.load()
+    ws = _workspace(lib.xml_q2c_rescore_workspace_bytes(nq, nv, kp), pair_vid.device)
+    j = 1 if n_mod > 1 else 0
+    check(lib.xml_q2c_rescore(n_mod, _p(qn[0]), _p(qn[j]), _p(cn[0]), _p(cn[j]), _p(masks[0]), _p(masks[j]), _p(pair_vid),
+                              _p(out), nq, nv, kp, lpad, hidden, dt_of(qn[0]), _p(ws), ws.numel(), _stream()),
+          "xml_q2c_rescore")
+    return out
+
+
+def exact_certificate(filter_scores, top_val, eq, ec, slack, alpha, outside):
+    """Per-query certificate of the exact-rank filter.  filter_scores (Nq, M) f32 desc (bf16 pass); top_val (Nq, K) f32 desc,
+    raw re-scored values -- turned into exp(alpha * s) IN PLACE; eq: list of (Nq,) f32 per modality; ec: list of floats.
+    Returns (fail (Nq,) int32, eps (Nq,) f32, n_fail (1,) int32 device tensor)."""
+    _req(filter_scores, "filter_scores", torch.float32); _req(top_val, "top_val", torch.float32)
+    n_mod = len(eq)
+    for e in eq:
+        _req(e, "eq", torch.float32)
+    nq, m = filter_scores.shape
+    k = top_val.shape[1]
+    dev = top_val.device
+    fail = torch.empty((nq,), dtype=torch.int32, device=dev)
+    eps = torch.empty((nq,), dtype=torch.float32, device=dev)
+    n_fail = torch.zeros((1,), dtype=torch.int32, device=dev)
+    j = 1 if n_mod > 1 else 0
+    check(_lib.load().xml_exact_certificate(_p(filter_scores), m, _p(top_val), k, _p(eq[0]), _p(eq[j]), float(ec[0]),
+                                            float(ec[j]), n_mod, float(slack), float(alpha), int(bool(outside)), _p(fail),
+                                            _p(eps), _p(n_fail), nq, _stream()), "xml_exact_certificate")
+    return fail, eps, n_fail

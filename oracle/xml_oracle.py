@@ -325,18 +325,24 @@ def cat_pad_context(tensor_list):
 
 
 def vcmr_tail(q2c, st_logits, ed_logits, q2c_alpha=20.0, max_vcmr_video=100, min_pred_l=2, max_pred_l=16,
-              max_before_nms=200):
+              max_before_nms=200, external_top=None):
     """Torch part of compute_query2ctx_info for one query batch, xml/inference.py:317-386.
 
     q2c (Nq,Nv); st/ed logits (Nq,Nv,L).  Returns dict with the arrays the reference hands to numpy:
     top video scores/indices (Nq,K) and the first `max_before_nms` entries of the flat descending sort
     over (K, L, L).  Multiplication order follows torch.einsum without opt_einsum: (st*w)*ed.
+    external_top = (meta indices (Nq,K) int64, scores (Nq,K) f32): the external-VR branch, xml/inference.py:349-355 --
+    another model's videos and cosine-like scores replace topk(exp(alpha * q2c)); the weights are exp(alpha * score).
     """
     w = torch.exp(q2c_alpha * q2c)
     st = torch.softmax(st_logits, dim=-1)
     ed = torch.softmax(ed_logits, dim=-1)
     k = min(max_vcmr_video, w.shape[1])
-    top_w, top_i = torch.topk(w, k, dim=1, largest=True)
+    if external_top is None:
+        top_w, top_i = torch.topk(w, k, dim=1, largest=True)
+    else:
+        top_i = torch.as_tensor(external_top[0]).long()
+        top_w = torch.exp(q2c_alpha * torch.as_tensor(external_top[1]).float())
     rows = torch.arange(len(st)).unsqueeze(1)
     st_k = st[rows, top_i]
     ed_k = ed[rows, top_i]

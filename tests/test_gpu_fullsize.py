@@ -78,15 +78,16 @@ def test_c2_full_shape_vs_oracle_fp32():
         n_mom_rows += len(rows)
         assert (gfi[sl][rows] >= 0).all()
         n_mom_diff += _tie_aware_equal(gkey[rows], gfs[sl][rows], wkey[rows], wfs[rows], kn, 5e-4, "top-200 moments")
-    assert n_mom_rows >= 0.98 * nq, "video sets differ for %d queries" % (nq - n_mom_rows)
+    assert n_mom_rows >= nq - 1, "video sets differ for %d queries" % (nq - n_mom_rows)      # measured: 0 or 1 of 256
     print("C2 full shape: q2c max err %.2e; %d / %d video positions and %d / %d moment positions swapped inside tie groups"
           % (err, n_vid_diff, nq * kv, n_mom_diff, n_mom_rows * kn))
-    assert n_vid_diff <= 0.01 * nq * kv and n_mom_diff <= 0.02 * n_mom_rows * kn
+    # measured 13 / 25 600 and 56 / 51 000; bounds at ~3x (a regression of an order of magnitude fails)
+    assert n_vid_diff <= 40 and n_mom_diff <= 170, (n_vid_diff, n_mom_diff)
 
 
 def test_c3_bf16_vs_fp32_rank_agreement():
     """Bounds on how far the bf16 lists move from the fp32 lists (full corpus, 1 000 queries).  The measured values are
-    committed in profiles/r02_bf16_vs_fp32_rank_agreement.json; the bounds here leave a margin below them."""
+    committed in profiles/r0*_bf16_vs_fp32_rank_agreement.json; the bounds here sit 0.4-0.8 points below them."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import rank_agreement
     res = rank_agreement.run(1000, 21793)
@@ -101,8 +102,27 @@ def test_c3_bf16_vs_fp32_rank_agreement():
 
 
 BOUNDS = {      # measured (profiles/r02_bf16_vs_fp32_rank_agreement.json): pipeline 0.988 / 0.986 / 0.979 / 0.960,
-    "pipeline_bf16": {"videos_top100_overlap": 0.975, "videos_top10_overlap": 0.97, "videos_top1_same": 0.955,
-                      "moment_top1_iou_ge_0.7": 0.93},
-    "k6_only_bf16": {"videos_top100_overlap": 0.985, "videos_top10_overlap": 0.975, "videos_top1_same": 0.965,
-                     "moment_top1_iou_ge_0.7": 0.965},                 # k6_only 0.992 / 0.990 / 0.986 / 0.988
+    "pipeline_bf16": {"videos_top100_overlap": 0.984, "videos_top10_overlap": 0.981, "videos_top1_same": 0.972,
+                      "moment_top1_iou_ge_0.7": 0.952},
+    "k6_only_bf16": {"videos_top100_overlap": 0.989, "videos_top10_overlap": 0.986, "videos_top1_same": 0.98,
+                     "moment_top1_iou_ge_0.7": 0.982},                 # k6_only 0.992 / 0.990 / 0.986 / 0.988
 }
+
+
+def test_c3_exact_rank_mode_gives_the_fp32_lists():
+    """configs[2] in exact-rank mode (bf16 K6 as a filter + f32 re-score + certificate, tests/test_gpu_exact.py) against
+    the plain f32 HIP path on 1 000 queries x the full 21 793-video corpus: EQUALITY, not overlap floors -- every top-100
+    video position and every top-192 (video, st, ed) position identical except inside groups of scores tied to f32
+    rounding (1e-6 on the cosine); top-1 video and top-1 moment identical for every query."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_exact
+    res = bench_exact.run(1000, 21793, "perturbed", 1000)
+    print(res)
+    v = res["vs_plain_f32"]
+    assert v["video_positions_really_different"] == 0 and v["moment_positions_really_different"] == 0, v
+    assert v["video_positions_swapped_in_f32_ties"] <= 50 and v["moment_positions_swapped_in_f32_ties"] <= 100, v
+    assert v["top1_video_same"] == 1.0 and v["top1_moment_same"] == 1.0, v
+    assert v["queries_with_identical_top100_order"] >= 990, v
+    c = res["certificate"]
+    assert c["fail_rate"] <= 0.05, c                                   # measured 0.1 %: the fallback stays rare
+    assert c["filter_abs_err_max"] < c["eps_mean"], c                 # the bound really bounds what the filter did

@@ -150,6 +150,38 @@ def test_golden_pipeline_fp32(name):
         _compare_lists(res[task], d["res/" + task], task)
 
 
+def test_golden_external_vr_fp32(tmp_path):
+    """The external-VR hook against the REFERENCE's own run of that branch (xml/inference.py:244-249,
+    264-273,349-355; fixture made by tools/make_golden.py::gen_external_vr_case): another model's VR submission -- 8
+    videos per query, trimmed to max_vcmr_video = 6 by get_submission_top_n -- replaces K6 + K8; VCMR moments are
+    re-ranked inside those videos with weights exp(alpha * s); the VR list is the external one."""
+    import argparse
+    from tvretrieval_amd import inference as inf
+    d, cfg, sd = load_golden("pipeline_external_vr_h128")
+    o = json.loads(str(d["opt"]))
+    m = build_model(cfg, sd)
+    ds = GoldenDataset(d, m.use_video, m.use_sub)
+    ext = dict(video2idx=ds.video2idx,
+               VR=[dict(desc_id=5000 + i, desc="query %d" % i,
+                        predictions=[[int(v), 0, 0, float(s)] for v, s in zip(d["ext/video_idx"][i], d["ext/score"][i])])
+                   for i in range(ds.n_q)])
+    path = str(tmp_path / "external_vr.json")
+    with open(path, "w") as f:
+        json.dump(ext, f)
+    opt = argparse.Namespace(eval_context_bsz=o["eval_context_bsz"], eval_query_bsz=o["eval_query_bsz"],
+                             device=torch.device(DEV), q2c_alpha=o["q2c_alpha"], min_pred_l=o["min_pred_l"],
+                             max_pred_l=o["max_pred_l"], clip_length=o["clip_length"], debug=False,
+                             external_inference_vr_res_path=path, max_ctx_l=cfg["max_ctx_l"])
+    with torch.no_grad():
+        ctx = inf.compute_context_info(m, ds, opt)
+        res = inf.compute_query2ctx_info(m, ds, opt, ctx, max_before_nms=o["max_before_nms"],
+                                         max_n_videos=o["max_vcmr_video"], tasks=("SVMR", "VCMR", "VR"))
+    for task in ("VR", "VCMR", "SVMR"):
+        _compare_lists(res[task], d["res/" + task], task + " (external VR)")
+    for e, want in zip(res["VR"], d["res/VR"]):      # the external list itself, position by position
+        assert [p[0] for p in e["predictions"]] == [int(v) for v in want[:, 0]]
+
+
 @pytest.mark.parametrize("name", ["xml_video_sub_cross_h128", "xml_video_only_h256"])
 def test_golden_bf16_overlap(name):
     """bf16 compute on the same fixtures: features within bf16 rounding of the fp32 reference, and the video
@@ -426,6 +458,65 @@ def test_short_corpus_zero_score_tail_is_dropped():
         gk = moment_keys(gf[q:q + 1, :n], out["top_indices"].cpu().numpy()[q:q + 1], l)
         wk = moment_keys(wf[q:q + 1, :n], want["top_indices"].numpy()[q:q + 1], l)
         tie_aware_equal(gk, gs[q:q + 1, :n], wk, ws[q:q + 1, :n], n, 2e-4, "positive-score prefix")
+
+
+def test_pad_tail_gives_the_reference_row_count():
+    """Opt-in pad_tail=True: max_before_nms rows like the reference (xml/inference.py:381-386) -- the positive-score prefix
+    unchanged, then rows of score 0 at positions whose score is exactly 0 in the reference's product tensor too, no
+    position twice; through the driver every prediction list then has max_before_nms entries."""
+    import argparse
+    from tvretrieval_amd import inference as inf
+    nv, nq, l = 2, 3, 16
+    m, cfg = _synthetic_model("video_sub", 128, 64, 64, 64, l, torch.float32, seed=4)
+    vf, vm = _feats(nv, [16, 9], 64, 1)
+    sf, sm = _feats(nv, [16, 9], 64, 2)
+    qf, qm = _feats(nq, [5, 9, 12], 64, 3)
+    om = O.OracleXML(cfg, {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        v1, v2, s1, s2 = om.encode_context(vf, vm, sf, sm)
+        q2c, st, ed = om.get_pred_from_raw_query(qf, qm, v1, v2, vm, s1, s2, sm, cross=True)
+        t = O.vcmr_tail(q2c, st, ed, 20.0, 2, 2, 16, 2 * l * l)           # the WHOLE sorted product tensor
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))])
+        gt = torch.tensor([0, 1, 1], dtype=torch.int32, device=DEV)
+        plain = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=2, max_before_nms=200, svmr_video=gt)
+        out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=2, max_before_nms=200, svmr_video=gt,
+                              pad_tail=True)
+    ref_score = np.zeros((nq, 2 * l * l), dtype=np.float32)               # reference score of every flat position
+    np.put_along_axis(ref_score, t["flat_indices"].numpy(), t["flat_scores"].numpy(), 1)
+    for key_f, key_s in (("flat_indices", "flat_scores"), ("svmr_flat", "svmr_scores")):
+        gf, gs = out[key_f].cpu().numpy(), out[key_s].cpu().numpy()
+        pf = plain[key_f].cpu().numpy()
+        assert gf.shape == (nq, 200) and (gf >= 0).all()
+        for q in range(nq):
+            n = int((pf[q] >= 0).sum())
+            assert 0 < n < 200
+            assert (gf[q][:n] == pf[q][:n]).all() and (gs[q][:n] == plain[key_s].cpu().numpy()[q][:n]).all()
+            assert (gs[q][n:] == 0).all() and len(set(gf[q].tolist())) == 200
+            if key_f == "flat_indices":
+                assert (ref_score[q][gf[q][n:]] == 0).all()               # zero in the reference's tensor as well
+            else:                                                         # SVMR: out of the band => masked => 0
+                d_ = gf[q][n:] % l - gf[q][n:] // l
+                assert ((d_ < 2) | (d_ >= 16)).all()
+    # the driver: every list has max_before_nms rows
+    d, cfg2, sd = load_golden("pipeline_video_only_h128")
+    o = json.loads(str(d["opt"]))
+    m2 = build_model(cfg2, sd)
+    ds = GoldenDataset(d, m2.use_video, m2.use_sub)
+    opt = argparse.Namespace(eval_context_bsz=o["eval_context_bsz"], eval_query_bsz=o["eval_query_bsz"],
+                             device=torch.device(DEV), q2c_alpha=o["q2c_alpha"], min_pred_l=o["min_pred_l"],
+                             max_pred_l=o["max_pred_l"], clip_length=o["clip_length"], debug=False,
+                             external_inference_vr_res_path=None, max_ctx_l=cfg2["max_ctx_l"], pad_tail=True)
+    with torch.no_grad():
+        ctx = inf.compute_context_info(m2, ds, opt)
+        res = inf.compute_query2ctx_info(m2, ds, opt, ctx, max_before_nms=800, max_n_videos=2, tasks=("SVMR", "VCMR"))
+        opt.pad_tail = False
+        short = inf.compute_query2ctx_info(m2, ds, opt, ctx, max_before_nms=800, max_n_videos=2, tasks=("SVMR", "VCMR"))
+    for task in ("SVMR", "VCMR"):      # 30 clips: < 800 banded candidates in one video (SVMR), and in two for most queries
+        assert [len(e["predictions"]) for e in res[task]] == [800] * ds.n_q
+        assert all(e["predictions"][-1][3] == 0.0 for e in res["SVMR"])
+        for a, b in zip(res[task], short[task]):
+            assert a["predictions"][:len(b["predictions"])] == b["predictions"] and len(b["predictions"]) <= 800
+    assert all(len(e["predictions"]) < 800 for e in short["SVMR"])
 
 
 def test_hip_graph_replay_equals_eager():

@@ -144,6 +144,52 @@ def test_pipeline(name):
         np.testing.assert_allclose(got, want)
 
 
+def test_pipeline_external_vr():
+    """The external-VR branch of the driver (xml/inference.py:244-249,264-273,349-355) through the oracle, against the
+    lists the reference produced with opt.external_inference_vr_res_path set (tools/make_golden.py::gen_external_vr_case):
+    the first max_vcmr_video entries of another model's VR submission replace top-k, their weights are exp(alpha * s)."""
+    d, cfg, sd = load_golden("pipeline_external_vr_h128")
+    opt = json.loads(str(d["opt"]))
+    m = O.OracleXML(cfg, sd)
+    vids, qs = _pipeline_inputs(d, cfg)
+    bs, kv = opt["eval_context_bsz"], opt["max_vcmr_video"]
+    idx2meta = {int(v): i for i, v in enumerate(d["video_idx"])}
+    f = dict(v1=[], v2=[], s1=[], s2=[], vm=[], sm=[])
+    with torch.no_grad():
+        for b in range(0, len(vids), bs):
+            vf, vm = _pad([v["video"] for v in vids[b:b + bs]])
+            sf, sm = _pad([v["sub"] for v in vids[b:b + bs]])
+            v1, v2, s1, s2 = m.encode_context(vf, vm, sf, sm)
+            f["v1"].append(v1), f["v2"].append(v2), f["vm"].append(torch.from_numpy(vm))
+            f["s1"].append(s1), f["s2"].append(s2), f["sm"].append(torch.from_numpy(sm))
+        ctx = {k: O.cat_pad_context(v) for k, v in f.items()}
+        qb = opt["eval_query_bsz"]
+        vcmr, vr = [], []
+        for b in range(0, len(qs), qb):
+            qf, qm = _pad(qs[b:b + qb])
+            q2c, st, ed = m.get_pred_from_raw_query(qf, qm, ctx["v1"], ctx["v2"], ctx["vm"], ctx["s1"], ctx["s2"],
+                                                    ctx["sm"], cross=True)
+            ext_i = np.array([[idx2meta[int(v)] for v in row[:kv]] for row in d["ext/video_idx"][b:b + qb]])
+            ext_s = d["ext/score"][b:b + qb, :kv].astype(np.float32)
+            t = O.vcmr_tail(q2c, st, ed, q2c_alpha=opt["q2c_alpha"], max_vcmr_video=kv, min_pred_l=opt["min_pred_l"],
+                            max_pred_l=opt["max_pred_l"], max_before_nms=opt["max_before_nms"],
+                            external_top=(ext_i, ext_s))
+            vid, st_s, ed_s = O.unravel_moments(t["flat_indices"].numpy(), t["top_indices"].numpy(), t["ctx_l"],
+                                                opt["clip_length"])
+            for i in range(len(qf)):
+                vcmr.append(np.stack([d["video_idx"][vid[i]], st_s[i], ed_s[i], t["flat_scores"].numpy()[i]], 1))
+                tw = t["top_scores"].numpy()[i]
+                vr.append(np.stack([d["video_idx"][t["top_indices"].numpy()[i]], 0 * tw, 0 * tw, tw], 1))
+    for got, want in ((vcmr, d["res/VCMR"]), (vr, d["res/VR"])):
+        got = np.stack(got)
+        _close(got[..., 3], want[..., 3], rtol=1e-5, atol=1e-9)
+        pos = want[..., 3] > 0
+        np.testing.assert_array_equal(got[..., :3][pos], want[..., :3][pos])
+    # the VR list IS the external one, trimmed to max_vcmr_video, with exp(alpha * s) as score
+    np.testing.assert_array_equal(d["res/VR"][..., 0], d["ext/video_idx"][:, :kv])
+    np.testing.assert_allclose(d["res/VR"][..., 3], np.exp(opt["q2c_alpha"] * d["ext/score"][:, :kv]), rtol=1e-5)    # (f32 exp)
+
+
 NO_DECAY = ["bias", "LayerNorm.bias", "LayerNorm.weight"]     # xml/train.py:355-362
 
 

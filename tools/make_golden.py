@@ -207,9 +207,8 @@ class FakeEvalDataset(torch.utils.data.Dataset):
         return dict(meta=meta, model_inputs=dict(query_feat=torch.from_numpy(q["query_feat"])))
 
 
-def gen_pipeline_case(ns, name, cfg, seed, n_v, len_lo, len_hi, n_q, ctx_bsz, q_bsz, kvid, nbefore, nms_thd):
-    """Runs the reference driver: compute_context_info -> compute_query2ctx_info(VCMR,SVMR,VR) -> NMS."""
-    import argparse as ap
+def _pipeline_world(ns, cfg, seed, n_v, len_lo, len_hi, n_q):
+    """Model + in-memory corpus / queries of a driver fixture (same draws, in the same order, for every caller)."""
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
     model = ns.model_xml.XML(EasyDict(cfg))
@@ -230,6 +229,13 @@ def gen_pipeline_case(ns, name, cfg, seed, n_v, len_lo, len_hi, n_q, ctx_bsz, q_
         queries.append(dict(desc_id=5000 + i, desc="query %d" % i, vid_name="vid_%03d" % int(rng.integers(0, n_v)),
                             query_feat=l2n(rng.standard_normal((lq, cfg["query_input_size"])).astype(np.float32))))
     ds = FakeEvalDataset(videos, queries, cfg["max_ctx_l"], use_video, use_sub)
+    return model, ds, videos, queries, lens, rng
+
+
+def gen_pipeline_case(ns, name, cfg, seed, n_v, len_lo, len_hi, n_q, ctx_bsz, q_bsz, kvid, nbefore, nms_thd):
+    """Runs the reference driver: compute_context_info -> compute_query2ctx_info(VCMR,SVMR,VR) -> NMS."""
+    import argparse as ap
+    model, ds, videos, queries, lens, rng = _pipeline_world(ns, cfg, seed, n_v, len_lo, len_hi, n_q)
     opt = ap.Namespace(eval_context_bsz=ctx_bsz, eval_query_bsz=q_bsz, num_workers=0, pin_memory=False,
                        device=torch.device("cpu"), ctx_mode=cfg["ctx_mode"], external_inference_vr_res_path=None,
                        max_ctx_l=cfg["max_ctx_l"], q2c_alpha=20.0, min_pred_l=2, max_pred_l=16, clip_length=1.5,
@@ -266,6 +272,59 @@ def gen_pipeline_case(ns, name, cfg, seed, n_v, len_lo, len_hi, n_q, ctx_bsz, q_
         out["nms/VCMR/%d" % i] = np.array(e["predictions"], dtype=np.float64).reshape(-1, 4)
     for i, e in enumerate(sv):
         out["nms/SVMR/%d" % i] = np.array(e["predictions"], dtype=np.float64).reshape(-1, 4)
+    path = os.path.join(OUT_DIR, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
+
+
+def gen_external_vr_case(ns, name, cfg, seed, n_v, len_lo, len_hi, n_q, ctx_bsz, q_bsz, kvid, kext, nbefore):
+    """The reference driver with opt.external_inference_vr_res_path set (xml/inference.py:244-249,264-273,349-355):
+    another model's VR submission replaces top-k + exp(alpha * s).  The submission is synthetic -- kext > kvid distinct
+    videos per query with descending cosine-like scores, so get_submission_top_n's trim to max_n_videos is exercised --
+    and is stored in the fixture as arrays; the reference reads it back through its own load_external_vr_res2."""
+    import argparse as ap
+    import tempfile
+    model, ds, videos, queries, lens, rng = _pipeline_world(ns, cfg, seed, n_v, len_lo, len_hi, n_q)
+    names = [v["vid_name"] for v in videos]
+    ext_vid = np.zeros((n_q, kext), dtype=np.int64)
+    ext_score = np.zeros((n_q, kext), dtype=np.float64)
+    vr = []
+    for i, q in enumerate(queries):
+        pick = rng.permutation(n_v)[:kext]
+        sc = np.sort(rng.uniform(-0.2, 0.9, kext))[::-1]
+        sc = np.round(sc.astype(np.float32).astype(np.float64), 6)
+        ext_vid[i] = [ds.video2idx[names[int(j)]] for j in pick]
+        ext_score[i] = sc
+        vr.append(dict(desc_id=q["desc_id"], desc=q["desc"],
+                       predictions=[[int(v), 0, 0, float(x)] for v, x in zip(ext_vid[i], sc)]))
+    with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+        json.dump(dict(video2idx=ds.video2idx, VR=vr), f)
+        ext_path = f.name
+    opt = ap.Namespace(eval_context_bsz=ctx_bsz, eval_query_bsz=q_bsz, num_workers=0, pin_memory=False,
+                       device=torch.device("cpu"), ctx_mode=cfg["ctx_mode"], external_inference_vr_res_path=ext_path,
+                       max_ctx_l=cfg["max_ctx_l"], q2c_alpha=20.0, min_pred_l=2, max_pred_l=16, clip_length=1.5,
+                       debug=False, max_before_nms=nbefore, max_vcmr_video=kvid)
+    try:
+        with torch.no_grad():
+            ctx_info = ns.inference.compute_context_info(model, ds, opt)
+            res = ns.inference.compute_query2ctx_info(model, ds, opt, ctx_info, max_before_nms=nbefore,
+                                                      max_n_videos=kvid, tasks=("SVMR", "VCMR", "VR"))
+    finally:
+        os.unlink(ext_path)
+    out = dict(cfg=json.dumps(cfg), ctx_lens=lens,
+               opt=json.dumps(dict(eval_context_bsz=ctx_bsz, eval_query_bsz=q_bsz, q2c_alpha=20.0, min_pred_l=2,
+                                   max_pred_l=16, clip_length=1.5, max_before_nms=nbefore, max_vcmr_video=kvid)))
+    out.update(sd_arrays(model))
+    for i, v in enumerate(videos):
+        out["video_feat/%d" % i] = v["video_feat"]
+        out["sub_feat/%d" % i] = v["sub_feat"]
+    for i, q in enumerate(queries):
+        out["query_feat/%d" % i] = q["query_feat"]
+    out["query_gt_video"] = np.array([int(q["vid_name"][4:]) for q in queries], dtype=np.int64)
+    out["video_idx"] = np.array([ds.video2idx[v["vid_name"]] for v in videos], dtype=np.int64)
+    out["ext/video_idx"], out["ext/score"] = ext_vid, ext_score
+    for task in ["VCMR", "SVMR", "VR"]:
+        out["res/" + task] = np.array([[p for p in e["predictions"]] for e in res[task]], dtype=np.float64)
     path = os.path.join(OUT_DIR, name + ".npz")
     np.savez_compressed(path, **out)
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
@@ -425,7 +484,8 @@ def main():
     only = sys.argv.pop(1) if len(sys.argv) > 1 and not sys.argv[1].startswith("-") else ""
     if only:      # regenerate a subset: python tools/make_golden.py train_step
         g = globals()
-        for fn in ("gen_model_case", "gen_pipeline_case", "gen_eval_case", "gen_train_case", "gen_ingest_case"):
+        for fn in ("gen_model_case", "gen_pipeline_case", "gen_external_vr_case", "gen_eval_case", "gen_train_case",
+                   "gen_ingest_case"):
             orig = g[fn]
             g[fn] = (lambda o: lambda ns, name, *a, **k: o(ns, name, *a, **k) if only in name else None)(orig)
     ap = argparse.ArgumentParser()
@@ -449,6 +509,8 @@ def main():
     gen_pipeline_case(ns, "pipeline_video_only_h128",
                       model_cfg(ctx_mode="video", max_ctx_l=30), 22, n_v=11, len_lo=8, len_hi=30,
                       n_q=7, ctx_bsz=4, q_bsz=3, kvid=5, nbefore=40, nms_thd=0.5)
+    gen_external_vr_case(ns, "pipeline_external_vr_h128", model_cfg(max_ctx_l=36), 23, n_v=14, len_lo=8, len_hi=36,
+                         n_q=9, ctx_bsz=5, q_bsz=4, kvid=6, kext=8, nbefore=50)
     gen_eval_case(ns, "eval_tvr_style", 41, n_q=60, n_v=25, didemo=False)
     gen_eval_case(ns, "eval_didemo_style", 42, n_q=30, n_v=12, didemo=True)
     gen_train_case(ns, "train_step_video_sub_h128", model_cfg(max_ctx_l=24, lw_st_ed=0.01, visual_input_size=48, sub_input_size=32,

@@ -350,15 +350,43 @@ def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=Tru
                              zero_skipped=zero_skipped)
 
 
+def pad_moment_tail(flat_scores, flat_indices, k_videos, l_ref, min_pred_l, max_pred_l):
+    """Opt-in reference-shaped tail of a moment list.  The reference sorts the WHOLE (k, L, L) product tensor and always
+    returns max_before_nms rows (xml/inference.py:381-386; SVMR: utils/tensor_utils.py:133-141): when fewer candidates
+    pass the length mask, its tail is rows of score exactly 0 at positions torch.sort leaves unspecified.  The kernels mark
+    those rows flat = -1; this fills them with the first length-masked positions of the (k, L, L) tensor in ascending flat
+    order (out of the band min_l <= ed - st < max_l, so their score is exactly 0 in the reference too and none of them can
+    already be in the list).  Index plumbing on the device, in place; returns (flat_scores, flat_indices)."""
+    n_out = flat_indices.shape[1]
+    dev = flat_indices.device
+    i = torch.arange(l_ref, device=dev)
+    d = i[None, :] - i[:, None]                                       # ed - st
+    inv = torch.nonzero(~((d >= min_pred_l) & (d < max_pred_l)).reshape(-1), as_tuple=False).reshape(-1)
+    reps = min(int(k_videos), -(-n_out // max(int(inv.numel()), 1)))
+    fill = (torch.arange(reps, device=dev)[:, None] * (l_ref * l_ref) + inv[None, :]).reshape(-1)[:n_out]
+    cnt = (flat_indices >= 0).sum(1, keepdim=True)
+    need = int((n_out - cnt).max())
+    if fill.numel() < need:        # (the reference itself fails when max_before_nms exceeds k * L * L)
+        raise ValueError("pad_tail: %d rows to fill but only %d length-masked positions exist" % (need, fill.numel()))
+    pos = torch.arange(n_out, device=dev)[None, :]
+    take = fill.to(flat_indices.dtype)[(pos - cnt).clamp(0, fill.numel() - 1)]
+    empty = pos >= cnt
+    flat_indices.copy_(torch.where(empty, take, flat_indices))
+    flat_scores.masked_fill_(empty, 0.0)
+    return flat_scores, flat_indices
+
+
 def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200, q2c_alpha=20.0,
-                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops, external_top=None):
+                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops, external_top=None, pad_tail=False):
     """Device part of compute_query2ctx_info for one query batch (xml/inference.py:308-386), single GPU.
 
     Returns device tensors:
       top_scores (Nq,K) f32 = exp(alpha*q2c) desc, top_indices (Nq,K) int32 video (meta) indices,
       flat_scores (Nq,n) f32 desc, flat_indices (Nq,n) int32 into (K, l_ref, l_ref)  [-1 = no candidate]
       and, if svmr_video (Nq,) int32 is given, svmr_scores / svmr_flat (Nq,n) over (l_ref, l_ref).
-    external_top = (indices (Nq,K) int32, weights (Nq,K) f32): use these videos / weights instead of K6 + K8."""
+    external_top = (indices (Nq,K) int32, weights (Nq,K) f32): use these videos / weights instead of K6 + K8.
+    pad_tail=True: always max_before_nms rows, the reference's shape -- missing candidates become zero-score rows at
+    length-masked positions (pad_moment_tail) instead of flat = -1."""
     qvec = stage_query_vectors(model, query_feat, query_mask)
     exact = None
     if external_top is None and index.exact is not None:
@@ -373,6 +401,8 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
         top_i, top_w = external_top
     st, ed = stage_span_probs(model, index, qvec, top_i, ops)
     fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
+    if pad_tail:
+        pad_moment_tail(fs, fi, top_i.shape[1], index.l_ref, min_pred_l, max_pred_l)
     out = dict(q2c=q2c, top_scores=top_w, top_indices=top_i, flat_scores=fs, flat_indices=fi)
     if exact is not None:
         out["exact"] = exact
@@ -380,6 +410,8 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
         pv = svmr_video.to(torch.int32).reshape(-1, 1).contiguous()
         st1, ed1 = stage_span_probs(model, index, qvec, pv, ops)
         ss, sf = ops.moment_topk(st1, ed1, None, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
+        if pad_tail:
+            pad_moment_tail(ss, sf, 1, index.l_ref, min_pred_l, max_pred_l)
         out.update(svmr_scores=ss, svmr_flat=sf, svmr_st=st1[:, 0], svmr_ed=ed1[:, 0])
     return out
 
@@ -439,7 +471,9 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
     """Mirror of compute_query2ctx_info (xml/inference.py:252-445).  Same result dict:
     {"VCMR"|"SVMR"|"VR": [dict(desc_id, desc, predictions=[[video_idx, st, ed, score], ...]), ...]}.
     opt.external_inference_vr_res_path (xml/inference.py:264-273,349-355): re-rank the videos of another model's VR
-    submission instead of this model's own top-k."""
+    submission instead of this model's own top-k.
+    opt.pad_tail=True (not a reference option): every list has max_before_nms rows like the reference's -- zero-score rows
+    where fewer candidates exist -- instead of the positive-score prefix."""
     is_svmr, is_vr, is_vcmr = "SVMR" in tasks, "VR" in tasks, "VCMR" in tasks
     index = ctx_info["index"]
     video2idx = eval_dataset.video2idx
@@ -476,7 +510,7 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
             external_top = (ext_i.to(opt.device).contiguous(), ext_w.to(opt.device).contiguous())
         out = vcmr_search(model, index, qf, qm, max_vcmr_video=max_n_videos, max_before_nms=max_before_nms,
                           q2c_alpha=opt.q2c_alpha, min_pred_l=opt.min_pred_l, max_pred_l=opt.max_pred_l,
-                          svmr_video=gt, ops=ops, external_top=external_top)
+                          svmr_video=gt, ops=ops, external_top=external_top, pad_tail=getattr(opt, "pad_tail", False))
         host = {k: v.cpu().numpy() for k, v in out.items() if v is not None and k not in ("q2c", "exact")}
         for i, m in enumerate(metas):
             if is_vr:
@@ -524,6 +558,8 @@ def compute_query2ctx_info_svmr_only(model, eval_dataset, opt, ctx_info, max_bef
         qvec = stage_query_vectors(model, qf, qm)
         st1, ed1 = stage_span_probs(model, index, qvec, gt.reshape(-1, 1).contiguous(), ops)
         ss, sf = ops.moment_topk(st1, ed1, None, l_ref, opt.min_pred_l, opt.max_pred_l, max_before_nms)
+        if getattr(opt, "pad_tail", False):
+            pad_moment_tail(ss, sf, 1, l_ref, opt.min_pred_l, opt.max_pred_l)
         ss, sf = ss.cpu().numpy(), sf.cpu().numpy()
         for i, m in enumerate(metas):
             valid = sf[i] >= 0

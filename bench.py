@@ -115,7 +115,7 @@ def list_overlap(a, b, ks=(1, 10, 100)):
     return out
 
 
-def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search):
+def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search, search_exact=None):
     """Oracle (reference formulation, torch CPU fp32) on a bounded slice -- 50 queries x 2 000 videos, median of 5 after
     one warm-up (BASELINE.md section 3 / SURVEY 8d; reference protocol profile_main.py:54,457-461) -- extrapolated
     linearly in Nv.  The same slice also goes through the HIP path (`search`), and the agreement of the two ranked
@@ -152,25 +152,36 @@ def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search):
                       "in Nv to %d videos" % (nq_s, nv_s, index.l_ref, cfg["hidden_size"], cfg["ctx_mode"], t,
                                               qps_sample, n_total))
     # the same sample through the HIP path (compute dtype of the run) vs the fp32 oracle lists
-    got = search(nq_s, nv_s)
-    if got is not None:
-        gi, wi = got["top_indices"].cpu().numpy(), want["top_indices"].numpy()
-        agree = dict(videos=list_overlap(gi, wi))
-        agree["q2c_max_abs_err"] = float((got["q2c"].cpu() - q2c_ref).abs().max())
-        # moments: compare (video, st, ed) triples, i.e. decode the flat index through each side's own video list
-        ll = index.l_ref * index.l_ref
+    ll = index.l_ref * index.l_ref
+    wi = want["top_indices"].numpy()
 
-        def triples(flat, vids):
-            flat = np.asarray(flat).astype(np.int64)
-            ok = flat >= 0
-            r = np.where(ok, flat // ll, 0)
-            v = np.take_along_axis(np.asarray(vids).astype(np.int64), r, 1)
-            return np.where(ok, v * ll + flat % ll, -1)
+    def triples(flat, vids):     # moments as (video, st, ed): decode the flat index through each side's own video list
+        flat = np.asarray(flat).astype(np.int64)
+        ok = flat >= 0
+        r = np.where(ok, flat // ll, 0)
+        v = np.take_along_axis(np.asarray(vids).astype(np.int64), r, 1)
+        return np.where(ok, v * ll + flat % ll, -1)
+
+    def agreement(got):
+        gi = got["top_indices"].cpu().numpy()
+        agree = dict(videos=list_overlap(gi, wi))
+        if got.get("q2c") is not None:
+            agree["q2c_max_abs_err"] = float((got["q2c"].cpu() - q2c_ref).abs().max())
+        agree["videos_top1_same"] = float(np.mean(gi[:, 0] == wi[:, 0]))
         agree["moments"] = list_overlap(triples(got["flat_indices"].cpu().numpy(), gi),
                                         triples(want["flat_indices"].numpy(), wi), ks=(1, 10, 100, 200))
-        res["hip_vs_oracle_on_sample"] = agree
+        return agree
+    got = search(nq_s, nv_s)
+    if got is not None:
+        res["hip_vs_oracle_on_sample"] = agreement(got)
         res["hip_vs_oracle_note"] = "share of the oracle's (fp32) top-k found in the %s HIP path's top-k, same %d x %d " \
                                     "slice" % (dtype_name, nq_s, nv_s)
+    if search_exact is not None:
+        got = search_exact(nq_s, nv_s)
+        res["exact_rank_vs_oracle_on_sample"] = agreement(got)
+        res["exact_rank_vs_oracle_on_sample"]["fell_back"] = got["exact"]["n_fail"]
+        res["exact_rank_note"] = "same slice through the exact-rank mode (f32 model, bf16 K6 as a filter + f32 re-score + " \
+                                 "certificate): the oracle's lists up to ties at f32 rounding"
     return res
 
 
@@ -203,13 +214,6 @@ class HipBackend(object):
         return {} if self.shared else dict(device_id=self.device)
 
 
-def load_backend(args, local_rank):
-    if args.backend_module:      # TEST HOOK: tests/cpu_backend.py stands in for the kernels (gloo ranks, no GPU)
-        import importlib
-        return importlib.import_module(args.backend_module).BenchBackend(local_rank)
-    return HipBackend(local_rank)
-
-
 def k6_traffic(root, workload, world):
     """HBM/fabric bytes per K6 launch from the committed PMC pass -- only if that pass was taken from THIS kernel source
     (tools/measure_k6_traffic.sh records the sha256 of the K6 sources; a stale file is refused, not quoted)."""
@@ -228,13 +232,75 @@ def k6_traffic(root, workload, world):
     return None, "no PMC pass for the current K6 source (sha256 %s...)" % h.hexdigest()[:12]
 
 
-def run(args):
+def run_extras(args, headline_qps):
+    """The other BASELINE configurations and modes, measured by the same process right after the headline run (the
+    reference's protocol: one process reports every bucket, baselines/profiling/profile_main.py:457-483).  None of these
+    numbers enters the headline fields."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_exact
+    import bench_train
+    out = {}
+
+    def leg(name, fn):
+        t0 = time.perf_counter()
+        try:
+            out[name] = fn()
+        except Exception as e:      # noqa: BLE001 -- an extra leg must never lose the headline measurement
+            out[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out[name]["leg_wall_s"] = round(time.perf_counter() - t0, 2)
+        torch.cuda.empty_cache()
+
+    def exact():
+        nq, nv = WORKLOADS["c3"][:2]
+        r = bench_exact.run(nq, nv, "reset", 0, steps=max(2, min(args.steps, 5)), warmup=2)
+        c = r["certificate"]
+        return {"value": r["queries_per_s"], "unit": "queries/s", "ms_per_step": r["ms_per_pass"], "dtype": "f32 lists",
+                "steps": r["steps_timed"], "vs_bf16_headline": r["queries_per_s"] / headline_qps,
+                "candidates_per_query": r["candidates"], "fell_back_rate": c["fail_rate"], "eps_mean": c["eps_mean"],
+                "filter_abs_err_max": c["filter_abs_err_max"], "margin_T100_minus_bM_p50": c["margin_T100_minus_bM"]["p50"],
+                "stage_ms": r["stage_ms"], "corpus_hbm_gb": r["hbm_gb"], "encode_index_s": r["encode_index_s"],
+                "what": "c3 with the f32 path's lists: f32 encoders, bf16 K6 as a filter (top-256), f32 re-score, per-query "
+                        "certificate, f32 ConvSE (tests/test_gpu_exact.py, test_c3_exact_rank_mode_gives_the_fp32_lists)"}
+
+    def sub(workload, steps, warmup):
+        import copy
+        a = copy.copy(args)
+        a.workload, a.steps, a.warmup, a.no_cpu_baseline, a.no_extras = workload, steps, warmup, True, True
+        r = run(a, emit=False)
+        keep = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "dtype": r["dtype"],
+                "steps": steps, "workload": r["config"]["workload"], "k6_tflops": r["roofline"]["achieved"],
+                "k6_frac": r["roofline"]["frac"], "k6_avg_launch_ms": r["roofline"]["avg_launch_ms"],
+                "breakdown_ms": r["breakdown_ms"]}
+        if "ragged_corpus" in r:
+            keep["executed_tflops"] = r["ragged_corpus"]["executed_tflops"]
+            keep["mean_clips"] = r["ragged_corpus"]["mean_clips"]
+        return keep
+
+    leg("exact_rank", exact)
+    leg("c2", lambda: sub("c2", 20, 3))
+    leg("c3r", lambda: sub("c3r", max(2, min(args.steps, 5)), 2))
+
+    def train():
+        r = bench_train.run(steps=10, warmup=3)
+        return {"ms": r["ms_per_step"], "tflops": r["tflops"], "frac_of_mfma_peak": r["frac_of_mfma_peak"],
+                "flops_per_step": r["flops_per_step"], "pairs_per_s": r["pairs_per_s"], "breakdown_ms": r["breakdown_ms"],
+                "config": r["config"], "dtype": r["dtype"],
+                "what": "BASELINE configs[4] on one GPU: batch 128 video+sub, L = 100, bf16, forward + backward + BertAdam"}
+    leg("train_step", train)
+    return out
+
+
+def run(args, backend_factory=None, emit=True):
+    """emit=False: return the result dict without printing (the extra legs of the default run).
+    backend_factory: None = the product (HipBackend).  tests/bench_cpu_entry.py passes tests/cpu_backend.BenchBackend to
+    drive this launcher / orchestration code with gloo ranks on a machine without a GPU; bench.py itself has no switch
+    that runs anything but libxmlhip's kernels."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus or world == 1, "--gpus must equal WORLD_SIZE under torch.distributed.run"
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    be = load_backend(args, local_rank)
+    be = (backend_factory or HipBackend)(local_rank)
     device = be.device
     multi = world > 1 or args.force_sharded      # --force-sharded: the N > 1 code path through a real 1-rank group
     if multi:
@@ -255,7 +321,8 @@ def run(args):
     model = be.make_model(cfg, dtype)
 
     # ---- one-off: encode this rank's shard of the corpus (HOT LOOP A), untimed for the metric -------------
-    lo, hi = xdist.shard_range(nv, rank, world, align=SHARD_ALIGN)
+    # (corpora too small for aligned shards on every rank -- the tiny test workload at 8 ranks -- are cut per video)
+    lo, hi = xdist.shard_range(nv, rank, world, align=SHARD_ALIGN if nv >= 2 * world * SHARD_ALIGN else 1)
     lens = real_clip_counts(nv, l) if args.workload in RAGGED else None
     with torch.no_grad():   # untimed warm-up of the encoder kernels (module load, first-launch costs, clocks)
         inf.build_corpus_index(model, context_batches(lo, min(hi, lo + 64), l, dv, ds, model.use_video, model.use_sub,
@@ -311,6 +378,11 @@ def run(args):
                 exchange = cand
             elif exch_note is None:
                 exch_note = "another rank failed the C-ABI self-check -> fell back"
+            if exch_note is not None:      # loud: this line is NOT measuring libxmlhip's collectives
+                print("bench.py rank %d: WARNING: %s; the exchanges of this run go through torch.distributed "
+                      "(config.collectives_fallback = 1)" % (rank, exch_note), file=sys.stderr, flush=True)
+        elif args.torch_collectives:
+            exch_note = "--torch-collectives"
 
     ev = []      # (start, end) event pairs around every K6 launch of the timed region
     def k6_timer():
@@ -351,6 +423,33 @@ def run(args):
         dist.all_reduce(nvs)
         per_rank_videos = [int(x) for x in nvs.cpu().tolist()]
         rccl_ranks = dist.get_world_size()
+
+    # ---- N > 1: the OTHER rerank scheme, same index, same steps (the headline keeps the scheme the flags chose) --------
+    alt_scheme = None
+    if multi and not args.no_extras:
+        alt_owner = bool(args.sharded_rerank)          # headline = sharded rerank -> alternative = owner rerank, and v.v.
+        if alt_owner and index.feat2_all is None:
+            xdist.replicate_rerank_features(index)
+
+        def alt_step():
+            with torch.no_grad():
+                return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False, ops=ops, exchange=exchange,
+                                                 owner_rerank=alt_owner, n_chunks=1)
+        alt_step()
+        dist.barrier()
+        be.sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            alt_step()
+        be.sync()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        alt_scheme = {"rerank": "query owner (feat2 replicated, feat1 sharded)" if alt_owner else
+                      "video owner (feat2 sharded): all-gather of the global top-100 + all-to-all of the local top-200",
+                      "value": nq * args.steps / float(t.item()), "unit": "queries/s",
+                      "ms_per_step": float(t.item()) / args.steps * 1e3, "steps": args.steps,
+                      "collectives_per_pass": 2 if alt_owner else 4}
 
     k6_ms = [s.elapsed_time(e) for s, e in ev]
     k6_avg_ms = float(np.mean(k6_ms))
@@ -416,6 +515,7 @@ def run(args):
                        "ranks_in_process_group": rccl_ranks, "backend": be.name,
                        "collectives": (exchange.name if exchange is not None else "none") +
                                       ("" if exch_note is None else " [%s]" % exch_note),
+                       "collectives_fallback": 0 if exch_note is None else 1,      # 1 = NOT the C-ABI exchange (see above)
                        "query_chunks": args.chunks if multi and not args.sharded_rerank else 1,
                        "launcher": "bench.py self-spawn" if os.environ.get("XML_SELF_SPAWNED") else
                                    ("torch.distributed.run" if world > 1 else "single process"),
@@ -436,6 +536,8 @@ def run(args):
             "corpus_hbm_gb_per_gpu": index.hbm_bytes() / 1e9, "replicate_feat2_s": rep_s,
             "breakdown_ms": breakdown,
         }
+        if alt_scheme is not None:
+            res["extras"] = {"other_rerank_scheme": alt_scheme}
         if ragged is not None:
             res["ragged_corpus"] = ragged
             res["roofline"]["note"] = "ragged corpus: `achieved` prices the VALID clip rows (algorithmic work); " \
@@ -446,15 +548,35 @@ def run(args):
                     sub = inf.build_corpus_index(model, context_batches(0, nv_s, l, dv, ds, model.use_video,
                                                                        model.use_sub, device, lens), ops=ops, l_ref=l)
                     return inf.vcmr_search(model, sub, qf[:nq_s].contiguous(), qm[:nq_s].contiguous(), ops=ops)
-            res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname, search)
+            search_exact = None
+            extras_on = args.workload == "c3" and not args.no_extras
+            if extras_on:
+                def search_exact(nq_s, nv_s):     # the same slice in exact-rank mode: f32 model with the SAME weights
+                    m32 = be.make_model(cfg, torch.float32)
+                    m32.load_state_dict(model.state_dict())
+                    with torch.no_grad():
+                        sub = inf.build_corpus_index(m32, context_batches(0, nv_s, l, dv, ds, m32.use_video, m32.use_sub,
+                                                                          device, lens), ops=ops, l_ref=l,
+                                                     exact_filter=True)
+                        return inf.vcmr_search(m32, sub, qf[:nq_s].contiguous(), qm[:nq_s].contiguous(), ops=ops)
+            res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname, search, search_exact)
         else:
             res["cpu_baseline"] = None
+        if world == 1 and be.name == "hip" and args.workload == "c3" and not args.no_extras:
+            enc_flops = 2.0 * l * hidden * (dv + ds) + 44.0 * l * hidden ** 2 + 24.0 * l ** 2 * hidden
+            enc_tf = res["encode_videos_per_s"] * enc_flops / 1e12
+            extras = {"encode": {"videos_per_s": res["encode_videos_per_s"], "flops_per_video": enc_flops,
+                                 "tflops": enc_tf, "frac_of_mfma_peak": enc_tf / PEAK_TFLOPS[dtname]}}
+            del index, model
+            torch.cuda.empty_cache()
+            extras.update(run_extras(args, res["value"]))
+            res["extras"] = extras
     if multi:       # RCCL's start-up banner sits in the C stdio buffer of every rank: push it out BEFORE the result line,
         import ctypes    # so that the JSON line is the last thing this job prints
         ctypes.CDLL(None).fflush(None)
         sys.stdout.flush()
         dist.barrier()
-    if rank == 0:
+    if rank == 0 and emit:
         print(json.dumps(res), flush=True)
     if multi:
         dist.barrier()
@@ -462,7 +584,7 @@ def run(args):
     return res
 
 
-def main(argv=None):
+def main(argv=None, backend_factory=None, script=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -476,18 +598,18 @@ def main(argv=None):
                     help="N > 1: query chunks of the pipelined owner pass (chunk c's exchange runs under chunk c+1's K6)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: keep the exchanges on torch.distributed instead of libxmlhip's xml_rccl_* entries (A/B)")
-    ap.add_argument("--backend-module", default=None,
-                    help="TEST HOOK: module providing BenchBackend (tests/cpu_backend.py: gloo ranks on CPU, kernels "
-                         "replaced by the oracle formulation) -- exercises this launcher without GPUs")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1, c3: skip the extra legs (exact-rank mode, c2, c3r, training step) after the headline run")
     args = ap.parse_args(argv)
     from tvretrieval_amd import launch
     if args.gpus > 1 and not launch.under_launcher():
         # `python bench.py --gpus N`: one process per GPU, started here (same environment torch.distributed.run gives)
-        rc = launch.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv), args.gpus)
+        rc = launch.spawn_local_ranks(script or os.path.abspath(__file__), sys.argv[1:] if argv is None else list(argv),
+                                      args.gpus)
         if rc != 0:
             sys.exit(rc)
         return None
-    return run(args)
+    return run(args, backend_factory)
 
 
 if __name__ == "__main__":

@@ -141,7 +141,7 @@ class _WallEvent(object):
 
 
 class BenchBackend(object):
-    """`bench.py --backend-module cpu_backend`: the launcher / sharded orchestration of bench.py on gloo ranks without a
+    """tests/bench_cpu_entry.py: the launcher / sharded orchestration of bench.py on gloo ranks without a
     GPU (tests/test_bench_launcher.py).  Kernels = CpuOps, model = CpuModel over a freshly initialised XML."""
     name, dist_backend = "cpu-stub", "gloo"
 

@@ -119,7 +119,11 @@ def _worker(rank, world, port, name, kvid, nbefore, ret):
                                                       ("xml_video_only_h256", 4, 40, 2),
                                                       ("xml_video_sub_nocross_nomerge_h128", 3, 30, 2),
                                                       ("xml_video_sub_cross_h128", 5, 60, 3),      # ragged query slices
-                                                      ("xml_video_only_h256", 4, 40, 4)])          # an empty slice
+                                                      ("xml_video_only_h256", 4, 40, 4),           # an empty slice
+                                                      # the first real 8-GPU run, rehearsed: 10 videos over 8 ranks (shards of
+                                                      # 2, 2, 1, 1, ...), 7 queries (rank 7 owns none), top-5 videos (most
+                                                      # ranks own none of a query's global top-k)
+                                                      ("xml_video_sub_cross_h128", 5, 60, 8)])
 def test_sharded_equals_single_gloo(name, kvid, nbefore, world):
     ctx = mp.get_context("spawn")
     ret = ctx.Queue()
@@ -128,9 +132,42 @@ def test_sharded_equals_single_gloo(name, kvid, nbefore, world):
     for p in procs:
         p.start()
     for p in procs:
-        p.join(180)
+        p.join(300)
         assert p.exitcode == 0
     assert ret.get(timeout=5) is True
+
+
+def _empty_shard_worker(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from tvretrieval_amd import dist as xd
+    from tvretrieval_amd import inference as inf
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n = 0 if rank == 1 else 3           # rank 1 holds an EMPTY shard
+        index = inf.CorpusIndex(["video"], {"video": torch.zeros(n, 16, 8)}, {"video": torch.zeros(n, 16, 8)},
+                                {"video": torch.ones(n, 16)}, 16, video_offset=3 * rank if rank < 1 else 3, n_total=6)
+        try:
+            xd.check_shards(index)
+            ret[rank] = "no error"
+        except ValueError as e:
+            ret[rank] = str(e)
+        dist.barrier()                      # both ranks get here: nobody is left waiting in a collective
+    finally:
+        dist.destroy_process_group()
+
+
+def test_empty_shard_raises_on_every_rank():
+    """An empty corpus shard is a configuration error that must FAIL the job, not hang it: the check is collective, so the
+    rank with videos raises too instead of walking into the next exchange alone."""
+    world = 3
+    port = _free_port()
+    ret = mp.Manager().dict()
+    mp.spawn(_empty_shard_worker, args=(world, port, ret), nprocs=world, join=True)
+    for r in range(world):
+        assert "rank(s) [1] hold an empty corpus shard" in ret[r], dict(ret)
 
 
 def test_shard_range():

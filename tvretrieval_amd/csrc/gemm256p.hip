@@ -30,6 +30,22 @@
 #include "common.h"
 #include "internal.h"
 
+// LayerNorm-epilogue exchange: per-row partials published and read with agent-scope accesses (on gfx950 the sc1 form of
+// the instruction: past the per-XCD L2, coherent across the 8 XCDs of the device)
+__device__ __forceinline__ void ln_publish(float* pp, float s, float m2) {
+  __hip_atomic_store(pp, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(pp + 1, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+typedef float xml_ln_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ xml_ln_f4 ln_read4(const float* pp) {
+  xml_ln_f4 v;
+  v.x = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.y = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.z = __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  v.w = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
 struct G256pArgs {
   const void* A;
   const void* W;
@@ -451,7 +467,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
             c2 += __shfl_xor(c2, 32, 64);
             if (fg_e == 0 && rok) {
               float* pp = a.ln_part + ((m * (2 * a.tn)) + nt * 2 + wn) * 2;
-              pp[0] = s; pp[1] = c2;
+              ln_publish(pp, s, c2);
             }
           }
           // Stores in FULL 128-byte lines.  Written as they lie, groups (q, fg = 0..3) of a row are 64 contiguous bytes: every
@@ -561,7 +577,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
             const float seg_m2 = lane16_sum_dpp(q8);
             if ((lane_e & 15) == 0) {
               float* pp = a.ln_part + ((m * (2 * a.tn)) + nt * 2 + wn) * 2;
-              pp[0] = seg_sum; pp[1] = seg_m2;
+              ln_publish(pp, seg_sum, seg_m2);
             }
           }
           if (F32O) {
@@ -578,16 +594,24 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       { const unsigned long long t = G256P_T(); pr[2] += t - pt; pt = t; }
       if constexpr (LNE) {
         // ---- publish, wait for the row block's other column tiles, normalise in place -------------------------------
-        // The partners share this XCD's L2 (tile walk above): stores are write-through, so "my stores are acknowledged"
-        // (vmcnt(0)) means they are in that L2; the counter lives there too (agent-scope atomics), and nobody has these
-        // lines in an L1 (first touch).  A device-scope fence here would write back and invalidate the whole L2 per tile
-        // (release / acquire at agent scope span the 8 XCDs) -- measured: it doubled the kernel's time.
+        // The exchange does NOT depend on which XCD a partner runs on: the partials are published and read with
+        // agent-scope (device-coherent) accesses (ln_publish / ln_read4: they go past the per-XCD L2 to the memory side, a
+        // few hundred bytes per tile), the counter is an agent-scope atomic, and "my stores are acknowledged" (vmcnt(0))
+        // orders the two.  The tile walk above still puts partners on ONE XCD in the same round -- that is speed (they finish
+        // together), not correctness.  A device-scope FENCE here would write back and invalidate the whole L2 per tile --
+        // measured: it doubled the kernel's time; coherent accesses to the partials alone cost nothing measurable.
+        // The wait is bounded: if the partners cannot get onto the chip (CUs held by another process that is itself waiting,
+        // a CU mask smaller than the grid), the kernel traps after ~4 s instead of hanging the device or normalising with
+        // missing statistics -- the runtime reports the fault to the caller.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (tid == 0) {
           __hip_atomic_fetch_add(a.ln_count + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          while (__hip_atomic_load(a.ln_count + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.tn)
+          const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+          while (__hip_atomic_load(a.ln_count + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.tn) {
             __builtin_amdgcn_s_sleep(1);
+            if (__builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) __builtin_trap();
+          }
         }
         __builtin_amdgcn_s_barrier();
         {   // lane l: statistics of row wm * 64 + l of the tile, combined from the 2 tn segment partials in fixed order
@@ -597,10 +621,10 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
             // all partials of the row in one batch of 16-byte loads (tn <= 4: at most 16 floats), then the arithmetic --
             // a load -> use loop would pay one memory round trip per iteration (hipcc waits vmcnt(0) at every use here)
             typedef float xml_f4 __attribute__((ext_vector_type(4)));
-            const xml_f4* pp = reinterpret_cast<const xml_f4*>(a.ln_part + m * (2 * a.tn) * 2);
+            const float* pp = a.ln_part + m * (2 * a.tn) * 2;
             xml_f4 pv[4];
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) pv[t4] = t4 < a.tn ? __builtin_nontemporal_load(pp + t4) : xml_f4{0.f, 0.f, 0.f, 0.f};
+            for (int t4 = 0; t4 < 4; ++t4) pv[t4] = t4 < a.tn ? ln_read4(pp + 4 * t4) : xml_f4{0.f, 0.f, 0.f, 0.f};
             float tot = 0.f;
 #pragma unroll
             for (int t4 = 0; t4 < 4; ++t4) tot += pv[t4].x + pv[t4].z;
@@ -793,8 +817,26 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
 // ---- GEMM with the LayerNorm in its epilogue --------------------------------------------------------------------
 // Eligible when the rows span whole 256-column tiles (N % 256 == 0, at most 4 of them) and there is enough work for the
 // persistent kernel; the callers fall back to GEMM (f32 out) + LayerNorm otherwise.
+// The fused kernel's workgroups wait for each other: it runs only where all 256 of them fit at once -- a device with at
+// least 256 CUs visible to this process (MI355X unpartitioned; a CPX / partitioned device or a CU mask reports fewer and
+// takes the three-launch path).
+static bool ln_fusion_device_ok() {
+  static std::atomic<int> cached[64];                  // 0 unknown, 1 ok, 2 not ok  (per device)
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  int c = cached[dev].load(std::memory_order_relaxed);
+  if (c == 0) {
+    int cus = 0;
+    const bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256;
+    c = ok ? 1 : 2;
+    cached[dev].store(c, std::memory_order_relaxed);
+  }
+  return c == 1;
+}
+
 bool xmli_gemm_ln_eligible(int64_t M, int N, int K, int dt) {
   const size_t kb = (size_t)K * dt_size(dt);
+  if (!ln_fusion_device_ok()) return false;
   return kb % 128 == 0 && kb >= 256 && N % 256 == 0 && N / 256 <= 4 && (int64_t)cdiv(M, 256) * (N / 256) >= 768;
 }
 size_t xmli_gemm_ln_workspace_bytes(int64_t M, int N) {

@@ -116,6 +116,27 @@ def _exchange_by_owner(buf, group, world, per):
     return cand[0].reshape(per, world * c).view(torch.float32), cand[1].reshape(per, world * c)
 
 
+def check_shards(index, group=None):
+    """Collective validation of the shard layout, once per index: every rank learns every rank's shard size, and an empty
+    shard raises on ALL ranks.  (Raised only where the shard is empty, the error would leave the other ranks waiting in
+    the next collective: a hang instead of a failure.)"""
+    if getattr(index, "_shards_checked", False):
+        return
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if _trivial(world):
+        sizes = [index.n_videos]
+    else:
+        mine = torch.tensor([index.n_videos], dtype=torch.int64, device=index.device)
+        allv = torch.empty((world,), dtype=torch.int64, device=index.device)
+        _all_gather_into_tensor(allv, mine, group)
+        sizes = [int(x) for x in allv.cpu().tolist()]
+    index._shards_checked = True
+    empty = [r for r, n in enumerate(sizes) if n == 0]
+    if empty:
+        raise ValueError("rank(s) %s hold an empty corpus shard (n_total=%d over %d ranks): use fewer ranks"
+                         % (empty, index.n_total, world))
+
+
 def replicate_rerank_features(index, group=None):
     """One-off, after the shard is encoded: all-gather the ConvSE-side context features (feat2) and clip masks of
     every shard into corpus-wide copies index.feat2_all[m] (n_total, lpad, H) / index.mask_all[m] (n_total, lpad).
@@ -124,6 +145,7 @@ def replicate_rerank_features(index, group=None):
     broadcast of the global top-k disappear.  Costs n_total*lpad*H*2 B per modality and GPU (4.3 GB at TVR scale,
     of 288 GB)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
+    check_shards(index, group)
     if _trivial(world):
         index.feat2_all, index.mask_all = index.feat2, index.mask
         return index
@@ -358,9 +380,7 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
         # (replicate_rerank_features) and the single-GPU pass take n_out up to 1024 (xml_moment_topk)
         raise ValueError("sharded rerank merges moment lists of at most 256 entries; max_before_nms=%d needs the owner "
                          "rerank (call replicate_rerank_features(index) first)" % max_before_nms)
-    if index.n_videos == 0:
-        raise ValueError("rank %d holds an empty corpus shard (n_total=%d over %d ranks): use fewer ranks"
-                         % (rank, index.n_total, world))
+    check_shards(index, group)      # collective on the first pass over an index: an empty shard raises on EVERY rank
     if not trivial and owner_rerank:
         top_w, top_gid, fs, fi, owned, q2c = _owner_pass(model, index, qvec, ex, k, max_before_nms, q2c_alpha,
                                                           min_pred_l, max_pred_l, ops, n_chunks)

@@ -132,7 +132,7 @@ def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search, search_
     g = lambda d, m: d[m] if m in d else None          # noqa: E731
     k_vid = min(100, nv_s)
 
-    def run():
+    def run(f1=f1, f2=f2, mk=mk):
         with torch.no_grad():
             q2c, st, ed = om.get_pred_from_raw_query(q, qmask, g(f1, "video"), g(f2, "video"), g(mk, "video"),
                                                      g(f1, "sub"), g(f2, "sub"), g(mk, "sub"), cross=True)
@@ -153,7 +153,6 @@ def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search, search_
                                               qps_sample, n_total))
     # the same sample through the HIP path (compute dtype of the run) vs the fp32 oracle lists
     ll = index.l_ref * index.l_ref
-    wi = want["top_indices"].numpy()
 
     def triples(flat, vids):     # moments as (video, st, ed): decode the flat index through each side's own video list
         flat = np.asarray(flat).astype(np.int64)
@@ -162,8 +161,8 @@ def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search, search_
         v = np.take_along_axis(np.asarray(vids).astype(np.int64), r, 1)
         return np.where(ok, v * ll + flat % ll, -1)
 
-    def agreement(got):
-        gi = got["top_indices"].cpu().numpy()
+    def agreement(got, want, q2c_ref):
+        gi, wi = got["top_indices"].cpu().numpy(), want["top_indices"].numpy()
         agree = dict(videos=list_overlap(gi, wi))
         if got.get("q2c") is not None:
             agree["q2c_max_abs_err"] = float((got["q2c"].cpu() - q2c_ref).abs().max())
@@ -173,15 +172,23 @@ def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search, search_
         return agree
     got = search(nq_s, nv_s)
     if got is not None:
-        res["hip_vs_oracle_on_sample"] = agreement(got)
+        res["hip_vs_oracle_on_sample"] = agreement(got, want, q2c_ref)
         res["hip_vs_oracle_note"] = "share of the oracle's (fp32) top-k found in the %s HIP path's top-k, same %d x %d " \
                                     "slice" % (dtype_name, nq_s, nv_s)
     if search_exact is not None:
-        got = search_exact(nq_s, nv_s)
-        res["exact_rank_vs_oracle_on_sample"] = agreement(got)
+        # exact-rank mode on the same slice: its corpus is encoded in f32, so the oracle is re-run on THOSE features (the
+        # headline's oracle above consumed the bf16-encoded index)
+        got, sub = search_exact(nq_s, nv_s)
+        xf1 = {m: sub.exact.feat1n_f32[m][:, :index.l_ref].cpu() for m in mods}
+        xf2 = {m: sub.feat2[m][:, :index.l_ref].float().cpu() for m in mods}
+        q2c_x, want_x = run(xf1, xf2, {m: sub.mask[m][:, :index.l_ref].cpu() for m in mods})
+        res["exact_rank_vs_oracle_on_sample"] = agreement(got, want_x, q2c_x)
         res["exact_rank_vs_oracle_on_sample"]["fell_back"] = got["exact"]["n_fail"]
+        cand = torch.gather(q2c_x, 1, got["exact"]["cand_indices"].cpu().long())
+        res["exact_rank_vs_oracle_on_sample"]["rescored_max_abs_err"] = float((got["exact"]["cand_scores"].cpu() - cand).abs().max())
         res["exact_rank_note"] = "same slice through the exact-rank mode (f32 model, bf16 K6 as a filter + f32 re-score + " \
-                                 "certificate): the oracle's lists up to ties at f32 rounding"
+                                 "certificate) against the oracle on the f32-encoded features: the oracle's lists up to ties " \
+                                 "at f32 rounding"
     return res
 
 
@@ -558,7 +565,7 @@ def run(args, backend_factory=None, emit=True):
                         sub = inf.build_corpus_index(m32, context_batches(0, nv_s, l, dv, ds, m32.use_video, m32.use_sub,
                                                                           device, lens), ops=ops, l_ref=l,
                                                      exact_filter=True)
-                        return inf.vcmr_search(m32, sub, qf[:nq_s].contiguous(), qm[:nq_s].contiguous(), ops=ops)
+                        return inf.vcmr_search(m32, sub, qf[:nq_s].contiguous(), qm[:nq_s].contiguous(), ops=ops), sub
             res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname, search, search_exact)
         else:
             res["cpu_baseline"] = None

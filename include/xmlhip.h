@@ -333,10 +333,14 @@ int xml_attn_softmax(const float* S, const float* dP, const float* q_mask, const
 /* Weight-gradient GEMM from the row-major operands: out (N, K) f32 = A^T B = sum_r A[r][n] B[r][k], A (rows, N), B (rows, K)
  * bf16, N and K multiples of 8 (xml_gemm_tn_supported; callers keep the transpose + xml_gemm_batched path otherwise).
  * Row ranges are combined with f32 atomics: the summation order, hence the last bits, vary from run to run (as with
- * xml_gemm_batched's split-K). */
+ * xml_gemm_batched's split-K).  colsum_a (N) f32 or NULL: column sums of A from the same launch (a layer's bias gradient).
+ * accumulate == 0: out / colsum_a are overwritten.  accumulate != 0: out += A^T B, colsum_a += column sums -- the outputs are
+ * gradient buffers that already hold a partial sum (the optimizer's flat .grad buffer, zeroed once per step), no fill.
+ * The f32 adds are hardware atomics: out / colsum_a must live in ordinary (coarse-grained) device memory -- on
+ * fine-grained or host-coherent allocations the hardware add is silently dropped. */
 int xml_gemm_tn_supported(int64_t rows, int N, int K, int dt);
 int xml_gemm_tn(const void* A, const void* B, float* out, float* colsum_a, int64_t rows, int N, int K, int dt,
-                xml_stream_t stream);      /* colsum_a (N) f32 or NULL: = sum_r A[r][n] (the layer's bias gradient), same launch */
+                int accumulate, xml_stream_t stream);      /* colsum_a (N) f32 or NULL: = sum_r A[r][n] (the layer's bias gradient), same launch */
 /* Fused training attention (bf16 storage; xml/model_components.py:266-303 incl. the probabilities dropout :297), one
  * launch each way instead of the split_heads / batched GEMM / xml_attn_softmax / xml_dropout / merge_heads chain:
  *   fwd   out (n, lq, ldo) head h columns [h dh, (h+1) dh)  =  dropout(softmax(Q K^T / sqrt(dh) + mask bias)) V

@@ -237,6 +237,13 @@ def _reducer_worker(rank, world, port, ret):
             want = sum(torch.randn(offs[-1], generator=torch.Generator().manual_seed(7 + 10 * step + r))
                        for r in range(world)) / world
             ok = ok and torch.allclose(o.flat_g, want, rtol=0, atol=1e-6)
+        # a gradient arriving for a bucket that was already reduced in this step (a second backward before step()) must fail
+        # loudly: it would otherwise add local gradients on top of the averaged ones and the ranks would diverge
+        try:
+            red.grad_ready(0)
+            ok = False
+        except RuntimeError:
+            pass
         ret[rank] = bool(ok)
     finally:
         dist.destroy_process_group()

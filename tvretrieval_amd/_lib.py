@@ -114,7 +114,7 @@ SIGNATURES = {
     "xml_q2c_tile_rows_l2norm_ok": (c_int, [c_int, c_int]),
     "xml_q2c_tile_rows_l2norm": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "xml_gemm_tn_supported": (c_int, [c_int64, c_int, c_int, c_int]),
-    "xml_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "xml_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "xml_attention_train_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "xml_attention_train_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                         c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64, c_int, c_void_p]),

@@ -32,6 +32,53 @@ def _packed(w, dtype):
     return w.contiguous() if dtype == F32 else ops.pack_weights(w.float().contiguous(), dtype)
 
 
+# ---- gradient sinks ---------------------------------------------------------------------------------------------------
+# BertAdam lays every parameter's .grad into ONE flat f32 buffer that it zeroes once per step (train.BertAdam._flatten) and
+# registers a GradSink on the parameter.  A backward node whose kernels ACCUMULATE (f32 atomics: the weight-gradient GEMM,
+# LayerNorm / pooling parameter gradients, column sums) then adds straight into that view and returns None for the
+# parameter instead of a fresh tensor -- autograd's AccumulateGrad would otherwise run `p.grad += dW` per parameter (96
+# elementwise launches per step at the C5 shape) on top of the 70 fills of the temporaries.  The sink tells the optimizer
+# that the gradient is there (what the post-accumulate hook does on the ordinary path: "has ever received a gradient",
+# data-parallel bucket bookkeeping).
+USE_GRAD_SINKS = True          # tests / A-B runs: False = every node returns its gradients to autograd
+
+
+class GradSink(object):
+    def __init__(self, opt, index, offset):
+        self.opt, self.index, self.offset = opt, index, offset      # offset in elements into opt.flat_g / opt.flat_p
+
+
+def _sink(p):
+    """p's persistent .grad view inside the optimizer's flat buffer, or None (no optimizer, view replaced, sinks off)."""
+    if not USE_GRAD_SINKS or p is None:
+        return None
+    reg = getattr(p, "_xml_sink", None)
+    g = p.grad
+    if reg is None or g is None or g.dtype != F32 or g.data_ptr() != reg.opt.flat_g.data_ptr() + 4 * reg.offset:
+        return None
+    return g
+
+
+def _sunk(*params):
+    for p in params:
+        if p is not None:
+            p._xml_sink.opt._touch(p._xml_sink.index)
+
+
+def _adjacent(params, flat_attr):
+    """The parameters' slices of the optimizer's flat buffer as ONE tensor if they lie back to back in the given order
+    (e.g. query / key / value weights of a layer within one parameter group), else None."""
+    regs = [getattr(p, "_xml_sink", None) for p in params]
+    if any(r is None for r in regs) or any(r.opt is not regs[0].opt for r in regs):
+        return None
+    off = regs[0].offset
+    for p, r in zip(params, regs):
+        if r.offset != off:
+            return None
+        off += p.numel()
+    return getattr(regs[0].opt, flat_attr)[regs[0].offset:off]
+
+
 class LinearFn(torch.autograd.Function):
     """y = [relu](x W^T + b); x (..., K) compute dtype, W (N, K) / b (N) f32 masters."""
 
@@ -41,6 +88,7 @@ class LinearFn(torch.autograd.Function):
         y = ops.linear(x.contiguous(), w, None if bias is None else bias.detach().float().contiguous(), relu=relu)
         ctx.relu = relu
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -62,6 +110,13 @@ class LinearFn(torch.autograd.Function):
                 a[:, :n] = dy2
             dx = ops.linear(a, wt).view(x.shape)                                   # dX = dY W
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
+        weight, bias = ctx.params
+        gw = _sink(weight) if ctx.needs_input_grad[1] else None
+        gb = _sink(bias) if want_db else None
+        if gw is not None and (gb is not None or not want_db) and \
+                T.gemm_tn(dy2, x2, out=gw, colsum_out=gb):                         # straight into the flat .grad buffer
+            _sunk(weight, bias if want_db else None)
+            return dx, None, None, None
         if ctx.needs_input_grad[1]:
             dw = T.gemm_tn(dy2, x2, colsum=want_db)                               # dW = dY^T X (+ db = column sums of dY)
             if dw is not None and want_db:
@@ -98,6 +153,7 @@ class LayerNormFn(torch.autograd.Function):
         a = a.contiguous()
         b = None if b is None else b.contiguous()
         y = ops.add_layernorm(a, b, gf, bf, out_dtype=out_dtype)
+        ctx.params = (g, beta)
         ctx.save_for_backward(a, b, gf)
         return y
 
@@ -105,7 +161,14 @@ class LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         a, b, g = ctx.saved_tensors
         need_dx = ctx.needs_input_grad[0] or (b is not None and ctx.needs_input_grad[1])
-        dx, dg, dbeta = T.layernorm_bwd(a, b, g, dy.contiguous(), need_dx=need_dx)
+        pg, pbeta = ctx.params
+        sg, sb = _sink(pg), _sink(pbeta)
+        sunk = sg is not None and sb is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+        dx, dg, dbeta = T.layernorm_bwd(a, b, g, dy.contiguous(), need_dx=need_dx, dg=sg.view(-1) if sunk else None,
+                                        dbeta=sb.view(-1) if sunk else None)
+        if sunk:
+            _sunk(pg, pbeta)
+            dg = dbeta = None
         da = db = None
         if ctx.needs_input_grad[0]:
             da = dx if dx.dtype == a.dtype else ops.convert(dx, a.dtype)
@@ -181,8 +244,12 @@ class QkvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv):
-        w = _packed(torch.cat([wq.detach(), wk.detach(), wv.detach()], 0), x.dtype)
-        b = torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
+        # the three weights (and biases) usually lie back to back in the optimizer's flat parameter buffer: one view, no cat
+        wf, bf = _adjacent((wq, wk, wv), "flat_p"), _adjacent((bq, bk, bv), "flat_p")
+        wcat = wf.view(3 * wq.shape[0], wq.shape[1]) if wf is not None else torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
+        w = _packed(wcat, x.dtype)
+        b = bf.detach() if bf is not None else torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
+        ctx.params = (wq, bq, wk, bk, wv, bv)
         ctx.save_for_backward(x, w)
         return ops.linear(x.contiguous(), w, b)
 
@@ -195,6 +262,12 @@ class QkvFn(torch.autograd.Function):
         rows = x.numel() // k
         dy2, x2 = dy.view(rows, n3), x.contiguous().view(rows, k)
         dx = ops.linear(dy2, T.transpose(w)).view(x.shape) if ctx.needs_input_grad[0] else None
+        wq, bq, wk, bk, wv, bv = ctx.params
+        if all(_sink(p) is not None for p in ctx.params) and all(ctx.needs_input_grad[1:]):
+            gw, gb = _adjacent((wq, wk, wv), "flat_g"), _adjacent((bq, bk, bv), "flat_g")
+            if gw is not None and gb is not None and T.gemm_tn(dy2, x2, out=gw, colsum_out=gb):
+                _sunk(*ctx.params)                                                         # six gradients, one launch, no adds
+                return dx, None, None, None, None, None, None
         dw = T.gemm_tn(dy2, x2, colsum=True)                                               # (3H, H) and the three bias gradients
         if dw is None:
             r8 = _r8(rows)
@@ -270,13 +343,19 @@ class ModularPoolFn(torch.autograd.Function):
         wmf = wm.detach().float().contiguous()
         enc = enc.contiguous()
         out = ops.modular_pool(enc, mask, wmf)
+        ctx.params = (wm,)
         ctx.save_for_backward(enc, mask, wmf)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         enc, mask, wmf = ctx.saved_tensors
-        denc, dwm = T.modular_pool_bwd(enc, mask, wmf, dout.contiguous())
+        wm, = ctx.params
+        sw = _sink(wm) if ctx.needs_input_grad[2] else None
+        denc, dwm = T.modular_pool_bwd(enc, mask, wmf, dout.contiguous(), dwm=sw)
+        if sw is not None:
+            _sunk(wm)
+            dwm = None
         return denc, None, dwm
 
 

@@ -23,7 +23,7 @@ __device__ __forceinline__ uint2 tn_read_tr16(const char* p) {
 // workgroups of the first k tile load anyway (one launch and one pass over dY less per layer).
 __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       float* __restrict__ out, float* __restrict__ colsum, int rows, int N,
-                                                      int K, int rows_per_split) {
+                                                      int K, int rows_per_split, int accumulate) {
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * 32 * TN_STRIDE];      // [buffer][operand][32 rows]
   __shared__ float s_cs[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256, 3) void gemm_tn_kernel(const bf16_t* __restric
     __syncthreads();
     if (tid < 128 && n0 + tid < N) unsafeAtomicAdd(colsum + n0 + tid, s_cs[tid]);
   }
-  const bool split = gridDim.z > 1;
+  const bool split = gridDim.z > 1 || accumulate;      // accumulate: out already holds a partial sum (a .grad buffer)
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -152,7 +152,7 @@ extern "C" int xml_gemm_tn_supported(int64_t rows, int N, int K, int dt) {
 }
 
 extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, float* colsum_a, int64_t rows, int N, int K, int dt,
-                           xml_stream_t stream) {
+                           int accumulate, xml_stream_t stream) {
   XML_ENTER();
   if (!A || !B || !out || rows <= 0 || rows > 0x7fffffff || N <= 0 || K <= 0) return XML_ERR_BAD_ARG;
   if (!xml_gemm_tn_supported(rows, N, K, dt)) return XML_ERR_UNSUPPORTED;
@@ -169,14 +169,16 @@ extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, float* cols
   int rps = (cdiv(rows, splits) + 31) / 32 * 32;               // rows per workgroup, whole 32-row slabs
   if (rps < 256) rps = 256;
   splits = cdiv(rows, rps);
-  if (splits > 1 && colsum_a == out + (size_t)N * K) {          // caller laid them out back to back: one fill
+  if (accumulate) {
+    // out / colsum_a are gradient buffers that already hold a (possibly zero) partial sum: every contribution is an atomic add
+  } else if (splits > 1 && colsum_a == out + (size_t)N * K) {   // caller laid them out back to back: one fill
     if (hipMemsetAsync(out, 0, ((size_t)N * K + N) * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
   } else {
     if (splits > 1 && hipMemsetAsync(out, 0, (size_t)N * K * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
     if (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)N * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(K, 128), cdiv(N, 128), splits), dim3(256), 0, st, (const bf16_t*)A,
-                     (const bf16_t*)B, out, colsum_a, (int)rows, N, K, rps);
+                     (const bf16_t*)B, out, colsum_a, (int)rows, N, K, rps, accumulate ? 1 : 0);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

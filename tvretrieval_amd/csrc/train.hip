@@ -920,6 +920,67 @@ __global__ __launch_bounds__(256) void q2c_scores_bwd_kernel(const T* __restrict
   }
 }
 
+// The same with 16-byte loads: one WAVE per (query, video) pair that carries a gradient; the lanes split the hidden
+// dimension in 8-element chunks (a clip row is one coalesced read) and every clip costs one wave reduction, four clips in
+// flight.  The scalar kernel above put one clip per lane -- 64 rows walked element by element, 2 bytes per load -- and took
+// 217 us for the 3 N pairs of a 128-video batch; this one takes a few.  hidden % 8 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void q2c_scores_bwd_vec_kernel(const T* __restrict__ qn, const T* __restrict__ cn,
+                                                                 const float* __restrict__ mask,
+                                                                 const float* __restrict__ dscores, int ld_ds, float scale,
+                                                                 float* __restrict__ dqn, float* __restrict__ dcn, int nq,
+                                                                 int nv, int L, int hidden) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.y * 4 + (threadIdx.x >> 6);
+  const int n = blockIdx.x;
+  if (m >= nq) return;
+  const float g = dscores[(int64_t)m * ld_ds + n] * scale;
+  if (g == 0.f) return;
+  const T* q = qn + (int64_t)m * hidden;
+  const T* cbase = cn + (int64_t)n * L * hidden;
+  const int chunks = hidden >> 3;
+  float best = -INFINITY;
+  int best_l = 0;
+  for (int l0 = 0; l0 < L; l0 += 4) {
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = lane; c < chunks; c += 64) {
+      float qv[8];
+      ld8<T>(q + c * 8, qv);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = min(l0 + u, L - 1);
+        float cv[8];
+        ld8<T>(cbase + (int64_t)l * hidden + c * 8, cv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[u] += qv[e] * cv[e];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int l = l0 + u;
+      float v = wave_sum(s[u]);
+      if (l < L) {
+        const float mk = mask[(int64_t)n * L + l];
+        v = v * mk + (1.f - mk) * -1e10f;
+        if (v > best) { best = v; best_l = l; }          // first clip on ties
+      }
+    }
+  }
+  const float gm = g * mask[(int64_t)n * L + best_l];
+  if (gm == 0.f) return;
+  const T* c = cbase + (int64_t)best_l * hidden;
+  for (int ch = lane; ch < chunks; ch += 64) {
+    float qv[8], cv[8];
+    ld8<T>(q + ch * 8, qv);
+    ld8<T>(c + ch * 8, cv);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      unsafeAtomicAdd(dqn + (int64_t)m * hidden + ch * 8 + e, gm * cv[e]);
+      unsafeAtomicAdd(dcn + ((int64_t)n * L + best_l) * hidden + ch * 8 + e, gm * qv[e]);
+    }
+  }
+}
+
 extern "C" int xml_q2c_scores_bwd(const void* qn, const void* cn, const float* mask, const float* dscores, int64_t ld_ds,
                                   float scale, float* dqn, float* dcn, int nq, int nv, int l, int hidden, int dt,
                                   xml_stream_t stream) {
@@ -929,6 +990,14 @@ extern "C" int xml_q2c_scores_bwd(const void* qn, const void* cn, const float* m
   if (hipMemsetAsync(dqn, 0, (size_t)nq * hidden * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
   if (hipMemsetAsync(dcn, 0, (size_t)nv * l * hidden * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
   dim3 grid(nv, cdiv(nq, 4));
+  if (hidden % 8 == 0 && (dt == XML_F32 || dt == XML_BF16)) {
+    if (dt == XML_F32)
+      hipLaunchKernelGGL(q2c_scores_bwd_vec_kernel<float>, grid, dim3(256), 0, st, (const float*)qn, (const float*)cn, mask, dscores, (int)ld_ds, scale, dqn, dcn, nq, nv, l, hidden);
+    else
+      hipLaunchKernelGGL(q2c_scores_bwd_vec_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)qn, (const bf16_t*)cn, mask, dscores, (int)ld_ds, scale, dqn, dcn, nq, nv, l, hidden);
+    XML_CHECK_LAUNCH();
+    return XML_OK;
+  }
   if (dt == XML_F32)
     hipLaunchKernelGGL(q2c_scores_bwd_kernel<float>, grid, dim3(256), 0, st, (const float*)qn, (const float*)cn, mask, dscores, (int)ld_ds, scale, dqn, dcn, nq, nv, l, hidden);
   else if (dt == XML_BF16)
@@ -971,6 +1040,49 @@ __global__ __launch_bounds__(256) void pair_sim_bwd_kernel(const T* __restrict__
   }
 }
 
+// 16-byte version: one workgroup per batch row, its four waves take the clips l = w, w + 4, ...; lanes hold 8-element
+// chunks of the hidden dimension; four clips in flight per wave; dq is combined across the waves in LDS.  (The kernel above
+// walks the L clips one after the other per thread: 122 us per call at L = 100, 128 workgroups.)  hidden % 8 == 0, <= 2048.
+template <typename T>
+__global__ __launch_bounds__(256) void pair_sim_bwd_vec_kernel(const T* __restrict__ q, const T* __restrict__ f2,
+                                                               const float* __restrict__ dsim, T* __restrict__ dq,
+                                                               T* __restrict__ df2, int L, int hidden) {
+  __shared__ float s_acc[4][2048];
+  const int64_t b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int chunks = hidden >> 3;
+  for (int c0 = 0; c0 < chunks; c0 += 64) {
+    const int c = c0 + lane;
+    const bool ok = c < chunks;
+    const int cc = ok ? c : 0;
+    float qv[8], acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    ld8<T>(q + b * hidden + cc * 8, qv);
+    for (int l0 = wave; l0 < L; l0 += 16) {
+      float fv[4][8], g[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = min(l0 + 4 * u, L - 1);
+        g[u] = (l0 + 4 * u < L) ? dsim[b * L + l] : 0.f;
+        ld8<T>(f2 + (b * L + l) * hidden + cc * 8, fv[u]);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int l = l0 + 4 * u;
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { acc[e] += g[u] * fv[u][e]; o[e] = g[u] * qv[e]; }
+        if (ok && l < L) st8<T>(df2 + (b * L + l) * hidden + c * 8, o);
+      }
+    }
+    if (ok)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s_acc[wave][c * 8 + e] = acc[e];
+  }
+  __syncthreads();
+  for (int h = threadIdx.x; h < hidden; h += 256)
+    DT<T>::st(dq + b * hidden + h, (s_acc[0][h] + s_acc[1][h]) + (s_acc[2][h] + s_acc[3][h]));
+}
+
 extern "C" int xml_pair_sim(const void* q, const void* f2, float* sim, int64_t n, int l, int hidden, int dt,
                             xml_stream_t stream) {
   XML_ENTER();
@@ -988,6 +1100,14 @@ extern "C" int xml_pair_sim_bwd(const void* q, const void* f2, const float* dsim
                                 int hidden, int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!q || !f2 || !dsim || !dq || !df2 || n <= 0 || l <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (hidden % 8 == 0 && hidden <= 2048 && (dt == XML_F32 || dt == XML_BF16)) {
+    if (dt == XML_F32)
+      hipLaunchKernelGGL(pair_sim_bwd_vec_kernel<float>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)f2, dsim, (float*)dq, (float*)df2, l, hidden);
+    else
+      hipLaunchKernelGGL(pair_sim_bwd_vec_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)q, (const bf16_t*)f2, dsim, (bf16_t*)dq, (bf16_t*)df2, l, hidden);
+    XML_CHECK_LAUNCH();
+    return XML_OK;
+  }
   if (dt == XML_F32)
     hipLaunchKernelGGL(pair_sim_bwd_kernel<float>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const float*)q, (const float*)f2, dsim, (float*)dq, (float*)df2, l, hidden);
   else if (dt == XML_BF16)

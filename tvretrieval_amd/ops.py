@@ -40,8 +40,14 @@ def _p(t):
     return None if t is None else ctypes.c_void_p(t.data_ptr())
 
 
+_raw_stream = torch._C._cuda_getCurrentRawStream      # (device index) -> hipStream_t as int; ~0.3 us
+_cur_device = torch._C._cuda_getDevice
+
+
 def _stream():
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """The current HIP stream of the current device as a void*.  (torch.cuda.current_stream() builds a Stream object through
+    three Python layers -- ~10 us per call, 90 calls per training step: 0.9 ms of a 6 ms step was spent asking for it.)"""
+    return ctypes.c_void_p(_raw_stream(_cur_device()))
 
 
 _ws_cache = {}
@@ -49,7 +55,7 @@ _ws_cache = {}
 
 def _workspace(nbytes, device):
     """Grow-only scratch buffer per (device, stream).  The C ABI never allocates."""
-    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    key = (device.index, _raw_stream(device.index if device.index is not None else _cur_device()))
     buf = _ws_cache.get(key)
     nbytes = max(int(nbytes), 256)
     if buf is None or buf.numel() < nbytes:

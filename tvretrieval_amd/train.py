@@ -40,11 +40,19 @@ class _PosTableFn(torch.autograd.Function):
         rows = rows if dtype == F32 else ops.pack_weights(rows.float(), dtype)
         ctx.shape = tuple(weight.shape)
         ctx.n, ctx.seq_len = n, seq_len
+        ctx.params = (weight,)
         return rows.unsqueeze(0).expand(n, seq_len, rows.shape[1]).contiguous()
 
     @staticmethod
     def backward(ctx, dy):
+        from .autograd import _sink, _sunk
         hidden = ctx.shape[1]
+        weight, = ctx.params
+        sw = _sink(weight)
+        if sw is not None:          # column sums accumulated straight into the flat .grad buffer
+            T.colsum(dy.contiguous(), ctx.n, ctx.seq_len * hidden, out=sw.view(-1)[:ctx.seq_len * hidden])
+            _sunk(weight)
+            return None, None, None, None
         dw = torch.zeros(ctx.shape, dtype=F32, device=dy.device)
         T.colsum(dy.contiguous(), ctx.n, ctx.seq_len * hidden, out=dw.view(-1)[:ctx.seq_len * hidden])
         return dw, None, None, None
@@ -298,8 +306,10 @@ class BertAdam(object):
         self.seg_steps = [0] * len(plist)
         self._active_key = None
         self._active_dev = None
-        for i, p in enumerate(plist):
+        from .autograd import GradSink
+        for i, (p, o) in enumerate(zip(plist, offs)):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touch(i))
+            p._xml_sink = GradSink(self, i, o)      # backward kernels may accumulate straight into p.grad (autograd.py)
 
     def _touch(self, i):
         self._touched[i] = True
@@ -378,9 +388,9 @@ class GradientReducer(object):
     has reported, the bucket's all-reduce(AVG) is issued on a side stream (ordered behind the backward kernels enqueued
     so far by an event) while backward keeps running on the main stream.  finish() -- called by allreduce_gradients()
     after loss.backward() -- reduces the buckets that never became complete (tensors without a gradient this step) and
-    makes the main stream wait for the side stream.  Every rank issues the same buckets in the same order: buckets are
-    flushed strictly in DESCENDING order (backward produces gradients roughly last-layer first), a complete bucket waits
-    for the buckets above it.
+    makes the main stream wait for the side stream.  Every rank issues the same buckets in the same order: a bucket is
+    flushed the moment it is complete, and every rank runs the same autograd graph, so completion order is the same on all
+    of them; the leftovers go in descending order.
     GPU ranks reduce through libxmlhip's xml_rccl_allreduce_avg_f32 on an ncclComm_t of their own; other devices (the
     gloo tests) through torch.distributed."""
 
@@ -409,11 +419,12 @@ class GradientReducer(object):
 
     def begin(self):
         self.count = [0] * len(self.buckets)
-        self.next_bucket = len(self.buckets) - 1      # descending flush order
+        self.reduced = [False] * len(self.buckets)
         self.works = []
 
     def _reduce(self, b):
         import torch.distributed as dist
+        self.reduced[b] = True
         lo, hi = self.buckets[b][:2]
         view = self.opt.flat_g[lo:hi]
         if self.cuda:
@@ -430,15 +441,23 @@ class GradientReducer(object):
 
     def grad_ready(self, seg):
         b = self.seg_bucket[seg]
+        if self.reduced[b]:
+            # a second backward() before step() (gradient accumulation) would add LOCAL gradients on top of the already
+            # averaged bucket, and finish() would have nothing left to reduce: the ranks would diverge silently
+            raise RuntimeError("GradientReducer: gradient for a bucket that was already all-reduced in this step -- run "
+                               "one backward per optimizer.zero_grad() (for gradient accumulation, detach the reducer and "
+                               "call allreduce_gradients() once after the last backward)")
         self.count[b] += 1
-        while self.next_bucket >= 0 and self.count[self.next_bucket] >= self.buckets[self.next_bucket][3]:
-            self._reduce(self.next_bucket)
-            self.next_bucket -= 1
+        if self.count[b] >= self.buckets[b][3]:
+            # flushed in COMPLETION order.  Every rank runs the same autograd graph, so the order is the same everywhere;
+            # (a fixed descending order made every bucket wait for the last one, which holds all biases and LayerNorm
+            # parameters -- the reference's [decay, no_decay] groups -- and completes only when backward ends)
+            self._reduce(b)
 
     def finish(self):
-        while self.next_bucket >= 0:
-            self._reduce(self.next_bucket)
-            self.next_bucket -= 1
+        for b in range(len(self.buckets) - 1, -1, -1):      # what never became complete (tensors without a gradient this step)
+            if not self.reduced[b]:
+                self._reduce(b)
         if self.cuda:
             torch.cuda.current_stream(self.opt.flat_g.device).wait_stream(self.side)
         for w, view in self.works:

@@ -56,13 +56,14 @@ def add_inplace(y, x):
     return y
 
 
-def layernorm_bwd(a, b, g, dy, need_dx=True):
-    """-> (dx or None, dg f32, dbeta f32) for y = LN(a [+ b]) * g + beta; a/b/dy (..., d)."""
+def layernorm_bwd(a, b, g, dy, need_dx=True, dg=None, dbeta=None):
+    """-> (dx or None, dg f32, dbeta f32) for y = LN(a [+ b]) * g + beta; a/b/dy (..., d).
+    dg / dbeta given: the kernel ACCUMULATES into them (gradient sinks); otherwise fresh zero-filled tensors."""
     _req(a, "a"); _req(g, "g", F32); _req(dy, "dy")
     d = a.shape[-1]
     rows = a.numel() // d
-    dg = torch.zeros(d, dtype=F32, device=a.device)
-    dbeta = torch.zeros(d, dtype=F32, device=a.device)
+    dg = torch.zeros(d, dtype=F32, device=a.device) if dg is None else _req(dg, "dg", F32)
+    dbeta = torch.zeros(d, dtype=F32, device=a.device) if dbeta is None else _req(dbeta, "dbeta", F32)
     wide = d > 1024 or d % 8 != 0
     dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (need_dx or not wide) else None
     ws = _workspace(rows * 16, a.device) if wide else None
@@ -116,18 +117,29 @@ def merge_heads(xh, n, l, heads, out=None, col0=0):
 DISABLE_GEMM_TN = False               # tests / A-B measurements: transposes + split-K NT GEMM for the weight gradients
 
 
-def gemm_tn(a, b, colsum=False):
+def gemm_tn(a, b, colsum=False, out=None, colsum_out=None):
     """a (rows, N), b (rows, K) -> a^T b (N, K) f32, or None when the shape / dtype is not served (caller falls back).
-    colsum=True: -> (a^T b, column sums of a (N,) f32) from the same launch (a layer's weight and bias gradients)."""
+    colsum=True: -> (a^T b, column sums of a (N,) f32) from the same launch (a layer's weight and bias gradients).
+    out (N, K) f32 [+ colsum_out (N,) f32]: ACCUMULATE into these buffers (persistent .grad views of the optimizer's flat
+    gradient buffer) instead of returning fresh tensors -- no fill, no add afterwards; returns True."""
     _req(a, "a"); _req(b, "b", a.dtype)
     rows, n = a.shape
     k = b.shape[1]
     if DISABLE_GEMM_TN or not _lib.load().xml_gemm_tn_supported(rows, n, k, dt_of(a)):
         return None
+    if out is not None:
+        _req(out, "out", F32)
+        assert out.numel() == n * k
+        if colsum_out is not None:
+            _req(colsum_out, "colsum_out", F32)
+            assert colsum_out.numel() == n
+        check(_lib.load().xml_gemm_tn(_p(a), _p(b), _p(out), _p(colsum_out), rows, n, k, dt_of(a), 1, _stream()),
+              "xml_gemm_tn")
+        return True
     buf = torch.empty(n * k + (n if colsum else 0), dtype=F32, device=a.device)      # back to back: one fill inside the entry
     out = buf[:n * k].view(n, k)
     cs = buf[n * k:] if colsum else None
-    check(_lib.load().xml_gemm_tn(_p(a), _p(b), _p(out), _p(cs), rows, n, k, dt_of(a), _stream()), "xml_gemm_tn")
+    check(_lib.load().xml_gemm_tn(_p(a), _p(b), _p(out), _p(cs), rows, n, k, dt_of(a), 0, _stream()), "xml_gemm_tn")
     return (out, cs) if colsum else out
 
 
@@ -187,12 +199,13 @@ def attn_softmax_bwd(s, dp, q_mask, k_mask, n, heads, lq, lk, dh, dtype):
     return ds, dst
 
 
-def modular_pool_bwd(enc, mask, wm, dout):
+def modular_pool_bwd(enc, mask, wm, dout, dwm=None):
+    """dwm given: accumulated into (a gradient sink); otherwise a fresh zero-filled tensor."""
     _req(enc, "enc"); _req(mask, "mask", F32); _req(wm, "wm", F32); _req(dout, "dout", enc.dtype)
     n, lq, hidden = enc.shape
     n_mod = wm.shape[0]
     denc = torch.empty_like(enc)
-    dwm = torch.zeros_like(wm)
+    dwm = torch.zeros_like(wm) if dwm is None else _req(dwm, "dwm", F32)
     check(_lib.load().xml_modular_pool_bwd(_p(enc), _p(mask), _p(wm), _p(dout), _p(denc), _p(dwm), n, lq, hidden,
                                            n_mod, dt_of(enc), _stream()), "xml_modular_pool_bwd")
     return denc, dwm

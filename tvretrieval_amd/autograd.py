@@ -59,10 +59,15 @@ def _sink(p):
     return g
 
 
-def _sunk(*params):
-    for p in params:
-        if p is not None:
-            p._xml_sink.opt._touch(p._xml_sink.index)
+def _claim(ctx, params, positions, extra_ok=True):
+    """Forward-time decision for the listed parameters of a node (positions = their indices in the node's inputs): True =
+    this node's backward accumulates their gradients straight into the sinks and returns None for them.
+    "The gradient of parameter i is complete" is still signalled by autograd: the parameter's AccumulateGrad node runs --
+    and its post-accumulate hook fires -- once EVERY node that uses the parameter has run its backward, whether those
+    returned tensors or None (checked on the GPU by tests/rccl_world1_check.py: reducer == plain path; a parameter shared
+    by two nodes, like the context positional table, is reported once, after both)."""
+    live = [p for p, pos in zip(params, positions) if p is not None and ctx.needs_input_grad[pos]]
+    return bool(live) and extra_ok and all(_sink(p) is not None for p in live)
 
 
 def _adjacent(params, flat_attr):
@@ -89,6 +94,9 @@ class LinearFn(torch.autograd.Function):
         ctx.relu = relu
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
+        n, k = w.shape
+        ctx.sunk = _claim(ctx, (weight, bias), (1, 2), ctx.needs_input_grad[1] and
+                          T.gemm_tn_supported(x.numel() // k, n, k, x.dtype))
         ctx.save_for_backward(x, w, y if relu else None)
         return y
 
@@ -111,12 +119,11 @@ class LinearFn(torch.autograd.Function):
             dx = ops.linear(a, wt).view(x.shape)                                   # dX = dY W
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
         weight, bias = ctx.params
-        gw = _sink(weight) if ctx.needs_input_grad[1] else None
-        gb = _sink(bias) if want_db else None
-        if gw is not None and (gb is not None or not want_db) and \
-                T.gemm_tn(dy2, x2, out=gw, colsum_out=gb):                         # straight into the flat .grad buffer
-            _sunk(weight, bias if want_db else None)
-            return dx, None, None, None
+        if ctx.sunk:
+            gw, gb = _sink(weight), (_sink(bias) if want_db else None)
+            if gw is not None and (gb is not None or not want_db):
+                assert T.gemm_tn(dy2, x2, out=gw, colsum_out=gb)                   # straight into the flat .grad buffer
+                return dx, None, None, None
         if ctx.needs_input_grad[1]:
             dw = T.gemm_tn(dy2, x2, colsum=want_db)                               # dW = dY^T X (+ db = column sums of dY)
             if dw is not None and want_db:
@@ -154,6 +161,7 @@ class LayerNormFn(torch.autograd.Function):
         b = None if b is None else b.contiguous()
         y = ops.add_layernorm(a, b, gf, bf, out_dtype=out_dtype)
         ctx.params = (g, beta)
+        ctx.sunk = _claim(ctx, (g, beta), (2, 3), ctx.needs_input_grad[2] and ctx.needs_input_grad[3])
         ctx.save_for_backward(a, b, gf)
         return y
 
@@ -162,12 +170,11 @@ class LayerNormFn(torch.autograd.Function):
         a, b, g = ctx.saved_tensors
         need_dx = ctx.needs_input_grad[0] or (b is not None and ctx.needs_input_grad[1])
         pg, pbeta = ctx.params
-        sg, sb = _sink(pg), _sink(pbeta)
-        sunk = sg is not None and sb is not None and ctx.needs_input_grad[2] and ctx.needs_input_grad[3]
+        sg, sb = (_sink(pg), _sink(pbeta)) if ctx.sunk else (None, None)
+        sunk = sg is not None and sb is not None
         dx, dg, dbeta = T.layernorm_bwd(a, b, g, dy.contiguous(), need_dx=need_dx, dg=sg.view(-1) if sunk else None,
                                         dbeta=sb.view(-1) if sunk else None)
         if sunk:
-            _sunk(pg, pbeta)
             dg = dbeta = None
         da = db = None
         if ctx.needs_input_grad[0]:
@@ -250,6 +257,11 @@ class QkvFn(torch.autograd.Function):
         w = _packed(wcat, x.dtype)
         b = bf.detach() if bf is not None else torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
         ctx.params = (wq, bq, wk, bk, wv, bv)
+        k = w.shape[1]
+        ctx.sunk = _claim(ctx, ctx.params, (1, 2, 3, 4, 5, 6),
+                          all(ctx.needs_input_grad[1:]) and _adjacent((wq, wk, wv), "flat_g") is not None and
+                          _adjacent((bq, bk, bv), "flat_g") is not None and
+                          T.gemm_tn_supported(x.numel() // k, w.shape[0], k, x.dtype))
         ctx.save_for_backward(x, w)
         return ops.linear(x.contiguous(), w, b)
 
@@ -263,10 +275,10 @@ class QkvFn(torch.autograd.Function):
         dy2, x2 = dy.view(rows, n3), x.contiguous().view(rows, k)
         dx = ops.linear(dy2, T.transpose(w)).view(x.shape) if ctx.needs_input_grad[0] else None
         wq, bq, wk, bk, wv, bv = ctx.params
-        if all(_sink(p) is not None for p in ctx.params) and all(ctx.needs_input_grad[1:]):
-            gw, gb = _adjacent((wq, wk, wv), "flat_g"), _adjacent((bq, bk, bv), "flat_g")
-            if gw is not None and gb is not None and T.gemm_tn(dy2, x2, out=gw, colsum_out=gb):
-                _sunk(*ctx.params)                                                         # six gradients, one launch, no adds
+        if ctx.sunk:
+            if all(_sink(p) is not None for p in ctx.params):
+                gw, gb = _adjacent((wq, wk, wv), "flat_g"), _adjacent((bq, bk, bv), "flat_g")
+                assert T.gemm_tn(dy2, x2, out=gw, colsum_out=gb)
                 return dx, None, None, None, None, None, None
         dw = T.gemm_tn(dy2, x2, colsum=True)                                               # (3H, H) and the three bias gradients
         if dw is None:
@@ -344,6 +356,7 @@ class ModularPoolFn(torch.autograd.Function):
         enc = enc.contiguous()
         out = ops.modular_pool(enc, mask, wmf)
         ctx.params = (wm,)
+        ctx.sunk = _claim(ctx, (wm,), (2,))
         ctx.save_for_backward(enc, mask, wmf)
         return out
 
@@ -351,10 +364,9 @@ class ModularPoolFn(torch.autograd.Function):
     def backward(ctx, dout):
         enc, mask, wmf = ctx.saved_tensors
         wm, = ctx.params
-        sw = _sink(wm) if ctx.needs_input_grad[2] else None
+        sw = _sink(wm) if ctx.sunk else None
         denc, dwm = T.modular_pool_bwd(enc, mask, wmf, dout.contiguous(), dwm=sw)
         if sw is not None:
-            _sunk(wm)
             dwm = None
         return denc, None, dwm
 

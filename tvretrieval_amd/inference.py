@@ -350,29 +350,36 @@ def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=Tru
                              zero_skipped=zero_skipped)
 
 
-def pad_moment_tail(flat_scores, flat_indices, k_videos, l_ref, min_pred_l, max_pred_l):
+def pad_moment_tail(flat_scores, flat_indices, k_videos, l_ref, min_pred_l=None, max_pred_l=None):
     """Opt-in reference-shaped tail of a moment list.  The reference sorts the WHOLE (k, L, L) product tensor and always
     returns max_before_nms rows (xml/inference.py:381-386; SVMR: utils/tensor_utils.py:133-141): when fewer candidates
-    pass the length mask, its tail is rows of score exactly 0 at positions torch.sort leaves unspecified.  The kernels mark
-    those rows flat = -1; this fills them with the first length-masked positions of the (k, L, L) tensor in ascending flat
-    order (out of the band min_l <= ed - st < max_l, so their score is exactly 0 in the reference too and none of them can
-    already be in the list).  Index plumbing on the device, in place; returns (flat_scores, flat_indices)."""
+    have a positive score -- short videos, the length mask -- its tail is rows of score exactly 0 in an order torch.sort
+    leaves unspecified.  The kernels mark those rows flat = -1; this fills them with the lowest flat positions of the
+    (k, L, L) tensor that are NOT in the list (a list with empty rows holds every positive-score candidate, so every other
+    position scores exactly 0 in the reference too) -- the order a stable descending sort would produce.
+    Index plumbing on the device, in place; returns (flat_scores, flat_indices)."""
     n_out = flat_indices.shape[1]
     dev = flat_indices.device
-    i = torch.arange(l_ref, device=dev)
-    d = i[None, :] - i[:, None]                                       # ed - st
-    inv = torch.nonzero(~((d >= min_pred_l) & (d < max_pred_l)).reshape(-1), as_tuple=False).reshape(-1)
-    reps = min(int(k_videos), -(-n_out // max(int(inv.numel()), 1)))
-    fill = (torch.arange(reps, device=dev)[:, None] * (l_ref * l_ref) + inv[None, :]).reshape(-1)[:n_out]
-    cnt = (flat_indices >= 0).sum(1, keepdim=True)
-    need = int((n_out - cnt).max())
-    if fill.numel() < need:        # (the reference itself fails when max_before_nms exceeds k * L * L)
-        raise ValueError("pad_tail: %d rows to fill but only %d length-masked positions exist" % (need, fill.numel()))
-    pos = torch.arange(n_out, device=dev)[None, :]
-    take = fill.to(flat_indices.dtype)[(pos - cnt).clamp(0, fill.numel() - 1)]
-    empty = pos >= cnt
-    flat_indices.copy_(torch.where(empty, take, flat_indices))
-    flat_scores.masked_fill_(empty, 0.0)
+    total = int(k_videos) * l_ref * l_ref
+    cnt = (flat_indices >= 0).sum(1)
+    rows = torch.nonzero(cnt < n_out, as_tuple=False).reshape(-1)
+    if rows.numel() == 0:
+        return flat_scores, flat_indices
+    if total < n_out:          # (the reference itself fails when max_before_nms exceeds k * L * L)
+        raise ValueError("pad_tail: max_before_nms = %d exceeds the %d positions of the (k, L, L) tensor" % (n_out, total))
+    # among the first 2 n_out positions at least n_out are not in a list of < n_out entries
+    cand = torch.arange(min(total, 2 * n_out), device=dev, dtype=flat_indices.dtype)
+    pos = torch.arange(n_out, device=dev)
+    for c in range(0, rows.numel(), 256):
+        r = rows[c:c + 256]
+        have = flat_indices[r]                                                        # (b, n_out), -1 = empty
+        free = ~(cand[None, :, None] == have[:, None, :]).any(-1)                     # (b, |cand|): not in the list
+        order = torch.argsort((~free).to(torch.int8), dim=1, stable=True)             # free positions first, ascending
+        fill = cand[order[:, :n_out]]                                                 # (b, n_out)
+        k = (pos[None, :] - cnt[r][:, None])                                          # index into fill for the empty rows
+        empty = k >= 0
+        flat_indices[r] = torch.where(empty, torch.gather(fill, 1, k.clamp_min(0)), have)
+        flat_scores[r] = flat_scores[r].masked_fill(empty, 0.0)
     return flat_scores, flat_indices
 
 

@@ -38,20 +38,21 @@ class _PosTableFn(torch.autograd.Function):
         from . import ops
         rows = weight.detach()[:seq_len].contiguous()
         rows = rows if dtype == F32 else ops.pack_weights(rows.float(), dtype)
+        from .autograd import _claim
         ctx.shape = tuple(weight.shape)
         ctx.n, ctx.seq_len = n, seq_len
         ctx.params = (weight,)
+        ctx.sunk = _claim(ctx, (weight,), (0,))
         return rows.unsqueeze(0).expand(n, seq_len, rows.shape[1]).contiguous()
 
     @staticmethod
     def backward(ctx, dy):
-        from .autograd import _sink, _sunk
+        from .autograd import _sink
         hidden = ctx.shape[1]
         weight, = ctx.params
-        sw = _sink(weight)
+        sw = _sink(weight) if ctx.sunk else None
         if sw is not None:          # column sums accumulated straight into the flat .grad buffer
             T.colsum(dy.contiguous(), ctx.n, ctx.seq_len * hidden, out=sw.view(-1)[:ctx.seq_len * hidden])
-            _sunk(weight)
             return None, None, None, None
         dw = torch.zeros(ctx.shape, dtype=F32, device=dy.device)
         T.colsum(dy.contiguous(), ctx.n, ctx.seq_len * hidden, out=dw.view(-1)[:ctx.seq_len * hidden])
@@ -312,6 +313,8 @@ class BertAdam(object):
             p._xml_sink = GradSink(self, i, o)      # backward kernels may accumulate straight into p.grad (autograd.py)
 
     def _touch(self, i):
+        """Post-accumulate hook of parameter i: every node that uses it has run its backward (its share of the gradient is
+        in the flat buffer -- added by AccumulateGrad, or already accumulated there by the node itself, autograd.py sinks)."""
         self._touched[i] = True
         if self._reducer is not None:
             self._reducer.grad_ready(i)

@@ -117,6 +117,10 @@ def merge_heads(xh, n, l, heads, out=None, col0=0):
 DISABLE_GEMM_TN = False               # tests / A-B measurements: transposes + split-K NT GEMM for the weight gradients
 
 
+def gemm_tn_supported(rows, n, k, dtype):
+    return not DISABLE_GEMM_TN and bool(_lib.load().xml_gemm_tn_supported(int(rows), int(n), int(k), dt_of(dtype)))
+
+
 def gemm_tn(a, b, colsum=False, out=None, colsum_out=None):
     """a (rows, N), b (rows, K) -> a^T b (N, K) f32, or None when the shape / dtype is not served (caller falls back).
     colsum=True: -> (a^T b, column sums of a (N,) f32) from the same launch (a layer's weight and bias gradients).

@@ -350,15 +350,18 @@ int xml_gemm_tn(const void* A, const void* B, float* out, float* colsum_a, int64
  * fused QKV tensor are passed as offset pointers).  Leading dimensions in elements, multiples of 8.  lq, lk <= 128;
  * dh = hidden / n_heads in {32, 64, 96, 128, 192}.  The dropout mask is xml_dropout's hash at the element's index in a
  * (n * heads, ceil8(lq), ceil8(lk)) tensor: the same elements the unfused chain drops for this seed.  p_drop = 0: none.
- * xml_attention_train_supported says whether a shape / dtype is served (callers keep the unfused chain otherwise). */
+ * xml_attention_train_supported says whether a shape / dtype is served (callers keep the unfused chain otherwise).
+ * seed_dev (here and in xml_dropout): NULL, or a DEVICE pointer to a 64-bit base seed that is ADDED to `seed` when the
+ * kernel runs -- a training step captured into a HIP graph keeps `seed` (a per-site constant) in its nodes and advances
+ * the base seed on the device, so every replay draws fresh masks. */
 int xml_attention_train_supported(int lq, int lk, int hidden, int n_heads, int dt);
 int xml_attention_train_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
                             const float* k_mask, void* out, int ldo, int64_t n, int lq, int lk, int hidden, int n_heads,
-                            float p_drop, uint64_t seed, int dt, xml_stream_t stream);
+                            float p_drop, uint64_t seed, const uint64_t* seed_dev, int dt, xml_stream_t stream);
 int xml_attention_train_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
                             const float* k_mask, const void* dout, int ldo, void* dq, int lddq, void* dk, int lddk,
                             void* dv, int lddv, int64_t n, int lq, int lk, int hidden, int n_heads, float p_drop,
-                            uint64_t seed, int dt, xml_stream_t stream);
+                            uint64_t seed, const uint64_t* seed_dev, int dt, xml_stream_t stream);
 /* get_modularized_queries backward (xml/model_xml.py:410-423): denc (n, lq, hidden) dt written, dw_m += . */
 int xml_modular_pool_bwd(const void* enc, const float* mask, const float* w_m, const void* dout, void* denc,
                          float* dw_m, int64_t n, int lq, int hidden, int n_mod, int dt, xml_stream_t stream);
@@ -395,7 +398,8 @@ int xml_rank_loss(const float* scores, const int* ranks_ctx, const int* ranks_q,
  * BertSelfOutput; xml/model_components.py:88,151,239,297,315): y = keep(i) ? x / (1 - p) : 0 with a counter-based
  * mask that is a pure function of (seed, element index) -- the backward pass calls it again on the gradient.
  * 0 <= p < 1; y == x allowed.  Not torch's Philox stream: statistically, not bitwise, equal to the reference. */
-int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dt, xml_stream_t stream);
+int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, int dt,
+                xml_stream_t stream);
 /* torch.nn.utils.clip_grad_norm_ over all gradients (xml/train.py:88-90, `--grad_clip`, off by default): g (n) f32 is
  * the flat gradient buffer; scaled in place by max_norm / (||g||_2 + 1e-6) when that is < 1.  ws: 4 bytes of scratch. */
 int xml_clip_grad_norm(float* g, int64_t n, float max_norm, float* ws, xml_stream_t stream);

@@ -311,6 +311,63 @@ def test_golden_train_steps_fp32(name):
     assert moved > 1e-5
 
 
+@pytest.mark.parametrize("name", ["train_step_video_sub_h128", "train_step_nocross_lse_h128"])
+def test_graphed_train_step_reproduces_the_reference_steps(name):
+    """train.GraphedTrainStep (the whole iteration as ONE HIP graph) on the golden fixture: the replayed steps give the
+    REFERENCE's per-step losses and its parameters after the third BertAdam step -- the schedule multiplier (0 at step 0,
+    then 1.0, 0.889), the injected negatives and the per-tensor clip all reach the captured kernels -- and constructing
+    the object (warm-up + capture) does not train."""
+    from tvretrieval_amd.train import BertAdam, GraphedTrainStep
+    d, cfg, _ = load_golden(name)
+    m = build_train_model(cfg, d)
+    okw = json.loads(str(d["optim"]))
+    named = list(m.named_parameters())
+    groups = [{"params": [p for n, p in named if not any(nd in n for nd in NO_DECAY)], "weight_decay": 0.01},
+              {"params": [p for n, p in named if any(nd in n for nd in NO_DECAY)], "weight_decay": 0.0}]
+    opt = BertAdam(groups, **okw)
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]))
+    before = opt.flat_p.clone()
+    step = GraphedTrainStep(m, opt, batch)
+    assert torch.equal(opt.flat_p, before) and opt.step_count == 0 and float(opt.flat_m.abs().max()) == 0.0
+    for it in range(3):
+        loss, parts = step(batch, neg_ctx_rank=d["neg_ctx_rank_steps"][it], neg_q_rank=d["neg_q_rank_steps"][it])
+        assert abs(float(loss) - float(d["step_losses"][it])) < 5e-5, (it, float(loss), float(d["step_losses"][it]))
+        assert abs(float(parts["loss_overall"]) - float(loss)) < 1e-6
+    assert opt.step_count == 3
+    worst = 0.0
+    for n, p in named:
+        want = torch.from_numpy(d["sd_after3/" + n])
+        worst = max(worst, float((p.detach().cpu() - want).abs().max()))
+    assert worst < 2e-5, worst
+
+
+def test_graphed_train_step_bf16_dropout_draws_fresh_masks_and_descends():
+    """bf16, model.train(): every replay advances the device-resident base seed (different masks => different losses on the
+    SAME batch with the learning rate at zero), and with a learning rate the loss goes down like the eager loop's."""
+    from tvretrieval_amd.model_xml import XML
+    from tvretrieval_amd.train import BertAdam, GraphedTrainStep
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]))
+    ranks = dict(neg_ctx_rank=d["neg_ctx_rank_steps"][0], neg_q_rank=d["neg_q_rank_steps"][0])
+    torch.manual_seed(3)
+    m = XML(cfg, compute_dtype=torch.bfloat16).to(DEV).train()
+    opt = BertAdam(m.parameters(), lr=0.0, warmup=-1, t_total=-1, schedule="none")
+    step = GraphedTrainStep(m, opt, batch)
+    losses = [float(step(None, **ranks)[0]) for _ in range(4)]
+    assert len({round(x, 6) for x in losses}) == 4, losses            # same weights, same batch: only the masks differ
+    m.eval()                                                          # (the graph was captured in train mode: unchanged)
+    torch.manual_seed(3)
+    m2 = XML(cfg, compute_dtype=torch.bfloat16).to(DEV).train()
+    opt2 = BertAdam(m2.parameters(), lr=2e-3, warmup=-1, t_total=-1, schedule="none")
+    step2 = GraphedTrainStep(m2, opt2, batch)
+    ls = [float(step2(None, **ranks)[0]) for _ in range(12)]
+    assert np.mean(ls[-3:]) < np.mean(ls[:3]) - 0.02, ls
+
+
 def test_golden_staged_training_fp32():
     """train_span_start_epoch: two steps with lw_st_ed = 0, then three with the span loss.  The 42 tensors behind the span
     branch must stay untouched (no weight decay, no moments) until they first receive a gradient and then run their OWN

@@ -29,8 +29,9 @@ def train_flops_per_sample(lc, lq, hidden, dv, ds, dq, cross=True):
 
 
 def run(bsz=128, ctx_l=100, desc_l=30, hidden=768, dv=3072, ds=768, dtype="bf16", steps=10, warmup=3, rank=0, world=1,
-        dev=None):
-    """Times `steps` training steps (forward, backward, [all-reduce], BertAdam) on this rank; returns the result dict."""
+        dev=None, graph=False):
+    """Times `steps` training steps (forward, backward, [all-reduce], BertAdam) on this rank; returns the result dict.
+    graph=True (one GPU): the whole iteration replayed as ONE HIP graph (train.GraphedTrainStep)."""
     import torch.distributed as dist
     from tvretrieval_amd.model_xml import XML, xml_base_config
     from tvretrieval_amd.train import BertAdam, GradientReducer, allreduce_gradients, xml_forward_train
@@ -66,6 +67,29 @@ def run(bsz=128, ctx_l=100, desc_l=30, hidden=768, dv=3072, ds=768, dtype="bf16"
                  video_mask=vm.to(dev), sub_feat=feats(lc, ds, vm), sub_mask=vm.to(dev),
                  st_ed_indices=torch.stack([st, ed], 1).to(dev))
 
+    if graph:
+        from tvretrieval_amd.train import GraphedTrainStep
+        assert world == 1, "the captured step does not include the all-reduce"
+        step = GraphedTrainStep(model, opt, batch)
+        for _ in range(warmup):
+            step(None)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        losses = []
+        for _ in range(steps):
+            loss, parts = step(None)
+            losses.append(float(loss))          # the reference logs the loss every step: one synchronisation per step
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t0) / steps * 1e3
+        n_param = sum(p.numel() for p in model.parameters())
+        flops = train_flops_per_sample(ctx_l, desc_l, hidden, dv, ds, ds) * bsz
+        peak = 2500.0 if dtype == "bf16" else 157.3
+        tflops = flops / (wall * 1e-3) / 1e12
+        return dict(metric="xml_train_step", ms_per_step=round(wall, 3), pairs_per_s=round(bsz / wall * 1e3, 1), n_gpus=1,
+                    dtype=dtype, mode="one HIP graph per step (train.GraphedTrainStep)", flops_per_step=flops,
+                    tflops=round(tflops, 1), frac_of_mfma_peak=round(tflops / peak, 4),
+                    config=dict(bsz_per_gpu=bsz, ctx_l=ctx_l, desc_l=desc_l, hidden=hidden, dv=dv, params=n_param),
+                    loss_first=round(losses[0], 4), loss_last=round(losses[-1], 4))
     ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
     acc = dict(fwd=0.0, bwd=0.0, allreduce=0.0, optim=0.0)
     losses = []
@@ -120,6 +144,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--graph", action="store_true", help="replay the whole step as one HIP graph (one GPU)")
     a = ap.parse_args()
     from tvretrieval_amd import launch
     if a.gpus > 1 and not launch.under_launcher():
@@ -134,7 +159,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
-    res = run(a.bsz, a.ctx_l, a.desc_l, a.hidden, a.dv, a.ds, a.dtype, a.steps, a.warmup, rank, world, dev)
+    res = run(a.bsz, a.ctx_l, a.desc_l, a.hidden, a.dv, a.ds, a.dtype, a.steps, a.warmup, rank, world, dev, graph=a.graph)
     if rank == 0:
         print(json.dumps(res))
     if world > 1:

@@ -117,10 +117,10 @@ SIGNATURES = {
     "xml_gemm_tn": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "xml_attention_train_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "xml_attention_train_fwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
-                                        c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64, c_int, c_void_p]),
+                                        c_int64, c_int, c_int, c_int, c_int, c_float, ctypes.c_uint64, c_void_p, c_int, c_void_p]),
     "xml_attention_train_bwd": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int,
                                         c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_int,
-                                        c_float, ctypes.c_uint64, c_int, c_void_p]),
+                                        c_float, ctypes.c_uint64, c_void_p, c_int, c_void_p]),
     "xml_modular_pool_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                      c_int, c_int, c_void_p]),
     "xml_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
@@ -133,7 +133,7 @@ SIGNATURES = {
                               c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xml_rank_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p]),
-    "xml_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_int, c_void_p]),
+    "xml_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p, c_int, c_void_p]),
     "xml_clip_grad_norm": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "xml_bert_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                    c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

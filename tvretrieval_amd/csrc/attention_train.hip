@@ -37,7 +37,8 @@ struct AttnTrainArgs {
   int lddq, lddk, lddv;
   int lq, lk, lq8, lk8;
   float sqrt_dh;
-  uint32_t thresh; float scale; uint32_t s0, s1;      // dropout: keep(i) = hash(i) >= thresh, kept values * scale
+  uint32_t thresh; float scale;                        // dropout: keep(i) = hash(i) >= thresh, kept values * scale
+  uint64_t seed; const uint64_t* seed_dev;             // host seed + optional device-resident base seed (xml_seed_words)
 };
 
 typedef short at_v4s __attribute__((ext_vector_type(4)));
@@ -248,6 +249,8 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(AttnTrainArgs a) {
   at_softmax(p, km, qmk, lk, 1.0f / a.sqrt_dh, fr);
   if (a.thresh) {
     const int64_t unit = (int64_t)n * gridDim.x + head;
+    uint32_t s0, s1;
+    xml_seed_words(a.seed, a.seed_dev, s0, s1);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -256,7 +259,7 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(AttnTrainArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int row = (wave + t * 4) * 16 + fg * 4 + r, col = j * 16 + fr;
           const uint64_t idx = (uint64_t)((unit * a.lq8 + row) * a.lk8 + col);
-          p[t][j][r] = at_drop_hash(idx, a.s0, a.s1) >= a.thresh ? p[t][j][r] * a.scale : 0.f;
+          p[t][j][r] = at_drop_hash(idx, s0, s1) >= a.thresh ? p[t][j][r] * a.scale : 0.f;
         }
   }
 #pragma unroll
@@ -307,6 +310,8 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
   at_rows_dot_rows<DH>(dp, da, r2, fr, fg);
   {
     const int64_t unit = (int64_t)n * gridDim.x + head;
+    uint32_t s0 = 0, s1 = 0;
+    if (a.thresh) xml_seed_words(a.seed, a.seed_dev, s0, s1);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -318,7 +323,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
 #pragma unroll
           for (int j = 0; j < AT_MAXNT; ++j) {
             const uint64_t idx = (uint64_t)((unit * a.lq8 + row) * a.lk8 + j * 16 + fr);
-            keep |= (at_drop_hash(idx, a.s0, a.s1) >= a.thresh ? 1u : 0u) << j;
+            keep |= (at_drop_hash(idx, s0, s1) >= a.thresh ? 1u : 0u) << j;
           }
         }
         float delta = 0.f;
@@ -416,7 +421,8 @@ int at_launch(bool bwd, const AttnTrainArgs& a, int64_t n, int n_heads, hipStrea
   return XML_OK;
 }
 
-int at_dispatch(bool bwd, AttnTrainArgs& a, int64_t n, int hidden, int n_heads, float p_drop, uint64_t seed, hipStream_t st) {
+int at_dispatch(bool bwd, AttnTrainArgs& a, int64_t n, int hidden, int n_heads, float p_drop, uint64_t seed,
+                const uint64_t* seed_dev, hipStream_t st) {
   if (n <= 0 || a.lq <= 0 || a.lk <= 0 || n_heads <= 0 || hidden % n_heads || !(p_drop >= 0.f) || p_drop >= 1.f)
     return XML_ERR_BAD_ARG;
   if (a.lq > 128 || a.lk > 128) return XML_ERR_UNSUPPORTED;
@@ -425,7 +431,7 @@ int at_dispatch(bool bwd, AttnTrainArgs& a, int64_t n, int hidden, int n_heads, 
   a.sqrt_dh = sqrtf((float)dh);
   a.thresh = (uint32_t)((double)p_drop * 4294967296.0);          // xml_dropout's threshold / scale / seed words
   a.scale = 1.f / (1.f - p_drop);
-  a.s0 = (uint32_t)seed; a.s1 = (uint32_t)(seed >> 32) * 0x27D4EB2Fu + 0x165667B1u;
+  a.seed = seed; a.seed_dev = seed_dev;
   switch (dh) {
     case 32: return at_launch<32>(bwd, a, n, n_heads, st);
     case 64: return at_launch<64>(bwd, a, n, n_heads, st);
@@ -446,7 +452,8 @@ extern "C" int xml_attention_train_supported(int lq, int lk, int hidden, int n_h
 
 extern "C" int xml_attention_train_fwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                                        const float* q_mask, const float* k_mask, void* out, int ldo, int64_t n, int lq, int lk,
-                                       int hidden, int n_heads, float p_drop, uint64_t seed, int dt, xml_stream_t stream) {
+                                       int hidden, int n_heads, float p_drop, uint64_t seed, const uint64_t* seed_dev, int dt,
+                                       xml_stream_t stream) {
   XML_ENTER();
   if (!q || !k || !v || !k_mask || !out) return XML_ERR_BAD_ARG;
   if (dt != XML_BF16) return XML_ERR_UNSUPPORTED;
@@ -454,13 +461,14 @@ extern "C" int xml_attention_train_fwd(const void* q, int ldq, const void* k, in
   AttnTrainArgs a = {};
   a.q = (const bf16_t*)q; a.k = (const bf16_t*)k; a.v = (const bf16_t*)v; a.ldq = ldq; a.ldk = ldk; a.ldv = ldv;
   a.q_mask = q_mask; a.k_mask = k_mask; a.out = (bf16_t*)out; a.ldo = ldo; a.lq = lq; a.lk = lk;
-  return at_dispatch(false, a, n, hidden, n_heads, p_drop, seed, (hipStream_t)stream);
+  return at_dispatch(false, a, n, hidden, n_heads, p_drop, seed, seed_dev, (hipStream_t)stream);
 }
 
 extern "C" int xml_attention_train_bwd(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                                        const float* q_mask, const float* k_mask, const void* dout, int ldo, void* dq, int lddq,
                                        void* dk, int lddk, void* dv, int lddv, int64_t n, int lq, int lk, int hidden,
-                                       int n_heads, float p_drop, uint64_t seed, int dt, xml_stream_t stream) {
+                                       int n_heads, float p_drop, uint64_t seed, const uint64_t* seed_dev, int dt,
+                                       xml_stream_t stream) {
   XML_ENTER();
   if (!q || !k || !v || !k_mask || !dout || !dq || !dk || !dv) return XML_ERR_BAD_ARG;
   if (dt != XML_BF16) return XML_ERR_UNSUPPORTED;
@@ -470,5 +478,5 @@ extern "C" int xml_attention_train_bwd(const void* q, int ldq, const void* k, in
   a.q_mask = q_mask; a.k_mask = k_mask; a.dout = (const bf16_t*)dout; a.ldo = ldo;
   a.dq = (bf16_t*)dq; a.dk = (bf16_t*)dk; a.dv = (bf16_t*)dv; a.lddq = lddq; a.lddk = lddk; a.lddv = lddv;
   a.lq = lq; a.lk = lk;
-  return at_dispatch(true, a, n, hidden, n_heads, p_drop, seed, (hipStream_t)stream);
+  return at_dispatch(true, a, n, hidden, n_heads, p_drop, seed, seed_dev, (hipStream_t)stream);
 }

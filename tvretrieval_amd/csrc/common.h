@@ -173,6 +173,32 @@ __device__ __forceinline__ uint4 ld_global16_as1(const void* p) {
 }
 __device__ __forceinline__ void st_global16(void* p, const uint4& v) { *reinterpret_cast<uint4*>(p) = v; }
 
+// Zero-fill as a KERNEL.  hipMemsetAsync is fine on a stream, but as a memset NODE of a captured HIP graph it did not
+// run again on the second replay (ROCm 7.2; found with inference.GraphedVcmrSearch -- stale K7 cursors); every fill inside
+// an entry point that may be captured (the search pass, the training step) is therefore a kernel.  bytes % 4 == 0.
+static __global__ void xml_zero_words_kernel(uint32_t* __restrict__ p, int64_t n_words) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i + 3 < n_words && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+    *reinterpret_cast<uint4*>(p + i) = make_uint4(0u, 0u, 0u, 0u);
+  } else {
+    for (int k = 0; k < 4; ++k) if (i + k < n_words) p[i + k] = 0u;
+  }
+}
+static inline bool xml_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const int64_t n_words = (int64_t)((bytes + 3) / 4);
+  if (n_words <= 0) return true;
+  hipLaunchKernelGGL(xml_zero_words_kernel, dim3((unsigned)((n_words + 1023) / 1024)), dim3(256), 0, st, (uint32_t*)p, n_words);
+  return hipGetLastError() == hipSuccess;
+}
+
+// dropout seed words of xml_dropout / the fused training attention: host seed + optional device-resident base seed (a
+// captured training step advances the base seed on the device, so every replay draws fresh masks)
+__device__ __forceinline__ void xml_seed_words(uint64_t seed, const uint64_t* seed_dev, uint32_t& s0, uint32_t& s1) {
+  if (seed_dev) seed += *seed_dev;
+  s0 = (uint32_t)seed;
+  s1 = (uint32_t)(seed >> 32) * 0x27D4EB2Fu + 0x165667B1u;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline size_t dt_size(int dt) { return dt == XML_F32 ? 4 : 2; }

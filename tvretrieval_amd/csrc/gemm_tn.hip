@@ -172,10 +172,10 @@ extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, float* cols
   if (accumulate) {
     // out / colsum_a are gradient buffers that already hold a (possibly zero) partial sum: every contribution is an atomic add
   } else if (splits > 1 && colsum_a == out + (size_t)N * K) {   // caller laid them out back to back: one fill
-    if (hipMemsetAsync(out, 0, ((size_t)N * K + N) * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (!xml_zero_async(out, ((size_t)N * K + N) * 4, st)) return XML_ERR_LAUNCH;
   } else {
-    if (splits > 1 && hipMemsetAsync(out, 0, (size_t)N * K * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
-    if (colsum_a && hipMemsetAsync(colsum_a, 0, (size_t)N * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (splits > 1 && !xml_zero_async(out, (size_t)N * K * 4, st)) return XML_ERR_LAUNCH;
+    if (colsum_a && !xml_zero_async(colsum_a, (size_t)N * 4, st)) return XML_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(gemm_tn_kernel, dim3(cdiv(K, 128), cdiv(N, 128), splits), dim3(256), 0, st, (const bf16_t*)A,
                      (const bf16_t*)B, out, colsum_a, (int)rows, N, K, rps, accumulate ? 1 : 0);

@@ -126,7 +126,7 @@ extern "C" int xml_colsum(const void* x, int x_dt, float* out, int64_t rows, int
   XML_ENTER();
   if (!x || !out || rows <= 0 || cols <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (!accumulate && hipMemsetAsync(out, 0, (size_t)cols * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  if (!accumulate && !xml_zero_async(out, (size_t)cols * 4, st)) return XML_ERR_LAUNCH;
   const int64_t rpb = rows >= 4096 ? 32 : 256;
   dim3 grid(cdiv(cols, 256), cdiv(rows, rpb));
   if (x_dt == XML_F32)
@@ -551,7 +551,7 @@ extern "C" int xml_gemm_batched(const void* A, const void* B, void* out, int bat
     if (kc < 256) kc = 256;
     ks = cdiv(K, kc);
     if (ks > 1) {
-      if (hipMemsetAsync(out, 0, (size_t)M * N * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+      if (!xml_zero_async(out, (size_t)M * N * 4, st)) return XML_ERR_LAUNCH;
       dim3 grid(cdiv(N, 128), cdiv(M, 128), ks);
       if (dt == XML_F32)
         hipLaunchKernelGGL((gemm_batched_kernel<float, float, true>), grid, dim3(256), 0, st, (const float*)A,
@@ -987,8 +987,8 @@ extern "C" int xml_q2c_scores_bwd(const void* qn, const void* cn, const float* m
   XML_ENTER();
   if (!qn || !cn || !mask || !dscores || !dqn || !dcn || nq <= 0 || nv <= 0 || l <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(dqn, 0, (size_t)nq * hidden * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
-  if (hipMemsetAsync(dcn, 0, (size_t)nv * l * hidden * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  if (!xml_zero_async(dqn, (size_t)nq * hidden * 4, st)) return XML_ERR_LAUNCH;
+  if (!xml_zero_async(dcn, (size_t)nv * l * hidden * 4, st)) return XML_ERR_LAUNCH;
   dim3 grid(nv, cdiv(nq, 4));
   if (hidden % 8 == 0 && (dt == XML_F32 || dt == XML_BF16)) {
     if (dt == XML_F32)
@@ -1229,13 +1229,13 @@ extern "C" int xml_span_loss(const float* sim0, const float* sim1, const float* 
   hipStream_t st = (hipStream_t)stream;
   if (!gout) {
     if (!loss_out) return XML_ERR_BAD_ARG;
-    if (hipMemsetAsync(loss_out, 0, 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (!xml_zero_async(loss_out, 4, st)) return XML_ERR_LAUNCH;
   } else {
     if (!dsim0 || !dconv_w || (n_sim == 2 && !dsim1)) return XML_ERR_BAD_ARG;
     const int n_filt = merged ? 1 : n_sim;
-    if (hipMemsetAsync(dsim0, 0, (size_t)n * l * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
-    if (n_sim == 2 && hipMemsetAsync(dsim1, 0, (size_t)n * l * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
-    if (hipMemsetAsync(dconv_w, 0, (size_t)2 * n_filt * ks * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (!xml_zero_async(dsim0, (size_t)n * l * 4, st)) return XML_ERR_LAUNCH;
+    if (n_sim == 2 && !xml_zero_async(dsim1, (size_t)n * l * 4, st)) return XML_ERR_LAUNCH;
+    if (!xml_zero_async(dconv_w, (size_t)2 * n_filt * ks * 4, st)) return XML_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(span_loss_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, sim0, sim1, conv_w, mask0, mask1 ? mask1 : mask0,
                      st_ed, merged, n_sim, ks, n, l, gout, loss_out, dsim0, dsim1, dconv_w);
@@ -1291,10 +1291,10 @@ extern "C" int xml_rank_loss(const float* scores, const int* ranks_ctx, const in
   hipStream_t st = (hipStream_t)stream;
   if (!gout) {
     if (!losses) return XML_ERR_BAD_ARG;
-    if (hipMemsetAsync(losses, 0, 8, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (!xml_zero_async(losses, 8, st)) return XML_ERR_LAUNCH;
   } else {
     if (!dscores) return XML_ERR_BAD_ARG;
-    if (hipMemsetAsync(dscores, 0, (size_t)n * n * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (!xml_zero_async(dscores, (size_t)n * n * 4, st)) return XML_ERR_LAUNCH;
   }
   hipLaunchKernelGGL(rank_loss_kernel, dim3(n, 2), dim3(256), 0, st, scores, ranks_ctx, ranks_q, margin, lse, n, gout,
                      losses, dscores);
@@ -1431,7 +1431,7 @@ extern "C" int xml_bert_adam_step(float* p, float* g, float* m, float* v, const 
   if (!p || !g || !m || !v || !seg_off || !seg_lr || !seg_wd || !norms || n_seg <= 0 || total <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (max_grad_norm > 0.f) {
-    if (hipMemsetAsync(norms, 0, (size_t)n_seg * 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+    if (!xml_zero_async(norms, (size_t)n_seg * 4, st)) return XML_ERR_LAUNCH;
     hipLaunchKernelGGL(adam_norm_kernel, dim3(cdiv(total, 4096)), dim3(256), 0, st, g, seg_off, n_seg, total, norms);
   }
   hipLaunchKernelGGL(adam_update_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, p, g, m, v, seg_off, seg_lr, seg_wd,
@@ -1456,21 +1456,23 @@ __device__ __forceinline__ uint32_t drop_hash(uint64_t i, uint32_t s0, uint32_t 
 }
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, uint32_t thresh, float scale,
-                               uint32_t s0, uint32_t s1) {
+                               uint64_t seed, const uint64_t* __restrict__ seed_dev) {
+  uint32_t s0, s1;
+  xml_seed_words(seed, seed_dev, s0, s1);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     DT<T>::st(y + i, drop_hash((uint64_t)i, s0, s1) >= thresh ? DT<T>::ld(x + i) * scale : 0.f);
 }
 
-extern "C" int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, int dt, xml_stream_t stream) {
+extern "C" int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, int dt,
+                           xml_stream_t stream) {
   XML_ENTER();
   if (!x || !y || n <= 0 || !(p >= 0.f) || p >= 1.f) return XML_ERR_BAD_ARG;
   const uint32_t thresh = (uint32_t)((double)p * 4294967296.0);
   const float scale = 1.f / (1.f - p);
-  const uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32) * 0x27D4EB2Fu + 0x165667B1u;
   if (dt == XML_F32)
-    hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, thresh, scale, s0, s1);
+    hipLaunchKernelGGL(dropout_kernel<float>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (float*)y, n, thresh, scale, seed, seed_dev);
   else if (dt == XML_BF16)
-    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n, thresh, scale, s0, s1);
+    hipLaunchKernelGGL(dropout_kernel<bf16_t>, dim3(ew_grid(n)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)y, n, thresh, scale, seed, seed_dev);
   else
     return XML_ERR_BAD_ARG;
   XML_CHECK_LAUNCH();
@@ -1507,7 +1509,7 @@ extern "C" int xml_clip_grad_norm(float* g, int64_t n, float max_norm, float* ws
   XML_ENTER();
   if (!g || !ws || n <= 0 || !(max_norm > 0.f)) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
-  if (hipMemsetAsync(ws, 0, 4, st) != hipSuccess) return XML_ERR_LAUNCH;
+  if (!xml_zero_async(ws, 4, st)) return XML_ERR_LAUNCH;
   const int blocks = (int)((n + 1023) / 1024 < 2048 ? (n + 1023) / 1024 : 2048);
   hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, st, g, n, ws);
   hipLaunchKernelGGL(clip_scale_kernel, dim3(ew_grid(n)), dim3(256), 0, st, g, n, ws, max_norm);

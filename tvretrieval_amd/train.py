@@ -59,8 +59,16 @@ class _PosTableFn(torch.autograd.Function):
         return dw, None, None, None
 
 
+_SITE = [0]      # dropout sites visited since the capture of a GraphedTrainStep began
+
+
 def _seed():
-    """A fresh 62-bit dropout seed from torch's CPU generator (so torch.manual_seed makes a run repeatable)."""
+    """A fresh 62-bit dropout seed from torch's CPU generator (so torch.manual_seed makes a run repeatable).  While a
+    training step is being captured into a HIP graph the seed is a per-site constant instead; the kernels add the
+    device-resident base seed that the graph itself advances (train_ops.SEED_BASE)."""
+    if T.SEED_BASE is not None:
+        _SITE[0] += 1
+        return (_SITE[0] * 0x9E3779B97F4A7C15) & (2 ** 62 - 1)
     return int(torch.randint(0, 2 ** 62, (1,)).item())
 
 
@@ -144,8 +152,10 @@ def draw_negative_ranks(model, bsz):
 
 
 def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub_feat, sub_mask, st_ed_indices,
-                      neg_ctx_rank=None, neg_q_rank=None):
-    """XML.forward (xml/model_xml.py:212-251) -> (loss 0-d tensor with grad_fn, loss dict of floats)."""
+                      neg_ctx_rank=None, neg_q_rank=None, as_tensors=False):
+    """XML.forward (xml/model_xml.py:212-251) -> (loss 0-d tensor with grad_fn, loss dict of floats).
+    as_tensors=True: the dict holds detached 0-d device tensors instead of floats (no host synchronisation: what a
+    captured step needs)."""
     cfg = model.config
     dev = query_feat.device
     fm = lambda m: None if m is None else m.float().contiguous()       # noqa: E731
@@ -198,7 +208,10 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
     loss_neg_ctx = cfg.lw_neg_ctx * loss_neg_ctx
     loss_neg_q = cfg.lw_neg_q * loss_neg_q
     loss = loss_st_ed + loss_neg_ctx + loss_neg_q
-    f = lambda t: float(t.detach()) if torch.is_tensor(t) else float(t)      # noqa: E731
+    if as_tensors:
+        f = lambda t: t.detach() if torch.is_tensor(t) else torch.full((), float(t), dtype=F32, device=dev)   # noqa: E731
+    else:
+        f = lambda t: float(t.detach()) if torch.is_tensor(t) else float(t)      # noqa: E731
     return loss, {"loss_st_ed": f(loss_st_ed), "loss_neg_ctx": f(loss_neg_ctx), "loss_neg_q": f(loss_neg_q),
                   "loss_overall": f(loss)}
 
@@ -350,36 +363,159 @@ class BertAdam(object):
                 out.append(g["lr"] * self.lr_multiplier(self.seg_steps[i]))
         return out
 
-    def step(self, closure=None):
-        loss = closure() if closure is not None else None
-        d = self.defaults
+    def _step_plan(self):
+        """Host side of a step: which tensors take part (`if p.grad is None: continue`) and their schedule multipliers
+        (per-tensor step counts, xml/optimization.py:289-291,325-330)."""
         # no hook has ever fired = gradients are being written into .grad by hand (no autograd): every tensor "has a grad"
         active = self._touched if any(self._touched) else [True] * len(self._touched)
-        seg_active = seg_mult = None
-        if not all(active):
-            key = tuple(active)
-            if key != self._active_key:      # uploaded only when the set of participating tensors changes
-                self._active_key = key
-                self._active_dev = torch.tensor([1 if a else 0 for a in active], dtype=torch.uint8,
-                                                device=self.flat_p.device)
-            seg_active = self._active_dev
-        steps = {s for s, a in zip(self.seg_steps, active) if a}
-        if len(steps) <= 1:                  # every participating tensor is at the same step: one scalar multiplier
-            mult = self.lr_multiplier(steps.pop() if steps else 0)
-        else:                                # tensors that joined later run their own warm-up
-            mult = 0.0
-            per = {s: self.lr_multiplier(s) for s in steps}
-            seg_mult = torch.tensor([per.get(s, 0.0) if a else 0.0 for s, a in zip(self.seg_steps, active)], dtype=F32,
-                                    device=self.flat_p.device)
-        T.bert_adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.seg_off, self.seg_lr, self.seg_wd,
-                         self.norms, mult, d["b1"], d["b2"], d["e"], d["max_grad_norm"], seg_active, seg_mult)
+        per = {st: self.lr_multiplier(st) for st in {s_ for s_, a in zip(self.seg_steps, active) if a}}
+        mults = [per[s_] if a else 0.0 for s_, a in zip(self.seg_steps, active)]
+        return active, mults
+
+    def _active_mask(self, active):
+        if all(active):
+            return None
+        key = tuple(active)
+        if key != self._active_key:      # uploaded only when the set of participating tensors changes
+            self._active_key = key
+            self._active_dev = torch.tensor([1 if a else 0 for a in active], dtype=torch.uint8, device=self.flat_p.device)
+        return self._active_dev
+
+    def _commit_step(self, active):
         for i, a in enumerate(active):
             if a:
                 self.seg_steps[i] += 1
         self.step_count += 1
         from .model_xml import _PackedMixin
         _PackedMixin.bump_generation()          # cached low-precision weight copies are stale now
+
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        d = self.defaults
+        active, mults = self._step_plan()
+        seg_active = self._active_mask(active)
+        distinct = {m for m, a in zip(mults, active) if a}
+        seg_mult = None
+        if len(distinct) <= 1:               # every participating tensor is at the same step: one scalar multiplier
+            mult = distinct.pop() if distinct else self.lr_multiplier(0)
+        else:                                # tensors that joined later run their own warm-up
+            mult = 0.0
+            seg_mult = torch.tensor(mults, dtype=F32, device=self.flat_p.device)
+        T.bert_adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.seg_off, self.seg_lr, self.seg_wd,
+                         self.norms, mult, d["b1"], d["b2"], d["e"], d["max_grad_norm"], seg_active, seg_mult)
+        self._commit_step(active)
         return loss
+
+
+class GraphedTrainStep(object):
+    """One training iteration of the reference's loop (xml/train.py:78-95: forward, zero_grad, backward, [clip], step)
+    captured ONCE into a HIP graph and replayed.
+
+    Why: after the kernel work of rounds 2-3 the C5-shape step (batch 128, bf16) is ~300 launches and ~6 ms of kernel time,
+    and the Python / autograd / ctypes side of issuing them costs about as much: the step had become CPU-bound.  One graph
+    launch replaces all of it.  What makes the capture faithful:
+      * inputs live in static device buffers (`__call__` copies the batch in; shapes are fixed at construction);
+      * the in-batch negatives of get_neg_scores are drawn per step on the CPU generator, in the reference's order
+        (draw_negative_ranks), and copied into static index tensors before the replay;
+      * dropout seeds frozen into the graph's nodes are per-site constants; the kernels add a device-resident base seed
+        that the FIRST node of the graph advances (train_ops.SEED_BASE): fresh masks on every replay, forward and backward
+        of one replay see the same ones;
+      * the learning-rate schedule reaches the optimizer kernel as a per-tensor multiplier array in device memory, written
+        by the host before each replay (per-tensor step counts, warm-up, `p.grad is None` semantics: BertAdam._step_plan);
+      * every fill inside the captured entries is a kernel (a memset NODE did not re-run on replay, ROCm 7.2).
+    The warm-up steps run on copies of the optimizer state, which is restored before the capture: constructing the object
+    does not train.  Not supported: a GradientReducer on the optimizer (data-parallel runs keep the eager step), changing
+    which tensors receive gradients after the capture (set_train_st_ed: re-create the object).
+    Returns (loss, loss_dict) as 0-d DEVICE tensors; reading them synchronises."""
+
+    def __init__(self, model, optimizer, batch, grad_clip=-1, warmup_steps=2):
+        if getattr(optimizer, "_reducer", None) is not None:
+            raise ValueError("GraphedTrainStep does not capture the data-parallel all-reduce: use train_step")
+        self.model, self.opt, self.grad_clip = model, optimizer, grad_clip
+        dev = optimizer.flat_p.device
+        self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in batch.items()
+                       if k not in ("neg_ctx_rank", "neg_q_rank")}
+        n = self.static["query_feat"].shape[0]
+        self.neg_ctx = torch.ones(n, dtype=torch.int32, device=dev)
+        self.neg_q = torch.ones(n, dtype=torch.int32, device=dev)
+        self.seed_base = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.lr_mult = torch.ones(len(optimizer.params), dtype=F32, device=dev)
+        # ---- warm-up on the side stream (workspaces, allocator pools, packed-weight caches), state restored afterwards
+        keep = [t.clone() for t in (optimizer.flat_p, optimizer.flat_m, optimizer.flat_v)]
+        keep_host = (list(optimizer.seg_steps), optimizer.step_count, list(optimizer._touched))
+        cpu_rng = torch.get_rng_state()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup_steps)):
+                self._set_ranks(None, None)
+                self._body()
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        for dst, src in zip((optimizer.flat_p, optimizer.flat_m, optimizer.flat_v), keep):
+            dst.copy_(src)
+        optimizer.seg_steps, optimizer.step_count = list(keep_host[0]), keep_host[1]
+        touched_after_warmup = list(optimizer._touched)     # which tensors this graph's backward reaches
+        torch.set_rng_state(cpu_rng)
+        # ---- capture
+        self.active = touched_after_warmup if any(touched_after_warmup) else [True] * len(touched_after_warmup)
+        self.seg_active = optimizer._active_mask(self.active)
+        self.graph = torch.cuda.CUDAGraph()
+        T.SEED_BASE = self.seed_base
+        _SITE[0] = 0
+        try:
+            with torch.cuda.graph(self.graph):
+                self.seed_base.add_(0x2545F4914F6CDD1D)          # first node: this replay's base seed
+                self.loss, self.parts = self._body(captured=True)
+        finally:
+            T.SEED_BASE = None
+        optimizer._touched = [a or b for a, b in zip(keep_host[2], self.active)]
+        torch.cuda.synchronize(dev)
+        # the capture itself executed nothing; bring the optimizer state back in any case (allocator reuse)
+        for dst, src in zip((optimizer.flat_p, optimizer.flat_m, optimizer.flat_v), keep):
+            dst.copy_(src)
+
+    def _set_ranks(self, neg_ctx_rank, neg_q_rank):
+        if neg_ctx_rank is None or neg_q_rank is None:
+            neg_ctx_rank, neg_q_rank = draw_negative_ranks(self.model, self.neg_ctx.shape[0])
+        self.neg_ctx.copy_(torch.as_tensor(neg_ctx_rank).to(torch.int32), non_blocking=True)
+        self.neg_q.copy_(torch.as_tensor(neg_q_rank).to(torch.int32), non_blocking=True)
+
+    def _body(self, captured=False):
+        opt = self.opt
+        loss, parts = xml_forward_train(self.model, neg_ctx_rank=self.neg_ctx, neg_q_rank=self.neg_q, as_tensors=True,
+                                        **self.static)
+        opt.flat_g.zero_()
+        loss.backward()
+        if self.grad_clip != -1:
+            T.clip_grad_norm(opt.flat_g, self.grad_clip)
+        d = opt.defaults
+        if captured:
+            T.bert_adam_step(opt.flat_p, opt.flat_g, opt.flat_m, opt.flat_v, opt.seg_off, opt.seg_lr, opt.seg_wd, opt.norms,
+                             0.0, d["b1"], d["b2"], d["e"], d["max_grad_norm"], self.seg_active, self.lr_mult)
+        else:
+            opt.step()
+        return loss.detach(), parts
+
+    def __call__(self, batch=None, neg_ctx_rank=None, neg_q_rank=None):
+        """batch: dict of the XML.forward keyword arguments with the shapes given at construction (None: keep the resident
+        batch).  neg_*_rank: inject the in-batch negatives (parity tests); default: drawn like the reference draws them."""
+        if batch is not None:
+            for k, v in batch.items():
+                if k in self.static and torch.is_tensor(v):
+                    if tuple(v.shape) != tuple(self.static[k].shape):
+                        raise ValueError("GraphedTrainStep was captured for %s %s, got %s" % (k, tuple(self.static[k].shape),
+                                                                                              tuple(v.shape)))
+                    self.static[k].copy_(v, non_blocking=True)
+        self._set_ranks(neg_ctx_rank if neg_ctx_rank is not None else (batch or {}).get("neg_ctx_rank"),
+                        neg_q_rank if neg_q_rank is not None else (batch or {}).get("neg_q_rank"))
+        opt = self.opt
+        # the set of tensors this graph updates was frozen at capture; each runs its own schedule step (xml/optimization.py:325-330)
+        mults = [opt.lr_multiplier(s_) if a else 0.0 for s_, a in zip(opt.seg_steps, self.active)]
+        self.lr_mult.copy_(torch.tensor(mults, dtype=F32), non_blocking=True)
+        self.graph.replay()
+        opt._commit_step(self.active)
+        return self.loss, self.parts
 
 
 class GradientReducer(object):

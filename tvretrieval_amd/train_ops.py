@@ -149,6 +149,15 @@ def gemm_tn(a, b, colsum=False, out=None, colsum_out=None):
 
 DISABLE_FUSED_ATTENTION = False      # tests / A-B measurements: keep the unfused chain for bf16 too
 
+# Device-resident base seed (int64 (1,) tensor) that the dropout kernels ADD to the seed they are given, or None.  A training
+# step captured into a HIP graph (train.GraphedTrainStep) sets it: the per-site seeds frozen into the graph's nodes are
+# constants, the base seed is advanced by a node of the graph itself, so every replay draws fresh masks.
+SEED_BASE = None
+
+
+def _seed_base_ptr():
+    return None if SEED_BASE is None else ctypes.c_void_p(SEED_BASE.data_ptr())
+
 
 def attention_train_supported(lq, lk, hidden, heads, dtype):
     if DISABLE_FUSED_ATTENTION:
@@ -168,8 +177,8 @@ def attention_train_fwd(q, k, v, q_mask, k_mask, heads, hidden, p_drop, seed, q_
     out = torch.empty((n, lq, hidden), dtype=q.dtype, device=q.device)
     check(_lib.load().xml_attention_train_fwd(_col_ptr(q, q_col), q.shape[2], _col_ptr(k, k_col), k.shape[2],
                                               _col_ptr(v, v_col), v.shape[2], _p(q_mask), _p(k_mask), _p(out), hidden, n, lq,
-                                              lk, hidden, heads, float(p_drop), int(seed), dt_of(q), _stream()),
-          "xml_attention_train_fwd")
+                                              lk, hidden, heads, float(p_drop), int(seed), _seed_base_ptr(), dt_of(q),
+                                              _stream()), "xml_attention_train_fwd")
     return out
 
 
@@ -182,7 +191,7 @@ def attention_train_bwd(q, k, v, q_mask, k_mask, dout, dq, dk, dv, heads, hidden
                                               _col_ptr(v, v_col), v.shape[2], _p(q_mask), _p(k_mask), _p(dout), dout.shape[2],
                                               _col_ptr(dq, dq_col), dq.shape[2], _col_ptr(dk, dk_col), dk.shape[2],
                                               _col_ptr(dv, dv_col), dv.shape[2], n, lq, lk, hidden, heads, float(p_drop),
-                                              int(seed), dt_of(q), _stream()), "xml_attention_train_bwd")
+                                              int(seed), _seed_base_ptr(), dt_of(q), _stream()), "xml_attention_train_bwd")
 
 
 def attn_softmax_fwd(s, q_mask, k_mask, n, heads, lq, lk, dh, dtype, want_t=False):
@@ -300,7 +309,8 @@ def dropout(x, p, seed, out=None):
     """y = mask(seed) * x / (1 - p); the same call on a gradient is the backward pass."""
     _req(x, "x")
     y = torch.empty_like(x) if out is None else out
-    check(_lib.load().xml_dropout(_p(x), _p(y), x.numel(), float(p), int(seed), dt_of(x), _stream()), "xml_dropout")
+    check(_lib.load().xml_dropout(_p(x), _p(y), x.numel(), float(p), int(seed), _seed_base_ptr(), dt_of(x), _stream()),
+          "xml_dropout")
     return y
 
 

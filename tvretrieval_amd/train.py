@@ -116,14 +116,50 @@ def _cross_context(model, main, main_mask, side, side_mask, cross, norm, self_at
     return _bert_attention(self_att, res, main_mask, dt)
 
 
+PARALLEL_BRANCHES = True      # video / subtitle branches of the training graph on two HIP streams
+_SIDE_STREAMS = {}
+
+
+def _side_stream(dev, which=0):
+    key = (torch.device(dev).index, which)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _SIDE_STREAMS[key]
+
+
 def encode_context_train(model, video_feat, video_mask, sub_feat, sub_mask):
     """encode_context (xml/model_xml.py:331-355,297-329) with gradient tape."""
     cfg = model.config
     dt = model.compute_dtype
     if cfg.cross_att:
-        ev = _encode_input(model, video_feat, video_mask, model.video_input_proj, model.video_encoder1,
-                           model.ctx_pos_embed)
-        es = _encode_input(model, sub_feat, sub_mask, model.sub_input_proj, model.sub_encoder1, model.ctx_pos_embed)
+        enc_v = lambda: _encode_input(model, video_feat, video_mask, model.video_input_proj, model.video_encoder1,    # noqa: E731
+                                      model.ctx_pos_embed)
+        enc_s = lambda: _encode_input(model, sub_feat, sub_mask, model.sub_input_proj, model.sub_encoder1,           # noqa: E731
+                                      model.ctx_pos_embed)
+        if PARALLEL_BRANCHES and video_feat.is_cuda:
+            # The video and the subtitle stream are independent until the cross-attention, and again after it.  At the C5
+            # shape one projection is 150 tiles of 256 x 256 on 256 CUs: issued on TWO HIP streams, the two branches' kernels
+            # share the chip (and autograd runs each backward node on its forward stream, so the backward pass overlaps the
+            # same way).  In a captured step (GraphedTrainStep) the two streams are parallel branches of the graph.
+            dev = video_feat.device
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_stream(main)
+            ev = enc_v()
+            with torch.cuda.stream(side):
+                es = enc_s()
+            main.wait_stream(side)
+            side.wait_stream(main)
+            es.record_stream(main)
+            ev.record_stream(side)
+            xv = _cross_context(model, ev, video_mask, es, sub_mask, model.video_cross_att, model.video_cross_layernorm,
+                                model.video_encoder2)
+            with torch.cuda.stream(side):
+                xs = _cross_context(model, es, sub_mask, ev, video_mask, model.sub_cross_att, model.sub_cross_layernorm,
+                                    model.sub_encoder2)
+            main.wait_stream(side)
+            xs.record_stream(main)
+            return ev, xv, es, xs
+        ev, es = enc_v(), enc_s()
         xv = _cross_context(model, ev, video_mask, es, sub_mask, model.video_cross_att, model.video_cross_layernorm,
                             model.video_encoder2)
         xs = _cross_context(model, es, sub_mask, ev, video_mask, model.sub_cross_att, model.sub_cross_layernorm,
@@ -161,6 +197,8 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
     fm = lambda m: None if m is None else m.float().contiguous()       # noqa: E731
     query_mask, video_mask, sub_mask = fm(query_mask), fm(video_mask), fm(sub_mask)
     v1, v2, s1, s2 = encode_context_train(model, video_feat, video_mask, sub_feat, sub_mask)
+    # (the query encoder on a THIRD stream was measured and not kept: 5.54 vs 5.04 ms per captured step -- its small kernels
+    # then interleave with the two context branches and break up their pairing)
     enc_q = _encode_input(model, query_feat, query_mask, model.query_input_proj, model.query_encoder,
                           model.query_pos_embed)
     mq = ModularPoolFn.apply(enc_q, query_mask, model.modular_vector_mapping.weight)

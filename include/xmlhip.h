@@ -88,6 +88,24 @@ int xml_attention_block(const void* x, const float* key_mask, const void* wqkv, 
                         size_t ws_bytes, xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * K3+K4 and K5 on PACKED variable-length sequences: the query encoder without its padding rows.
+ * The reference pads every query to the batch maximum (start_end_dataset.py:346-359; TVR: 30 tokens, mean 17.5 valid)
+ * and computes all padded rows; here the valid tokens of n sequences lie back to back -- x / y (rows, hidden),
+ * sequence i = rows cu_seqlens[i] .. cu_seqlens[i+1]-1 (cu_seqlens: n+1 int32, cu_seqlens[n] == rows), every sequence
+ * 1 .. max_len <= 32 tokens.  Per valid token the result is that of xml_attention_block / xml_modular_pool on the padded
+ * batch: projections and LayerNorm are row-wise, and a padded key adds exp(-10000 + s - max) = +0 to the softmax sum and
+ * 0 * v to P V.  (K1+K2 on packed rows is xml_linear_ln_relu_pos with seq_len = rows and the positional rows gathered per
+ * token.)  hidden % (32 * n_heads) == 0 as for xml_attention_block; xml_modular_pool_varlen: hidden <= 1024.
+ * --------------------------------------------------------------------------------------------- */
+size_t xml_attention_block_varlen_workspace_bytes(int64_t rows, int hidden, int dt);
+int xml_attention_block_varlen(const void* x, const int32_t* cu_seqlens, const void* wqkv, const float* bqkv,
+                               const void* wo, const float* bo, const float* ln_g, const float* ln_b, void* y,
+                               int64_t rows, int64_t n, int max_len, int hidden, int n_heads, int dt, void* ws,
+                               size_t ws_bytes, xml_stream_t stream);
+int xml_modular_pool_varlen(const void* enc, const int32_t* cu_seqlens, const float* w_m, void* out, int64_t n,
+                            int max_len, int hidden, int n_mod, int dt, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Cross-attention step of XML.cross_context_encoder (xml/model_xml.py:369-371):
  *   y = LN( MHA(q=main, k=v=side, mask = main_mask (x) side_mask) + main )
  *   main (n, lq, hidden), side (n, lk, hidden) dt; masks f32

@@ -517,6 +517,39 @@ def test_pad_tail_gives_the_reference_row_count():
     assert all(len(e["predictions"]) < 800 for e in short["SVMR"])
 
 
+@pytest.mark.parametrize("dtype,hidden,nq", [(torch.float32, 128, 700), (torch.bfloat16, 768, 3000), (torch.float32, 768, 600)])
+def test_packed_query_encode_equals_padded(dtype, hidden, nq, monkeypatch):
+    """encode_query on the packed valid tokens (xml_attention_block_varlen / xml_modular_pool_varlen, no padding rows) gives
+    the padded path's query vectors: projections and LayerNorms are row-wise, a padded key adds +0 to the softmax."""
+    from tvretrieval_amd import model_xml
+    m, cfg = _synthetic_model("video_sub", hidden, 256, 128, 128, 64, dtype, seed=2)
+    rng = np.random.default_rng(4)
+    lens = rng.integers(1, 31, nq)
+    lens[0], lens[1] = 30, 1
+    qf, qm = _feats(nq, lens, 128, 9)
+    qf, qm = qf.to(DEV), qm.to(DEV)
+    with torch.no_grad():
+        monkeypatch.setattr(model_xml, "PACK_QUERY_TOKENS", False)
+        v0, s0 = m.encode_query(qf, qm)
+        monkeypatch.setattr(model_xml, "PACK_QUERY_TOKENS", True)
+        assert m._encode_query_packed(qf, qm) is not None
+        v1, s1 = m.encode_query(qf, qm)
+        # a mask that is not a prefix of ones (or an empty query) keeps the padded path
+        qm2 = qm.clone()
+        qm2[0, 3] = 0
+        assert m._encode_query_packed(qf, qm2) is None
+    # f32: the same arithmetic per valid token.  bf16: the packed batch has fewer rows, so a projection may run on another
+    # GEMM kernel of the family (LayerNorm in the epilogue or behind it: one rounding of the pre-LN value more or less) --
+    # a couple of bf16 ulps on single elements, nothing systematic
+    for a, b, nm in ((v1, v0, "video query"), (s1, s0, "sub query")):
+        d_ = (a.float() - b.float()).abs()
+        scale = max(1.0, float(b.float().abs().max()))
+        if dtype == torch.float32:
+            assert float(d_.max()) <= 2e-6 * scale, (nm, float(d_.max()))
+        else:
+            assert float(d_.max()) <= 0.012 * scale and float(d_.mean()) <= 1e-3 * scale, (nm, float(d_.max()), float(d_.mean()))
+
+
 def test_hip_graph_replay_equals_eager():
     """GraphedVcmrSearch (one HIP graph per query-batch shape) returns exactly what the eager pass returns, for
     several different batches replayed through the same graph."""

@@ -41,6 +41,12 @@ SIGNATURES = {
     "xml_attention_block_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "xml_attention_block": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "xml_attention_block_varlen_workspace_bytes": (c_size_t, [c_int64, c_int, c_int]),
+    "xml_attention_block_varlen": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                           c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t,
+                                           c_void_p]),
+    "xml_modular_pool_varlen": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
+                                        c_void_p]),
     "xml_cross_attention_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
     "xml_cross_attention": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,

@@ -306,7 +306,11 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
                                                                    const float* __restrict__ q_mask,
                                                                    const float* __restrict__ k_mask,
                                                                    OutT* __restrict__ out, int ldo, int lq, int lk,
-                                                                   int n_heads, int64_t n_units, float sqrt_dh) {
+                                                                   int n_heads, int64_t n_units, float sqrt_dh,
+                                                                   const int32_t* __restrict__ cu) {
+  // cu != NULL (packed / variable-length self-attention, xml_attention_block_varlen): sequence n is rows cu[n] .. cu[n+1]-1
+  // of Q / K / V / out, every key valid; lq == lk is then the LONGEST sequence (it sizes the LDS strides), the unit's own
+  // length drives the loads, the masks and the loops.
   constexpr int CE = ChunkOf<T>::elems;
   constexpr int VEC = 16 / (int)sizeof(T);
   constexpr int DCH = DH / CE;
@@ -320,10 +324,17 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
   const int64_t n = unit / n_heads;
   const int head = (int)(unit - n * n_heads);
   const int fr = lane & 15, fg = lane >> 4;
+  const int lkp_max = (lk + CE - 1) / CE * CE;
+  int64_t row_q = n * lq, row_k = n * lk;       // first row of this unit's sequence in Q / out and in K / V
+  if (cu) {
+    const int r0 = __builtin_amdgcn_readfirstlane(cu[n]), r1 = __builtin_amdgcn_readfirstlane(cu[n + 1]);
+    row_q = row_k = r0;
+    lq = lk = r1 - r0;
+  }
   const int lkp = (lk + CE - 1) / CE * CE;
   const int nkt = (lk + 15) / 16;
   const int k_stride = DH * (int)sizeof(T) + 16;
-  const int vt_stride = lkp * (int)sizeof(T) + 16;
+  const int vt_stride = lkp_max * (int)sizeof(T) + 16;
   constexpr bool TR = sizeof(T) == 2;         // bf16: V stays row-major, P V reads it with ds_read_b64_tr_b16 (see above)
   const int kv_bytes = TR ? 32 * k_stride : max(32 * k_stride, DH * vt_stride);
   const int wave_bytes = kv_bytes + 16 * vt_stride;
@@ -334,9 +345,9 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
     __builtin_amdgcn_wave_barrier();
   };
 
-  const T* qbase = Q + n * lq * ldq + head * DH;
-  const T* kbase = Kp + n * lk * ldk + head * DH;
-  const T* vbase = Vp + n * lk * ldv + head * DH;
+  const T* qbase = Q + row_q * ldq + head * DH;
+  const T* kbase = Kp + row_k * ldk + head * DH;
+  const T* vbase = Vp + row_k * ldv + head * DH;
 
   constexpr int VPR = DH / VEC;               // 16-byte vectors per row
   constexpr int NV = 32 * VPR / 64;           // vectors per lane of a 32-row tile
@@ -385,7 +396,7 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
 #pragma unroll
   for (int j = 0; j < NT; ++j) {
     const int col = j * 16 + fr;
-    km[j] = (col < lk) ? k_mask[n * lk + col] : 0.f;
+    km[j] = (col < lk) ? (cu ? 1.f : k_mask[row_k + col]) : 0.f;
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -403,7 +414,7 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = t * 16 + fg * 4 + r;
-      const float qm = (q_mask && row < lq) ? q_mask[n * lq + row] : 1.f;
+      const float qm = (q_mask && row < lq) ? q_mask[row_q + row] : 1.f;
       float mx = -INFINITY;
 #pragma unroll
       for (int j = 0; j < NT; ++j) {
@@ -492,7 +503,7 @@ __global__ __launch_bounds__(256) void attention_core_small_kernel(const T* __re
     for (int r = 0; r < 4; ++r) {
       const int row = t * 16 + fg * 4 + r;
       if (row >= lq) continue;
-      OutT* po = out + (n * lq + row) * ldo + head * DH;
+      OutT* po = out + (row_q + row) * ldo + head * DH;
 #pragma unroll
       for (int d = 0; d < DT16; ++d) DT<OutT>::st(po + d * 16 + fr, o[d][r]);
     }
@@ -529,7 +540,7 @@ static int launch_attn(const void* q, int ldq, const void* k, int ldk, const voi
       const int64_t units = n * n_heads;
       hipLaunchKernelGGL(ks, dim3((unsigned)((units + 3) / 4)), dim3(256), lds_s, st, (const T*)q, ldq, (const T*)k, ldk,
                          (const T*)v, ldv, q_mask, k_mask, (OutT*)out, hidden, lq, lk, n_heads, units,
-                         sqrtf((float)DH));
+                         sqrtf((float)DH), (const int32_t*)nullptr);
       XML_CHECK_LAUNCH();
       return XML_OK;
     }
@@ -626,6 +637,75 @@ extern "C" int xml_attention_block(const void* x, const float* key_mask, const v
 }
 
 // ---------------------------------------------------------------------------------------------------
+// public: BertAttention block on PACKED variable-length sequences (the query encoder without its padding rows).
+//   x / y (rows, hidden): the valid tokens of n sequences back to back, sequence i = rows cu[i] .. cu[i+1]-1, every
+//   sequence 1 .. max_len <= 32 tokens long.  Same arithmetic per valid token as xml_attention_block on the padded batch:
+//   the projections and the LayerNorm are row-wise, and a padded key contributes exp(-10000 + s - max) = +0 to the softmax
+//   and 0 * v to P V, so dropping it changes nothing.   ws = [ qkv | att | pre-LN f32 or LN partials ] as above.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int DH>
+static int launch_attn_varlen(const char* qkv, int hidden, const int32_t* cu, void* att, int64_t n, int max_len,
+                              int n_heads, int dt, hipStream_t st) {
+  const size_t lds_s = attn_small_lds_bytes(max_len, DH, dt);
+  if (lds_s > 160 * 1024) return XML_ERR_UNSUPPORTED;
+  if (lds_s > 64 * 1024 && !xml_lds_attr_once<attention_core_small_kernel<T, T, DH>>(160 * 1024)) return XML_ERR_LAUNCH;
+  const int64_t units = n * n_heads;
+  const T* q = (const T*)qkv;
+  hipLaunchKernelGGL((attention_core_small_kernel<T, T, DH>), dim3((unsigned)((units + 3) / 4)), dim3(256), lds_s, st, q,
+                     3 * hidden, q + hidden, 3 * hidden, q + 2 * hidden, 3 * hidden, (const float*)nullptr,
+                     (const float*)nullptr, (T*)att, hidden, max_len, max_len, n_heads, units, sqrtf((float)DH), cu);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+extern "C" size_t xml_attention_block_varlen_workspace_bytes(int64_t rows, int hidden, int dt) {
+  const size_t pre = align_up((size_t)rows * hidden * 4, 256);
+  const size_t lnw = xmli_gemm_ln_eligible(rows, hidden, hidden, dt) ? xmli_gemm_ln_workspace_bytes(rows, hidden) : 0;
+  return align_up((size_t)rows * 3 * hidden * dt_size(dt), 256) + align_up((size_t)rows * hidden * dt_size(dt), 256) +
+         (pre > lnw ? pre : lnw);
+}
+
+extern "C" int xml_attention_block_varlen(const void* x, const int32_t* cu_seqlens, const void* wqkv, const float* bqkv,
+                                          const void* wo, const float* bo, const float* ln_g, const float* ln_b, void* y,
+                                          int64_t rows, int64_t n, int max_len, int hidden, int n_heads, int dt, void* ws,
+                                          size_t ws_bytes, xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !cu_seqlens || !wqkv || !bqkv || !wo || !bo || !ln_g || !ln_b || !y || !ws) return XML_ERR_BAD_ARG;
+  if (rows <= 0 || n <= 0 || max_len <= 0 || n_heads <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (max_len > 32 || hidden % 8 || hidden % n_heads) return XML_ERR_UNSUPPORTED;
+  if (ws_bytes < xml_attention_block_varlen_workspace_bytes(rows, hidden, dt)) return XML_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* qkv = (char*)ws;
+  char* att = qkv + align_up((size_t)rows * 3 * hidden * dt_size(dt), 256);
+  char* pre = att + align_up((size_t)rows * hidden * dt_size(dt), 256);
+  int rc = xmli_gemm(x, wqkv, bqkv, nullptr, qkv, rows, 3 * hidden, hidden, 0, 0, 1, 0, dt, st);
+  if (rc) return rc;
+  const int dh = hidden / n_heads;
+  rc = XML_ERR_UNSUPPORTED;
+#define XML_VL_CASE(D)                                                                                              \
+  case D:                                                                                                           \
+    rc = dt == XML_F32 ? launch_attn_varlen<float, D>(qkv, hidden, cu_seqlens, att, n, max_len, n_heads, dt, st)    \
+                       : launch_attn_varlen<bf16_t, D>(qkv, hidden, cu_seqlens, att, n, max_len, n_heads, dt, st);  \
+    break;
+  switch (dh) {
+    XML_VL_CASE(32)
+    XML_VL_CASE(64)
+    XML_VL_CASE(96)
+    XML_VL_CASE(128)
+    XML_VL_CASE(192)
+    default: break;
+  }
+#undef XML_VL_CASE
+  if (rc) return rc;
+  if (xmli_gemm_ln_eligible(rows, hidden, hidden, dt) && y != x &&
+      xmli_gemm_ln(att, wo, bo, x, ln_g, ln_b, y, rows, hidden, hidden, 0, /*residual*/ 2, 1, dt, pre, st) == XML_OK)
+    return XML_OK;
+  rc = xmli_gemm(att, wo, bo, x, pre, rows, hidden, hidden, 0, /*residual*/ 2, 1, /*out_f32*/ 1, dt, st);
+  if (rc) return rc;
+  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_g, ln_b, y, rows, hidden, hidden, dt, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
 // public: cross-attention + residual LayerNorm.
 //   ws = [ q (n*lq x H) dt | kv (n*lk x 2H) dt | att f32 (n*lq x H) ]
 // ---------------------------------------------------------------------------------------------------
@@ -709,12 +789,20 @@ __global__ __launch_bounds__(256) void modular_pool_kernel(const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(256) void modular_pool_small_kernel(const T* __restrict__ enc, const float* __restrict__ mask,
                                                                  const float* __restrict__ wm, T* __restrict__ out,
-                                                                 int64_t n, int lq, int hidden, int n_mod) {
+                                                                 int64_t n, int lq, int hidden, int n_mod,
+                                                                 const int32_t* __restrict__ cu) {
+  // cu != NULL (xml_modular_pool_varlen): packed tokens, query q = rows cu[q] .. cu[q+1]-1, all valid (mask unused)
   __shared__ float s_att[2][32];
   __shared__ float s_part[4][2][1024];
   const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nvec = hidden >> 3;
-  const T* e = enc + (int64_t)q * lq * hidden;
+  int64_t row0 = (int64_t)q * lq;
+  if (cu) {
+    const int r0 = cu[q], r1 = cu[q + 1];
+    row0 = r0;
+    lq = r1 - r0;
+  }
+  const T* e = enc + row0 * hidden;
   float x[8][16];                       // up to 8 tokens per wave, 2 vectors of 8 per lane
   float w0[16], w1[16];
   // Every load of this kernel is UNCONDITIONAL, from a clamped (always valid) index, and zeroed by a select afterwards: with
@@ -732,7 +820,7 @@ __global__ __launch_bounds__(256) void modular_pool_small_kernel(const T* __rest
   for (int t = 0; t < 8; ++t) {
     const int l = wave + t * 4;
     const int lc = l < lq ? l : 0;
-    mk8[t] = mask[(int64_t)q * lq + lc];
+    mk8[t] = cu ? 1.f : mask[row0 + lc];
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
       const int v = lane + k * 64;
@@ -827,10 +915,10 @@ extern "C" int xml_modular_pool(const void* enc, const float* mask, const float*
   if (lq <= 32 && hidden % 8 == 0 && hidden <= 1024) {
     if (dt == XML_F32)
       hipLaunchKernelGGL(modular_pool_small_kernel<float>, dim3((unsigned)n), dim3(256), 0, st, (const float*)enc, mask,
-                         w_m, (float*)out, n, lq, hidden, n_mod);
+                         w_m, (float*)out, n, lq, hidden, n_mod, (const int32_t*)nullptr);
     else if (dt == XML_BF16)
       hipLaunchKernelGGL(modular_pool_small_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, st, (const bf16_t*)enc,
-                         mask, w_m, (bf16_t*)out, n, lq, hidden, n_mod);
+                         mask, w_m, (bf16_t*)out, n, lq, hidden, n_mod, (const int32_t*)nullptr);
     else
       return XML_ERR_BAD_ARG;
     XML_CHECK_LAUNCH();
@@ -842,6 +930,26 @@ extern "C" int xml_modular_pool(const void* enc, const float* mask, const float*
   else if (dt == XML_BF16)
     hipLaunchKernelGGL(modular_pool_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, st, (const bf16_t*)enc, mask,
                        w_m, (bf16_t*)out, n, lq, hidden, n_mod);
+  else
+    return XML_ERR_BAD_ARG;
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// K5 on packed variable-length queries (xml_attention_block_varlen's layout): out[m][q] = sum_l a[l][m] enc[cu[q] + l],
+// a = softmax over the query's own tokens.  max_len <= 32, hidden % 8 == 0, hidden <= 1024, every query >= 1 token.
+extern "C" int xml_modular_pool_varlen(const void* enc, const int32_t* cu_seqlens, const float* w_m, void* out, int64_t n,
+                                       int max_len, int hidden, int n_mod, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!enc || !cu_seqlens || !w_m || !out || n <= 0 || max_len <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
+  if (n_mod < 1 || n_mod > 2 || max_len > 32 || hidden % 8 || hidden > 1024) return XML_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(modular_pool_small_kernel<float>, dim3((unsigned)n), dim3(256), 0, st, (const float*)enc,
+                       (const float*)nullptr, w_m, (float*)out, n, max_len, hidden, n_mod, cu_seqlens);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(modular_pool_small_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, st, (const bf16_t*)enc,
+                       (const float*)nullptr, w_m, (bf16_t*)out, n, max_len, hidden, n_mod, cu_seqlens);
   else
     return XML_ERR_BAD_ARG;
   XML_CHECK_LAUNCH();

@@ -537,3 +537,32 @@ def exact_certificate(filter_scores, top_val, eq, ec, slack, alpha, outside):
                                             float(ec[j]), n_mod, float(slack), float(alpha), int(bool(outside)), _p(fail),
                                             _p(eps), _p(n_fail), nq, _stream()), "xml_exact_certificate")
     return fail, eps, n_fail
+
+
+# ---- packed variable-length sequences (the query encoder without its padding rows) -------------------------------------
+def attention_block_varlen(x, cu_seqlens, n, max_len, wqkv, bqkv, wo, bo, ln_g, ln_b, n_heads):
+    """K3+K4 on packed tokens.  x (rows, H); cu_seqlens (n + 1,) int32 -> (rows, H)."""
+    _req(x, "x"); _req(cu_seqlens, "cu_seqlens", torch.int32); _req(wqkv, "wqkv", x.dtype); _req(wo, "wo", x.dtype)
+    for t, nm in ((bqkv, "bqkv"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b")):
+        _req(t, nm, torch.float32)
+    rows, hidden = x.shape
+    assert cu_seqlens.numel() == n + 1
+    lib = _lib.load()
+    dt = dt_of(x)
+    y = torch.empty_like(x)
+    ws = _workspace(lib.xml_attention_block_varlen_workspace_bytes(rows, hidden, dt), x.device)
+    check(lib.xml_attention_block_varlen(_p(x), _p(cu_seqlens), _p(wqkv), _p(bqkv), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(y),
+                                         rows, n, int(max_len), hidden, n_heads, dt, _p(ws), ws.numel(), _stream()),
+          "xml_attention_block_varlen")
+    return y
+
+
+def modular_pool_varlen(enc, cu_seqlens, n, max_len, w_m):
+    """K5 on packed tokens.  enc (rows, H); w_m (n_mod, H) f32 -> (n_mod, n, H)."""
+    _req(enc, "enc"); _req(cu_seqlens, "cu_seqlens", torch.int32); _req(w_m, "w_m", torch.float32)
+    hidden = enc.shape[1]
+    n_mod = w_m.shape[0]
+    out = torch.empty((n_mod, n, hidden), dtype=enc.dtype, device=enc.device)
+    check(_lib.load().xml_modular_pool_varlen(_p(enc), _p(cu_seqlens), _p(w_m), _p(out), n, int(max_len), hidden, n_mod,
+                                              dt_of(enc), _stream()), "xml_modular_pool_varlen")
+    return out

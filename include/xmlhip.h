@@ -242,16 +242,24 @@ int xml_topk_rows(const float* scores, int64_t ld, const int32_t* idx_in, float*
  *     the f32 accumulation error of the dot products; outside = 1 if videos exist outside the candidate set (nv > m).
  *     fail[q] = outside && !( filter_scores[q, m-1] + eps_q < top_val[q, k-1] ),
  *     eps_q = mean_m( eq_m[q] * c + (c + eq_m[q]) * ec_m ) + slack, c = 1 + 1e-6 (Cauchy-Schwarz on the two rounding errors).
- *     eps_out (nq) f32 or NULL; *n_fail (int32, zeroed by the caller) += number of failing queries.
+ *     eps_out (nq) f32 or NULL; thr_out (nq) f32 or NULL = top_val[q, k-1] (raw) - eps_q, the second-tier line of
+ *     xml_select_ge_rows; *n_fail (int32, zeroed by the caller) += number of failing queries.
  * --------------------------------------------------------------------------------------------- */
 int xml_round_bf16_rows_err(const float* y, void* yb, float* err, int64_t rows, int d, xml_stream_t stream);
+/* Second tier of the exact-rank mode: per row of scores (rows, n) f32 (row stride ld) the columns whose value is >= thr[row].
+ * idx == NULL: cnt[row] = how many.  idx (rows, cap) int32: the first cap of them in unspecified order (entries beyond
+ * cnt[row] are left untouched), cnt[row] = how many exist.  With thr = T_k - eps_q of xml_exact_certificate these are ALL
+ * videos that can still belong to a failing query's f32 top-k: T_k (the k-th re-scored value over the first candidates) is a
+ * lower bound of the final k-th score, and a video below thr has an f32 score < thr + eps_q = T_k. */
+int xml_select_ge_rows(const float* scores, int64_t ld, const float* thr, int32_t* idx, int cap, int32_t* cnt, int rows,
+                       int n, xml_stream_t stream);
 size_t xml_q2c_rescore_workspace_bytes(int nq, int nv, int kpairs);
 int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, const void* cn0, const void* cn1, const float* mask0,
                     const float* mask1, const int32_t* pair_vid, float* out, int nq, int nv, int kpairs, int lpad,
                     int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream);
 int xml_exact_certificate(const float* filter_scores, int m, float* top_val, int k, const float* eq0, const float* eq1,
                           float ec0, float ec1, int n_mod, float slack, float alpha, int outside, int32_t* fail,
-                          float* eps_out, int32_t* n_fail, int nq, xml_stream_t stream);
+                          float* eps_out, float* thr_out, int32_t* n_fail, int nq, xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K7: similarity contraction #2 + ConvSE start/end scorer on selected (query, video) pairs

@@ -85,17 +85,34 @@ def test_exact_certificate_kernel(ops):
     eps = sum(e * c + (c + e) * x for e, x in zip(eq, ec)) / 2 + slack
     want_fail = ~(filt[:, -1] + eps < top[:, -1])
     tv = top.clone().to(DEV)
-    fail, eps_g, n_fail = ops.exact_certificate(filt.to(DEV), tv, [e.to(DEV) for e in eq], ec, slack, alpha, True)
+    fail, eps_g, thr_g, n_fail = ops.exact_certificate(filt.to(DEV), tv, [e.to(DEV) for e in eq], ec, slack, alpha, True)
     margin = (filt[:, -1] + eps - top[:, -1]).abs() > 1e-6            # (f32 vs f64 evaluation of the same inequality)
     assert torch.equal(fail.cpu().bool()[margin], want_fail[margin])
     assert int(n_fail.item()) == int(fail.sum().item()) and 0 < int(n_fail.item()) < nq
     close("eps", eps_g, eps, 1e-8, 1e-5)
+    close("second-tier line", thr_g, top[:, -1] - eps, 1e-7, 1e-6)
     close("exp(alpha s)", tv, torch.exp(alpha * top), 0, 1e-6)
     # no videos outside the candidate set: nothing can fail; one modality
     tv = top.clone().to(DEV)
-    fail, _, n_fail = ops.exact_certificate(filt.to(DEV), tv, [eq[0].to(DEV)], ec[:1], slack, 0.0, False)
+    fail, _, _, n_fail = ops.exact_certificate(filt.to(DEV), tv, [eq[0].to(DEV)], ec[:1], slack, 0.0, False)
     assert int(n_fail.item()) == 0 and not bool(fail.any())
     assert torch.equal(tv.cpu(), top)                                   # alpha == 0: values untouched
+
+
+def test_select_ge_rows(ops):
+    g = torch.Generator().manual_seed(7)
+    s_ = torch.rand(37, 5000, generator=g)
+    thr = torch.rand(37, generator=g) * 0.1 + 0.9
+    thr[3] = 2.0                                                          # nothing reaches it
+    cnt = ops.select_ge_rows(s_.to(DEV), thr.to(DEV)).cpu()
+    want = (s_ >= thr[:, None]).sum(1)
+    assert torch.equal(cnt.long(), want) and int(cnt[3]) == 0
+    idx, cnt2 = ops.select_ge_rows(s_.to(DEV), thr.to(DEV), int(want.max()))
+    assert torch.equal(cnt2.cpu().long(), want)
+    for r in range(37):
+        got = sorted(idx[r, :int(want[r])].cpu().tolist())
+        assert got == torch.nonzero(s_[r] >= thr[r]).reshape(-1).tolist()
+        assert (idx[r, int(want[r]):] == -1).all()
 
 
 def _lists_equal(out, ref, l, kv, kn, what):
@@ -157,20 +174,20 @@ def test_exact_mode_equals_f32_path(ctx_mode, ragged, monkeypatch):
     print("exact mode (%s, ragged=%s): %d / %d queries fell back; %d video / %d moment positions swapped in f32 ties"
           % (ctx_mode, ragged, info["n_fail"], nq, n_v, n_m))
 
-    # every query forced through the fallback: bitwise the f32 path (all-pairs f32 K6 on the gathered queries) ...
+    # every query's certificate forced to fail.  Second tier (every video whose filter score reaches T_k - eps is re-scored
+    # too; with eps = 10 that is the whole corpus): the f32 path's lists again ...
     exact.exact.e_c = {k: 10.0 for k in exact.exact.e_c}
-    assert nq > inf.EXACT_SMALL_FALLBACK
     with torch.no_grad():
         forced = inf.vcmr_search(m, exact, qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=200)
-    assert forced["exact"]["n_fail"] == nq
+    assert forced["exact"]["n_fail"] == nq and forced["exact"]["n_full_rows"] == 0
+    _lists_equal(forced, ref, l, 10, 200, "second tier vs f32")
+    # ... and with the second tier capped away the fallback is the f32 K6 row itself: BITWISE the f32 path
+    monkeypatch.setattr(inf, "EXACT_TIER2_CAP", 0)
+    with torch.no_grad():
+        forced = inf.vcmr_search(m, exact, qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=200)
+    assert forced["exact"]["n_fail"] == nq and forced["exact"]["n_full_rows"] == nq
     for key in ("top_indices", "top_scores", "flat_indices", "flat_scores"):
         assert torch.equal(forced[key], ref[key]), key
-    # ... and through the few-failures form of the fallback (pair kernel over every video): the f32 path's lists again
-    monkeypatch.setattr(inf, "EXACT_SMALL_FALLBACK", 10 ** 6)
-    with torch.no_grad():
-        forced = inf.vcmr_search(m, exact, qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=200)
-    assert forced["exact"]["n_fail"] == nq
-    _lists_equal(forced, ref, l, 10, 200, "small fallback vs f32")
 
     # and the oracle (reference formulation) on the same inputs
     om = O.OracleXML(cfg, {k: v.detach().cpu() for k, v in m.state_dict().items()})

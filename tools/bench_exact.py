@@ -93,7 +93,7 @@ def run(nq, nv, init, n_compare, log=lambda s: None, steps=1, warmup=2):
         cr, st["rescore_f32"] = timed(lambda: ops.q2c_rescore(qn, f32rows, masks, ci))
         (tw, ti), st["k8_top100_of_candidates"] = timed(lambda: ops.topk_rows(cr, 100, alpha=0.0, idx_in=ci))
         t100 = tw[:, -1].clone()
-        (fail, eps, n_fail), st["certificate"] = timed(lambda: ops.exact_certificate(
+        (fail, eps, _thr, n_fail), st["certificate"] = timed(lambda: ops.exact_certificate(
             cs, tw, eq, [ex.e_c[m] for m in mods], inf.exact_slack(hidden), 20.0, nv > m_c))
         (s_t, e_t), st["convse_k7_f32"] = timed(lambda: inf.stage_span_probs(model, index, qvec, ti, ops))
         _, st["moment_k9"] = timed(lambda: ops.moment_topk(s_t, e_t, tw, l, 2, 16, 200))

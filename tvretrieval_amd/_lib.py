@@ -73,11 +73,12 @@ SIGNATURES = {
                               c_void_p, c_size_t, c_void_p]),
     # ---- exact-rank mode (exact.hip, convse.hip) ----
     "xml_round_bf16_rows_err": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "xml_select_ge_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "xml_q2c_rescore_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "xml_q2c_rescore": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                 c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "xml_exact_certificate": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_float, c_float, c_int,
-                                      c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+                                      c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "xml_convse_rerank_workspace_bytes": (c_size_t, [ctypes.POINTER(ConvseDesc)]),
     "xml_convse_rerank": (c_int, [ctypes.POINTER(ConvseDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                   c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),

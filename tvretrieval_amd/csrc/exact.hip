@@ -18,6 +18,10 @@
 //                             accumulation bound of both dot products.  Queries that fail are re-done against the whole
 //                             corpus in f32 by the caller.  Also turns the raw top-k values into exp(alpha * s) (what K8
 //                             emits, xml/inference.py:317).
+//   xml_select_ge_rows        the second tier for the few queries whose certificate fails: every video whose FILTER score
+//                             reaches T_k - eps_q (the re-scored k-th value is a lower bound of the final one, so nothing
+//                             below that line can enter the top-k) -- usually a few dozen more than M; they are re-scored
+//                             like the first M and the lists re-selected, no second certificate needed.
 #include "common.h"
 
 namespace {
@@ -52,7 +56,7 @@ __global__ void exact_certificate_kernel(const float* __restrict__ filt, int m, 
                                          const float* __restrict__ eq0, const float* __restrict__ eq1, float ec0,
                                          float ec1, int n_mod, float slack, float alpha, int outside,
                                          int32_t* __restrict__ fail, float* __restrict__ eps_out,
-                                         int32_t* __restrict__ n_fail, int nq) {
+                                         float* __restrict__ thr_out, int32_t* __restrict__ n_fail, int nq) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
   const float c_norm = 1.f + 1e-6f;                       // | c | of an f32-normalised row
@@ -64,12 +68,48 @@ __global__ void exact_certificate_kernel(const float* __restrict__ filt, int m, 
   const int f = (outside && !(b_m + eps < t_k)) ? 1 : 0;
   fail[q] = f;
   if (eps_out) eps_out[q] = eps;
+  if (thr_out) thr_out[q] = t_k - eps;                    // second tier: filter scores below this line cannot enter the top-k
   if (f) atomicAdd(n_fail, 1);
   if (alpha != 0.f)
     for (int j = 0; j < k; ++j) top_val[(int64_t)q * k + j] = expf(alpha * top_val[(int64_t)q * k + j]);
 }
 
+// one workgroup per row: the columns whose score reaches the row's threshold.  idx == NULL: count only.
+__global__ __launch_bounds__(256) void select_ge_rows_kernel(const float* __restrict__ scores, int64_t ld, const float* __restrict__ thr,
+                                                             int32_t* __restrict__ idx, int cap, int32_t* __restrict__ cnt,
+                                                             int n) {
+  __shared__ int s_cnt;
+  const int row = blockIdx.x, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) s_cnt = 0;
+  __syncthreads();
+  const float t = thr[row];
+  const float* r = scores + (int64_t)row * ld;
+  for (int base = 0; base < n; base += 256) {
+    const int i = base + threadIdx.x;
+    const bool take = i < n && r[i] >= t;
+    const unsigned long long bal = __ballot(take);
+    if (bal) {
+      int off = 0;
+      const int leader = __ffsll((long long)bal) - 1;
+      if (lane == leader) off = atomicAdd(&s_cnt, (int)__popcll(bal));
+      off = __shfl(off, leader, 64) + (int)__popcll(bal & ((1ull << lane) - 1ull));
+      if (take && idx && off < cap) idx[(int64_t)row * cap + off] = i;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) cnt[row] = s_cnt;
+}
+
 }  // namespace
+
+extern "C" int xml_select_ge_rows(const float* scores, int64_t ld, const float* thr, int32_t* idx, int cap, int32_t* cnt,
+                                  int rows, int n, xml_stream_t stream) {
+  XML_ENTER();
+  if (!scores || !thr || !cnt || rows <= 0 || n <= 0 || ld < n || (idx && cap <= 0)) return XML_ERR_BAD_ARG;
+  hipLaunchKernelGGL(select_ge_rows_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, scores, ld, thr, idx, cap, cnt, n);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
 
 extern "C" int xml_round_bf16_rows_err(const float* y, void* yb, float* err, int64_t rows, int d, xml_stream_t stream) {
   XML_ENTER();
@@ -83,13 +123,14 @@ extern "C" int xml_round_bf16_rows_err(const float* y, void* yb, float* err, int
 
 extern "C" int xml_exact_certificate(const float* filter_scores, int m, float* top_val, int k, const float* eq0,
                                      const float* eq1, float ec0, float ec1, int n_mod, float slack, float alpha,
-                                     int outside, int32_t* fail, float* eps_out, int32_t* n_fail, int nq,
+                                     int outside, int32_t* fail, float* eps_out, float* thr_out, int32_t* n_fail, int nq,
                                      xml_stream_t stream) {
   XML_ENTER();
   if (!filter_scores || !top_val || !eq0 || !fail || !n_fail || nq <= 0 || m <= 0 || k <= 0 || k > m) return XML_ERR_BAD_ARG;
   if (n_mod < 1 || n_mod > 2 || (n_mod == 2 && !eq1)) return XML_ERR_BAD_ARG;
   hipLaunchKernelGGL(exact_certificate_kernel, dim3(cdiv(nq, 128)), dim3(128), 0, (hipStream_t)stream, filter_scores, m,
-                     top_val, k, eq0, eq1 ? eq1 : eq0, ec0, ec1, n_mod, slack, alpha, outside, fail, eps_out, n_fail, nq);
+                     top_val, k, eq0, eq1 ? eq1 : eq0, ec0, ec1, n_mod, slack, alpha, outside, fail, eps_out, thr_out, n_fail,
+                     nq);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -283,7 +283,7 @@ def stage_q2c(index, qvec, ops=hip_ops):
     return _k6(index, [ops.l2norm_rows(qvec[m].contiguous()) for m in index.modalities], ops)
 
 
-EXACT_SMALL_FALLBACK = 32     # failing queries up to which the fallback runs on the pair kernel instead of the K6 kernel
+EXACT_TIER2_CAP = 4096        # second-tier candidates per failing query beyond which the f32 K6 row is computed instead
 
 
 def exact_slack(hidden):
@@ -298,7 +298,9 @@ def stage_exact_topk(index, qvec, k, alpha, ops=hip_ops):
       2. K8 proposes the M best filter scores per query (raw values + ids);
       3. xml_q2c_rescore: those (q, v) pairs against the f32 operands -> f32 scores of the candidates;
       4. K8 again on the (Nq, M) re-scored values with the ids as payload: top-k by (score desc, id asc);
-      5. per-query certificate  b_M + eps_q < T_k ; the queries that fail get a full f32 K6 row (the f32 path itself).
+      5. per-query certificate  b_M + eps_q < T_k ; the few queries that fail get a second tier -- every video whose filter
+         score reaches T_k - eps_q (nothing below that line can enter the top-k) is re-scored too -- or, when the scores are
+         too close together for that (> EXACT_TIER2_CAP such videos), a full f32 K6 row (the f32 path itself).
     Returns (top_w = exp(alpha s) (Nq, k) f32, top_i (Nq, k) int32, info dict)."""
     ex = index.exact
     mods = index.modalities
@@ -316,23 +318,29 @@ def stage_exact_topk(index, qvec, k, alpha, ops=hip_ops):
     f32rows = [ex.feat1n_f32[m] for m in mods]
     cand_r = ops.q2c_rescore(qn, f32rows, masks, cand_i)
     top_w, top_i = ops.topk_rows(cand_r, k, alpha=0.0, idx_in=cand_i)
-    fail, eps, n_fail = ops.exact_certificate(cand_s, top_w, eq, [ex.e_c[m] for m in mods], exact_slack(qn[0].shape[1]),
-                                              alpha, index.n_videos > m_c)
-    nf = int(n_fail.item())        # (host sync: the fallback's launch shape depends on it)
+    fail, eps, thr_all, n_fail = ops.exact_certificate(cand_s, top_w, eq, [ex.e_c[m] for m in mods],
+                                                       exact_slack(qn[0].shape[1]), alpha, index.n_videos > m_c)
+    nf = int(n_fail.item())        # (host sync: the launch shapes below depend on it)
+    n_full = 0
     if nf:
         rows = torch.nonzero(fail, as_tuple=False).reshape(-1)
         qsub = [q.index_select(0, rows).contiguous() for q in qn]
-        if nf <= EXACT_SMALL_FALLBACK:
-            # a handful of queries: the pair kernel with EVERY video listed (one 64-row chunk per video, the f32 corpus
-            # streamed once) -- the all-pairs K6 kernel would pad them to a 256-query tile (16 ms for 12 queries)
-            allv = torch.arange(index.n_videos, dtype=torch.int32, device=rows.device).repeat(nf, 1).contiguous()
-            full = ops.q2c_rescore(qsub, f32rows, masks, allv)
-        else:
+        # Second tier: T_k (the k-th re-scored value) is a LOWER bound of the final k-th score, so only videos whose filter
+        # score reaches T_k - eps can still enter: usually a few dozen more than M.  Re-score exactly those.
+        thr = thr_all.index_select(0, rows).contiguous()
+        frows = filt.index_select(0, rows).contiguous()
+        cap = int(ops.select_ge_rows(frows, thr).max())
+        if cap <= EXACT_TIER2_CAP:
+            cand2, _ = ops.select_ge_rows(frows, thr, cap)
+            full = ops.q2c_rescore(qsub, f32rows, masks, cand2)                       # (-inf where a row has fewer candidates)
+            fw, fi = ops.topk_rows(full, k, alpha=alpha, idx_in=cand2)
+        else:   # scores so close together that the filter cannot separate them: the f32 K6 row itself
+            n_full = nf
             full = ops.q2c_scores_fused(qsub, f32rows, masks)
-        fw, fi = ops.topk_rows(full, k, alpha=alpha)
+            fw, fi = ops.topk_rows(full, k, alpha=alpha)
         top_w.index_copy_(0, rows, fw)
         top_i.index_copy_(0, rows, fi)
-    info = dict(n_fail=nf, fail=fail, eps=eps, q2c_filter=filt, cand_indices=cand_i, cand_filter=cand_s,
+    info = dict(n_fail=nf, n_full_rows=n_full, fail=fail, eps=eps, q2c_filter=filt, cand_indices=cand_i, cand_filter=cand_s,
                 cand_scores=cand_r, n_candidates=m_c)
     return top_w, top_i, info
 

@@ -521,7 +521,7 @@ def q2c_rescore(qn, cn, masks, pair_vid):
 def exact_certificate(filter_scores, top_val, eq, ec, slack, alpha, outside):
     """Per-query certificate of the exact-rank filter.  filter_scores (Nq, M) f32 desc (bf16 pass); top_val (Nq, K) f32 desc,
     raw re-scored values -- turned into exp(alpha * s) IN PLACE; eq: list of (Nq,) f32 per modality; ec: list of floats.
-    Returns (fail (Nq,) int32, eps (Nq,) f32, n_fail (1,) int32 device tensor)."""
+    Returns (fail (Nq,) int32, eps (Nq,) f32, thr (Nq,) f32 = raw T_k - eps, n_fail (1,) int32 device tensor)."""
     _req(filter_scores, "filter_scores", torch.float32); _req(top_val, "top_val", torch.float32)
     n_mod = len(eq)
     for e in eq:
@@ -531,12 +531,13 @@ def exact_certificate(filter_scores, top_val, eq, ec, slack, alpha, outside):
     dev = top_val.device
     fail = torch.empty((nq,), dtype=torch.int32, device=dev)
     eps = torch.empty((nq,), dtype=torch.float32, device=dev)
+    thr = torch.empty((nq,), dtype=torch.float32, device=dev)
     n_fail = torch.zeros((1,), dtype=torch.int32, device=dev)
     j = 1 if n_mod > 1 else 0
     check(_lib.load().xml_exact_certificate(_p(filter_scores), m, _p(top_val), k, _p(eq[0]), _p(eq[j]), float(ec[0]),
                                             float(ec[j]), n_mod, float(slack), float(alpha), int(bool(outside)), _p(fail),
-                                            _p(eps), _p(n_fail), nq, _stream()), "xml_exact_certificate")
-    return fail, eps, n_fail
+                                            _p(eps), _p(thr), _p(n_fail), nq, _stream()), "xml_exact_certificate")
+    return fail, eps, thr, n_fail
 
 
 # ---- packed variable-length sequences (the query encoder without its padding rows) -------------------------------------
@@ -566,3 +567,17 @@ def modular_pool_varlen(enc, cu_seqlens, n, max_len, w_m):
     check(_lib.load().xml_modular_pool_varlen(_p(enc), _p(cu_seqlens), _p(w_m), _p(out), n, int(max_len), hidden, n_mod,
                                               dt_of(enc), _stream()), "xml_modular_pool_varlen")
     return out
+
+
+def select_ge_rows(scores, thr, cap=None):
+    """Columns of every row of scores (rows, n) f32 that reach thr (rows,) f32.  cap None -> counts (rows,) int32;
+    else -> (idx (rows, cap) int32 filled with -1 beyond each row's count, counts)."""
+    _req(scores, "scores", torch.float32); _req(thr, "thr", torch.float32)
+    rows, n = scores.shape
+    cnt = torch.empty((rows,), dtype=torch.int32, device=scores.device)
+    idx = None
+    if cap is not None:
+        idx = torch.full((rows, int(cap)), -1, dtype=torch.int32, device=scores.device)
+    check(_lib.load().xml_select_ge_rows(_p(scores), scores.stride(0), _p(thr), _p(idx), int(cap or 0), _p(cnt), rows, n,
+                                         _stream()), "xml_select_ge_rows")
+    return cnt if idx is None else (idx, cnt)

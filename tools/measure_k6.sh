@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round-2 measurement artefacts of the bench command, one GPU call:
+# Measurement artefacts of the bench command, one GPU call (ROUND=r03 bash tools/measure_k6.sh; default tag r03):
 #   (1) rocprofv3 --kernel-trace --stats of `python bench.py --steps 5 --warmup 2 --no-cpu-baseline`  -> r02_bench_kernel_stats.csv
 #   (2) separate --pmc passes (no trace domains beside --kernel-trace): FETCH_SIZE, WRITE_SIZE, and
 #       SQ_VALU_MFMA_BUSY_CYCLES + SQ_BUSY_CYCLES + GRBM_GUI_ACTIVE                                    -> r02_bench_pmc.txt
@@ -8,13 +8,15 @@
 # Raw traces stay in /tmp; summaries go to gpurun_out/ (copy them to profiles/).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-RAW=/tmp/prof_r02; OUT=$R/gpurun_out; mkdir -p $RAW $OUT
-CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline"
-CMD_S="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline"
+TAG=${ROUND:-r03}
+RAW=/tmp/prof_$TAG; OUT=$R/gpurun_out; mkdir -p $RAW $OUT
+# (--no-extras: the headline pass only -- the extra legs of the default run would be traced / counted once per PMC pass)
+CMD="python $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras"
+CMD_S="python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras"
 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -o bench -- $CMD > $RAW/stats.log 2>&1
-echo "stats rc=$?"; grep "^{\"metric\"" $RAW/stats.log | tail -1 > $OUT/r02_bench_under_rocprof.json.log
+echo "stats rc=$?"; grep "^{\"metric\"" $RAW/stats.log | tail -1 > $OUT/${TAG}_bench_under_rocprof.json.log
 f=$(find $RAW/stats -name "*kernel_stats.csv" | head -1)
-cp "$f" $OUT/r02_bench_kernel_stats.csv
+cp "$f" $OUT/${TAG}_bench_kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   d=$(echo $c | tr ' ' '_')
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $RAW/$d -o bench -- $CMD_S > $RAW/$d.log 2>&1
@@ -22,12 +24,12 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
 done
 python - <<PY
 import csv, glob, collections, hashlib, json, os
-R = "$R"; RAW = "$RAW"; OUT = "$OUT"
+R = "$R"; RAW = "$RAW"; OUT = "$OUT"; TAG = "$TAG"
 agg = collections.defaultdict(lambda: [0.0, 0])
 for f in sorted(glob.glob(RAW + "/*/**/*counter_collection.csv", recursive=True)):
     for r in csv.DictReader(open(f)):
         a = agg[(r["Kernel_Name"][:70], r["Counter_Name"])]; a[0] += float(r["Counter_Value"]); a[1] += 1
-lines = ["# rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline (one pass per group)",
+lines = ["# rocprofv3 --pmc <counters> --kernel-trace -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras (one pass per group)",
          "# per-launch averages; FETCH_SIZE / WRITE_SIZE in KiB as reported (uncorrected)"]
 for (k, c), (s, n) in sorted(agg.items(), key=lambda kv: -kv[1][0])[:40]:
     lines.append("%-72s %-26s per-launch avg %.6g  (%d launches)" % (k, c, s / n, n))
@@ -42,7 +44,7 @@ if k6:
                traffic_bytes_per_launch=2 * fetch + write,
                correction="FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md HBM section; "
                           "re-calibrated on this access pattern in profiles/r01_k6_fetch_calibration_tiled.txt), WRITE_SIZE as is",
-               command="bench.py --steps 2 --warmup 1 --no-cpu-baseline (c3, 1 GPU), one --pmc pass per counter")
+               command="bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras (c3, 1 GPU), one --pmc pass per counter")
     if "SQ_VALU_MFMA_BUSY_CYCLES" in k6 and "GRBM_GUI_ACTIVE" in k6:
         # SQ_VALU_MFMA_BUSY_CYCLES is summed over the chip's 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE over its 8 XCDs (per-launch
         # value / 8 / launch time = the ~1.9 GHz shader clock)
@@ -50,7 +52,7 @@ if k6:
         rec["mfma_busy_fraction"] = k6["SQ_VALU_MFMA_BUSY_CYCLES"] / (cyc * 256 * 4)
         rec["shader_cycles_per_launch"] = cyc
         lines.append("# K6: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs) = %.4f" % rec["mfma_busy_fraction"])
-    json.dump(rec, open(OUT + "/r02_k6_traffic.json", "w"), indent=1)
-open(OUT + "/r02_bench_pmc.txt", "w").write("\n".join(lines) + "\n")
+    json.dump(rec, open(OUT + "/" + TAG + "_k6_traffic.json", "w"), indent=1)
+open(OUT + "/" + TAG + "_bench_pmc.txt", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:24]))
 PY

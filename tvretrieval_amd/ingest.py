@@ -59,7 +59,10 @@ class FeatureStore(object):
 
 class ContextFeeder(object):
     def __init__(self, video_names, video_store=None, sub_store=None, max_ctx_len=100, batch_size=200,
-                 normalize_vfeat=True, normalize_tfeat=True, device="cuda:0", ops=hip_ops):
+                 normalize_vfeat=True, normalize_tfeat=True, device="cuda:0", ops=hip_ops, feature_dtype=torch.float32):
+        """feature_dtype=torch.bfloat16 (bf16 models only): the normalised features are handed over in bf16 -- the encoder's
+        input LayerNorm reads half the bytes (the C ABI takes f32 or the compute dtype); the reference's contract is f32."""
+        self.feature_dtype = feature_dtype
         self.names, self.vs, self.ss = list(video_names), video_store, sub_store
         self.max_ctx_len, self.bsz = int(max_ctx_len), int(batch_size)
         self.norm = dict(video=normalize_vfeat, sub=normalize_tfeat)
@@ -120,6 +123,8 @@ class ContextFeeder(object):
                     dev, dmask = host.clone(), mask
                 if self.norm[tag]:
                     dev = self.ops.l2norm_rows_eps(dev.contiguous(), 1e-5)
+                if self.feature_dtype != torch.float32 and hasattr(self.ops, "convert"):
+                    dev = self.ops.convert(dev.contiguous(), self.feature_dtype)
                 out += [dev, dmask]
             yield tuple(out)
 

@@ -328,6 +328,11 @@ def run(args, backend_factory=None, emit=True):
 
     nq, nv, l, hidden, dv, ds, dq, ctx_mode, dtname = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if dtname == "bf16" else torch.float32
+    exact = bool(getattr(args, "exact_rank", False))
+    if exact:        # exact-rank mode: f32 model, bf16 K6 as a filter in front of f32 scores (inference.stage_exact_topk)
+        assert dtname == "bf16", "--exact-rank applies to the bf16 workloads"
+        dtype, dtname = torch.float32, "bf16 filter + f32 scores"
+    xkw = dict(exact_filter=True) if exact else {}
     cfg = model_config(hidden, dv, ds, dq, ctx_mode, l)
     torch.manual_seed(0)
     model = be.make_model(cfg, dtype)
@@ -338,20 +343,22 @@ def run(args, backend_factory=None, emit=True):
     lens = real_clip_counts(nv, l) if args.workload in RAGGED else None
     with torch.no_grad():   # untimed warm-up of the encoder kernels (module load, first-launch costs, clocks)
         inf.build_corpus_index(model, context_batches(lo, min(hi, lo + 64), l, dv, ds, model.use_video, model.use_sub,
-                                                      device, lens), ops=ops, video_offset=lo, n_total=nv, l_ref=l)
+                                                      device, lens), ops=ops, video_offset=lo, n_total=nv, l_ref=l, **xkw)
     # the raw features of the shard are made resident first (43 GB of 288 for the whole TVR corpus): encode_videos_per_s
     # times the engine -- features in HBM -> resident index -- not the synthetic-data generator
     raw = list(context_batches(lo, hi, l, dv, ds, model.use_video, model.use_sub, device, lens))
     with torch.no_grad():   # second warm-up at the real batch size: workspaces and the allocator's pools reach their final size
-        inf.build_corpus_index(model, iter(raw[:1]), ops=ops, video_offset=lo, n_total=nv, l_ref=l)
+        inf.build_corpus_index(model, iter(raw[:1]), ops=ops, video_offset=lo, n_total=nv, l_ref=l, **xkw)
     be.sync()
     t0 = time.perf_counter()
     with torch.no_grad():
-        index = inf.build_corpus_index(model, iter(raw), ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo)
+        index = inf.build_corpus_index(model, iter(raw), ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo,
+                                       **xkw)
     be.sync()
     enc_s = time.perf_counter() - t0
     enc_bf16_s = None
-    if world == 1 and be.name == "hip" and args.workload == "c3" and not args.no_extras and dtype == torch.bfloat16:
+    if world == 1 and be.name == "hip" and args.workload == "c3" and not args.no_extras and dtype == torch.bfloat16 \
+            and not exact:
         # the same corpus with the RAW features resident as bf16 (the C ABI takes f32 or the compute dtype, x_dt of
         # xml_linear_ln_relu_pos): the input LayerNorm then reads half the bytes -- 3.2 GB less per 2 048 videos
         raw16 = [tuple(t.to(torch.bfloat16) if (t is not None and i in (0, 2)) else t for i, t in enumerate(b)) for b in raw]
@@ -504,8 +511,12 @@ def run(args, backend_factory=None, emit=True):
             return r
         with torch.no_grad():
             qvec = timed("query_encode", lambda: inf.stage_query_vectors(model, qf, qm))
-            q2c = timed("q2c_k6", lambda: inf.stage_q2c(index, qvec, ops))
-            tw, ti = timed("topk_k8", lambda: ops.topk_rows(q2c, min(100, index.n_videos), alpha=20.0))
+            if exact:
+                tw, ti, _ = timed("exact_topk(k6 filter+k8+rescore+certificate)",
+                                  lambda: inf.stage_exact_topk(index, qvec, min(100, index.n_videos), 20.0, ops))
+            else:
+                q2c = timed("q2c_k6", lambda: inf.stage_q2c(index, qvec, ops))
+                tw, ti = timed("topk_k8", lambda: ops.topk_rows(q2c, min(100, index.n_videos), alpha=20.0))
             st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti, ops))
             timed("moment_k9", lambda: ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
     else:       # rank 0's view of one sharded pass, collectives (and the waiting for slower ranks in them) included
@@ -547,8 +558,8 @@ def run(args, backend_factory=None, emit=True):
                        "result_placement": "all on the GPU" if not multi else "final lists on the query's owner rank",
                        "rerank": "local" if not multi else ("video owner (feat2 sharded)" if args.sharded_rerank else
                                                              "query owner (feat2 replicated, feat1 sharded)")},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[dtname], "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_TFLOPS[dtname], "traffic": traffic,
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS["bf16" if exact else dtname],
+                         "unit": "TFLOP/s", "frac": achieved / PEAK_TFLOPS["bf16" if exact else dtname], "traffic": traffic,
                          "traffic_note": "bytes per launch, rocprofv3 FETCH_SIZE(x2 gfx950 correction)+WRITE_SIZE: %s; "
                                          "algorithmic bytes = %.3g" % (
                                              traffic_src,
@@ -567,7 +578,7 @@ def run(args, backend_factory=None, emit=True):
             res["ragged_corpus"] = ragged
             res["roofline"]["note"] = "ragged corpus: `achieved` prices the VALID clip rows (algorithmic work); " \
                                       "executed_tflops in ragged_corpus prices the padded rows the MFMA pipe actually ran"
-        if world == 1 and not args.no_cpu_baseline and be.name == "hip":
+        if world == 1 and not args.no_cpu_baseline and be.name == "hip" and not exact:
             def search(nq_s, nv_s):       # the baseline's slice through the HIP path, for the agreement figures
                 with torch.no_grad():
                     sub = inf.build_corpus_index(model, context_batches(0, nv_s, l, dv, ds, model.use_video,
@@ -587,7 +598,7 @@ def run(args, backend_factory=None, emit=True):
             res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname, search, search_exact)
         else:
             res["cpu_baseline"] = None
-        if world == 1 and be.name == "hip" and args.workload == "c3" and not args.no_extras:
+        if world == 1 and be.name == "hip" and args.workload == "c3" and not args.no_extras and not exact:
             enc_flops = 2.0 * l * hidden * (dv + ds) + 44.0 * l * hidden ** 2 + 24.0 * l ** 2 * hidden
             enc_tf = res["encode_videos_per_s"] * enc_flops / 1e12
             extras = {"encode": {"videos_per_s": res["encode_videos_per_s"], "flops_per_video": enc_flops,
@@ -628,6 +639,9 @@ def main(argv=None, backend_factory=None, script=None):
                     help="N > 1: query chunks of the pipelined owner pass (chunk c's exchange runs under chunk c+1's K6)")
     ap.add_argument("--torch-collectives", action="store_true",
                     help="N > 1: keep the exchanges on torch.distributed instead of libxmlhip's xml_rccl_* entries (A/B)")
+    ap.add_argument("--exact-rank", action="store_true",
+                    help="run the pass in exact-rank mode (f32 model, bf16 K6 as a filter + f32 re-score + certificate): the "
+                         "f32 path's lists; any N (every shard hands its exact local top-k to the merge)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1, c3: skip the extra legs (exact-rank mode, c2, c3r, training step) after the headline run")
     args = ap.parse_args(argv)

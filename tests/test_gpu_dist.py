@@ -36,13 +36,15 @@ def test_ranks_sharing_one_gpu_sharded_search_equals_single_process(world):
     assert r.returncode == 0 and "TWO_RANKS_ONE_GPU_OK world=%d" % world in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
-def test_bench_two_ranks_on_one_gpu():
-    """`python bench.py --gpus 2` (self-spawned ranks, real kernels, shards of the tiny workload): one JSON line, n_gpus 2."""
+@pytest.mark.parametrize("extra", [[], ["--exact-rank"]])
+def test_bench_two_ranks_on_one_gpu(extra):
+    """`python bench.py --gpus 2` (self-spawned ranks, real kernels, shards of the tiny workload): one JSON line, n_gpus 2;
+    also in exact-rank mode (every shard hands its exact local top-k to the merge)."""
     import json
     env = dict(os.environ, XML_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workload", "tiny",
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
-                       timeout=600)
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, env=env, capture_output=True,
+                       text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-2000:]

@@ -54,6 +54,29 @@ def main():
         idx = own["query_index"]
         for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"):
             assert torch.equal(own[k], want[k][idx.to(want[k].device)]), (rank, str(dtype), "owner slice", k)
+    # exact-rank mode, sharded: every shard runs the bf16 filter / f32 re-score / certificate chain on its own videos and
+    # hands its EXACT local top-k to the owner's merge -- the lists are the plain f32 single-process lists (ties at f32
+    # rounding aside: here, with a handful of candidates per shard, bit for bit except the video scores' last bits)
+    m = XML(cfg, compute_dtype=torch.float32)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd.items()})
+    m = m.to(dev).eval()
+    lo, hi = xd.shard_range(nv, rank, world)
+    with torch.no_grad():
+        full = inf.build_corpus_index(m, [(vf, vm, sf, sm)])
+        want = inf.vcmr_search(m, full, qf, qm, max_vcmr_video=6, max_before_nms=50)
+        shard = inf.build_corpus_index(m, [(vf[lo:hi], vm[lo:hi], sf[lo:hi], sm[lo:hi])], video_offset=lo, n_total=nv,
+                                       l_ref=full.l_ref, exact_filter=True)
+        shard.exact.n_candidates = 8                        # fewer candidates than local videos: the filter really filters
+        assert shard.n_videos > 8
+        got = xd.sharded_vcmr_search(m, shard, qf, qm, max_vcmr_video=6, max_before_nms=50)              # video-owner rerank
+        xd.replicate_rerank_features(shard)
+        got2 = xd.sharded_vcmr_search(m, shard, qf, qm, max_vcmr_video=6, max_before_nms=50)             # query-owner rerank
+    torch.cuda.synchronize()
+    for name, g in (("exact video-owner", got), ("exact query-owner", got2)):
+        assert torch.equal(g["top_indices"], want["top_indices"]), (rank, name, "top_indices")
+        assert torch.equal(g["flat_indices"], want["flat_indices"]), (rank, name, "flat_indices")
+        assert torch.allclose(g["top_scores"], want["top_scores"], rtol=2e-5, atol=0), (rank, name)
+        assert torch.allclose(g["flat_scores"], want["flat_scores"], rtol=5e-5, atol=0), (rank, name)
     # data-parallel gradient average over gloo (flat buffer on the GPU)
     from tvretrieval_amd.train import allreduce_gradients
 

@@ -263,6 +263,31 @@ def encode_queries_sharded(model, query_feat, query_mask, group=None, exchange=N
     return {m: out[:nq, j].contiguous() for j, m in enumerate(names)}
 
 
+def _local_scores_topk(index, qvec, k, ops):
+    """K6 over this shard + its local top-k: (q2c or None, raw scores (Nq, k), GLOBAL video ids (Nq, k)).
+    Exact-rank shards (index.exact: f32 model, bf16 filter image): the local top-k comes out of the filter / re-score /
+    certificate chain (inference.stage_exact_topk) -- exact per shard, and the global f32 top-k is a subset of the union of
+    the shards' exact top-k lists, so the owner's merge (same scores, same tie rule) yields the f32 path's global list."""
+    if index.exact is not None:
+        k_loc = min(k, index.n_videos)
+        loc_s, loc_i, info = inf.stage_exact_topk(index, qvec, k_loc, 0.0, ops)
+        _mark("exact_local_topk")
+        return None, _pad_local(loc_s, loc_i + index.video_offset, k, k_loc)
+    q2c = inf.stage_q2c(index, qvec, ops)
+    _mark("q2c_k6")
+    loc = _local_topk(index, q2c, k, ops)
+    _mark("topk_local_k8")
+    return q2c, loc
+
+
+def _pad_local(loc_s, loc_i, k, k_loc):
+    if k_loc < k:       # tiny shard: pad with -inf so that every rank contributes k slots
+        pad_s = loc_s.new_full((loc_s.shape[0], k - k_loc), float("-inf"))
+        pad_i = loc_i.new_full((loc_i.shape[0], k - k_loc), 2 ** 31 - 1)
+        loc_s, loc_i = torch.cat([loc_s, pad_s], 1), torch.cat([loc_i, pad_i], 1)
+    return loc_s.contiguous(), loc_i.contiguous()
+
+
 def _local_topk(index, q2c, k, ops):
     """Local top-k of every query over this shard, with GLOBAL video ids, padded to k slots per rank."""
     k_loc = min(k, index.n_videos)
@@ -319,11 +344,9 @@ def _owner_pass(model, index, qvec, ex, k, n_out, q2c_alpha, min_pred_l, max_pre
         if c_hi <= c_lo:
             continue
         qv_c = {m: qvec[m][c_lo:c_hi].contiguous() for m in names} if n_chunks > 1 else qvec
-        q2c = inf.stage_q2c(index, qv_c, ops)
-        _mark("q2c_k6")
-        loc_s, loc_i = _local_topk(index, q2c, k, ops)
-        _mark("topk_local_k8")
-        q2c_parts.append(q2c)
+        q2c, (loc_s, loc_i) = _local_scores_topk(index, qv_c, k, ops)
+        if q2c is not None:
+            q2c_parts.append(q2c)
         if pending is not None:
             finish(pending)             # K7 / K9 of the previous chunk, behind this chunk's K6 in the stream
         if cuda:
@@ -343,7 +366,7 @@ def _owner_pass(model, index, qvec, ex, k, n_out, q2c_alpha, min_pred_l, max_pre
             pending = (c_lo, qv_c, own, None)
     finish(pending)
     cat = lambda j: torch.cat([p[j] for p in parts]) if len(parts) > 1 else parts[0][j]       # noqa: E731
-    q2c_all = torch.cat(q2c_parts) if len(q2c_parts) > 1 else q2c_parts[0]
+    q2c_all = None if not q2c_parts else (torch.cat(q2c_parts) if len(q2c_parts) > 1 else q2c_parts[0])
     return cat(0), cat(1), cat(2), cat(3), (torch.cat(owned) if len(owned) > 1 else owned[0]), q2c_all
 
 
@@ -412,15 +435,19 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
         res.update(top_scores=top_w, top_indices=top_gid, flat_scores=fs, flat_indices=fi)
         return res
     # ---- phase 1: global top-k videos ------------------------------------------------------------------
-    q2c = inf.stage_q2c(index, qvec, ops)
-    _mark("q2c_k6")
-    if trivial:
+    if trivial and index.exact is not None:
+        q2c = None
+        top_w, top_gid, _ = inf.stage_exact_topk(index, qvec, min(k, index.n_videos), q2c_alpha, ops)
+        top_gid = top_gid + index.video_offset
+        _mark("exact_topk")
+    elif trivial:
+        q2c = inf.stage_q2c(index, qvec, ops)
+        _mark("q2c_k6")
         top_w, top_gid = ops.topk_rows(q2c, k, alpha=q2c_alpha)
         top_gid = top_gid + index.video_offset
         _mark("topk_k8")
     else:
-        loc_s, loc_i = _local_topk(index, q2c, k, ops)
-        _mark("topk_local_k8")
+        q2c, (loc_s, loc_i) = _local_scores_topk(index, qvec, k, ops)
         top_w, top_gid = ex.allgather_topk(loc_s, loc_i, k, q2c_alpha, ops)       # every rank: global top-k of all queries
         _mark("allgather+merge_topk")
     # ---- phase 2: moments of the global top-k videos this rank owns -------------------------------------

@@ -357,8 +357,8 @@ def run(args, backend_factory=None, emit=True):
     be.sync()
     enc_s = time.perf_counter() - t0
     enc_bf16_s = None
-    if world == 1 and be.name == "hip" and args.workload == "c3" and not args.no_extras and dtype == torch.bfloat16 \
-            and not exact:
+    if world == 1 and not multi and be.name == "hip" and args.workload == "c3" and not args.no_extras \
+            and dtype == torch.bfloat16 and not exact:
         # the same corpus with the RAW features resident as bf16 (the C ABI takes f32 or the compute dtype, x_dt of
         # xml_linear_ln_relu_pos): the input LayerNorm then reads half the bytes -- 3.2 GB less per 2 048 videos
         raw16 = [tuple(t.to(torch.bfloat16) if (t is not None and i in (0, 2)) else t for i, t in enumerate(b)) for b in raw]
@@ -585,7 +585,7 @@ def run(args, backend_factory=None, emit=True):
                                                                        model.use_sub, device, lens), ops=ops, l_ref=l)
                     return inf.vcmr_search(model, sub, qf[:nq_s].contiguous(), qm[:nq_s].contiguous(), ops=ops)
             search_exact = None
-            extras_on = args.workload == "c3" and not args.no_extras
+            extras_on = args.workload == "c3" and not args.no_extras and not multi
             if extras_on:
                 def search_exact(nq_s, nv_s):     # the same slice in exact-rank mode: f32 model with the SAME weights
                     m32 = be.make_model(cfg, torch.float32)
@@ -598,7 +598,7 @@ def run(args, backend_factory=None, emit=True):
             res["cpu_baseline"] = cpu_baseline(model, cfg, index, qf, qm, nv, dtname, search, search_exact)
         else:
             res["cpu_baseline"] = None
-        if world == 1 and be.name == "hip" and args.workload == "c3" and not args.no_extras and not exact:
+        if world == 1 and not multi and be.name == "hip" and args.workload == "c3" and not args.no_extras and not exact:
             enc_flops = 2.0 * l * hidden * (dv + ds) + 44.0 * l * hidden ** 2 + 24.0 * l ** 2 * hidden
             enc_tf = res["encode_videos_per_s"] * enc_flops / 1e12
             extras = {"encode": {"videos_per_s": res["encode_videos_per_s"], "flops_per_video": enc_flops,

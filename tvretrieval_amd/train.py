@@ -608,6 +608,12 @@ class GradientReducer(object):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(view.device))
             self.side.wait_event(ev)
+            # the branch streams of the training graph (PARALLEL_BRANCHES) write gradients too: a node that accumulated
+            # straight into the flat buffer (gradient sink) hands no tensor to autograd, so nothing else orders its kernel
+            # before this bucket's all-reduce
+            for (dev_index, _), st in list(_SIDE_STREAMS.items()):
+                if dev_index == view.device.index:
+                    self.side.wait_stream(st)
             with torch.cuda.stream(self.side):
                 if self.comm is not None:
                     self.comm.allreduce_avg_(view)

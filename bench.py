@@ -302,6 +302,27 @@ def run_extras(args, headline_qps):
     return out
 
 
+def extras_in_child(args, headline_qps, timeout_s=420):
+    """run_extras in a CHILD process: whatever happens there (a device fault in an experimental leg, a timeout) cannot cost
+    the headline measurement, which the parent already holds.  The child prints one JSON object."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--extras-only", repr(float(headline_qps)), "--steps", str(args.steps),
+           "--warmup", str(args.warmup)]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        if r.returncode == 0 and lines:
+            out = json.loads(lines[-1])
+        else:
+            out = {"error": "extras child exited with %d: %s" % (r.returncode, (r.stderr or "")[-400:])}
+    except subprocess.TimeoutExpired:
+        out = {"error": "extras child exceeded %d s" % timeout_s}
+    out["extras_wall_s"] = round(time.perf_counter() - t0, 1)
+    return out
+
+
 def run(args, backend_factory=None, emit=True):
     """emit=False: return the result dict without printing (the extra legs of the default run).
     backend_factory: None = the product (HipBackend).  tests/bench_cpu_entry.py passes tests/cpu_backend.BenchBackend to
@@ -610,7 +631,7 @@ def run(args, backend_factory=None, emit=True):
                                                          "frac_of_mfma_peak": v16 * enc_flops / 1e12 / PEAK_TFLOPS[dtname]}
             del index, model
             torch.cuda.empty_cache()
-            extras.update(run_extras(args, res["value"]))
+            extras.update(extras_in_child(args, res["value"]))
             res["extras"] = extras
     if multi:       # RCCL's start-up banner sits in the C stdio buffer of every rank: push it out BEFORE the result line,
         import ctypes    # so that the JSON line is the last thing this job prints
@@ -644,7 +665,13 @@ def main(argv=None, backend_factory=None, script=None):
                          "f32 path's lists; any N (every shard hands its exact local top-k to the merge)")
     ap.add_argument("--no-extras", action="store_true",
                     help="N = 1, c3: skip the extra legs (exact-rank mode, c2, c3r, training step) after the headline run")
+    ap.add_argument("--extras-only", default=None, metavar="HEADLINE_QPS",
+                    help="(internal) run only the extra legs of the default run and print them as one JSON object")
     args = ap.parse_args(argv)
+    if args.extras_only is not None:
+        torch.cuda.set_device(0)
+        print(json.dumps(run_extras(args, float(args.extras_only))), flush=True)
+        return None
     from tvretrieval_amd import launch
     if args.gpus > 1 and not launch.under_launcher():
         # `python bench.py --gpus N`: one process per GPU, started here (same environment torch.distributed.run gives)

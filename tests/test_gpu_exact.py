@@ -212,6 +212,31 @@ def test_exact_mode_equals_f32_path(ctx_mode, ragged, monkeypatch):
                     5e-4, "exact vs oracle moments")
 
 
+def test_exact_mode_svmr_and_small_corpus():
+    """SVMR lists come out of the f32 K7 / K9 in exact-rank mode unchanged, and a corpus smaller than the candidate count
+    needs no filter at all (every video is a candidate: no certificate can fail)."""
+    from tvretrieval_amd import inference as inf
+    nq, nv, l = 9, 40, 64
+    m, cfg = _synthetic_model("video_sub", 128, 256, 128, 128, l, torch.float32, seed=6)
+    rng = np.random.default_rng(2)
+    lens = rng.integers(10, l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, 256, 1)
+    sf, sm = _feats(nv, lens, 128, 2)
+    qf, qm = _feats(nq, rng.integers(3, 21, nq), 128, 3)
+    gt = torch.tensor(rng.integers(0, nv, nq), dtype=torch.int32, device=DEV)
+    b = [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))]
+    with torch.no_grad():
+        ref = inf.vcmr_search(m, inf.build_corpus_index(m, b), qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=50,
+                              svmr_video=gt)
+        out = inf.vcmr_search(m, inf.build_corpus_index(m, b, exact_filter=True), qf.to(DEV), qm.to(DEV), max_vcmr_video=10,
+                              max_before_nms=50, svmr_video=gt)
+    assert out["exact"]["n_fail"] == 0 and out["exact"]["n_candidates"] == nv
+    for k in ("svmr_scores", "svmr_flat"):
+        assert torch.equal(out[k], ref[k]), k
+    assert torch.equal(out["top_indices"], ref["top_indices"]) and torch.equal(out["flat_indices"], ref["flat_indices"])
+    close("video weights", out["top_scores"], ref["top_scores"], 0, 2e-5)
+
+
 def test_exact_mode_rejects_bf16_model():
     from tvretrieval_amd import inference as inf
     m, _ = _synthetic_model("video", 128, 256, 128, 128, 64, torch.bfloat16, seed=3)

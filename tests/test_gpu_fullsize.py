@@ -43,6 +43,10 @@ def test_c2_full_shape_vs_oracle_fp32():
         batches = ((vf[b:b + bs].to(DEV), vm[b:b + bs].to(DEV), None, None) for b in range(0, nv, bs))
         index = inf.build_corpus_index(m, batches, l_ref=l)
         out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=100, max_before_nms=200)
+        # the same shape in exact-rank mode (bf16 K6 as a filter in front of the f32 scores): must be the same lists
+        batches = ((vf[b:b + bs].to(DEV), vm[b:b + bs].to(DEV), None, None) for b in range(0, nv, bs))
+        xindex = inf.build_corpus_index(m, batches, l_ref=l, exact_filter=True)
+        xout = inf.vcmr_search(m, xindex, qf.to(DEV), qm.to(DEV), max_vcmr_video=100, max_before_nms=200)
     torch.cuda.synchronize()
 
     # ---- oracle on the host cores, same batching (every batch holds a full-length video: same padded-row semantics)
@@ -79,6 +83,25 @@ def test_c2_full_shape_vs_oracle_fp32():
         assert (gfi[sl][rows] >= 0).all()
         n_mom_diff += _tie_aware_equal(gkey[rows], gfs[sl][rows], wkey[rows], wfs[rows], kn, 5e-4, "top-200 moments")
     assert n_mom_rows >= nq - 1, "video sets differ for %d queries" % (nq - n_mom_rows)      # measured: 0 or 1 of 256
+    # exact-rank mode against the SAME oracle lists, same tie-aware rule
+    xi, xw = xout["top_indices"].cpu().numpy().astype(np.int64), xout["top_scores"].cpu().numpy()
+    xfi, xfs = xout["flat_indices"].cpu().numpy().astype(np.int64), xout["flat_scores"].cpu().numpy()
+    x_vid = x_mom = x_rows = 0
+    for c in range(0, nq, 32):
+        sl = slice(c, c + 32)
+        with torch.no_grad():
+            tail = O.vcmr_tail(q2c[sl], st[sl], ed[sl], 20.0, kv, 2, 16, kn + extra)
+            ww, wi = torch.topk(torch.exp(20.0 * q2c[sl]), kv + extra, dim=1)
+        x_vid += _tie_aware_equal(xi[sl], xw[sl], wi.numpy(), ww.numpy(), kv, 2e-4, "exact-rank top-100 videos")
+        wfi, wfs = tail["flat_indices"].numpy(), tail["flat_scores"].numpy()
+        wkey = np.take_along_axis(tail["top_indices"].numpy(), wfi // ll, 1) * ll + wfi % ll
+        xkey = np.take_along_axis(xi[sl], np.clip(xfi[sl] // ll, 0, kv - 1), 1) * ll + xfi[sl] % ll
+        rows = np.nonzero((np.sort(xi[sl], 1) == np.sort(tail["top_indices"].numpy(), 1)).all(1))[0]
+        x_rows += len(rows)
+        x_mom += _tie_aware_equal(xkey[rows], xfs[sl][rows], wkey[rows], wfs[rows], kn, 5e-4, "exact-rank top-200 moments")
+    print("C2 full shape, exact-rank mode: %d queries fell back; %d / %d video and %d / %d moment positions swapped in ties"
+          % (xout["exact"]["n_fail"], x_vid, nq * kv, x_mom, x_rows * kn))
+    assert x_rows >= nq - 1 and x_vid <= 40 and x_mom <= 170, (x_rows, x_vid, x_mom)
     print("C2 full shape: q2c max err %.2e; %d / %d video positions and %d / %d moment positions swapped inside tie groups"
           % (err, n_vid_diff, nq * kv, n_mom_diff, n_mom_rows * kn))
     # measured 13 / 25 600 and 56 / 51 000; bounds at ~3x (a regression of an order of magnitude fails)

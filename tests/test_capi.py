@@ -53,6 +53,21 @@ def test_argument_validation_without_gpu(lib):
     assert lib.xml_linear_ln_relu_pos_workspace_bytes(512, 3072, 768, 0) >= 512 * (3072 + 768) * 4
 
 
+def test_round3_entries_validate_arguments(lib):
+    """The exact-rank, packed-sequence and accumulate entries added in round 3 (ABI 3) reject bad arguments before any launch."""
+    assert lib.xml_round_bf16_rows_err(None, None, None, 4, 768, None) == -1
+    assert lib.xml_q2c_rescore_workspace_bytes(10000, 21793, 256) >= (10000 * 256 + 2 * 21793) * 4
+    assert lib.xml_q2c_rescore(2, None, None, None, None, None, None, None, None, 1, 1, 1, 128, 768, 0, None, 0, None) == -1
+    assert lib.xml_exact_certificate(None, 256, None, 100, None, None, 0.0, 0.0, 2, 0.0, 20.0, 1, None, None, None, None, 10,
+                                     None) == -1
+    assert lib.xml_select_ge_rows(None, 0, None, None, 0, None, 1, 1, None) == -1
+    assert lib.xml_attention_block_varlen_workspace_bytes(175000, 768, 1) >= 175000 * 768 * (3 * 2 + 2)
+    assert lib.xml_attention_block_varlen(None, None, None, None, None, None, None, None, None, 10, 2, 30, 768, 4, 1, None, 0,
+                                          None) == -1
+    assert lib.xml_modular_pool_varlen(None, None, None, None, 2, 30, 768, 2, 1, None) == -1
+    assert lib.xml_gemm_tn(None, None, None, None, 100, 768, 768, 1, 1, None) == -1
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No CPU fallback: CPU tensors are rejected by the ops layer."""
     import torch

@@ -104,6 +104,34 @@ def main():
             allreduce_gradients(opt)
         torch.cuda.synchronize()
         results.append(opt.flat_g.clone())
+    # the captured step with the reducer's RCCL all-reduces INSIDE the graph (1 rank: the average is the identity):
+    # three replays == three eager steps from the same state
+    from tvretrieval_amd.train import GraphedTrainStep
+    finals = []
+    for graphed in (False, True):
+        tm = XML(tcfg)
+        tm.load_state_dict({k[len("sd_before/"):]: torch.from_numpy(v.copy()) for k, v in dt.items() if k.startswith("sd_before/")})
+        tm = tm.to(dev)
+        tm.eval()
+        opt = BertAdam(tm.parameters(), lr=1e-3, warmup=-1, t_total=-1, schedule="none")
+        red = GradientReducer(opt, bucket_bytes=64 << 10)
+        assert red.comm is not None
+        tb = {k: v for k, v in batch.items() if k not in ("neg_ctx_rank", "neg_q_rank")}
+        if graphed:
+            step = GraphedTrainStep(tm, opt, tb)
+            for _ in range(3):
+                step(tb, neg_ctx_rank=dt["neg_ctx_rank"], neg_q_rank=dt["neg_q_rank"])
+        else:
+            for _ in range(3):
+                loss, _ = xml_forward_train(tm, **batch)
+                opt.zero_grad()
+                loss.backward()
+                allreduce_gradients(opt)
+                opt.step()
+        torch.cuda.synchronize()
+        finals.append(opt.flat_p.clone())
+    rel = float((finals[0] - finals[1]).abs().max()) / float(finals[0].abs().max())
+    assert rel <= 2e-5, rel
     # (weight gradients use split-K f32 atomics: equal to rounding, not bitwise, between any two runs)
     scale = float(results[0].abs().max())
     assert float((results[0] - results[1]).abs().max()) <= 1e-5 * scale, float((results[0] - results[1]).abs().max()) / scale

@@ -69,11 +69,12 @@ def run(bsz=128, ctx_l=100, desc_l=30, hidden=768, dv=3072, ds=768, dtype="bf16"
 
     if graph:
         from tvretrieval_amd.train import GraphedTrainStep
-        assert world == 1, "the captured step does not include the all-reduce"
-        step = GraphedTrainStep(model, opt, batch)
+        step = GraphedTrainStep(model, opt, batch)      # (world > 1: the reducer's bucketed all-reduces are captured too)
         for _ in range(warmup):
             step(None)
         torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
         t0 = time.perf_counter()
         losses = []
         for _ in range(steps):
@@ -85,7 +86,8 @@ def run(bsz=128, ctx_l=100, desc_l=30, hidden=768, dv=3072, ds=768, dtype="bf16"
         flops = train_flops_per_sample(ctx_l, desc_l, hidden, dv, ds, ds) * bsz
         peak = 2500.0 if dtype == "bf16" else 157.3
         tflops = flops / (wall * 1e-3) / 1e12
-        return dict(metric="xml_train_step", ms_per_step=round(wall, 3), pairs_per_s=round(bsz / wall * 1e3, 1), n_gpus=1,
+        return dict(metric="xml_train_step", ms_per_step=round(wall, 3), pairs_per_s=round(bsz * world / wall * 1e3, 1),
+                    n_gpus=world,
                     dtype=dtype, mode="one HIP graph per step (train.GraphedTrainStep)", flops_per_step=flops,
                     tflops=round(tflops, 1), frac_of_mfma_peak=round(tflops / peak, 4),
                     config=dict(bsz_per_gpu=bsz, ctx_l=ctx_l, desc_l=desc_l, hidden=hidden, dv=dv, params=n_param),

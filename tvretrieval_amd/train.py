@@ -462,13 +462,16 @@ class GraphedTrainStep(object):
         by the host before each replay (per-tensor step counts, warm-up, `p.grad is None` semantics: BertAdam._step_plan);
       * every fill inside the captured entries is a kernel (a memset NODE did not re-run on replay, ROCm 7.2).
     The warm-up steps run on copies of the optimizer state, which is restored before the capture: constructing the object
-    does not train.  Not supported: a GradientReducer on the optimizer (data-parallel runs keep the eager step), changing
-    which tensors receive gradients after the capture (set_train_st_ed: re-create the object).
+    does not train.  Data-parallel runs: attach the GradientReducer BEFORE constructing this object; its bucketed
+    all-reduces are captured too (see __init__).  Not supported: changing which tensors receive gradients after the capture
+    (set_train_st_ed: re-create the object).
     Returns (loss, loss_dict) as 0-d DEVICE tensors; reading them synchronises."""
 
     def __init__(self, model, optimizer, batch, grad_clip=-1, warmup_steps=2):
-        if getattr(optimizer, "_reducer", None) is not None:
-            raise ValueError("GraphedTrainStep does not capture the data-parallel all-reduce: use train_step")
+        # data-parallel runs: with a GradientReducer attached, its bucketed all-reduces (xml_rccl_allreduce_avg_f32 on the
+        # reducer's side stream, ordered by events behind the backward kernels of each bucket) are captured as parallel
+        # branches of the same graph -- the overlap with backward is part of every replay.  Every rank must construct the
+        # object at the same point (the warm-up steps and the capture issue collectives).
         self.model, self.opt, self.grad_clip = model, optimizer, grad_clip
         dev = optimizer.flat_p.device
         self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in batch.items()
@@ -523,8 +526,12 @@ class GraphedTrainStep(object):
         opt = self.opt
         loss, parts = xml_forward_train(self.model, neg_ctx_rank=self.neg_ctx, neg_q_rank=self.neg_q, as_tensors=True,
                                         **self.static)
+        if opt._reducer is not None:
+            opt._reducer.begin()
         opt.flat_g.zero_()
         loss.backward()
+        if opt._reducer is not None:
+            opt._reducer.finish()           # leftover buckets + join the all-reduce stream
         if self.grad_clip != -1:
             T.clip_grad_norm(opt.flat_g, self.grad_clip)
         d = opt.defaults

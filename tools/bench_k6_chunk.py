@@ -16,12 +16,15 @@ from tvretrieval_amd import ops  # noqa: E402
 def main():
     vals = [20, 0, 1, 2, 3, 4, -1]
     abls = [0]
+    lines = [0]                     # --lines=0,2: rounds an XCD spends on ADJACENT clip tiles = 2^v (Q2cPersistArgs::lsh)
     nq, nv, h = 10000, 21793, 768
     for a in sys.argv[1:]:
         if a.startswith("--values="):
             vals = [int(x) for x in a.split("=")[1].split(",")]
         if a.startswith("--ablations="):
             abls = [int(x) for x in a.split("=")[1].split(",")]
+        if a.startswith("--lines="):
+            lines = [int(x) for x in a.split("=")[1].split(",")]
         if a.startswith("--nq="):
             nq = int(a.split("=")[1])
         if a.startswith("--nv="):
@@ -45,8 +48,9 @@ def main():
     flops = 2.0 * nq * nv * 128 * h * 2
     ref = None
     for rep in range(2):
-        for v, ab in [(v, ab) for v in vals for ab in abls]:
+        for v, ab, ln in [(v, ab, ln) for v in vals for ab in abls for ln in lines]:
             lib.xml_debug_set_q2c_chunk(ctypes.c_int(v))
+            lib.xml_debug_set_q2c_line(ctypes.c_int(ln))
             lib.xml_debug_set_q2c_ablation(ctypes.c_int(ab))
             for _ in range(2):
                 ops.q2c_scores_fused(qs, tiles, [mask, mask], out=out)
@@ -61,9 +65,10 @@ def main():
                 ref = out.clone()
             else:
                 same = "  bitwise equal to the first setting: %s" % bool(torch.equal(ref, out))
-            print("chunk 2^%-2d rounds, ablation %2d: median %.3f ms (min %.3f) -> %.1f TFLOP/s%s" %
-                  (v, ab, ms[2], ms[0], flops / ms[2] / 1e9, same), flush=True)
+            print("chunk 2^%-2d rounds, ablation %2d, line 2^%d: median %.3f ms (min %.3f) -> %.1f TFLOP/s%s" %
+                  (v, ab, ln, ms[2], ms[0], flops / ms[2] / 1e9, same), flush=True)
     lib.xml_debug_set_q2c_chunk(ctypes.c_int(-1))
+    lib.xml_debug_set_q2c_line(ctypes.c_int(0))
     lib.xml_debug_set_q2c_ablation(ctypes.c_int(0))
 
 

@@ -12,9 +12,10 @@ extern int g_q2c_ablation;      // per-kernel ablation id (see the ABL template 
 extern int g_gemm_variant;      // 0 auto, 1 force the 128x128 register-staged kernel, 2 never the persistent 256x256 one
 extern int g_q2c_xcd_swizzle;
 extern int g_q2c_chunk_log2;    // -1 auto; K6 corpus walk: rounds per MALL-resident chunk = 2^v (30 = one chunk = old order)
+extern int g_q2c_line_log2;     // K6 walk: 2^v consecutive rounds of an XCD on adjacent clip tiles (Q2cPersistArgs::lsh)
 #else
 static constexpr int g_q2c_variant = 0, g_q2c_ablation = 0, g_gemm_variant = 0, g_q2c_xcd_swizzle = 1,
-                     g_q2c_chunk_log2 = -1;
+                     g_q2c_chunk_log2 = -1, g_q2c_line_log2 = 0;
 #endif
 
 // hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device) and per growth of the requested size -- not on

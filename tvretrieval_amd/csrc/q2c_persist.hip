@@ -34,6 +34,8 @@ struct Q2cPersistArgs {
   int64_t ld_out;
   int nq, nv, hidden, n_mod, tq, tc;
   int qsh;     // log2 of the query tiles per XCD super-tile (0..3): the 32 workgroups of an XCD form 2^qsh x 2^(5-qsh)
+  int lsh;     // log2 of the consecutive rounds an XCD spends on ADJACENT clip tiles (0: round c of XCD x takes tiles
+               // 2^csh (8c + x) ..; 2: four rounds cover 16 adjacent tiles = 32 videos = one 128-byte line of `out` rows)
   int rsh;     // log2 of the rounds per corpus chunk: all query groups visit a chunk before the walk moves on, so that
                // passes 2..n over a chunk's clip tiles are served by the 256 MB Infinity Cache instead of HBM
 };
@@ -248,11 +250,15 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const int row_stride = TILED ? ROWB : k_bytes;
   constexpr int SLICE_STRIDE = TILED ? 256 * ROWB : ROWB;
   const int n_qgroups = (a.tq + (1 << qsh) - 1) >> qsh;
-  const int cr = (((a.tc + (1 << csh) - 1) >> csh) + 7) >> 3;    // rounds per query group on one XCD
+  const int lsh = a.lsh, lmask = (1 << a.lsh) - 1;
+  const int cr = ((a.tc + (8 << (csh + lsh)) - 1) / (8 << (csh + lsh))) << lsh;    // rounds per query group on one XCD
 
-  // tile of (query group g, round c):  qt = 2^qsh g + qt_off,  ct = 2^csh (8 c + xcd) + ct_off
+  // tile of (query group g, round c):  qt = 2^qsh g + qt_off,  ct = 2^(csh+lsh) (8 (c >> lsh) + xcd) + 2^csh (c & lmask) + ct_off
+  auto clip_tile = [&](int c) -> int {
+    return ((((((c >> lsh) << 3) + xcd) << lsh) + (c & lmask)) << csh) + ct_off;
+  };
   auto tile_valid = [&](int g, int c) -> bool {
-    return ((g << qsh) + qt_off) < a.tq && ((((c << 3) + xcd) << csh) + ct_off) < a.tc;
+    return ((g << qsh) + qt_off) < a.tq && clip_tile(c) < a.tc;
   };
   // Walk order: the corpus is visited in chunks of 2^rsh rounds (one round = the 8 XCDs x 2^csh clip tiles the chip
   // works on at a time); EVERY query group visits a chunk before the walk moves to the next chunk.  A chunk is sized to
@@ -283,7 +289,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   const char* sbase_b = nullptr;
 
   auto setup_issue_segment = [&](bool new_tile) {
-    const int q0 = ((i_g << qsh) + qt_off) * 256, v0 = ((((i_c << 3) + xcd) << csh) + ct_off) * 2;
+    const int q0 = ((i_g << qsh) + qt_off) * 256, v0 = clip_tile(i_c) * 2;
     int lane_o = lane;                              // opaque copy: keeps LICM from hoisting (and keeping live across
     asm volatile("" : "+v"(lane_o));                // the MFMA loop) everything derived from the lane id below
     if (new_tile) {
@@ -566,7 +572,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     }
     // ---- end of a (tile, modality) segment: mask_logits + max over the video's 128 clips, inside the wave -----
     if constexpr (PACKED) {
-      const int q0 = ((c_g << qsh) + qt_off) * 256, ct = (((c_c << 3) + xcd) << csh) + ct_off;
+      const int q0 = ((c_g << qsh) + qt_off) * 256, ct = clip_tile(c_c);
       int fr_e = fr, fg_e = fg;
       asm volatile("" : "+v"(fr_e), "+v"(fg_e));
       const bool last_mod = c_mod == a.n_mod - 1;
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         slot(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{}, stash4[3], ids.w);
       }
     } else {
-      const int q0 = ((c_g << qsh) + qt_off) * 256, vid = ((((c_c << 3) + xcd) << csh) + ct_off) * 2 + wn;
+      const int q0 = ((c_g << qsh) + qt_off) * 256, vid = clip_tile(c_c) * 2 + wn;
       int fr_e = fr, fg_e = fg;                     // opaque copies (see setup_issue_segment)
       asm volatile("" : "+v"(fr_e), "+v"(fg_e));
       const float* mpatch = reinterpret_cast<const float*>(smem + MASK_OFF + (c_seg & 1) * 1024) + wn * 128 + fr_e;
@@ -802,6 +808,7 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
   // and were +0.6 % faster, but the fabric-side FETCH_SIZE -- which counts Infinity-Cache hits -- rose from 129 to 209 GB
   // per launch (the query tiles are re-fetched at every chunk switch): not kept (profiles/r02_k6_notes.md).
   a.rsh = g_q2c_chunk_log2 >= 0 ? g_q2c_chunk_log2 : 20;
+  a.lsh = g_q2c_line_log2;
   if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled, mask_mode);
   return launch_q2c_persist<float>(a, st, tiled, mask_mode);
 }

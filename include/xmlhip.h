@@ -94,9 +94,21 @@ int xml_attention_block(const void* x, const float* key_mask, const void* wqkv, 
  * sequence i = rows cu_seqlens[i] .. cu_seqlens[i+1]-1 (cu_seqlens: n+1 int32, cu_seqlens[n] == rows), every sequence
  * 1 .. max_len <= 32 tokens.  Per valid token the result is that of xml_attention_block / xml_modular_pool on the padded
  * batch: projections and LayerNorm are row-wise, and a padded key adds exp(-10000 + s - max) = +0 to the softmax sum and
- * 0 * v to P V.  (K1+K2 on packed rows is xml_linear_ln_relu_pos with seq_len = rows and the positional rows gathered per
- * token.)  hidden % (32 * n_heads) == 0 as for xml_attention_block; xml_modular_pool_varlen: hidden <= 1024.
+ * 0 * v to P V.  (K1+K2 on packed rows: xml_linear_ln_relu_pos_packed below.)  hidden % (32 * n_heads) == 0 as for xml_attention_block; xml_modular_pool_varlen: hidden <= 1024.
  * --------------------------------------------------------------------------------------------- */
+/* Packing plan of a padded batch: mask (n, lq) f32, every row a non-empty prefix of ones (lq <= 64).
+ *   cu_seqlens (n + 1) int32, src_row (>= n * lq) int32: packed token i is row src_row[i] = seq * lq + t of the padded batch;
+ *   status (2) int32: status[0] = number of packed rows, or -1 when some mask row is not such a prefix (the caller keeps
+ *   the padded path).  Three small launches; the caller reads status[0] back (its launch shapes depend on it).
+ * K1+K2 on the packed tokens: xml_linear_ln_relu_pos with the source rows read through src_row (x is the PADDED batch,
+ * (n * lq, d_in)) and the positional row of token i = pos[src_row[i] % lq].  d_in % 8 == 0, d_in <= 4096. */
+int xml_pack_plan(const float* mask, int64_t n, int lq, int32_t* cu_seqlens, int32_t* src_row, int32_t* status,
+                  xml_stream_t stream);
+size_t xml_linear_ln_relu_pos_packed_workspace_bytes(int64_t rows, int d_in, int hidden, int dt);
+int xml_linear_ln_relu_pos_packed(const void* x, int x_dt, const int32_t* src_row, int lq, const float* ln_in_g,
+                                  const float* ln_in_b, const void* w, const float* b, const void* pos,
+                                  const float* ln_pos_g, const float* ln_pos_b, void* y, int64_t rows, int d_in,
+                                  int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream);
 size_t xml_attention_block_varlen_workspace_bytes(int64_t rows, int hidden, int dt);
 int xml_attention_block_varlen(const void* x, const int32_t* cu_seqlens, const void* wqkv, const float* bqkv,
                                const void* wo, const float* bo, const float* ln_g, const float* ln_b, void* y,

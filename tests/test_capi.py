@@ -66,6 +66,11 @@ def test_round3_entries_validate_arguments(lib):
                                           None) == -1
     assert lib.xml_modular_pool_varlen(None, None, None, None, 2, 30, 768, 2, 1, None) == -1
     assert lib.xml_gemm_tn(None, None, None, None, 100, 768, 768, 1, 1, None) == -1
+    assert lib.xml_pack_plan(None, 10, 30, None, None, None, None) == -1
+    assert lib.xml_linear_ln_relu_pos_packed_workspace_bytes(175000, 768, 768, 1) > \
+        lib.xml_linear_ln_relu_pos_workspace_bytes(175000, 768, 768, 1)
+    assert lib.xml_linear_ln_relu_pos_packed(None, 0, None, 30, None, None, None, None, None, None, None, None, 10, 768, 768,
+                                             1, None, 0, None) == -1
 
 
 def test_product_path_fails_loudly_without_gpu():

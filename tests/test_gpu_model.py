@@ -538,6 +538,16 @@ def test_packed_query_encode_equals_padded(dtype, hidden, nq, monkeypatch):
         qm2 = qm.clone()
         qm2[0, 3] = 0
         assert m._encode_query_packed(qf, qm2) is None
+        # the plan itself: cu_seqlens = running token counts, src_row = (sequence, token) of every packed row
+        from tvretrieval_amd import ops
+        cu, src, rows = ops.pack_plan(qm.float().contiguous())
+        assert rows == int(lens.sum())
+        want_cu = np.concatenate([[0], np.cumsum(lens)])
+        assert np.array_equal(cu.cpu().numpy(), want_cu)
+        want_src = np.concatenate([i * qm.shape[1] + np.arange(n_) for i, n_ in enumerate(lens)])
+        assert np.array_equal(src[:rows].cpu().numpy(), want_src)
+        for bad in (qm2, torch.zeros_like(qm), qm * 0.5):
+            assert ops.pack_plan(bad.float().contiguous())[2] == -1
     # f32: the same arithmetic per valid token.  bf16: the packed batch has fewer rows, so a projection may run on another
     # GEMM kernel of the family (LayerNorm in the epilogue or behind it: one rounding of the pre-LN value more or less) --
     # a couple of bf16 ulps on single elements, nothing systematic

@@ -39,3 +39,30 @@ for m, n, k in [(300000, 2304, 768), (300000, 768, 768), (262144, 768, 3072)]:
         t = max(p[6], 1)
         print("  wave %d: tiles %3d  K loop %6.2f us  bias/drain %5.2f us  rows+stores %5.2f us  ln-sync %5.2f  ln-pass2 %5.2f   total/tile %6.2f us"
               % (w_, p[6], p[0] / t / 100, p[1] / t / 100, p[2] / t / 100, p[3] / t / 100, p[4] / t / 100, p[5] / t / 100))
+
+
+def show(tag, ms, k):
+    buf = (ctypes.c_ulonglong * 64)()
+    assert lib.xml_debug_read_gemm_probe(buf) == 0
+    print("%s: %.3f ms" % (tag, ms))
+    for w_ in range(8):
+        p = [buf[w_ * 8 + i] for i in range(8)]
+        t = max(p[6], 1)
+        print("  wave %d: tiles %3d  K loop %6.2f us  bias/drain %5.2f us  rows+stores %5.2f us  ln-sync %5.2f  ln-pass2 %5.2f   total/tile %6.2f us"
+              % (w_, p[6], p[0] / t / 100, p[1] / t / 100, p[2] / t / 100, p[3] / t / 100, p[4] / t / 100, p[5] / t / 100))
+
+
+# the LayerNorm-epilogue kernel through K1+K2 on packed query tokens (175 000 rows, N = K = 768)
+rows, h = 175000, 768
+x = torch.randn(1, rows, h, device="cuda", generator=g)
+gam, bet = torch.ones(h, device="cuda"), torch.zeros(h, device="cuda")
+w = (torch.randn(h, h, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+b = torch.zeros(h, device="cuda")
+pos = (torch.randn(rows, h, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+for _ in range(3):
+    ops.linear_ln_relu_pos(x, gam, bet, w, b, pos, gam, bet)
+torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); ops.linear_ln_relu_pos(x, gam, bet, w, b, pos, gam, bet); e1.record()
+torch.cuda.synchronize()
+show("K1+K2 (input LN launch + LN-epilogue GEMM), rows %d" % rows, e0.elapsed_time(e1), h)

@@ -18,7 +18,7 @@ static constexpr int LP = 128 + 4;       // padded row length of the LDS similar
 struct ConvseWs {
   int32_t* counts;     // [nv]   pairs per video
   int32_t* offsets;    // [nv+1] exclusive scan of counts
-  int32_t* cursor;     // [nv]
+  int32_t* pos;        // [P]    rank of a pair among the pairs of its video (the value its counting atomic returned)
   int32_t* chunk_off;  // [nv+1] exclusive scan of ceil(count / TM)
   int32_t* bucket;     // [P]    pair ids grouped by video
   int32_t* chunk_vid;  // [P / TM + min(P, nv)] video of every chunk (saves a 15-step dependent binary search per workgroup)
@@ -33,14 +33,14 @@ static size_t convse_ws_layout(const xml_convse_desc* d, ConvseWs* w, char* base
   };
   const size_t nv = (size_t)d->nv, P = (size_t)d->nq * d->kpairs;
   char* counts = take(nv * 4);
-  char* cursor = take(nv * 4);   // counts and cursor are adjacent: one memset clears both
   char* offsets = take((nv + 1) * 4);
   char* chunk_off = take((nv + 1) * 4);
   char* bucket = take(P * 4);
+  char* pos = take(P * 4);
   char* chunk_vid = take((P / TM + (P < nv ? P : nv) + 1) * 4);
   if (w) {
     w->chunk_vid = (int32_t*)chunk_vid;
-    w->counts = (int32_t*)counts; w->cursor = (int32_t*)cursor; w->offsets = (int32_t*)offsets;
+    w->counts = (int32_t*)counts; w->pos = (int32_t*)pos; w->offsets = (int32_t*)offsets;
     w->chunk_off = (int32_t*)chunk_off; w->bucket = (int32_t*)bucket;
   }
   return off;
@@ -51,70 +51,72 @@ extern "C" size_t xml_convse_rerank_workspace_bytes(const xml_convse_desc* d) {
   return convse_ws_layout(d, nullptr, nullptr);
 }
 
-__global__ void convse_count_kernel(const int32_t* __restrict__ pair_vid, int32_t* __restrict__ counts, int64_t P,
-                                    int nv) {
+// Inverting the pair list (video -> the pairs that selected it) in three passes with ONE atomic per pair: the counting
+// atomic's return value is the pair's rank inside its video's bucket, so the fill pass is a plain scatter.  (The order of a
+// bucket depends on the atomics' arrival order; every pair writes its own output row, so the results do not.)
+__global__ void convse_count_kernel(const int32_t* __restrict__ pair_vid, int32_t* __restrict__ counts,
+                                    int32_t* __restrict__ pos, int64_t P, int nv) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int v = pair_vid[p];
-  if (v >= 0 && v < nv) atomicAdd(&counts[v], 1);
+  pos[p] = (v >= 0 && v < nv) ? atomicAdd(&counts[v], 1) : -1;
 }
 
-// rows of skipped pairs (pair_vid < 0: owned by another shard / padding) are zero-filled, 16 B per thread, coalesced
+// rows of skipped pairs (pair_vid < 0: owned by another shard / padding) are zero-filled: one thread per pair looks, the
+// (rare) skipped ones write their two rows
 __global__ void convse_zero_skipped_kernel(const int32_t* __restrict__ pair_vid, float* __restrict__ st_out,
                                            float* __restrict__ ed_out, int64_t P, int nv, int lpad4) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p = i / lpad4;
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int v = pair_vid[p];
   if (v >= 0 && v < nv) return;
   const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-  reinterpret_cast<float4*>(st_out)[i] = z;
-  reinterpret_cast<float4*>(ed_out)[i] = z;
+  float4* s4 = reinterpret_cast<float4*>(st_out) + p * lpad4;
+  float4* e4 = reinterpret_cast<float4*>(ed_out) + p * lpad4;
+  for (int i = 0; i < lpad4; ++i) { s4[i] = z; e4[i] = z; }
 }
 
-// single workgroup: exclusive scans of counts and of ceil(counts / TM)
+// single workgroup: exclusive scans of counts and of ceil(counts / TM).  Thread t owns the consecutive videos
+// [t * per, (t + 1) * per): serial sums, one shuffle scan over the 1024 partial sums, serial write-out.
 __global__ __launch_bounds__(1024) void convse_scan_kernel(const int32_t* __restrict__ counts,
                                                            int32_t* __restrict__ offsets,
                                                            int32_t* __restrict__ chunk_off,
                                                            int32_t* __restrict__ chunk_vid, int nv) {
-  __shared__ int32_t sa[1024], sb[1024];
-  __shared__ int32_t carry_a, carry_b;
-  const int tid = threadIdx.x;
-  if (tid == 0) { carry_a = 0; carry_b = 0; }
-  __syncthreads();
-  for (int base = 0; base < nv; base += 1024) {
-    const int i = base + tid;
-    const int c = i < nv ? counts[i] : 0;
-    const int ch = (c + TM - 1) / TM;
-    sa[tid] = c; sb[tid] = ch;
-    __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-      const int va = tid >= o ? sa[tid - o] : 0, vb = tid >= o ? sb[tid - o] : 0;
-      __syncthreads();
-      sa[tid] += va; sb[tid] += vb;
-      __syncthreads();
-    }
-    if (i < nv) {
-      offsets[i] = carry_a + sa[tid] - c;
-      const int c0 = carry_b + sb[tid] - ch;
-      chunk_off[i] = c0;
-      for (int j = 0; j < ch; ++j) chunk_vid[c0 + j] = i;
-    }
-    __syncthreads();
-    if (tid == 1023) { carry_a += sa[1023]; carry_b += sb[1023]; }
-    __syncthreads();
+  __shared__ int32_t wa[16], wb[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (nv + 1023) / 1024;
+  const int r0 = min(nv, tid * per), r1 = min(nv, r0 + per);
+  int sa = 0, sb = 0;
+  for (int i = r0; i < r1; ++i) {
+    const int c = counts[i];
+    sa += c; sb += (c + TM - 1) / TM;
   }
-  if (tid == 0) { offsets[nv] = carry_a; chunk_off[nv] = carry_b; }
+  int ia = sa, ib = sb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int va = __shfl_up(ia, o, 64), vb = __shfl_up(ib, o, 64);
+    if (lane >= o) { ia += va; ib += vb; }
+  }
+  if (lane == 63) { wa[wave] = ia; wb[wave] = ib; }
+  __syncthreads();
+  int a = ia - sa, b = ib - sb;
+  for (int w = 0; w < wave; ++w) { a += wa[w]; b += wb[w]; }
+  for (int i = r0; i < r1; ++i) {
+    const int c = counts[i], ch = (c + TM - 1) / TM;
+    offsets[i] = a;
+    chunk_off[i] = b;
+    for (int j = 0; j < ch; ++j) chunk_vid[b + j] = i;
+    a += c; b += ch;
+  }
+  if (tid == 1023) { offsets[nv] = a; chunk_off[nv] = b; }    // the last thread's running sums are the totals
 }
 
 __global__ void convse_fill_kernel(const int32_t* __restrict__ pair_vid, const int32_t* __restrict__ offsets,
-                                   int32_t* __restrict__ cursor, int32_t* __restrict__ bucket, int64_t P, int nv) {
+                                   const int32_t* __restrict__ pos, int32_t* __restrict__ bucket, int64_t P) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
-  const int v = pair_vid[p];
-  if (v < 0 || v >= nv) return;
-  const int pos = atomicAdd(&cursor[v], 1);
-  bucket[offsets[v] + pos] = (int32_t)p;
+  const int r = pos[p];
+  if (r >= 0) bucket[offsets[pair_vid[p]] + r] = (int32_t)p;
 }
 
 struct ConvseArgs {
@@ -367,7 +369,7 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   ConvseWs w;
   convse_ws_layout(d, &w, (char*)ws);
   const int64_t P = (int64_t)d->nq * d->kpairs;
-  // counts and cursor are the first two (adjacent, 256-aligned) regions.  Zeroed by a kernel, not hipMemsetAsync:
+  // counts is the first (256-aligned) region.  Zeroed by a kernel, not hipMemsetAsync:
   // as a memset NODE of a captured HIP graph the reset did not happen on the second replay (stale cursors ->
   // out-of-bounds bucket writes, seen with inference.GraphedVcmrSearch); a kernel node replays faithfully.
   {
@@ -375,18 +377,17 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
     hipLaunchKernelGGL(convse_zero_words_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, st, (uint32_t*)w.counts, nwords);
     XML_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, P, d->nv);
+  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, w.pos, P, d->nv);
   XML_CHECK_LAUNCH();
   if (!(d->softmax & 2)) {     // bit 1: the caller never reads the rows of skipped pairs
-    hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P * (d->lpad / 4), 256)), dim3(256), 0, st, pair_vid,
-                       st_out, ed_out, P, d->nv, d->lpad / 4);
+    hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, st_out, ed_out, P,
+                       d->nv, d->lpad / 4);
     XML_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid,
                      d->nv);
   XML_CHECK_LAUNCH();
-  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.cursor, w.bucket,
-                     P, d->nv);
+  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P);
   XML_CHECK_LAUNCH();
   ConvseArgs a;
   a.q_lin[0] = q_lin0; a.q_lin[1] = q_lin1;
@@ -442,14 +443,13 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
     hipLaunchKernelGGL(convse_zero_words_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, st, (uint32_t*)w.counts, nwords);
     XML_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, P, nv);
+  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, w.pos, P, nv);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(rescore_fill_skipped_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, out, P, nv);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid, nv);
   XML_CHECK_LAUNCH();
-  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.cursor, w.bucket, P,
-                     nv);
+  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P);
   XML_CHECK_LAUNCH();
   RescoreArgs a;
   a.qn[0] = qn0; a.qn[1] = qn1; a.cn[0] = cn0; a.cn[1] = cn1;

@@ -158,12 +158,13 @@ template <typename InT, typename BT, typename OutT, int VPL>
 __global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __restrict__ a, const BT* __restrict__ b,
                                                                 const float* __restrict__ g,
                                                                 const float* __restrict__ beta, OutT* __restrict__ y,
-                                                                int64_t rows, int d, int ld_out, float eps) {
+                                                                int64_t rows, int d, int ld_out, float eps,
+                                                                const int32_t* __restrict__ src_row) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int nvec = d >> 3;
-  const InT* pa = a + row * d;
+  const InT* pa = a + (src_row ? (int64_t)src_row[row] : row) * d;        // (packed tokens: row i reads source row src_row[i])
   const BT* pb = b ? b + row * d : nullptr;
   OutT* py = y + row * ld_out;
   float x[VPL * 8];
@@ -211,12 +212,13 @@ __global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __res
 
 template <typename InT, typename BT, typename OutT>
 static int launch_ln(const void* a, const void* b, const float* g, const float* beta, void* y, int64_t rows, int d,
-                     int ld_out, hipStream_t st) {
+                     int ld_out, hipStream_t st, const int32_t* src_row = nullptr) {
   const dim3 grid(cdiv(rows, 4)), blk(256);
   const bool vec = (d % 8 == 0) && (ld_out % 8 == 0);     // 16-byte aligned rows on both sides
 #define XML_LN_VEC(VPL)                                                                                              \
   hipLaunchKernelGGL((add_layernorm_vec_kernel<InT, BT, OutT, VPL>), grid, blk, 0, st, (const InT*)a, (const BT*)b, g, \
-                     beta, (OutT*)y, rows, d, ld_out, 1e-5f)
+                     beta, (OutT*)y, rows, d, ld_out, 1e-5f, src_row)
+  if (src_row && !(vec && d <= 4096)) return XML_ERR_UNSUPPORTED;
   if (vec && d <= 1024) XML_LN_VEC(2);
   else if (vec && d <= 3072) XML_LN_VEC(6);
   else if (vec && d <= 4096) XML_LN_VEC(8);
@@ -228,16 +230,21 @@ static int launch_ln(const void* a, const void* b, const float* g, const float* 
   return XML_OK;
 }
 
-int xmli_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
-                       int64_t rows, int d, int ld_out, int dt, hipStream_t st) {
-  XML_ENTER();
+static int add_layernorm_rows(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
+                              int64_t rows, int d, int ld_out, int dt, hipStream_t st, const int32_t* src_row) {
   if (rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
   if (dt == XML_F32) {
     if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
-    return launch_ln<float, float, float>(a, b, g, beta, y, rows, d, ld_out, st);
+    return launch_ln<float, float, float>(a, b, g, beta, y, rows, d, ld_out, st, src_row);
   }
-  if (a_dt == XML_F32) return launch_ln<float, bf16_t, bf16_t>(a, b, g, beta, y, rows, d, ld_out, st);
-  return launch_ln<bf16_t, bf16_t, bf16_t>(a, b, g, beta, y, rows, d, ld_out, st);
+  if (a_dt == XML_F32) return launch_ln<float, bf16_t, bf16_t>(a, b, g, beta, y, rows, d, ld_out, st, src_row);
+  return launch_ln<bf16_t, bf16_t, bf16_t>(a, b, g, beta, y, rows, d, ld_out, st, src_row);
+}
+
+int xmli_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
+                       int64_t rows, int d, int ld_out, int dt, hipStream_t st) {
+  XML_ENTER();
+  return add_layernorm_rows(a, a_dt, b, g, beta, y, rows, d, ld_out, dt, st, nullptr);
 }
 
 extern "C" int xml_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta,
@@ -404,6 +411,122 @@ extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_i
                    st) == XML_OK)
     return XML_OK;                                         // (a refused launch falls through to the 3-launch path)
   rc = xmli_gemm(xn, w, b, pos, pre, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, /*out_f32*/ 1, dt, st);
+  if (rc) return rc;
+  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, dt, st);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Packing plan of a padded token batch + K1+K2 on the packed tokens (the query encoder without its padding rows)
+// ---------------------------------------------------------------------------------------------------
+// Three small launches instead of a dozen framework kernels with a host sync in between (10 000 x 30 tokens: ~1 MB of mask):
+//   lengths   one wave per sequence: lane t reads mask[t]; the row must be a non-empty PREFIX of ones (values exactly 0 / 1)
+//   scan      one workgroup: cu_seqlens = exclusive scan of the lengths; status[0] = packed rows, or -1 for a bad mask
+//   fill      one wave per sequence: source row of every packed token
+__global__ __launch_bounds__(256) void pack_len_kernel(const float* __restrict__ mask, int n, int lq, int32_t* __restrict__ cu,
+                                                       int32_t* __restrict__ status) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float v = lane < lq ? mask[(int64_t)r * lq + lane] : 0.f;
+  const unsigned long long ones = __ballot(v == 1.f), other = __ballot(v != 1.f && v != 0.f);
+  const int len = (int)__popcll(ones);
+  const bool ok = other == 0 && len > 0 && ones == (len == 64 ? ~0ull : ((1ull << len) - 1ull));
+  if (lane == 0) {
+    cu[r + 1] = len;
+    if (!ok) atomicOr(&status[1], 1);
+  }
+}
+
+__global__ __launch_bounds__(1024) void pack_scan_kernel(int n, int32_t* __restrict__ cu, int32_t* __restrict__ status) {
+  __shared__ int s_wave[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (n + 1023) / 1024;
+  const int r0 = min(n, tid * per), r1 = min(n, r0 + per);
+  int sum = 0;
+  for (int r = r0; r < r1; ++r) sum += cu[r + 1];
+  int inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int v = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += v;
+  }
+  if (lane == 63) s_wave[wave] = inc;
+  __syncthreads();
+  int base = inc - sum;
+  for (int w = 0; w < wave; ++w) base += s_wave[w];
+  for (int r = r0; r < r1; ++r) {            // (a thread reads only its own entries before it overwrites them)
+    base += cu[r + 1];
+    cu[r + 1] = base;
+  }
+  if (tid == 0) {
+    cu[0] = 0;
+    int total = 0;
+    for (int w = 0; w < 16; ++w) total += s_wave[w];
+    status[0] = status[1] ? -1 : total;
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_fill_kernel(int n, int lq, const int32_t* __restrict__ cu, int32_t* __restrict__ src_row) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int b = cu[r], len = cu[r + 1] - b;
+  if (lane < len) src_row[b + lane] = r * lq + lane;
+}
+
+extern "C" int xml_pack_plan(const float* mask, int64_t n, int lq, int32_t* cu_seqlens, int32_t* src_row, int32_t* status,
+                             xml_stream_t stream) {
+  XML_ENTER();
+  if (!mask || !cu_seqlens || !src_row || !status || n <= 0 || lq <= 0) return XML_ERR_BAD_ARG;
+  if (lq > 64 || n * lq > (int64_t)INT32_MAX) return XML_ERR_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  xml_zero_async(status, 8, st);
+  hipLaunchKernelGGL(pack_len_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, mask, (int)n, lq, cu_seqlens, status);
+  hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, (int)n, cu_seqlens, status);
+  hipLaunchKernelGGL(pack_fill_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, (int)n, lq, cu_seqlens, src_row);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// dst[i] = table[src_row[i] % lq]: the positional row of every packed token (16-byte pieces; row_bytes % 16 == 0)
+__global__ __launch_bounds__(256) void gather_pos_rows_kernel(const uint4* __restrict__ table, const int32_t* __restrict__ src_row,
+                                                              uint4* __restrict__ dst, int64_t rows, int lq, int vec_per_row) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * vec_per_row) return;
+  const int64_t r = i / vec_per_row;
+  const int v = (int)(i - r * vec_per_row);
+  dst[i] = table[(int64_t)(src_row[r] % lq) * vec_per_row + v];
+}
+
+extern "C" size_t xml_linear_ln_relu_pos_packed_workspace_bytes(int64_t rows, int d_in, int hidden, int dt) {
+  return xml_linear_ln_relu_pos_workspace_bytes(rows, d_in, hidden, dt) + align_up((size_t)rows * hidden * dt_size(dt), 256);
+}
+
+extern "C" int xml_linear_ln_relu_pos_packed(const void* x, int x_dt, const int32_t* src_row, int lq, const float* ln_in_g,
+                                             const float* ln_in_b, const void* w, const float* b, const void* pos,
+                                             const float* ln_pos_g, const float* ln_pos_b, void* y, int64_t rows, int d_in,
+                                             int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !src_row || !ln_in_g || !ln_in_b || !w || !b || !pos || !ln_pos_g || !ln_pos_b || !y || !ws) return XML_ERR_BAD_ARG;
+  if (rows <= 0 || rows > (int64_t)INT32_MAX || lq <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (d_in <= 0 || d_in % 8 || d_in > 4096 || hidden % 8) return XML_ERR_UNSUPPORTED;
+  if (ws_bytes < xml_linear_ln_relu_pos_packed_workspace_bytes(rows, d_in, hidden, dt)) return XML_ERR_WORKSPACE;
+  hipStream_t st = (hipStream_t)stream;
+  char* pg = (char*)ws;                                            // gathered positional rows (rows, hidden) dt
+  char* xn = pg + align_up((size_t)rows * hidden * dt_size(dt), 256);
+  char* pre = xn + align_up((size_t)rows * d_in * dt_size(dt), 256);
+  const int vpr = hidden * (int)dt_size(dt) / 16;
+  hipLaunchKernelGGL(gather_pos_rows_kernel, dim3(cdiv(rows * vpr, 256)), dim3(256), 0, st, (const uint4*)pos, src_row,
+                     (uint4*)pg, rows, lq, vpr);
+  XML_CHECK_LAUNCH();
+  int rc = add_layernorm_rows(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_in, dt, st, src_row);
+  if (rc) return rc;
+  // with seq_len = rows, "row % seq_len" addresses the gathered positional rows one to one
+  if (xmli_gemm_ln_eligible(rows, hidden, d_in, dt) &&
+      xmli_gemm_ln(xn, w, b, pg, ln_pos_g, ln_pos_b, y, rows, hidden, d_in, /*relu*/ 1, /*add_mode*/ 1, (int)rows, dt, pre,
+                   st) == XML_OK)
+    return XML_OK;
+  rc = xmli_gemm(xn, w, b, pg, pre, rows, hidden, d_in, /*relu*/ 1, /*add_mode*/ 1, (int)rows, /*out_f32*/ 1, dt, st);
   if (rc) return rc;
   return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, dt, st);
 }

@@ -360,24 +360,18 @@ class XML(nn.Module):
         Returns None (caller keeps the padded path) unless every mask row is a non-empty prefix of ones."""
         dt = self.compute_dtype
         n, lq, d_in = query_feat.shape
-        mask = query_mask.float()
-        lens = mask.sum(1)
-        ar = torch.arange(lq, device=mask.device, dtype=torch.float32)
-        if not bool(((mask == (ar[None, :] < lens[:, None]).float()).all()) & (lens >= 1).all()):     # (one host sync)
-            return None
-        idx = torch.nonzero(mask.reshape(-1), as_tuple=False).reshape(-1)           # source row of every packed token
-        rows = int(idx.numel())
-        cu = torch.zeros(n + 1, dtype=torch.int32, device=mask.device)
-        cu[1:] = torch.cumsum(lens, 0).to(torch.int32)
         p, e = self.query_input_proj.packed(dt), self.query_pos_embed.packed(dt)
         if lq > e["pos"].shape[0]:
             raise IndexError("sequence length %d exceeds the positional table (%d)" % (lq, e["pos"].shape[0]))
+        if d_in % 8 or d_in > 4096:
+            return None
+        cu, src_row, rows = ops.pack_plan(query_mask.float().contiguous())         # (one 4-byte read-back)
+        if rows < 0:
+            return None
         feat = query_feat if query_feat.dtype in (torch.float32, dt) else query_feat.float()
-        x = feat.reshape(n * lq, d_in).index_select(0, idx).contiguous()
-        pos_rows = e["pos"].index_select(0, idx % lq).contiguous()                  # positional row of every packed token
-        # K1+K2 on the packed rows: with seq_len = rows, "row % seq_len" addresses the gathered positional rows one to one
-        x = ops.linear_ln_relu_pos(x.view(1, rows, d_in), p["ln_g"], p["ln_b"], p["w"], p["b"], pos_rows, e["ln_g"],
-                                   e["ln_b"]).view(rows, -1)
+        # K1+K2: token i of the packed batch reads row src_row[i] of the padded one, positional row src_row[i] % lq
+        x = ops.linear_ln_relu_pos_packed(feat.reshape(n * lq, d_in).contiguous(), src_row, rows, lq, p["ln_g"], p["ln_b"],
+                                          p["w"], p["b"], e["pos"], e["ln_g"], e["ln_b"])
         a, o = self.query_encoder.self.packed(dt), self.query_encoder.output.packed(dt)
         max_len = int(lq)
         x = ops.attention_block_varlen(x, cu, n, max_len, a["wqkv"], a["bqkv"], o["wo"], o["bo"], o["ln_g"], o["ln_b"],

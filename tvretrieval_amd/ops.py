@@ -541,6 +541,37 @@ def exact_certificate(filter_scores, top_val, eq, ec, slack, alpha, outside):
 
 
 # ---- packed variable-length sequences (the query encoder without its padding rows) -------------------------------------
+def pack_plan(mask):
+    """Packing plan of a padded batch.  mask (n, lq) f32 -> (cu_seqlens (n + 1,) int32, src_row (n * lq,) int32, rows);
+    rows = -1 when some mask row is not a non-empty prefix of ones.  (One 4-byte read-back: the launch shapes of the
+    packed kernels depend on rows.)"""
+    _req(mask, "mask", torch.float32)
+    n, lq = mask.shape
+    cu = torch.empty(n + 1, dtype=torch.int32, device=mask.device)
+    src = torch.empty(n * lq, dtype=torch.int32, device=mask.device)
+    status = torch.empty(2, dtype=torch.int32, device=mask.device)
+    check(_lib.load().xml_pack_plan(_p(mask), n, lq, _p(cu), _p(src), _p(status), _stream()), "xml_pack_plan")
+    return cu, src, int(status[0].item())
+
+
+def linear_ln_relu_pos_packed(x, src_row, rows, lq, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
+    """K1+K2 on packed tokens: x (n * lq, d_in) f32 or w.dtype is the PADDED batch, packed token i = x[src_row[i]] with
+    positional row pos[src_row[i] % lq] -> (rows, hidden) w.dtype."""
+    _req(x, "x"); _req(src_row, "src_row", torch.int32); _req(w, "w"); _req(pos, "pos", w.dtype)
+    for t, nm in ((ln_in_g, "ln_in_g"), (ln_in_b, "ln_in_b"), (b, "b"), (ln_pos_g, "ln_pos_g"), (ln_pos_b, "ln_pos_b")):
+        _req(t, nm, torch.float32)
+    d_in, hidden = x.shape[1], w.shape[0]
+    assert w.shape[1] == d_in and pos.shape[0] >= lq and pos.shape[1] == hidden and src_row.numel() >= rows
+    lib = _lib.load()
+    dt = dt_of(w)
+    y = torch.empty((rows, hidden), dtype=w.dtype, device=x.device)
+    ws = _workspace(lib.xml_linear_ln_relu_pos_packed_workspace_bytes(rows, d_in, hidden, dt), x.device)
+    check(lib.xml_linear_ln_relu_pos_packed(_p(x), dt_of(x), _p(src_row), int(lq), _p(ln_in_g), _p(ln_in_b), _p(w), _p(b),
+                                            _p(pos), _p(ln_pos_g), _p(ln_pos_b), _p(y), rows, d_in, hidden, dt, _p(ws),
+                                            ws.numel(), _stream()), "xml_linear_ln_relu_pos_packed")
+    return y
+
+
 def attention_block_varlen(x, cu_seqlens, n, max_len, wqkv, bqkv, wo, bo, ln_g, ln_b, n_heads):
     """K3+K4 on packed tokens.  x (rows, H); cu_seqlens (n + 1,) int32 -> (rows, H)."""
     _req(x, "x"); _req(cu_seqlens, "cu_seqlens", torch.int32); _req(wqkv, "wqkv", x.dtype); _req(wo, "wo", x.dtype)

@@ -380,6 +380,43 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       int gcol[DIRECT ? NGRP : 1];
       bool gok[DIRECT ? NGRP : 1];
       int pcol[DIRECT ? NGRP / 2 : 1];      // column this lane STORES for group pair pq (see the stores below)
+      // Stores in FULL 128-byte lines.  Written as they lie, groups (q, fg = 0..3) of a row are 64 contiguous bytes: every
+      // store instruction touches 16 rows x half a line, 2048 line requests per tile -- and the CU's write path retires
+      // one request per 5-8 cycles (the phase probe: 17 K cycles to drain a tile, a third of its time; vmcnt counts the
+      // stores, so the K loop's counted waits block behind them).  Groups 2 p and 2 p + 1 of a row are the two halves of
+      // one line: the EVEN store of a pair writes rows fr & ~1 -- even lanes their own group 2 p, odd lanes group 2 p + 1
+      // of the row BELOW them (DPP row_shr:1) --, the ODD store rows fr | 1 likewise (row_shl:1): 8 rows x one whole
+      // line per instruction, 1024 requests per tile, no LDS.
+      auto store_rows = [&](int m4, auto& v) {        // (DIRECT only; v: float [NGRP][GC])
+        uint4 pk[NGRP];
+#pragma unroll
+        for (int q = 0; q < NGRP; ++q) pk[q] = pack16<OutT>(v[q]);
+        const bool odd = (fr_e & 1) != 0;
+        const int64_t m_even = m0 + wm * 64 + m4 * 16 + (fr_e & ~1);
+#pragma unroll
+        for (int pq = 0; pq < NGRP / 2; ++pq) {
+          const uint4 dn = dpp_u4<0x111>(pk[2 * pq + 1]);       // row_shr:1: lane i <- lane i - 1
+          const uint4 up = dpp_u4<0x101>(pk[2 * pq]);           // row_shl:1: lane i <- lane i + 1
+          // (component-wise selects: `odd ? a : b` on the struct type becomes a select of stack ADDRESSES + a scratch load)
+          const uint4 own_e = pk[2 * pq], own_o = pk[2 * pq + 1];
+          const uint4 d_even = make_uint4(odd ? dn.x : own_e.x, odd ? dn.y : own_e.y, odd ? dn.z : own_e.z, odd ? dn.w : own_e.w);
+          const uint4 d_odd = make_uint4(odd ? own_o.x : up.x, odd ? own_o.y : up.y, odd ? own_o.z : up.z, odd ? own_o.w : up.w);
+          const int col = pcol[pq];
+          if (col + GC <= N) {
+            // non-temporal: this kernel only runs on outputs of >= 3072 tiles (400 MB and up), nothing of which survives
+            // in a cache until its consumer starts; streaming stores retire ~2.5 % faster here (886 -> 906 TF at
+            // N = 2304, same box).  Not for LNE: pass 2 re-reads the tile through this XCD's L2.
+            if (!LNE && !(a.probe & 8)) {      // (probe bit 3: plain stores, A/B)
+              typedef unsigned int g_u4 __attribute__((ext_vector_type(4)));
+              if (m_even < M && !(a.probe & 4)) __builtin_nontemporal_store(g_u4{d_even.x, d_even.y, d_even.z, d_even.w}, reinterpret_cast<g_u4*>(out + m_even * N + col));
+              if (m_even + 1 < M && !(a.probe & 4)) __builtin_nontemporal_store(g_u4{d_odd.x, d_odd.y, d_odd.z, d_odd.w}, reinterpret_cast<g_u4*>(out + (m_even + 1) * N + col));
+            } else {
+              if (m_even < M && !(a.probe & 4)) st_global16(out + m_even * N + col, d_even);        // probe bit 2: no stores
+              if (m_even + 1 < M && !(a.probe & 4)) st_global16(out + (m_even + 1) * N + col, d_odd);
+            }
+          }
+        }
+      };
       if constexpr (DIRECT) {
 #pragma unroll
         for (int q = 0; q < NGRP; ++q) {
@@ -470,42 +507,18 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
               ln_publish(pp, s, c2);
             }
           }
-          // Stores in FULL 128-byte lines.  Written as they lie, groups (q, fg = 0..3) of a row are 64 contiguous bytes: every
-          // store instruction touches 16 rows x half a line, 2048 line requests per tile -- and the CU's write path retires
-          // one request per 5-8 cycles (the phase probe: 17 K cycles to drain a tile, a third of its time; vmcnt counts the
-          // stores, so the K loop's counted waits block behind them).  Groups 2 p and 2 p + 1 of a row are the two halves of
-          // one line: the EVEN store of a pair writes rows fr & ~1 -- even lanes their own group 2 p, odd lanes group 2 p + 1
-          // of the row BELOW them (DPP row_shr:1) --, the ODD store rows fr | 1 likewise (row_shl:1): 8 rows x one whole
-          // line per instruction, 1024 requests per tile, no LDS.
-          {
-            uint4 pk[NGRP];
+          if constexpr (LNE) {
+            // the pre-LayerNorm values stay in the accumulators (f32) until the row statistics are complete: no store of the
+            // pre-LN rows, no re-read after the exchange, and the normalisation sees unrounded values
 #pragma unroll
-            for (int q = 0; q < NGRP; ++q) pk[q] = pack16<OutT>(v[q]);
-            const bool odd = (fr_e & 1) != 0;
-            const int64_t m_even = m0 + wm * 64 + m4 * 16 + (fr_e & ~1);
+            for (int q = 0; q < NGRP; ++q)
 #pragma unroll
-            for (int pq = 0; pq < NGRP / 2; ++pq) {
-              const uint4 dn = dpp_u4<0x111>(pk[2 * pq + 1]);       // row_shr:1: lane i <- lane i - 1
-              const uint4 up = dpp_u4<0x101>(pk[2 * pq]);           // row_shl:1: lane i <- lane i + 1
-              // (component-wise selects: `odd ? a : b` on the struct type becomes a select of stack ADDRESSES + a scratch load)
-              const uint4 own_e = pk[2 * pq], own_o = pk[2 * pq + 1];
-              const uint4 d_even = make_uint4(odd ? dn.x : own_e.x, odd ? dn.y : own_e.y, odd ? dn.z : own_e.z, odd ? dn.w : own_e.w);
-              const uint4 d_odd = make_uint4(odd ? own_o.x : up.x, odd ? own_o.y : up.y, odd ? own_o.z : up.z, odd ? own_o.w : up.w);
-              const int col = pcol[pq];
-              if (col + GC <= N) {
-                // non-temporal: this kernel only runs on outputs of >= 3072 tiles (400 MB and up), nothing of which survives
-                // in a cache until its consumer starts; streaming stores retire ~2.5 % faster here (886 -> 906 TF at
-                // N = 2304, same box).  Not for LNE: pass 2 re-reads the tile through this XCD's L2.
-                if (!LNE && !(a.probe & 8)) {      // (probe bit 3: plain stores, A/B)
-                  typedef unsigned int g_u4 __attribute__((ext_vector_type(4)));
-                  if (m_even < M && !(a.probe & 4)) __builtin_nontemporal_store(g_u4{d_even.x, d_even.y, d_even.z, d_even.w}, reinterpret_cast<g_u4*>(out + m_even * N + col));
-                  if (m_even + 1 < M && !(a.probe & 4)) __builtin_nontemporal_store(g_u4{d_odd.x, d_odd.y, d_odd.z, d_odd.w}, reinterpret_cast<g_u4*>(out + (m_even + 1) * N + col));
-                } else {
-                  if (m_even < M && !(a.probe & 4)) st_global16(out + m_even * N + col, d_even);        // probe bit 2: no stores
-                  if (m_even + 1 < M && !(a.probe & 4)) st_global16(out + (m_even + 1) * N + col, d_odd);
-                }
+              for (int e = 0; e < GC; ++e) {
+                if constexpr (PAIRED) acc[m4][2 * q + (e >> 2)][e & 3] = v[q][e];
+                else acc[m4][q][e & 3] = v[q][e];
               }
-            }
+          } else {
+            store_rows(m4, v);
           }
         }
       } else {
@@ -644,50 +657,44 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
         }
         { const unsigned long long t = G256P_T(); pr[3] += t - pt; pt = t; }
         if constexpr (DIRECT) {
+          // gamma / beta of this wave's 128 columns -> its LDS patch (floats 384..511 / 512..639), read per row block like the
+          // bias (held in registers they would be 64 VGPRs next to the 128 live accumulators)
+          {
+            const int bc = n0 + wn * 128 + (lane_e & 31) * 4;
+            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4;
+            if (bc + 4 <= N) {
+              g4 = *reinterpret_cast<const float4*>(a.ln_g + bc);
+              b4 = *reinterpret_cast<const float4*>(a.ln_b + bc);
+            }
+            if (lane_e < 32) {
+              *reinterpret_cast<float4*>(patch + 384 + lane_e * 4) = g4;
+              *reinterpret_cast<float4*>(patch + 512 + lane_e * 4) = b4;
+            }
+          }
           __builtin_amdgcn_s_waitcnt(0xc07f);
           __builtin_amdgcn_wave_barrier();
-          // the same (row, group) walk as above: a lane re-reads exactly what it wrote.  The accumulators are dead: all loads
-          // of a batch of row blocks first, one wait, then arithmetic and stores
-          float gg[NGRP / 2][GC], gbt[NGRP / 2][GC];               // gamma / beta of the columns this lane stores
+          // the pre-LayerNorm values are still in the accumulators (f32): normalise and store, once
 #pragma unroll
-          for (int pq = 0; pq < NGRP / 2; ++pq)
+          for (int m4 = 0; m4 < 4; ++m4) {
+            const int lr64 = m4 * 16 + fr_e;
+            const float mean = patch[lr64 * 2], rstd = patch[lr64 * 2 + 1];
+            int boff = fg_e * GC;
+            asm volatile("" : "+v"(boff));
+            float v[NGRP][GC];
 #pragma unroll
-            for (int e = 0; e < GC; e += 4) {
-              const float4 g4 = *reinterpret_cast<const float4*>(a.ln_g + pcol[pq] + e);
-              const float4 b4 = *reinterpret_cast<const float4*>(a.ln_b + pcol[pq] + e);
-              gg[pq][e] = g4.x; gg[pq][e + 1] = g4.y; gg[pq][e + 2] = g4.z; gg[pq][e + 3] = g4.w;
-              gbt[pq][e] = b4.x; gbt[pq][e + 1] = b4.y; gbt[pq][e + 2] = b4.z; gbt[pq][e + 3] = b4.w;
-            }
-          constexpr int MB = sizeof(OutT) == 4 ? 2 : 4;              // row blocks per batch (16 x 16-byte loads per lane)
+            for (int q = 0; q < NGRP; ++q)
 #pragma unroll
-          for (int mb = 0; mb < 4; mb += MB) {
-            uint4 rbd[MB][NGRP / 2][2];
+              for (int e = 0; e < GC; e += 4) {
+                const float4 g4 = *reinterpret_cast<const float4*>(patch + 384 + q * (4 * GC) + boff + e);
+                const float4 b4 = *reinterpret_cast<const float4*>(patch + 512 + q * (4 * GC) + boff + e);
+                const float gq[4] = {g4.x, g4.y, g4.z, g4.w}, bq[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
-            for (int mi = 0; mi < MB; ++mi) {
-              const int64_t m_even = m0 + wm * 64 + (mb + mi) * 16 + (fr_e & ~1);
-#pragma unroll
-              for (int par = 0; par < 2; ++par) {
-                const int64_t ms = m_even + par < M ? m_even + par : m0;   // (rows beyond M: any valid row, the result is not stored)
-#pragma unroll
-                for (int pq = 0; pq < NGRP / 2; ++pq) rbd[mi][pq][par] = ld_global16(out + ms * N + pcol[pq]);
-              }
-            }
-#pragma unroll
-            for (int mi = 0; mi < MB; ++mi)
-#pragma unroll
-              for (int par = 0; par < 2; ++par) {
-                const int lr64 = (mb + mi) * 16 + (fr_e & ~1) + par;
-                const int64_t m = m0 + wm * 64 + lr64;
-                const float mean = patch[lr64 * 2], rstd = patch[lr64 * 2 + 1];
-#pragma unroll
-                for (int pq = 0; pq < NGRP / 2; ++pq) {
-                  float v[8];
-                  unpack16<OutT>(rbd[mi][pq][par], v);
-#pragma unroll
-                  for (int e = 0; e < GC; ++e) v[e] = (v[e] - mean) * rstd * gg[pq][e] + gbt[pq][e];
-                  if (m < M) st_global16(out + m * N + pcol[pq], pack16<OutT>(v));
+                for (int j = 0; j < 4; ++j) {
+                  const float x = PAIRED ? acc[m4][2 * q + ((e + j) >> 2)][(e + j) & 3] : acc[m4][q][(e + j) & 3];
+                  v[q][e + j] = (x - mean) * rstd * gq[j] + bq[j];
                 }
               }
+            store_rows(m4, v);
           }
         } else {
         float gv[8], bb[8];

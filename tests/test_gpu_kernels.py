@@ -692,3 +692,50 @@ def test_moment_topk_flat_distribution_fallback(ops):
     assert ((fl >= 0) & (fl < l * l)).all(), "all winners must come from the boosted video 0"
     for q in range(nq):
         assert len(set(fl[q].tolist())) == n_out
+
+
+@pytest.mark.parametrize("n,lq", [(1, 30), (3, 5), (1025, 64), (4097, 17), (10000, 30)])
+def test_pack_plan_shapes(ops, n, lq):
+    """xml_pack_plan (packing plan of a padded token batch): cu_seqlens / source rows for batches smaller and larger than
+    its one-workgroup scan, the widest supported sequence (64 = one wave), and the masks it must refuse."""
+    rng = np.random.default_rng(n * 131 + lq)
+    lens = rng.integers(1, lq + 1, n)
+    lens[0] = lq
+    mask = (np.arange(lq)[None, :] < lens[:, None]).astype(np.float32)
+    cu, src, rows = ops.pack_plan(torch.from_numpy(mask).to(DEV))
+    assert rows == int(lens.sum())
+    assert np.array_equal(cu.cpu().numpy(), np.concatenate([[0], np.cumsum(lens)]))
+    want = np.concatenate([i * lq + np.arange(k) for i, k in enumerate(lens)])
+    assert np.array_equal(src[:rows].cpu().numpy(), want)
+    bad = mask.copy(); bad[n // 2, :] = 0                                   # an empty sequence
+    assert ops.pack_plan(torch.from_numpy(bad).to(DEV))[2] == -1
+    if lq > 2:
+        bad = mask.copy(); bad[n - 1, 0] = 0; bad[n - 1, 1] = 1             # ones that are not a prefix
+        assert ops.pack_plan(torch.from_numpy(bad).to(DEV))[2] == -1
+        bad = mask.copy(); bad[0, 1] = 0.5                                  # a value that is neither 0 nor 1
+        assert ops.pack_plan(torch.from_numpy(bad).to(DEV))[2] == -1
+
+
+def test_convse_pair_inversion_corner_cases(ops):
+    """K7's pair inversion (count with the atomic's return as the pair's rank, one-workgroup scan, scatter): one video
+    selected by every query (a bucket longer than a chunk), videos nobody selected, skipped pairs, and more videos than the
+    scan has threads -- the rows must equal the plain one-pair-at-a-time evaluation."""
+    h, l, nq, nv, k = 128, 48, 150, 1500, 7
+    g = torch.Generator(device=DEV).manual_seed(5)
+    q = [torch.randn(nq, h, device=DEV, generator=g) for _ in range(2)]
+    f2 = [torch.randn(nv, l, h, device=DEV, generator=g) for _ in range(2)]
+    lens = torch.randint(5, l + 1, (nv,), generator=torch.Generator().manual_seed(1))
+    mask = (torch.arange(l)[None, :] < lens[:, None]).float().to(DEV)
+    pv = torch.randint(0, nv, (nq, k), generator=torch.Generator().manual_seed(2)).int()
+    pv[:, 0] = 77                       # every query selects video 77: 150 pairs = three chunks
+    pv[::3, 1] = -1                     # skipped pairs
+    pv[pv == 5] = 6                     # nobody selects video 5
+    pv = pv.to(DEV)
+    conv_w = torch.randn(10, device=DEV, generator=g) * 0.3
+    st, ed = ops.convse_rerank(q, f2, [mask, mask], pv, conv_w, l, True, 5, softmax=True)
+    # reference: each query alone against its own pair list (buckets of one pair: no inversion effects)
+    for qi in (0, 1, 3, 149):
+        st1, ed1 = ops.convse_rerank([t[qi:qi + 1] for t in q], f2, [mask, mask], pv[qi:qi + 1].contiguous(), conv_w, l, True, 5,
+                                     softmax=True)
+        assert torch.equal(st[qi], st1[0]) and torch.equal(ed[qi], ed1[0])
+    assert float(st[::3, 1].abs().max()) == 0.0 and float(ed[::3, 1].abs().max()) == 0.0

@@ -1,3 +1,5 @@
+# Kernel timeline of ONE bench.py step (c3): everything between the last two K6 launches, with the idle gaps.
+#   gpurun -- bash tools/trace_step.sh     (writes gpurun_out/trace/)
 mkdir -p gpurun_out/trace
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp

@@ -1,4 +1,5 @@
-"""K7 (xml_convse_rerank) alone at the C3 shape with ablations: 0 full, 1 no GEMMs, 2 no epilogue."""
+"""K7 (xml_convse_rerank) alone at the C3 shape with ablations: 0 full, 1 no GEMMs, 2 no epilogue, 40 register-staged
+mainloop instead of the LDS-DMA ring.  K7_DTYPE=f32 for the exact-rank mode's f32 operands (default bf16)."""
 import ctypes, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
@@ -7,7 +8,7 @@ from tvretrieval_amd.model_xml import XML
 nq, nv, l, hidden, dv, ds, dq, ctx_mode, _ = bench.WORKLOADS["c3"]
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
-m = XML(bench.model_config(hidden, dv, ds, dq, ctx_mode, l), compute_dtype=torch.bfloat16).to(dev).eval()
+m = XML(bench.model_config(hidden, dv, ds, dq, ctx_mode, l), compute_dtype=torch.float32 if os.environ.get("K7_DTYPE", "bf16") == "f32" else torch.bfloat16).to(dev).eval()
 with torch.no_grad():
     index = inf.build_corpus_index(m, bench.context_batches(0, nv, l, dv, ds, True, True, dev), n_total=nv, l_ref=l)
     qf, qm = bench.synth_queries(nq, dq, dev)

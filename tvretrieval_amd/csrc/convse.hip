@@ -132,6 +132,7 @@ struct ConvseArgs {
   const int32_t* chunk_vid;
   int nv, kpairs, lpad, l_ref, hidden, n_mod, merged, ksize, softmax;
   int dbg;   // perf ablations (xml_debug_set_q2c_ablation): 1 skip the GEMMs, 2 skip the conv / softmax / store epilogue
+  int dma;   // rows are whole 128-byte K steps and every row offset fits 32 bits: the LDS-DMA mainloop (gemm.h)
 };
 
 template <typename T>
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int32_t s_pair[TM];
   const int n_sim_l = a.merged ? 1 : a.n_mod;
-  float (*sim)[TM][LP] = reinterpret_cast<float (*)[TM][LP]>(n_sim_l == 1 ? smem : smem + Cfg::LDS_BYTES);
+  float (*sim)[TM][LP] = reinterpret_cast<float (*)[TM][LP]>(n_sim_l == 1 ? smem : smem + GemmDma<Cfg>::LDS_BYTES);
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x;
   if (chunk >= a.chunk_off[a.nv]) return;
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
   const int lane = tid & 63, wn = tid >> 6;
   const int fr = lane & 15, fg = lane >> 4;
   const int n_sim = a.merged ? 1 : a.n_mod;
+  const int mt_used = (cnt + 15) >> 4;             // a video has ~46 pairs at the TVR shape: 3 of the 4 row tiles
   f32x4 acc[Cfg::MT][Cfg::NT];
   for (int m = 0; m < a.n_mod; ++m) {
     const T* ql = reinterpret_cast<const T*>(a.q_lin[m]);
@@ -167,15 +169,28 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
     auto b_row = [&](int r) -> const char* {
       return r < a.lpad ? reinterpret_cast<const char*>(f2 + ((int64_t)v * a.lpad + r) * a.hidden) : nullptr;
     };
+    const int k_bytes = a.hidden * (int)sizeof(T);
+    auto a_off = [&](int r) -> uint32_t {             // rows beyond the chunk: any valid row (their products are never read)
+      const int p = s_pair[r] >= 0 ? s_pair[r] : s_pair[0];
+      return (uint32_t)(p / a.kpairs) * (uint32_t)k_bytes;
+    };
+    auto b_off = [&](int r) -> uint32_t { return (uint32_t)min(r, a.lpad - 1) * (uint32_t)k_bytes; };
+    const char* b_base = reinterpret_cast<const char*>(f2 + (int64_t)v * a.lpad * a.hidden);
     if (a.dbg == 1) {
 #pragma unroll
       for (int mt = 0; mt < Cfg::MT; ++mt)
 #pragma unroll
         for (int nt = 0; nt < Cfg::NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    } else if (a.dma) {
+      if (m > 0) __syncthreads();                     // the previous modality's last step is still being read
+      if (a.merged && m > 0)
+        gemm_mainloop_dma<T, Cfg, false>(acc, reinterpret_cast<const char*>(ql), a_off, b_base, b_off, k_bytes, smem, mt_used);
+      else
+        gemm_mainloop_dma<T, Cfg, true>(acc, reinterpret_cast<const char*>(ql), a_off, b_base, b_off, k_bytes, smem, mt_used);
     } else if (a.merged && m > 0)
-      gemm_mainloop<T, Cfg, false>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem);
+      gemm_mainloop<T, Cfg, false>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem, mt_used);
     else
-      gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem);
+      gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem, mt_used);
     if (!a.merged || m == a.n_mod - 1) {
       const float scale = (a.merged && a.n_mod == 2) ? 0.5f : 1.f;
       const int si = a.merged ? 0 : m;
@@ -283,6 +298,7 @@ struct RescoreArgs {
   const int32_t* bucket;
   const int32_t* chunk_vid;
   int nv, kpairs, lpad, hidden, n_mod;
+  int dma;   // see ConvseArgs
 };
 
 template <typename T>
@@ -319,7 +335,20 @@ __global__ __launch_bounds__(256, 3) void rescore_kernel(RescoreArgs a) {
       const int c = wn * 32 + nt * 16 + fr;
       mk[nt] = c < a.lpad ? a.mask[m][(int64_t)v * a.lpad + c] : 0.f;
     }
-    gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem);
+    if (a.dma) {
+      const int k_bytes = a.hidden * (int)sizeof(T);
+      auto a_off = [&](int r) -> uint32_t {
+        const int p = s_pair[r] >= 0 ? s_pair[r] : s_pair[0];
+        return (uint32_t)(p / a.kpairs) * (uint32_t)k_bytes;
+      };
+      auto b_off = [&](int r) -> uint32_t { return (uint32_t)min(r, a.lpad - 1) * (uint32_t)k_bytes; };
+      // (the barrier behind the previous modality's row maxima also frees its last ring stage)
+      gemm_mainloop_dma<T, Cfg, true>(acc, reinterpret_cast<const char*>(qn), a_off,
+                                      reinterpret_cast<const char*>(cn + (int64_t)v * a.lpad * a.hidden), b_off, k_bytes, smem,
+                                      (cnt + 15) >> 4);
+    } else {
+      gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem, (cnt + 15) >> 4);
+    }
 #pragma unroll
     for (int mt = 0; mt < Cfg::MT; ++mt)
 #pragma unroll
@@ -398,18 +427,25 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
   a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax & 1;
   a.dbg = g_q2c_ablation;       // constant 0 in the product build (debug.h)
+  {
+    const int64_t kb = (int64_t)d->hidden * (d->dt == XML_F32 ? 4 : 2);
+    a.dma = (kb % 128 == 0 && (int64_t)d->nq * kb < (1ll << 32) && (int64_t)d->lpad * kb < (1ll << 32)) ? 1 : 0;
+    if (g_q2c_ablation == 40) a.dma = 0;             // (debug build: A/B against the register-staged mainloop)
+  }
   const int64_t max_chunks = P / TM + (P < d->nv ? P : d->nv);
   const int n_sim = d->merged ? 1 : d->n_mod;
   const size_t patch = (size_t)TM * LP * 4;
   if (d->dt == XML_F32) {
     using Cfg = GemmCfg<float, TM, 128, 1, 4>;
-    const size_t lds = n_sim == 1 ? (Cfg::LDS_BYTES > patch ? Cfg::LDS_BYTES : patch) : Cfg::LDS_BYTES + 2 * patch;
-    if (!xml_lds_attr_once<convse_kernel<float>>((int)(Cfg::LDS_BYTES + 2 * patch))) return XML_ERR_LAUNCH;
+    constexpr size_t stg = GemmDma<Cfg>::LDS_BYTES;
+    const size_t lds = n_sim == 1 ? (stg > patch ? stg : patch) : stg + 2 * patch;
+    if (!xml_lds_attr_once<convse_kernel<float>>((int)(stg + 2 * patch))) return XML_ERR_LAUNCH;
     hipLaunchKernelGGL(convse_kernel<float>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
   } else {
     using Cfg = GemmCfg<bf16_t, TM, 128, 1, 4>;
-    const size_t lds = n_sim == 1 ? (Cfg::LDS_BYTES > patch ? Cfg::LDS_BYTES : patch) : Cfg::LDS_BYTES + 2 * patch;
-    if (!xml_lds_attr_once<convse_kernel<bf16_t>>((int)(Cfg::LDS_BYTES + 2 * patch))) return XML_ERR_LAUNCH;
+    constexpr size_t stg = GemmDma<Cfg>::LDS_BYTES;
+    const size_t lds = n_sim == 1 ? (stg > patch ? stg : patch) : stg + 2 * patch;
+    if (!xml_lds_attr_once<convse_kernel<bf16_t>>((int)(stg + 2 * patch))) return XML_ERR_LAUNCH;
     hipLaunchKernelGGL(convse_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
   }
   XML_CHECK_LAUNCH();
@@ -457,15 +493,20 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
   a.out = out;
   a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket; a.chunk_vid = w.chunk_vid;
   a.nv = nv; a.kpairs = kpairs; a.lpad = lpad; a.hidden = hidden; a.n_mod = n_mod;
+  {
+    const int64_t kb = (int64_t)hidden * (dt == XML_F32 ? 4 : 2);
+    a.dma = (kb % 128 == 0 && (int64_t)nq * kb < (1ll << 32) && (int64_t)lpad * kb < (1ll << 32)) ? 1 : 0;
+    if (g_q2c_ablation == 40) a.dma = 0;
+  }
   const int64_t max_chunks = P / TM + (P < nv ? P : nv);
   if (dt == XML_F32) {
     using Cfg = GemmCfg<float, TM, 128, 1, 4>;
-    if (!xml_lds_attr_once<rescore_kernel<float>>((int)Cfg::LDS_BYTES)) return XML_ERR_LAUNCH;
-    hipLaunchKernelGGL(rescore_kernel<float>, dim3((unsigned)max_chunks), dim3(256), Cfg::LDS_BYTES, st, a);
+    if (!xml_lds_attr_once<rescore_kernel<float>>((int)GemmDma<Cfg>::LDS_BYTES)) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(rescore_kernel<float>, dim3((unsigned)max_chunks), dim3(256), GemmDma<Cfg>::LDS_BYTES, st, a);
   } else {
     using Cfg = GemmCfg<bf16_t, TM, 128, 1, 4>;
-    if (!xml_lds_attr_once<rescore_kernel<bf16_t>>((int)Cfg::LDS_BYTES)) return XML_ERR_LAUNCH;
-    hipLaunchKernelGGL(rescore_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), Cfg::LDS_BYTES, st, a);
+    if (!xml_lds_attr_once<rescore_kernel<bf16_t>>((int)GemmDma<Cfg>::LDS_BYTES)) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(rescore_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), GemmDma<Cfg>::LDS_BYTES, st, a);
   }
   XML_CHECK_LAUNCH();
   return XML_OK;

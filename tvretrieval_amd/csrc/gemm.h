@@ -12,6 +12,8 @@
 //   Global loads are 16 B per lane, 8 lanes per 128-byte row segment (fully coalesced), issued one K step
 //   ahead into registers and written to the other LDS stage after the MFMAs of the current step.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 template <typename T, int BM_, int BN_, int WM_, int WN_>
@@ -42,7 +44,9 @@ __device__ __forceinline__ int lds_slot_off(int row, int slot) { return row * 12
 // (rows are then zero-filled).  k_bytes = K * sizeof(T), must be a multiple of 16.
 template <typename T, typename Cfg, bool ZERO_INIT = true, typename ARow, typename BRow>
 __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], ARow a_row, BRow b_row,
-                                              int k_bytes, char* smem) {
+                                              int k_bytes, char* smem, int mt_used = Cfg::MT) {
+  // mt_used (block-uniform): only the first mt_used 16-row tiles of a wave's rows carry real rows (a ragged chunk of a
+  // gathered pair list); the MFMAs and fragment reads of the others are skipped, their accumulators keep what they hold
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -122,7 +126,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
 #pragma unroll
       for (int m = 0; m < Cfg::MT; ++m) {
         const int r = wm * (Cfg::BM / Cfg::WM) + m * 16 + fr;
-        fa[m] = *reinterpret_cast<const uint4*>(sa + lds_slot_off(r, c * 4 + fg));
+        if (m < mt_used) fa[m] = *reinterpret_cast<const uint4*>(sa + lds_slot_off(r, c * 4 + fg));
       }
 #pragma unroll
       for (int n = 0; n < Cfg::NT; ++n) {
@@ -131,11 +135,118 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
       }
 #pragma unroll
       for (int m = 0; m < Cfg::MT; ++m)
+        if (m < mt_used) {
 #pragma unroll
-        for (int n = 0; n < Cfg::NT; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
+          for (int n = 0; n < Cfg::NT; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
+        }
     }
     if (s + 1 < nsteps) lstore((s + 1) & 1);
     __syncthreads();
   }
 }
 
+
+// ---- LDS-DMA variant of the mainloop (gathered-pair contractions: K7, exact-rank re-score) -------------------------------
+// Same LDS image, same fragment reads and MFMA order as gemm_mainloop (bitwise the same accumulators), but the K steps
+// arrive through `global_load_lds_dwordx4` into a THREE-stage ring: two steps (2 x 24 KiB per workgroup) are in flight
+// behind the one being multiplied, no staging registers, one barrier per step.  The register-staged loop has one step in
+// flight for the length of one step's MFMAs: a pair-list chunk spent most of its time waiting for HBM (f32 ConvSE:
+// 2.5 TB/s and a half-busy MFMA pipe at three workgroups per CU).
+//   A 1 KiB DMA piece = 8 tile rows x 128 B; lane i of a piece lands at LDS byte 16 i of it = row i / 8, PHYSICAL slot
+//   i % 8, so it fetches the row's LOGICAL slot (i % 8) ^ ((row >> 1) & 7) -- the swizzle of lds_slot_off moves to the
+//   global address.  Piece j of a step covers tile rows 8 j .. 8 j + 7 (A rows first), wave w issues pieces w, w + 4, ...
+//   Rows are addressed as SGPR base + 32-bit byte offset (a_off / b_off: offset of tile row r from a_base / b_base; rows
+//   without data must return the offset of some VALID row -- their products are never read, and with mt_used mostly not
+//   computed).  Requirements: Cfg = <T, 64, 128, 1, 4> shape family (WM == 1, 256 threads), k_bytes % 128 == 0.
+// vmcnt: the DMAs are invisible to hipcc's counters, the waits are hand-counted (PPW pieces per wave and step); any VMEM
+// operation of the caller issued BEFORE this loop is older than every DMA and therefore covered by the first wait.
+template <typename Cfg> struct GemmDma {
+  static constexpr int STAGES = 3;
+  static constexpr int PIECES = (Cfg::BM + Cfg::BN) / 8;
+  static constexpr int PPW = PIECES / 4;
+  static constexpr int LDS_BYTES = STAGES * Cfg::STAGE_BYTES;
+  static_assert(Cfg::WM == 1 && Cfg::WN == 4 && Cfg::BM % 32 == 0 && Cfg::BN % 32 == 0, "piece / wave split");
+};
+
+__device__ __forceinline__ void gemm_dma_piece(uint32_t voff, const char* sbase, uint32_t lds_dst) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+
+template <typename T, typename Cfg, bool ZERO_INIT = true, typename AOff, typename BOff>
+__device__ __forceinline__ void gemm_mainloop_dma(f32x4 (&acc)[Cfg::MT][Cfg::NT], const char* a_base, AOff a_off,
+                                                  const char* b_base, BOff b_off, int k_bytes, char* smem,
+                                                  int mt_used = Cfg::MT) {
+  using D = GemmDma<Cfg>;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wn = wave;
+  constexpr int A_PIECES = Cfg::BM / 8 / 4;                 // per wave
+  uint32_t voff[D::PPW];
+#pragma unroll
+  for (int i = 0; i < D::PPW; ++i) {
+    const int row = (wave + 4 * i) * 8 + (lane >> 3), phys = lane & 7;
+    if (i < A_PIECES) voff[i] = a_off(row) + (uint32_t)((phys ^ ((row >> 1) & 7)) << 4);
+    else { const int r = row - Cfg::BM; voff[i] = b_off(r) + (uint32_t)((phys ^ ((r >> 1) & 7)) << 4); }
+  }
+  // wave-uniform values the DMA instruction takes from SGPRs
+  const uint32_t lds0 = (uint32_t)__builtin_amdgcn_readfirstlane(
+      (int)((uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem + (uint32_t)wave * 1024u));
+  auto uni = [](const char* p) -> const char* {
+    const uint64_t u = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+  };
+  const char* ab = uni(a_base);
+  const char* bb = uni(b_base);
+  auto issue = [&](int step, int stage) {
+    const uint32_t dst = lds0 + (uint32_t)stage * (uint32_t)Cfg::STAGE_BYTES;
+    const char* sa = ab + (int64_t)step * Cfg::ROWB;
+    const char* sb = bb + (int64_t)step * Cfg::ROWB;
+#pragma unroll
+    for (int i = 0; i < D::PPW; ++i) gemm_dma_piece(voff[i], i < A_PIECES ? sa : sb, dst + (uint32_t)i * 4096u);
+  };
+  if (ZERO_INIT) {
+#pragma unroll
+    for (int m = 0; m < Cfg::MT; ++m)
+#pragma unroll
+      for (int n = 0; n < Cfg::NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const int nsteps = k_bytes / Cfg::ROWB;
+  const int fr = lane & 15, fg = lane >> 4;
+  // the whole step loop once per number of live row tiles: straight-line MFMA blocks, no per-tile branches
+  auto run = [&](auto mtu_c) {
+    constexpr int MTU = decltype(mtu_c)::value;
+    issue(0, 0);
+    if (nsteps > 1) issue(1, 1);
+    int stage = 0;
+    for (int s = 0; s < nsteps; ++s) {
+      if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(D::PPW) : "memory");   // my pieces of step s have landed
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();        // everyone's have; everyone is done reading the stage step s + 2 goes to
+      if (s + 2 < nsteps) issue(s + 2, stage >= 1 ? stage - 1 : 2);
+      const char* sa = smem + stage * Cfg::STAGE_BYTES;
+      const char* sb = sa + Cfg::BM * Cfg::ROWB;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        uint4 fa[MTU], fb[Cfg::NT];
+#pragma unroll
+        for (int m = 0; m < MTU; ++m) fa[m] = *reinterpret_cast<const uint4*>(sa + lds_slot_off(m * 16 + fr, c * 4 + fg));
+#pragma unroll
+        for (int n = 0; n < Cfg::NT; ++n) {
+          const int r = wn * (Cfg::BN / Cfg::WN) + n * 16 + fr;
+          fb[n] = *reinterpret_cast<const uint4*>(sb + lds_slot_off(r, c * 4 + fg));
+        }
+#pragma unroll
+        for (int m = 0; m < MTU; ++m)
+#pragma unroll
+          for (int n = 0; n < Cfg::NT; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
+      }
+      stage = stage == 2 ? 0 : stage + 1;
+    }
+  };
+  static_assert(Cfg::MT == 4, "row-tile dispatch below");
+  if (mt_used >= 4) run(std::integral_constant<int, 4>{});
+  else if (mt_used == 3) run(std::integral_constant<int, 3>{});
+  else if (mt_used == 2) run(std::integral_constant<int, 2>{});
+  else run(std::integral_constant<int, 1>{});
+}

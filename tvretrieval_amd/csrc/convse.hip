@@ -301,6 +301,7 @@ struct RescoreArgs {
   int dma;   // see ConvseArgs
 };
 
+static constexpr int RS_STAGES = 2;   // re-score ring depth: 2 stages = 49 KiB = three workgroups per CU (f32 MFMA-bound: waves per SIMD matter more than depth)
 template <typename T>
 __global__ __launch_bounds__(256, 3) void rescore_kernel(RescoreArgs a) {
   using Cfg = GemmCfg<T, TM, 128, 1, 4>;
@@ -343,9 +344,9 @@ __global__ __launch_bounds__(256, 3) void rescore_kernel(RescoreArgs a) {
       };
       auto b_off = [&](int r) -> uint32_t { return (uint32_t)min(r, a.lpad - 1) * (uint32_t)k_bytes; };
       // (the barrier behind the previous modality's row maxima also frees its last ring stage)
-      gemm_mainloop_dma<T, Cfg, true>(acc, reinterpret_cast<const char*>(qn), a_off,
-                                      reinterpret_cast<const char*>(cn + (int64_t)v * a.lpad * a.hidden), b_off, k_bytes, smem,
-                                      (cnt + 15) >> 4);
+      gemm_mainloop_dma<T, Cfg, true, RS_STAGES>(acc, reinterpret_cast<const char*>(qn), a_off,
+                                                 reinterpret_cast<const char*>(cn + (int64_t)v * a.lpad * a.hidden), b_off,
+                                                 k_bytes, smem, (cnt + 15) >> 4);
     } else {
       gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem, (cnt + 15) >> 4);
     }
@@ -501,12 +502,14 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
   const int64_t max_chunks = P / TM + (P < nv ? P : nv);
   if (dt == XML_F32) {
     using Cfg = GemmCfg<float, TM, 128, 1, 4>;
-    if (!xml_lds_attr_once<rescore_kernel<float>>((int)GemmDma<Cfg>::LDS_BYTES)) return XML_ERR_LAUNCH;
-    hipLaunchKernelGGL(rescore_kernel<float>, dim3((unsigned)max_chunks), dim3(256), GemmDma<Cfg>::LDS_BYTES, st, a);
+    constexpr int lds = GemmDma<Cfg, RS_STAGES>::LDS_BYTES;
+    if (!xml_lds_attr_once<rescore_kernel<float>>(lds)) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(rescore_kernel<float>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
   } else {
     using Cfg = GemmCfg<bf16_t, TM, 128, 1, 4>;
-    if (!xml_lds_attr_once<rescore_kernel<bf16_t>>((int)GemmDma<Cfg>::LDS_BYTES)) return XML_ERR_LAUNCH;
-    hipLaunchKernelGGL(rescore_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), GemmDma<Cfg>::LDS_BYTES, st, a);
+    constexpr int lds = GemmDma<Cfg, RS_STAGES>::LDS_BYTES;
+    if (!xml_lds_attr_once<rescore_kernel<bf16_t>>(lds)) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(rescore_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
   }
   XML_CHECK_LAUNCH();
   return XML_OK;

@@ -160,8 +160,8 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
 //   computed).  Requirements: Cfg = <T, 64, 128, 1, 4> shape family (WM == 1, 256 threads), k_bytes % 128 == 0.
 // vmcnt: the DMAs are invisible to hipcc's counters, the waits are hand-counted (PPW pieces per wave and step); any VMEM
 // operation of the caller issued BEFORE this loop is older than every DMA and therefore covered by the first wait.
-template <typename Cfg> struct GemmDma {
-  static constexpr int STAGES = 3;
+template <typename Cfg, int STAGES_ = 3> struct GemmDma {
+  static constexpr int STAGES = STAGES_;
   static constexpr int PIECES = (Cfg::BM + Cfg::BN) / 8;
   static constexpr int PPW = PIECES / 4;
   static constexpr int LDS_BYTES = STAGES * Cfg::STAGE_BYTES;
@@ -172,11 +172,12 @@ __device__ __forceinline__ void gemm_dma_piece(uint32_t voff, const char* sbase,
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" : : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
 }
 
-template <typename T, typename Cfg, bool ZERO_INIT = true, typename AOff, typename BOff>
+template <typename T, typename Cfg, bool ZERO_INIT = true, int STAGES = 3, typename AOff, typename BOff>
 __device__ __forceinline__ void gemm_mainloop_dma(f32x4 (&acc)[Cfg::MT][Cfg::NT], const char* a_base, AOff a_off,
                                                   const char* b_base, BOff b_off, int k_bytes, char* smem,
                                                   int mt_used = Cfg::MT) {
-  using D = GemmDma<Cfg>;
+  using D = GemmDma<Cfg, STAGES>;
+  static_assert(STAGES == 2 || STAGES == 3, "ring depth");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wn = wave;
   constexpr int A_PIECES = Cfg::BM / 8 / 4;                 // per wave
@@ -217,13 +218,14 @@ __device__ __forceinline__ void gemm_mainloop_dma(f32x4 (&acc)[Cfg::MT][Cfg::NT]
   auto run = [&](auto mtu_c) {
     constexpr int MTU = decltype(mtu_c)::value;
     issue(0, 0);
-    if (nsteps > 1) issue(1, 1);
+    if (STAGES == 3 && nsteps > 1) issue(1, 1);
     int stage = 0;
     for (int s = 0; s < nsteps; ++s) {
-      if (s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(D::PPW) : "memory");   // my pieces of step s have landed
+      if (STAGES == 3 && s + 1 < nsteps) asm volatile("s_waitcnt vmcnt(%0)" : : "n"(D::PPW) : "memory");   // my pieces of step s have landed
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();        // everyone's have; everyone is done reading the stage step s + 2 goes to
-      if (s + 2 < nsteps) issue(s + 2, stage >= 1 ? stage - 1 : 2);
+      __builtin_amdgcn_s_barrier();        // everyone's have; everyone is done reading the stage the next issue goes to
+      if (STAGES == 3) { if (s + 2 < nsteps) issue(s + 2, stage >= 1 ? stage - 1 : 2); }
+      else if (s + 1 < nsteps) issue(s + 1, stage ^ 1);
       const char* sa = smem + stage * Cfg::STAGE_BYTES;
       const char* sb = sa + Cfg::BM * Cfg::ROWB;
 #pragma unroll
@@ -241,7 +243,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(f32x4 (&acc)[Cfg::MT][Cfg::NT]
 #pragma unroll
           for (int n = 0; n < Cfg::NT; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
       }
-      stage = stage == 2 ? 0 : stage + 1;
+      stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
   };
   static_assert(Cfg::MT == 4, "row-tile dispatch below");

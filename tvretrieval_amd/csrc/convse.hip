@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int32_t s_pair[TM];
   const int n_sim_l = a.merged ? 1 : a.n_mod;
-  float (*sim)[TM][LP] = reinterpret_cast<float (*)[TM][LP]>(n_sim_l == 1 ? smem : smem + GemmDma<Cfg>::LDS_BYTES);
+  float (*sim)[TM][LP] = reinterpret_cast<float (*)[TM][LP]>(n_sim_l == 1 ? smem : smem + Cfg::LDS_BYTES);
   const int tid = threadIdx.x;
   const int chunk = blockIdx.x;
   if (chunk >= a.chunk_off[a.nv]) return;
@@ -182,11 +182,14 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
 #pragma unroll
         for (int nt = 0; nt < Cfg::NT; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
     } else if (a.dma) {
+      // two-stage ring: 49 KiB of staging = three workgroups per CU.  (Three stages / two workgroups measured 8 % SLOWER
+      // than the register-staged loop in bf16 -- the epilogue of one workgroup needs the GEMM phases of two others to
+      // hide behind --, two stages 1 % / 7 % faster in bf16 / f32: tools/bench_k7.py, ablations 40 / 41.)
       if (m > 0) __syncthreads();                     // the previous modality's last step is still being read
       if (a.merged && m > 0)
-        gemm_mainloop_dma<T, Cfg, false>(acc, reinterpret_cast<const char*>(ql), a_off, b_base, b_off, k_bytes, smem, mt_used);
+        gemm_mainloop_dma<T, Cfg, false, 2>(acc, reinterpret_cast<const char*>(ql), a_off, b_base, b_off, k_bytes, smem, mt_used);
       else
-        gemm_mainloop_dma<T, Cfg, true>(acc, reinterpret_cast<const char*>(ql), a_off, b_base, b_off, k_bytes, smem, mt_used);
+        gemm_mainloop_dma<T, Cfg, true, 2>(acc, reinterpret_cast<const char*>(ql), a_off, b_base, b_off, k_bytes, smem, mt_used);
     } else if (a.merged && m > 0)
       gemm_mainloop<T, Cfg, false>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem, mt_used);
     else
@@ -438,13 +441,13 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   const size_t patch = (size_t)TM * LP * 4;
   if (d->dt == XML_F32) {
     using Cfg = GemmCfg<float, TM, 128, 1, 4>;
-    constexpr size_t stg = GemmDma<Cfg>::LDS_BYTES;
+    constexpr size_t stg = Cfg::LDS_BYTES;           // = GemmDma<Cfg, 2>::LDS_BYTES: both mainloops stage two steps
     const size_t lds = n_sim == 1 ? (stg > patch ? stg : patch) : stg + 2 * patch;
     if (!xml_lds_attr_once<convse_kernel<float>>((int)(stg + 2 * patch))) return XML_ERR_LAUNCH;
     hipLaunchKernelGGL(convse_kernel<float>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
   } else {
     using Cfg = GemmCfg<bf16_t, TM, 128, 1, 4>;
-    constexpr size_t stg = GemmDma<Cfg>::LDS_BYTES;
+    constexpr size_t stg = Cfg::LDS_BYTES;           // = GemmDma<Cfg, 2>::LDS_BYTES: both mainloops stage two steps
     const size_t lds = n_sim == 1 ? (stg > patch ? stg : patch) : stg + 2 * patch;
     if (!xml_lds_attr_once<convse_kernel<bf16_t>>((int)(stg + 2 * patch))) return XML_ERR_LAUNCH;
     hipLaunchKernelGGL(convse_kernel<bf16_t>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);

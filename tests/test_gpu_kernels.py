@@ -739,3 +739,36 @@ def test_convse_pair_inversion_corner_cases(ops):
                                      softmax=True)
         assert torch.equal(st[qi], st1[0]) and torch.equal(ed[qi], ed1[0])
     assert float(st[::3, 1].abs().max()) == 0.0 and float(ed[::3, 1].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,lq,d_in,h", [(40, 30, 128, 128), (9000, 30, 768, 768)])
+def test_linear_ln_relu_pos_packed_vs_oracle(ops, dtype, n, lq, d_in, h):
+    """K1+K2 on packed tokens (xml_pack_plan + xml_linear_ln_relu_pos_packed): token t of sequence i is row i * lq + t of
+    the PADDED batch read through the source-row map, with positional row t -- the oracle's LinearLayer +
+    TrainablePositionalEncoding at the valid positions (small batch: the three-launch path; large: LayerNorm in the GEMM)."""
+    rng = np.random.default_rng(n)
+    lens = rng.integers(1, lq + 1, n)
+    lens[0] = lq
+    x = rnd(n, lq, d_in, seed=20)
+    mask = torch.from_numpy((np.arange(lq)[None, :] < lens[:, None]).astype(np.float32))
+    sd = {"LayerNorm.weight": 1 + 0.1 * rnd(d_in, seed=11), "LayerNorm.bias": 0.1 * rnd(d_in, seed=12),
+          "net.1.weight": rnd(h, d_in, seed=13, scale=d_in ** -0.5), "net.1.bias": 0.1 * rnd(h, seed=14)}
+    pe = {"position_embeddings.weight": rnd(lq + 2, h, seed=15, scale=0.5), "LayerNorm.weight": 1 + 0.1 * rnd(h, seed=16),
+          "LayerNorm.bias": 0.1 * rnd(h, seed=17)}
+    cu, src, rows = ops.pack_plan(dev(mask))
+    assert rows == int(lens.sum())
+    got = ops.linear_ln_relu_pos_packed(dev(x).reshape(n * lq, d_in), src, rows, lq, dev(sd["LayerNorm.weight"]),
+                                        dev(sd["LayerNorm.bias"]), dev(sd["net.1.weight"], dtype), dev(sd["net.1.bias"]),
+                                        dev(pe["position_embeddings.weight"], dtype), dev(pe["LayerNorm.weight"]),
+                                        dev(pe["LayerNorm.bias"]))
+    ns = min(n, 64)                                            # the oracle on the first sequences
+    want = O.trainable_pos_enc(O.linear_layer(x[:ns], O.Weights(sd)), O.Weights(pe))
+    want = torch.cat([want[i, :lens[i]] for i in range(ns)])
+    close("linear_ln_relu_pos_packed", got[:want.shape[0]], want, _tol(dtype, 5e-5, 6e-2))
+    # and the padded entry on the same batch, every valid token
+    full = ops.linear_ln_relu_pos(dev(x), dev(sd["LayerNorm.weight"]), dev(sd["LayerNorm.bias"]), dev(sd["net.1.weight"], dtype),
+                                  dev(sd["net.1.bias"]), dev(pe["position_embeddings.weight"], dtype),
+                                  dev(pe["LayerNorm.weight"]), dev(pe["LayerNorm.bias"]))
+    sel = full.reshape(n * lq, h)[src[:rows].long()]
+    close("packed vs padded K1+K2", got, sel, 2e-5 if dtype == torch.float32 else 3e-2, 0.0 if dtype == torch.float32 else 1.6e-2)

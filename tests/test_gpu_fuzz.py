@@ -1,0 +1,183 @@
+"""Seeded random-shape parity sweeps of the HIP kernels against the oracle: the fixed cases of test_gpu_kernels.py pin the
+documented corner cases, these walk the supported shape space (ragged lengths, odd row counts, tie-heavy scores, skipped
+pairs, every clip padding) with a different shape per seed.  Deterministic: the seed is the test id."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import xml_oracle as O
+from test_gpu_kernels import (DEV, _att_weights, _check_moment_lists, _conv_case, _conv_oracle, _normed, _ragged_mask,  # noqa: F401
+                              _tol, close, dev, ops, rnd)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_fuzz_topk_rows(ops, seed):
+    rng = np.random.default_rng(1000 + seed)
+    rows = int(rng.integers(1, 13))
+    n = int(np.exp(rng.uniform(np.log(2), np.log(6000))))
+    k = int(rng.integers(1, min(256, n) + 1))
+    s = rnd(rows, n, seed=2000 + seed) * 0.3
+    q = float(rng.choice([0.0, 1 / 8, 1 / 64, 1 / 1024]))            # tie density
+    if q:
+        s = torch.round(s / q) * q
+    alpha = float(rng.choice([0.0, 20.0]))
+    vals, idx = ops.topk_rows(dev(s), k, alpha=alpha)
+    vals, idx = vals.cpu(), idx.cpu().long()
+    wv = torch.topk(s, k, dim=1)[0]
+    close("topk values", vals, torch.exp(alpha * wv) if alpha else wv, 0, 1e-5 if alpha else 0)
+    assert torch.equal(torch.gather(s, 1, idx), wv)
+    for r in range(rows):
+        key = [(-float(s[r, i]), int(i)) for i in idx[r]]
+        assert key == sorted(key) and len(set(idx[r].tolist())) == k
+        thr = float(s[r, idx[r, -1]])
+        tied = (s[r] == thr).nonzero().flatten().tolist()
+        took = sorted(i for i in idx[r].tolist() if float(s[r, i]) == thr)
+        assert took == tied[:len(took)], "ties at the threshold go to the lowest columns"
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_fuzz_moment_topk(ops, seed):
+    rng = np.random.default_rng(3000 + seed)
+    nq, k = int(rng.integers(1, 5)), int(rng.integers(1, 101))
+    l = int(rng.integers(2, 129))
+    lpad = (l + 15) // 16 * 16
+    min_l = int(rng.integers(0, 4))
+    max_l = min_l + int(rng.integers(1, 21))
+    n_out = int(rng.integers(1, 301))
+    temp = float(rng.choice([0.05, 1.0, 3.0, 8.0]))                  # flat ... peaky span distributions
+    g = torch.Generator().manual_seed(4000 + seed)
+    mask = (torch.arange(l)[None, None] < torch.randint(1, l + 1, (nq, k, 1), generator=g)).float()
+    st = torch.softmax(O.mask_logits(torch.randn(nq, k, l, generator=g) * temp, mask), -1)
+    ed = torch.softmax(O.mask_logits(torch.randn(nq, k, l, generator=g) * temp, mask), -1)
+    w, _ = torch.sort(torch.exp(20 * (torch.rand(nq, k, generator=g) * 0.3)), dim=1, descending=True)
+    if seed % 3 == 0:
+        w = torch.where(torch.rand(nq, k, generator=g) < 0.4, torch.zeros_like(w), w)     # pairs owned elsewhere
+    prod = torch.einsum("qvm,qv,qvn->qvmn", st, w, ed) * torch.from_numpy(O.min_max_length_mask(l, min_l, max_l))
+    ws, wi = torch.sort(prod.reshape(nq, -1), dim=1, descending=True, stable=True)
+    n_have = ws.shape[1]
+    stp, edp = torch.zeros(nq, k, lpad), torch.zeros(nq, k, lpad)
+    stp[..., :l], edp[..., :l] = st, ed
+    sc, fl = ops.moment_topk(dev(stp), dev(edp), dev(w.contiguous()), l, min_l, max_l, n_out)
+    want_s, want_i = torch.zeros(nq, n_out), torch.full((nq, n_out), -1, dtype=torch.long)
+    m = min(n_out, n_have)
+    want_s[:, :m], want_i[:, :m] = ws[:, :m], wi[:, :m]
+    _check_moment_lists(sc, fl, want_s, want_i, l)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_convse_rerank(ops, seed):
+    rng = np.random.default_rng(5000 + seed)
+    dtype = torch.float32 if seed % 2 else torch.bfloat16
+    nq, nv = int(rng.integers(1, 71)), int(rng.integers(1, 41))
+    l = int(rng.integers(5, 129))
+    h = int(rng.choice([64, 128, 256, 768]))
+    n_mod = int(rng.integers(1, 3))
+    merged = bool(n_mod == 2 and rng.integers(0, 2))
+    softmax = bool(rng.integers(0, 2))
+    lpad = (l + 15) // 16 * 16
+    q, f, mask, cw = _conv_case(nq, nv, l, h, merged, n_mod, 6000 + seed)
+    k = int(rng.integers(1, min(8, nv) + 1))
+    g = torch.Generator().manual_seed(7000 + seed)
+    pair = torch.stack([torch.randperm(nv, generator=g)[:k] for _ in range(nq)]).int()
+    skip = torch.rand(nq, k, generator=g) < 0.15
+    want_st, want_ed = _conv_oracle(q, f, mask, cw, merged, pair, softmax)
+    want_st[skip] = 0; want_ed[skip] = 0
+    fp = [torch.zeros(nv, lpad, h) for _ in f]
+    for a, b in zip(fp, f):
+        a[:, :l] = b
+    mp = torch.zeros(nv, lpad); mp[:, :l] = mask
+    pair_skip = torch.where(skip, torch.full_like(pair, -1), pair).contiguous()
+    st, ed = ops.convse_rerank([dev(x, dtype) for x in q], [dev(x, dtype) for x in fp], [dev(mp)] * n_mod, dev(pair_skip),
+                               dev(cw), l, merged, 5, softmax=softmax)
+    st, ed = st[..., :l].cpu(), ed[..., :l].cpu()
+    if softmax:
+        close("convse st prob", st, want_st, 1e-5, 1e-4)
+        close("convse ed prob", ed, want_ed, 1e-5, 1e-4)
+    else:
+        close("convse st logits", st, want_st, 1e-4, 1e-5)
+        close("convse ed logits", ed, want_ed, 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_q2c_fused(ops, seed):
+    rng = np.random.default_rng(8000 + seed)
+    dtype = torch.float32 if seed % 2 else torch.bfloat16
+    nq, nv = int(rng.integers(1, 400)), int(rng.integers(1, 80))
+    l = int(rng.integers(1, 129)) if seed % 3 else 128
+    h = int(rng.choice([64, 128, 192, 256, 512, 768]))
+    n_mod = int(rng.integers(1, 3))
+    lpad = (l + 15) // 16 * 16
+    qs = [_normed(nq, h, seed=8100 + seed + m) for m in range(n_mod)]
+    cs = [_normed(nv, l, h, seed=8200 + seed + m) for m in range(n_mod)]
+    masks = [_ragged_mask(nv, l, 8300 + seed + m) for m in range(n_mod)]
+    want = None
+    for m in range(n_mod):
+        s = torch.einsum("md,nld->mln", qs[m], cs[m])
+        s = torch.max(O.mask_logits(s, masks[m].t().unsqueeze(0)), dim=1)[0]
+        want = s if want is None else (want + s) / 2
+    cps, mps = [], []
+    for m in range(n_mod):
+        cp = torch.zeros(nv, lpad, h); cp[:, :l] = cs[m]
+        mp = torch.zeros(nv, lpad); mp[:, :l] = masks[m]
+        cps.append(dev(cp, dtype)); mps.append(dev(mp))
+    out = torch.full((nq, nv), float("nan"), device=DEV)
+    got = ops.q2c_scores_fused([dev(q, dtype) for q in qs], cps, mps, out=out)
+    close("q2c fused", got, want, 1e-5)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_select_ge_and_certificate(ops, seed):
+    rng = np.random.default_rng(9000 + seed)
+    rows, n = int(rng.integers(1, 60)), int(rng.integers(1, 3000))
+    s = torch.from_numpy(rng.standard_normal((rows, n)).astype(np.float32))
+    thr = torch.from_numpy(rng.standard_normal(rows).astype(np.float32))
+    cnt = ops.select_ge_rows(dev(s), dev(thr)).cpu().numpy()
+    want_cnt = (s >= thr[:, None]).sum(1).numpy()
+    assert np.array_equal(cnt, want_cnt)
+    cap = int(max(1, want_cnt.max()))
+    idx, cnt2 = ops.select_ge_rows(dev(s), dev(thr), cap)
+    idx = idx.cpu().numpy()
+    for r in range(rows):
+        assert sorted(idx[r][:want_cnt[r]].tolist()) == np.nonzero((s[r] >= thr[r]).numpy())[0].tolist()
+        assert (idx[r][want_cnt[r]:] == -1).all()
+    # certificate: b_M + eps < T_k  with eps from the two error norms
+    nq, m, k = rows, int(rng.integers(2, 40)), 1
+    k = int(rng.integers(1, m + 1))
+    filt = torch.sort(torch.from_numpy(rng.uniform(0.2, 0.3, (nq, m)).astype(np.float32)), dim=1, descending=True)[0]
+    top = torch.sort(torch.from_numpy(rng.uniform(0.29, 0.31, (nq, k)).astype(np.float32)), dim=1, descending=True)[0]
+    eq = [torch.from_numpy(rng.uniform(1e-3, 2e-3, nq).astype(np.float32)) for _ in range(2)]
+    ec = [2.0e-3, 2.2e-3]
+    slack, alpha = 9e-5, 20.0
+    tv = dev(top.clone())
+    fail, eps, thr_out, n_fail = ops.exact_certificate(dev(filt), tv, [dev(e) for e in eq], ec, slack, alpha, True)
+    c = np.float32(1.0 + 1e-6)
+    e0 = eq[0].numpy() * c + (c + eq[0].numpy()) * np.float32(ec[0])
+    e1 = eq[1].numpy() * c + (c + eq[1].numpy()) * np.float32(ec[1])
+    want_eps = (e0 + e1) * np.float32(0.5) + np.float32(slack)
+    np.testing.assert_allclose(eps.cpu().numpy(), want_eps, rtol=1e-6)
+    want_fail = ~(filt[:, -1].numpy() + want_eps < top[:, -1].numpy())
+    got_fail = fail.cpu().numpy().astype(bool)
+    edge = np.abs(filt[:, -1].numpy() + want_eps - top[:, -1].numpy()) < 1e-6          # (one-ulp boundary cases may differ)
+    assert np.array_equal(got_fail[~edge], want_fail[~edge]) and int(n_fail.item()) == int(got_fail.sum())
+    np.testing.assert_allclose(tv.cpu().numpy(), np.exp(alpha * top.numpy()), rtol=2e-6)
+    np.testing.assert_allclose(thr_out.cpu().numpy(), top[:, -1].numpy() - want_eps, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_attention_block(ops, seed):
+    rng = np.random.default_rng(10000 + seed)
+    dtype = torch.float32 if seed % 2 else torch.bfloat16
+    n, l = int(rng.integers(1, 24)), int(rng.integers(1, 129))
+    h = int(rng.choice([128, 256, 512, 768]))
+    nh = 4
+    x = rnd(n, l, h, seed=10100 + seed)
+    mask = _ragged_mask(n, l, 10200 + seed)
+    w = _att_weights(h, 10300 + seed)
+    want = O.bert_attention(x, mask.unsqueeze(1), O.Weights(w), nh)
+    wqkv = torch.cat([w["self.query.weight"], w["self.key.weight"], w["self.value.weight"]], 0)
+    bqkv = torch.cat([w["self.query.bias"], w["self.key.bias"], w["self.value.bias"]], 0)
+    got = ops.attention_block(dev(x, dtype), dev(mask), dev(wqkv, dtype), dev(bqkv), dev(w["output.dense.weight"], dtype),
+                              dev(w["output.dense.bias"]), dev(w["output.LayerNorm.weight"]), dev(w["output.LayerNorm.bias"]), nh)
+    close("attention_block", got, want, _tol(dtype, 2e-4, 8e-2))

@@ -181,3 +181,41 @@ def test_fuzz_attention_block(ops, seed):
     got = ops.attention_block(dev(x, dtype), dev(mask), dev(wqkv, dtype), dev(bqkv), dev(w["output.dense.weight"], dtype),
                               dev(w["output.dense.bias"]), dev(w["output.LayerNorm.weight"]), dev(w["output.LayerNorm.bias"]), nh)
     close("attention_block", got, want, _tol(dtype, 2e-4, 8e-2))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_exact_rank_mode_equals_f32_path(seed):
+    """Whole exact-rank searches on random small worlds (context mode, hidden size, clip padding, corpus and candidate
+    counts, ragged or full videos): the lists must be the plain f32 path's, tie-aware at f32 rounding."""
+    from tvretrieval_amd import inference as inf
+    from test_gpu_exact import _lists_equal
+    from test_gpu_model import _feats, _synthetic_model
+    rng = np.random.default_rng(11000 + seed)
+    ctx_mode = str(rng.choice(["video_sub", "video", "sub"]))
+    hidden = int(rng.choice([128, 256]))
+    l = int(rng.choice([128, 128, 64, 48]))
+    nv, nq = int(rng.integers(30, 900)), int(rng.integers(1, 90))
+    kv = int(rng.integers(1, min(12, nv) + 1))
+    n_cand = int(rng.integers(kv, min(nv, 4 * kv + 8) + 1))
+    m, cfg = _synthetic_model(ctx_mode, hidden, 256, 128, 128, l, torch.float32, seed=100 + seed)
+    lens = rng.integers(4, l + 1, nv) if seed % 2 else np.full(nv, l)
+    lens[0] = l
+    vf, vm = _feats(nv, lens, 256, 1 + seed)
+    sf, sm = _feats(nv, lens, 128, 2 + seed)
+    qf, qm = _feats(nq, rng.integers(1, 31, nq), 128, 3 + seed)
+    bs = int(rng.integers(20, 200))
+
+    def batches():
+        for b in range(0, nv, bs):
+            yield (vf[b:b + bs].to(DEV), vm[b:b + bs].to(DEV), sf[b:b + bs].to(DEV), sm[b:b + bs].to(DEV))
+    n_mom = 100
+    with torch.no_grad():
+        plain = inf.build_corpus_index(m, batches(), l_ref=l)
+        ref = inf.vcmr_search(m, plain, qf.to(DEV), qm.to(DEV), max_vcmr_video=kv, max_before_nms=n_mom)
+        exact = inf.build_corpus_index(m, batches(), l_ref=l, exact_filter=True)
+        exact.exact.n_candidates = n_cand
+        out = inf.vcmr_search(m, exact, qf.to(DEV), qm.to(DEV), max_vcmr_video=kv, max_before_nms=n_mom)
+    n_v, n_m, n_same = _lists_equal(out, ref, l, kv, n_mom, "fuzz %d exact vs f32" % seed)
+    assert n_same >= nq - max(1, nq // 20)
+    print("seed %d: %s h=%d l=%d nv=%d nq=%d k=%d M=%d: %d fell back, %d / %d tie swaps"
+          % (seed, ctx_mode, hidden, l, nv, nq, kv, n_cand, out["exact"]["n_fail"], n_v, n_m))

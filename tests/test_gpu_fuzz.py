@@ -219,3 +219,55 @@ def test_fuzz_exact_rank_mode_equals_f32_path(seed):
     assert n_same >= nq - max(1, nq // 20)
     print("seed %d: %s h=%d l=%d nv=%d nq=%d k=%d M=%d: %d fell back, %d / %d tie swaps"
           % (seed, ctx_mode, hidden, l, nv, nq, kv, n_cand, out["exact"]["n_fail"], n_v, n_m))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_search_vs_oracle_fp32(seed):
+    """Whole VCMR searches (encode, K6, top-k, ConvSE, moment top-n; f32) against the reference formulation on random
+    configurations: context mode, cross attention on / off, merged or per-stream span predictors, hidden size, clip
+    count, ragged lengths, feature widths, list sizes."""
+    from tvretrieval_amd import inference as inf
+    from oracle.listcmp import moment_keys, tie_aware_equal
+    from test_gpu_model import _feats, _synthetic_model
+    rng = np.random.default_rng(12000 + seed)
+    ctx_mode = str(rng.choice(["video_sub", "video_sub", "video", "sub"]))
+    cross, merge = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    hidden = int(rng.choice([128, 256, 384]))
+    l = int(rng.choice([128, 100, 64, 40, 17]))
+    dv, ds_, dq = int(rng.choice([256, 512, 1024])), int(rng.choice([128, 256])), int(rng.choice([128, 256]))
+    nv, nq = int(rng.integers(3, 60)), int(rng.integers(1, 40))
+    kv = int(rng.integers(1, min(10, nv) + 1))
+    n_mom = int(rng.integers(5, 150))
+    m, cfg = _synthetic_model(ctx_mode, hidden, dv, ds_, dq, l, torch.float32, seed=200 + seed, cross=cross, merge=merge)
+    lens = rng.integers(max(2, l // 6), l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, dv, 1 + seed)
+    sf, sm = _feats(nv, lens, ds_, 2 + seed)
+    qf, qm = _feats(nq, rng.integers(1, 31, nq), dq, 3 + seed)
+    om = O.OracleXML(cfg, {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    min_l, max_l = 2, int(rng.choice([8, 16]))
+    with torch.no_grad():
+        ov1, ov2, os1, os2 = om.encode_context(vf, vm, sf, sm)
+        q2c, st, ed = om.get_pred_from_raw_query(qf, qm, ov1, ov2, vm if om.use_video else None, os1, os2,
+                                                 sm if om.use_sub else None, cross=True)
+        want = O.vcmr_tail(q2c, st, ed, 20.0, kv, min_l, max_l, n_mom + 16)
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))])
+        out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=kv, max_before_nms=n_mom, min_pred_l=min_l,
+                              max_pred_l=max_l)
+    close("q2c", out["q2c"], q2c, 1e-4)
+    gi, wi = out["top_indices"].cpu().numpy(), want["top_indices"].numpy()
+    ww, wi2 = torch.topk(torch.exp(20.0 * q2c), min(kv + 6, nv), dim=1)
+    tie_aware_equal(gi, out["top_scores"].cpu().numpy(), wi2.numpy(), ww.numpy(), kv, 4e-3, "fuzz %d videos" % seed)
+    same = np.nonzero((gi == wi).all(1))[0]             # same ranked videos => same (k, L, L) candidate tensor
+    fs, fi = out["flat_scores"].cpu().numpy(), out["flat_indices"].cpu().numpy()
+    gk, wk = moment_keys(fi, gi, l), moment_keys(want["flat_indices"].numpy(), wi, l)
+    ws = want["flat_scores"].numpy()
+    for q in same:                                      # compare the positive-score prefix (zero-score rows are dropped)
+        npos = int((ws[q][:n_mom] > 0).sum())
+        got_n = int((fi[q] >= 0).sum())
+        assert got_n == npos, (seed, q, got_n, npos)
+        if npos > 2:
+            tie_aware_equal(gk[q:q + 1, :npos], fs[q:q + 1, :npos], wk[q:q + 1], ws[q:q + 1], max(1, npos - 2), 1e-3,
+                            "fuzz %d moments of query %d" % (seed, q))
+    print("seed %d: %s cross=%s merge=%s h=%d l=%d nv=%d nq=%d k=%d n=%d: %d / %d queries with the oracle's video order"
+          % (seed, ctx_mode, cross, merge, hidden, l, nv, nq, kv, n_mom, len(same), nq))
+    assert len(same) >= 0.8 * nq

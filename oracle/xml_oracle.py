@@ -297,8 +297,8 @@ class OracleXML(object):
         loss_st_ed = self.cfg["lw_st_ed"] * loss_st_ed
         l_ctx = self.cfg["lw_neg_ctx"] * l_ctx
         l_q = self.cfg["lw_neg_q"] * l_q
-        return loss_st_ed + l_ctx + l_q, dict(loss_st_ed=float(loss_st_ed), loss_neg_ctx=float(l_ctx),
-                                              loss_neg_q=float(l_q))
+        val = lambda x: float(x.detach()) if torch.is_tensor(x) else float(x)      # noqa: E731
+        return loss_st_ed + l_ctx + l_q, dict(loss_st_ed=val(loss_st_ed), loss_neg_ctx=val(l_ctx), loss_neg_q=val(l_q))
 
 
 # ------------------------------------------------------------------------------------------

@@ -271,3 +271,77 @@ def test_fuzz_search_vs_oracle_fp32(seed):
     print("seed %d: %s cross=%s merge=%s h=%d l=%d nv=%d nq=%d k=%d n=%d: %d / %d queries with the oracle's video order"
           % (seed, ctx_mode, cross, merge, hidden, l, nv, nq, kv, n_mom, len(same), nq))
     assert len(same) >= 0.8 * nq
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_training_forward_backward_vs_oracle_autograd(seed):
+    """XML.forward + backward (f32, dropout off) on random configurations against the oracle restatement differentiated
+    by torch autograd on the CPU: the three loss terms and every parameter gradient, with the two negative-sample draws
+    injected on both sides (as in the golden train-step fixtures)."""
+    from tvretrieval_amd.model_xml import XML
+    from tvretrieval_amd.train import xml_forward_train
+    from test_gpu_model import _feats
+    rng = np.random.default_rng(13000 + seed)
+    ctx_mode = str(rng.choice(["video_sub", "video_sub", "video", "sub"]))
+    cross, merge = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    if ctx_mode != "video_sub":
+        cross = merge = False
+    hidden = int(rng.choice([128, 256]))
+    l = int(rng.integers(8, 101))
+    dv, ds_, dq = int(rng.choice([256, 512])), int(rng.choice([128, 256])), int(rng.choice([128, 256]))
+    bsz = int(rng.integers(3, 25))
+    cfg = dict(merge_two_stream=merge, cross_att=cross, span_predictor_type="conv", encoder_type="transformer",
+               visual_input_size=dv, sub_input_size=ds_, query_input_size=dq, hidden_size=hidden, conv_kernel_size=5,
+               stack_conv_predictor_conv_kernel_sizes=-1, conv_stride=1, max_ctx_l=l, max_desc_l=30, input_drop=0.0, drop=0.0,
+               n_heads=4, initializer_range=0.02, ctx_mode=ctx_mode, margin=float(rng.choice([0.1, 0.2])),
+               ranking_loss_type=str(rng.choice(["hinge", "lse"])), lw_neg_q=float(rng.choice([1, 0.5])),
+               lw_neg_ctx=float(rng.choice([1, 2])), lw_st_ed=float(rng.choice([0.01, 0.1])), use_hard_negative=False,
+               hard_pool_size=20, use_self_attention=True, no_modular=False)
+    torch.manual_seed(300 + seed)
+    m = XML(cfg, compute_dtype=torch.float32)
+    g = torch.Generator().manual_seed(301 + seed)
+    with torch.no_grad():        # richer than N(0, 0.02): scores that differ, losses with active terms
+        for n_, p in m.named_parameters():
+            if n_.lower().endswith("layernorm.weight"):
+                p.copy_(1 + 0.2 * torch.randn(p.shape, generator=g))
+            elif n_.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+            elif "predictor" in n_:
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))
+            elif p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) / np.sqrt(p.shape[-1]))
+    m = m.to(DEV).train()
+    lens = rng.integers(3, l + 1, bsz); lens[0] = l
+    vf, vm = _feats(bsz, lens, dv, 1 + seed)
+    sf, sm = _feats(bsz, lens, ds_, 2 + seed)
+    qf, qm = _feats(bsz, rng.integers(1, 31, bsz), dq, 3 + seed)
+    st = np.array([rng.integers(0, n) for n in lens]); ed = np.array([rng.integers(s, n) for s, n in zip(st, lens)])
+    st_ed = torch.from_numpy(np.stack([st, ed], 1)).long()
+    neg_ctx, neg_q = rng.integers(1, bsz, bsz), rng.integers(1, bsz, bsz)
+    # oracle + autograd
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    om = O.OracleXML(cfg, sd)
+    want_loss, want_parts = om.forward_loss(qf, qm, vf, vm, sf, sm, st_ed, neg_ctx, neg_q)
+    want_loss.backward()
+    # HIP
+    T = lambda t: t.to(DEV)      # noqa: E731
+    loss, parts = xml_forward_train(m, T(qf), T(qm), T(vf), T(vm), T(sf), T(sm), T(st_ed), neg_ctx_rank=neg_ctx,
+                                    neg_q_rank=neg_q)
+    m.zero_grad()
+    loss.backward()
+    assert abs(float(loss) - float(want_loss)) <= 1e-4 * max(1.0, abs(float(want_loss))), (float(loss), float(want_loss))
+    for k in ("loss_st_ed", "loss_neg_ctx", "loss_neg_q"):
+        assert abs(parts[k] - want_parts[k]) <= 1e-4 * max(1.0, abs(want_parts[k])), (k, parts[k], want_parts[k])
+    worst = []
+    for n_, p in m.named_parameters():
+        wg = sd[n_].grad
+        if wg is None:                      # parameters of an unused modality
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n_
+            continue
+        assert p.grad is not None, n_
+        err = float((p.grad.cpu() - wg).abs().max())
+        worst.append((err / max(float(wg.abs().max()), 1e-4), n_, err))
+    worst.sort(reverse=True)
+    print("seed %d: %s cross=%s merge=%s %s h=%d l=%d bsz=%d: loss %.5f, worst gradient errors %s"
+          % (seed, ctx_mode, cross, merge, cfg["ranking_loss_type"], hidden, l, bsz, float(loss), worst[:2]))
+    assert worst[0][0] < 1e-3, worst[:5]

@@ -50,3 +50,29 @@ def test_evaluator_matches_reference(name):
     got = evaluate.eval_retrieval(case["submission"], case["ground_truth"], iou_thds=(0.5, 0.7), verbose=False,
                                   match_number=True, use_desc_type=case["use_desc_type"])
     assert json.loads(json.dumps(got)) == case["metrics"]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_nms_vs_oracle(seed):
+    """Host NMS (C++ behind the ABI) against the oracle's restatement of utils/temporal_nms.py on random prediction lists:
+    heavy overlaps, exact score ties (the reference's stable sort order), zero-length spans, more survivors than the cap,
+    many videos per query."""
+    from oracle import xml_oracle as O
+    from tvretrieval_amd import postproc
+    rng = np.random.default_rng(500 + seed)
+    n = int(rng.integers(1, 400))
+    st = np.round(rng.uniform(0, 60, n) / 1.5) * 1.5
+    ln = np.round(rng.uniform(0, 24, n) / 1.5) * 1.5 * (rng.random(n) > 0.05)          # a few zero-length spans
+    sc = np.round(rng.random(n), int(rng.choice([2, 3, 8])))                            # coarse scores: exact ties
+    preds = [[float(a), float(a + b), float(c)] for a, b, c in zip(st, ln, sc)]
+    thd = float(rng.choice([0.3, 0.5, 0.7]))
+    cap = int(rng.choice([5, 100]))
+    assert postproc.temporal_non_maximum_suppression([list(p) for p in preds], thd, max_after_nms=cap) == \
+        O.temporal_nms([list(p) for p in preds], thd, max_after_nms=cap)
+    # VCMR: [video, st, ed, score] rows, sorted by score as the search emits them
+    vids = rng.integers(0, int(rng.integers(1, 12)), n)
+    rows = sorted(([int(v)] + p for v, p in zip(vids, preds)), key=lambda r: -r[3])
+    mb = int(rng.choice([50, 1000]))
+    got = postproc.filter_vcmr_by_nms([list(r) for r in rows], thd, max_before_nms=mb, max_after_nms=cap)
+    want = O.vcmr_nms([list(r) for r in rows], thd, max_before_nms=mb, max_after_nms=cap)
+    assert [list(map(float, r)) for r in got] == [list(map(float, r)) for r in want]

@@ -345,3 +345,61 @@ def test_fuzz_training_forward_backward_vs_oracle_autograd(seed):
     print("seed %d: %s cross=%s merge=%s %s h=%d l=%d bsz=%d: loss %.5f, worst gradient errors %s"
           % (seed, ctx_mode, cross, merge, cfg["ranking_loss_type"], hidden, l, bsz, float(loss), worst[:2]))
     assert worst[0][0] < 1e-3, worst[:5]
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_cross_attention(ops, seed):
+    rng = np.random.default_rng(14000 + seed)
+    dtype = torch.float32 if seed % 2 else torch.bfloat16
+    n, lq, lk = int(rng.integers(1, 16)), int(rng.integers(1, 129)), int(rng.integers(1, 129))
+    h = int(rng.choice([128, 256, 768]))
+    nh = 4
+    main, side = rnd(n, lq, h, seed=14100 + seed), rnd(n, lk, h, seed=14200 + seed)
+    mm, sm = _ragged_mask(n, lq, 14300 + seed), _ragged_mask(n, lk, 14400 + seed)
+    sd = _att_weights(h, 14500 + seed)
+    att = {k[5:]: v for k, v in sd.items() if k.startswith("self.")}
+    g, b = sd["output.LayerNorm.weight"], sd["output.LayerNorm.bias"]
+    cross = O.bert_self_attention(main, side, side, torch.einsum("bm,bn->bmn", mm, sm), O.Weights(att), nh)
+    want = torch.nn.functional.layer_norm(cross + main, (h,), g, b, 1e-5)
+    wkv = torch.cat([att["key.weight"], att["value.weight"]], 0)
+    bkv = torch.cat([att["key.bias"], att["value.bias"]], 0)
+    got = ops.cross_attention(dev(main, dtype), dev(mm), dev(side, dtype), dev(sm), dev(att["query.weight"], dtype),
+                              dev(att["query.bias"]), dev(wkv, dtype), dev(bkv), dev(g), dev(b), nh)
+    # padded QUERY rows see (score - 10000) on every key: f32 keeps ~1e-3 of the score there, in the reference too, so their
+    # softmax -- and with it the row -- carries that much rounding noise; valid rows are compared at the tight tolerance
+    valid = mm.bool()
+    close("cross_attention, valid query rows", got.float().cpu()[valid], want[valid], _tol(dtype, 2e-4, 8e-2))
+    close("cross_attention, padded query rows", got.float().cpu()[~valid], want[~valid], _tol(dtype, 3e-3, 8e-2))
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_packed_query_ops_equal_padded(ops, seed):
+    """xml_attention_block_varlen / xml_modular_pool_varlen on packed tokens against the padded entries (and the padded
+    modular pooling against the oracle), random sequence counts and lengths <= 32."""
+    rng = np.random.default_rng(15000 + seed)
+    dtype = torch.float32 if seed % 2 else torch.bfloat16
+    n, lq = int(rng.integers(1, 300)), int(rng.integers(1, 33))
+    h = int(rng.choice([128, 256, 768]))
+    n_mod = int(rng.integers(1, 3))
+    lens = rng.integers(1, lq + 1, n); lens[0] = lq
+    mask = torch.from_numpy((np.arange(lq)[None, :] < lens[:, None]).astype(np.float32))
+    x = rnd(n, lq, h, seed=15100 + seed)
+    sd = _att_weights(h, 15200 + seed)
+    wqkv = torch.cat([sd["self.query.weight"], sd["self.key.weight"], sd["self.value.weight"]], 0)
+    bqkv = torch.cat([sd["self.query.bias"], sd["self.key.bias"], sd["self.value.bias"]], 0)
+    wargs = (dev(wqkv, dtype), dev(bqkv), dev(sd["output.dense.weight"], dtype), dev(sd["output.dense.bias"]),
+             dev(sd["output.LayerNorm.weight"]), dev(sd["output.LayerNorm.bias"]))
+    cu, src, rows = ops.pack_plan(dev(mask))
+    xp = dev(x, dtype).reshape(n * lq, h)[src[:rows].long()].contiguous()
+    padded = ops.attention_block(dev(x, dtype), dev(mask), *wargs, 4)
+    packed = ops.attention_block_varlen(xp, cu, n, lq, *wargs, 4)
+    sel = padded.reshape(n * lq, h)[src[:rows].long()]
+    close("attention varlen vs padded", packed, sel, 2e-5 if dtype == torch.float32 else 3e-2, 0.0 if dtype == torch.float32 else 1.6e-2)
+    wm = rnd(n_mod, h, seed=15300 + seed, scale=h ** -0.5)
+    pool_pad = ops.modular_pool(padded, dev(mask), dev(wm))
+    pool_pack = ops.modular_pool_varlen(sel.contiguous(), cu, n, lq, dev(wm))
+    close("modular pool varlen vs padded", pool_pack, pool_pad, 2e-5 if dtype == torch.float32 else 2e-2)
+    pf = padded.float().cpu()
+    att = torch.softmax(O.mask_logits(torch.einsum("nld,md->nlm", pf, wm), mask.unsqueeze(2)), dim=1)
+    want = torch.einsum("nlm,nld->mnd", att, pf)
+    close("modular pool vs the reference formulation", pool_pad, want, _tol(dtype, 2e-5, 2e-2))

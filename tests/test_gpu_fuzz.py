@@ -403,3 +403,46 @@ def test_fuzz_packed_query_ops_equal_padded(ops, seed):
     att = torch.softmax(O.mask_logits(torch.einsum("nld,md->nlm", pf, wm), mask.unsqueeze(2)), dim=1)
     want = torch.einsum("nlm,nld->mnd", att, pf)
     close("modular pool vs the reference formulation", pool_pad, want, _tol(dtype, 2e-5, 2e-2))
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_svmr_vs_oracle_fp32(seed):
+    """SVMR (moments inside each query's ground-truth video; xml/inference.py:195-241, 330-340) on random configurations
+    against the reference formulation: the softmaxed span probabilities of the given video and its banded top-n."""
+    from tvretrieval_amd import inference as inf
+    from oracle.listcmp import tie_aware_equal
+    from test_gpu_model import _feats, _synthetic_model
+    rng = np.random.default_rng(16000 + seed)
+    ctx_mode = str(rng.choice(["video_sub", "video", "sub"]))
+    cross, merge = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    hidden = int(rng.choice([128, 256]))
+    l = int(rng.choice([128, 96, 50, 24]))
+    nv, nq = int(rng.integers(2, 40)), int(rng.integers(1, 30))
+    n_mom = int(rng.integers(5, 120))
+    m, cfg = _synthetic_model(ctx_mode, hidden, 256, 128, 128, l, torch.float32, seed=400 + seed, cross=cross, merge=merge)
+    lens = rng.integers(max(3, l // 5), l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, 256, 1 + seed)
+    sf, sm = _feats(nv, lens, 128, 2 + seed)
+    qf, qm = _feats(nq, rng.integers(1, 31, nq), 128, 3 + seed)
+    gt = torch.from_numpy(rng.integers(0, nv, nq)).int()
+    om = O.OracleXML(cfg, {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        ov1, ov2, os1, os2 = om.encode_context(vf, vm, sf, sm)
+        _, st, ed = om.get_pred_from_raw_query(qf, qm, ov1, ov2, vm if om.use_video else None, os1, os2,
+                                               sm if om.use_sub else None, cross=True)
+        ar = torch.arange(nq)
+        st_p, ed_p = torch.softmax(st, -1)[ar, gt.long()], torch.softmax(ed, -1)[ar, gt.long()]
+        want = O.svmr_tail(st_p.numpy(), ed_p.numpy(), 2, 16, n_mom + 8)
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))])
+        out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=min(5, nv), max_before_nms=n_mom,
+                              svmr_video=gt.to(DEV))
+    close("svmr st prob", out["svmr_st"][:, :l], st_p, 1e-6, 2e-3)
+    close("svmr ed prob", out["svmr_ed"][:, :l], ed_p, 1e-6, 2e-3)
+    gs, gf = out["svmr_scores"].cpu().numpy(), out["svmr_flat"].cpu().numpy()
+    for q in range(nq):
+        ws, wf = want[q, :, 2], (want[q, :, 0] * l + want[q, :, 1]).astype(np.int64)
+        npos = int((ws[:n_mom] > 0).sum())
+        assert int((gf[q] >= 0).sum()) == npos, (seed, q)
+        if npos > 2:
+            tie_aware_equal(gf[q:q + 1, :npos], gs[q:q + 1, :npos], wf[None], ws[None], max(1, npos - 2), 2e-3,
+                            "fuzz %d SVMR moments of query %d" % (seed, q))

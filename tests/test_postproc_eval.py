@@ -43,7 +43,8 @@ def test_nms_edge_cases():
     assert top["VR"][0]["predictions"] == [0, 1, 2]
 
 
-@pytest.mark.parametrize("name", ["eval_tvr_style", "eval_didemo_style"])
+@pytest.mark.parametrize("name", ["eval_tvr_style", "eval_didemo_style", "eval_more_tiny", "eval_more_large",
+                                  "eval_more_vcmr_only", "eval_more_svmr_vr_didemo"])
 def test_evaluator_matches_reference(name):
     from tvretrieval_amd import evaluate
     case = json.load(open(os.path.join(GOLDEN, name + ".json")))

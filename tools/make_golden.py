@@ -408,7 +408,7 @@ def gen_train_case(ns, name, cfg, seed, bsz, len_lo, len_hi, lw_st_ed_schedule=N
     print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))
 
 
-def gen_eval_case(ns, name, seed, n_q, n_v, didemo):
+def gen_eval_case(ns, name, seed, n_q, n_v, didemo, tasks=("VCMR", "SVMR", "VR"), p_right_vid=0.15, max_pred=121):
     """standalone_eval/eval.py eval_retrieval on a synthetic submission + ground truth (the reference's own
     known-answer input file is a missing large blob)."""
     rng = np.random.default_rng(seed)
@@ -424,7 +424,7 @@ def gen_eval_case(ns, name, seed, n_q, n_v, didemo):
             ts = [st, ed]
         gt.append(dict(desc_id=900 + q, desc="q%d" % q, type=["v", "t", "vt"][int(rng.integers(0, 3))], vid_name=vn,
                        ts=ts, duration=90.0))
-        n_pred = int(rng.integers(3, 121))
+        n_pred = int(rng.integers(3, max_pred))
 
         def moment(correct):
             if correct:
@@ -433,7 +433,7 @@ def gen_eval_case(ns, name, seed, n_q, n_v, didemo):
             return [a, a + float(np.round(rng.uniform(1.5, 24), 2))]
         vc, sv, vr = [], [], []
         for j in range(n_pred):
-            right_vid = rng.random() < 0.15
+            right_vid = rng.random() < p_right_vid
             v = video2idx[vn] if right_vid else video2idx[names[int(rng.integers(0, n_v))]]
             vc.append([v] + moment(right_vid and rng.random() < 0.6) + [float(1.0 / (j + 1))])
             sv.append([video2idx[vn]] + moment(rng.random() < 0.2) + [float(1.0 / (j + 1))])
@@ -441,6 +441,7 @@ def gen_eval_case(ns, name, seed, n_q, n_v, didemo):
         vr = [[video2idx[names[int(i)]], 0, 0, float(1.0 / (j + 1))] for j, i in enumerate(perm)]
         for k, lst in (("VCMR", vc), ("SVMR", sv), ("VR", vr)):
             sub[k].append(dict(desc_id=900 + q, desc="q%d" % q, predictions=lst))
+    sub = {k: v for k, v in sub.items() if k == "video2idx" or k in tasks}
     metrics = ns.standalone_eval.eval_retrieval(sub, gt, iou_thds=(0.5, 0.7), verbose=False, match_number=True,
                                                 use_desc_type=not didemo)
     path = os.path.join(OUT_DIR, name + ".json")
@@ -513,6 +514,12 @@ def main():
                          n_q=9, ctx_bsz=5, q_bsz=4, kvid=6, kext=8, nbefore=50)
     gen_eval_case(ns, "eval_tvr_style", 41, n_q=60, n_v=25, didemo=False)
     gen_eval_case(ns, "eval_didemo_style", 42, n_q=30, n_v=12, didemo=True)
+    # more of the evaluator's input space: tiny and large problems, short prediction lists (fewer than the recall cut-offs),
+    # submissions with a subset of the tasks, hardly any / mostly correct videos
+    gen_eval_case(ns, "eval_more_tiny", 43, n_q=4, n_v=3, didemo=False, max_pred=8)
+    gen_eval_case(ns, "eval_more_large", 44, n_q=80, n_v=70, didemo=False)
+    gen_eval_case(ns, "eval_more_vcmr_only", 45, n_q=40, n_v=20, didemo=False, tasks=("VCMR",), p_right_vid=0.02)
+    gen_eval_case(ns, "eval_more_svmr_vr_didemo", 46, n_q=35, n_v=9, didemo=True, tasks=("SVMR", "VR"), p_right_vid=0.6)
     gen_train_case(ns, "train_step_video_sub_h128", model_cfg(max_ctx_l=24, lw_st_ed=0.01, visual_input_size=48, sub_input_size=32,
                                                            query_input_size=32), 31, bsz=6,
                    len_lo=6, len_hi=24)

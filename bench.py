@@ -42,8 +42,12 @@ WORKLOADS = {
     # per tile).  Reported next to the all-valid headline, never instead of it.
     "c3r": (10000, 21793, 128, 768, 3072, 768, 768, "video_sub", "bf16"),
     "tinyr": (64, 300, 128, 256, 512, 256, 256, "video_sub", "bf16"),
+    # the reference's AS-TRAINED shape, the configuration its only published number is quoted on (README.md:131): TVR val,
+    # 10 895 queries x 2 179 videos, hidden 256 (xml/config.py:143), max_ctx_l 100 (:86-88), resnet_i3d + subtitles, real
+    # clip counts.  K6 contracts over K = 256: a third of the headline's arithmetic intensity.
+    "tvr_val": (10895, 2179, 100, 256, 3072, 768, 768, "video_sub", "bf16"),
 }
-RAGGED = {"c3r", "tinyr"}
+RAGGED = {"c3r", "tinyr", "tvr_val"}
 PEAK_TFLOPS = {"bf16": 2500.0, "f32": 157.3}     # dense MFMA peaks, MI355X_MICROARCH.md
 CHUNK = int(os.environ.get("XML_BENCH_CHUNK", "2048"))  # videos per synthetic / encode batch (>= 3072 GEMM tiles: persistent kernel)
 SHARD_ALIGN = 64                                  # shard boundaries: one K6 round of an XCD set = 8 XCDs x 4 tiles x 2 videos
@@ -283,7 +287,14 @@ def run_extras(args, headline_qps):
             keep["mean_clips"] = r["ragged_corpus"]["mean_clips"]
         return keep
 
+    def tvr_val():
+        import bench_tvr_val
+        r = sub("tvr_val", 10, 3)
+        r["served_in_batches_of_50"] = bench_tvr_val.run(50)
+        return r
+
     leg("exact_rank", exact)
+    leg("tvr_val", tvr_val)
     leg("c2", lambda: sub("c2", 20, 3))
     leg("c3r", lambda: sub("c3r", max(2, min(args.steps, 5)), 2))
 
@@ -370,13 +381,24 @@ def run(args, backend_factory=None, emit=True):
     raw = list(context_batches(lo, hi, l, dv, ds, model.use_video, model.use_sub, device, lens))
     with torch.no_grad():   # second warm-up at the real batch size: workspaces and the allocator's pools reach their final size
         inf.build_corpus_index(model, iter(raw[:1]), ops=ops, video_offset=lo, n_total=nv, l_ref=l, **xkw)
+    # the index's own memory is mapped and touched first (IndexStorage: hipMalloc + zero-fill of 26 GB inside the timed
+    # region is what made this figure swing 32 K .. 151 K videos/s from box to box); alloc_s is reported next to it
     be.sync()
     t0 = time.perf_counter()
+    storage = inf.IndexStorage(model, hi - lo, l, ops=ops, device=device) if be.name == "hip" else None
+    be.sync()
+    alloc_s = time.perf_counter() - t0
+    enc_ev = (be.event(), be.event())
+    t0 = time.perf_counter()
+    enc_ev[0].record()
     with torch.no_grad():
         index = inf.build_corpus_index(model, iter(raw), ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo,
-                                       **xkw)
+                                       storage=storage, **xkw)
+    enc_ev[1].record()
     be.sync()
     enc_s = time.perf_counter() - t0
+    enc_dev_s = enc_ev[0].elapsed_time(enc_ev[1]) * 1e-3
+    del storage
     enc_bf16_s = None
     if world == 1 and not multi and be.name == "hip" and args.workload == "c3" and not args.no_extras \
             and dtype == torch.bfloat16 and not exact:
@@ -386,11 +408,14 @@ def run(args, backend_factory=None, emit=True):
         with torch.no_grad():
             inf.build_corpus_index(model, iter(raw16[:1]), ops=ops, video_offset=lo, n_total=nv, l_ref=l)
             be.sync()
+            st16 = inf.IndexStorage(model, hi - lo, l, ops=ops, device=device)
+            be.sync()
             t0 = time.perf_counter()
-            idx16 = inf.build_corpus_index(model, iter(raw16), ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo)
+            idx16 = inf.build_corpus_index(model, iter(raw16), ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo,
+                                           storage=st16)
             be.sync()
             enc_bf16_s = time.perf_counter() - t0
-        del raw16, idx16
+        del raw16, idx16, st16
     del raw
     rep_s = None
     if multi and not args.sharded_rerank:
@@ -590,6 +615,11 @@ def run(args, backend_factory=None, emit=True):
                          "launches_timed": len(k6_ms), "avg_launch_ms": k6_avg_ms,
                          "flops_per_launch": flops_per_launch},
             "encode_videos_per_s": (hi - lo) * world / enc_s if enc_s > 0 else None,
+            "encode": {"wall_s": enc_s, "hip_event_s": enc_dev_s, "index_alloc_and_touch_s": alloc_s,
+                       "videos_per_s_wall": (hi - lo) * world / enc_s if enc_s > 0 else None,
+                       "videos_per_s_hip_events": (hi - lo) * world / enc_dev_s if enc_dev_s > 0 else None,
+                       "note": "raw features and the index's memory resident before the clock starts; wall-clock and HIP "
+                               "events around the same build_corpus_index call"},
             "corpus_hbm_gb_per_gpu": index.hbm_bytes() / 1e9, "replicate_feat2_s": rep_s,
             "breakdown_ms": breakdown,
         }
@@ -622,7 +652,9 @@ def run(args, backend_factory=None, emit=True):
         if world == 1 and not multi and be.name == "hip" and args.workload == "c3" and not args.no_extras and not exact:
             enc_flops = 2.0 * l * hidden * (dv + ds) + 44.0 * l * hidden ** 2 + 24.0 * l ** 2 * hidden
             enc_tf = res["encode_videos_per_s"] * enc_flops / 1e12
-            extras = {"encode": {"videos_per_s": res["encode_videos_per_s"], "flops_per_video": enc_flops,
+            extras = {"encode": {"videos_per_s": res["encode_videos_per_s"],
+                                 "videos_per_s_hip_events": res["encode"]["videos_per_s_hip_events"],
+                                 "alloc_s": alloc_s, "flops_per_video": enc_flops,
                                  "tflops": enc_tf, "frac_of_mfma_peak": enc_tf / PEAK_TFLOPS[dtname],
                                  "raw_features": "f32 resident in HBM (the reference's input contract)"}}
             if enc_bf16_s:

@@ -29,7 +29,10 @@ extern "C" {
 
 typedef void* xml_stream_t; /* hipStream_t */
 
-typedef enum { XML_F32 = 0, XML_BF16 = 1 } xml_dtype;
+/* XML_F32 / XML_BF16: the two compute dtypes of the model.  XML_F16 / XML_F16S exist for the exact-rank mode only (see
+ * "Exact-rank mode on the 16-bit pipe"): XML_F16 = IEEE half rows (the similarity FILTER operands), XML_F16S = "split f16",
+ * f32-grade values carried as hi + lo halves (4 bytes per element). */
+typedef enum { XML_F32 = 0, XML_BF16 = 1, XML_F16 = 2, XML_F16S = 3 } xml_dtype;
 
 typedef enum {
   XML_OK = 0,

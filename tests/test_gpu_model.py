@@ -584,6 +584,37 @@ def test_hip_graph_replay_equals_eager():
         g(qf[:10].to(DEV), qm[:10].to(DEV))
 
 
+def test_hip_graph_large_batch_keeps_the_padded_query_path():
+    """A batch large enough for the packed-token query encoder (nq * lq >= PACK_MIN_ROWS) can still be captured: the graph
+    takes the padded path (the packing plan needs a host read-back and its launch shapes depend on the batch), and replays
+    with DIFFERENT valid-token counts give the padded path's results."""
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import model_xml
+    nv, l, lq = 24, 128, 30
+    nq = model_xml.PACK_MIN_ROWS // lq + 40
+    assert nq * lq >= model_xml.PACK_MIN_ROWS
+    m, cfg = _synthetic_model("video_sub", 128, 256, 128, 128, l, torch.bfloat16, seed=8)
+    rng = np.random.default_rng(6)
+    lens = rng.integers(20, l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, 256, 1)
+    sf, sm = _feats(nv, lens, 128, 2)
+    with torch.no_grad():
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))])
+        g = inf.GraphedVcmrSearch(m, index, nq, lq, 128, max_vcmr_video=10, max_before_nms=50)
+        assert model_xml.PACK_QUERY_TOKENS            # restored after the capture
+        for seed, lo in ((3, 5), (4, 25)):            # short and long queries: very different packed row counts
+            qf, qm = _feats(nq, np.concatenate([[lq], rng.integers(lo, lq + 1, nq - 1)]), 128, seed)
+            model_xml.PACK_QUERY_TOKENS = False
+            try:
+                want = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=50)
+            finally:
+                model_xml.PACK_QUERY_TOKENS = True
+            want = {k: v.clone() for k, v in want.items() if v is not None}
+            got = g(qf.to(DEV), qm.to(DEV))
+            for k in ("q2c", "top_scores", "top_indices", "flat_scores", "flat_indices"):
+                assert torch.equal(got[k], want[k]), (seed, k)
+
+
 def test_full_scale_c3_pipeline_properties():
     """BASELINE configs[2] at FULL size (10 000 queries x 21 793 videos x 128 clips, H=768, video_sub, bf16) through
     the whole search pass, checked by size-independent properties and by sampled comparisons with the reference

@@ -76,12 +76,46 @@ def _adjacent(params, flat_attr):
     regs = [getattr(p, "_xml_sink", None) for p in params]
     if any(r is None for r in regs) or any(r.opt is not regs[0].opt for r in regs):
         return None
+    flat = getattr(regs[0].opt, flat_attr)
     off = regs[0].offset
     for p, r in zip(params, regs):
         if r.offset != off:
             return None
+        # ... and the live tensor must still BE that slice: after model.to() / .float(), a second optimizer or a stale one
+        # the registered offsets survive while p.data (or p.grad) points elsewhere -- the flat view would be stale values
+        t = p.data if flat_attr == "flat_p" else p.grad
+        if t is None or t.dtype != flat.dtype or t.data_ptr() != flat.data_ptr() + flat.element_size() * r.offset:
+            return None
         off += p.numel()
-    return getattr(regs[0].opt, flat_attr)[regs[0].offset:off]
+    return flat[regs[0].offset:off]
+
+
+_HOOK_ON_UNDEFINED_GRAD = None
+
+
+def hook_fires_on_undefined_grad():
+    """One-off self-check of what the gradient sinks rely on: AccumulateGrad still runs the parameter's post-accumulate hook
+    when the node feeding it returned None (true on torch 2.10; older 2.x returned early before the hook -- sunk parameters
+    would then never be reported to the optimizer / the bucket reducer, silently)."""
+    global _HOOK_ON_UNDEFINED_GRAD
+    if _HOOK_ON_UNDEFINED_GRAD is None:
+        fired = []
+        p = torch.nn.Parameter(torch.zeros(2))
+        p.register_post_accumulate_grad_hook(lambda _p: fired.append(1))
+
+        class _NoneGrad(torch.autograd.Function):
+            @staticmethod
+            def forward(ctx, x, w):
+                return x.clone()
+
+            @staticmethod
+            def backward(ctx, dy):
+                return dy, None
+
+        x = torch.ones(2, requires_grad=True)
+        _NoneGrad.apply(x, p).sum().backward()
+        _HOOK_ON_UNDEFINED_GRAD = bool(fired)
+    return _HOOK_ON_UNDEFINED_GRAD
 
 
 class LinearFn(torch.autograd.Function):

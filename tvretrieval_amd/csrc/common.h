@@ -114,6 +114,38 @@ template <> struct Mma<bf16_t> {
   }
 };
 
+// ---- f16 / split-f16 (exact-rank mode on the 16-bit MFMA pipe) --------------------------------------------------------
+// f16_t : IEEE half storage (raw bits), one v_mfma_f32_16x16x32_f16 per 64-byte chunk -- same rate as bf16, 3 more
+//         mantissa bits (the exact-rank FILTER: rounding error 8x smaller than bf16's, so half the candidates suffice).
+// f16s_t: "split f16" -- an f32-grade value x carried as hi + lo, hi = rn_f16(x S), lo = rn_f16(x S - hi) (S a power of two
+//         per row): |x S - hi - lo| <= 2^-22 |x S|.  Rows are stored INTERLEAVED per 32 elements: [32 x hi | 32 x lo] =
+//         128 bytes, the K step of gemm_mainloop{,_dma} -- 4 bytes per element like f32.  A step is multiplied as
+//         hi.hi + lo.hi + hi.lo (three f16 MFMAs, f32 accumulate; the dropped lo.lo term is 2^-22 relative): f32-grade dot
+//         products at 16/3 of the f32 MFMA rate.  sizeof(f16s_t) == 4 so that k_bytes = K * sizeof(T) holds.
+// Subnormal halves are flushed to zero when the planes are WRITTEN (split16.hip), so what the MFMA consumes is what the
+// error norms were computed from, whatever its denormal mode.
+struct f16_t { unsigned short bits; };
+struct f16s_t { uint32_t pair; };
+typedef _Float16 f16x8_v __attribute__((ext_vector_type(8)));
+template <> struct Mma<f16_t> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; f16x8_v v; } ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.v, ub.v, acc, 0, 0, 0);
+  }
+};
+template <typename T> struct IsSplit16 { static constexpr bool value = false; };
+template <> struct IsSplit16<f16s_t> { static constexpr bool value = true; };
+// rn_f16(v) as raw bits, subnormal results flushed to (signed) zero
+__device__ __forceinline__ uint32_t f32_to_f16_bits_ftz(float v) {
+  const _Float16 h = (_Float16)v;
+  const uint32_t b = (uint32_t)__builtin_bit_cast(unsigned short, h);
+  return (b & 0x7c00u) ? b : (b & 0x8000u);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint32_t b) {
+  return (float)__builtin_bit_cast(_Float16, (unsigned short)b);
+}
+
 // ---- wave / block reductions ---------------------------------------------------------------------
 // reductions over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float lane16_max(float v) {
@@ -201,4 +233,4 @@ __device__ __forceinline__ void xml_seed_words(uint64_t seed, const uint64_t* se
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
-static inline size_t dt_size(int dt) { return dt == XML_F32 ? 4 : 2; }
+static inline size_t dt_size(int dt) { return (dt == XML_F32 || dt == XML_F16S) ? 4 : 2; }

@@ -85,6 +85,18 @@ def _exact_filter_operands(f1_raw, mask, plan, ops):
     return ops.pack_q2c_corpus(fb, mask, plan, normalize=False), fn, e_c
 
 
+def index_lpad(l_ref, model, ops=hip_ops):
+    """Padded clip count of the index tensors: l_ref rounded up to 16 -- or 128 when that lets K6 take its persistent tiled
+    kernel (which is built for 128-column video groups): the reference's as-trained shape, max_ctx_l = 100
+    (xml/config.py:86-88), pads 100 -> 128 (the length-bucketed layout then packs the videos of <= 64 / <= 32 clips 4 / 8 to
+    a tile, so the padding rows of SHORT videos cost no MFMA work) instead of 112 on the slow per-modality kernels."""
+    lp = _round_up(int(l_ref), 16)
+    if 64 < lp < 128 and hasattr(ops, "q2c_tiled_ok") and model is not None and \
+            ops.q2c_tiled_ok(128, model.config.hidden_size, getattr(model, "compute_dtype", torch.float32)):
+        return 128
+    return lp
+
+
 def pad_batch(seqs, device=None, dtype=torch.float32):
     """pad_sequences_1d (utils/tensor_utils.py:5-53) for a list of (L_i, D) arrays -> (N, Lmax, D), (N, Lmax)."""
     lens = [len(s) for s in seqs]
@@ -100,8 +112,32 @@ def pad_batch(seqs, device=None, dtype=torch.float32):
     return out, mask
 
 
+class IndexStorage(object):
+    """Device memory of a corpus index, allocated (and zero-filled: touched) BEFORE the encode -- a resident engine maps its
+    index once; hipMalloc + first touch of tens of GB inside the encode loop is what a fresh process pays, not the encoder
+    (bench.py times the two separately).  f1 / f2 / mk: per-modality (n_videos, lpad, H) compute dtype x2 and (n_videos,
+    lpad) f32; tiles: per-modality flat buffer of the K6 tile image (full-length corpora: the size is known up front)."""
+
+    def __init__(self, model, n_videos, l_ref, ops=hip_ops, device=None):
+        mods = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
+        dev = device if device is not None else next(model.parameters()).device
+        dt, h = model.compute_dtype, model.config.hidden_size
+        self.n_videos, self.l_ref, self.lpad = int(n_videos), int(l_ref), index_lpad(l_ref, model, ops)
+        self.f1 = {m: torch.zeros((self.n_videos, self.lpad, h), dtype=dt, device=dev) for m in mods}
+        self.f2 = {m: torch.zeros((self.n_videos, self.lpad, h), dtype=dt, device=dev) for m in mods}
+        self.mk = {m: torch.zeros((self.n_videos, self.lpad), dtype=torch.float32, device=dev) for m in mods}
+        self.tiles = {}
+        if hasattr(ops, "q2c_tiled_numel") and self.lpad == 128 and dt in (torch.float32, torch.bfloat16):
+            n = ops.q2c_tiled_numel(self.n_videos * self.lpad, h, dt)
+            if n:
+                self.tiles = {m: torch.zeros(n, dtype=dt, device=dev) for m in mods}
+
+    def nbytes(self):
+        return sum(t.numel() * t.element_size() for d in (self.f1, self.f2, self.mk, self.tiles) for t in d.values())
+
+
 def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, video_offset=0, n_total=None,
-                       l_ref=None, n_videos=None, exact_filter=False):
+                       l_ref=None, n_videos=None, exact_filter=False, storage=None):
     """Encode context batches and assemble the resident index.
 
     context_batches: iterable of (video_feat, video_mask, sub_feat, sub_mask) device tensors (unused modality:
@@ -112,9 +148,13 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
     exact_filter=True (f32 model): exact-rank mode -- feat1n becomes the bf16 filter image, index.exact the f32 operands
     (ExactFilter); vcmr_search then returns the f32 path's lists at close to the bf16 path's speed."""
     mods = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
+    if storage is not None:
+        assert l_ref is None or int(l_ref) == storage.l_ref
+        assert n_videos is None or int(n_videos) == storage.n_videos
+        l_ref, n_videos = storage.l_ref, storage.n_videos
     if n_videos is not None and l_ref is not None:
         return _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, int(l_ref),
-                                            int(n_videos), mods, exact_filter)
+                                            int(n_videos), mods, exact_filter, storage)
     parts = {m: dict(f1=[], f2=[], mk=[]) for m in mods}
     for video_feat, video_mask, sub_feat, sub_mask in context_batches:
         v1, v2, s1, s2 = model.encode_context(video_feat, video_mask, sub_feat, sub_mask)
@@ -125,7 +165,7 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
     batch_max = max(t.shape[1] for t in parts[mods[0]]["f2"])
     l_ref = batch_max if l_ref is None else int(l_ref)
     assert l_ref >= batch_max
-    lpad = _round_up(l_ref, 16)
+    lpad = index_lpad(l_ref, model, ops)
 
     def cat(tensors):
         n = sum(t.shape[0] for t in tensors)
@@ -160,14 +200,16 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
 
 
 def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, l_ref, n_videos, mods,
-                                 exact_filter=False):
+                                 exact_filter=False, storage=None):
     """build_corpus_index when the number of videos and the corpus-wide length are known up front (a resident engine knows
     its corpus): the three index tensors per modality are allocated once and every encoded batch is written into its
     rows -- no growing list of per-batch outputs, no concatenation pass, and the per-batch activations are recycled by the
     allocator instead of each batch mapping fresh memory.  Same contents as the list + cat path (zero rows beyond a
     batch's own padded length)."""
-    lpad = _round_up(l_ref, 16)
+    lpad = index_lpad(l_ref, model, ops)
     f1, f2, mk = {}, {}, {}
+    if storage is not None:       # (zero-filled by IndexStorage; used for ONE build)
+        f1, f2, mk = dict(storage.f1), dict(storage.f2), dict(storage.mk)
     r = 0
     for video_feat, video_mask, sub_feat, sub_mask in context_batches:
         # batches of full padded length are encoded STRAIGHT into their rows of the index tensors (the last layer of each
@@ -206,7 +248,9 @@ def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_of
         if exact_filter:
             feat1n[m], ex_f32[m], ex_ec[m] = _exact_filter_operands(f1[m], mk[m], plan, ops)
         else:
-            feat1n[m] = ops.pack_q2c_corpus(f1[m], mk[m], plan, normalize=True) if hasattr(ops, "pack_q2c_corpus") \
+            tile_buf = storage.tiles.get(m) if (storage is not None and plan is None) else None
+            kw = dict(out=tile_buf) if tile_buf is not None else {}
+            feat1n[m] = ops.pack_q2c_corpus(f1[m], mk[m], plan, normalize=True, **kw) if hasattr(ops, "pack_q2c_corpus") \
                 else ops.l2norm_rows(f1[m])
         if keep_raw:
             raw[m] = f1[m]
@@ -304,6 +348,9 @@ def stage_exact_topk(index, qvec, k, alpha, ops=hip_ops):
     Returns (top_w = exp(alpha s) (Nq, k) f32, top_i (Nq, k) int32, info dict)."""
     ex = index.exact
     mods = index.modalities
+    if k > min(ex.n_candidates, index.n_videos):
+        raise ValueError("exact-rank mode: top-%d videos asked of %d candidates per query (ExactFilter.n_candidates; K8 "
+                         "proposes at most 256) -- lower max_vcmr_video or raise n_candidates" % (k, ex.n_candidates))
     masks = [index.mask[m] for m in mods]
     qn = [ops.l2norm_rows(qvec[m].contiguous()) for m in mods]
     if qn[0].dtype != torch.float32:
@@ -381,7 +428,12 @@ def pad_moment_tail(flat_scores, flat_indices, k_videos, l_ref, min_pred_l=None,
     for c in range(0, rows.numel(), 256):
         r = rows[c:c + 256]
         have = flat_indices[r]                                                        # (b, n_out), -1 = empty
-        free = ~(cand[None, :, None] == have[:, None, :]).any(-1)                     # (b, |cand|): not in the list
+        # membership by scatter, O(b (|cand| + n_out)) memory (a (b, |cand|, n_out) comparison is 512 MB per chunk at the
+        # evaluation default max_before_nms = 1000): list entries inside [0, |cand|) mark their position as taken
+        taken = torch.zeros((r.numel(), cand.numel() + 1), dtype=torch.bool, device=dev)
+        slot = torch.where((have >= 0) & (have < cand.numel()), have, torch.full_like(have, cand.numel())).long()
+        taken.scatter_(1, slot, True)
+        free = ~taken[:, :cand.numel()]                                               # (b, |cand|): not in the list
         order = torch.argsort((~free).to(torch.int8), dim=1, stable=True)             # free positions first, ascending
         fill = cand[order[:, :n_out]]                                                 # (b, n_out)
         k = (pos[None, :] - cnt[r][:, None])                                          # index into fill for the empty rows
@@ -451,16 +503,24 @@ class GraphedVcmrSearch(object):
         self.query_mask[:, 0] = 1.0
         self._args = (model, index)
         self._kw = dict(search_kwargs)
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(2):
-                vcmr_search(model, index, self.query_feat, self.query_mask, **self._kw)
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
-            self.out = vcmr_search(model, index, self.query_feat, self.query_mask, **self._kw)
+        # the packed-token query encoder (large batches) reads its plan back on the host and launches shapes that depend on
+        # the batch's valid-token count: the graph keeps the padded path -- in the warm-ups too, so that the workspaces they
+        # size are the captured path's
+        from . import model_xml
+        pack_was, model_xml.PACK_QUERY_TOKENS = model_xml.PACK_QUERY_TOKENS, False
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(2):
+                    vcmr_search(model, index, self.query_feat, self.query_mask, **self._kw)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph), torch.no_grad():
+                self.out = vcmr_search(model, index, self.query_feat, self.query_mask, **self._kw)
+        finally:
+            model_xml.PACK_QUERY_TOKENS = pack_was
 
     def __call__(self, query_feat, query_mask):
         if tuple(query_feat.shape) != tuple(self.query_feat.shape) or tuple(query_mask.shape) != tuple(self.query_mask.shape):

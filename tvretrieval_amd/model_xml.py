@@ -342,8 +342,11 @@ class XML(nn.Module):
 
     def encode_query(self, query_feat, query_mask):
         """xml/model_xml.py:291-295."""
+        # (not while a HIP graph is being captured: the packing plan needs a host read-back and the packed launch shapes
+        # depend on the number of valid tokens of THIS batch -- a graph would bake the warm-up batch's in)
         if PACK_QUERY_TOKENS and query_feat.is_cuda and query_feat.shape[0] * query_feat.shape[1] >= PACK_MIN_ROWS \
-                and query_feat.shape[1] <= 32 and self.config.hidden_size <= 1024:
+                and query_feat.shape[1] <= 32 and self.config.hidden_size <= 1024 \
+                and not torch.cuda.is_current_stream_capturing():
             packed = self._encode_query_packed(query_feat, query_mask)
             if packed is not None:
                 return packed

@@ -323,7 +323,14 @@ def q2c_tile_rows(x):
     return TiledRows(data, rows, hidden, x.shape)
 
 
-def pack_q2c_corpus(feat1n, mask=None, plan=None, normalize=False):
+def q2c_tiled_numel(rows, hidden, dtype):
+    """Elements of the K6 tile image of (rows, hidden) rows of `dtype`, 0 when the tiled kernel does not take the shape."""
+    if not q2c_tiled_ok(128, hidden, dtype) or os.environ.get("XML_Q2C_ROW_MAJOR"):
+        return 0
+    return int(_lib.load().xml_q2c_tiled_bytes(rows, hidden, _DT[dtype])) // torch.empty(0, dtype=dtype).element_size()
+
+
+def pack_q2c_corpus(feat1n, mask=None, plan=None, normalize=False, out=None):
     """Resident form of the similarity operand: slice-major tiles when the persistent kernel takes it, else as is.
     mask (Nv, Lpad): if every entry is 1 (full-length videos) the tiles are marked all_valid and K6 skips the masks.
     plan (q2c_pack_plan over ALL modalities' masks): the length-bucketed image instead.
@@ -354,7 +361,12 @@ def pack_q2c_corpus(feat1n, mask=None, plan=None, normalize=False):
             hidden = feat1n.shape[-1]
             rows = feat1n.numel() // hidden
             nbytes = lib.xml_q2c_tiled_bytes(rows, hidden, dt_of(feat1n))
-            data = torch.empty(nbytes // feat1n.element_size(), dtype=feat1n.dtype, device=feat1n.device)
+            if out is not None:            # caller-owned tile buffer (inference.IndexStorage)
+                _req(out, "out", feat1n.dtype)
+                assert out.numel() == nbytes // feat1n.element_size()
+                data = out
+            else:
+                data = torch.empty(nbytes // feat1n.element_size(), dtype=feat1n.dtype, device=feat1n.device)
             check(lib.xml_q2c_tile_rows_l2norm(_p(feat1n), None, _p(data), rows, nbytes // (hidden * feat1n.element_size()),
                                                hidden, dt_of(feat1n), _stream()), "xml_q2c_tile_rows_l2norm")
             t = TiledRows(data, rows, hidden, feat1n.shape)

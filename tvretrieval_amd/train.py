@@ -358,7 +358,13 @@ class BertAdam(object):
         self.seg_steps = [0] * len(plist)
         self._active_key = None
         self._active_dev = None
+        from . import autograd as _ag
         from .autograd import GradSink
+        if _ag.USE_GRAD_SINKS and not _ag.hook_fires_on_undefined_grad():
+            import warnings
+            warnings.warn("this torch does not run post-accumulate hooks for undefined gradients: gradient sinks disabled "
+                          "(backward nodes return their parameter gradients to autograd)")
+            _ag.USE_GRAD_SINKS = False
         for i, (p, o) in enumerate(zip(plist, offs)):
             p.register_post_accumulate_grad_hook(lambda _p, i=i: self._touch(i))
             p._xml_sink = GradSink(self, i, o)      # backward kernels may accumulate straight into p.grad (autograd.py)
@@ -605,6 +611,11 @@ class GradientReducer(object):
         self.count = [0] * len(self.buckets)
         self.reduced = [False] * len(self.buckets)
         self.works = []
+        # the stream the step is issued on (zero_grad / the captured body call begin() from it).  A bucket's last hook may
+        # fire with a BRANCH stream current (PARALLEL_BRANCHES: AccumulateGrad of a subtitle-branch parameter runs on that
+        # branch's stream), so "the current stream" inside the hook is not enough to order the bucket behind the gradient
+        # kernels the main stream still has in flight
+        self.main = torch.cuda.current_stream(self.opt.flat_g.device) if self.cuda else None
 
     def _reduce(self, b):
         import torch.distributed as dist
@@ -615,6 +626,8 @@ class GradientReducer(object):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(view.device))
             self.side.wait_event(ev)
+            if self.main is not None:
+                self.side.wait_stream(self.main)
             # the branch streams of the training graph (PARALLEL_BRANCHES) write gradients too: a node that accumulated
             # straight into the flat buffer (gradient sink) hands no tensor to autograd, so nothing else orders its kernel
             # before this bucket's all-reduce

@@ -33,6 +33,9 @@ typedef void* xml_stream_t; /* hipStream_t */
  * "Exact-rank mode on the 16-bit pipe"): XML_F16 = IEEE half rows (the similarity FILTER operands), XML_F16S = "split f16",
  * f32-grade values carried as hi + lo halves (4 bytes per element). */
 typedef enum { XML_F32 = 0, XML_BF16 = 1, XML_F16 = 2, XML_F16S = 3 } xml_dtype;
+/* log2 of the FIXED scale of unit-norm rows in XML_F16 / XML_F16S form (xml_split_f16_rows(fixed_log2 = this)): the
+ * similarity kernels (xml_q2c_scores_tiled / _packed with dt = XML_F16, xml_q2c_rescore with dt = XML_F16S) undo 2^-28. */
+#define XML_F16_UNIT_LOG2 14
 
 typedef enum {
   XML_OK = 0,
@@ -277,6 +280,43 @@ int xml_exact_certificate(const float* filter_scores, int m, float* top_val, int
                           float* eps_out, float* thr_out, int32_t* n_fail, int nq, xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Exact-rank mode on the 16-bit pipe (XML_F16 / XML_F16S).  The three stages that must reproduce the reference's f32 scores
+ * -- query encoder, candidate re-score, ConvSE (xml/model_xml.py:291-295,436-453,455-502) -- ran on v_mfma_f32_16x16x4_f32,
+ * 1/16 of the f16 / bf16 MFMA rate.  An f32 value x is carried instead as two halves, x S = hi + lo (S a power of two,
+ * hi = rn_f16(x S), lo = rn_f16(x S - hi): |x S - hi - lo| <= 2^-22 |x S|), and a dot product as hi.hi + lo.hi + hi.lo with
+ * f32 accumulation: three f16 MFMAs per 32 k instead of eight f32 ones; the dropped lo.lo term is <= 2^-22 |x||y|.  The
+ * FILTER (K6) runs on the hi planes alone (XML_F16): same MFMA rate as bf16, rounding error 8x smaller, so half as many
+ * candidates per query carry the same certificate.
+ *
+ *   xml_split_f16_rows: x (rows, k) f32 -> y (rows, k) XML_F16S = per 32 elements [32 x hi | 32 x lo] f16 (4 bytes per
+ *     element; the 128-byte K step of the gathered-pair kernels), inv_scale (rows) f32 = 1 / S or NULL; optionally the plain
+ *     hi plane (rows, k) f16 -- K6's XML_F16 operand, to be tiled with xml_q2c_tile_rows -- and err (rows) f32 =
+ *     || x - hi / S ||_2, the rounding-error norm the certificate is made of.  fixed_log2 = -1: S = the power of two that
+ *     brings the row maximum into [2^13, 2^14); otherwise S = 2^fixed_log2 for every row (XML_F16_UNIT_LOG2 for the
+ *     unit-norm similarity operands: |x| <= 1 required).  Subnormal halves are flushed to zero.  k % 32 == 0.
+ *   xml_unsplit_f16_rows: the inverse, x = (hi + lo) * inv_scale[row]  (tests, exporting a split index).
+ *   xml_pack_weights_f16s: w (n, k) f32 nn.Linear weight -> dst: (n, 3k) f16 = [hi | hi | lo] at ONE power-of-two scale,
+ *     followed (16-byte aligned) by a 16-byte trailer whose first float is 1 / S; xml_pack_weights_f16s_bytes(n, k) bytes.
+ *     A projection with dt = XML_F16S (xml_linear_ln_relu_pos[_packed], xml_attention_block[_varlen], xml_cross_attention,
+ *     xml_linear_f16s) takes such weights, f32 activations / positional table / outputs, splits its input rows
+ *     into [hi | lo | hi] per call (inside its workspace) and runs the unchanged f16 GEMM over K' = 3k.  k % 8 == 0.
+ *   xml_linear_f16s: y (rows, n) f32 = [relu](x W^T + b), x (rows, k) f32, W from xml_pack_weights_f16s
+ *     (the query linears, xml/model_xml.py:462,516).
+ *   xml_convse_rerank_f16s: xml_convse_rerank with q_lin / feat2 as XML_F16S rows (desc.dt = XML_F16S, hidden % 32 == 0)
+ *     and their per-row 1 / S: q_inv_m (nq) f32, c_inv_m (nv * lpad) f32.
+ *   xml_q2c_scores_tiled / xml_q2c_scores_packed take dt = XML_F16 (tiles of hi planes at the fixed unit scale) and
+ *   xml_q2c_rescore takes dt = XML_F16S (rows from xml_split_f16_rows(fixed_log2 = XML_F16_UNIT_LOG2)); both undo 2^-28.
+ * --------------------------------------------------------------------------------------------- */
+int xml_split_f16_rows(const float* x, void* y, float* inv_scale, void* hi_plane, float* err, int64_t rows, int k,
+                       int fixed_log2, xml_stream_t stream);
+int xml_unsplit_f16_rows(const void* y, const float* inv_scale, float* x, int64_t rows, int k, xml_stream_t stream);
+size_t xml_pack_weights_f16s_bytes(int n, int k);
+int xml_pack_weights_f16s(const float* w, void* dst, int n, int k, xml_stream_t stream);
+size_t xml_linear_f16s_workspace_bytes(int64_t rows, int k);
+int xml_linear_f16s(const float* x, const void* w, const float* b, float* y, int64_t rows, int n, int k, int relu, void* ws,
+                    size_t ws_bytes, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K7: similarity contraction #2 + ConvSE start/end scorer on selected (query, video) pairs
  *   sim_m[l]  = q'_m . feat2_m[v,l]                       m in {video, sub}
  *   merged:   x = (sim_v + sim_s)/2 ; st = conv(x, w_st[0]) ; ed = conv(x, w_ed[0])
@@ -306,6 +346,12 @@ int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, const void* 
                       const void* feat2_0, const void* feat2_1, const float* mask0,
                       const float* mask1, const int32_t* pair_vid, const float* conv_w,
                       float* st_out, float* ed_out, void* ws, size_t ws_bytes, xml_stream_t stream);
+/* split-f16 operands (see "Exact-rank mode on the 16-bit pipe"); same workspace as xml_convse_rerank */
+int xml_convse_rerank_f16s(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const float* q_inv0,
+                           const float* q_inv1, const void* feat2_0, const void* feat2_1, const float* c_inv0,
+                           const float* c_inv1, const float* mask0, const float* mask1, const int32_t* pair_vid,
+                           const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
+                           xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9+K10: banded moment candidates + per-query top-n

@@ -34,7 +34,8 @@ def test_every_header_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_identity(lib):
-    assert lib.xml_abi_version() == 3
+    from tvretrieval_amd import _lib
+    assert lib.xml_abi_version() == _lib.ABI_VERSION == 4
     assert lib.xml_build_arch() == b"gfx950"
     assert lib.xml_status_string(0) == b"ok"
     assert lib.xml_status_string(-2) == b"unsupported shape"
@@ -132,3 +133,27 @@ def test_config_pickles_as_easydict_module():
     assert names and all(n.startswith("easydict ") for n in names), names
     back = pickle.loads(blob)
     assert back.hidden_size == 256 and dict(back) == dict(m.config)
+
+
+def test_split_f16_entries_validate_without_gpu(lib):
+    """The split-f16 entries (ABI 4: exact-rank mode on the 16-bit pipe) reject bad arguments before any launch."""
+    import ctypes
+    p = ctypes.c_void_p(0x1000)
+    z = ctypes.c_void_p(0)
+    assert lib.xml_split_f16_rows(z, p, p, z, z, 4, 64, -1, z) == -1            # null input
+    assert lib.xml_split_f16_rows(p, p, p, z, z, 4, 48, -1, z) == -2            # k % 32
+    assert lib.xml_split_f16_rows(p, p, p, z, z, 4, 64, 99, z) == -1            # scale out of range
+    assert lib.xml_unsplit_f16_rows(p, z, p, 4, 64, z) == -1
+    assert lib.xml_pack_weights_f16s_bytes(8, 16) == 8 * 16 * 6 + 16 and lib.xml_pack_weights_f16s_bytes(0, 16) == 0
+    assert lib.xml_pack_weights_f16s(p, p, 8, 12, z) == -2                      # k % 8
+    assert lib.xml_linear_f16s(p, p, z, p, 4, 8, 16, 0, z, 0, z) == -1          # no workspace
+    assert lib.xml_linear_f16s_workspace_bytes(100, 64) >= 100 * 64 * 6 + 400
+    assert lib.xml_linear_f16s(p, p, z, p, 100, 8, 64, 0, p, 16, z) == -3       # workspace too small
+    from tvretrieval_amd._lib import ConvseDesc, XML_F16S, XML_F32
+    d = ConvseDesc(nq=2, nv=2, kpairs=1, lpad=16, l_ref=16, hidden=64, n_mod=1, merged=0, ksize=5, softmax=1, dt=XML_F32)
+    assert lib.xml_convse_rerank_f16s(ctypes.byref(d), p, z, p, z, p, z, p, z, p, z, p, p, p, p, p, 1 << 20, z) == -1   # dt
+    d.dt, d.hidden = XML_F16S, 40
+    assert lib.xml_convse_rerank_f16s(ctypes.byref(d), p, z, p, z, p, z, p, z, p, z, p, p, p, p, p, 1 << 20, z) == -2   # hidden % 32
+    # the model entries accept XML_F16S as a compute dtype and still validate their workspace
+    assert lib.xml_attention_block_workspace_bytes(4, 16, 64, XML_F16S) > lib.xml_attention_block_workspace_bytes(4, 16, 64, XML_F32)
+    assert lib.xml_q2c_tiled_ok(128, 768, 2) == 1 and lib.xml_q2c_tiled_ok(128, 768, 3) == 0

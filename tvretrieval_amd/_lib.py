@@ -14,8 +14,10 @@ LIB_PATH = os.environ.get("XMLHIP_LIB") or os.path.join(_HERE, "csrc", "libxmlhi
 
 XML_F32 = 0
 XML_BF16 = 1
+XML_F16 = 2       # IEEE half rows: the exact-rank FILTER operands of K6
+XML_F16S = 3      # split f16 (hi + lo halves, 4 bytes per element): f32-grade values on the 16-bit MFMA pipe
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class XmlHipError(RuntimeError):
@@ -78,6 +80,16 @@ SIGNATURES = {
                               c_void_p, c_size_t, c_void_p]),
     # ---- exact-rank mode (exact.hip, convse.hip) ----
     "xml_round_bf16_rows_err": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "xml_split_f16_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "xml_unsplit_f16_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_void_p]),
+    "xml_pack_weights_f16s_bytes": (c_size_t, [c_int, c_int]),
+    "xml_pack_weights_f16s": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p]),
+    "xml_linear_f16s_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "xml_linear_f16s": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p, c_size_t,
+                                c_void_p]),
+    "xml_convse_rerank_f16s": (c_int, [ctypes.POINTER(ConvseDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_size_t, c_void_p]),
     "xml_select_ge_rows": (c_int, [c_void_p, c_int64, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_void_p]),
     "xml_q2c_rescore_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "xml_q2c_rescore": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,

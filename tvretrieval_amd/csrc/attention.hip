@@ -605,7 +605,7 @@ extern "C" size_t xml_attention_block_workspace_bytes(int64_t n, int seq_len, in
   const size_t pre = align_up(rows * hidden * 4, 256);      // f32 pre-LN rows, or the fused epilogue's partial statistics
   const size_t lnw = xmli_gemm_ln_eligible((int64_t)rows, hidden, hidden, dt) ? xmli_gemm_ln_workspace_bytes((int64_t)rows, hidden) : 0;
   return align_up(rows * 3 * hidden * dt_size(dt), 256) + align_up(rows * hidden * dt_size(dt), 256) +
-         (pre > lnw ? pre : lnw);
+         (pre > lnw ? pre : lnw) + xmli_gemm_split_ws_bytes((int64_t)rows, hidden, dt);
 }
 
 extern "C" int xml_attention_block(const void* x, const float* key_mask, const void* wqkv, const float* bqkv,
@@ -614,26 +614,29 @@ extern "C" int xml_attention_block(const void* x, const float* key_mask, const v
                                    xml_stream_t stream) {
   XML_ENTER();
   if (!x || !key_mask || !wqkv || !bqkv || !wo || !bo || !ln_g || !ln_b || !y || !ws) return XML_ERR_BAD_ARG;
-  if (n <= 0 || seq_len <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (n <= 0 || seq_len <= 0 || !xmli_model_dt_ok(dt)) return XML_ERR_BAD_ARG;
   if (seq_len > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
   if (ws_bytes < xml_attention_block_workspace_bytes(n, seq_len, hidden, dt)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const int64_t rows = n * seq_len;
+  const int adt = xmli_act_dt(dt);              // XML_F16S: f32 activations, split-f16 projections
   char* qkv = (char*)ws;
   char* att = qkv + align_up((size_t)rows * 3 * hidden * dt_size(dt), 256);
   char* pre = att + align_up((size_t)rows * hidden * dt_size(dt), 256);
-  int rc = xmli_gemm(x, wqkv, bqkv, nullptr, qkv, rows, 3 * hidden, hidden, 0, 0, 1, 0, dt, st);
+  char* sws = dt == XML_F16S ? (char*)ws + xml_attention_block_workspace_bytes(n, seq_len, hidden, dt) -
+                                   xmli_gemm_split_ws_bytes(rows, hidden, dt) : nullptr;
+  int rc = xmli_gemm(x, wqkv, bqkv, nullptr, qkv, rows, 3 * hidden, hidden, 0, 0, 1, 0, dt, st, sws);
   if (rc) return rc;
   const size_t es = dt_size(dt);
   rc = xmli_attention_core(qkv, 3 * hidden, qkv + (size_t)hidden * es, 3 * hidden, qkv + (size_t)2 * hidden * es,
-                           3 * hidden, nullptr, key_mask, att, 0, n, seq_len, seq_len, hidden, n_heads, dt, st);
+                           3 * hidden, nullptr, key_mask, att, 0, n, seq_len, seq_len, hidden, n_heads, adt, st);
   if (rc) return rc;
   if (xmli_gemm_ln_eligible(rows, hidden, hidden, dt) && y != x &&   // BertSelfOutput: dense + residual + LayerNorm in one launch
       xmli_gemm_ln(att, wo, bo, x, ln_g, ln_b, y, rows, hidden, hidden, 0, /*residual*/ 2, 1, dt, pre, st) == XML_OK)
     return XML_OK;
-  rc = xmli_gemm(att, wo, bo, x, pre, rows, hidden, hidden, 0, /*residual*/ 2, 1, /*out_f32*/ 1, dt, st);
+  rc = xmli_gemm(att, wo, bo, x, pre, rows, hidden, hidden, 0, /*residual*/ 2, 1, /*out_f32*/ 1, dt, st, sws);
   if (rc) return rc;
-  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_g, ln_b, y, rows, hidden, hidden, dt, st);
+  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_g, ln_b, y, rows, hidden, hidden, adt, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -662,7 +665,7 @@ extern "C" size_t xml_attention_block_varlen_workspace_bytes(int64_t rows, int h
   const size_t pre = align_up((size_t)rows * hidden * 4, 256);
   const size_t lnw = xmli_gemm_ln_eligible(rows, hidden, hidden, dt) ? xmli_gemm_ln_workspace_bytes(rows, hidden) : 0;
   return align_up((size_t)rows * 3 * hidden * dt_size(dt), 256) + align_up((size_t)rows * hidden * dt_size(dt), 256) +
-         (pre > lnw ? pre : lnw);
+         (pre > lnw ? pre : lnw) + xmli_gemm_split_ws_bytes(rows, hidden, dt);
 }
 
 extern "C" int xml_attention_block_varlen(const void* x, const int32_t* cu_seqlens, const void* wqkv, const float* bqkv,
@@ -671,21 +674,24 @@ extern "C" int xml_attention_block_varlen(const void* x, const int32_t* cu_seqle
                                           size_t ws_bytes, xml_stream_t stream) {
   XML_ENTER();
   if (!x || !cu_seqlens || !wqkv || !bqkv || !wo || !bo || !ln_g || !ln_b || !y || !ws) return XML_ERR_BAD_ARG;
-  if (rows <= 0 || n <= 0 || max_len <= 0 || n_heads <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (rows <= 0 || n <= 0 || max_len <= 0 || n_heads <= 0 || !xmli_model_dt_ok(dt)) return XML_ERR_BAD_ARG;
   if (max_len > 32 || hidden % 8 || hidden % n_heads) return XML_ERR_UNSUPPORTED;
   if (ws_bytes < xml_attention_block_varlen_workspace_bytes(rows, hidden, dt)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  const int adt = xmli_act_dt(dt);
   char* qkv = (char*)ws;
   char* att = qkv + align_up((size_t)rows * 3 * hidden * dt_size(dt), 256);
   char* pre = att + align_up((size_t)rows * hidden * dt_size(dt), 256);
-  int rc = xmli_gemm(x, wqkv, bqkv, nullptr, qkv, rows, 3 * hidden, hidden, 0, 0, 1, 0, dt, st);
+  char* sws = dt == XML_F16S ? (char*)ws + xml_attention_block_varlen_workspace_bytes(rows, hidden, dt) -
+                                   xmli_gemm_split_ws_bytes(rows, hidden, dt) : nullptr;
+  int rc = xmli_gemm(x, wqkv, bqkv, nullptr, qkv, rows, 3 * hidden, hidden, 0, 0, 1, 0, dt, st, sws);
   if (rc) return rc;
   const int dh = hidden / n_heads;
   rc = XML_ERR_UNSUPPORTED;
 #define XML_VL_CASE(D)                                                                                              \
   case D:                                                                                                           \
-    rc = dt == XML_F32 ? launch_attn_varlen<float, D>(qkv, hidden, cu_seqlens, att, n, max_len, n_heads, dt, st)    \
-                       : launch_attn_varlen<bf16_t, D>(qkv, hidden, cu_seqlens, att, n, max_len, n_heads, dt, st);  \
+    rc = adt == XML_F32 ? launch_attn_varlen<float, D>(qkv, hidden, cu_seqlens, att, n, max_len, n_heads, adt, st)    \
+                        : launch_attn_varlen<bf16_t, D>(qkv, hidden, cu_seqlens, att, n, max_len, n_heads, adt, st);  \
     break;
   switch (dh) {
     XML_VL_CASE(32)
@@ -700,9 +706,9 @@ extern "C" int xml_attention_block_varlen(const void* x, const int32_t* cu_seqle
   if (xmli_gemm_ln_eligible(rows, hidden, hidden, dt) && y != x &&
       xmli_gemm_ln(att, wo, bo, x, ln_g, ln_b, y, rows, hidden, hidden, 0, /*residual*/ 2, 1, dt, pre, st) == XML_OK)
     return XML_OK;
-  rc = xmli_gemm(att, wo, bo, x, pre, rows, hidden, hidden, 0, /*residual*/ 2, 1, /*out_f32*/ 1, dt, st);
+  rc = xmli_gemm(att, wo, bo, x, pre, rows, hidden, hidden, 0, /*residual*/ 2, 1, /*out_f32*/ 1, dt, st, sws);
   if (rc) return rc;
-  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_g, ln_b, y, rows, hidden, hidden, dt, st);
+  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_g, ln_b, y, rows, hidden, hidden, adt, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -711,7 +717,7 @@ extern "C" int xml_attention_block_varlen(const void* x, const int32_t* cu_seqle
 // ---------------------------------------------------------------------------------------------------
 extern "C" size_t xml_cross_attention_workspace_bytes(int64_t n, int lq, int lk, int hidden, int dt) {
   return align_up((size_t)n * lq * hidden * dt_size(dt), 256) + align_up((size_t)n * lk * 2 * hidden * dt_size(dt), 256) +
-         align_up((size_t)n * lq * hidden * 4, 256);
+         align_up((size_t)n * lq * hidden * 4, 256) + xmli_gemm_split_ws_bytes(n * (lq > lk ? lq : lk), hidden, dt);
 }
 
 extern "C" int xml_cross_attention(const void* main_x, const float* main_mask, const void* side_x,
@@ -722,22 +728,24 @@ extern "C" int xml_cross_attention(const void* main_x, const float* main_mask, c
   XML_ENTER();
   if (!main_x || !main_mask || !side_x || !side_mask || !wq || !bq || !wkv || !bkv || !ln_g || !ln_b || !y || !ws)
     return XML_ERR_BAD_ARG;
-  if (n <= 0 || lq <= 0 || lk <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (n <= 0 || lq <= 0 || lk <= 0 || !xmli_model_dt_ok(dt)) return XML_ERR_BAD_ARG;
   if (lq > 128 || lk > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
   if (ws_bytes < xml_cross_attention_workspace_bytes(n, lq, lk, hidden, dt)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   const size_t es = dt_size(dt);
+  const int adt = xmli_act_dt(dt);
   char* q = (char*)ws;
   char* kv = q + align_up((size_t)n * lq * hidden * es, 256);
   char* att = kv + align_up((size_t)n * lk * 2 * hidden * es, 256);
-  int rc = xmli_gemm(main_x, wq, bq, nullptr, q, n * lq, hidden, hidden, 0, 0, 1, 0, dt, st);
+  char* sws = dt == XML_F16S ? att + align_up((size_t)n * lq * hidden * 4, 256) : nullptr;
+  int rc = xmli_gemm(main_x, wq, bq, nullptr, q, n * lq, hidden, hidden, 0, 0, 1, 0, dt, st, sws);
   if (rc) return rc;
-  rc = xmli_gemm(side_x, wkv, bkv, nullptr, kv, n * lk, 2 * hidden, hidden, 0, 0, 1, 0, dt, st);
+  rc = xmli_gemm(side_x, wkv, bkv, nullptr, kv, n * lk, 2 * hidden, hidden, 0, 0, 1, 0, dt, st, sws);
   if (rc) return rc;
   rc = xmli_attention_core(q, hidden, kv, 2 * hidden, kv + (size_t)hidden * es, 2 * hidden, main_mask, side_mask, att,
-                           /*out_f32*/ 1, n, lq, lk, hidden, n_heads, dt, st);
+                           /*out_f32*/ 1, n, lq, lk, hidden, n_heads, adt, st);
   if (rc) return rc;
-  return xmli_add_layernorm(att, XML_F32, main_x, ln_g, ln_b, y, n * lq, hidden, hidden, dt, st);
+  return xmli_add_layernorm(att, XML_F32, main_x, ln_g, ln_b, y, n * lq, hidden, hidden, adt, st);
 }
 
 // ---------------------------------------------------------------------------------------------------

@@ -133,6 +133,10 @@ struct ConvseArgs {
   int nv, kpairs, lpad, l_ref, hidden, n_mod, merged, ksize, softmax;
   int dbg;   // perf ablations (xml_debug_set_q2c_ablation): 1 skip the GEMMs, 2 skip the conv / softmax / store epilogue
   int dma;   // rows are whole 128-byte K steps and every row offset fits 32 bits: the LDS-DMA mainloop (gemm.h)
+  // XML_F16S operands (split-f16 rows, split16.hip): 1 / S of every query row (nq) and of every clip row (nv * lpad),
+  // per modality -- powers of two, so moving an accumulator from one modality's units to the other's is exact
+  const float* q_inv[2];
+  const float* c_inv[2];
 };
 
 template <typename T>
@@ -151,7 +155,16 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
   const int v = a.chunk_vid[chunk];                // video owning this chunk
   const int first = a.offsets[v] + (chunk - a.chunk_off[v]) * TM;
   const int cnt = min(TM, a.offsets[v + 1] - first);
-  if (tid < TM) s_pair[tid] = tid < cnt ? a.bucket[first + tid] : -1;
+  constexpr bool SPLIT = IsSplit16<T>::value;
+  __shared__ float s_qinv[SPLIT ? 2 : 1][SPLIT ? TM : 1];
+  if (tid < TM) {
+    const int p = tid < cnt ? a.bucket[first + tid] : -1;
+    s_pair[tid] = p;
+    if constexpr (SPLIT) {
+#pragma unroll
+      for (int m = 0; m < 2; ++m) s_qinv[m][tid] = (p >= 0 && m < a.n_mod) ? a.q_inv[m][p / a.kpairs] : 1.f;
+    }
+  }
   __syncthreads();
 
   const int lane = tid & 63, wn = tid >> 6;
@@ -160,6 +173,12 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
   const int mt_used = (cnt + 15) >> 4;             // a video has ~46 pairs at the TVR shape: 3 of the 4 row tiles
   f32x4 acc[Cfg::MT][Cfg::NT];
   for (int m = 0; m < a.n_mod; ++m) {
+    float cinv[Cfg::NT];                           // SPLIT: 1 / S of this lane's clip columns, this modality
+#pragma unroll
+    for (int nt = 0; nt < Cfg::NT; ++nt) {
+      cinv[nt] = 1.f;
+      if constexpr (SPLIT) cinv[nt] = a.c_inv[m][(int64_t)v * a.lpad + min(wn * 32 + nt * 16 + fr, a.lpad - 1)];
+    }
     const T* ql = reinterpret_cast<const T*>(a.q_lin[m]);
     const T* f2 = reinterpret_cast<const T*>(a.feat2[m]);
     auto a_row = [&](int r) -> const char* {
@@ -194,6 +213,24 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
       gemm_mainloop<T, Cfg, false>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem, mt_used);
     else
       gemm_mainloop<T, Cfg, true>(acc, a_row, b_row, a.hidden * (int)sizeof(T), smem, mt_used);
+    if constexpr (SPLIT) {
+      if (a.merged && m + 1 < a.n_mod) {
+        // the next modality accumulates on top: move the accumulators into ITS units (exact: ratios of powers of two)
+        float cnext[Cfg::NT];
+#pragma unroll
+        for (int nt = 0; nt < Cfg::NT; ++nt)
+          cnext[nt] = cinv[nt] / a.c_inv[m + 1][(int64_t)v * a.lpad + min(wn * 32 + nt * 16 + fr, a.lpad - 1)];
+#pragma unroll
+        for (int mt = 0; mt < Cfg::MT; ++mt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mt * 16 + fg * 4 + r;
+            const float qr = s_qinv[m][row] / s_qinv[m + 1][row];
+#pragma unroll
+            for (int nt = 0; nt < Cfg::NT; ++nt) acc[mt][nt][r] *= qr * cnext[nt];
+          }
+      }
+    }
     if (!a.merged || m == a.n_mod - 1) {
       const float scale = (a.merged && a.n_mod == 2) ? 0.5f : 1.f;
       const int si = a.merged ? 0 : m;
@@ -203,8 +240,11 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
 #pragma unroll
         for (int nt = 0; nt < Cfg::NT; ++nt)
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
-            sim[si][mt * 16 + fg * 4 + r][wn * 32 + nt * 16 + fr] = acc[mt][nt][r] * scale;
+          for (int r = 0; r < 4; ++r) {
+            float x = acc[mt][nt][r] * scale;
+            if constexpr (SPLIT) x *= s_qinv[m][mt * 16 + fg * 4 + r] * cinv[nt];
+            sim[si][mt * 16 + fg * 4 + r][wn * 32 + nt * 16 + fr] = x;
+          }
     }
   }
   __syncthreads();
@@ -359,8 +399,12 @@ __global__ __launch_bounds__(256, 3) void rescore_kernel(RescoreArgs a) {
       for (int r = 0; r < 4; ++r) {
         float best = -INFINITY;
 #pragma unroll
-        for (int nt = 0; nt < Cfg::NT; ++nt)
-          best = fmaxf(best, acc[mt][nt][r] * mk[nt] + (1.f - mk[nt]) * -1e10f);      // mask_logits
+        for (int nt = 0; nt < Cfg::NT; ++nt) {
+          float x = acc[mt][nt][r];
+          // XML_F16S: both operands are unit-norm rows at the fixed scale 2^XML_F16_UNIT_LOG2
+          if constexpr (IsSplit16<T>::value) x *= 1.f / (float)(1u << (2 * XML_F16_UNIT_LOG2));
+          best = fmaxf(best, x * mk[nt] + (1.f - mk[nt]) * -1e10f);      // mask_logits
+        }
         best = lane16_max_dpp(best);
         if (fr == 0) s_max[wn][mt * 16 + fg * 4 + r] = best;
       }
@@ -384,6 +428,12 @@ __global__ void convse_zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
   if (i < n) p[i] = 0u;
 }
 
+static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const void* feat2_0,
+                              const void* feat2_1, const float* mask0, const float* mask1, const int32_t* pair_vid,
+                              const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
+                              const float* q_inv0, const float* q_inv1, const float* c_inv0, const float* c_inv1,
+                              xml_stream_t stream);
+
 extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1,
                                  const void* feat2_0, const void* feat2_1, const float* mask0, const float* mask1,
                                  const int32_t* pair_vid, const float* conv_w, float* st_out, float* ed_out, void* ws,
@@ -397,6 +447,34 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   if (d->lpad % 16 || d->lpad > 128 || d->l_ref > d->lpad || d->l_ref <= 0 || d->hidden % 8) return XML_ERR_UNSUPPORTED;
   if (!(d->ksize & 1) || d->ksize > 15 || d->ksize < 1) return XML_ERR_UNSUPPORTED;
   if (d->dt != XML_F32 && d->dt != XML_BF16) return XML_ERR_BAD_ARG;
+  return convse_rerank_impl(d, q_lin0, q_lin1, feat2_0, feat2_1, mask0, mask1, pair_vid, conv_w, st_out, ed_out, ws, ws_bytes,
+                            nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+extern "C" int xml_convse_rerank_f16s(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const float* q_inv0,
+                                      const float* q_inv1, const void* feat2_0, const void* feat2_1, const float* c_inv0,
+                                      const float* c_inv1, const float* mask0, const float* mask1, const int32_t* pair_vid,
+                                      const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
+                                      xml_stream_t stream) {
+  XML_ENTER();
+  if (!d || !q_lin0 || !feat2_0 || !mask0 || !pair_vid || !conv_w || !st_out || !ed_out || !ws || !q_inv0 || !c_inv0)
+    return XML_ERR_BAD_ARG;
+  if (d->nq <= 0 || d->nv <= 0 || d->kpairs <= 0 || d->hidden <= 0) return XML_ERR_BAD_ARG;
+  if (d->n_mod < 1 || d->n_mod > 2 || (d->n_mod == 2 && (!q_lin1 || !feat2_1 || !q_inv1 || !c_inv1))) return XML_ERR_BAD_ARG;
+  if (d->n_mod == 2 && !d->merged && !mask1) return XML_ERR_BAD_ARG;
+  if (d->merged && d->n_mod != 2) return XML_ERR_BAD_ARG;
+  if (d->lpad % 16 || d->lpad > 128 || d->l_ref > d->lpad || d->l_ref <= 0 || d->hidden % 32) return XML_ERR_UNSUPPORTED;
+  if (!(d->ksize & 1) || d->ksize > 15 || d->ksize < 1) return XML_ERR_UNSUPPORTED;
+  if (d->dt != XML_F16S) return XML_ERR_BAD_ARG;
+  return convse_rerank_impl(d, q_lin0, q_lin1, feat2_0, feat2_1, mask0, mask1, pair_vid, conv_w, st_out, ed_out, ws, ws_bytes,
+                            q_inv0, q_inv1, c_inv0, c_inv1, stream);
+}
+
+static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const void* feat2_0,
+                              const void* feat2_1, const float* mask0, const float* mask1, const int32_t* pair_vid,
+                              const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
+                              const float* q_inv0, const float* q_inv1, const float* c_inv0, const float* c_inv1,
+                              xml_stream_t stream) {
   if (ws_bytes < xml_convse_rerank_workspace_bytes(d)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   ConvseWs w;
@@ -431,15 +509,24 @@ extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, c
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
   a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax & 1;
   a.dbg = g_q2c_ablation;       // constant 0 in the product build (debug.h)
+  a.q_inv[0] = q_inv0; a.q_inv[1] = q_inv1 ? q_inv1 : q_inv0;
+  a.c_inv[0] = c_inv0; a.c_inv[1] = c_inv1 ? c_inv1 : c_inv0;
   {
-    const int64_t kb = (int64_t)d->hidden * (d->dt == XML_F32 ? 4 : 2);
+    const int64_t kb = (int64_t)d->hidden * (int64_t)dt_size(d->dt);
     a.dma = (kb % 128 == 0 && (int64_t)d->nq * kb < (1ll << 32) && (int64_t)d->lpad * kb < (1ll << 32)) ? 1 : 0;
     if (g_q2c_ablation == 40) a.dma = 0;             // (debug build: A/B against the register-staged mainloop)
   }
   const int64_t max_chunks = P / TM + (P < d->nv ? P : d->nv);
   const int n_sim = d->merged ? 1 : d->n_mod;
   const size_t patch = (size_t)TM * LP * 4;
-  if (d->dt == XML_F32) {
+  if (d->dt == XML_F16S) {
+    if (!a.dma) return XML_ERR_UNSUPPORTED;          // split rows are whole 128-byte steps by construction (hidden % 32 == 0)
+    using Cfg = GemmCfg<f16s_t, TM, 128, 1, 4>;
+    constexpr size_t stg = Cfg::LDS_BYTES;
+    const size_t lds = n_sim == 1 ? (stg > patch ? stg : patch) : stg + 2 * patch;
+    if (!xml_lds_attr_once<convse_kernel<f16s_t>>((int)(stg + 2 * patch))) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(convse_kernel<f16s_t>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
+  } else if (d->dt == XML_F32) {
     using Cfg = GemmCfg<float, TM, 128, 1, 4>;
     constexpr size_t stg = Cfg::LDS_BYTES;           // = GemmDma<Cfg, 2>::LDS_BYTES: both mainloops stage two steps
     const size_t lds = n_sim == 1 ? (stg > patch ? stg : patch) : stg + 2 * patch;
@@ -470,7 +557,8 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
   if (n_mod < 1 || n_mod > 2 || (n_mod == 2 && (!qn1 || !cn1 || !mask1))) return XML_ERR_BAD_ARG;
   if (nq <= 0 || nv <= 0 || kpairs <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
   if (lpad % 16 || lpad > 128 || lpad <= 0 || hidden % 8) return XML_ERR_UNSUPPORTED;
-  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16 && dt != XML_F16S) return XML_ERR_BAD_ARG;
+  if (dt == XML_F16S && hidden % 32) return XML_ERR_UNSUPPORTED;
   if (ws_bytes < xml_q2c_rescore_workspace_bytes(nq, nv, kpairs)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   xml_convse_desc d{};
@@ -498,12 +586,17 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
   a.offsets = w.offsets; a.chunk_off = w.chunk_off; a.bucket = w.bucket; a.chunk_vid = w.chunk_vid;
   a.nv = nv; a.kpairs = kpairs; a.lpad = lpad; a.hidden = hidden; a.n_mod = n_mod;
   {
-    const int64_t kb = (int64_t)hidden * (dt == XML_F32 ? 4 : 2);
+    const int64_t kb = (int64_t)hidden * (int64_t)dt_size(dt);
     a.dma = (kb % 128 == 0 && (int64_t)nq * kb < (1ll << 32) && (int64_t)lpad * kb < (1ll << 32)) ? 1 : 0;
     if (g_q2c_ablation == 40) a.dma = 0;
   }
   const int64_t max_chunks = P / TM + (P < nv ? P : nv);
-  if (dt == XML_F32) {
+  if (dt == XML_F16S) {
+    using Cfg = GemmCfg<f16s_t, TM, 128, 1, 4>;
+    constexpr int lds = GemmDma<Cfg, RS_STAGES>::LDS_BYTES;
+    if (!xml_lds_attr_once<rescore_kernel<f16s_t>>(lds)) return XML_ERR_LAUNCH;
+    hipLaunchKernelGGL(rescore_kernel<f16s_t>, dim3((unsigned)max_chunks), dim3(256), lds, st, a);
+  } else if (dt == XML_F32) {
     using Cfg = GemmCfg<float, TM, 128, 1, 4>;
     constexpr int lds = GemmDma<Cfg, RS_STAGES>::LDS_BYTES;
     if (!xml_lds_attr_once<rescore_kernel<float>>(lds)) return XML_ERR_LAUNCH;

@@ -120,6 +120,31 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
     if (s + 1 < nsteps) gload(s + 1);
     const char* sa = smem + (s & 1) * Cfg::STAGE_BYTES;
     const char* sb = sa + Cfg::BM * Cfg::ROWB;
+    if constexpr (IsSplit16<T>::value) {
+      // split-f16 rows: the step's 128 bytes are [32 x hi | 32 x lo] of the same 32 k -> hi.hi + lo.hi + hi.lo
+      uint4 fa[2][Cfg::MT], fb[2][Cfg::NT];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int m = 0; m < Cfg::MT; ++m) {
+          const int r = wm * (Cfg::BM / Cfg::WM) + m * 16 + fr;
+          if (m < mt_used) fa[c][m] = *reinterpret_cast<const uint4*>(sa + lds_slot_off(r, c * 4 + fg));
+        }
+#pragma unroll
+        for (int n = 0; n < Cfg::NT; ++n) {
+          const int r = wn * (Cfg::BN / Cfg::WN) + n * 16 + fr;
+          fb[c][n] = *reinterpret_cast<const uint4*>(sb + lds_slot_off(r, c * 4 + fg));
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int m = 0; m < Cfg::MT; ++m)
+          if (m < mt_used) {
+#pragma unroll
+            for (int n = 0; n < Cfg::NT; ++n) Mma<f16_t>::chunk(acc[m][n], fa[t == 1 ? 1 : 0][m], fb[t == 2 ? 1 : 0][n]);
+          }
+    } else {
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
       uint4 fa[Cfg::MT], fb[Cfg::NT];
@@ -139,6 +164,7 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
 #pragma unroll
           for (int n = 0; n < Cfg::NT; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
         }
+    }
     }
     if (s + 1 < nsteps) lstore((s + 1) & 1);
     __syncthreads();
@@ -228,6 +254,26 @@ __device__ __forceinline__ void gemm_mainloop_dma(f32x4 (&acc)[Cfg::MT][Cfg::NT]
       else if (s + 1 < nsteps) issue(s + 1, stage ^ 1);
       const char* sa = smem + stage * Cfg::STAGE_BYTES;
       const char* sb = sa + Cfg::BM * Cfg::ROWB;
+      if constexpr (IsSplit16<T>::value) {
+        // split-f16 rows (see gemm_mainloop): [32 x hi | 32 x lo] per step -> hi.hi + lo.hi + hi.lo
+        uint4 fa[2][MTU], fb[2][Cfg::NT];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+          for (int m = 0; m < MTU; ++m) fa[c][m] = *reinterpret_cast<const uint4*>(sa + lds_slot_off(m * 16 + fr, c * 4 + fg));
+#pragma unroll
+          for (int n = 0; n < Cfg::NT; ++n) {
+            const int r = wn * (Cfg::BN / Cfg::WN) + n * 16 + fr;
+            fb[c][n] = *reinterpret_cast<const uint4*>(sb + lds_slot_off(r, c * 4 + fg));
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int m = 0; m < MTU; ++m)
+#pragma unroll
+            for (int n = 0; n < Cfg::NT; ++n) Mma<f16_t>::chunk(acc[m][n], fa[t == 1 ? 1 : 0][m], fb[t == 2 ? 1 : 0][n]);
+      } else {
 #pragma unroll
       for (int c = 0; c < 2; ++c) {
         uint4 fa[MTU], fb[Cfg::NT];
@@ -242,6 +288,7 @@ __device__ __forceinline__ void gemm_mainloop_dma(f32x4 (&acc)[Cfg::MT][Cfg::NT]
         for (int m = 0; m < MTU; ++m)
 #pragma unroll
           for (int n = 0; n < Cfg::NT; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
+      }
       }
       stage = stage == STAGES - 1 ? 0 : stage + 1;
     }

@@ -44,6 +44,13 @@ template <> struct G256Init<bf16_t> {
     acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
   }
 };
+template <> struct G256Init<f16_t> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; f16x8_v v; } ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+};
 template <int CTRL>
 __device__ __forceinline__ uint4 g256_dpp_u4(const uint4& v) {
   uint4 r;
@@ -62,7 +69,10 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
                                                          const float* __restrict__ bias,
                                                          const AddT* __restrict__ addend, OutT* __restrict__ out,
                                                          int64_t M, int N, int K, int relu, int add_mode, int seq_len,
-                                                         int tm, int tn) {
+                                                         int tm, int tn, const float* __restrict__ row_scale) {
+  // T == f16_t: the split-f16 projection (split16.hip): A / W are the K-concatenated halves, K = 3 x the logical K, and
+  // every accumulator row is multiplied by row_scale[m] = 1 / (S_row S_weights) before bias / activation
+  constexpr bool SCALED = std::is_same<T, f16_t>::value;
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
   constexpr int SLOT_BYTES = 2 * OPER_BYTES;
@@ -245,12 +255,16 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
       const int lrow = wm * 64 + m4 * 16 + fr;
       const int64_t m = m0 + lrow;
       const bool rok = m < M;
+      float rsc = 1.f;
+      if constexpr (SCALED) rsc = rok ? row_scale[m] : 0.f;
       float v[NGRP][GC];
 #pragma unroll
       for (int q = 0; q < NGRP; ++q)
 #pragma unroll
         for (int e = 0; e < GC; ++e) {
-          float x = (PAIRED ? acc[m4][2 * q + (e >> 2)][e & 3] : acc[m4][q][e & 3]) + gb[q][e];
+          float x = (PAIRED ? acc[m4][2 * q + (e >> 2)][e & 3] : acc[m4][q][e & 3]);
+          if constexpr (SCALED) x *= rsc;
+          x += gb[q][e];
           if (relu) x = fmaxf(x, 0.f);
           v[q][e] = x;
         }
@@ -346,6 +360,11 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
       const float4 v1 = *reinterpret_cast<const float4*>(patch + prow * PLD + oc1);
       float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
       if (m >= M) continue;
+      if constexpr (SCALED) {
+        const float rsc = row_scale[m];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] *= rsc;
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         v[j] += bv[j];
@@ -393,7 +412,8 @@ __global__ __launch_bounds__(512, 2) void gemm256_kernel(const T* __restrict__ A
 
 template <typename T, typename OutT, typename AddT>
 static int launch_gemm256(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
-                          int N, int K, int relu, int add_mode, int seq_len, hipStream_t st) {
+                          int N, int K, int relu, int add_mode, int seq_len, hipStream_t st,
+                          const float* row_scale = nullptr) {
   const int tm = cdiv(M, 256), tn = cdiv(N, 256);
   const int64_t nsup = (int64_t)((tm + 7) / 8) * ((tn + 3) / 4);
   const unsigned grid = (unsigned)(((nsup + 7) / 8) * 8 * 32);
@@ -403,7 +423,7 @@ static int launch_gemm256(const void* A, const void* W, const float* bias, const
                 : xml_lds_attr_once<gemm256_kernel<T, OutT, AddT, false>>(lds)))
     return XML_ERR_LAUNCH;
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, st, (const T*)A, (const T*)W, bias, (const AddT*)addend,
-                     (OutT*)out, M, N, K, relu, add_mode, seq_len, tm, tn);
+                     (OutT*)out, M, N, K, relu, add_mode, seq_len, tm, tn, row_scale);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }
@@ -411,6 +431,16 @@ static int launch_gemm256(const void* A, const void* W, const float* bias, const
 bool xmli_gemm256_eligible(int64_t M, int N, int K, int dt) {
   const size_t kb = (size_t)K * dt_size(dt);
   return M >= 256 && N >= 128 && kb % 128 == 0 && kb >= 256;
+}
+
+// split-f16 projection: A' (M, K3) / W' (N, K3) f16, K3 = 3 x the logical K; out / addend f32
+bool xmli_gemm256_f16s_eligible(int64_t M, int N, int K3) {
+  return M >= 256 && N >= 128 && N % 8 == 0 && (K3 * 2) % 128 == 0 && K3 * 2 >= 256;
+}
+int xmli_gemm256_f16s(const void* A, const void* W, const float* bias, const void* addend, void* out,
+                      const float* row_scale, int64_t M, int N, int K3, int relu, int add_mode, int seq_len,
+                      hipStream_t st) {
+  return launch_gemm256<f16_t, float, float>(A, W, bias, addend, out, M, N, K3, relu, add_mode, seq_len, st, row_scale);
 }
 
 int xmli_gemm256(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,

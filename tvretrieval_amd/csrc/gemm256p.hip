@@ -842,6 +842,7 @@ static bool ln_fusion_device_ok() {
 }
 
 bool xmli_gemm_ln_eligible(int64_t M, int N, int K, int dt) {
+  if (dt != XML_F32 && dt != XML_BF16) return false;      // (split-f16 projections take the three-launch path)
   const size_t kb = (size_t)K * dt_size(dt);
   if (!ln_fusion_device_ok()) return false;
   return kb % 128 == 0 && kb >= 256 && N % 256 == 0 && N / 256 <= 4 && (int64_t)cdiv(M, 256) * (N / 256) >= 768;

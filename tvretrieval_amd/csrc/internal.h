@@ -3,8 +3,13 @@
 #include "common.h"
 
 // out = act(A W^T + bias) + addend ; add_mode 0 none / 1 positional table row (m % seq_len) / 2 residual row m
+// dt == XML_F16S (split-f16 projection: f32 activations, weights from xml_pack_weights_f16s): split_ws must hold
+// xmli_gemm_split_ws_bytes(M, K, dt) bytes; every other kernel of such a call runs on act_dt(dt) = f32 storage
 int xmli_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
-              int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st);
+              int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st, void* split_ws = nullptr);
+size_t xmli_gemm_split_ws_bytes(int64_t M, int K, int dt);
+static inline int xmli_act_dt(int dt) { return dt == XML_F16S ? XML_F32 : dt; }
+static inline bool xmli_model_dt_ok(int dt) { return dt == XML_F32 || dt == XML_BF16 || dt == XML_F16S; }
 // y = LN(act(A W^T + bias) + addend) * g + b with the LayerNorm in the GEMM epilogue (gemm256p.hip); callers check
 // xmli_gemm_ln_eligible and pass xmli_gemm_ln_workspace_bytes(M, N) bytes of scratch
 bool xmli_gemm_ln_eligible(int64_t M, int N, int K, int dt);

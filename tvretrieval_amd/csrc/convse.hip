@@ -81,7 +81,7 @@ __global__ void convse_zero_skipped_kernel(const int32_t* __restrict__ pair_vid,
 __global__ __launch_bounds__(1024) void convse_scan_kernel(const int32_t* __restrict__ counts,
                                                            int32_t* __restrict__ offsets,
                                                            int32_t* __restrict__ chunk_off,
-                                                           int32_t* __restrict__ chunk_vid, int nv) {
+                                                           int32_t* __restrict__ chunk_vid, int nv, int TM) {
   __shared__ int32_t wa[16], wb[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (nv + 1023) / 1024;
@@ -345,8 +345,11 @@ struct RescoreArgs {
 };
 
 static constexpr int RS_STAGES = 2;   // re-score ring depth: 2 stages = 49 KiB = three workgroups per CU (f32 MFMA-bound: waves per SIMD matter more than depth)
-template <typename T>
-__global__ __launch_bounds__(256, 3) void rescore_kernel(RescoreArgs a) {
+// TM = pairs per chunk: 64 (three workgroups per CU) or 128 -- with 256 candidates per query a video is listed by ~117
+// queries, and one 128-row chunk fetches its tile ONCE where two 64-row chunks fetch it twice (the kernel is bound by
+// those fetches: 393 KiB per modality and chunk in split-f16 form)
+template <typename T, int TM = 64>
+__global__ __launch_bounds__(256, TM == 64 ? 3 : 2) void rescore_kernel(RescoreArgs a) {
   using Cfg = GemmCfg<T, TM, 128, 1, 4>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   __shared__ int32_t s_pair[TM];
@@ -496,7 +499,7 @@ static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, cons
     XML_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid,
-                     d->nv);
+                     d->nv, TM);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P);
   XML_CHECK_LAUNCH();
@@ -575,7 +578,11 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(rescore_fill_skipped_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, out, P, nv);
   XML_CHECK_LAUNCH();
-  hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid, nv);
+  // rows per chunk: 128 when the average video is listed by more than 64 pairs (then most videos would need two 64-row
+  // chunks, each fetching the tile again)
+  const bool big = dt == XML_F16S && P > 64 * (int64_t)nv;
+  hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid, nv,
+                     big ? 128 : TM);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P);
   XML_CHECK_LAUNCH();
@@ -591,7 +598,14 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
     if (g_q2c_ablation == 40) a.dma = 0;
   }
   const int64_t max_chunks = P / TM + (P < nv ? P : nv);
-  if (dt == XML_F16S) {
+  if (dt == XML_F16S && big) {
+    if (!a.dma) return XML_ERR_UNSUPPORTED;
+    using Cfg = GemmCfg<f16s_t, 128, 128, 1, 4>;
+    constexpr int lds = GemmDma<Cfg, RS_STAGES>::LDS_BYTES;
+    if (!xml_lds_attr_once<rescore_kernel<f16s_t, 128>>(lds)) return XML_ERR_LAUNCH;
+    const int64_t chunks128 = P / 128 + (P < nv ? P : nv);
+    hipLaunchKernelGGL((rescore_kernel<f16s_t, 128>), dim3((unsigned)chunks128), dim3(256), lds, st, a);
+  } else if (dt == XML_F16S) {
     using Cfg = GemmCfg<f16s_t, TM, 128, 1, 4>;
     constexpr int lds = GemmDma<Cfg, RS_STAGES>::LDS_BYTES;
     if (!xml_lds_attr_once<rescore_kernel<f16s_t>>(lds)) return XML_ERR_LAUNCH;

@@ -293,9 +293,16 @@ __device__ __forceinline__ void gemm_mainloop_dma(f32x4 (&acc)[Cfg::MT][Cfg::NT]
       stage = stage == STAGES - 1 ? 0 : stage + 1;
     }
   };
-  static_assert(Cfg::MT == 4, "row-tile dispatch below");
-  if (mt_used >= 4) run(std::integral_constant<int, 4>{});
-  else if (mt_used == 3) run(std::integral_constant<int, 3>{});
-  else if (mt_used == 2) run(std::integral_constant<int, 2>{});
-  else run(std::integral_constant<int, 1>{});
+  static_assert(Cfg::MT == 4 || Cfg::MT == 8, "row-tile dispatch below");
+  if constexpr (Cfg::MT == 8) {      // 128-row chunks: live row tiles rounded up to 2 (four loop bodies, not eight)
+    if (mt_used > 6) run(std::integral_constant<int, 8>{});
+    else if (mt_used > 4) run(std::integral_constant<int, 6>{});
+    else if (mt_used > 2) run(std::integral_constant<int, 4>{});
+    else run(std::integral_constant<int, 2>{});
+  } else {
+    if (mt_used >= 4) run(std::integral_constant<int, 4>{});
+    else if (mt_used == 3) run(std::integral_constant<int, 3>{});
+    else if (mt_used == 2) run(std::integral_constant<int, 2>{});
+    else run(std::integral_constant<int, 1>{});
+  }
 }

@@ -83,17 +83,28 @@ class ExactFilter(object):
         self.tier2_cap = 1024         # candidates per second-tier query
 
 
-def _exact_filter_operands(f1_raw, mask, plan, ops, mode="f32"):
+# Filter operand of the split-f16 exact mode.  The K6 kernel is power-limited and every mantissa bit of its operands costs
+# ~0.85 ms of a 65 ms launch (tools/bench_k6_dtype.py: bf16 64.8, f16 69.3 ms on one box); an f16 filter needs 128
+# candidates per query, a bf16 filter 256 -- and the 128-row re-score chunks make the second 128 candidates cheap.
+EXACT_F16S_FILTER = "bf16"          # "bf16" (256 candidates) or "f16" (128 candidates)
+
+
+def _exact_filter_operands(f1_raw, mask, plan, ops, mode="f32", filter_dtype=None):
     """raw f32 feat1 (Nv, lpad, H) -> (filter image for K6, re-score operand, largest rounding-error norm).
-    mode "f32": bf16 tiles + f32 normalised rows; mode "f16s": f16 tiles (hi planes) + SplitRows."""
+    mode "f32": bf16 tiles + f32 normalised rows; mode "f16s": bf16 or f16 tiles + SplitRows."""
     if f1_raw.dtype != torch.float32:
         raise ValueError("exact-rank mode needs f32 activations (XML(cfg, compute_dtype=torch.float32 or ops.F16S)); got %s"
                          % f1_raw.dtype)
     fn = ops.l2norm_rows(f1_raw)
-    if mode == "f16s":
+    if mode == "f16s" and (filter_dtype or EXACT_F16S_FILTER) == "f16":
         sr, hi, err = ops.split_f16_rows(fn, ops.F16_UNIT_LOG2, want_hi=True, want_err=True)
         e_c = float(err.max()) if err.numel() else 0.0
         return ops.pack_q2c_corpus(hi, mask, plan, normalize=False), sr, e_c
+    if mode == "f16s":
+        sr = ops.split_f16_rows(fn, ops.F16_UNIT_LOG2)
+        fb, err = ops.round_bf16_rows_err(fn)
+        e_c = float(err.max()) if err.numel() else 0.0
+        return ops.pack_q2c_corpus(fb, mask, plan, normalize=False), sr, e_c
     fb, err = ops.round_bf16_rows_err(fn)
     e_c = float(err.max()) if err.numel() else 0.0
     return ops.pack_q2c_corpus(fb, mask, plan, normalize=False), fn, e_c
@@ -225,7 +236,7 @@ def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vide
 
 def _make_exact_filter(ex_f32, ex_ec, mode):
     # f16 filter: rounding errors 8x smaller than bf16's -> the certificate holds with half the candidates
-    return ExactFilter(ex_f32, ex_ec, n_candidates=128 if mode == "f16s" else 256, mode=mode)
+    return ExactFilter(ex_f32, ex_ec, n_candidates=128 if (mode == "f16s" and EXACT_F16S_FILTER == "f16") else 256, mode=mode)
 
 
 def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_offset, n_total, l_ref, n_videos, mods,
@@ -398,7 +409,12 @@ def stage_exact_topk_f16s(index, qvec, k, alpha, ops=hip_ops, defer_check=False)
         q = qvec[m].contiguous()
         if q.dtype != torch.float32:
             raise ValueError("exact-rank mode needs f32 query vectors (an f32 / ops.F16S model)")
-        sr, hi, e = ops.split_f16_rows(ops.l2norm_rows(q), ops.F16_UNIT_LOG2, want_hi=True, want_err=True)
+        qn = ops.l2norm_rows(q)
+        if index.feat1n[m].dtype == torch.float16:              # f16 filter: the hi plane of the split
+            sr, hi, e = ops.split_f16_rows(qn, ops.F16_UNIT_LOG2, want_hi=True, want_err=True)
+        else:                                                   # bf16 filter
+            sr = ops.split_f16_rows(qn, ops.F16_UNIT_LOG2)
+            hi, e = ops.round_bf16_rows_err(qn)
         q_sr.append(sr), q_hi.append(hi), eq.append(e)
     nq, hidden = q_hi[0].shape
     filt = _k6(index, q_hi, ops)

@@ -397,7 +397,7 @@ def run(args, backend_factory=None, emit=True):
     t0 = time.perf_counter()
     enc_ev[0].record()
     with torch.no_grad():
-        index = inf.build_corpus_index(model, iter(raw), ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo,
+        index = inf.build_corpus_index(model, raw, ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo,
                                        storage=storage, **xkw)
     enc_ev[1].record()
     be.sync()
@@ -548,6 +548,53 @@ def run(args, backend_factory=None, emit=True):
                       "ms_per_step": float(t.item()) / args.steps * 1e3, "steps": args.steps,
                       "collectives_per_pass": 2 if alt_owner else 4}
 
+    # ---- N > 1: the same sharded pass in exact-rank mode (ops.F16S model with the same weights; every shard hands its
+    #      exact local top-k to the merge), so that one line carries bf16 and identical-lists throughput at this N ----------
+    exact_sharded = None
+    if multi and not args.no_extras and be.name == "hip" and not exact and dtname == "bf16":
+        xi = m16 = None
+        build_err = None
+        try:        # local part first; the ranks then AGREE to run the leg (a rank failing alone must not leave the others
+            m16 = be.make_model(cfg, ops.F16S)     # waiting in a collective)
+            m16.load_state_dict(model.state_dict())
+            with torch.no_grad():
+                xi = inf.build_corpus_index(m16, list(context_batches(lo, hi, l, dv, ds, model.use_video, model.use_sub,
+                                                                      device, lens)),
+                                            ops=ops, video_offset=lo, n_total=nv, l_ref=l, n_videos=hi - lo, exact_filter=True)
+        except Exception as e:      # noqa: BLE001
+            build_err = "%s: %s" % (type(e).__name__, e)
+        flag = torch.tensor([0 if build_err else 1], device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            exact_sharded = {"error": build_err or "another rank could not build its exact-rank shard"}
+    if exact_sharded is None and multi and not args.no_extras and be.name == "hip" and not exact and dtname == "bf16":
+        try:
+            with torch.no_grad():
+                if not args.sharded_rerank:
+                    xdist.replicate_rerank_features(xi)
+
+                def x_step():
+                    return xdist.sharded_vcmr_search(m16, xi, qf, qm, gather_results=False, ops=ops, exchange=exchange,
+                                                     n_chunks=1)
+                x_step()
+                dist.barrier()
+                be.sync()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    x_step()
+                be.sync()
+                dist.barrier()
+            t = torch.tensor([time.perf_counter() - t0], device=device, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            exact_sharded = {"value": nq * args.steps / float(t.item()), "unit": "queries/s",
+                             "ms_per_step": float(t.item()) / args.steps * 1e3, "steps": args.steps,
+                             "candidates_per_query_and_shard": xi.exact.n_candidates,
+                             "what": "the same sharded pass with the f32 path's lists (exact-rank mode: bf16 filter, "
+                                     "split-f16 re-score / ConvSE, per-shard certificates)"}
+            del xi, m16
+        except Exception as e:      # noqa: BLE001 -- an extra leg must never lose the headline measurement
+            exact_sharded = {"error": "%s: %s" % (type(e).__name__, e)}
+
     k6_ms = [s.elapsed_time(e) for s, e in ev]
     k6_avg_ms = float(np.mean(k6_ms))
     launches_per_step = len(k6_ms) / float(args.steps)          # > 1 when the sharded pass is pipelined over query chunks
@@ -646,6 +693,8 @@ def run(args, backend_factory=None, emit=True):
             res["exact_rank"] = exact_info
         if alt_scheme is not None:
             res["extras"] = {"other_rerank_scheme": alt_scheme}
+        if exact_sharded is not None:
+            res.setdefault("extras", {})["exact_rank_sharded"] = exact_sharded
         if ragged is not None:
             res["ragged_corpus"] = ragged
             res["roofline"]["note"] = "ragged corpus: `achieved` prices the VALID clip rows (algorithmic work); " \

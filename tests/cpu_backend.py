@@ -43,6 +43,56 @@ class CpuOps(object):
             vals = torch.exp(alpha * vals)
         return vals, idx.int()
 
+    # ---- exact-rank mode (round 3's pipeline: bf16 filter values held in f32 tensors, exact re-score) -----------------
+    @staticmethod
+    def round_bf16_rows_err(y):
+        yb = y.float().to(torch.bfloat16).float()
+        return yb, (y.double() - yb.double()).norm(dim=-1).float()
+
+    @staticmethod
+    def pack_q2c_corpus(feat1n, mask=None, plan=None, normalize=False):
+        return F.normalize(feat1n.float(), dim=-1) if normalize else feat1n
+
+    @staticmethod
+    def q2c_rescore(qn, cn, masks, pair_vid):
+        nq, kp = pair_vid.shape
+        nv = cn[0].shape[0]
+        out = torch.full((nq, kp), float("-inf"))
+        pv = pair_vid.long()
+        ok = (pv >= 0) & (pv < nv)
+        for q in range(nq):
+            v = pv[q][ok[q]]
+            if v.numel() == 0:
+                continue
+            tot = 0
+            for m in range(len(qn)):
+                s = torch.einsum("d,nld->nl", qn[m][q].double(), cn[m][v].double()).float()
+                tot = tot + O.mask_logits(s, masks[m][v]).max(1)[0]
+            out[q, ok[q]] = tot / len(qn)
+        return out
+
+    @staticmethod
+    def exact_certificate(filter_scores, top_val, eq, ec, slack, alpha, outside):
+        c = 1 + 1e-6
+        eps = sum(e * c + (c + e) * x for e, x in zip(eq, ec)) / len(eq) + slack
+        t_k = top_val[:, -1].clone()
+        fail = ((~(filter_scores[:, -1] + eps < t_k)) & bool(outside)).int()
+        if alpha != 0.0:
+            top_val.copy_(torch.exp(alpha * top_val))
+        return fail, eps, t_k - eps, fail.sum().reshape(1).int()
+
+    @staticmethod
+    def select_ge_rows(scores, thr, cap=None):
+        take = scores >= thr[:, None]
+        cnt = take.sum(1).int()
+        if cap is None:
+            return cnt
+        idx = torch.full((scores.shape[0], int(cap)), -1, dtype=torch.int32)
+        for r in range(scores.shape[0]):
+            cols = torch.nonzero(take[r]).reshape(-1)[:int(cap)]
+            idx[r, :cols.numel()] = cols.int()
+        return idx, cnt
+
     @staticmethod
     def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, softmax=True, zero_skipped=True):
         n_mod = len(q_lin)

@@ -137,6 +137,70 @@ def test_sharded_equals_single_gloo(name, kvid, nbefore, world):
     assert ret.get(timeout=5) is True
 
 
+def _exact_worker(rank, world, port, name, kvid, nbefore, bounds, ret):
+    """exact-rank mode sharded over UNEVEN contiguous shards (bounds[r] .. bounds[r + 1]): every shard runs the filter /
+    re-score / certificate chain on its own videos (a tiny candidate count, so that the filter filters and certificates
+    fail) and hands its exact local top-k to the owner merge; the lists must be the single-process exact lists."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from cpu_backend import CpuModel, CpuOps
+    from tvretrieval_amd import dist as xd
+    from tvretrieval_amd import inference as inf
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.set_num_threads(1)
+        d, cfg, sd = load_golden(name)
+        model = CpuModel(cfg, sd)
+        n_total = len(d["ctx_lens"])
+        l_ref = d["video_feat"].shape[1]
+        T = torch.from_numpy
+
+        def index_of(lo, hi):
+            b = [(T(d["video_feat"][lo:hi]), T(d["video_mask"][lo:hi]), T(d["sub_feat"][lo:hi]), T(d["sub_mask"][lo:hi]))]
+            ix = inf.build_corpus_index(model, b, ops=CpuOps, video_offset=lo, n_total=n_total, l_ref=l_ref, exact_filter=True)
+            ix.exact.n_candidates = 2          # fewer than most shards hold: filter, certificate and both fallback tiers run
+            return ix
+        lo, hi = bounds[rank], bounds[rank + 1]
+        index = index_of(lo, hi)
+        qf, qm = T(d["query_feat"]), T(d["query_mask"])
+        kv = min(kvid, 2)
+        out = xd.sharded_vcmr_search(model, index, qf, qm, max_vcmr_video=kv, max_before_nms=nbefore, ops=CpuOps)
+        xd.replicate_rerank_features(index)
+        out2 = xd.sharded_vcmr_search(model, index, qf, qm, max_vcmr_video=kv, max_before_nms=nbefore, ops=CpuOps)
+        if rank == 0:
+            want = inf.vcmr_search(model, index_of(0, n_total), qf, qm, max_vcmr_video=kv, max_before_nms=nbefore, ops=CpuOps)
+            ok = True
+            for got in (out, out2):
+                ok = ok and torch.equal(got["top_indices"], want["top_indices"])
+                ok = ok and torch.equal(got["flat_indices"], want["flat_indices"])
+                ok = ok and torch.allclose(got["top_scores"], want["top_scores"], rtol=2e-5, atol=0)
+                ok = ok and torch.allclose(got["flat_scores"], want["flat_scores"], rtol=5e-5, atol=0)
+            ret.put(bool(ok))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,bounds", [(3, (0, 5, 6, 10)), (8, (0, 3, 4, 5, 6, 7, 8, 9, 10))])
+def test_exact_rank_sharded_uneven_shards_gloo(world, bounds):
+    """The first real 8-GPU exact-rank run, rehearsed on CPU: 10 videos over 8 ranks with UNEVEN shards (3, 1, 1, ...), 2
+    candidates per query and shard, top-2 videos -- most ranks own none of a query's global top-k, some shards are smaller
+    than the candidate count (no filter there), the 3-video shard filters and its certificates fail into the fallback."""
+    ctx = mp.get_context("spawn")
+    ret = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_exact_worker, args=(r, world, port, "xml_video_sub_cross_h128", 5, 40, bounds, ret))
+             for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(300)
+        assert p.exitcode == 0
+    assert ret.get(timeout=5) is True
+
+
 def _empty_shard_worker(rank, world, port, ret):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

@@ -243,8 +243,15 @@ def run_f16s(nq, nv, init, n_compare, log=lambda s: None, steps=1, warmup=2):
         same = (got["top_indices"] == ref["top_indices"]).all(1)
         gk = moment_keys(got["flat_indices"], got["top_indices"], l)[same].cpu().numpy()
         wk = moment_keys(ref["flat_indices"], ref["top_indices"], l)[same].cpu().numpy()
-        m_tie, m_real = tie_aware_diff(gk, got["flat_scores"][same].cpu().numpy(), wk, ref["flat_scores"][same].cpu().numpy(),
-                                       192, 5e-5)
+        # split-f16 scores are f32-GRADE (2^-22 per operand, four f32 ulps), not the f32 MFMA's bits: a moment score -- a
+        # product of two softmax outputs over logits of magnitude ~10 -- lands within 2e-4 of the f32 kernel's value, and two
+        # moments closer than that may swap.  (Against the CPU oracle both paths are held to the same 5e-4 rule,
+        # tests/test_gpu_fullsize.py::test_c2_full_shape_vs_oracle_fp32.)
+        gs_, ws_ = got["flat_scores"][same].cpu().numpy(), ref["flat_scores"][same].cpu().numpy()
+        m_tie, m_real = tie_aware_diff(gk, gs_, wk, ws_, 192, 2e-4)
+        m_tie_tight, m_real_tight = tie_aware_diff(gk, gs_, wk, ws_, 192, 5e-5)
+        eq_pos = gk[:, :192] == wk[:, :192]
+        dev = np.abs(gs_[:, :192] - ws_[:, :192])[eq_pos] / np.maximum(ws_[:, :192][eq_pos], 1e-30)
         cand = torch.gather(ref["q2c"], 1, got["exact"]["cand_indices"].long())
         res["vs_plain_f32"] = dict(
             queries=n, f32_pass_ms=t_ref, fell_back=got["exact"]["n_fail"],
@@ -252,7 +259,10 @@ def run_f16s(nq, nv, init, n_compare, log=lambda s: None, steps=1, warmup=2):
             video_positions=n * 100, video_positions_swapped_in_f32_ties=v_tie, video_positions_really_different=v_real,
             queries_with_identical_top100_order=int(same.sum()),
             moment_positions=int(same.sum()) * 192, moment_positions_swapped_in_f32_ties=m_tie,
-            moment_positions_really_different=m_real,
+            moment_positions_really_different=m_real, moment_tie_rtol=2e-4,
+            moment_positions_outside_rtol_5e_5=m_real_tight,
+            moment_score_rel_dev_same_position={"max": float(dev.max()), "p999": float(np.quantile(dev, 0.999)),
+                                                "mean": float(dev.mean())},
             top1_video_same=float((got["top_indices"][:, 0] == ref["top_indices"][:, 0]).float().mean()),
             top1_moment_same=float((moment_keys(got["flat_indices"], got["top_indices"], l)[:, 0] ==
                                     moment_keys(ref["flat_indices"], ref["top_indices"], l)[:, 0]).float().mean()))

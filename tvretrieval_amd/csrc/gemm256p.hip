@@ -24,6 +24,9 @@
 // A fifth ring slot for this kernel (the direct epilogue leaves LDS free; bias in registers): neutral as well -- unlike K6,
 // this K loop is not short of bytes in flight.
 // Same MFMA sequence per accumulator as gemm256_kernel: bitwise the same results.
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 
@@ -45,6 +48,10 @@ __device__ __forceinline__ xml_ln_f4 ln_read4(const float* pp) {
   v.w = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   return v;
 }
+
+// number of row-block waits of the LayerNorm-epilogue kernel that gave up (see the exchange below); read and cleared by
+// xml_ln_fusion_status
+__device__ int g_ln_timeouts = 0;
 
 struct G256pArgs {
   const void* A;
@@ -623,7 +630,15 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
           const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();        // 100 MHz
           while (__hip_atomic_load(a.ln_count + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.tn) {
             __builtin_amdgcn_s_sleep(1);
-            if (__builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) __builtin_trap();
+            // bounded wait.  No trap: the tile is normalised with whatever statistics are there (wrong values), the
+            // device-wide counter says so, every later wait of this launch gives up at once, and the host -- which reads
+            // the counter at its next natural synchronisation point (xml_ln_fusion_status) -- switches the fused path
+            // off and redoes the work through the three-launch path.
+            if (__hip_atomic_load(&g_ln_timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+                __builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) {
+              __hip_atomic_fetch_add(&g_ln_timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
           }
         }
         __builtin_amdgcn_s_barrier();
@@ -771,6 +786,8 @@ __global__ void g256p_zero_kernel(int* p, int n) {
   if (i < n) p[i] = 0;
 }
 
+static bool ln_coop_wanted();
+
 template <typename T, typename OutT, typename AddT, bool LNE = false, bool DIRECT = true>
 static int launch_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
                            int N, int K, int relu, int add_mode, int seq_len, hipStream_t st, const float* ln_g = nullptr,
@@ -811,7 +828,24 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
     std::lock_guard<std::mutex> lock(mu);
     if (!last_ev[dev] && hipEventCreateWithFlags(&last_ev[dev], hipEventDisableTiming) != hipSuccess) return XML_ERR_LAUNCH;
     else if (last_st[dev] != st && hipStreamWaitEvent(st, last_ev[dev], 0) != hipSuccess) return XML_ERR_LAUNCH;
-    hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
+    // Cooperative launch (the runtime refuses a grid that cannot be co-resident instead of letting it wait): the default
+    // outside profiler runs and stream captures; XML_LN_COOP=0 / 1 forces it off / on.  A refused launch returns an error
+    // here and the caller takes the three-launch path.
+    bool coop = ln_coop_wanted();
+    if (coop) {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) coop = false;
+      (void)hipGetLastError();
+    }
+    if (coop) {
+      void* kargs[] = {(void*)&a};
+      if (hipLaunchCooperativeKernel((const void*)kern, dim3(256), dim3(512), kargs, (unsigned)lds, st) != hipSuccess) {
+        (void)hipGetLastError();
+        return XML_ERR_LAUNCH;
+      }
+    } else {
+      hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
+    }
     const bool ok = hipGetLastError() == hipSuccess && hipEventRecord(last_ev[dev], st) == hipSuccess;
     last_st[dev] = st;
     return ok ? XML_OK : XML_ERR_LAUNCH;
@@ -827,7 +861,45 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
 // The fused kernel's workgroups wait for each other: it runs only where all 256 of them fit at once -- a device with at
 // least 256 CUs visible to this process (MI355X unpartitioned; a CPX / partitioned device or a CU mask reports fewer and
 // takes the three-launch path).
+static std::atomic<int> g_ln_fusion_off{0};     // set by xml_ln_fusion_status after a timed-out exchange, or XML_LN_FUSION=0
+
+static bool ln_coop_wanted() {
+  static const int mode = [] {
+    const char* e = getenv("XML_LN_COOP");
+    if (e && *e) return atoi(e) ? 1 : 0;
+    // rocprofiler-sdk 7.2 crashes at process exit after a traced cooperative launch (round 2): plain launch under it
+    const char* pre = getenv("LD_PRELOAD");
+    if ((pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES"))
+      return 0;
+    return 1;
+  }();
+  if (!mode) return false;
+  int dev = 0, ok = 0;
+  return hipGetDevice(&dev) == hipSuccess &&
+         hipDeviceGetAttribute(&ok, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && ok != 0;
+}
+
+// How many row-block exchanges of the LayerNorm-epilogue GEMM gave up since the last call (their tiles hold wrong values).
+// Synchronises the device.  disable != 0: a non-zero count also switches the fused path off for this process -- every later
+// projection takes GEMM + LayerNorm launches, which wait for nothing.  Returns the count, or a negative xml_status.
+extern "C" int xml_ln_fusion_status(int disable) {
+  XML_ENTER();
+  int n = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ln_timeouts), sizeof(int)) != hipSuccess) return XML_ERR_LAUNCH;
+  if (n != 0) {
+    const int zero = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ln_timeouts), &zero, sizeof(int)) != hipSuccess) return XML_ERR_LAUNCH;
+    if (disable) g_ln_fusion_off.store(1);
+  }
+  return n;
+}
+extern "C" int xml_ln_fusion_enabled(void) {
+  static const int env_off = [] { const char* e = getenv("XML_LN_FUSION"); return (e && *e && !atoi(e)) ? 1 : 0; }();
+  return (env_off || g_ln_fusion_off.load()) ? 0 : 1;
+}
+
 static bool ln_fusion_device_ok() {
+  if (!xml_ln_fusion_enabled()) return false;
   static std::atomic<int> cached[64];                  // 0 unknown, 1 ok, 2 not ok  (per device)
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;

@@ -156,17 +156,23 @@ def replicate_rerank_features(index, group=None):
     metas = metas.view(world, 2).cpu().tolist()
     n_max = max(n for _, n in metas)
     feat2_all, mask_all = {}, {}
+
+    def gather(src):
+        pad = src.new_zeros((n_max,) + tuple(src.shape[1:]))
+        pad[:src.shape[0]] = src
+        out = src.new_empty((world * n_max,) + tuple(src.shape[1:]))
+        _all_gather_into_tensor(out, pad, group)
+        full = src.new_empty((index.n_total,) + tuple(src.shape[1:]))
+        for r, (off, n) in enumerate(metas):
+            full[off:off + n] = out[r * n_max:r * n_max + n]
+        return full
     for m in index.modalities:
-        for src, dst in ((index.feat2[m], feat2_all), (index.mask[m], mask_all)):
-            pad = src.new_zeros((n_max,) + tuple(src.shape[1:]))
-            pad[:src.shape[0]] = src
-            out = src.new_empty((world * n_max,) + tuple(src.shape[1:]))
-            _all_gather_into_tensor(out, pad, group)
-            full = src.new_empty((index.n_total,) + tuple(src.shape[1:]))
-            for r, (off, n) in enumerate(metas):
-                full[off:off + n] = out[r * n_max:r * n_max + n]
-            dst[m] = full
-            del pad, out
+        f2 = index.feat2[m]
+        if hasattr(f2, "inv"):       # split-f16 rows (exact-rank mode on an ops.F16S model): the halves and the row scales
+            feat2_all[m] = type(f2)(gather(f2.data), gather(f2.inv))
+        else:
+            feat2_all[m] = gather(f2)
+        mask_all[m] = gather(index.mask[m])
     index.feat2_all, index.mask_all = feat2_all, mask_all
     return index
 

@@ -159,6 +159,18 @@ def linear_ln_relu_pos(x, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
     return y
 
 
+def ln_fusion_status(disable=True):
+    """Exchanges of the LayerNorm-epilogue GEMM that gave up since the last call (device sync).  > 0: results of the encode
+    that ran since then are invalid; with disable=True the fused path is off from now on -- redo the encode."""
+    return int(check_count(_lib.load().xml_ln_fusion_status(int(bool(disable))), "xml_ln_fusion_status"))
+
+
+def check_count(v, what):
+    if v < 0:
+        check(v, what)
+    return v
+
+
 ENCODE_INTO_INDEX = True      # attention_block(out=...) exists: inference.build_corpus_index encodes into the index tensors
 
 

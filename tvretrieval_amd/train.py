@@ -491,6 +491,12 @@ class GraphedTrainStep(object):
         keep = [t.clone() for t in (optimizer.flat_p, optimizer.flat_m, optimizer.flat_v)]
         keep_host = (list(optimizer.seg_steps), optimizer.step_count, list(optimizer._touched))
         cpu_rng = torch.get_rng_state()
+        # data-parallel capture: one stream (see GradientReducer._reduce) -- the branch streams are switched off for the
+        # warm-up and the capture of THIS object; what is lost is the 10 % the two-stream capture gains on one GPU
+        global PARALLEL_BRANCHES
+        self._branches_were = PARALLEL_BRANCHES
+        if optimizer._reducer is not None:
+            PARALLEL_BRANCHES = False
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
@@ -516,6 +522,7 @@ class GraphedTrainStep(object):
                 self.loss, self.parts = self._body(captured=True)
         finally:
             T.SEED_BASE = None
+            PARALLEL_BRANCHES = self._branches_were
         optimizer._touched = [a or b for a, b in zip(keep_host[2], self.active)]
         torch.cuda.synchronize(dev)
         # the capture itself executed nothing; bring the optimizer state back in any case (allocator reuse)
@@ -626,7 +633,11 @@ class GradientReducer(object):
             ev = torch.cuda.Event()
             ev.record(torch.cuda.current_stream(view.device))
             self.side.wait_event(ev)
-            if self.main is not None:
+            # (eager steps only.  Inside a stream capture the same extra edge -- an event recorded on the capturing origin
+            # stream from a hook that runs on a branch stream -- produced a graph whose replays lose gradient updates
+            # (tests/rccl_world1_check.py: parameters 1.4e-2 off after three steps, ROCm 7.2); GraphedTrainStep therefore
+            # captures a data-parallel step on ONE stream, where the event on the current stream above orders everything.)
+            if self.main is not None and not torch.cuda.is_current_stream_capturing():
                 self.side.wait_stream(self.main)
             # the branch streams of the training graph (PARALLEL_BRANCHES) write gradients too: a node that accumulated
             # straight into the flat buffer (gradient sink) hands no tensor to autograd, so nothing else orders its kernel

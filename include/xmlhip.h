@@ -78,9 +78,8 @@ int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const 
                            int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream);
 
 /* The large projections (K1 + K2, the output dense of K3 + K4) may run as ONE kernel with the LayerNorm in the GEMM's
- * epilogue; its 256 workgroups exchange per-row statistics and therefore wait for each other.  They are launched
- * cooperatively (XML_LN_COOP=0/1 overrides; off under rocprofiler and inside stream captures) and the wait is bounded: an
- * exchange that gives up is COUNTED, not trapped.
+ * epilogue; its 256 workgroups exchange per-row statistics and therefore wait for each other (one workgroup per CU; a
+ * cooperative launch is opt-in, XML_LN_COOP=1).  The wait is bounded: an exchange that gives up is COUNTED, not trapped.
  *   xml_ln_fusion_status(disable): the count since the last call (the affected tiles hold wrong values); synchronises the
  *     device, so call it where the host waits anyway (the end of a corpus encode); disable != 0 switches the fused path off
  *     for the process when the count is non-zero -- the caller then redoes the work, which takes plain GEMM + LayerNorm

@@ -865,13 +865,14 @@ static std::atomic<int> g_ln_fusion_off{0};     // set by xml_ln_fusion_status a
 
 static bool ln_coop_wanted() {
   static const int mode = [] {
+    // OPT-IN (XML_LN_COOP=1).  Measured in round 4: after ONE cooperative launch in a process, every later kernel of that
+    // process's neighbours on the GPU -- and graph replays of the process itself -- ran 1.5-3x slower for the rest of the
+    // run (bench.py's extras child next to its idle parent: K6 94.9 instead of 37.7 ms, training step 16.3 instead of
+    // 5.05 ms; the queue a cooperative launch goes through stays gang-scheduled).  And rocprofiler-sdk 7.2 crashes at
+    // process exit after a traced cooperative launch (round 2).  The default is therefore the plain launch + the bounded,
+    // COUNTED wait (xml_ln_fusion_status).
     const char* e = getenv("XML_LN_COOP");
-    if (e && *e) return atoi(e) ? 1 : 0;
-    // rocprofiler-sdk 7.2 crashes at process exit after a traced cooperative launch (round 2): plain launch under it
-    const char* pre = getenv("LD_PRELOAD");
-    if ((pre && strstr(pre, "rocprof")) || getenv("ROCPROFILER_REGISTER_FORCE_LOAD") || getenv("ROCP_TOOL_LIBRARIES"))
-      return 0;
-    return 1;
+    return (e && *e && atoi(e)) ? 1 : 0;
   }();
   if (!mode) return false;
   int dev = 0, ok = 0;

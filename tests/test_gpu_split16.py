@@ -401,3 +401,149 @@ def test_exact_mode_f16s_is_capturable():
         assert want["exact"]["n_full_rows"] > 0
         for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"):
             assert torch.equal(got[k], want[k]), k
+
+
+# ---- seeded sweeps over the supported shape space (one random case per test id) ----------------------------------------
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_linear_f16s(ops, seed):
+    """split-f16 projections over random (rows, n, k): both GEMM kernels, ragged row / column tiles, bias and ReLU, row
+    magnitudes spread over six decades -- float64 is the judge, an f32 GEMM the yardstick."""
+    rng = np.random.default_rng(21000 + seed)
+    rows = int(rng.choice([1, 7, 130, 255, 256, 700, 3000]))
+    n = int(rng.integers(1, 160)) * 8
+    k = int(rng.integers(1, 200)) * 8
+    relu = bool(rng.integers(0, 2))
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(rows, k, generator=g) * torch.logspace(-3, 3, rows)[:, None]
+    w = torch.randn(n, k, generator=g) * float(rng.choice([1e-3, 0.05, 3.0]))
+    b = torch.randn(n, generator=g) if rng.integers(0, 2) else None
+    want = x.double() @ w.double().t() + (b.double() if b is not None else 0)
+    if relu:
+        want = want.clamp_min(0)
+    got = ops.linear(x.to(DEV), ops.pack_weights_f16s(w.to(DEV)), None if b is None else b.to(DEV), relu=relu).cpu()
+    scale = (x.norm(dim=1, keepdim=True) * w.norm(dim=1)[None]).double().clamp_min(1e-30)
+    err = float(((got.double() - want).abs() / scale).max())
+    f32 = x.to(DEV) @ w.to(DEV).t() + (b.to(DEV) if b is not None else 0)
+    f32 = (f32.clamp_min(0) if relu else f32).cpu()
+    f32err = float(((f32.double() - want).abs() / scale).max())
+    assert err <= max(8e-7, 2.5 * f32err), (rows, n, k, err, f32err)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_rescore_f16s(ops, seed):
+    """xml_q2c_rescore on split rows over random clip paddings / hidden sizes / modalities / pair lists (skipped pairs,
+    videos listed by many queries -> 64- and 128-row chunks) against float64."""
+    rng = np.random.default_rng(22000 + seed)
+    n_mod = int(rng.integers(1, 3))
+    lpad = int(rng.choice([16, 48, 64, 112, 128]))
+    hidden = int(rng.choice([32, 64, 128, 256, 384, 768]))
+    nq, nv, kp = int(rng.integers(1, 400)), int(rng.integers(1, 60)), int(rng.integers(1, 12))
+    g = torch.Generator().manual_seed(100 + seed)
+    lens = torch.randint(1, lpad + 1, (nv,), generator=g)
+    mask = (torch.arange(lpad)[None] < lens[:, None]).float()
+    if nv > 2:
+        mask[1] = 0
+    qn = [_unit_rows(nq, hidden, seed=seed * 7 + m) for m in range(n_mod)]
+    cn = [_unit_rows(nv, lpad, hidden, seed=seed * 11 + 3 + m) * mask[..., None] for m in range(n_mod)]
+    pair = torch.randint(-1, nv + 1, (nq, kp), generator=g).int()
+    pair[:, 0] = int(rng.integers(0, nv))
+    got = ops.q2c_rescore([ops.split_f16_rows(q.to(DEV), ops.F16_UNIT_LOG2) for q in qn],
+                          [ops.split_f16_rows(c.to(DEV), ops.F16_UNIT_LOG2) for c in cn], [mask.to(DEV)] * n_mod,
+                          pair.to(DEV)).cpu()
+    tot = 0
+    for q, c in zip(qn, cn):
+        s = torch.einsum("md,nld->mln", q.double(), c.double())
+        s = s * mask.double().t()[None] + (1 - mask.double().t()[None]) * -1e10
+        tot = tot + s.max(1)[0]
+    ok = (pair >= 0) & (pair < nv)
+    want = torch.gather(tot / n_mod, 1, pair.clamp(0, nv - 1).long())
+    assert torch.isinf(got[~ok]).all() and bool((got[~ok] < 0).all())
+    live = ok & (want > -1e9)
+    assert float((got[live].double() - want[live]).abs().max()) < 5e-7 if live.any() else True
+    dead = ok & ~live                                   # fully masked videos: -1e10 on both sides
+    assert bool((got[dead] < -1e9).all())
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_convse_f16s(ops, seed):
+    """xml_convse_rerank_f16s against the f32 kernel over clip paddings, reference lengths, kernel sizes, merged or
+    per-stream predictors, skipped pairs and operand magnitudes that differ by many powers of two between the streams."""
+    rng = np.random.default_rng(23000 + seed)
+    n_mod = int(rng.integers(1, 3))
+    merged = bool(n_mod == 2 and rng.integers(0, 2))
+    lpad = int(rng.choice([16, 32, 64, 112, 128]))
+    l_ref = int(rng.integers(max(1, lpad - 15), lpad + 1))
+    hidden = int(rng.choice([32, 96, 128, 256, 768]))
+    ksize = int(rng.choice([1, 3, 5, 7]))
+    nq, nv, kp = int(rng.integers(1, 120)), int(rng.integers(1, 30)), int(rng.integers(1, 9))
+    g = torch.Generator().manual_seed(300 + seed)
+    lens = torch.randint(1, l_ref + 1, (nv,), generator=g)
+    mask = (torch.arange(lpad)[None] < lens[:, None]).float()
+    q_lin = [torch.randn(nq, hidden, generator=g) * float(rng.choice([0.01, 1.0, 40.0])) for _ in range(n_mod)]
+    feat2 = [torch.randn(nv, lpad, hidden, generator=g) * mask[..., None] * float(rng.choice([0.02, 1.0, 8.0]))
+             for _ in range(n_mod)]
+    conv_w = torch.randn(2 * (1 if merged else n_mod) * ksize, generator=g) * 0.5
+    pair = torch.randint(-1, nv, (nq, kp), generator=g).int()
+    masks = [mask.to(DEV)] * n_mod
+    lscale = 1.0
+    for softmax in (False, True):
+        w_st, w_ed = ops.convse_rerank([q.to(DEV) for q in q_lin], [f.to(DEV) for f in feat2], masks, pair.to(DEV),
+                                       conv_w.to(DEV), l_ref, merged, ksize, softmax=softmax)
+        g_st, g_ed = ops.convse_rerank([ops.split_f16_rows(q.to(DEV)) for q in q_lin],
+                                       [ops.split_f16_rows(f.to(DEV)) for f in feat2], masks, pair.to(DEV),
+                                       conv_w.to(DEV), l_ref, merged, ksize, softmax=softmax)
+        for nm, a, b in (("st", g_st, w_st), ("ed", g_ed, w_ed)):
+            a, b = a.cpu(), b.cpu()
+            live = b > -1e9
+            assert torch.equal(a > -1e9, live), (seed, nm)
+            if not live.any():
+                continue
+            if not softmax:      # logits: a few f32 ulps of their own magnitude
+                lscale = max(lscale, float(b[live].abs().max()))
+                close("fuzz %d convse f16s %s logits" % (seed, nm), a[live], b[live], 4e-6 * lscale, 4e-6)
+            else:                # probabilities: exp() turns a logit error d into a RELATIVE error d
+                close("fuzz %d convse f16s %s probabilities" % (seed, nm), a[live], b[live], 1e-9, 8e-6 * lscale + 4e-6)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzz_f16s_search_vs_oracle(seed):
+    """WHOLE searches on an ops.F16S model -- exact-rank mode when the corpus is large enough to filter, the plain path
+    otherwise -- against the reference formulation on the CPU: context mode, cross attention, merged / per-stream predictors,
+    hidden size, clip count, ragged lengths."""
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import ops
+    rng = np.random.default_rng(24000 + seed)
+    ctx_mode = str(rng.choice(["video_sub", "video_sub", "video", "sub"]))
+    cross, merge = bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+    hidden = int(rng.choice([128, 256]))
+    l = int(rng.choice([128, 100, 64, 40]))
+    dv, ds_, dq = int(rng.choice([256, 512])), int(rng.choice([128, 256])), int(rng.choice([128, 256]))
+    nv, nq = int(rng.integers(12, 70)), int(rng.integers(1, 40))
+    kv = int(rng.integers(1, 6))
+    n_mom = int(rng.integers(5, 120))
+    m16, cfg = _synthetic_model(ctx_mode, hidden, dv, ds_, dq, l, ops.F16S, seed=400 + seed, cross=cross, merge=merge)
+    lens = rng.integers(max(2, l // 6), l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, dv, 1 + seed)
+    sf, sm = _feats(nv, lens, ds_, 2 + seed)
+    qf, qm = _feats(nq, rng.integers(1, 31, nq), dq, 3 + seed)
+    om = O.OracleXML(cfg, {k: v.detach().cpu() for k, v in m16.state_dict().items()})
+    b = [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))]
+    with torch.no_grad():
+        index = inf.build_corpus_index(m16, b, exact_filter=True)
+        index.exact.n_candidates = max(kv, min(nv - 1, 2 * kv + 3))
+        out = inf.vcmr_search(m16, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=kv, max_before_nms=n_mom)
+        o = om.encode_context(vf if om.use_video else None, vm if om.use_video else None, sf if om.use_sub else None,
+                              sm if om.use_sub else None)
+        q2c, st, ed = om.get_pred_from_raw_query(qf, qm, o[0], o[1], vm if om.use_video else None, o[2], o[3],
+                                                 sm if om.use_sub else None, cross=True)
+        want = O.vcmr_tail(q2c, st, ed, 20.0, kv, 2, 16, n_mom + 8)
+        ww, wi = torch.topk(torch.exp(20.0 * q2c), min(kv + 6, nv), dim=1)
+    gi = out["top_indices"].cpu().numpy()
+    tie_aware_equal(gi, out["top_scores"].cpu().numpy(), wi.numpy(), ww.numpy(), kv, 2e-3, "fuzz %d f16s videos" % seed)
+    same = np.nonzero((gi == want["top_indices"].numpy()).all(1))[0]
+    assert len(same) >= nq - max(1, nq // 10)
+    gk = moment_keys(out["flat_indices"].cpu().numpy(), gi, index.l_ref)
+    wk = moment_keys(want["flat_indices"].numpy(), want["top_indices"].numpy(), index.l_ref)
+    n_pos = (out["flat_indices"].cpu().numpy()[same] >= 0).sum(1).min() if len(same) else 0
+    tie_aware_equal(gk[same], out["flat_scores"].cpu().numpy()[same], wk[same], want["flat_scores"].numpy()[same],
+                    int(min(n_mom, n_pos)), 1e-3, "fuzz %d f16s moments" % seed)

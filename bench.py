@@ -629,8 +629,13 @@ def run(args, backend_factory=None, emit=True):
             else:
                 q2c = timed("q2c_k6", lambda: inf.stage_q2c(index, qvec, ops))
                 tw, ti = timed("topk_k8", lambda: ops.topk_rows(q2c, min(100, index.n_videos), alpha=20.0))
-            st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti, ops))
-            timed("moment_k9", lambda: ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
+            if inf.K7_SUMMARIES:      # (what vcmr_search runs: K7 hands K9 its per-pair candidate summaries)
+                st, ed, sm = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti, ops, pair_w=tw,
+                                                                             band=(2, 16)))
+                timed("moment_k9", lambda: ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200, summ=sm))
+            else:
+                st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti, ops))
+                timed("moment_k9", lambda: ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
     else:       # rank 0's view of one sharded pass, collectives (and the waiting for slower ranks in them) included
         marks = []
 

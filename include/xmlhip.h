@@ -363,6 +363,19 @@ int xml_convse_rerank_f16s(const xml_convse_desc* d, const void* q_lin0, const v
                            const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
                            xml_stream_t stream);
 
+/* K7 + the start of K9: xml_convse_rerank (or _f16s, by desc.dt; the q_inv / c_inv pointers are read for XML_F16S only) that
+ * also emits, per pair, XML_MOMENT_SUMM banded row maxima  (st[i] * pair_w[p]) * max_{min_l <= d < max_l} ed[i + d]  -- the
+ * largest one of each group of 16 rows { i : i % 64 in [8 g, 8 g + 8) } -- while the pair's rows are still in registers:
+ * summ_out (nq, kpairs, XML_MOMENT_SUMM) f32.  xml_moment_topk_ex
+ * builds its selection threshold from those values instead of a first pass over the st / ed rows.  pair_w (nq, kpairs) f32 =
+ * the video weights exp(alpha * s) (NULL: 1); desc.softmax bit 0 must be set; rows of skipped pairs are not written. */
+#define XML_MOMENT_SUMM 8
+int xml_convse_rerank_ex(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const float* q_inv0,
+                         const float* q_inv1, const void* feat2_0, const void* feat2_1, const float* c_inv0,
+                         const float* c_inv1, const float* mask0, const float* mask1, const int32_t* pair_vid,
+                         const float* conv_w, const float* pair_w, int min_l, int max_l, float* st_out, float* ed_out,
+                         float* summ_out, void* ws, size_t ws_bytes, xml_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K9+K10: banded moment candidates + per-query top-n
  *   score(r,i,j) = (st[q,r,i] * w[q,r]) * ed[q,r,j]   for min_l <= j-i < max_l, j < l_ref
@@ -378,6 +391,11 @@ int xml_convse_rerank_f16s(const xml_convse_desc* d, const void* q_lin0, const v
 int xml_moment_topk(const float* st, const float* ed, const float* w, float* out_score,
                     int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l,
                     int n_out, xml_stream_t stream);
+/* summ != NULL: (nq, kpairs, XML_MOMENT_SUMM) f32 from xml_convse_rerank_ex (same pair_w, min_l, max_l, l_ref): the selection
+ * threshold comes from these instead of a pass over the rows; pairs of weight 0 are ignored.  Same lists, bit for bit. */
+int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ, float* out_score,
+                       int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
+                       xml_stream_t stream);
 
 /* Row-wise LayerNorm of (a [+ b]) -- exposed for the host-side mirror and tests.
  *   y = LN(a + b) * g + beta;  a,b,y (rows, d) dt (b may be NULL), x_dt of `a` may be XML_F32. */

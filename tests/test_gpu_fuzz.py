@@ -446,3 +446,57 @@ def test_fuzz_svmr_vs_oracle_fp32(seed):
         if npos > 2:
             tie_aware_equal(gf[q:q + 1, :npos], gs[q:q + 1, :npos], wf[None], ws[None], max(1, npos - 2), 2e-3,
                             "fuzz %d SVMR moments of query %d" % (seed, q))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_k7_candidate_summaries_feed_k9(ops, seed):
+    """xml_convse_rerank_ex emits, per pair, 8 banded row maxima (st * w) * max_d ed (one per group of 16 rows) -- checked against a torch
+    restatement on the probabilities the kernel itself returned -- and xml_moment_topk_ex started from them returns the SAME
+    lists, bit for bit, as the kernel that makes its own first pass: peaky and flat distributions, skipped pairs, weights
+    of 0, one pair per query (SVMR), every band / clip padding."""
+    rng = np.random.default_rng(31000 + seed)
+    n_mod = int(rng.integers(1, 3))
+    merged = bool(n_mod == 2 and rng.integers(0, 2))
+    lpad = int(rng.choice([16, 48, 64, 112, 128]))
+    l_ref = int(rng.integers(max(2, lpad - 15), lpad + 1))
+    hidden = int(rng.choice([64, 128, 256]))
+    nq, nv = int(rng.integers(1, 60)), int(rng.integers(1, 25))
+    kp = 1 if seed % 5 == 0 else int(rng.integers(1, 101))
+    min_l = int(rng.integers(0, 4))
+    max_l = min_l + int(rng.integers(1, 20))
+    n_out = int(rng.integers(1, 300))
+    dtype = torch.float32 if seed % 2 else torch.bfloat16
+    g = torch.Generator().manual_seed(500 + seed)
+    lens = torch.randint(1, l_ref + 1, (nv,), generator=g)
+    mask = (torch.arange(lpad)[None] < lens[:, None]).float()
+    sharp = float(rng.choice([0.05, 1.0, 6.0]))              # flat ... peaky start / end distributions
+    q_lin = [(torch.randn(nq, hidden, generator=g) * sharp).to(dtype) for _ in range(n_mod)]
+    feat2 = [(torch.randn(nv, lpad, hidden, generator=g) * mask[..., None]).to(dtype) for _ in range(n_mod)]
+    conv_w = torch.randn(2 * (1 if merged else n_mod) * 5, generator=g) * 0.5
+    pair = torch.randint(-1 if seed % 3 == 0 else 0, nv, (nq, kp), generator=g).int()
+    w = None
+    if kp > 1:
+        w = torch.exp(20.0 * (0.1 + 0.02 * torch.rand(nq, kp, generator=g))).sort(1, descending=True)[0].contiguous()
+        w = torch.where(pair >= 0, w, torch.zeros_like(w))   # skipped pairs carry weight 0 (the sharded pass)
+    dev = lambda ts: [t.to(DEV) for t in ts]                 # noqa: E731
+    masks = [mask.to(DEV)] * n_mod
+    wd = None if w is None else w.to(DEV)
+    st, ed, summ = ops.convse_rerank(dev(q_lin), dev(feat2), masks, pair.to(DEV), conv_w.to(DEV), l_ref, merged, 5,
+                                     pair_w=wd, band=(min_l, max_l))
+    st0, ed0 = ops.convse_rerank(dev(q_lin), dev(feat2), masks, pair.to(DEV), conv_w.to(DEV), l_ref, merged, 5)
+    assert torch.equal(st, st0) and torch.equal(ed, ed0)     # the summaries change nothing else
+    # restatement: m[i] = (st[i] * w) * max_{min_l <= d < max_l, i + d < l_ref} ed[i + d]; top 8 per pair, descending
+    s_, e_ = st.cpu()[..., :l_ref], ed.cpu()[..., :l_ref]
+    a = s_ * (w[..., None] if w is not None else 1.0)
+    best = torch.zeros_like(a)
+    for d_ in range(min_l, max_l):
+        if d_ < l_ref:
+            best[..., :l_ref - d_] = torch.maximum(best[..., :l_ref - d_], e_[..., d_:])
+    m = (a * best).clamp_min(0)
+    mp = torch.cat([m, torch.zeros(nq, kp, 128 - l_ref)], -1)
+    want = torch.maximum(mp[..., :64], mp[..., 64:]).view(nq, kp, 8, 8).amax(-1)      # group g: rows 8 g .. + 7 and + 64
+    live = (pair >= 0)
+    assert torch.equal(summ.cpu()[live], want[live]), float((summ.cpu()[live] - want[live]).abs().max())
+    a1 = ops.moment_topk(st, ed, wd, l_ref, min_l, max_l, n_out, summ=summ)
+    a0 = ops.moment_topk(st, ed, wd, l_ref, min_l, max_l, n_out)
+    assert torch.equal(a1[0], a0[0]) and torch.equal(a1[1], a0[1]), seed

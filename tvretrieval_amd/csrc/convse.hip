@@ -10,6 +10,7 @@
 //   bytes ~= Nv*L*H*b*modalities (+ L2-resident query vectors) instead of Nq*k*L*H*b*modalities.
 // Epilogue per pair row, in LDS: k-tap zero-padded cross-correlation x2 (start / end filters), mask_logits,
 // softmax over clips.
+#include "band.h"
 #include "gemm.h"
 
 static constexpr int TM = 64;            // pairs per workgroup chunk (a video has ~46 pairs at C3: one chunk each)
@@ -137,6 +138,12 @@ struct ConvseArgs {
   // per modality -- powers of two, so moving an accumulator from one modality's units to the other's is exact
   const float* q_inv[2];
   const float* c_inv[2];
+  // candidate summaries for K9 (xml_convse_rerank_ex): summ[p][g] = the largest banded row maximum
+  // (st[i] * pair_w[p]) * max_{min_l <= d < max_l} ed[i + d] over the rows i of group g (i % 64 in [8 g, 8 g + 8)) of pair p,
+  // taken while its rows are in this wave's registers
+  const float* pair_w;
+  float* summ;
+  int min_l, max_l;
 };
 
 template <typename T>
@@ -321,6 +328,24 @@ __global__ __launch_bounds__(256, 3) void convse_kernel(ConvseArgs a) {      // 
         a.ed_out[(int64_t)p * a.lpad + l] = in ? ed[h] : 0.f;
       }
     }
+    if (a.summ) {
+      // K9's row maxima, from the very values just stored (same two f32 multiplies, so the same bits K9 would compute):
+      // a = st * w, m = a * (window maximum of ed); then the 8 largest of the pair's 128, one wave maximum each
+      const float wv = a.pair_w ? a.pair_w[p] : 1.f;
+      const bool in0 = lane < a.l_ref, in1 = lane + 64 < a.l_ref;
+      float e_lo = in0 ? ed[0] : 0.f, e_hi = in1 ? ed[1] : 0.f;
+      band_window_max(e_lo, e_hi, a.max_l - a.min_l, a.min_l, lane);
+      const float m_lo = fmaxf((in0 ? st[0] : 0.f) * wv * e_lo, 0.f), m_hi = fmaxf((in1 ? st[1] : 0.f) * wv * e_hi, 0.f);
+      // ... and 8 of them, one per group of 16 rows (lanes 8 g .. 8 g + 7 hold rows 8 g .. + 7 and 64 + 8 g .. + 7): the
+      // group maxima, three DPP steps.  (The 8 LARGEST of the pair -- eight sequential wave maxima -- cost K7 0.45-0.75 ms
+      // per pass and bought K9 0.2: measured, profiles/r04_notes.md.)  Disjoint groups = distinct rows, which is all
+      // K9's bound needs.
+      float mg = fmaxf(m_lo, m_hi);
+      mg = fmaxf(mg, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mg), 0xB1, 0xf, 0xf, false)));    // quad_perm [1,0,3,2]
+      mg = fmaxf(mg, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mg), 0x4E, 0xf, 0xf, false)));    // quad_perm [2,3,0,1]
+      mg = fmaxf(mg, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mg), 0x141, 0xf, 0xf, false)));   // row_half_mirror
+      if ((lane & 7) == 0) a.summ[(int64_t)p * XML_MOMENT_SUMM + (lane >> 3)] = mg;
+    }
   }
 }
 
@@ -431,11 +456,43 @@ __global__ void convse_zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
   if (i < n) p[i] = 0u;
 }
 
+struct ConvseSumm {          // optional candidate summaries (xml_convse_rerank_ex)
+  const float* pair_w;
+  float* summ;
+  int min_l, max_l;
+};
 static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const void* feat2_0,
                               const void* feat2_1, const float* mask0, const float* mask1, const int32_t* pair_vid,
                               const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
                               const float* q_inv0, const float* q_inv1, const float* c_inv0, const float* c_inv1,
-                              xml_stream_t stream);
+                              xml_stream_t stream, ConvseSumm sm = ConvseSumm{nullptr, nullptr, 0, 0});
+
+// xml_convse_rerank / xml_convse_rerank_f16s (by desc.dt) + the candidate summaries K9 starts from
+extern "C" int xml_convse_rerank_ex(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const float* q_inv0,
+                                    const float* q_inv1, const void* feat2_0, const void* feat2_1, const float* c_inv0,
+                                    const float* c_inv1, const float* mask0, const float* mask1, const int32_t* pair_vid,
+                                    const float* conv_w, const float* pair_w, int min_l, int max_l, float* st_out,
+                                    float* ed_out, float* summ_out, void* ws, size_t ws_bytes, xml_stream_t stream) {
+  XML_ENTER();
+  if (!d || !q_lin0 || !feat2_0 || !mask0 || !pair_vid || !conv_w || !st_out || !ed_out || !ws || !summ_out) return XML_ERR_BAD_ARG;
+  if (d->nq <= 0 || d->nv <= 0 || d->kpairs <= 0 || d->hidden <= 0) return XML_ERR_BAD_ARG;
+  if (d->n_mod < 1 || d->n_mod > 2 || (d->n_mod == 2 && (!q_lin1 || !feat2_1))) return XML_ERR_BAD_ARG;
+  if (d->n_mod == 2 && !d->merged && !mask1) return XML_ERR_BAD_ARG;
+  if (d->merged && d->n_mod != 2) return XML_ERR_BAD_ARG;
+  if (d->lpad % 16 || d->lpad > 128 || d->l_ref > d->lpad || d->l_ref <= 0 || d->hidden % 8) return XML_ERR_UNSUPPORTED;
+  if (!(d->ksize & 1) || d->ksize > 15 || d->ksize < 1) return XML_ERR_UNSUPPORTED;
+  if (min_l < 0 || max_l <= min_l || !(d->softmax & 1)) return XML_ERR_BAD_ARG;       // summaries are of PROBABILITIES
+  if (d->dt == XML_F16S) {
+    if (!q_inv0 || !c_inv0 || (d->n_mod == 2 && (!q_inv1 || !c_inv1))) return XML_ERR_BAD_ARG;
+    if (d->hidden % 32) return XML_ERR_UNSUPPORTED;
+  } else if (d->dt != XML_F32 && d->dt != XML_BF16) {
+    return XML_ERR_BAD_ARG;
+  }
+  return convse_rerank_impl(d, q_lin0, q_lin1, feat2_0, feat2_1, mask0, mask1, pair_vid, conv_w, st_out, ed_out, ws, ws_bytes,
+                            d->dt == XML_F16S ? q_inv0 : nullptr, d->dt == XML_F16S ? q_inv1 : nullptr,
+                            d->dt == XML_F16S ? c_inv0 : nullptr, d->dt == XML_F16S ? c_inv1 : nullptr, stream,
+                            ConvseSumm{pair_w, summ_out, min_l, max_l});
+}
 
 extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1,
                                  const void* feat2_0, const void* feat2_1, const float* mask0, const float* mask1,
@@ -477,7 +534,7 @@ static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, cons
                               const void* feat2_1, const float* mask0, const float* mask1, const int32_t* pair_vid,
                               const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
                               const float* q_inv0, const float* q_inv1, const float* c_inv0, const float* c_inv1,
-                              xml_stream_t stream) {
+                              xml_stream_t stream, ConvseSumm sm) {
   if (ws_bytes < xml_convse_rerank_workspace_bytes(d)) return XML_ERR_WORKSPACE;
   hipStream_t st = (hipStream_t)stream;
   ConvseWs w;
@@ -512,6 +569,7 @@ static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, cons
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
   a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax & 1;
   a.dbg = g_q2c_ablation;       // constant 0 in the product build (debug.h)
+  a.pair_w = sm.pair_w; a.summ = sm.summ; a.min_l = sm.min_l; a.max_l = sm.max_l;
   a.q_inv[0] = q_inv0; a.q_inv[1] = q_inv1 ? q_inv1 : q_inv0;
   a.c_inv[0] = c_inv0; a.c_inv[1] = c_inv1 ? c_inv1 : c_inv0;
   {

@@ -22,7 +22,7 @@
 //   5. bitonic sort of the list on (score desc, flat index asc); emit n_out.
 // Zero products (masked clips, skipped pairs) are not candidates: the reference's order among zeros is unspecified.
 // This is LDS/latency-bound integer-ish work; it is not reshaped into a GEMM.
-#include "common.h"
+#include "band.h"
 
 static constexpr int MT_CAP = 2048;   // LDS candidate list capacity
 static constexpr int MT_PPW = 32;     // pairs per wave -> kpairs <= 128 (pair weights live in two lane registers)
@@ -101,7 +101,8 @@ __device__ uint32_t block_radix_select(Each each, uint32_t need, uint32_t* hist 
 __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restrict__ st, const float* __restrict__ ed,
                                                           const float* __restrict__ w, float* __restrict__ out_score,
                                                           int32_t* __restrict__ out_flat, int kpairs, int lpad,
-                                                          int l_ref, int min_l, int max_l, int n_out) {
+                                                          int l_ref, int min_l, int max_l, int n_out,
+                                                          const float* __restrict__ summ) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
@@ -130,15 +131,6 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   if (tid == 0) { sh.prefix = 0; sh.flag = 0; }
   __syncthreads();
 
-  // x[c + s] for a 128-long sequence held as (lo: clip lane, hi: clip lane + 64); zero beyond the end
-  auto shifted = [&](float lo, float hi, int s, float& olo, float& ohi) {
-    const int s1 = s & 63;
-    const int srcl = (lane + s1) & 63;
-    const bool wrap = lane + s1 >= 64;
-    const float from_lo = __shfl(lo, srcl, 64), from_hi = __shfl(hi, srcl, 64);
-    if (s < 64) { olo = wrap ? from_hi : from_lo; ohi = wrap ? 0.f : from_hi; }
-    else { olo = wrap ? 0.f : from_hi; ohi = 0.f; }
-  };
   // raw (st_lo, st_hi, ed_lo, ed_hi) of pair r for this lane's two start clips
   auto pair_load = [&](int r, float (&raw)[4]) {
     const float* sp = gst + r * lpad;
@@ -154,19 +146,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     a_lo = raw[0] * wv;
     a_hi = raw[1] * wv;
     float lo = raw[2], hi = raw[3];
-    int p = 1;
-    while (2 * p <= band) {                                // window width p -> 2 p
-      float slo, shi;
-      shifted(lo, hi, p, slo, shi);
-      lo = fmaxf(lo, slo); hi = fmaxf(hi, shi);
-      p <<= 1;
-    }
-    if (p < band) {                                        // two overlapping windows of width p cover width band
-      float slo, shi;
-      shifted(lo, hi, band - p, slo, shi);
-      lo = fmaxf(lo, slo); hi = fmaxf(hi, shi);
-    }
-    if (min_l > 0) shifted(lo, hi, min_l, lo, hi);
+    band_window_max(lo, hi, band, min_l, lane);            // band.h (shared with K7's candidate summaries)
     m_lo = fmaxf(a_lo * lo, 0.f);
     m_hi = fmaxf(a_hi * hi, 0.f);
   };
@@ -199,6 +179,20 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
 
   // ---- 2+3. ONE histogram pass over the row maxima on bits [30:20] (8 exponent + 3 mantissa bits); the lower edge
   //           of the bin holding the n_out-th largest row maximum is a lower bound of the n_out-th best score ------
+  if (summ) {
+    // K7 already took the XML_MOMENT_SUMM largest row maxima of every pair while the pair's rows were in its registers
+    // (xml_convse_rerank_ex): the histogram is built from those kpairs x 8 values instead of a pass over the st / ed rows
+    // (1 GB at the TVR shape).  Every value is the best candidate of a DISTINCT row, so the lower edge of the bin that holds
+    // the n_out-th largest of them is still a valid lower bound of the n_out-th best score -- a weaker one than the bound
+    // from all rows when one pair owns more than 8 of the best rows, which costs list refinements below, never exactness.
+    const float* gs = summ + (int64_t)q * kpairs * XML_MOMENT_SUMM;
+    for (int i = tid; i < kpairs * XML_MOMENT_SUMM; i += 256) {
+      const int r = i / XML_MOMENT_SUMM;
+      const bool on = gw ? gw[r] != 0.f : true;            // skipped pairs (weight 0) have no summary
+      const uint32_t key = on ? __float_as_uint(gs[i]) : 0u;
+      if (key != 0u && !(key & 0x80000000u)) atomicAdd(&s_hist[key >> 20], 1u);
+    }
+  } else {
   for_pairs([&](int r, const float (&a2)[2], const float (&m2)[2]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -216,6 +210,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
       }
     }
   });
+  }
   __syncthreads();
   if (tid < 64) {                                          // wave 0: suffix scan, 32 bins per lane
     uint32_t local = 0;
@@ -388,6 +383,12 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
 extern "C" int xml_moment_topk(const float* st, const float* ed, const float* w, float* out_score, int32_t* out_flat,
                                int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
                                xml_stream_t stream) {
+  return xml_moment_topk_ex(st, ed, w, nullptr, out_score, out_flat, nq, kpairs, lpad, l_ref, min_l, max_l, n_out, stream);
+}
+
+extern "C" int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ, float* out_score,
+                                  int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
+                                  xml_stream_t stream) {
   XML_ENTER();
   if (!st || !ed || !out_score || !out_flat || nq <= 0 || kpairs <= 0 || lpad <= 0 || l_ref <= 0 || n_out <= 0)
     return XML_ERR_BAD_ARG;
@@ -395,7 +396,7 @@ extern "C" int xml_moment_topk(const float* st, const float* ed, const float* w,
   if (n_out > 1024 || lpad > 128 || kpairs > 4 * MT_PPW) return XML_ERR_UNSUPPORTED;   // (st, ed: probabilities, >= 0)
   const size_t lds = (size_t)MT_CAP * 8 + 2048 * 4;
   hipLaunchKernelGGL(moment_topk_kernel, dim3(nq), dim3(256), lds, (hipStream_t)stream, st, ed, w, out_score, out_flat,
-                     kpairs, lpad, l_ref, min_l, max_l, n_out);
+                     kpairs, lpad, l_ref, min_l, max_l, n_out, summ);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -372,6 +372,11 @@ def stage_query_vectors(model, query_feat, query_mask):
     return out
 
 
+import os as _os
+# Measured in round 4 (profiles/r04_notes.md) and NOT the default: handing K9 its selection threshold from K7 takes K9 from
+# 0.65 to 0.45-0.53 ms at the TVR shape, but the extra epilogue work costs K7 as much or more (+0.2 ms with one maximum per
+# group of 16 rows, +0.45 ms with the 8 largest rows of a pair), and at the as-trained shape the weaker bound makes K9 slower.
+K7_SUMMARIES = _os.environ.get("XML_K7_SUMMARIES", "0") == "1"   # vcmr_search: K7 emits per-pair candidate summaries for K9 (False: K9 makes its own first pass; A/B)
 K6_TIMER = None   # bench.py: callable returning (start, end) torch.cuda.Event pair recorded around each K6 launch
 
 
@@ -551,7 +556,8 @@ def stage_exact_topk_f32(index, qvec, k, alpha, ops=hip_ops):
     return top_w, top_i, info
 
 
-def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=True, replicated=False):
+def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=True, replicated=False, pair_w=None,
+                     band=None):
     """K7 on the listed (query, local video) pairs -> softmaxed st / ed (Nq, K, lpad).
     replicated=True: pair_vid holds GLOBAL video ids into the corpus-wide copies index.feat2_all / index.mask_all
     (tvretrieval_amd.dist.replicate_rerank_features)."""
@@ -561,9 +567,11 @@ def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=Tru
     feat2, mask = (index.feat2_all, index.mask_all) if replicated else (index.feat2, index.mask)
     if getattr(feat2[mods[0]], "dtype", None) is getattr(ops, "F16S", object()):
         q_lin = [ops.split_f16_rows(q.float().contiguous()) for q in q_lin]      # per-row scales: q' is not normalised
+    # band = (min_l, max_l) [+ pair_w]: K7 also returns the per-pair candidate summaries K9 starts from (st, ed, summ)
+    kw = dict(pair_w=pair_w, band=band) if (band is not None and hasattr(ops, "MOMENT_SUMM")) else {}
     return ops.convse_rerank(q_lin, [feat2[m] for m in mods], [mask[m] for m in mods], pair_vid,
                              model._conv_weights(), index.l_ref, merged, model.config.conv_kernel_size, softmax=True,
-                             zero_skipped=zero_skipped)
+                             zero_skipped=zero_skipped, **kw)
 
 
 def pad_moment_tail(flat_scores, flat_indices, k_videos, l_ref, min_pred_l=None, max_pred_l=None):
@@ -631,8 +639,14 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
     else:   # external video-retrieval results replace K6/K8 (xml/inference.py:349-355): (meta idx int32, exp(alpha*s))
         q2c = None
         top_i, top_w = external_top
-    st, ed = stage_span_probs(model, index, qvec, top_i, ops)
-    fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
+    if hasattr(ops, "MOMENT_SUMM") and K7_SUMMARIES:
+        # K7 hands K9 the 8 largest row maxima of every pair (taken while the rows were in its registers): K9 reads the
+        # 1 GB of span probabilities once instead of twice
+        st, ed, summ = stage_span_probs(model, index, qvec, top_i, ops, pair_w=top_w.contiguous(), band=(min_pred_l, max_pred_l))
+        fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms, summ=summ)
+    else:
+        st, ed = stage_span_probs(model, index, qvec, top_i, ops)
+        fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
     if pad_tail:
         pad_moment_tail(fs, fi, top_i.shape[1], index.l_ref, min_pred_l, max_pred_l)
     out = dict(q2c=q2c, top_scores=top_w, top_indices=top_i, flat_scores=fs, flat_indices=fi)

@@ -390,7 +390,7 @@ def run(args, backend_factory=None, emit=True):
     # region is what made this figure swing 32 K .. 151 K videos/s from box to box); alloc_s is reported next to it
     be.sync()
     t0 = time.perf_counter()
-    storage = inf.IndexStorage(model, hi - lo, l, ops=ops, device=device) if be.name == "hip" else None
+    storage = inf.IndexStorage(model, hi - lo, l, ops=ops, device=device, tiles=not exact) if be.name == "hip" else None
     be.sync()
     alloc_s = time.perf_counter() - t0
     enc_ev = (be.event(), be.event())

@@ -151,7 +151,8 @@ class IndexStorage(object):
     (bench.py times the two separately).  f1 / f2 / mk: per-modality (n_videos, lpad, H) compute dtype x2 and (n_videos,
     lpad) f32; tiles: per-modality flat buffer of the K6 tile image (full-length corpora: the size is known up front)."""
 
-    def __init__(self, model, n_videos, l_ref, ops=hip_ops, device=None):
+    def __init__(self, model, n_videos, l_ref, ops=hip_ops, device=None, tiles=True):
+        # tiles=False: an exact-rank index builds its filter image itself (from the normalised f32 rows)
         mods = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
         dev = device if device is not None else next(model.parameters()).device
         dt, h = getattr(model, "act_dtype", model.compute_dtype), model.config.hidden_size
@@ -160,7 +161,7 @@ class IndexStorage(object):
         self.f2 = {m: torch.zeros((self.n_videos, self.lpad, h), dtype=dt, device=dev) for m in mods}
         self.mk = {m: torch.zeros((self.n_videos, self.lpad), dtype=torch.float32, device=dev) for m in mods}
         self.tiles = {}
-        if hasattr(ops, "q2c_tiled_numel") and self.lpad == 128 and dt in (torch.float32, torch.bfloat16):
+        if tiles and hasattr(ops, "q2c_tiled_numel") and self.lpad == 128 and dt in (torch.float32, torch.bfloat16):
             n = ops.q2c_tiled_numel(self.n_videos * self.lpad, h, dt)
             if n:
                 self.tiles = {m: torch.zeros(n, dtype=dt, device=dev) for m in mods}

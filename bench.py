@@ -267,14 +267,14 @@ def run_extras(args, headline_qps):
         r = bench_exact.run(nq, nv, "reset", 0, steps=max(2, args.steps), warmup=2, mode="f16s")
         c = r["certificate"]
         return {"value": r["queries_per_s"], "unit": "queries/s", "ms_per_step": r["ms_per_pass"],
-                "dtype": "f32-grade lists: f16 filter + split-f16 scores",
+                "dtype": "f32-grade lists: %s filter + split-f16 scores" % r.get("filter", "bf16"),
                 "steps": r["steps_timed"], "vs_bf16_headline": r["queries_per_s"] / headline_qps,
                 "candidates_per_query": r["candidates"], "fell_back_rate": c["fail_rate"], "eps_mean": c["eps_mean"],
                 "filter_abs_err_max": c["filter_abs_err_max"], "margin_T100_minus_bM_p50": c["margin_T100_minus_bM"]["p50"],
                 "stage_ms": r["stage_ms"], "corpus_hbm_gb": r["hbm_gb"], "encode_index_s": r["encode_index_s"],
                 "second_tier_overflowed_passes": c["second_tier_overflowed_in_timed_passes"],
-                "what": "c3 with the f32 path's lists: ops.F16S model (every projection a split-f16 product), f16 K6 as a "
-                        "filter (top-128), split-f16 re-score, per-query certificate with an on-device second tier, split-f16 "
+                "what": "c3 with the f32 path's lists: ops.F16S model (every projection a split-f16 product), bf16 K6 as a "
+                        "filter (top-256), split-f16 re-score, per-query certificate with an on-device second tier, split-f16 "
                         "ConvSE; no host read-back in the pass (tests/test_gpu_split16.py, tests/test_gpu_fullsize.py)"}
 
     def sub(workload, steps, warmup):
@@ -368,7 +368,8 @@ def run(args, backend_factory=None, emit=True):
     if exact:        # exact-rank mode (inference.stage_exact_topk_f16s): ops.F16S model -- f32 activations, every projection,
         # the candidate re-score and ConvSE as split-f16 products on the 16-bit MFMA pipe --, f16 K6 as the filter
         assert dtname == "bf16", "--exact-rank applies to the bf16 workloads"
-        dtype, dtname = ops.F16S, "f16 filter + split-f16 (f32-grade) scores"
+        from tvretrieval_amd import inference as _inf
+        dtype, dtname = ops.F16S, "%s filter + split-f16 (f32-grade) scores" % _inf.EXACT_F16S_FILTER
     xkw = dict(exact_filter=True) if exact else {}
     cfg = model_config(hidden, dv, ds, dq, ctx_mode, l)
     torch.manual_seed(0)

@@ -515,6 +515,21 @@ int xml_rank_loss(const float* scores, const int* ranks_ctx, const int* ranks_q,
  * 0 <= p < 1; y == x allowed.  Not torch's Philox stream: statistically, not bitwise, equal to the reference. */
 int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, int dt,
                 xml_stream_t stream);
+/* Training LayerNorm with its neighbouring dropout sites applied in place (xml/model_components.py:201-210 BertSelfOutput
+ * dense -> dropout -> LayerNorm(+ residual); :103-114 LinearLayer LayerNorm -> dropout -> Linear; :139-156
+ * TrainablePositionalEncoding LayerNorm -> dropout):
+ *     y = drop_out( LN( drop_in(a) + b ) * g + beta )
+ * with xml_dropout's masks (element i of `a` / of `y`, seeds seed_in / seed_out [+ *seed_dev]); p_in / p_out = 0 switch a
+ * site off.  a (a_dt f32 or dt), b (dt or NULL), y (dt) are (rows, d) contiguous, d % 8 == 0, d <= 4096; dt f32 or bf16.
+ * xml_layernorm_bwd_drop is its backward pass: dy is masked with the output site, dx = gradient of b (and of a when
+ * p_in == 0), dxa = gradient of a when p_in > 0 (required then, ignored otherwise); dg / dbeta f32 are accumulated into.
+ * d <= 1024: all of it.  1024 < d <= 4096: parameter gradients only (b, dx, dxa NULL, p_in == 0, dt bf16). */
+int xml_add_layernorm_drop(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
+                           int64_t rows, int d, int dt, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out,
+                           const uint64_t* seed_dev, xml_stream_t stream);
+int xml_layernorm_bwd_drop(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx, void* dxa,
+                           float* dg, float* dbeta, int64_t rows, int d, int dt, float p_in, uint64_t seed_in, float p_out,
+                           uint64_t seed_out, const uint64_t* seed_dev, xml_stream_t stream);
 /* torch.nn.utils.clip_grad_norm_ over all gradients (xml/train.py:88-90, `--grad_clip`, off by default): g (n) f32 is
  * the flat gradient buffer; scaled in place by max_norm / (||g||_2 + 1e-6) when that is < 1.  ws: 4 bytes of scratch. */
 int xml_clip_grad_norm(float* g, int64_t n, float max_norm, float* ws, xml_stream_t stream);

@@ -640,6 +640,98 @@ def test_train_mode_step_with_dropout_runs():
     assert all(torch.isfinite(p.grad).all() for p in m.parameters() if p.grad is not None)
 
 
+@pytest.mark.parametrize("rows,d,resid,p_in,p_out,dt", [
+    (50, 128, True, 0.1, 0.0, F32), (33, 768, False, 0.0, 0.2, F32), (700, 384, True, 0.1, 0.1, F32),
+    (9, 200, True, 0.3, 0.1, F32), (1300, 384, True, 0.1, 0.0, torch.bfloat16), (257, 768, False, 0.0, 0.1, torch.bfloat16),
+    (5000, 384, True, 0.1, 0.1, torch.bfloat16)])
+def test_layernorm_with_dropout_sites_vs_masked_reference(rows, d, resid, p_in, p_out, dt):
+    """LayerNormFn with the dropout sites in front of `a` / behind the LayerNorm applied in its kernels
+    (xml_add_layernorm_drop / xml_layernorm_bwd_drop) == float64 LayerNorm with xml_dropout's masks for the same seeds
+    injected; f32: 5e-5 of the largest value, bf16 storage: 1.2e-2 (one bf16 rounding of y / of the gradients)."""
+    from tvretrieval_amd import train_ops as TO
+    from tvretrieval_amd.autograd import LayerNormFn
+    si, so = 1234567, 7654321
+    a = rnd(rows, d, seed=1).to(dt)
+    b = rnd(rows, d, seed=2).to(dt) if resid else None
+    g, beta = 1 + rnd(d, seed=3, scale=0.2), rnd(d, seed=4, scale=0.2)
+    dy = rnd(rows, d, seed=5).to(dt)
+    ones = torch.ones(rows, d, device=DEV)
+    m_in = TO.dropout(ones, p_in, si).double() if p_in else ones.double()
+    m_out = TO.dropout(ones, p_out, so).double() if p_out else ones.double()
+    assert TO.layernorm_drop_supported(d, dt, True, resid, p_in)
+    la = a.clone().requires_grad_(True)
+    lb = b.clone().requires_grad_(True) if resid else None
+    lg, lbeta = g.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y = LayerNormFn.apply(la, lb, lg, lbeta, dt, (p_in, si) if p_in else None, (p_out, so) if p_out else None)
+    y.backward(dy)
+    ra = a.double().requires_grad_(True)
+    rb = b.double().requires_grad_(True) if resid else None
+    rg, rbeta = g.double().requires_grad_(True), beta.double().requires_grad_(True)
+    x = ra * m_in + (rb if resid else 0)
+    ry = F.layer_norm(x, (d,), rg, rbeta, 1e-5) * m_out
+    ry.backward(dy.double())
+    tol = 5e-5 if dt == F32 else 1.2e-2
+    check("y", y, ry, tol)
+    assert torch.equal(y == 0, (ry == 0) | (y == 0)) and int((y == 0).sum()) >= int((m_out == 0).sum())
+    check("da", la.grad, ra.grad, tol)
+    assert torch.equal(la.grad[m_in == 0], torch.zeros_like(la.grad[m_in == 0]))
+    if resid:
+        check("db", lb.grad, rb.grad, tol)
+    check("dgamma", lg.grad, rg.grad, 5e-5 if dt == F32 else 6e-3)
+    check("dbeta", lbeta.grad, rbeta.grad, 5e-5 if dt == F32 else 6e-3)
+
+
+@pytest.mark.parametrize("rows,d,a_dt", [(5000, 3072, F32), (37, 3072, torch.bfloat16), (301, 2056, F32)])
+def test_wide_layernorm_output_dropout_parameters_only(rows, d, a_dt):
+    """3072-d input LayerNorm followed by the LinearLayer dropout (xml/model_components.py:103-114) in one launch each
+    way: forward == dropout(LN) with the injected mask, dgamma / dbeta == the float64 sums over the masked dy."""
+    from tvretrieval_amd import train_ops as TO
+    p, seed = 0.1, 424242
+    a = (rnd(rows, d, seed=1) * 2 + 0.3).to(a_dt)
+    dy = rnd(rows, d, seed=2).to(torch.bfloat16)
+    g, beta = 1 + rnd(d, seed=3, scale=0.2), rnd(d, seed=4, scale=0.2)
+    assert TO.layernorm_drop_supported(d, torch.bfloat16, False, False, 0.0)
+    assert not TO.layernorm_drop_supported(d, torch.bfloat16, True, False, 0.0)
+    mask = TO.dropout(torch.ones(rows, d, device=DEV), p, seed).double()
+    y = TO.add_layernorm_drop(a, None, g, beta, torch.bfloat16, 0.0, 0, p, seed)
+    x = a.double()
+    xh = (x - x.mean(-1, keepdim=True)) / torch.sqrt(x.var(-1, unbiased=False, keepdim=True) + 1e-5)
+    check("y", y, (xh * g.double() + beta.double()) * mask, 1e-2)
+    dx, dxa, dg, db = TO.layernorm_bwd_drop(a, None, g, dy, 0.0, 0, p, seed, need_dx=False)
+    assert dx is None and dxa is None
+    check("dgamma", dg, (dy.double() * mask * xh).sum(0), 2e-5)
+    check("dbeta", db, (dy.double() * mask).sum(0), 2e-5)
+
+
+def test_train_step_fused_dropout_sites_equal_separate_launches():
+    """train.FUSE_DROPOUT on / off under the same torch seed: the same masks at every site (the seeds are drawn in the same
+    order), so the fp32 loss and gradients agree to summation-order noise."""
+    import tvretrieval_amd.train as TR
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    m = build_train_model(cfg, d).train()
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]), neg_ctx_rank=d["neg_ctx_rank"], neg_q_rank=d["neg_q_rank"])
+    res = []
+    try:
+        for fuse in (True, False):
+            TR.FUSE_DROPOUT = fuse
+            m.zero_grad()
+            torch.manual_seed(11)
+            loss, _ = TR.xml_forward_train(m, **batch)
+            loss.backward()
+            res.append((float(loss), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        TR.FUSE_DROPOUT = True
+    assert abs(res[0][0] - res[1][0]) < 2e-6 * max(1.0, abs(res[1][0])), (res[0][0], res[1][0])
+    assert abs(res[0][0] - float(d["loss"])) > 1e-6            # (dropout really on)
+    assert res[0][1].keys() == res[1][1].keys()
+    for n, g0 in res[0][1].items():
+        if n.endswith(".key.bias"):        # softmax is invariant to the key bias: its gradient is rounding noise around 0
+            continue
+        check(n, g0, res[1][1][n], 2e-4)
+
+
 def test_global_grad_clip():
     from tvretrieval_amd import train_ops as TO
     for scale, n in ((5.0, 100003), (1e-4, 4096)):          # clipped / left alone

@@ -147,8 +147,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--graph", action="store_true", help="replay the whole step as one HIP graph (one GPU)")
+    ap.add_argument("--separate-dropout", action="store_true", help="A/B: dropout sites as their own launches (train.FUSE_DROPOUT = False)")
     a = ap.parse_args()
     from tvretrieval_amd import launch
+    if a.separate_dropout:
+        import tvretrieval_amd.train as TR
+        TR.FUSE_DROPOUT = False
     if a.gpus > 1 and not launch.under_launcher():
         rc = launch.spawn_local_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus)
         sys.exit(rc)

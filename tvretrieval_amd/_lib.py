@@ -165,6 +165,11 @@ SIGNATURES = {
     "xml_rank_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_int, c_int, c_void_p, c_void_p, c_void_p,
                               c_void_p]),
     "xml_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p, c_int, c_void_p]),
+    "xml_add_layernorm_drop": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
+                                       c_float, ctypes.c_uint64, c_float, ctypes.c_uint64, c_void_p, c_void_p]),
+    "xml_layernorm_bwd_drop": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                       c_void_p, c_int64, c_int, c_int, c_float, ctypes.c_uint64, c_float,
+                                       ctypes.c_uint64, c_void_p, c_void_p]),
     "xml_clip_grad_norm": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "xml_bert_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                    c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),

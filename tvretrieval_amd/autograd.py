@@ -189,11 +189,19 @@ class LayerNormFn(torch.autograd.Function):
     """y = LN(a [+ b]) * g + beta; a may be raw f32 features (no gradient), b optional residual."""
 
     @staticmethod
-    def forward(ctx, a, b, g, beta, out_dtype):
+    def forward(ctx, a, b, g, beta, out_dtype, drop_in=None, drop_out=None):
+        """drop_in / drop_out: (p, seed) of the dropout site in front of `a` / behind the LayerNorm, applied inside the
+        LayerNorm kernels (xml_add_layernorm_drop) -- the caller checks train_ops.layernorm_drop_supported first."""
         gf, bf = g.detach().float().contiguous(), beta.detach().float().contiguous()
         a = a.contiguous()
         b = None if b is None else b.contiguous()
-        y = ops.add_layernorm(a, b, gf, bf, out_dtype=out_dtype)
+        drop_in = drop_in if drop_in and drop_in[0] > 0 else None
+        drop_out = drop_out if drop_out and drop_out[0] > 0 else None
+        ctx.drop = (drop_in or (0.0, 0)) + (drop_out or (0.0, 0)) if (drop_in or drop_out) else None
+        if ctx.drop:
+            y = T.add_layernorm_drop(a, b, gf, bf, out_dtype, *ctx.drop)
+        else:
+            y = ops.add_layernorm(a, b, gf, bf, out_dtype=out_dtype)
         ctx.params = (g, beta)
         ctx.sunk = _claim(ctx, (g, beta), (2, 3), ctx.needs_input_grad[2] and ctx.needs_input_grad[3])
         ctx.save_for_backward(a, b, gf)
@@ -206,16 +214,22 @@ class LayerNormFn(torch.autograd.Function):
         pg, pbeta = ctx.params
         sg, sb = (_sink(pg), _sink(pbeta)) if ctx.sunk else (None, None)
         sunk = sg is not None and sb is not None
-        dx, dg, dbeta = T.layernorm_bwd(a, b, g, dy.contiguous(), need_dx=need_dx, dg=sg.view(-1) if sunk else None,
-                                        dbeta=sb.view(-1) if sunk else None)
+        dxa = None
+        if ctx.drop:
+            dx, dxa, dg, dbeta = T.layernorm_bwd_drop(a, b, g, dy.contiguous(), *ctx.drop, need_dx=need_dx,
+                                                      dg=sg.view(-1) if sunk else None, dbeta=sb.view(-1) if sunk else None)
+        else:
+            dx, dg, dbeta = T.layernorm_bwd(a, b, g, dy.contiguous(), need_dx=need_dx, dg=sg.view(-1) if sunk else None,
+                                            dbeta=sb.view(-1) if sunk else None)
         if sunk:
             dg = dbeta = None
         da = db = None
         if ctx.needs_input_grad[0]:
-            da = dx if dx.dtype == a.dtype else ops.convert(dx, a.dtype)
+            da = dx if dxa is None else dxa
+            da = da if da.dtype == a.dtype else ops.convert(da, a.dtype)
         if b is not None and ctx.needs_input_grad[1]:
             db = dx if dx.dtype == b.dtype else ops.convert(dx, b.dtype)
-        return da, db, dg, dbeta, None
+        return da, db, dg, dbeta, None, None, None
 
 
 class AttentionCoreFn(torch.autograd.Function):

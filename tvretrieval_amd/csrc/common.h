@@ -231,6 +231,30 @@ __device__ __forceinline__ void xml_seed_words(uint64_t seed, const uint64_t* se
   s1 = (uint32_t)(seed >> 32) * 0x27D4EB2Fu + 0x165667B1u;
 }
 
+// counter-based dropout mask of xml_dropout: element i of a tensor is KEPT when drop_hash(i, s0, s1) >= p * 2^32
+__device__ __forceinline__ uint32_t drop_hash(uint64_t i, uint32_t s0, uint32_t s1) {
+  uint32_t h = (uint32_t)i * 0x9E3779B1u + s0;
+  h ^= (uint32_t)(i >> 32) * 0x85EBCA77u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu;
+  h ^= h >> 13; h += s1; h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  return h;
+}
+// dropout sites fused into another kernel's loads / stores (xml_add_layernorm_drop, xml_layernorm_bwd_drop):
+// thresh == 0 means "no dropout at this site"
+struct XmlDropSite {
+  uint32_t thresh;
+  float scale;
+  uint64_t seed;
+};
+static inline XmlDropSite xml_drop_site(float p, uint64_t seed) {
+  XmlDropSite s;
+  s.thresh = p > 0.f ? (uint32_t)((double)p * 4294967296.0) : 0u;
+  s.scale = p > 0.f ? 1.f / (1.f - p) : 1.f;
+  s.seed = seed;
+  return s;
+}
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 static inline size_t dt_size(int dt) { return (dt == XML_F32 || dt == XML_F16S) ? 4 : 2; }

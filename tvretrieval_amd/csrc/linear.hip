@@ -186,12 +186,18 @@ __global__ __launch_bounds__(256) void add_layernorm_kernel(const InT* __restric
 // Vectorised variant (d % 8 == 0, d <= 64 * 8 * VPL): lane owns the 8-element vectors lane + 64 k, the row stays in
 // registers, inputs are read once with 16-byte loads.  VPL = 2 covers the hidden size (<= 1024), 6 / 8 the raw
 // feature rows of the input LayerNorm (3072 / 4096).
-template <typename InT, typename BT, typename OutT, int VPL>
+// DROP (training, xml_add_layernorm_drop): y = drop_out( LN( drop_in(a) + b ) * g + beta ) with xml_dropout's masks -- element
+// i of `a` / of `y` is kept when drop_hash(i, seed) >= thresh -- applied in the loads / stores instead of by two elementwise
+// passes (22 dropout launches per training step at the configs[4] shape).
+template <typename InT, typename BT, typename OutT, int VPL, bool DROP = false>
 __global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __restrict__ a, const BT* __restrict__ b,
                                                                 const float* __restrict__ g,
                                                                 const float* __restrict__ beta, OutT* __restrict__ y,
                                                                 int64_t rows, int d, int ld_out, float eps,
-                                                                const int32_t* __restrict__ src_row) {
+                                                                const int32_t* __restrict__ src_row,
+                                                                XmlDropSite din = XmlDropSite{0u, 1.f, 0ull},
+                                                                XmlDropSite dout = XmlDropSite{0u, 1.f, 0ull},
+                                                                const uint64_t* __restrict__ seed_dev = nullptr) {
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -199,6 +205,11 @@ __global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __res
   const InT* pa = a + (src_row ? (int64_t)src_row[row] : row) * d;        // (packed tokens: row i reads source row src_row[i])
   const BT* pb = b ? b + row * d : nullptr;
   OutT* py = y + row * ld_out;
+  uint32_t si0 = 0, si1 = 0, so0 = 0, so1 = 0;
+  if constexpr (DROP) {
+    xml_seed_words(din.seed, seed_dev, si0, si1);
+    xml_seed_words(dout.seed, seed_dev, so0, so1);
+  }
   float x[VPL * 8];
   float s = 0.f;
 #pragma unroll
@@ -206,6 +217,13 @@ __global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __res
     const int v = lane + k * 64;
     if (v < nvec) {
       ld8<InT>(pa + v * 8, x + k * 8);
+      if constexpr (DROP) {
+        if (din.thresh) {
+          const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)v * 8u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[k * 8 + j] = drop_hash(i0 + j, si0, si1) >= din.thresh ? x[k * 8 + j] * din.scale : 0.f;
+        }
+      }
       if (pb) {
         float t[8];
         ld8<BT>(pb + v * 8, t);
@@ -236,10 +254,51 @@ __global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __res
       ld8<float>(beta + v * 8, bv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) o[j] = (x[k * 8 + j] - mean) * rstd * gv[j] + bv[j];
+      if constexpr (DROP) {
+        if (dout.thresh) {
+          const uint64_t i0 = (uint64_t)row * (uint64_t)ld_out + (uint64_t)v * 8u;
+#pragma unroll
+          for (int j = 0; j < 8; ++j) o[j] = drop_hash(i0 + j, so0, so1) >= dout.thresh ? o[j] * dout.scale : 0.f;
+        }
+      }
       st8<OutT>(py + v * 8, o);
     }
   }
   for (int i = d + lane; i < ld_out; i += 64) DT<OutT>::st(py + i, 0.f);  // zero K padding
+}
+
+// training: LayerNorm with the dropout sites before / behind it applied in place (d % 8 == 0, d <= 4096, ld_out == d)
+template <typename InT, typename BT, typename OutT>
+static int launch_ln_drop(const void* a, const void* b, const float* g, const float* beta, void* y, int64_t rows, int d,
+                          XmlDropSite din, XmlDropSite dout, const uint64_t* seed_dev, hipStream_t st) {
+  const dim3 grid(cdiv(rows, 4)), blk(256);
+#define XML_LN_DROP(VPL)                                                                                                    \
+  hipLaunchKernelGGL((add_layernorm_vec_kernel<InT, BT, OutT, VPL, true>), grid, blk, 0, st, (const InT*)a, (const BT*)b, g, \
+                     beta, (OutT*)y, rows, d, d, 1e-5f, (const int32_t*)nullptr, din, dout, seed_dev)
+  if (d <= 1024) XML_LN_DROP(2);
+  else if (d <= 3072) XML_LN_DROP(6);
+  else XML_LN_DROP(8);
+#undef XML_LN_DROP
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+extern "C" int xml_add_layernorm_drop(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
+                                      int64_t rows, int d, int dt, float p_in, uint64_t seed_in, float p_out,
+                                      uint64_t seed_out, const uint64_t* seed_dev, xml_stream_t stream) {
+  XML_ENTER();
+  if (!a || !g || !beta || !y || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
+  if (!(p_in >= 0.f) || p_in >= 1.f || !(p_out >= 0.f) || p_out >= 1.f) return XML_ERR_BAD_ARG;
+  if (d % 8 || d > 4096) return XML_ERR_UNSUPPORTED;
+  const XmlDropSite din = xml_drop_site(p_in, seed_in), dout = xml_drop_site(p_out, seed_out);
+  hipStream_t st = (hipStream_t)stream;
+  if (dt == XML_F32) {
+    if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
+    return launch_ln_drop<float, float, float>(a, b, g, beta, y, rows, d, din, dout, seed_dev, st);
+  }
+  if (dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (a_dt == XML_F32) return launch_ln_drop<float, bf16_t, bf16_t>(a, b, g, beta, y, rows, d, din, dout, seed_dev, st);
+  return launch_ln_drop<bf16_t, bf16_t, bf16_t>(a, b, g, beta, y, rows, d, din, dout, seed_dev, st);
 }
 
 template <typename InT, typename BT, typename OutT>

@@ -190,15 +190,27 @@ extern "C" int xml_add_inplace(void* y, int y_dt, const void* x, int x_dt, int64
 // ---------------------------------------------------------------------------------------------------------
 // d % 8 == 0, d <= 1024: lane owns the 8-element vectors v = lane + 64*k (k < 2).  A block (4 waves) walks
 // 4 * rows_per_wave rows, combines the column partials of its waves in LDS and issues one atomic per column.
-template <typename InT, typename BT, typename T>
+// DROP (xml_layernorm_bwd_drop): the forward pass was y = drop_out( LN( drop_in(a) + b ) * g + beta ) (xml_add_layernorm_drop):
+// dy is masked with the output site's mask on load, x is rebuilt from the masked a, and the gradient of a (dx times the
+// input site's mask) goes to `dxa` next to dx (the gradient of b).
+template <typename InT, typename BT, typename T, bool DROP = false>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restrict__ a, const BT* __restrict__ b,
                                                             const float* __restrict__ g, const T* __restrict__ dy,
                                                             T* __restrict__ dx, float* __restrict__ dg,
                                                             float* __restrict__ dbeta, int64_t rows, int d,
-                                                            float eps, int rows_per_wave) {
+                                                            float eps, int rows_per_wave,
+                                                            XmlDropSite din = XmlDropSite{0u, 1.f, 0ull},
+                                                            XmlDropSite dout = XmlDropSite{0u, 1.f, 0ull},
+                                                            const uint64_t* __restrict__ seed_dev = nullptr,
+                                                            T* __restrict__ dxa = nullptr) {
   __shared__ float s_pg[4][1024], s_pb[4][1024];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d >> 3;
+  uint32_t si0 = 0, si1 = 0, so0 = 0, so1 = 0;
+  if constexpr (DROP) {
+    xml_seed_words(din.seed, seed_dev, si0, si1);
+    xml_seed_words(dout.seed, seed_dev, so0, so1);
+  }
   float pg[16], pb[16], gv[16];
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
@@ -239,6 +251,13 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
       const bool on = lane + k * 64 < nvec;
 #pragma unroll
       for (int h = 0; h < VA; ++h) unpack16<InT>(ra[k][h], x + k * 8 + h * (8 / VA));
+      [[maybe_unused]] const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)(lane + k * 64) * 8u;
+      if constexpr (DROP) {
+        if (din.thresh) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[k * 8 + j] = drop_hash(i0 + j, si0, si1) >= din.thresh ? x[k * 8 + j] * din.scale : 0.f;
+        }
+      }
       if (b) {
         float t[8];
 #pragma unroll
@@ -248,6 +267,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
       }
 #pragma unroll
       for (int h = 0; h < VD; ++h) unpack16<T>(rd[k][h], gy + k * 8 + h * (8 / VD));
+      if constexpr (DROP) {
+        if (dout.thresh) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) gy[k * 8 + j] = drop_hash(i0 + j, so0, so1) >= dout.thresh ? gy[k * 8 + j] * dout.scale : 0.f;
+        }
+      }
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         x[k * 8 + j] = on ? x[k * 8 + j] : 0.f;
@@ -286,6 +311,14 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] = rstd * (gy[k * 8 + j] - s1 - x[k * 8 + j] * s2);
         st8<T>(dx + row * d + v * 8, o);
+        if constexpr (DROP) {
+          if (dxa) {
+            const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)v * 8u;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o[j] = drop_hash(i0 + j, si0, si1) >= din.thresh ? o[j] * din.scale : 0.f;
+            st8<T>(dxa + row * d + v * 8, o);
+          }
+        }
       }
     }
   }
@@ -359,10 +392,13 @@ __global__ __launch_bounds__(256) void ln_bwd_cols_kernel(const InT* __restrict_
 template <typename InT, typename T, int KV>
 __global__ __launch_bounds__(256) void ln_bwd_wide_params_kernel(const InT* __restrict__ a, const T* __restrict__ dy,
                                                                  float* __restrict__ dg, float* __restrict__ dbeta,
-                                                                 int64_t rows, int d, float eps, int rows_per_wave) {
+                                                                 int64_t rows, int d, float eps, int rows_per_wave,
+                                                                 XmlDropSite dout, const uint64_t* __restrict__ seed_dev) {
   extern __shared__ float s_acc[];               // [2][d]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nvec = d >> 3;
+  uint32_t so0 = 0, so1 = 0;
+  if (dout.thresh) xml_seed_words(dout.seed, seed_dev, so0, so1);   // (output dropout site of xml_add_layernorm_drop)
   for (int i = threadIdx.x; i < 2 * d; i += 256) s_acc[i] = 0.f;
   __syncthreads();
   float pg[KV * 8], pb[KV * 8];
@@ -379,6 +415,11 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_params_kernel(const InT* __re
       const int vc = v < nvec ? v : 0;
       ld8<InT>(a + row * d + vc * 8, x + k * 8);
       ld8<T>(dy + row * d + vc * 8, gy + k * 8);
+      if (dout.thresh) {
+        const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)vc * 8u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) gy[k * 8 + j] = drop_hash(i0 + j, so0, so1) >= dout.thresh ? gy[k * 8 + j] * dout.scale : 0.f;
+      }
     }
     float s = 0.f;
 #pragma unroll
@@ -423,14 +464,15 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_params_kernel(const InT* __re
 }
 
 template <typename InT, typename T>
-static int ln_bwd_wide_params(const void* a, const void* dy, float* dg, float* dbeta, int64_t rows, int d, hipStream_t st) {
+static int ln_bwd_wide_params(const void* a, const void* dy, float* dg, float* dbeta, int64_t rows, int d, hipStream_t st,
+                              XmlDropSite dout = XmlDropSite{0u, 1.f, 0ull}, const uint64_t* seed_dev = nullptr) {
   const int rpw = rows >= 8192 ? 8 : rows >= 4096 ? 4 : 1;      // every block ends in 2 d global atomics: fewer, longer blocks (12 800 x 3072: 198 -> 108 us)
   const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
   const size_t lds = (size_t)2 * d * 4;
   const int kv = cdiv(d >> 3, 64);
 #define XML_LNW(KV)                                                                                                       \
   hipLaunchKernelGGL((ln_bwd_wide_params_kernel<InT, T, KV>), grid, blk, lds, st, (const InT*)a, (const T*)dy, dg, dbeta, rows, \
-                     d, 1e-5f, rpw)
+                     d, 1e-5f, rpw, dout, seed_dev)
   if (kv <= 2) XML_LNW(2);
   else if (kv <= 4) XML_LNW(4);
   else if (kv <= 6) XML_LNW(6);
@@ -488,6 +530,48 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
     else
       hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, bf16_t>), grid, blk, 0, st, (const bf16_t*)a,
                          (const bf16_t*)b, g, (const bf16_t*)dy, (bf16_t*)dx, dg, dbeta, rows, d, 1e-5f, rpw);
+  } else {
+    return XML_ERR_BAD_ARG;
+  }
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+// Backward of xml_add_layernorm_drop.  dx: gradient of b (and of a when p_in == 0); dxa: gradient of a when p_in > 0
+// (required then).  d <= 1024: everything; wider rows: parameter gradients only (dx == NULL), bf16, p_in == 0.
+extern "C" int xml_layernorm_bwd_drop(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx,
+                                      void* dxa, float* dg, float* dbeta, int64_t rows, int d, int dt, float p_in,
+                                      uint64_t seed_in, float p_out, uint64_t seed_out, const uint64_t* seed_dev,
+                                      xml_stream_t stream) {
+  XML_ENTER();
+  if (!a || !g || !dy || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
+  if (!(p_in >= 0.f) || p_in >= 1.f || !(p_out >= 0.f) || p_out >= 1.f) return XML_ERR_BAD_ARG;
+  if (d & 7) return XML_ERR_UNSUPPORTED;
+  const XmlDropSite din = xml_drop_site(p_in, seed_in), dout = xml_drop_site(p_out, seed_out);
+  hipStream_t st = (hipStream_t)stream;
+  if (d > 1024) {
+    if (b || dx || dxa || din.thresh || d > 4096 || dt != XML_BF16) return XML_ERR_UNSUPPORTED;
+    if (a_dt == XML_F32) return ln_bwd_wide_params<float, bf16_t>(a, dy, dg, dbeta, rows, d, st, dout, seed_dev);
+    if (a_dt == XML_BF16) return ln_bwd_wide_params<bf16_t, bf16_t>(a, dy, dg, dbeta, rows, d, st, dout, seed_dev);
+    return XML_ERR_BAD_ARG;
+  }
+  if (!dx || (din.thresh && !dxa)) return XML_ERR_BAD_ARG;
+  if (!din.thresh) dxa = nullptr;
+  const int rpw = rows >= 65536 ? 16 : (rows >= 1024 ? 4 : 1);
+  const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
+  if (dt == XML_F32) {
+    if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float, float, float, true>), grid, blk, 0, st, (const float*)a, (const float*)b,
+                       g, (const float*)dy, (float*)dx, dg, dbeta, rows, d, 1e-5f, rpw, din, dout, seed_dev, (float*)dxa);
+  } else if (dt == XML_BF16) {
+    if (a_dt == XML_F32)
+      hipLaunchKernelGGL((layernorm_bwd_kernel<float, bf16_t, bf16_t, true>), grid, blk, 0, st, (const float*)a,
+                         (const bf16_t*)b, g, (const bf16_t*)dy, (bf16_t*)dx, dg, dbeta, rows, d, 1e-5f, rpw, din, dout,
+                         seed_dev, (bf16_t*)dxa);
+    else
+      hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t, bf16_t, bf16_t, true>), grid, blk, 0, st, (const bf16_t*)a,
+                         (const bf16_t*)b, g, (const bf16_t*)dy, (bf16_t*)dx, dg, dbeta, rows, d, 1e-5f, rpw, din, dout,
+                         seed_dev, (bf16_t*)dxa);
   } else {
     return XML_ERR_BAD_ARG;
   }
@@ -1446,14 +1530,7 @@ extern "C" int xml_bert_adam_step(float* p, float* g, float* m, float* v, const 
 // gradient instead of storing a mask.  In place (y == x) is allowed.  The random stream is NOT torch's Philox
 // stream: dropout is statistically, not bitwise, equivalent to the reference's.
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t drop_hash(uint64_t i, uint32_t s0, uint32_t s1) {
-  uint32_t h = (uint32_t)i * 0x9E3779B1u + s0;
-  h ^= (uint32_t)(i >> 32) * 0x85EBCA77u;
-  h ^= h >> 16; h *= 0x85EBCA6Bu;
-  h ^= h >> 13; h += s1; h *= 0xC2B2AE35u;
-  h ^= h >> 16;
-  return h;
-}
+// (drop_hash: common.h -- shared with the LayerNorm kernels that apply the same masks in their loads / stores)
 template <typename T>
 __global__ void dropout_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n, uint32_t thresh, float scale,
                                uint64_t seed, const uint64_t* __restrict__ seed_dev) {

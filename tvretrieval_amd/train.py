@@ -79,6 +79,26 @@ def _drop(x, module):
     return DropoutFn.apply(x, float(module.p), _seed())
 
 
+FUSE_DROPOUT = True      # dropout sites next to a LayerNorm run inside the LayerNorm kernels (same masks, 22 launches fewer)
+
+
+def _site(module):
+    return (float(module.p), _seed()) if (module is not None and module.training and module.p > 0) else None
+
+
+def _ln(a, b, norm, dt, drop_in=None, drop_out=None):
+    """drop_out(LayerNorm(drop_in(a) + b)); drop_in / drop_out: the nn.Dropout holders of the two sites, or None."""
+    si, so = _site(drop_in), _site(drop_out)
+    need_dx = a.requires_grad or (b is not None and b.requires_grad)
+    if (si or so) and FUSE_DROPOUT and T.layernorm_drop_supported(a.shape[-1], dt, need_dx, b is not None,
+                                                                  si[0] if si else 0.0):
+        return LayerNormFn.apply(a, b, norm.weight, norm.bias, dt, si, so)
+    if si:
+        a = DropoutFn.apply(a, *si)
+    y = LayerNormFn.apply(a, b, norm.weight, norm.bias, dt)
+    return DropoutFn.apply(y, *so) if so else y
+
+
 def _probs_drop(sa):
     return (float(sa.dropout.p), _seed()) if (sa.training and sa.dropout.p > 0) else (0.0, 0)
 
@@ -88,8 +108,7 @@ def _bert_attention(mod, x, key_mask, dt):
     sa, so = mod.self, mod.output
     qkv = QkvFn.apply(x, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias)
     a = AttentionQkvFn.apply(qkv, key_mask, sa.num_attention_heads, *_probs_drop(sa))
-    d = _drop(LinearFn.apply(a, so.dense.weight, so.dense.bias, False), so.dropout)
-    return LayerNormFn.apply(d, x, so.LayerNorm.weight, so.LayerNorm.bias, dt)
+    return _ln(LinearFn.apply(a, so.dense.weight, so.dense.bias, False), x, so.LayerNorm, dt, drop_in=so.dropout)
 
 
 def _encode_input(model, feat, mask, proj, enc, pos):
@@ -98,10 +117,10 @@ def _encode_input(model, feat, mask, proj, enc, pos):
     if feat.dtype not in (F32, dt):
         feat = feat.float()
     n, seq_len = feat.shape[:2]
-    x = LayerNormFn.apply(feat.contiguous(), None, proj.LayerNorm.weight, proj.LayerNorm.bias, dt)
-    x = LinearFn.apply(_drop(x, proj.net[0]), proj.net[1].weight, proj.net[1].bias, True)
+    x = _ln(feat.contiguous(), None, proj.LayerNorm, dt, drop_out=proj.net[0])
+    x = LinearFn.apply(x, proj.net[1].weight, proj.net[1].bias, True)
     p = _PosTableFn.apply(pos.position_embeddings.weight, n, seq_len, dt)
-    x = _drop(LayerNormFn.apply(x, p, pos.LayerNorm.weight, pos.LayerNorm.bias, dt), pos.dropout)
+    x = _ln(x, p, pos.LayerNorm, dt, drop_out=pos.dropout)
     return _bert_attention(enc, x, mask, dt)
 
 

@@ -73,6 +73,44 @@ def layernorm_bwd(a, b, g, dy, need_dx=True, dg=None, dbeta=None):
     return dx, dg, dbeta
 
 
+def layernorm_drop_supported(d, dt, need_dx, has_b, p_in):
+    """Shapes xml_add_layernorm_drop / xml_layernorm_bwd_drop serve (callers keep separate dropout launches otherwise)."""
+    if d % 8 or d > 4096 or dt not in (F32, torch.bfloat16):
+        return False
+    if d > 1024:
+        return dt == torch.bfloat16 and not need_dx and not has_b and p_in == 0
+    return True
+
+
+def add_layernorm_drop(a, b, g, beta, out_dtype, p_in, seed_in, p_out, seed_out):
+    """y = drop_out(LN(drop_in(a) + b) * g + beta) in one launch (xml_dropout's masks for the two seeds)."""
+    _req(a, "a"); _req(g, "g", F32); _req(beta, "beta", F32)
+    d = a.shape[-1]
+    rows = a.numel() // d
+    if b is not None:
+        _req(b, "b", out_dtype)
+    y = torch.empty(a.shape, dtype=out_dtype, device=a.device)
+    check(_lib.load().xml_add_layernorm_drop(_p(a), dt_of(a), _p(b), _p(g), _p(beta), _p(y), rows, d, dt_of(y),
+                                             float(p_in), int(seed_in), float(p_out), int(seed_out), _seed_base_ptr(),
+                                             _stream()), "xml_add_layernorm_drop")
+    return y
+
+
+def layernorm_bwd_drop(a, b, g, dy, p_in, seed_in, p_out, seed_out, need_dx=True, dg=None, dbeta=None):
+    """Backward of add_layernorm_drop -> (dx or None, dxa or None, dg, dbeta); dxa (gradient of a) only when p_in > 0."""
+    _req(a, "a"); _req(g, "g", F32); _req(dy, "dy")
+    d = a.shape[-1]
+    rows = a.numel() // d
+    dg = torch.zeros(d, dtype=F32, device=a.device) if dg is None else _req(dg, "dg", F32)
+    dbeta = torch.zeros(d, dtype=F32, device=a.device) if dbeta is None else _req(dbeta, "dbeta", F32)
+    dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (need_dx or d <= 1024) else None
+    dxa = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (dx is not None and p_in > 0) else None
+    check(_lib.load().xml_layernorm_bwd_drop(_p(a), dt_of(a), _p(b), _p(g), _p(dy), _p(dx), _p(dxa), _p(dg), _p(dbeta),
+                                             rows, d, dt_of(dy), float(p_in), int(seed_in), float(p_out), int(seed_out),
+                                             _seed_base_ptr(), _stream()), "xml_layernorm_bwd_drop")
+    return dx, dxa, dg, dbeta
+
+
 def gemm_batched(a, b, scale=1.0, out_f32=False):
     """out[z] = scale * a[z] @ b[z]^T ; a (B, M, K), b (B, N, K) -> (B, M, N) (2-D inputs: B = 1, 2-D output)."""
     _req(a, "a"); _req(b, "b", a.dtype)

@@ -489,6 +489,25 @@ int xml_l2norm_bwd(const void* x, const float* dy, void* dx, int64_t rows, int d
 int xml_q2c_scores_bwd(const void* qn, const void* cn, const float* mask, const float* dscores,
                        int64_t ld_ds, float scale, float* dqn, float* dcn, int nq, int nv, int l, int hidden,
                        int dt, xml_stream_t stream);
+/* get_video_level_scores backward (xml/model_xml.py:436-453) in ONE launch, for the sparse score gradients of the ranking
+ * loss: replaces xml_q2c_scores_bwd (two f32 fills + atomics) + a slice copy + two xml_l2norm_bwd passes.
+ *   query (nq, hidden), feat (nv, l, hidden): the un-normalised inputs of the forward pass; qn (nq, hidden), cn (nv, lpad,
+ *   hidden), mask (nv, lpad): what the forward pass scored (F.normalize'd rows, clips padded to lpad >= l);
+ *   dscores (nq, nv) f32 row stride ld_ds, multiplied by `scale`;  dq (nq, hidden), dfeat (nv, l, hidden) dt: every element
+ *   written (rows no pair points at are zero).  Per pair with a gradient the arg-max clip is re-derived (first clip on
+ *   ties), its gradient goes through the F.normalize backward of that one row.  Any dscores is handled, the cost grows with
+ *   the number of non-zeros.  _supported: dt f32 / bf16, nq, nv <= 1024, hidden % 8 == 0, hidden <= 2048. */
+int xml_q2c_scores_l2norm_bwd_supported(int nq, int nv, int l, int hidden, int dt);
+int xml_q2c_scores_l2norm_bwd(const void* query, const void* feat, const void* qn, const void* cn, const float* mask,
+                              const float* dscores, int64_t ld_ds, float scale, void* dq, void* dfeat, int nq, int nv, int l,
+                              int lpad, int hidden, int dt, xml_stream_t stream);
+/* The loss sum of XML.forward (xml/model_xml.py:241-251): parts4 = {w_st_ed * st_ed[0], w_neg_ctx * rank2[0],
+ * w_neg_q * rank2[1], their sum}, overall[0] = the sum; st_ed / rank2 NULL: that term is 0.  _bwd: from the gradient g[0] of
+ * the sum, d_st_ed[0] = w_st_ed g, d_rank2 = {w_neg_ctx g, w_neg_q g} (NULL: not wanted).  All device f32. */
+int xml_loss_combine(const float* st_ed, const float* rank2, float w_st_ed, float w_neg_ctx, float w_neg_q, float* parts4,
+                     float* overall, xml_stream_t stream);
+int xml_loss_combine_bwd(const float* g, float w_st_ed, float w_neg_ctx, float w_neg_q, float* d_st_ed, float* d_rank2,
+                         xml_stream_t stream);
 /* einsum("bd,bld->bl") of the cross=False branch (xml/model_xml.py:478-479,532) and its backward. */
 int xml_pair_sim(const void* q, const void* f2, float* sim, int64_t n, int l, int hidden, int dt,
                  xml_stream_t stream);
@@ -515,6 +534,13 @@ int xml_rank_loss(const float* scores, const int* ranks_ctx, const int* ranks_q,
  * 0 <= p < 1; y == x allowed.  Not torch's Philox stream: statistically, not bitwise, equal to the reference. */
 int xml_dropout(const void* x, void* y, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, int dt,
                 xml_stream_t stream);
+/* Transposed bf16 copies of many f32 weight matrices of ONE flat buffer in one launch -- the W^T operands of the training
+ * step's dX = dY W GEMMs, refreshed once per step from the optimizer's flat parameter buffer (BertAdam.refresh_shadows)
+ * instead of one xml_transpose_batched per layer and step.  table (device memory): n_ent rows of six int64
+ *   {src_off (elements into src), n, k, dst (device address of bf16 storage), ld_dst, col0}:
+ *   dst[kk * ld_dst + col0 + nn] = bf16(src[src_off + nn * k + kk]),  nn < n, kk < k   (other dst elements untouched).
+ * max_tiles >= max over the entries of ceil(n / 64) * ceil(k / 64).  dt: XML_BF16 only. */
+int xml_transpose_segments(const float* src, const int64_t* table, int n_ent, int max_tiles, int dt, xml_stream_t stream);
 /* Training LayerNorm with its neighbouring dropout sites applied in place (xml/model_components.py:201-210 BertSelfOutput
  * dense -> dropout -> LayerNorm(+ residual); :103-114 LinearLayer LayerNorm -> dropout -> Linear; :139-156
  * TrainablePositionalEncoding LayerNorm -> dropout):

@@ -132,9 +132,10 @@ def test_attention_core_fn(n, lq, lk, hsz, heads, cross):
 
 
 @pytest.mark.parametrize("n_mod", [1, 2])
-def test_modular_pool_fn(n_mod):
+@pytest.mark.parametrize("n,l,h", [(5, 11, 128), (9, 30, 768), (3, 128, 200), (2, 17, 2048), (4, 13, 100)])
+def test_modular_pool_fn(n_mod, n, l, h):
+    """h % 8 == 0 (<= 2048): the 16-byte backward kernel (loss_tail.hip); h = 100: the scalar one."""
     from tvretrieval_amd.autograd import ModularPoolFn
-    n, l, h = 5, 11, 128
     enc, wm, mask = rnd(n, l, h, seed=1), rnd(n_mod, h, seed=2, scale=0.3), lens_mask(n, l, seed=3, lo=2)
 
     def ref(enc, wm):
@@ -161,6 +162,83 @@ def test_video_level_scores_fn(n_mod, l):
             tot = tot + torch.max(s, dim=1)[0]
         return tot / n_mod
     run_pair(lambda *t: VideoLevelScoresFn.apply(n_mod, *t, *ms), ref, qs + fs, [True] * (2 * n_mod), tol=5e-5)
+
+
+@pytest.mark.parametrize("nq,nv,l,h,dt,dense", [(128, 128, 100, 768, torch.bfloat16, False), (40, 24, 19, 128, F32, False),
+                                                 (16, 9, 32, 256, F32, True), (7, 300, 5, 64, torch.bfloat16, True)])
+def test_video_level_scores_backward_one_launch_vs_separate_kernels(nq, nv, l, h, dt, dense):
+    """xml_q2c_scores_l2norm_bwd == xml_q2c_scores_bwd (f32 atomics) -> slice -> xml_l2norm_bwd on the same saved tensors:
+    a ranking-loss-like sparse dscores (<= 3 pairs per row / column) and a dense one; clips padded to a multiple of 16;
+    masked clips; an all-zero clip row (F.normalize clamps its norm)."""
+    from tvretrieval_amd import ops, train_ops as TO
+    lpad = (l + 15) // 16 * 16
+    query, feat = rnd(nq, h, seed=1).to(dt), rnd(nv, l, h, seed=2).to(dt)
+    feat[1, 0] = 0
+    mask = lens_mask(nv, l, seed=3, lo=2)
+    qn, cn = ops.l2norm_rows(query), ops.l2norm_rows(feat)
+    cn_p = torch.zeros(nv, lpad, h, dtype=dt, device=DEV)
+    mk_p = torch.zeros(nv, lpad, device=DEV)
+    cn_p[:, :l], mk_p[:, :l] = cn, mask
+    g = torch.Generator().manual_seed(7)
+    if dense:
+        ds = torch.randn(nq, nv, generator=g)
+    else:
+        ds = torch.zeros(nq, nv)
+        for m in range(nq):
+            for n in torch.randint(0, nv, (3,), generator=g).tolist():
+                ds[m, n] += float(torch.randn((), generator=g))
+    ds = ds.to(DEV)
+    assert TO.q2c_scores_l2norm_bwd_supported(nq, nv, l, h, dt)
+    dq, df = TO.q2c_scores_l2norm_bwd(query, feat, qn, cn_p, mk_p, ds, scale=0.5)
+    dqn, dcn = TO.q2c_scores_bwd(qn, cn_p, mk_p, ds, scale=0.5)
+    want_q, want_f = TO.l2norm_bwd(query, dqn), TO.l2norm_bwd(feat, dcn[:, :l].contiguous())
+    tol = 2e-5 if dt == F32 else 8e-3           # bf16: one rounding of the outputs, different f32 summation orders
+    check("dquery", dq, want_q, tol)
+    check("dfeat", df, want_f, tol)
+    assert torch.equal(df == 0, want_f == 0) or dt != F32      # the same rows are touched
+    assert float(df.float().abs().sum()) > 0
+
+
+def test_loss_combine_fn():
+    from tvretrieval_amd.autograd import CombineLossFn
+    a = torch.tensor(0.73, device=DEV, requires_grad=True)
+    r = torch.tensor([1.25, -0.5], device=DEV, requires_grad=True)
+    loss, parts = CombineLossFn.apply(a, r, 0.01, 1.0, 2.0)
+    assert not parts.requires_grad
+    (loss * 3.0).backward()
+    want = [0.01 * 0.73, 1.25, -1.0]
+    assert torch.allclose(parts.cpu(), torch.tensor(want + [sum(want)]), rtol=1e-6)
+    assert abs(float(loss) - sum(want)) < 1e-6
+    assert abs(float(a.grad) - 0.03) < 1e-7 and torch.allclose(r.grad.cpu(), torch.tensor([3.0, 6.0]))
+    loss2, parts2 = CombineLossFn.apply(None, r, 0.0, 1.0, 1.0)
+    assert abs(float(loss2) - 0.75) < 1e-6 and float(parts2[0]) == 0.0
+
+
+def test_train_step_fused_loss_tail_equals_separate_launches():
+    """autograd.FUSED_LOSS_TAIL on / off on the golden batch (fp32, eval): same loss, same gradients."""
+    import tvretrieval_amd.autograd as AG
+    import tvretrieval_amd.train as TR
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    m = build_train_model(cfg, d)
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]), neg_ctx_rank=d["neg_ctx_rank"], neg_q_rank=d["neg_q_rank"])
+    res = []
+    try:
+        for fused in (True, False):
+            AG.FUSED_LOSS_TAIL = fused
+            m.zero_grad()
+            loss, parts = TR.xml_forward_train(m, **batch)
+            loss.backward()
+            res.append((float(loss), parts, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    finally:
+        AG.FUSED_LOSS_TAIL = True
+    assert abs(res[0][0] - res[1][0]) < 1e-6 and abs(res[0][0] - float(d["loss"])) < 5e-5
+    for k in res[1][1]:
+        assert abs(res[0][1][k] - res[1][1][k]) < 1e-6, k
+    for n, g0 in res[0][2].items():
+        if not n.endswith(".key.bias"):
+            check(n, g0, res[1][2][n], 5e-5)
 
 
 def test_pair_sim_fn():
@@ -730,6 +808,80 @@ def test_train_step_fused_dropout_sites_equal_separate_launches():
         if n.endswith(".key.bias"):        # softmax is invariant to the key bias: its gradient is rounding noise around 0
             continue
         check(n, g0, res[1][1][n], 2e-4)
+
+
+def test_transpose_segments_one_launch():
+    """xml_transpose_segments: bf16 W^T blocks of several f32 matrices of one flat buffer, incl. three matrices written side
+    by side into one (K, 3H) block (fused QKV) and a row count that is not a multiple of 8 (zero-padded leading dimension)."""
+    from tvretrieval_amd import train_ops as TO
+    shapes = [(128, 384), (100, 64), (2, 128), (96, 96), (96, 96), (96, 96), (770, 130)]
+    offs, total = [], 0
+    for n, k in shapes:
+        offs.append(total)
+        total += (n * k + 3) // 4 * 4
+    flat = rnd(total, seed=5)
+    bufs, rows, tiles = [], [], 0
+    groups = [(0,), (1,), (2,), (3, 4, 5), (6,)]
+    for grp in groups:
+        n_tot, k = sum(shapes[i][0] for i in grp), shapes[grp[0]][1]
+        buf = torch.zeros(k, (n_tot + 7) // 8 * 8, dtype=torch.bfloat16, device=DEV)
+        col = 0
+        for i in grp:
+            n = shapes[i][0]
+            rows.append([offs[i], n, k, buf.data_ptr(), buf.shape[1], col])
+            tiles = max(tiles, ((n + 63) // 64) * ((k + 63) // 64))
+            col += n
+        bufs.append(buf)
+    TO.transpose_segments(flat, torch.tensor(rows, dtype=torch.int64, device=DEV), tiles)
+    for grp, buf in zip(groups, bufs):
+        w = torch.cat([flat[offs[i]:offs[i] + shapes[i][0] * shapes[i][1]].view(shapes[i]) for i in grp], 0)
+        want = torch.zeros_like(buf)
+        want[:, :w.shape[0]] = w.to(torch.bfloat16).t()
+        assert torch.equal(buf, want), grp
+
+
+def test_weight_shadows_equal_per_use_conversion_and_never_go_stale():
+    """bf16 steps with the optimizer's per-step weight copies (BertAdam.refresh_shadows: one bf16 copy of the flat buffer, one
+    launch of transposes) == steps that convert / transpose every weight at its use: the GEMM operands are the same bits,
+    so losses agree to the summation-order noise of the f32 atomics.  A weight written through torch after the refresh is
+    NOT served from the shadow."""
+    import tvretrieval_amd.train as TR
+    from tvretrieval_amd.autograd import LinearFn
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]), neg_ctx_rank=d["neg_ctx_rank"], neg_q_rank=d["neg_q_rank"])
+    runs = []
+    try:
+        for shadows in (True, False):
+            TR.SHADOW_WEIGHTS = shadows
+            m = build_train_model(cfg, d, torch.bfloat16)
+            opt = TR.BertAdam(m.parameters(), lr=5e-4, warmup=-1, t_total=-1, schedule="none")
+            runs.append([float(TR.train_step(m, opt, batch)[0]) for _ in range(6)])
+            if shadows:
+                sh = opt._shadow
+                assert sh is not None and sh["table"] is not None and len(sh["t"]) >= 8 and not sh["fresh"]
+                # every kept transpose is the transpose of the CURRENT masters after a refresh
+                opt.refresh_shadows(torch.bfloat16)
+                for idx, ent in sh["t"].items():
+                    assert ent["ready"]
+                    w = torch.cat([opt.params[i].detach() for i in idx], 0).to(torch.bfloat16)
+                    assert torch.equal(ent["buf"][:, :w.shape[0]], w.t()), idx
+                # a torch-side write after the refresh: the shadow of that tensor is refused, the fresh value is used
+                lin = m.video_query_linear
+                x = rnd(16, lin.weight.shape[1], seed=3).to(torch.bfloat16)
+                y0 = LinearFn.apply(x, lin.weight, lin.bias, False)
+                with torch.no_grad():
+                    lin.weight.mul_(2.0)
+                y1 = LinearFn.apply(x, lin.weight, lin.bias, False)
+                want = F.linear(x.float(), lin.weight.detach().to(torch.bfloat16).float(), lin.bias.detach())
+                check("after the write", y1, want, 1e-2)
+                assert rel_err(y0, want) > 0.2
+    finally:
+        TR.SHADOW_WEIGHTS = True
+    for a, b in zip(*runs):
+        assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), runs
+    assert runs[0][-1] < runs[0][0] - 0.02
 
 
 def test_global_grad_clip():

@@ -32,6 +32,35 @@ def _packed(w, dtype):
     return w.contiguous() if dtype == F32 else ops.pack_weights(w.float().contiguous(), dtype)
 
 
+def _weights(params, dtype):
+    """Compute-dtype (sum N, K) weight of the row-concatenated f32 parameters: the optimizer's copy of this step when it is
+    current (BertAdam.refresh_shadows), else converted now."""
+    if dtype != F32:
+        reg = getattr(params[0], "_xml_sink", None)
+        if reg is not None:
+            v = reg.opt.shadow_w(params, dtype)
+            if v is not None:
+                return v
+    if len(params) == 1:
+        return _packed(params[0], dtype)
+    wf = _adjacent(params, "flat_p")      # usually back to back in the optimizer's flat parameter buffer: one view, no cat
+    wcat = wf.view(-1, params[0].shape[1]) if wf is not None else torch.cat([p.detach() for p in params], 0)
+    return _packed(wcat, dtype)
+
+
+def _weights_t(params, w):
+    """(K, ceil8(N)) transpose of the compute-dtype weight w of `params` (the B operand of dX = dY W): the optimizer's
+    per-step copy when current, else transposed now."""
+    n = w.shape[0]
+    if w.dtype != F32:
+        reg = getattr(params[0], "_xml_sink", None)
+        if reg is not None:
+            t = reg.opt.shadow_t(params, w.dtype)
+            if t is not None:
+                return t
+    return T.transpose(w, _r8(n)) if n % 8 else T.transpose(w)
+
+
 # ---- gradient sinks ---------------------------------------------------------------------------------------------------
 # BertAdam lays every parameter's .grad into ONE flat f32 buffer that it zeroes once per step (train.BertAdam._flatten) and
 # registers a GradSink on the parameter.  A backward node whose kernels ACCUMULATE (f32 atomics: the weight-gradient GEMM,
@@ -40,6 +69,7 @@ def _packed(w, dtype):
 # elementwise launches per step at the C5 shape) on top of the 70 fills of the temporaries.  The sink tells the optimizer
 # that the gradient is there (what the post-accumulate hook does on the ordinary path: "has ever received a gradient",
 # data-parallel bucket bookkeeping).
+FUSED_LOSS_TAIL = True         # A-B runs / tests: False = the separate q2c_scores_bwd + l2norm_bwd launches, torch loss sum
 USE_GRAD_SINKS = True          # tests / A-B runs: False = every node returns its gradients to autograd
 
 
@@ -123,7 +153,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        w = _packed(weight, x.dtype)
+        w = _weights((weight,), x.dtype)
         y = ops.linear(x.contiguous(), w, None if bias is None else bias.detach().float().contiguous(), relu=relu)
         ctx.relu = relu
         ctx.has_bias = bias is not None
@@ -144,15 +174,15 @@ class LinearFn(torch.autograd.Function):
         rows = x.numel() // k
         dy2, x2 = dy.view(rows, n), x.contiguous().view(rows, k)
         dx = dw = db = None
+        weight, bias = ctx.params
         if ctx.needs_input_grad[0]:
-            wt = T.transpose(w, _r8(n)) if n % 8 else T.transpose(w)              # (K, N[8])
+            wt = _weights_t((weight,), w)                                          # (K, N[8])
             a = dy2
             if n % 8:                                                              # pad the reduction dim
                 a = torch.zeros((rows, _r8(n)), dtype=dy.dtype, device=dy.device)
                 a[:, :n] = dy2
             dx = ops.linear(a, wt).view(x.shape)                                   # dX = dY W
         want_db = ctx.has_bias and ctx.needs_input_grad[2]
-        weight, bias = ctx.params
         if ctx.sunk:
             gw, gb = _sink(weight), (_sink(bias) if want_db else None)
             if gw is not None and (gb is not None or not want_db):
@@ -299,10 +329,8 @@ class QkvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv):
-        # the three weights (and biases) usually lie back to back in the optimizer's flat parameter buffer: one view, no cat
-        wf, bf = _adjacent((wq, wk, wv), "flat_p"), _adjacent((bq, bk, bv), "flat_p")
-        wcat = wf.view(3 * wq.shape[0], wq.shape[1]) if wf is not None else torch.cat([wq.detach(), wk.detach(), wv.detach()], 0)
-        w = _packed(wcat, x.dtype)
+        w = _weights((wq, wk, wv), x.dtype)
+        bf = _adjacent((bq, bk, bv), "flat_p")
         b = bf.detach() if bf is not None else torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
         ctx.params = (wq, bq, wk, bk, wv, bv)
         k = w.shape[1]
@@ -321,8 +349,8 @@ class QkvFn(torch.autograd.Function):
         h = n3 // 3
         rows = x.numel() // k
         dy2, x2 = dy.view(rows, n3), x.contiguous().view(rows, k)
-        dx = ops.linear(dy2, T.transpose(w)).view(x.shape) if ctx.needs_input_grad[0] else None
         wq, bq, wk, bk, wv, bv = ctx.params
+        dx = ops.linear(dy2, _weights_t((wq, wk, wv), w)).view(x.shape) if ctx.needs_input_grad[0] else None
         if ctx.sunk:
             if all(_sink(p) is not None for p in ctx.params):
                 gw, gb = _adjacent((wq, wk, wv), "flat_g"), _adjacent((bq, bk, bv), "flat_g")
@@ -458,12 +486,39 @@ class VideoLevelScoresFn(torch.autograd.Function):
         dq, df = [], []
         for i in range(n_mod):
             query, feat1, qn, cn_p, mk_p = ctx.saved_tensors[5 * i:5 * i + 5]
+            if FUSED_LOSS_TAIL and T.q2c_scores_l2norm_bwd_supported(query.shape[0], feat1.shape[0], feat1.shape[1],
+                                                                     feat1.shape[2], query.dtype):
+                dq_i, df_i = T.q2c_scores_l2norm_bwd(query, feat1, qn, cn_p, mk_p, dscores, scale=1.0 / n_mod)
+                dq.append(dq_i)
+                df.append(df_i)
+                continue
             dqn, dcn = T.q2c_scores_bwd(qn, cn_p, mk_p, dscores, scale=1.0 / n_mod)
             if cn_p.shape[1] != feat1.shape[1]:
                 dcn = dcn[:, :feat1.shape[1]].contiguous()
             dq.append(T.l2norm_bwd(query, dqn))
             df.append(T.l2norm_bwd(feat1, dcn))
         return (None,) + tuple(dq) + tuple(df) + (None,) * n_mod
+
+
+class CombineLossFn(torch.autograd.Function):
+    """loss = lw_st_ed * loss_st_ed + lw_neg_ctx * loss_neg_ctx + lw_neg_q * loss_neg_q (xml/model_xml.py:241-251) in one
+    launch each way.  forward(st_ed 0-d or None, rank_losses (2,) or None, weights) -> (overall 0-d,
+    parts (4,) [the three weighted terms, their sum], not differentiable)."""
+
+    @staticmethod
+    def forward(ctx, st_ed, rank2, w_st_ed, w_neg_ctx, w_neg_q):
+        ctx.w = (float(w_st_ed), float(w_neg_ctx), float(w_neg_q))
+        ctx.has = (st_ed is not None, rank2 is not None)
+        parts, overall = T.loss_combine(None if st_ed is None else st_ed.contiguous(),
+                                        None if rank2 is None else rank2.contiguous(), *ctx.w)
+        ctx.mark_non_differentiable(parts)
+        return overall, parts
+
+    @staticmethod
+    def backward(ctx, g, _g_parts):
+        d0, d1 = T.loss_combine_bwd(g.float().contiguous(), *ctx.w, ctx.has[0] and ctx.needs_input_grad[0],
+                                    ctx.has[1] and ctx.needs_input_grad[1])
+        return d0, d1, None, None, None
 
 
 class PairSimFn(torch.autograd.Function):

@@ -24,3 +24,6 @@ int xmli_add_layernorm(const void* a, int a_dt, const void* b, const float* g, c
 int xmli_attention_core(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv,
                         const float* q_mask, const float* k_mask, void* out, int out_f32, int64_t n, int lq, int lk,
                         int hidden, int n_heads, int dt, hipStream_t st);
+// loss_tail.hip: 16-byte modular-pooling backward; 0 = launched, -1 = shape not served (caller keeps the scalar kernel)
+int xmli_modular_pool_bwd_vec(const void* enc, const float* mask, const float* w_m, const void* dout, void* denc, float* dw_m,
+                              int64_t n, int lq, int hidden, int n_mod, int dt, hipStream_t st);

@@ -97,6 +97,44 @@ extern "C" int xml_transpose_batched(const void* x, void* y, int batch, int rows
   return XML_OK;
 }
 
+// Transposed bf16 copies of many f32 matrices of one flat buffer in ONE launch (xml_transpose_segments): blockIdx.y = table
+// entry {src_off, n, k, dst pointer, ld_dst, col0}, blockIdx.x = 64 x 64 tile of that (n, k) matrix (blocks beyond its tile
+// count leave).  dst[kk * ld_dst + col0 + nn] = bf16(src[src_off + nn * k + kk]); 256-byte row reads, 128-byte row writes.
+__global__ __launch_bounds__(256) void transpose_segments_kernel(const float* __restrict__ src,
+                                                                 const int64_t* __restrict__ table) {
+  __shared__ float tile[64][65];
+  const int64_t* e = table + (int64_t)blockIdx.y * 6;
+  const int64_t src_off = e[0];
+  const int n = (int)e[1], k = (int)e[2];
+  bf16_t* dst = reinterpret_cast<bf16_t*>(e[3]);
+  const int64_t ld = e[4], col0 = e[5];
+  const int tk = (k + 63) >> 6, tn = (n + 63) >> 6;
+  if ((int)blockIdx.x >= tk * tn) return;
+  const int n0 = ((int)blockIdx.x / tk) * 64, k0 = ((int)blockIdx.x % tk) * 64;
+  const int c = threadIdx.x & 63, r4 = threadIdx.x >> 6;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int r = r4 + j * 4;
+    tile[r][c] = (n0 + r < n && k0 + c < k) ? src[src_off + (int64_t)(n0 + r) * k + k0 + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int r = r4 + j * 4;                            // output row k0 + r, output column n0 + c
+    if (k0 + r < k && n0 + c < n) DT<bf16_t>::st(dst + (int64_t)(k0 + r) * ld + col0 + n0 + c, tile[c][r]);
+  }
+}
+
+extern "C" int xml_transpose_segments(const float* src, const int64_t* table, int n_ent, int max_tiles, int dt,
+                                      xml_stream_t stream) {
+  XML_ENTER();
+  if (!src || !table || n_ent <= 0 || max_tiles <= 0) return XML_ERR_BAD_ARG;
+  if (dt != XML_BF16) return XML_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(transpose_segments_kernel, dim3(max_tiles, n_ent), dim3(256), 0, (hipStream_t)stream, src, table);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // column sums: out[c] (+)= sum_r x[r][c]   (bias / positional-table gradients)
 // ---------------------------------------------------------------------------------------------------------
@@ -910,6 +948,10 @@ extern "C" int xml_modular_pool_bwd(const void* enc, const float* mask, const fl
   XML_ENTER();
   if (!enc || !mask || !w_m || !dout || !denc || !dw_m || n <= 0 || lq <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
   if (n_mod < 1 || n_mod > 2 || lq > 128) return XML_ERR_UNSUPPORTED;
+  if (xmli_modular_pool_bwd_vec(enc, mask, w_m, dout, denc, dw_m, n, lq, hidden, n_mod, dt, (hipStream_t)stream) == 0) {
+    XML_CHECK_LAUNCH();                  // loss_tail.hip: hidden % 8 == 0, <= 2048
+    return XML_OK;
+  }
   if (dt == XML_F32)
     hipLaunchKernelGGL(modular_pool_bwd_kernel<float>, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, (const float*)enc, mask, w_m, (const float*)dout, (float*)denc, dw_m, n, lq, hidden, n_mod);
   else if (dt == XML_BF16)

@@ -129,11 +129,16 @@ def convert(x, dtype):
     return out
 
 
-def pack_weights(w_f32, dtype):
+def pack_weights(w_f32, dtype, out=None):
     _req(w_f32, "w", torch.float32)
     if dtype is F16S:
+        assert out is None, "pack_weights: out= is for the plain low-precision copies"
         return pack_weights_f16s(w_f32)
-    out = torch.empty(w_f32.shape, dtype=dtype, device=w_f32.device)
+    if out is None:
+        out = torch.empty(w_f32.shape, dtype=dtype, device=w_f32.device)
+    else:
+        _req(out, "out", dtype)
+        assert out.numel() == w_f32.numel(), "pack_weights: out has the wrong size"
     check(_lib.load().xml_pack_weights(_p(w_f32), _p(out), dt_of(dtype), w_f32.numel(), _stream()), "xml_pack_weights")
     return out
 

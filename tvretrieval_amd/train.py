@@ -20,8 +20,10 @@ import math
 
 import torch
 
+from . import ops
 from . import train_ops as T
-from .autograd import (AttentionCoreFn, AttentionQkvFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn,
+from . import autograd as _ag
+from .autograd import (AttentionCoreFn, AttentionQkvFn, CombineLossFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn,
                        QkvFn, SpanLossFn, VideoLevelScoresFn)
 
 F32 = torch.float32
@@ -79,6 +81,7 @@ def _drop(x, module):
     return DropoutFn.apply(x, float(module.p), _seed())
 
 
+SHADOW_WEIGHTS = True    # bf16 steps: weights converted / transposed once per step by the optimizer (BertAdam.refresh_shadows)
 FUSE_DROPOUT = True      # dropout sites next to a LayerNorm run inside the LayerNorm kernels (same masks, 22 launches fewer)
 
 
@@ -215,6 +218,10 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
     dev = query_feat.device
     fm = lambda m: None if m is None else m.float().contiguous()       # noqa: E731
     query_mask, video_mask, sub_mask = fm(query_mask), fm(video_mask), fm(sub_mask)
+    if SHADOW_WEIGHTS and model.compute_dtype == torch.bfloat16 and torch.is_grad_enabled():
+        reg = getattr(next(iter(model.parameters())), "_xml_sink", None)
+        if reg is not None:             # an optimizer owns the parameters: its bf16 / transposed weight copies for this step
+            reg.opt.refresh_shadows(model.compute_dtype)
     v1, v2, s1, s2 = encode_context_train(model, video_feat, video_mask, sub_feat, sub_mask)
     # (the query encoder on a THIRD stream was measured and not kept: 5.54 vs 5.04 ms per captured step -- its small kernels
     # then interleave with the two context branches and break up their pairing)
@@ -249,6 +256,7 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
                                       *sims, *masks, *filters)
 
     loss_neg_ctx = loss_neg_q = zero
+    losses = None
     if cfg.lw_neg_ctx != 0 or cfg.lw_neg_q != 0:
         q2c = VideoLevelScoresFn.apply(len(names), *[qs[n] for n in names], *[f1[n] for n in names],
                                        *[ms[n] for n in names])
@@ -261,6 +269,14 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
                                   cfg.ranking_loss_type == "lse")
         loss_neg_ctx, loss_neg_q = losses[0], losses[1]
 
+    if _ag.FUSED_LOSS_TAIL and dev.type == "cuda" and (cfg.lw_st_ed != 0 or losses is not None):
+        # the weighted sum and its backward as one launch each (a dozen scalar torch kernels in the serial middle of the step)
+        loss, parts = CombineLossFn.apply(loss_st_ed if cfg.lw_st_ed != 0 else None, losses, cfg.lw_st_ed, cfg.lw_neg_ctx,
+                                          cfg.lw_neg_q)
+        if as_tensors:
+            return loss, {"loss_st_ed": parts[0], "loss_neg_ctx": parts[1], "loss_neg_q": parts[2], "loss_overall": parts[3]}
+        vals = parts.tolist()                # one host read for the four numbers
+        return loss, {"loss_st_ed": vals[0], "loss_neg_ctx": vals[1], "loss_neg_q": vals[2], "loss_overall": vals[3]}
     loss_st_ed = cfg.lw_st_ed * loss_st_ed
     loss_neg_ctx = cfg.lw_neg_ctx * loss_neg_ctx
     loss_neg_q = cfg.lw_neg_q * loss_neg_q
@@ -363,6 +379,8 @@ class BertAdam(object):
                 p.data = view
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
         self.params = plist
+        self._offs = offs
+        self._shadow = None                  # compute-dtype copies of the weights, refreshed once per step (refresh_shadows)
         self.seg_off = torch.tensor(offs, dtype=torch.int64, device=dev)
         self.seg_lr = torch.tensor(lrs, dtype=F32, device=dev)
         self.seg_wd = torch.tensor(wds, dtype=F32, device=dev)
@@ -394,6 +412,97 @@ class BertAdam(object):
         self._touched[i] = True
         if self._reducer is not None:
             self._reducer.grad_ready(i)
+
+    # ---- weight shadows ------------------------------------------------------------------------------------------------
+    # The bf16 training step used to convert every f32 master weight to bf16 in the forward pass and transpose it again for
+    # the dX GEMM of the backward pass: 24 + 21 launches, 0.33 ms of the 5 ms step at the C5 shape, all of them pure
+    # functions of the flat parameter buffer.  refresh_shadows (called by xml_forward_train at the start of a step) makes
+    # ONE bf16 copy of the whole buffer and ONE launch that writes every transposed matrix the backward nodes have asked for
+    # (shadow_t registers a matrix the first time it is wanted; it is served from the following refresh on).
+    # A shadow is only handed out while it is current: refreshed since the last step(), and no parameter it covers has been
+    # written through torch since (Tensor._version -- load_state_dict, manual edits); otherwise the caller packs afresh.
+    def refresh_shadows(self, dtype):
+        sh = self._shadow
+        if sh is None or sh["dtype"] != dtype:
+            sh = self._shadow = dict(dtype=dtype, flat=torch.empty(self.flat_p.numel(), dtype=dtype, device=self.flat_p.device),
+                                     t={}, ents={}, table=None, tables=[], max_tiles=0, dirty=False, fresh=False, versions=None)
+        ops.pack_weights(self.flat_p, dtype, out=sh["flat"])
+        if sh["dirty"] and not torch.cuda.is_current_stream_capturing():
+            rows, tiles = [], 0
+            for idx, ent in sh["t"].items():
+                col = 0
+                for i in idx:
+                    n, k = self.params[i].shape
+                    rows.append([self._offs[i], n, k, ent["buf"].data_ptr(), ent["buf"].shape[1], col])
+                    tiles = max(tiles, ((n + 63) // 64) * ((k + 63) // 64))
+                    col += n
+                ent["ready"] = True
+            sh["table"] = torch.tensor(rows, dtype=torch.int64, device=self.flat_p.device)
+            sh["tables"].append(sh["table"])      # a captured step keeps reading the table it was captured with
+            sh["max_tiles"], sh["dirty"] = tiles, False
+        if sh["table"] is not None:
+            T.transpose_segments(self.flat_p, sh["table"], sh["max_tiles"])
+        sh["versions"] = [p._version for p in self.params]
+        sh["fresh"] = True
+
+    def _shadow_entry(self, params):
+        """Resolve (once) the parameter tuple of a node: its indices here when the tensors lie back to back in the flat
+        buffer, in this order; False otherwise."""
+        sh = self._shadow
+        key = tuple(map(id, params))
+        ent = sh["ents"].get(key)
+        if ent is None:
+            ent = False
+            regs = [getattr(p, "_xml_sink", None) for p in params]
+            if all(r is not None and r.opt is self for r in regs):
+                idx = tuple(r.index for r in regs)
+                off, ok = self._offs[idx[0]], True
+                for p, i in zip(params, idx):
+                    ok = ok and self._offs[i] == off and self.params[i] is p
+                    off += p.numel()
+                if ok:
+                    base = self.flat_p.data_ptr()
+                    ent = dict(params=tuple(params), idx=idx, ptrs=tuple(base + 4 * self._offs[i] for i in idx),
+                               view=sh["flat"][self._offs[idx[0]]:off].view(-1, params[0].shape[-1]), t=None)
+            sh["ents"][key] = ent
+        return ent
+
+    @staticmethod
+    def _shadow_current(sh, ent):
+        # refreshed since the last step(), the tensors still ARE their slices of the flat buffer (model.to() / .float() move
+        # them away), and nothing has written them through torch since the refresh
+        vers = sh["versions"]
+        for p, i, ptr in zip(ent["params"], ent["idx"], ent["ptrs"]):
+            if p._version != vers[i] or p.data_ptr() != ptr:
+                return False
+        return sh["fresh"]
+
+    def shadow_w(self, params, dtype):
+        """The compute-dtype copy (sum N, K) of the row-concatenated parameters, or None when there is no current one."""
+        sh = self._shadow
+        if sh is None or not sh["fresh"] or sh["dtype"] != dtype:
+            return None
+        ent = self._shadow_entry(params)
+        return ent["view"] if ent and self._shadow_current(sh, ent) else None
+
+    def shadow_t(self, params, dtype):
+        """The transposed copy (K, ceil8(sum N)) of the row-concatenated 2-D parameters, or None -- registering it for the
+        refreshes to come when it is not kept yet."""
+        sh = self._shadow
+        if sh is None or sh["dtype"] != dtype:
+            return None
+        ent = self._shadow_entry(params)
+        if not ent:
+            return None
+        t = sh["t"].get(ent["idx"])
+        if t is None:
+            if not torch.cuda.is_current_stream_capturing():
+                n, k = sum(p.shape[0] for p in params), params[0].shape[1]
+                sh["t"][ent["idx"]] = dict(buf=torch.zeros((k, (n + 7) // 8 * 8), dtype=dtype, device=self.flat_p.device),
+                                           ready=False)
+                sh["dirty"] = True
+            return None
+        return t["buf"] if t["ready"] and self._shadow_current(sh, ent) else None
 
     def zero_grad(self):
         if self._reducer is not None:
@@ -449,6 +558,8 @@ class BertAdam(object):
             if a:
                 self.seg_steps[i] += 1
         self.step_count += 1
+        if self._shadow is not None:
+            self._shadow["fresh"] = False       # the masters have moved
         from .model_xml import _PackedMixin
         _PackedMixin.bump_generation()          # cached low-precision weight copies are stale now
 

@@ -32,6 +32,13 @@ def transpose(x, ld_out=None):
     return y[0] if squeeze else y
 
 
+def transpose_segments(flat_f32, table, max_tiles):
+    """table (n_ent, 6) int64 on the device: {src_off, n, k, dst address, ld_dst, col0} -> bf16 W^T blocks, one launch."""
+    _req(flat_f32, "flat", F32); _req(table, "table", torch.int64)
+    check(_lib.load().xml_transpose_segments(_p(flat_f32), _p(table), table.shape[0], int(max_tiles), _lib.XML_BF16,
+                                             _stream()), "xml_transpose_segments")
+
+
 def colsum(x, rows, cols, out=None):
     """sum over rows of x viewed as (rows, cols) -> f32 (cols,)."""
     _req(x, "x")
@@ -279,6 +286,48 @@ def q2c_scores_bwd(qn, cn, mask, dscores, scale=1.0):
     check(_lib.load().xml_q2c_scores_bwd(_p(qn), _p(cn), _p(mask), _p(dscores), dscores.stride(0), float(scale), _p(dqn), _p(dcn),
                                          nq, nv, l, hidden, dt_of(qn), _stream()), "xml_q2c_scores_bwd")
     return dqn, dcn
+
+
+def q2c_scores_l2norm_bwd_supported(nq, nv, l, hidden, dtype):
+    return bool(_lib.load().xml_q2c_scores_l2norm_bwd_supported(nq, nv, l, hidden, _lib.XML_F32 if dtype == F32 else
+                                                                 (_lib.XML_BF16 if dtype == torch.bfloat16 else -1)))
+
+
+def q2c_scores_l2norm_bwd(query, feat, qn, cn_p, mask_p, dscores, scale=1.0):
+    """VideoLevelScoresFn backward of one modality in one launch -> (dquery, dfeat) in the activation dtype."""
+    _req(query, "query"); _req(feat, "feat", query.dtype); _req(qn, "qn", query.dtype); _req(cn_p, "cn", query.dtype)
+    _req(mask_p, "mask", F32); _req(dscores, "dscores", F32)
+    nq, hidden = query.shape
+    nv, l, _ = feat.shape
+    lpad = cn_p.shape[1]
+    assert cn_p.shape == (nv, lpad, hidden) and mask_p.shape == (nv, lpad) and dscores.shape == (nq, nv) and dscores.stride(1) == 1
+    dq, df = torch.empty_like(query), torch.empty_like(feat)
+    check(_lib.load().xml_q2c_scores_l2norm_bwd(_p(query), _p(feat), _p(qn), _p(cn_p), _p(mask_p), _p(dscores),
+                                                dscores.stride(0), float(scale), _p(dq), _p(df), nq, nv, l, lpad, hidden,
+                                                dt_of(query), _stream()), "xml_q2c_scores_l2norm_bwd")
+    return dq, df
+
+
+def loss_combine(st_ed, rank2, w_st_ed, w_neg_ctx, w_neg_q):
+    """-> (parts (4,) f32 [weighted st_ed, neg_ctx, neg_q, sum], overall 0-d f32); st_ed 0-d / rank2 (2,) f32 or None."""
+    ref = st_ed if st_ed is not None else rank2
+    for t, nm in ((st_ed, "st_ed"), (rank2, "rank2")):
+        if t is not None:
+            _req(t, nm, F32)
+    parts = torch.empty(4, dtype=F32, device=ref.device)
+    overall = torch.empty((), dtype=F32, device=ref.device)
+    check(_lib.load().xml_loss_combine(_p(st_ed), _p(rank2), float(w_st_ed), float(w_neg_ctx), float(w_neg_q), _p(parts),
+                                       _p(overall), _stream()), "xml_loss_combine")
+    return parts, overall
+
+
+def loss_combine_bwd(g, w_st_ed, w_neg_ctx, w_neg_q, want_st_ed, want_rank):
+    _req(g, "g", F32)
+    d0 = torch.empty((), dtype=F32, device=g.device) if want_st_ed else None
+    d1 = torch.empty(2, dtype=F32, device=g.device) if want_rank else None
+    check(_lib.load().xml_loss_combine_bwd(_p(g), float(w_st_ed), float(w_neg_ctx), float(w_neg_q), _p(d0), _p(d1),
+                                           _stream()), "xml_loss_combine_bwd")
+    return d0, d1
 
 
 def pair_sim(q, f2):

@@ -496,11 +496,17 @@ int xml_q2c_scores_bwd(const void* qn, const void* cn, const float* mask, const 
  *   dscores (nq, nv) f32 row stride ld_ds, multiplied by `scale`;  dq (nq, hidden), dfeat (nv, l, hidden) dt: every element
  *   written (rows no pair points at are zero).  Per pair with a gradient the arg-max clip is re-derived (first clip on
  *   ties), its gradient goes through the F.normalize backward of that one row.  Any dscores is handled, the cost grows with
- *   the number of non-zeros.  _supported: dt f32 / bf16, nq, nv <= 1024, hidden % 8 == 0, hidden <= 2048. */
+ *   the number of non-zeros.  arg (nq, nv) int32 row stride ld_arg: the arg-max clips kept by xml_q2c_scores_arg (no
+ *   re-derivation: the pairs' rows are plain gathers), or NULL.
+ *   _supported: dt f32 / bf16, nq, nv <= 1024, hidden % 8 == 0, hidden <= 2048.
+ * xml_q2c_scores_arg: the forward pass for these in-batch scores -- xml_q2c_scores (same `combine`) on the UNPADDED
+ *   cn (nv, l, hidden) / mask (nv, l), l <= 128, that also writes arg[q, v] = the first clip attaining the maximum. */
 int xml_q2c_scores_l2norm_bwd_supported(int nq, int nv, int l, int hidden, int dt);
 int xml_q2c_scores_l2norm_bwd(const void* query, const void* feat, const void* qn, const void* cn, const float* mask,
                               const float* dscores, int64_t ld_ds, float scale, void* dq, void* dfeat, int nq, int nv, int l,
-                              int lpad, int hidden, int dt, xml_stream_t stream);
+                              int lpad, int hidden, const int32_t* arg, int64_t ld_arg, int dt, xml_stream_t stream);
+int xml_q2c_scores_arg(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int32_t* arg,
+                       int64_t ld_arg, int nq, int nv, int l, int hidden, int combine, int dt, xml_stream_t stream);
 /* The loss sum of XML.forward (xml/model_xml.py:241-251): parts4 = {w_st_ed * st_ed[0], w_neg_ctx * rank2[0],
  * w_neg_q * rank2[1], their sum}, overall[0] = the sum; st_ed / rank2 NULL: that term is 0.  _bwd: from the gradient g[0] of
  * the sum, d_st_ed[0] = w_st_ed g, d_rank2 = {w_neg_ctx g, w_neg_q g} (NULL: not wanted).  All device f32. */

@@ -190,6 +190,11 @@ def test_video_level_scores_backward_one_launch_vs_separate_kernels(nq, nv, l, h
     ds = ds.to(DEV)
     assert TO.q2c_scores_l2norm_bwd_supported(nq, nv, l, h, dt)
     dq, df = TO.q2c_scores_l2norm_bwd(query, feat, qn, cn_p, mk_p, ds, scale=0.5)
+    # ... and with the arg-max clips kept by the forward kernel (unpadded operands): the same rows, the same values
+    _, arg = TO.q2c_scores_arg(qn, cn, mask.contiguous())
+    dq2, df2 = TO.q2c_scores_l2norm_bwd(query, feat, qn, cn, mask.contiguous(), ds, scale=0.5, arg=arg)
+    check("dquery (arg kept)", dq2, dq, 1e-6)
+    check("dfeat (arg kept)", df2, df, 1e-6)
     dqn, dcn = TO.q2c_scores_bwd(qn, cn_p, mk_p, ds, scale=0.5)
     want_q, want_f = TO.l2norm_bwd(query, dqn), TO.l2norm_bwd(feat, dcn[:, :l].contiguous())
     tol = 2e-5 if dt == F32 else 8e-3           # bf16: one rounding of the outputs, different f32 summation orders
@@ -197,6 +202,46 @@ def test_video_level_scores_backward_one_launch_vs_separate_kernels(nq, nv, l, h
     check("dfeat", df, want_f, tol)
     assert torch.equal(df == 0, want_f == 0) or dt != F32      # the same rows are touched
     assert float(df.float().abs().sum()) > 0
+
+
+@pytest.mark.parametrize("nq,nv,l,h,dt", [(128, 128, 100, 768, torch.bfloat16), (40, 24, 19, 128, F32), (7, 300, 5, 64, torch.bfloat16),
+                                           (130, 9, 128, 256, F32), (1, 1, 1, 8, F32)])
+def test_q2c_scores_arg_forward(nq, nv, l, h, dt):
+    """xml_q2c_scores_arg (unpadded clips, arg-max kept) == xml_q2c_scores on the zero-padded operands, incl. combine; the
+    arg-max is the float64 arg-max wherever the top two clips are further apart than the f32 summation noise; a video whose
+    clips are all masked out reports clip 0."""
+    from tvretrieval_amd import ops, train_ops as TO
+    lpad = (l + 15) // 16 * 16
+    qn = ops.l2norm_rows(rnd(nq, h, seed=1).to(dt))
+    cn = ops.l2norm_rows(rnd(nv, l, h, seed=2).to(dt))
+    mask = lens_mask(nv, l, seed=3, lo=1)
+    if nv > 2:
+        mask[2] = 0
+    cn_p = torch.zeros(nv, lpad, h, dtype=dt, device=DEV)
+    mk_p = torch.zeros(nv, lpad, device=DEV)
+    cn_p[:, :l], mk_p[:, :l] = cn, mask
+    want = ops.q2c_scores(qn, cn_p, mk_p)
+    got, arg = TO.q2c_scores_arg(qn, cn, mask.contiguous())
+    assert float((got - want).abs().max()) <= 2e-6
+    s = torch.einsum("md,nld->mnl", qn.double(), cn.double())
+    s = s * mask.double()[None] + (1 - mask.double()[None]) * -1e10
+    top2 = torch.topk(s, min(2, l), dim=-1)
+    clear = (top2.values[..., 0] - top2.values[..., -1] > 1e-5) if l > 1 else torch.ones_like(s[..., 0], dtype=torch.bool)
+    assert torch.equal(arg.long()[clear], top2.indices[..., 0][clear])
+    assert float(clear.float().mean()) > 0.85 or nv <= 2
+    assert int(arg.min()) >= 0 and int(arg.max()) < l
+    if nv > 2:
+        assert int(arg[:, 2].abs().max()) == 0 and float(got[:, 2].max()) == -1e10
+    # combine: (previous + this) / 2, as xml_q2c_scores
+    prev = rnd(nq, nv, seed=9)
+    a, b = prev.clone(), prev.clone()
+    ops.q2c_scores(qn, cn_p, mk_p, out=a, combine=True)
+    TO.q2c_scores_arg(qn, cn, mask.contiguous(), out=b, combine=True)
+    assert float((a - b).abs().max()) <= 2e-6 * max(1.0, float(a.abs().max())) or nv > 2
+    if nv > 2:
+        keep = torch.ones(nv, dtype=torch.bool, device=DEV)
+        keep[2] = False
+        assert float((a - b)[:, keep].abs().max()) <= 2e-6
 
 
 def test_loss_combine_fn():

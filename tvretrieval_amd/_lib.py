@@ -167,7 +167,10 @@ SIGNATURES = {
     "xml_dropout": (c_int, [c_void_p, c_void_p, c_int64, c_float, ctypes.c_uint64, c_void_p, c_int, c_void_p]),
     "xml_q2c_scores_l2norm_bwd_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
     "xml_q2c_scores_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
-                                          c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+                                          c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
+                                          c_void_p]),
+    "xml_q2c_scores_arg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
+                                   c_int, c_int, c_int, c_void_p]),
     "xml_loss_combine": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "xml_loss_combine_bwd": (c_int, [c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "xml_transpose_segments": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),

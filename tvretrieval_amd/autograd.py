@@ -462,6 +462,16 @@ class VideoLevelScoresFn(torch.autograd.Function):
             lpad = (l + 15) // 16 * 16
             qn = ops.l2norm_rows(query)
             cn = ops.l2norm_rows(feat1)
+            if (FUSED_LOSS_TAIL and l <= 128 and hidden % 8 == 0 and
+                    T.q2c_scores_l2norm_bwd_supported(query.shape[0], n, l, hidden, query.dtype)):
+                # training form: unpadded clips, the arg-max clip kept for the one-launch backward (loss_tail.hip)
+                mk = mask.contiguous()
+                if scores is None:
+                    scores, arg = T.q2c_scores_arg(qn, cn, mk)
+                else:
+                    _, arg = T.q2c_scores_arg(qn, cn, mk, out=scores, combine=True)
+                saved += [query, feat1, qn, cn, mk, arg]
+                continue
             if lpad != l:
                 cn_p = torch.zeros((n, lpad, hidden), dtype=cn.dtype, device=cn.device)
                 mk_p = torch.zeros((n, lpad), dtype=F32, device=cn.device)
@@ -473,7 +483,7 @@ class VideoLevelScoresFn(torch.autograd.Function):
                 scores = ops.q2c_scores(qn, cn_p, mk_p)
             else:
                 ops.q2c_scores(qn, cn_p, mk_p, out=scores, combine=True)      # (a + b) / 2
-            saved += [query, feat1, qn, cn_p, mk_p]
+            saved += [query, feat1, qn, cn_p, mk_p, None]
         assert n_mod in (1, 2)
         ctx.n_mod = n_mod
         ctx.save_for_backward(*saved)
@@ -485,10 +495,10 @@ class VideoLevelScoresFn(torch.autograd.Function):
         dscores = dscores.contiguous()
         dq, df = [], []
         for i in range(n_mod):
-            query, feat1, qn, cn_p, mk_p = ctx.saved_tensors[5 * i:5 * i + 5]
-            if FUSED_LOSS_TAIL and T.q2c_scores_l2norm_bwd_supported(query.shape[0], feat1.shape[0], feat1.shape[1],
-                                                                     feat1.shape[2], query.dtype):
-                dq_i, df_i = T.q2c_scores_l2norm_bwd(query, feat1, qn, cn_p, mk_p, dscores, scale=1.0 / n_mod)
+            query, feat1, qn, cn_p, mk_p, arg = ctx.saved_tensors[6 * i:6 * i + 6]
+            if arg is not None or (FUSED_LOSS_TAIL and T.q2c_scores_l2norm_bwd_supported(
+                    query.shape[0], feat1.shape[0], feat1.shape[1], feat1.shape[2], query.dtype)):
+                dq_i, df_i = T.q2c_scores_l2norm_bwd(query, feat1, qn, cn_p, mk_p, dscores, scale=1.0 / n_mod, arg=arg)
                 dq.append(dq_i)
                 df.append(df_i)
                 continue

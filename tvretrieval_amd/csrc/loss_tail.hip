@@ -7,7 +7,7 @@
 //   xml_modular_pool_bwd        16-byte loads, clips in flight (was 124 us: one thread walked the clips one by one)
 //   xml_loss_combine            the weighted loss sum and its backward (was ~15 scalar torch kernels)
 // reference: get_video_level_scores xml/model_xml.py:436-453, get_modularized_queries :410-423, forward :241-251.
-#include "common.h"
+#include "gemm.h"
 #include "internal.h"
 
 namespace {
@@ -62,6 +62,92 @@ __device__ __forceinline__ int pair_argmax(const T* __restrict__ q, const T* __r
   return best_l;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// In-batch video-level scores with the arg-max clip kept (training forward).  Same tile scheme as q2c_scores_kernel
+// (q2c.hip): 128 queries x 128 clip columns per workgroup, a tile holds vpt = 128 / lpad whole videos, lpad = ceil16(L) --
+// but the clip rows are read from the UNPADDED (nv, L, hidden) tensor (columns >= L of a video are zero rows with mask 0), and
+// the epilogue carries (value, column) through the 16-lane and cross-tile reductions: first clip on ties.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int lane16_min_int_dpp(int v) {
+#define XML_ROR_I(x, n) __builtin_amdgcn_update_dpp(0x7fffffff, (x), 0x120 + (n), 0xf, 0xf, false)
+  v = min(v, XML_ROR_I(v, 8));
+  v = min(v, XML_ROR_I(v, 4));
+  v = min(v, XML_ROR_I(v, 2));
+  v = min(v, XML_ROR_I(v, 1));
+#undef XML_ROR_I
+  return v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void q2c_scores_arg_kernel(const T* __restrict__ qn, const T* __restrict__ cn,
+                                                             const float* __restrict__ mask, float* __restrict__ out,
+                                                             int64_t ld_out, int32_t* __restrict__ arg, int64_t ld_arg, int nq,
+                                                             int nv, int L, int lpad, int hidden, int combine, int tq) {
+  using Cfg = GemmCfg<T, 128, 128, 2, 2>;
+  __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
+  const int qt = blockIdx.x % tq, ct = blockIdx.x / tq;
+  const int vpt = 128 / lpad;
+  const int cols = vpt * lpad;
+  const int q0 = qt * 128, v0 = ct * vpt;
+
+  f32x4 acc[Cfg::MT][Cfg::NT];
+  auto a_row = [&](int r) -> const char* {
+    return (q0 + r) < nq ? reinterpret_cast<const char*>(qn + (int64_t)(q0 + r) * hidden) : nullptr;
+  };
+  auto b_row = [&](int r) -> const char* {
+    const int v = r / lpad, l = r - v * lpad;
+    return (r < cols && v0 + v < nv && l < L) ? reinterpret_cast<const char*>(cn + ((int64_t)(v0 + v) * L + l) * hidden)
+                                             : nullptr;
+  };
+  gemm_mainloop<T, Cfg>(acc, a_row, b_row, hidden * (int)sizeof(T), smem);
+
+  float* red_v = reinterpret_cast<float*>(smem);            // [128 rows][8 column tiles]
+  int* red_c = reinterpret_cast<int*>(smem) + 128 * 8;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int fr = lane & 15, fg = lane >> 4;
+  __syncthreads();                                          // (the mainloop's last LDS reads)
+#pragma unroll
+  for (int nt = 0; nt < Cfg::NT; ++nt) {
+    const int col = wn * 64 + nt * 16 + fr;
+    const int v = col / lpad, l = col - v * lpad;
+    const float m = (col < cols && v0 + v < nv && l < L) ? mask[(int64_t)(v0 + v) * L + l] : 0.f;
+    const float fill = (1.f - m) * -1e10f;
+#pragma unroll
+    for (int mt = 0; mt < Cfg::MT; ++mt) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float sv = acc[mt][nt][r] * m + fill;         // mask_logits, xml/model_xml.py:640-641
+        const float mx = lane16_max_dpp(sv);
+        const int c = lane16_min_int_dpp(sv == mx ? col : 0x7fffffff);
+        if (fr == 0) {
+          const int i = (wm * 64 + mt * 16 + fg * 4 + r) * 8 + wn * 4 + nt;
+          red_v[i] = mx;
+          red_c[i] = c;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const int tiles_per_video = lpad >> 4;
+  for (int i = threadIdx.x; i < 128 * vpt; i += 256) {
+    const int row = i % 128, v = i / 128;
+    if (q0 + row >= nq || v0 + v >= nv) continue;
+    float mx = -INFINITY;
+    int mc = 0;
+    for (int t = 0; t < tiles_per_video; ++t) {
+      const float x = red_v[row * 8 + v * tiles_per_video + t];
+      if (x > mx) { mx = x; mc = red_c[row * 8 + v * tiles_per_video + t]; }
+    }
+    mc -= v * lpad;
+    // every clip masked out: all columns tie at -1e10 (or the padding columns at -1e10 beat nothing): the first clip, as
+    // torch.max picks; a padding column (l >= L) can only win such a tie and never comes first
+    float* po = out + (int64_t)(q0 + row) * ld_out + v0 + v;
+    *po = combine ? (*po + mx) * 0.5f : mx;
+    arg[(int64_t)(q0 + row) * ld_arg + v0 + v] = mc < L ? mc : 0;
+  }
+}
+
 // In-order compaction of the non-zero entries of g[0 .. count) (stride `stride`) into s_idx / s_val (capacity cap, checked by
 // the caller: count <= cap).  Returns the number of entries; all threads see it after the trailing barrier.
 __device__ __forceinline__ int collect_active(const float* __restrict__ g, int64_t stride, int count, float scale, int* s_idx,
@@ -97,7 +183,8 @@ __global__ __launch_bounds__(256) void q2c_l2_bwd_kernel(const T* __restrict__ q
                                                          const T* __restrict__ qn, const T* __restrict__ cn,
                                                          const float* __restrict__ mask, const float* __restrict__ dscores,
                                                          int64_t ld_ds, float scale, T* __restrict__ dq, T* __restrict__ dfeat,
-                                                         int nq, int nv, int L, int lpad, int hidden, float eps) {
+                                                         int nq, int nv, int L, int lpad, int hidden, float eps,
+                                                         const int32_t* __restrict__ arg, int64_t ld_arg) {
   __shared__ int s_idx[Q2C_BWD_CAP];
   __shared__ float s_val[Q2C_BWD_CAP];
   __shared__ int s_l[Q2C_BWD_CAP];
@@ -115,7 +202,8 @@ __global__ __launch_bounds__(256) void q2c_l2_bwd_kernel(const T* __restrict__ q
     for (int j = 0; j < cnt; ++j) {
       const int n = s_idx[j];
       const T* cbase = cn + (int64_t)n * lpad * hidden;
-      const int bl = pair_argmax<T>(q, cbase, mask + (int64_t)n * lpad, L, hidden, s_best, s_bl);
+      const int bl = arg ? arg[(int64_t)m * ld_arg + n]          // kept by the forward pass (xml_q2c_scores_arg)
+                         : pair_argmax<T>(q, cbase, mask + (int64_t)n * lpad, L, hidden, s_best, s_bl);
       const float gm = s_val[j] * mask[(int64_t)n * lpad + bl];
       if (gm != 0.f && own) {
         float cv[8];
@@ -151,7 +239,8 @@ __global__ __launch_bounds__(256) void q2c_l2_bwd_kernel(const T* __restrict__ q
   const T* cbase = cn + (int64_t)n * lpad * hidden;
   const float* mrow = mask + (int64_t)n * lpad;
   for (int j = 0; j < cnt; ++j) {
-    const int bl = pair_argmax<T>(qn + (int64_t)s_idx[j] * hidden, cbase, mrow, L, hidden, s_best, s_bl);
+    const int bl = arg ? arg[(int64_t)s_idx[j] * ld_arg + n]
+                       : pair_argmax<T>(qn + (int64_t)s_idx[j] * hidden, cbase, mrow, L, hidden, s_best, s_bl);
     if (tid == 0) {
       s_l[j] = bl;
       s_val[j] *= mrow[bl];
@@ -368,20 +457,43 @@ extern "C" int xml_q2c_scores_l2norm_bwd_supported(int nq, int nv, int l, int hi
 
 extern "C" int xml_q2c_scores_l2norm_bwd(const void* query, const void* feat, const void* qn, const void* cn,
                                          const float* mask, const float* dscores, int64_t ld_ds, float scale, void* dq,
-                                         void* dfeat, int nq, int nv, int l, int lpad, int hidden, int dt,
-                                         xml_stream_t stream) {
+                                         void* dfeat, int nq, int nv, int l, int lpad, int hidden, const int32_t* arg,
+                                         int64_t ld_arg, int dt, xml_stream_t stream) {
   XML_ENTER();
   if (!query || !feat || !qn || !cn || !mask || !dscores || !dq || !dfeat || lpad < l || ld_ds < nv) return XML_ERR_BAD_ARG;
+  if (arg && ld_arg < nv) return XML_ERR_BAD_ARG;
   if (!xml_q2c_scores_l2norm_bwd_supported(nq, nv, l, hidden, dt)) return XML_ERR_UNSUPPORTED;
   const dim3 grid(nq + nv), blk(256);
   if (dt == XML_F32)
     hipLaunchKernelGGL(q2c_l2_bwd_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)query, (const float*)feat,
                        (const float*)qn, (const float*)cn, mask, dscores, ld_ds, scale, (float*)dq, (float*)dfeat, nq, nv, l,
-                       lpad, hidden, 1e-12f);
+                       lpad, hidden, 1e-12f, arg, ld_arg);
   else
     hipLaunchKernelGGL(q2c_l2_bwd_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)query,
                        (const bf16_t*)feat, (const bf16_t*)qn, (const bf16_t*)cn, mask, dscores, ld_ds, scale, (bf16_t*)dq,
-                       (bf16_t*)dfeat, nq, nv, l, lpad, hidden, 1e-12f);
+                       (bf16_t*)dfeat, nq, nv, l, lpad, hidden, 1e-12f, arg, ld_arg);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
+extern "C" int xml_q2c_scores_arg(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out,
+                                  int32_t* arg, int64_t ld_arg, int nq, int nv, int l, int hidden, int combine, int dt,
+                                  xml_stream_t stream) {
+  XML_ENTER();
+  if (!qn || !cn || !mask || !out || !arg || nq <= 0 || nv <= 0 || l <= 0 || hidden <= 0 || ld_out < nv || ld_arg < nv)
+    return XML_ERR_BAD_ARG;
+  if (l > 128 || hidden % 8) return XML_ERR_UNSUPPORTED;
+  const int lpad = (l + 15) / 16 * 16, vpt = 128 / lpad;
+  const int tq = cdiv(nq, 128), tc = cdiv(nv, vpt);
+  const dim3 grid((unsigned)((int64_t)tq * tc)), blk(256);
+  if (dt == XML_F32)
+    hipLaunchKernelGGL(q2c_scores_arg_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)qn, (const float*)cn,
+                       mask, out, ld_out, arg, ld_arg, nq, nv, l, lpad, hidden, combine, tq);
+  else if (dt == XML_BF16)
+    hipLaunchKernelGGL(q2c_scores_arg_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)qn,
+                       (const bf16_t*)cn, mask, out, ld_out, arg, ld_arg, nq, nv, l, lpad, hidden, combine, tq);
+  else
+    return XML_ERR_BAD_ARG;
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -293,8 +293,26 @@ def q2c_scores_l2norm_bwd_supported(nq, nv, l, hidden, dtype):
                                                                  (_lib.XML_BF16 if dtype == torch.bfloat16 else -1)))
 
 
-def q2c_scores_l2norm_bwd(query, feat, qn, cn_p, mask_p, dscores, scale=1.0):
-    """VideoLevelScoresFn backward of one modality in one launch -> (dquery, dfeat) in the activation dtype."""
+def q2c_scores_arg(qn, cn, mask, out=None, combine=False):
+    """In-batch video-level scores with the arg-max clips: qn (Nq, H), cn (Nv, L, H) normalised rows, mask (Nv, L) f32, all
+    unpadded (L <= 128) -> (out (Nq, Nv) f32 [averaged into `out` when combine], arg (Nq, Nv) int32)."""
+    _req(qn, "qn"); _req(cn, "cn", qn.dtype); _req(mask, "mask", F32)
+    nq, hidden = qn.shape
+    nv, l, _ = cn.shape
+    assert mask.shape == (nv, l) and cn.shape[2] == hidden
+    if out is None:
+        assert not combine
+        out = torch.empty((nq, nv), dtype=F32, device=qn.device)
+    _req(out, "out", F32)
+    arg = torch.empty((nq, nv), dtype=torch.int32, device=qn.device)
+    check(_lib.load().xml_q2c_scores_arg(_p(qn), _p(cn), _p(mask), _p(out), out.stride(0), _p(arg), arg.stride(0), nq, nv, l,
+                                         hidden, int(combine), dt_of(qn), _stream()), "xml_q2c_scores_arg")
+    return out, arg
+
+
+def q2c_scores_l2norm_bwd(query, feat, qn, cn_p, mask_p, dscores, scale=1.0, arg=None):
+    """VideoLevelScoresFn backward of one modality in one launch -> (dquery, dfeat) in the activation dtype.
+    arg: the (Nq, Nv) int32 arg-max clips of q2c_scores_arg, or None (re-derived per pair with a gradient)."""
     _req(query, "query"); _req(feat, "feat", query.dtype); _req(qn, "qn", query.dtype); _req(cn_p, "cn", query.dtype)
     _req(mask_p, "mask", F32); _req(dscores, "dscores", F32)
     nq, hidden = query.shape
@@ -302,9 +320,13 @@ def q2c_scores_l2norm_bwd(query, feat, qn, cn_p, mask_p, dscores, scale=1.0):
     lpad = cn_p.shape[1]
     assert cn_p.shape == (nv, lpad, hidden) and mask_p.shape == (nv, lpad) and dscores.shape == (nq, nv) and dscores.stride(1) == 1
     dq, df = torch.empty_like(query), torch.empty_like(feat)
+    if arg is not None:
+        _req(arg, "arg", torch.int32)
+        assert arg.shape == (nq, nv)
     check(_lib.load().xml_q2c_scores_l2norm_bwd(_p(query), _p(feat), _p(qn), _p(cn_p), _p(mask_p), _p(dscores),
                                                 dscores.stride(0), float(scale), _p(dq), _p(df), nq, nv, l, lpad, hidden,
-                                                dt_of(query), _stream()), "xml_q2c_scores_l2norm_bwd")
+                                                _p(arg), 0 if arg is None else arg.stride(0), dt_of(query), _stream()),
+          "xml_q2c_scores_l2norm_bwd")
     return dq, df
 
 

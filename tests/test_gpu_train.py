@@ -349,7 +349,7 @@ def test_rank_loss_fn(lse):
 
 def test_bert_adam_kernel_vs_oracle():
     from tvretrieval_amd.train import BertAdam
-    shapes = [(128, 96), (128,), (1, 1, 5), (40, 128), (3,), (257, 33)]
+    shapes = [(128, 96), (128,), (1, 1, 5), (40, 128), (3,), (257, 33), (300, 128), (4096,), (2, 4096), (1,)]
     ps = [torch.nn.Parameter(rnd(*s, seed=i, scale=0.05)) for i, s in enumerate(shapes)]
     names = ["w%d" % i for i in range(len(ps))]
     wd = {n: (0.01 if p.dim() > 1 else 0.0) for n, p in zip(names, ps)}

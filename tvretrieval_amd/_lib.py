@@ -181,7 +181,7 @@ SIGNATURES = {
                                        ctypes.c_uint64, c_void_p, c_void_p]),
     "xml_clip_grad_norm": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "xml_bert_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
-                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p]),
+                                   c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
 }
 
 _lib = None

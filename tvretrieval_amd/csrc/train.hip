@@ -532,6 +532,12 @@ static int ln_bwd_wide(const void* a, const float* g, const void* dy, void* dx, 
   return XML_OK;
 }
 
+// rows per wave of layernorm_bwd_kernel: a wave handles its rows one after the other, each a memory round trip plus four
+// dependent wave reductions, so the launch must be wide -- 16 rows per wave left 200 workgroups for the step's 12 800 rows
+// (58 us per call) -- but every workgroup ends in 2 d device-scope atomics on the same 2 d addresses: at 12 800 x 768 bf16,
+// 4 rows per wave (800 workgroups) 36 us, of which 14 us atomics; 8 rows per wave 26.5 us; 3 840 rows: 15 us (4) vs 17 us (8).
+static inline int ln_bwd_rows_per_wave(int64_t rows) { return rows >= 65536 ? 16 : rows >= 8192 ? 8 : rows >= 1024 ? 4 : 1; }
+
 // dx may be NULL only on the wide path (input features need no gradient); ws: rows*16 bytes, needed when d > 1024
 extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx,
                                  float* dg, float* dbeta, int64_t rows, int d, int dt, void* ws, size_t ws_bytes,
@@ -552,10 +558,7 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
     return XML_ERR_BAD_ARG;
   }
   if (!dx) return XML_ERR_BAD_ARG;
-  // rows per wave: a wave handles its rows one after the other, each a memory round trip plus four dependent wave
-  // reductions (~3.5 us), so the launch must be wide -- 16 rows per wave left 200 workgroups for the step's 12 800 rows
-  // (58 us per call); more workgroups cost d atomics each for dg / dbeta
-  const int rpw = rows >= 65536 ? 16 : (rows >= 1024 ? 4 : 1);
+  const int rpw = ln_bwd_rows_per_wave(rows);
   const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
   if (dt == XML_F32) {
     if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
@@ -595,7 +598,7 @@ extern "C" int xml_layernorm_bwd_drop(const void* a, int a_dt, const void* b, co
   }
   if (!dx || (din.thresh && !dxa)) return XML_ERR_BAD_ARG;
   if (!din.thresh) dxa = nullptr;
-  const int rpw = rows >= 65536 ? 16 : (rows >= 1024 ? 4 : 1);
+  const int rpw = ln_bwd_rows_per_wave(rows);
   const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
   if (dt == XML_F32) {
     if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
@@ -1486,6 +1489,65 @@ __global__ __launch_bounds__(256) void adam_norm_kernel(const float* __restrict_
     }
   }
 }
+// The same without the atomics of the common case (norm_ws given): a block that lies inside one tensor stores its partial sum
+// (loads issued before the tensor search); adam_norm_reduce_kernel -- one wave per tensor -- adds them up in a fixed order.
+// 4 930 device-scope atomics on ~100 addresses (576 of them on the largest tensor) made the kernel above 92 us for 80 MB.
+__global__ __launch_bounds__(256) void adam_norm_partial_kernel(const float* __restrict__ g, const int64_t* __restrict__ seg_off,
+                                                                int n_seg, int64_t total, float* __restrict__ norms,
+                                                                float* __restrict__ partials) {
+  __shared__ float s_part[4];
+  const int64_t base = (int64_t)blockIdx.x * 4096;
+  const int64_t last = base + 4095 < total ? base + 4095 : total - 1;
+  float4 v[4];
+  const bool vec_ok = (total & 3) == 0;                  // (tensors are padded to 4 elements: always, see BertAdam._flatten)
+#pragma unroll
+  for (int it = 0; it < 4; ++it) {
+    const int64_t i = base + it * 1024 + threadIdx.x * 4;
+    v[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (vec_ok && i + 3 < total) v[it] = *reinterpret_cast<const float4*>(g + i);
+  }
+  const int s_lo = find_seg(seg_off, n_seg, base);
+  const bool uniform = last < seg_off[s_lo + 1] && vec_ok;
+  if (uniform) {
+    float acc = 0.f;
+#pragma unroll
+    for (int it = 0; it < 4; ++it) acc += v[it].x * v[it].x + v[it].y * v[it].y + v[it].z * v[it].z + v[it].w * v[it].w;
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    return;
+  }
+  if (threadIdx.x == 0) partials[blockIdx.x] = 0.f;
+  const int lane = threadIdx.x & 63;
+  for (int it = 0; it < 16; ++it) {       // tensor boundary inside the block: segmented reduction per wave, atomics
+    const int64_t i = base + it * 256 + threadIdx.x;
+    const bool valid = i < total;
+    const int seg = valid ? find_seg(seg_off, n_seg, i) : -1;
+    const float val = valid ? g[i] * g[i] : 0.f;
+    unsigned long long todo = __ballot(valid);
+    while (todo) {
+      const int leader = __ffsll((long long)todo) - 1;
+      const int s_cur = __shfl(seg, leader);
+      const bool mine = valid && seg == s_cur;
+      const float part = wave_sum(mine ? val : 0.f);
+      if (lane == leader) unsafeAtomicAdd(norms + s_cur, part);
+      todo &= ~__ballot(mine);
+    }
+  }
+}
+__global__ __launch_bounds__(64) void adam_norm_reduce_kernel(const int64_t* __restrict__ seg_off, int n_seg, int64_t total,
+                                                              const float* __restrict__ partials, float* __restrict__ norms) {
+  const int s = blockIdx.x;
+  const bool vec_ok = (total & 3) == 0;
+  const int64_t b0 = (seg_off[s] + 4095) / 4096;
+  const int64_t b1 = s == n_seg - 1 ? (total + 4095) / 4096 : seg_off[s + 1] / 4096;
+  float acc = 0.f;
+  if (vec_ok)
+    for (int64_t b = b0 + threadIdx.x; b < b1; b += 64) acc += partials[b];
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0 && acc != 0.f) unsafeAtomicAdd(norms + s, acc);     // (after the boundary blocks' atomics: same stream)
+}
 // one element: the reference's update (xml/optimization.py:289-338) for element i of tensor s
 __device__ __forceinline__ void adam_update_one(float& pi, float& gi, float& mi, float& vi, bool& g_changed, float clip_coef,
                                                 float lr, float wd, float b1, float b2, float eps) {
@@ -1552,13 +1614,19 @@ __global__ __launch_bounds__(256) void adam_update_kernel(float* __restrict__ p,
 extern "C" int xml_bert_adam_step(float* p, float* g, float* m, float* v, const int64_t* seg_off, const float* seg_lr,
                                   const float* seg_wd, int n_seg, int64_t total, float lr_mult, float b1, float b2,
                                   float eps, float max_grad_norm, float* norms, const uint8_t* seg_active,
-                                  const float* seg_lr_mult, xml_stream_t stream) {
+                                  const float* seg_lr_mult, float* norm_ws, xml_stream_t stream) {
   XML_ENTER();
   if (!p || !g || !m || !v || !seg_off || !seg_lr || !seg_wd || !norms || n_seg <= 0 || total <= 0) return XML_ERR_BAD_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (max_grad_norm > 0.f) {
     if (!xml_zero_async(norms, (size_t)n_seg * 4, st)) return XML_ERR_LAUNCH;
-    hipLaunchKernelGGL(adam_norm_kernel, dim3(cdiv(total, 4096)), dim3(256), 0, st, g, seg_off, n_seg, total, norms);
+    if (norm_ws) {
+      hipLaunchKernelGGL(adam_norm_partial_kernel, dim3(cdiv(total, 4096)), dim3(256), 0, st, g, seg_off, n_seg, total, norms,
+                         norm_ws);
+      hipLaunchKernelGGL(adam_norm_reduce_kernel, dim3(n_seg), dim3(64), 0, st, seg_off, n_seg, total, norm_ws, norms);
+    } else {
+      hipLaunchKernelGGL(adam_norm_kernel, dim3(cdiv(total, 4096)), dim3(256), 0, st, g, seg_off, n_seg, total, norms);
+    }
   }
   hipLaunchKernelGGL(adam_update_kernel, dim3(cdiv(total, 1024)), dim3(256), 0, st, p, g, m, v, seg_off, seg_lr, seg_wd,
                      n_seg, total, norms, lr_mult, b1, b2, eps, max_grad_norm, seg_active, seg_lr_mult);

@@ -385,6 +385,7 @@ class BertAdam(object):
         self.seg_lr = torch.tensor(lrs, dtype=F32, device=dev)
         self.seg_wd = torch.tensor(wds, dtype=F32, device=dev)
         self.norms = torch.zeros(len(plist), dtype=F32, device=dev)
+        self.norm_ws = torch.zeros((total + 4095) // 4096, dtype=F32, device=dev)      # per-block partial sums of g^2
         # `if p.grad is None: continue` + per-tensor state['step'] (xml/optimization.py:289-291,325-330): a tensor takes
         # part in a step once it has EVER received a gradient (the reference's pinned torch 1.4 zero_grad() zeroes
         # existing .grad tensors in place, it does not reset them to None); its schedule counts its own steps.
@@ -576,7 +577,8 @@ class BertAdam(object):
             mult = 0.0
             seg_mult = torch.tensor(mults, dtype=F32, device=self.flat_p.device)
         T.bert_adam_step(self.flat_p, self.flat_g, self.flat_m, self.flat_v, self.seg_off, self.seg_lr, self.seg_wd,
-                         self.norms, mult, d["b1"], d["b2"], d["e"], d["max_grad_norm"], seg_active, seg_mult)
+                         self.norms, mult, d["b1"], d["b2"], d["e"], d["max_grad_norm"], seg_active, seg_mult,
+                         norm_ws=self.norm_ws)
         self._commit_step(active)
         return loss
 
@@ -680,7 +682,8 @@ class GraphedTrainStep(object):
         d = opt.defaults
         if captured:
             T.bert_adam_step(opt.flat_p, opt.flat_g, opt.flat_m, opt.flat_v, opt.seg_off, opt.seg_lr, opt.seg_wd, opt.norms,
-                             0.0, d["b1"], d["b2"], d["e"], d["max_grad_norm"], self.seg_active, self.lr_mult)
+                             0.0, d["b1"], d["b2"], d["e"], d["max_grad_norm"], self.seg_active, self.lr_mult,
+                             norm_ws=opt.norm_ws)
         else:
             opt.step()
         return loss.detach(), parts

@@ -433,9 +433,13 @@ def clip_grad_norm(flat_g, max_norm):
 
 
 def bert_adam_step(p, g, m, v, seg_off, seg_lr, seg_wd, norms, lr_mult, b1, b2, eps, max_grad_norm, seg_active=None,
-                   seg_lr_mult=None):
+                   seg_lr_mult=None, norm_ws=None):
+    """norm_ws: ceil(p.numel() / 4096) f32 of scratch (atomic-free gradient norms) or None."""
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (seg_lr, "seg_lr"), (seg_wd, "seg_wd"), (norms, "norms")):
         _req(t, nm, F32)
+    if norm_ws is not None:
+        _req(norm_ws, "norm_ws", F32)
+        assert norm_ws.numel() >= (p.numel() + 4095) // 4096, "bert_adam_step: norm_ws too small"
     _req(seg_off, "seg_off", torch.int64)
     if seg_active is not None:
         _req(seg_active, "seg_active", torch.uint8)
@@ -443,5 +447,6 @@ def bert_adam_step(p, g, m, v, seg_off, seg_lr, seg_wd, norms, lr_mult, b1, b2, 
         _req(seg_lr_mult, "seg_lr_mult", F32)
     check(_lib.load().xml_bert_adam_step(_p(p), _p(g), _p(m), _p(v), _p(seg_off), _p(seg_lr), _p(seg_wd),
                                          seg_lr.numel(), p.numel(), float(lr_mult), float(b1), float(b2), float(eps),
-                                         float(max_grad_norm), _p(norms), _p(seg_active), _p(seg_lr_mult), _stream()),
+                                         float(max_grad_norm), _p(norms), _p(seg_active), _p(seg_lr_mult), _p(norm_ws),
+                                         _stream()),
           "xml_bert_adam_step")

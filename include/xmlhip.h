@@ -422,8 +422,9 @@ int xml_relu_bwd(const void* y, const void* dy, void* dx, int64_t n, int dt, xml
 /* y (y_dt) += x (x_dt). */
 int xml_add_inplace(void* y, int y_dt, const void* x, int x_dt, int64_t n, xml_stream_t stream);
 /* LayerNorm backward of y = LN(a [+ b]) * g + beta: dx (grad of a and of b), dg +=, dbeta +=.
- *   d <= 1024: one wave per row.  d > 1024 (input LayerNorm over raw features): b must be NULL, dx may be NULL,
- *   ws = rows * 16 bytes of scratch. */
+ *   dx may be NULL (raw input features need no gradient: dg / dbeta only).
+ *   d <= 1024: one wave per row.  d > 1024 (input LayerNorm over raw features): b must be NULL,
+ *   ws = rows * 16 bytes of scratch (not needed when dx is NULL, bf16, d % 8 == 0, d <= 4096). */
 int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx,
                       float* dg, float* dbeta, int64_t rows, int d, int dt, void* ws, size_t ws_bytes,
                       xml_stream_t stream);
@@ -554,7 +555,8 @@ int xml_transpose_segments(const float* src, const int64_t* table, int n_ent, in
  * with xml_dropout's masks (element i of `a` / of `y`, seeds seed_in / seed_out [+ *seed_dev]); p_in / p_out = 0 switch a
  * site off.  a (a_dt f32 or dt), b (dt or NULL), y (dt) are (rows, d) contiguous, d % 8 == 0, d <= 4096; dt f32 or bf16.
  * xml_layernorm_bwd_drop is its backward pass: dy is masked with the output site, dx = gradient of b (and of a when
- * p_in == 0), dxa = gradient of a when p_in > 0 (required then, ignored otherwise); dg / dbeta f32 are accumulated into.
+ * p_in == 0; NULL: parameter gradients only), dxa = gradient of a when p_in > 0 (required then unless dx is NULL, ignored
+ * otherwise); dg / dbeta f32 are accumulated into.
  * d <= 1024: all of it.  1024 < d <= 4096: parameter gradients only (b, dx, dxa NULL, p_in == 0, dt bf16). */
 int xml_add_layernorm_drop(const void* a, int a_dt, const void* b, const float* g, const float* beta, void* y,
                            int64_t rows, int d, int dt, float p_in, uint64_t seed_in, float p_out, uint64_t seed_out,

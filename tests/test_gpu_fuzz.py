@@ -344,7 +344,7 @@ def test_fuzz_training_forward_backward_vs_oracle_autograd(seed):
     worst.sort(reverse=True)
     print("seed %d: %s cross=%s merge=%s %s h=%d l=%d bsz=%d: loss %.5f, worst gradient errors %s"
           % (seed, ctx_mode, cross, merge, cfg["ranking_loss_type"], hidden, l, bsz, float(loss), worst[:2]))
-    assert worst[0][0] < 1e-3, worst[:5]
+    assert worst[0][0] < 1e-3, [w for w in worst if w[0] >= 1e-3][:40]
 
 
 @pytest.mark.parametrize("seed", range(10))

@@ -81,6 +81,26 @@ def test_layernorm_fn(rows, d, resid):
              [needs_a, resid, True, True], tol=5e-5)
 
 
+def test_narrow_layernorm_backward_parameters_only():
+    """d <= 1024 with dx = NULL (the 768-d subtitle / query input LayerNorm: raw features need no gradient): dgamma / dbeta
+    equal those of the call that also writes dx; with and without the output dropout site."""
+    from tvretrieval_amd import train_ops as TO
+    rows, d = 3000, 768
+    a = rnd(rows, d, seed=1) * 2 + 0.3
+    dy = rnd(rows, d, seed=2).to(torch.bfloat16)
+    g = 1 + rnd(d, seed=3, scale=0.2)
+    dx0, dg0, db0 = TO.layernorm_bwd(a, None, g, dy, need_dx=False)
+    dx1, dg1, db1 = TO.layernorm_bwd(a, None, g, dy, need_dx=True)
+    assert dx0 is None and dx1 is not None
+    check("dgamma", dg0, dg1, 2e-6)
+    check("dbeta", db0, db1, 2e-6)
+    r0 = TO.layernorm_bwd_drop(a, None, g, dy, 0.0, 0, 0.1, 99, need_dx=False)
+    r1 = TO.layernorm_bwd_drop(a, None, g, dy, 0.0, 0, 0.1, 99, need_dx=True)
+    assert r0[0] is None and r0[1] is None and r1[0] is not None
+    check("dgamma (dropout site)", r0[2], r1[2], 2e-6)
+    check("dbeta (dropout site)", r0[3], r1[3], 2e-6)
+
+
 @pytest.mark.parametrize("rows,d,a_dt", [(5000, 3072, F32), (37, 3072, torch.bfloat16), (301, 2056, F32), (64, 4096, F32)])
 def test_wide_layernorm_backward_parameters_only(rows, d, a_dt):
     """the input LayerNorm of the 3072-d video features needs dgamma / dbeta only: xml_layernorm_bwd's one-pass kernel
@@ -927,6 +947,47 @@ def test_weight_shadows_equal_per_use_conversion_and_never_go_stale():
     for a, b in zip(*runs):
         assert abs(a - b) <= 2e-3 * max(1.0, abs(b)), runs
     assert runs[0][-1] < runs[0][0] - 0.02
+
+
+def test_two_stream_step_survives_a_caller_that_drops_its_batch():
+    """The subtitle branch runs on a side stream (train.PARALLEL_BRANCHES) and keeps the caller's feature / mask tensors for
+    its backward kernels.  A caller that passes temporaries lets the allocator take those blocks back as soon as autograd
+    releases them -- before the side stream's kernels have run, unless encode_context_train recorded the side stream on them.
+    Made deterministic here: the side stream is stalled in front of the backward pass, and the main stream refills every freed
+    block with garbage right after backward() returns.  Gradients must equal those of the one-stream run."""
+    import tvretrieval_amd.train as TR
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    if not cfg.get("cross_att", False):
+        pytest.skip("fixture without cross attention: no two-stream path")
+    m = build_train_model(cfg, d)
+    names = ("query_feat", "query_mask", "video_feat", "video_mask", "sub_feat", "sub_mask", "st_ed_indices")
+    kw = dict(neg_ctx_rank=d["neg_ctx_rank"], neg_q_rank=d["neg_q_rank"])
+
+    def grads():
+        return {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+    try:
+        TR.PARALLEL_BRANCHES = False
+        m.zero_grad()
+        TR.xml_forward_train(m, **{k: T(d[k]) for k in names}, **kw)[0].backward()
+        want = grads()
+        TR.PARALLEL_BRANCHES = True
+        side = TR._side_stream(DEV)
+        for _ in range(3):
+            m.zero_grad()
+            loss, _ = TR.xml_forward_train(m, **{k: T(d[k]) for k in names}, **kw)      # temporaries: autograd holds the last reference
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                torch.cuda._sleep(200_000_000)                                           # ~0.1 s: the side stream falls behind
+            loss.backward()
+            junk = [torch.full((int(d[k].size),), 7e3, device=DEV) for k in names for _ in range(4)]      # reuse what was freed
+            torch.cuda.synchronize()
+            del junk
+            got = grads()
+            for n, g in want.items():
+                if not n.endswith(".key.bias"):
+                    check(n, got[n], g, 5e-5)
+    finally:
+        TR.PARALLEL_BRANCHES = True
 
 
 def test_global_grad_clip():

@@ -339,6 +339,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
       pg[i] += dyv * xh;
       pb[i] += dyv;
     }
+    if (!dx) continue;                  // (block-uniform) parameter gradients only: the input needs no gradient
     s1 = wave_sum(s1) / (float)d;
     s2 = wave_sum(s2) / (float)d;
 #pragma unroll
@@ -538,7 +539,7 @@ static int ln_bwd_wide(const void* a, const float* g, const void* dy, void* dx, 
 // 4 rows per wave (800 workgroups) 36 us, of which 14 us atomics; 8 rows per wave 26.5 us; 3 840 rows: 15 us (4) vs 17 us (8).
 static inline int ln_bwd_rows_per_wave(int64_t rows) { return rows >= 65536 ? 16 : rows >= 8192 ? 8 : rows >= 1024 ? 4 : 1; }
 
-// dx may be NULL only on the wide path (input features need no gradient); ws: rows*16 bytes, needed when d > 1024
+// dx may be NULL (input features need no gradient: dg / dbeta only); ws: rows*16 bytes, needed when d > 1024 and dx is wanted
 extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx,
                                  float* dg, float* dbeta, int64_t rows, int d, int dt, void* ws, size_t ws_bytes,
                                  xml_stream_t stream) {
@@ -557,8 +558,7 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
     if (dt == XML_BF16 && a_dt == XML_BF16) return ln_bwd_wide<bf16_t, bf16_t>(a, g, dy, dx, dg, dbeta, rows, d, (float*)ws, st);
     return XML_ERR_BAD_ARG;
   }
-  if (!dx) return XML_ERR_BAD_ARG;
-  const int rpw = ln_bwd_rows_per_wave(rows);
+  const int rpw = ln_bwd_rows_per_wave(rows);      // (dx NULL: dg / dbeta only -- raw input features need no gradient)
   const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
   if (dt == XML_F32) {
     if (a_dt != XML_F32) return XML_ERR_BAD_ARG;
@@ -596,8 +596,8 @@ extern "C" int xml_layernorm_bwd_drop(const void* a, int a_dt, const void* b, co
     if (a_dt == XML_BF16) return ln_bwd_wide_params<bf16_t, bf16_t>(a, dy, dg, dbeta, rows, d, st, dout, seed_dev);
     return XML_ERR_BAD_ARG;
   }
-  if (!dx || (din.thresh && !dxa)) return XML_ERR_BAD_ARG;
-  if (!din.thresh) dxa = nullptr;
+  if (din.thresh && dx && !dxa) return XML_ERR_BAD_ARG;
+  if (!din.thresh || !dx) dxa = nullptr;
   const int rpw = ln_bwd_rows_per_wave(rows);
   const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
   if (dt == XML_F32) {

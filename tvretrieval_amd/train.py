@@ -166,6 +166,15 @@ def encode_context_train(model, video_feat, video_mask, sub_feat, sub_mask):
             dev = video_feat.device
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
             side.wait_stream(main)
+            # The caller's tensors were allocated on ITS stream but are read by kernels on the side stream, in this pass and --
+            # as saved tensors -- in the backward pass.  Tell the caching allocator: a caller that drops its batch before the
+            # backward kernels have run (a loop that loads the next batch, a test that passes temporaries) would otherwise get
+            # the block back at once and overwrite it under the side stream's feet (seen as an intermittently wrong
+            # sub_input_proj.LayerNorm.weight gradient: dgamma from overwritten features, dbeta right).
+            if not torch.cuda.is_current_stream_capturing():
+                for t in (sub_feat, sub_mask, video_mask):
+                    if t is not None and t.is_cuda:
+                        t.record_stream(side)
             ev = enc_v()
             with torch.cuda.stream(side):
                 es = enc_s()

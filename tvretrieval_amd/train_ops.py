@@ -72,7 +72,7 @@ def layernorm_bwd(a, b, g, dy, need_dx=True, dg=None, dbeta=None):
     dg = torch.zeros(d, dtype=F32, device=a.device) if dg is None else _req(dg, "dg", F32)
     dbeta = torch.zeros(d, dtype=F32, device=a.device) if dbeta is None else _req(dbeta, "dbeta", F32)
     wide = d > 1024 or d % 8 != 0
-    dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (need_dx or not wide) else None
+    dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if need_dx else None
     ws = _workspace(rows * 16, a.device) if wide else None
     check(_lib.load().xml_layernorm_bwd(_p(a), dt_of(a), _p(b), _p(g), _p(dy), _p(dx), _p(dg), _p(dbeta), rows, d,
                                         dt_of(dy), _p(ws), 0 if ws is None else ws.numel(), _stream()),
@@ -110,7 +110,7 @@ def layernorm_bwd_drop(a, b, g, dy, p_in, seed_in, p_out, seed_out, need_dx=True
     rows = a.numel() // d
     dg = torch.zeros(d, dtype=F32, device=a.device) if dg is None else _req(dg, "dg", F32)
     dbeta = torch.zeros(d, dtype=F32, device=a.device) if dbeta is None else _req(dbeta, "dbeta", F32)
-    dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (need_dx or d <= 1024) else None
+    dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if need_dx else None
     dxa = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (dx is not None and p_in > 0) else None
     check(_lib.load().xml_layernorm_bwd_drop(_p(a), dt_of(a), _p(b), _p(g), _p(dy), _p(dx), _p(dxa), _p(dg), _p(dbeta),
                                              rows, d, dt_of(dy), float(p_in), int(seed_in), float(p_out), int(seed_out),

@@ -1021,6 +1021,40 @@ def test_fused_qkv_self_attention():
     run_pair(hip, ref, args, [True, True, True, True, False, True, True], tol=5e-5)
 
 
+@pytest.mark.parametrize("p_drop", [0.0, 0.1])
+def test_cross_attention_stacked_key_value_projection(p_drop):
+    """bf16 cross attention with key + value of the other stream as ONE stacked projection (QkvFn with two weights +
+    AttentionKvFn) == two LinearFn + AttentionCoreFn: same GEMM operands column for column, same dropout mask (same seed),
+    so outputs are bitwise equal and gradients agree to the summation order of the f32 atomics."""
+    from tvretrieval_amd.autograd import AttentionCoreFn, AttentionKvFn, LinearFn, QkvFn
+    from tvretrieval_amd import train_ops as TO
+    bf = torch.bfloat16
+    n, lq, lk, hsz, heads, seed = 3, 100, 100, 768, 4, 4242
+    assert TO.attention_train_supported(lq, lk, hsz, heads, bf)
+    q0, side0 = rnd(n, lq, hsz, seed=1).to(bf), rnd(n, lk, hsz, seed=2).to(bf)
+    ws = [rnd(hsz, hsz, seed=10 + i, scale=0.05) for i in range(2)]
+    bs = [rnd(hsz, seed=20 + i, scale=0.1) for i in range(2)]
+    qm, km = lens_mask(n, lq, seed=4, lo=3), lens_mask(n, lk, seed=5, lo=5)
+    gout = rnd(n, lq, hsz, seed=6).to(bf)
+    res = []
+    for fused in (True, False):
+        q, side = q0.clone().requires_grad_(True), side0.clone().requires_grad_(True)
+        wk, wv = (w.clone().requires_grad_(True) for w in ws)
+        bk, bv = (b.clone().requires_grad_(True) for b in bs)
+        if fused:
+            out = AttentionKvFn.apply(q, QkvFn.apply(side, wk, bk, wv, bv), qm, km, heads, p_drop, seed)
+        else:
+            out = AttentionCoreFn.apply(q, LinearFn.apply(side, wk, bk, False), LinearFn.apply(side, wv, bv, False), qm, km,
+                                        heads, p_drop, seed)
+        out.backward(gout)
+        res.append((out.detach(), q.grad, side.grad, wk.grad, wv.grad, bv.grad))
+    assert torch.equal(res[0][0], res[1][0])
+    assert torch.equal(res[0][1], res[1][1])                      # dq: same kernel, same operands
+    check("dside", res[0][2], res[1][2], 1.2e-2)                  # one GEMM over 2H vs two over H, added in bf16
+    for name, i in (("dWk", 3), ("dWv", 4), ("dbv", 5)):
+        check(name, res[0][i], res[1][i], 2e-5)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("shape", [(1, 768, 768), (3, 104, 200), (1, 12800, 768), (2, 64, 64), (1, 50, 70),
                                    (2, 72, 3072), (1, 8, 8)])

@@ -150,11 +150,15 @@ def main():
     ap.add_argument("--separate-dropout", action="store_true", help="A/B: dropout sites as their own launches (train.FUSE_DROPOUT = False)")
     ap.add_argument("--no-shadows", action="store_true", help="A/B: convert / transpose every weight at its use (train.SHADOW_WEIGHTS = False)")
     ap.add_argument("--separate-loss-tail", action="store_true", help="A/B: autograd.FUSED_LOSS_TAIL = False")
+    ap.add_argument("--separate-kv", action="store_true", help="A/B: train.FUSE_KV = False")
     a = ap.parse_args()
     from tvretrieval_amd import launch
     if a.separate_loss_tail:
         import tvretrieval_amd.autograd as AG
         AG.FUSED_LOSS_TAIL = False
+    if a.separate_kv:
+        import tvretrieval_amd.train as TR
+        TR.FUSE_KV = False
     if a.no_shadows:
         import tvretrieval_amd.train as TR
         TR.SHADOW_WEIGHTS = False

@@ -323,20 +323,23 @@ class AttentionCoreFn(torch.autograd.Function):
 
 
 class QkvFn(torch.autograd.Function):
-    """The three projections of BertSelfAttention (xml/model_components.py:266-272) as ONE GEMM on the stacked weight
-    [Wq; Wk; Wv]: x (N, L, H) -> (N, L, 3H).  Backward: one dX GEMM, one split-K dW GEMM (3H x H), one column sum;
-    the input is transposed once instead of three times."""
+    """Several projections of the same input as ONE GEMM on the stacked weight: the three of BertSelfAttention
+    (xml/model_components.py:266-272), [Wq; Wk; Wv]: x (N, L, H) -> (N, L, 3H), or key + value of the cross attention
+    (xml/model_xml.py:357-373), x -> (N, L, 2H).  apply(x, w0, b0, w1, b1, ...), all weights (H, K).  Backward: one dX GEMM,
+    one split-K dW GEMM (nH x K), one column sum; the input is transposed once instead of n times."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv):
-        w = _weights((wq, wk, wv), x.dtype)
-        bf = _adjacent((bq, bk, bv), "flat_p")
-        b = bf.detach() if bf is not None else torch.cat([bq.detach(), bk.detach(), bv.detach()], 0).float().contiguous()
-        ctx.params = (wq, bq, wk, bk, wv, bv)
+    def forward(ctx, x, *wb):
+        ws, bs = tuple(wb[0::2]), tuple(wb[1::2])
+        assert len(ws) == len(bs) >= 2 and all(w_.shape == ws[0].shape for w_ in ws)
+        w = _weights(ws, x.dtype)
+        bf = _adjacent(bs, "flat_p")
+        b = bf.detach() if bf is not None else torch.cat([b_.detach() for b_ in bs], 0).float().contiguous()
+        ctx.params = tuple(wb)
         k = w.shape[1]
-        ctx.sunk = _claim(ctx, ctx.params, (1, 2, 3, 4, 5, 6),
-                          all(ctx.needs_input_grad[1:]) and _adjacent((wq, wk, wv), "flat_g") is not None and
-                          _adjacent((bq, bk, bv), "flat_g") is not None and
+        ctx.sunk = _claim(ctx, ctx.params, tuple(range(1, 1 + len(wb))),
+                          all(ctx.needs_input_grad[1:]) and _adjacent(ws, "flat_g") is not None and
+                          _adjacent(bs, "flat_g") is not None and
                           T.gemm_tn_supported(x.numel() // k, w.shape[0], k, x.dtype))
         ctx.save_for_backward(x, w)
         return ops.linear(x.contiguous(), w, b)
@@ -345,25 +348,52 @@ class QkvFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
-        n3, k = w.shape
-        h = n3 // 3
+        nh, k = w.shape
+        ws, bs = ctx.params[0::2], ctx.params[1::2]
+        h = nh // len(ws)
         rows = x.numel() // k
-        dy2, x2 = dy.view(rows, n3), x.contiguous().view(rows, k)
-        wq, bq, wk, bk, wv, bv = ctx.params
-        dx = ops.linear(dy2, _weights_t((wq, wk, wv), w)).view(x.shape) if ctx.needs_input_grad[0] else None
+        dy2, x2 = dy.view(rows, nh), x.contiguous().view(rows, k)
+        dx = ops.linear(dy2, _weights_t(ws, w)).view(x.shape) if ctx.needs_input_grad[0] else None
         if ctx.sunk:
             if all(_sink(p) is not None for p in ctx.params):
-                gw, gb = _adjacent((wq, wk, wv), "flat_g"), _adjacent((bq, bk, bv), "flat_g")
+                gw, gb = _adjacent(ws, "flat_g"), _adjacent(bs, "flat_g")
                 assert T.gemm_tn(dy2, x2, out=gw, colsum_out=gb)
-                return dx, None, None, None, None, None, None
-        dw = T.gemm_tn(dy2, x2, colsum=True)                                               # (3H, H) and the three bias gradients
+                return (dx,) + (None,) * len(ctx.params)
+        dw = T.gemm_tn(dy2, x2, colsum=True)                                               # (nH, K) and the n bias gradients
         if dw is None:
             r8 = _r8(rows)
             dw = T.gemm_batched(T.transpose(dy2, r8), T.transpose(x2, r8), out_f32=True)
-            db = T.colsum(dy2, rows, n3)
+            db = T.colsum(dy2, rows, nh)
         else:
             dw, db = dw
-        return dx, dw[:h], db[:h], dw[h:2 * h], db[h:2 * h], dw[2 * h:], db[2 * h:]
+        out = [dx]
+        for i in range(len(ws)):
+            out += [dw[i * h:(i + 1) * h], db[i * h:(i + 1) * h]]
+        return tuple(out)
+
+
+class AttentionKvFn(torch.autograd.Function):
+    """AttentionCoreFn with the keys and values as the column blocks of ONE (N, Lk, 2H) tensor (the stacked key / value
+    projection of the cross attention, QkvFn) -- fused bf16 kernels only: the caller checks attention_train_supported."""
+
+    @staticmethod
+    def forward(ctx, q, kv, q_mask, k_mask, heads, p_drop=0.0, seed=0):
+        q, kv = q.contiguous(), kv.contiguous()
+        hidden = q.shape[2]
+        assert kv.shape[2] == 2 * hidden and T.attention_train_supported(q.shape[1], kv.shape[1], hidden, heads, q.dtype)
+        ctx.cfg = (heads, p_drop, seed)
+        ctx.save_for_backward(q, kv, q_mask, k_mask)
+        return T.attention_train_fwd(q, kv, kv, q_mask, k_mask, heads, hidden, p_drop, seed, 0, 0, hidden)
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, kv, q_mask, k_mask = ctx.saved_tensors
+        heads, p_drop, seed = ctx.cfg
+        hidden = q.shape[2]
+        dq, dkv = torch.empty_like(q), torch.empty_like(kv)
+        T.attention_train_bwd(q, kv, kv, q_mask, k_mask, dout.contiguous(), dq, dkv, dkv, heads, hidden, p_drop, seed,
+                              0, 0, hidden, 0, 0, hidden)
+        return dq, dkv, None, None, None, None, None
 
 
 class AttentionQkvFn(torch.autograd.Function):

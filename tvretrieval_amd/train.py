@@ -23,7 +23,7 @@ import torch
 from . import ops
 from . import train_ops as T
 from . import autograd as _ag
-from .autograd import (AttentionCoreFn, AttentionQkvFn, CombineLossFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn,
+from .autograd import (AttentionCoreFn, AttentionKvFn, AttentionQkvFn, CombineLossFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn,
                        QkvFn, SpanLossFn, VideoLevelScoresFn)
 
 F32 = torch.float32
@@ -82,6 +82,7 @@ def _drop(x, module):
 
 
 SHADOW_WEIGHTS = True    # bf16 steps: weights converted / transposed once per step by the optimizer (BertAdam.refresh_shadows)
+FUSE_KV = True           # cross attention (bf16): key + value projections stacked into one GEMM (QkvFn) / one attention operand
 FUSE_DROPOUT = True      # dropout sites next to a LayerNorm run inside the LayerNorm kernels (same masks, 22 launches fewer)
 
 
@@ -131,9 +132,15 @@ def _cross_context(model, main, main_mask, side, side_mask, cross, norm, self_at
     """cross_context_encoder (xml/model_xml.py:357-373)."""
     dt = model.compute_dtype
     q = LinearFn.apply(main, cross.query.weight, cross.query.bias, False)
-    k = LinearFn.apply(side, cross.key.weight, cross.key.bias, False)
-    v = LinearFn.apply(side, cross.value.weight, cross.value.bias, False)
-    a = AttentionCoreFn.apply(q, k, v, main_mask, side_mask, cross.num_attention_heads, *_probs_drop(cross))
+    heads, hidden = cross.num_attention_heads, main.shape[2]
+    if FUSE_KV and main.is_cuda and T.attention_train_supported(main.shape[1], side.shape[1], hidden, heads, dt):
+        # key and value projections of the other stream as one GEMM each way (and one gradient fewer to add into `side`)
+        kv = QkvFn.apply(side, cross.key.weight, cross.key.bias, cross.value.weight, cross.value.bias)
+        a = AttentionKvFn.apply(q, kv, main_mask, side_mask, heads, *_probs_drop(cross))
+    else:
+        k = LinearFn.apply(side, cross.key.weight, cross.key.bias, False)
+        v = LinearFn.apply(side, cross.value.weight, cross.value.bias, False)
+        a = AttentionCoreFn.apply(q, k, v, main_mask, side_mask, heads, *_probs_drop(cross))
     res = LayerNormFn.apply(a, main, norm.weight, norm.bias, dt)
     return _bert_attention(self_att, res, main_mask, dt)
 

@@ -506,6 +506,13 @@ int xml_q2c_scores_l2norm_bwd_supported(int nq, int nv, int l, int hidden, int d
 int xml_q2c_scores_l2norm_bwd(const void* query, const void* feat, const void* qn, const void* cn, const float* mask,
                               const float* dscores, int64_t ld_ds, float scale, void* dq, void* dfeat, int nq, int nv, int l,
                               int lpad, int hidden, const int32_t* arg, int64_t ld_arg, int dt, xml_stream_t stream);
+/* xml_q2c_scores_l2norm_bwd for the n_mod (1 or 2) modalities of the model in ONE launch: every per-modality argument is a
+ * HOST array of n_mod entries (arg may be NULL, or hold NULL entries); dscores / scale / nq / nv / hidden are shared. */
+int xml_q2c_scores_l2norm_bwd_multi(int n_mod, const void* const* query, const void* const* feat, const void* const* qn,
+                                    const void* const* cn, const float* const* mask, const float* dscores, int64_t ld_ds,
+                                    float scale, void* const* dq, void* const* dfeat, int nq, int nv, const int* l,
+                                    const int* lpad, int hidden, const int32_t* const* arg, int64_t ld_arg, int dt,
+                                    xml_stream_t stream);
 int xml_q2c_scores_arg(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out, int32_t* arg,
                        int64_t ld_arg, int nq, int nv, int l, int hidden, int combine, int dt, xml_stream_t stream);
 /* The loss sum of XML.forward (xml/model_xml.py:241-251): parts4 = {w_st_ed * st_ed[0], w_neg_ctx * rank2[0],

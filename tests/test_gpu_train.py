@@ -215,6 +215,16 @@ def test_video_level_scores_backward_one_launch_vs_separate_kernels(nq, nv, l, h
     dq2, df2 = TO.q2c_scores_l2norm_bwd(query, feat, qn, cn, mask.contiguous(), ds, scale=0.5, arg=arg)
     check("dquery (arg kept)", dq2, dq, 1e-6)
     check("dfeat (arg kept)", df2, df, 1e-6)
+    # ... and both modalities in one launch (the second one: other values, no kept arg-max, padded clips)
+    query_b, feat_b = rnd(nq, h, seed=11).to(dt), rnd(nv, l, h, seed=12).to(dt)
+    qn_b, cn_b = ops.l2norm_rows(query_b), ops.l2norm_rows(feat_b)
+    cn_bp = torch.zeros(nv, lpad, h, dtype=dt, device=DEV)
+    cn_bp[:, :l] = cn_b
+    want_b = TO.q2c_scores_l2norm_bwd(query_b, feat_b, qn_b, cn_bp, mk_p, ds, scale=0.5)
+    got = TO.q2c_scores_l2norm_bwd_multi([(query, feat, qn, cn, mask.contiguous(), arg), (query_b, feat_b, qn_b, cn_bp, mk_p, None)],
+                                         ds, scale=0.5)
+    assert torch.equal(got[0][0], dq2) and torch.equal(got[0][1], df2)
+    assert torch.equal(got[1][0], want_b[0]) and torch.equal(got[1][1], want_b[1])
     dqn, dcn = TO.q2c_scores_bwd(qn, cn_p, mk_p, ds, scale=0.5)
     want_q, want_f = TO.l2norm_bwd(query, dqn), TO.l2norm_bwd(feat, dcn[:, :l].contiguous())
     tol = 2e-5 if dt == F32 else 8e-3           # bf16: one rounding of the outputs, different f32 summation orders

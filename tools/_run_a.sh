@@ -1,5 +1,4 @@
+timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -3
 for i in 1 2 3; do
 timeout 300 python tools/bench_train.py --graph --steps 30 --warmup 5 2>&1 | tail -n 1 | cut -c1-70
-timeout 300 python tools/bench_train.py --graph --steps 30 --warmup 5 --separate-kv 2>&1 | tail -n 1 | cut -c1-70
 done
-timeout 900 python -m pytest tests/test_gpu_train.py tests/test_gpu_fuzz.py -x -q -m gpu 2>&1 | tail -3

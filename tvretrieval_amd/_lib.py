@@ -169,6 +169,9 @@ SIGNATURES = {
     "xml_q2c_scores_l2norm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_float,
                                           c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_int,
                                           c_void_p]),
+    "xml_q2c_scores_l2norm_bwd_multi": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
+                                                c_float, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_int,
+                                                c_void_p, c_int64, c_int, c_void_p]),
     "xml_q2c_scores_arg": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int,
                                    c_int, c_int, c_int, c_void_p]),
     "xml_loss_combine": (c_int, [c_void_p, c_void_p, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p]),

@@ -524,6 +524,11 @@ class VideoLevelScoresFn(torch.autograd.Function):
         n_mod = ctx.n_mod
         dscores = dscores.contiguous()
         dq, df = [], []
+        sets = [ctx.saved_tensors[6 * i:6 * i + 6] for i in range(n_mod)]
+        if n_mod == 2 and all(s_[5] is not None for s_ in sets) and sets[0][0].shape == sets[1][0].shape and \
+                sets[0][1].shape[0] == sets[1][1].shape[0]:
+            res = T.q2c_scores_l2norm_bwd_multi(sets, dscores, scale=1.0 / n_mod)      # both modalities, one launch
+            return (None,) + tuple(r[0] for r in res) + tuple(r[1] for r in res) + (None,) * n_mod
         for i in range(n_mod):
             query, feat1, qn, cn_p, mk_p, arg = ctx.saved_tensors[6 * i:6 * i + 6]
             if arg is not None or (FUSED_LOSS_TAIL and T.q2c_scores_l2norm_bwd_supported(
@@ -552,6 +557,7 @@ class CombineLossFn(torch.autograd.Function):
         parts, overall = T.loss_combine(None if st_ed is None else st_ed.contiguous(),
                                         None if rank2 is None else rank2.contiguous(), *ctx.w)
         ctx.mark_non_differentiable(parts)
+        ctx.set_materialize_grads(False)
         return overall, parts
 
     @staticmethod

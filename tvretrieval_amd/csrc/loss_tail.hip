@@ -178,13 +178,36 @@ constexpr int Q2C_BWD_MAXH = 2048;
 
 // (F.normalize backward of a row, as in l2norm_bwd_kernel: dx = (dy - x (x . dy) / den^2) / den, den = max(|x|, eps); when
 // the norm is clamped it is a constant and only dy / den survives.)
+struct Q2cBwdSet {                      // one modality
+  const void *query, *feat, *qn, *cn;
+  const float* mask;
+  void *dq, *dfeat;
+  const int32_t* arg;
+  int L, lpad;
+};
+struct Q2cBwdArgs {
+  Q2cBwdSet s[2];                       // blockIdx.y picks the modality
+  const float* dscores;
+  int64_t ld_ds, ld_arg;
+  float scale, eps;
+  int nq, nv, hidden;
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void q2c_l2_bwd_kernel(const T* __restrict__ query, const T* __restrict__ feat,
-                                                         const T* __restrict__ qn, const T* __restrict__ cn,
-                                                         const float* __restrict__ mask, const float* __restrict__ dscores,
-                                                         int64_t ld_ds, float scale, T* __restrict__ dq, T* __restrict__ dfeat,
-                                                         int nq, int nv, int L, int lpad, int hidden, float eps,
-                                                         const int32_t* __restrict__ arg, int64_t ld_arg) {
+__global__ __launch_bounds__(256) void q2c_l2_bwd_kernel(Q2cBwdArgs a) {
+  const Q2cBwdSet& set = a.s[blockIdx.y];
+  const T* __restrict__ query = (const T*)set.query;
+  const T* __restrict__ feat = (const T*)set.feat;
+  const T* __restrict__ qn = (const T*)set.qn;
+  const T* __restrict__ cn = (const T*)set.cn;
+  const float* __restrict__ mask = set.mask;
+  const float* __restrict__ dscores = a.dscores;
+  T* __restrict__ dq = (T*)set.dq;
+  T* __restrict__ dfeat = (T*)set.dfeat;
+  const int32_t* __restrict__ arg = set.arg;
+  const int64_t ld_ds = a.ld_ds, ld_arg = a.ld_arg;
+  const float scale = a.scale, eps = a.eps;
+  const int nq = a.nq, nv = a.nv, L = set.L, lpad = set.lpad, hidden = a.hidden;
   __shared__ int s_idx[Q2C_BWD_CAP];
   __shared__ float s_val[Q2C_BWD_CAP];
   __shared__ int s_l[Q2C_BWD_CAP];
@@ -455,25 +478,46 @@ extern "C" int xml_q2c_scores_l2norm_bwd_supported(int nq, int nv, int l, int hi
          hidden % 8 == 0 && hidden > 0 && hidden <= Q2C_BWD_MAXH;
 }
 
+static int q2c_l2_bwd_launch(int n_mod, const void* const* query, const void* const* feat, const void* const* qn,
+                             const void* const* cn, const float* const* mask, const float* dscores, int64_t ld_ds, float scale,
+                             void* const* dq, void* const* dfeat, int nq, int nv, const int* l, const int* lpad, int hidden,
+                             const int32_t* const* arg, int64_t ld_arg, int dt, hipStream_t st) {
+  if (n_mod < 1 || n_mod > 2 || !dscores || ld_ds < nv) return XML_ERR_BAD_ARG;
+  Q2cBwdArgs a;
+  for (int m = 0; m < n_mod; ++m) {
+    if (!query[m] || !feat[m] || !qn[m] || !cn[m] || !mask[m] || !dq[m] || !dfeat[m] || lpad[m] < l[m]) return XML_ERR_BAD_ARG;
+    if (arg && arg[m] && ld_arg < nv) return XML_ERR_BAD_ARG;
+    if (!xml_q2c_scores_l2norm_bwd_supported(nq, nv, l[m], hidden, dt)) return XML_ERR_UNSUPPORTED;
+    a.s[m] = Q2cBwdSet{query[m], feat[m], qn[m], cn[m], mask[m], dq[m], dfeat[m], arg ? arg[m] : nullptr, l[m], lpad[m]};
+  }
+  if (n_mod == 1) a.s[1] = a.s[0];
+  a.dscores = dscores; a.ld_ds = ld_ds; a.ld_arg = ld_arg; a.scale = scale; a.eps = 1e-12f;
+  a.nq = nq; a.nv = nv; a.hidden = hidden;
+  const dim3 grid(nq + nv, n_mod), blk(256);
+  if (dt == XML_F32) hipLaunchKernelGGL(q2c_l2_bwd_kernel<float>, grid, blk, 0, st, a);
+  else hipLaunchKernelGGL(q2c_l2_bwd_kernel<bf16_t>, grid, blk, 0, st, a);
+  XML_CHECK_LAUNCH();
+  return XML_OK;
+}
+
 extern "C" int xml_q2c_scores_l2norm_bwd(const void* query, const void* feat, const void* qn, const void* cn,
                                          const float* mask, const float* dscores, int64_t ld_ds, float scale, void* dq,
                                          void* dfeat, int nq, int nv, int l, int lpad, int hidden, const int32_t* arg,
                                          int64_t ld_arg, int dt, xml_stream_t stream) {
   XML_ENTER();
-  if (!query || !feat || !qn || !cn || !mask || !dscores || !dq || !dfeat || lpad < l || ld_ds < nv) return XML_ERR_BAD_ARG;
-  if (arg && ld_arg < nv) return XML_ERR_BAD_ARG;
-  if (!xml_q2c_scores_l2norm_bwd_supported(nq, nv, l, hidden, dt)) return XML_ERR_UNSUPPORTED;
-  const dim3 grid(nq + nv), blk(256);
-  if (dt == XML_F32)
-    hipLaunchKernelGGL(q2c_l2_bwd_kernel<float>, grid, blk, 0, (hipStream_t)stream, (const float*)query, (const float*)feat,
-                       (const float*)qn, (const float*)cn, mask, dscores, ld_ds, scale, (float*)dq, (float*)dfeat, nq, nv, l,
-                       lpad, hidden, 1e-12f, arg, ld_arg);
-  else
-    hipLaunchKernelGGL(q2c_l2_bwd_kernel<bf16_t>, grid, blk, 0, (hipStream_t)stream, (const bf16_t*)query,
-                       (const bf16_t*)feat, (const bf16_t*)qn, (const bf16_t*)cn, mask, dscores, ld_ds, scale, (bf16_t*)dq,
-                       (bf16_t*)dfeat, nq, nv, l, lpad, hidden, 1e-12f, arg, ld_arg);
-  XML_CHECK_LAUNCH();
-  return XML_OK;
+  return q2c_l2_bwd_launch(1, &query, &feat, &qn, &cn, &mask, dscores, ld_ds, scale, &dq, &dfeat, nq, nv, &l, &lpad, hidden,
+                           &arg, ld_arg, dt, (hipStream_t)stream);
+}
+
+extern "C" int xml_q2c_scores_l2norm_bwd_multi(int n_mod, const void* const* query, const void* const* feat,
+                                               const void* const* qn, const void* const* cn, const float* const* mask,
+                                               const float* dscores, int64_t ld_ds, float scale, void* const* dq,
+                                               void* const* dfeat, int nq, int nv, const int* l, const int* lpad, int hidden,
+                                               const int32_t* const* arg, int64_t ld_arg, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!query || !feat || !qn || !cn || !mask || !dq || !dfeat || !l || !lpad) return XML_ERR_BAD_ARG;
+  return q2c_l2_bwd_launch(n_mod, query, feat, qn, cn, mask, dscores, ld_ds, scale, dq, dfeat, nq, nv, l, lpad, hidden, arg,
+                           ld_arg, dt, (hipStream_t)stream);
 }
 
 extern "C" int xml_q2c_scores_arg(const void* qn, const void* cn, const float* mask, float* out, int64_t ld_out,

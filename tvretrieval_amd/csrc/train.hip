@@ -1362,9 +1362,14 @@ extern "C" int xml_span_loss(const float* sim0, const float* sim1, const float* 
   } else {
     if (!dsim0 || !dconv_w || (n_sim == 2 && !dsim1)) return XML_ERR_BAD_ARG;
     const int n_filt = merged ? 1 : n_sim;
-    if (!xml_zero_async(dsim0, (size_t)n * l * 4, st)) return XML_ERR_LAUNCH;
-    if (n_sim == 2 && !xml_zero_async(dsim1, (size_t)n * l * 4, st)) return XML_ERR_LAUNCH;
-    if (!xml_zero_async(dconv_w, (size_t)2 * n_filt * ks * 4, st)) return XML_ERR_LAUNCH;
+    const size_t sb = (size_t)n * l * 4, cb = (size_t)2 * n_filt * ks * 4;
+    if (n_sim == 2 && (char*)dsim1 == (char*)dsim0 + sb && (char*)dconv_w == (char*)dsim1 + sb) {
+      if (!xml_zero_async(dsim0, 2 * sb + cb, st)) return XML_ERR_LAUNCH;      // caller laid the three out back to back: one fill
+    } else {
+      if (!xml_zero_async(dsim0, sb, st)) return XML_ERR_LAUNCH;
+      if (n_sim == 2 && !xml_zero_async(dsim1, sb, st)) return XML_ERR_LAUNCH;
+      if (!xml_zero_async(dconv_w, cb, st)) return XML_ERR_LAUNCH;
+    }
   }
   hipLaunchKernelGGL(span_loss_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, sim0, sim1, conv_w, mask0, mask1 ? mask1 : mask0,
                      st_ed, merged, n_sim, ks, n, l, gout, loss_out, dsim0, dsim1, dconv_w);

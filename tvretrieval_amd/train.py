@@ -245,7 +245,8 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
     enc_q = _encode_input(model, query_feat, query_mask, model.query_input_proj, model.query_encoder,
                           model.query_pos_embed)
     mq = ModularPoolFn.apply(enc_q, query_mask, model.modular_vector_mapping.weight)
-    video_query, sub_query = (mq[0], mq[1]) if mq.shape[0] == 2 else (mq[0], mq[0])
+    # (unbind, not mq[0] / mq[1]: its backward is one stack instead of two zero-fills, two copies and an add)
+    video_query, sub_query = mq.unbind(0) if mq.shape[0] == 2 else (mq[0], mq[0])
 
     names = [n for n, u in (("video", model.use_video), ("sub", model.use_sub)) if u]
     qs = dict(video=video_query, sub=sub_query)

@@ -330,6 +330,38 @@ def q2c_scores_l2norm_bwd(query, feat, qn, cn_p, mask_p, dscores, scale=1.0, arg
     return dq, df
 
 
+def q2c_scores_l2norm_bwd_multi(sets, dscores, scale=1.0):
+    """The same for both modalities in one launch.  sets: list (1 or 2) of (query, feat, qn, cn, mask, arg) with the shapes of
+    q2c_scores_l2norm_bwd (arg may be None) -> list of (dquery, dfeat)."""
+    _req(dscores, "dscores", F32)
+    n_mod = len(sets)
+    nq, hidden = sets[0][0].shape
+    nv = sets[0][1].shape[0]
+    outs, cols = [], [[] for _ in range(10)]
+    for query, feat, qn, cn_p, mask_p, arg in sets:
+        _req(query, "query"); _req(feat, "feat", query.dtype); _req(qn, "qn", query.dtype); _req(cn_p, "cn", query.dtype)
+        _req(mask_p, "mask", F32)
+        assert query.shape == (nq, hidden) and feat.shape[0] == nv and feat.shape[2] == hidden and query.dtype == sets[0][0].dtype
+        l, lpad = feat.shape[1], cn_p.shape[1]
+        assert cn_p.shape == (nv, lpad, hidden) and mask_p.shape == (nv, lpad)
+        if arg is not None:
+            _req(arg, "arg", torch.int32)
+            assert arg.shape == (nq, nv) and arg.stride(0) == nv
+        dq, df = torch.empty_like(query), torch.empty_like(feat)
+        outs.append((dq, df))
+        for c, v in zip(cols, (query, feat, qn, cn_p, mask_p, dq, df, arg)):
+            c.append(0 if v is None else v.data_ptr())
+        cols[8].append(l); cols[9].append(lpad)
+    assert dscores.shape == (nq, nv) and dscores.stride(1) == 1
+    vp = lambda vals: (ctypes.c_void_p * n_mod)(*vals)      # noqa: E731
+    ip = lambda vals: (ctypes.c_int * n_mod)(*vals)         # noqa: E731
+    check(_lib.load().xml_q2c_scores_l2norm_bwd_multi(n_mod, vp(cols[0]), vp(cols[1]), vp(cols[2]), vp(cols[3]), vp(cols[4]),
+                                                      _p(dscores), dscores.stride(0), float(scale), vp(cols[5]), vp(cols[6]),
+                                                      nq, nv, ip(cols[8]), ip(cols[9]), hidden, vp(cols[7]), nv,
+                                                      dt_of(sets[0][0]), _stream()), "xml_q2c_scores_l2norm_bwd_multi")
+    return outs
+
+
 def loss_combine(st_ed, rank2, w_st_ed, w_neg_ctx, w_neg_q):
     """-> (parts (4,) f32 [weighted st_ed, neg_ctx, neg_q, sum], overall 0-d f32); st_ed 0-d / rank2 (2,) f32 or None."""
     ref = st_ed if st_ed is not None else rank2
@@ -388,8 +420,13 @@ def span_loss(sims, conv_w, masks, st_ed, merged, ks, gout=None):
                                 ks, n, l, None, _p(loss), None, None, None, _stream()), "xml_span_loss")
         return loss[0]
     _req(gout, "gout", F32)
-    dsims = [torch.empty_like(s) for s in sims]
-    dconv = torch.empty_like(conv_w)
+    if n_sim == 2:          # one allocation [dsim0 | dsim1 | dconv_w]: xml_span_loss zero-fills it with one launch
+        buf = torch.empty(2 * n * l + conv_w.numel(), dtype=F32, device=sims[0].device)
+        dsims = [buf[:n * l].view(n, l), buf[n * l:2 * n * l].view(n, l)]
+        dconv = buf[2 * n * l:]
+    else:
+        dsims = [torch.empty_like(s) for s in sims]
+        dconv = torch.empty_like(conv_w)
     check(lib.xml_span_loss(_p(sims[0]), _p(s1), _p(conv_w), _p(masks[0]), _p(m1), _p(st_ed), int(merged), n_sim, ks, n,
                             l, _p(gout), None, _p(dsims[0]), _p(dsims[1]) if n_sim > 1 else None, _p(dconv),
                             _stream()), "xml_span_loss")

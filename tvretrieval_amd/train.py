@@ -635,6 +635,7 @@ class GraphedTrainStep(object):
         n = self.static["query_feat"].shape[0]
         self.neg_ctx = torch.ones(n, dtype=torch.int32, device=dev)
         self.neg_q = torch.ones(n, dtype=torch.int32, device=dev)
+        self._one = torch.ones((), dtype=F32, device=dev)
         self.seed_base = torch.zeros(1, dtype=torch.int64, device=dev)
         self.lr_mult = torch.ones(len(optimizer.params), dtype=F32, device=dev)
         # ---- warm-up on the side stream (workspaces, allocator pools, packed-weight caches), state restored afterwards
@@ -692,7 +693,7 @@ class GraphedTrainStep(object):
         if opt._reducer is not None:
             opt._reducer.begin()
         opt.flat_g.zero_()
-        loss.backward()
+        loss.backward(self._one)            # (a resident 1.0: no ones_like fill node in front of the backward pass)
         if opt._reducer is not None:
             opt._reducer.finish()           # leftover buckets + join the all-reduce stream
         if self.grad_clip != -1:

@@ -583,8 +583,10 @@ int xml_clip_grad_norm(float* g, int64_t n, float max_norm, float* ws, xml_strea
  *   seg_lr_mult (n_seg) f32 or NULL: per-tensor schedule multiplier replacing the scalar lr_mult -- the reference keeps
  *     state['step'] per tensor (:325-330), so tensors that join the training later (train_span_start_epoch) restart
  *     their warm-up;
- *   norm_ws: ceil(total / 4096) floats of device scratch or NULL.  Given: the per-tensor gradient norms are summed from
- *     per-block partials in a fixed order (20 us for 20 M parameters) instead of by one f32 atomic per block (92 us). */
+ *   norm_ws: ceil(total / XML_ADAM_NORM_BLOCK) floats of device scratch or NULL.  Given: the per-tensor gradient norms are
+ *     summed from per-block partials in a fixed order (25 us for 20 M parameters) instead of by one f32 atomic per block
+ *     (92 us). */
+#define XML_ADAM_NORM_BLOCK 1024
 int xml_bert_adam_step(float* p, float* g, float* m, float* v, const int64_t* seg_off, const float* seg_lr,
                        const float* seg_wd, int n_seg, int64_t total, float lr_mult, float b1, float b2,
                        float eps, float max_grad_norm, float* norms, const uint8_t* seg_active,

@@ -403,7 +403,7 @@ class BertAdam(object):
         self.seg_lr = torch.tensor(lrs, dtype=F32, device=dev)
         self.seg_wd = torch.tensor(wds, dtype=F32, device=dev)
         self.norms = torch.zeros(len(plist), dtype=F32, device=dev)
-        self.norm_ws = torch.zeros((total + 4095) // 4096, dtype=F32, device=dev)      # per-block partial sums of g^2
+        self.norm_ws = torch.zeros((total + 1023) // 1024, dtype=F32, device=dev)      # per-block partial sums of g^2
         # `if p.grad is None: continue` + per-tensor state['step'] (xml/optimization.py:289-291,325-330): a tensor takes
         # part in a step once it has EVER received a gradient (the reference's pinned torch 1.4 zero_grad() zeroes
         # existing .grad tensors in place, it does not reset them to None); its schedule counts its own steps.

@@ -471,12 +471,12 @@ def clip_grad_norm(flat_g, max_norm):
 
 def bert_adam_step(p, g, m, v, seg_off, seg_lr, seg_wd, norms, lr_mult, b1, b2, eps, max_grad_norm, seg_active=None,
                    seg_lr_mult=None, norm_ws=None):
-    """norm_ws: ceil(p.numel() / 4096) f32 of scratch (atomic-free gradient norms) or None."""
+    """norm_ws: ceil(p.numel() / 1024) f32 of scratch (XML_ADAM_NORM_BLOCK; atomic-free gradient norms) or None."""
     for t, nm in ((p, "p"), (g, "g"), (m, "m"), (v, "v"), (seg_lr, "seg_lr"), (seg_wd, "seg_wd"), (norms, "norms")):
         _req(t, nm, F32)
     if norm_ws is not None:
         _req(norm_ws, "norm_ws", F32)
-        assert norm_ws.numel() >= (p.numel() + 4095) // 4096, "bert_adam_step: norm_ws too small"
+        assert norm_ws.numel() >= (p.numel() + 1023) // 1024, "bert_adam_step: norm_ws too small"
     _req(seg_off, "seg_off", torch.int64)
     if seg_active is not None:
         _req(seg_active, "seg_active", torch.uint8)

@@ -2,7 +2,7 @@
 # HBM-side traffic and achieved bandwidth of the kernels of one bench step BESIDE K6 (top-k, ConvSE, moment top-n, the query
 # encoder's kernels): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (one pass each, --kernel-trace only) joined with the kernel
 # durations of a --stats pass.  FETCH_SIZE x2 on gfx950 (MI355X_MICROARCH.md HBM section), both counters in KiB.
-#   gpurun -- bash tools/tail_traffic.sh   -> gpurun_out/r03_tail_traffic.txt
+#   gpurun -- bash tools/tail_traffic.sh   -> gpurun_out/r04_tail_traffic.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras"
@@ -10,7 +10,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/tt_stats -o b -- $C
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/tt_$c -o b -- $CMD > /tmp/tt_$c.log 2>&1
 done
-python - > $OUT/r03_tail_traffic.txt <<'PY'
+python - > $OUT/r04_tail_traffic.txt <<'PY'
 import csv, glob, collections
 dur = {}
 for f in glob.glob("/tmp/tt_stats/**/*kernel_stats.csv", recursive=True):
@@ -34,4 +34,4 @@ for k, (ns, calls) in dur.items():
 for ns, k, calls, rd, wr in sorted(rows, reverse=True):
     print("%-64s %6d %10.1f %10.1f %10.1f %9.2f" % (k.split("(")[0][:64], calls, ns / 1e3, rd / 1e6, wr / 1e6, (rd + wr) / ns / 1e3))
 PY
-cat $OUT/r03_tail_traffic.txt
+cat $OUT/r04_tail_traffic.txt

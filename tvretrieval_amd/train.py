@@ -527,8 +527,10 @@ class BertAdam(object):
         if self._reducer is not None:
             self._reducer.begin()
         self.flat_g.zero_()
-        for p, o in zip(self.params, self.seg_off.tolist()):
-            if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * o:
+        base = self.flat_g.data_ptr()
+        for p, o in zip(self.params, self._offs):           # (host offsets: seg_off.tolist() was a device sync per step)
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * o:
                 p.grad = self.flat_g[o:o + p.numel()].view(p.shape)
 
     def lr_multiplier(self, step=None):

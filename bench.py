@@ -297,8 +297,17 @@ def run_extras(args, headline_qps):
         r["served_in_batches_of_50"] = bench_tvr_val.run(50)
         return r
 
+    def e2e():
+        import bench_e2e
+        r = bench_e2e.run(50)                       # the reference's eval_query_bsz (xml/config.py)
+        big = bench_e2e.run(1000, repeats=1)
+        r["eval_query_bsz_1000"] = {k: big[k] for k in ("total_s", "queries_per_s", "stage_s", "search_device_only_s",
+                                                        "search_host_overhead_s", "host_tail_s", "nms_s")}
+        return r
+
     leg("exact_rank", exact)
     leg("tvr_val", tvr_val)
+    leg("e2e_tvr_val", e2e)
     leg("c2", lambda: sub("c2", 20, 3))
     leg("c3r", lambda: sub("c3r", max(2, min(args.steps, 5)), 2))
 

@@ -397,6 +397,29 @@ int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const f
                        int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
                        xml_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * K10: the index tail of compute_query2ctx_info as a device epilogue -- one 16-byte record per list entry, so a query batch
+ * leaves the device in ONE copy and the host never loops over queries or list entries.
+ *   replaces np.unravel_index(flat, (max_n_videos, max_ctx_l, max_ctx_l)), sorted_q2c_indices[i, local],
+ *   st_idx.astype(np.float32) * clip_length, ed_idx.astype(np.float32) * clip_length + clip_length and the
+ *   video2idx[video_metas[meta]["vid_name"]] lookup (xml/inference.py:415-439); the VR list (:402-413); and, with
+ *   seconds = 0, the index part of get_svmr_res_from_st_ed_probs (:229-233).
+ *   flat  (nq, n) int32 row stride ld_in = xml_moment_topk's out_flat (< 0: no candidate), score (nq, n) f32 same stride
+ *   top_idx (nq, k) int32: video (meta) index of local rank r = flat / l_ref^2; NULL: row_vid[q] (SVMR: the query's one
+ *     video) or, when that is NULL too, r itself
+ *   meta2vid (n_videos) int32: meta index -> video2idx value, NULL = identity
+ *   seconds != 0: st = f32(st_idx) * clip_length, ed = f32(ed_idx) * clip_length + clip_length, each operation rounded to
+ *     f32 once (numpy float32 arithmetic, no fma); seconds == 0: st = st_idx, ed = ed_idx + 1 in clip units (exact) -- the
+ *     reference's SVMR tail scales these in float64 on the host
+ *   flat == NULL: the video-retrieval list -- top_idx (nq, n) stride ld_in, records {meta2vid[top_idx], 0, 0, score}
+ *   out (nq, n) xml_moment, row stride ld_out records, 16-byte aligned; entries without a candidate: {-1, 0, 0, 0}
+ *   out_count (nq) int32 or NULL: number of entries with a candidate (they form a prefix of the row)
+ * --------------------------------------------------------------------------------------------- */
+typedef struct { int32_t vid; float st; float ed; float score; } xml_moment;
+int xml_moments_decode(const int32_t* flat, const float* score, const int32_t* top_idx, const int32_t* row_vid,
+                       const int32_t* meta2vid, int nq, int n, int64_t ld_in, int k, int l_ref, float clip_length,
+                       int seconds, xml_moment* out, int64_t ld_out, int32_t* out_count, xml_stream_t stream);
+
 /* Row-wise LayerNorm of (a [+ b]) -- exposed for the host-side mirror and tests.
  *   y = LN(a + b) * g + beta;  a,b,y (rows, d) dt (b may be NULL), x_dt of `a` may be XML_F32. */
 int xml_add_layernorm(const void* a, int a_dt, const void* b, const float* g, const float* beta,
@@ -642,6 +665,15 @@ int xml_nms_vcmr_host(const int64_t* vid, const double* st, const double* ed, co
                       double thd, int max_before, int max_after, int32_t* out_index, int32_t* n_out);
 int xml_nms_svmr_host(const double* st, const double* ed, const double* score, int n, double thd,
                       int max_before, int max_after, int32_t* out_index, int32_t* n_out);
+/* The same for a whole result set at once: (nq, ld) arrays (the columns of K10's records widened to the Python types the
+ * reference operates on), count (nq) = valid entries per row; out_index (nq, ld_out >= max_after) int32 indices into each row,
+ * out_count (nq).  Queries are spread over n_threads host threads (0: one per hardware thread, at most 64). */
+int xml_nms_vcmr_batched_host(const int64_t* vid, const double* st, const double* ed, const double* score,
+                              const int32_t* count, int nq, int64_t ld, double thd, int max_before, int max_after,
+                              int32_t* out_index, int64_t ld_out, int32_t* out_count, int n_threads);
+int xml_nms_svmr_batched_host(const double* st, const double* ed, const double* score, const int32_t* count, int nq,
+                              int64_t ld, double thd, int max_before, int max_after, int32_t* out_index, int64_t ld_out,
+                              int32_t* out_count, int n_threads);
 
 #ifdef __cplusplus
 }

@@ -35,7 +35,7 @@ def test_every_header_symbol_is_exported_and_bound(lib):
 
 def test_abi_identity(lib):
     from tvretrieval_amd import _lib
-    assert lib.xml_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.xml_abi_version() == _lib.ABI_VERSION == 5
     assert lib.xml_build_arch() == b"gfx950"
     assert lib.xml_status_string(0) == b"ok"
     assert lib.xml_status_string(-2) == b"unsupported shape"
@@ -72,6 +72,13 @@ def test_round3_entries_validate_arguments(lib):
         lib.xml_linear_ln_relu_pos_workspace_bytes(175000, 768, 768, 1)
     assert lib.xml_linear_ln_relu_pos_packed(None, 0, None, 30, None, None, None, None, None, None, None, None, 10, 768, 768,
                                              1, None, 0, None) == -1
+
+
+def test_round5_entries_validate_arguments(lib):
+    """K10 (xml_moments_decode) and the batched host NMS (ABI 5) reject bad arguments before any launch / thread."""
+    assert lib.xml_moments_decode(None, None, None, None, None, 4, 8, 8, 2, 16, 1.5, 1, None, 8, None, None) == -1
+    assert lib.xml_nms_vcmr_batched_host(None, None, None, None, None, 1, 8, 0.5, 100, 100, None, 100, None, 0) == -1
+    assert lib.xml_nms_svmr_batched_host(None, None, None, None, 1, 8, 0.5, 100, 100, None, 100, None, 0) == -1
 
 
 def test_product_path_fails_loudly_without_gpu():

@@ -772,3 +772,56 @@ def test_linear_ln_relu_pos_packed_vs_oracle(ops, dtype, n, lq, d_in, h):
                                   dev(pe["LayerNorm.weight"]), dev(pe["LayerNorm.bias"]))
     sel = full.reshape(n * lq, h)[src[:rows].long()]
     close("packed vs padded K1+K2", got, sel, 2e-5 if dtype == torch.float32 else 3e-2, 0.0 if dtype == torch.float32 else 1.6e-2)
+
+
+@pytest.mark.parametrize("case", [(7, 50, 5, 32, 1.5), (33, 200, 100, 128, 1.5), (5, 1000, 3, 100, 0.7),
+                                  (300, 17, 100, 64, 2.0 / 3.0)])
+def test_moments_decode_vs_oracle(ops, case):
+    """K10 (xml_moments_decode) against the oracle's restatement of the reference's numpy tail (np.unravel_index, the local
+    rank -> meta index gather, float32 seconds; xml/inference.py:423-431): video ids and spans bit for bit -- also for clip
+    lengths whose float32 products round (the kernel must not contract mul + add into an fma) -- empty tails marked and
+    counted, the VR form, the SVMR form in clip units, and writing into a slice of a larger result buffer."""
+    from tvretrieval_amd.results import MOMENT_DTYPE
+    nq, n, k, l, clip = case
+    g = torch.Generator().manual_seed(nq * 1000 + n)
+    flat = torch.randint(0, k * l * l, (nq, n), generator=g).int()
+    cnt = torch.randint(0, n + 1, (nq,), generator=g)
+    cnt[0], cnt[-1] = n, 0
+    flat[torch.arange(n)[None, :] >= cnt[:, None]] = -1
+    score = torch.rand(nq, n, generator=g)
+    nv = 500
+    top = torch.stack([torch.randperm(nv, generator=g)[:k] for _ in range(nq)]).int()
+    meta2vid = torch.randperm(100000, generator=g)[:nv].int()
+    big = torch.full((nq + 5, n + 3, 4), -7, dtype=torch.int32, device=DEV)
+    bigc = torch.full((nq + 5,), -7, dtype=torch.int32, device=DEV)
+    rec, c = ops.moments_decode(score.to(DEV), flat=flat.to(DEV), top_idx=top.to(DEV), meta2vid=meta2vid.to(DEV), l_ref=l,
+                                clip_length=clip, seconds=True, out=big[2:2 + nq, :n], out_count=bigc[2:2 + nq])
+    torch.cuda.synchronize()
+    assert (big[:2] == -7).all() and (big[2 + nq:] == -7).all() and (big[:, n:] == -7).all() and (bigc[:2] == -7).all()
+    h = np.ascontiguousarray(rec.cpu().numpy()).view(MOMENT_DTYPE)[..., 0]
+    np.testing.assert_array_equal(c.cpu().numpy(), cnt.numpy())
+    valid = (flat >= 0).numpy()
+    vid, st_s, ed_s = O.unravel_moments(np.where(valid, flat.numpy(), 0), top.numpy(), l, clip_length=clip)
+    assert st_s.dtype == np.float32 and ed_s.dtype == np.float32
+    np.testing.assert_array_equal(h["vid"], np.where(valid, meta2vid.numpy()[vid], -1))
+    np.testing.assert_array_equal(h["st"], np.where(valid, st_s, 0))
+    np.testing.assert_array_equal(h["ed"], np.where(valid, ed_s, 0))
+    np.testing.assert_array_equal(h["score"], np.where(valid, score.numpy(), 0))
+    # SVMR form: one video per query, clip units (st_idx, ed_idx + 1); identity meta map
+    fl1 = torch.where(flat >= 0, flat % (l * l), flat)
+    rv = torch.randint(0, nv, (nq,), generator=g).int()
+    rec, c = ops.moments_decode(score.to(DEV), flat=fl1.to(DEV), row_vid=rv.to(DEV), l_ref=l, seconds=False)
+    h = rec.cpu().numpy().view(MOMENT_DTYPE)[..., 0]
+    si, ei = np.where(valid, fl1.numpy() // l, 0), np.where(valid, fl1.numpy() % l, 0)
+    np.testing.assert_array_equal(h["vid"], np.where(valid, rv.numpy()[:, None], -1))
+    np.testing.assert_array_equal(h["st"], np.where(valid, si, 0).astype(np.float32))
+    np.testing.assert_array_equal(h["ed"], np.where(valid, ei + 1, 0).astype(np.float32))
+    # VR form: [video_idx, 0, 0, score] for the first n_vr columns of the top-k lists
+    n_vr = min(k, 100)
+    w = torch.rand(nq, k, generator=g)
+    rec, c = ops.moments_decode(w.to(DEV), top_idx=top.to(DEV), meta2vid=meta2vid.to(DEV), n=n_vr)
+    h = rec.cpu().numpy().view(MOMENT_DTYPE)[..., 0]
+    assert h.shape == (nq, n_vr) and (c.cpu().numpy() == n_vr).all()
+    np.testing.assert_array_equal(h["vid"], meta2vid.numpy()[top.numpy()[:, :n_vr]])
+    np.testing.assert_array_equal(h["score"], w.numpy()[:, :n_vr])
+    assert (h["st"] == 0).all() and (h["ed"] == 0).all()

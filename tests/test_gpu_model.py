@@ -148,6 +148,35 @@ def test_golden_pipeline_fp32(name):
                                          max_n_videos=o["max_vcmr_video"], tasks=("SVMR", "VCMR", "VR"))
     for task in ("VR", "VCMR", "SVMR"):
         _compare_lists(res[task], d["res/" + task], task)
+        span = int if task == "VR" else float          # the reference's VR entries are [video_idx, 0, 0, score]
+        assert all(type(p[0]) is int and type(p[1]) is span and type(p[2]) is span and type(p[3]) is float
+                   for e in res[task] for p in e["predictions"]), "the reference's element types"
+    # the array form of the same results (what eval_epoch works on) and the device tuple vs the oracle's numpy tail
+    from tvretrieval_amd.results import MomentResults
+    with torch.no_grad():
+        arr = inf.compute_query2ctx_info(m, ds, opt, ctx, max_before_nms=o["max_before_nms"],
+                                         max_n_videos=o["max_vcmr_video"], tasks=("SVMR", "VCMR", "VR"), as_arrays=True)
+    for task in ("VR", "VCMR", "SVMR"):
+        assert isinstance(arr[task], MomentResults) and arr[task].to_list() == res[task]
+    meta_vid = np.array([ds.video2idx["vid_%03d" % i] for i in range(ds.n_v)])
+    v = arr["VCMR"]
+    bs = o["eval_query_bsz"]
+    for b in range(0, ds.n_q, bs):          # the driver's own batching: the same launches, bit for bit
+        e = min(ds.n_q, b + bs)
+        with torch.no_grad():
+            qf, qm = inf.pad_batch([d["query_feat/%d" % i] for i in range(b, e)], DEV)
+            out = inf.vcmr_search(m, ctx["index"], qf, qm, max_vcmr_video=o["max_vcmr_video"],
+                                  max_before_nms=o["max_before_nms"], q2c_alpha=o["q2c_alpha"],
+                                  min_pred_l=o["min_pred_l"], max_pred_l=o["max_pred_l"])
+        fi, ti = out["flat_indices"].cpu().numpy(), out["top_indices"].cpu().numpy()
+        ok = fi >= 0
+        vid, st_s, ed_s = O.unravel_moments(np.where(ok, fi, 0), ti, ctx["index"].l_ref, clip_length=o["clip_length"])
+        n = fi.shape[1]
+        np.testing.assert_array_equal(v.count[b:e], ok.sum(1))
+        np.testing.assert_array_equal(v.vid[b:e, :n], np.where(ok, meta_vid[vid], -1))
+        np.testing.assert_array_equal(v.st[b:e, :n], np.where(ok, st_s, 0).astype(np.float64))
+        np.testing.assert_array_equal(v.ed[b:e, :n], np.where(ok, ed_s, 0).astype(np.float64))
+        np.testing.assert_array_equal(v.score[b:e, :n], np.where(ok, out["flat_scores"].cpu().numpy(), 0).astype(np.float64))
 
 
 def test_golden_external_vr_fp32(tmp_path):

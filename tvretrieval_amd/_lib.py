@@ -17,7 +17,7 @@ XML_BF16 = 1
 XML_F16 = 2       # IEEE half rows: the exact-rank FILTER operands of K6
 XML_F16S = 3      # split f16 (hi + lo halves, 4 bytes per element): f32-grade values on the 16-bit MFMA pipe
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class XmlHipError(RuntimeError):
@@ -112,6 +112,12 @@ SIGNATURES = {
                                   c_void_p]),
     "xml_nms_svmr_host": (c_int, [c_void_p, c_void_p, c_void_p, c_int, ctypes.c_double, c_int, c_int, c_void_p,
                                   c_void_p]),
+    "xml_nms_vcmr_batched_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, ctypes.c_double,
+                                          c_int, c_int, c_void_p, c_int64, c_void_p, c_int]),
+    "xml_nms_svmr_batched_host": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, ctypes.c_double, c_int,
+                                          c_int, c_void_p, c_int64, c_void_p, c_int]),
+    "xml_moments_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
+                                   c_float, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "xml_add_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
                                   c_void_p]),
     # ---- multi-GPU collectives (collectives.hip) ----

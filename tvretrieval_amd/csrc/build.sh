@@ -8,7 +8,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-SRCS="api.hip linear.hip gemm256.hip gemm256p.hip attention.hip attention_train.hip q2c.hip q2c_ring.hip q2c_persist.hip topk.hip convse.hip moment.hip postproc.hip train.hip gemm_tn.hip index_build.hip collectives.hip exact.hip split16.hip loss_tail.hip"
+SRCS="api.hip linear.hip gemm256.hip gemm256p.hip attention.hip attention_train.hip q2c.hip q2c_ring.hip q2c_persist.hip topk.hip convse.hip moment.hip decode.hip postproc.hip train.hip gemm_tn.hip index_build.hip collectives.hip exact.hip split16.hip loss_tail.hip"
 DBG_SRCS="q2c256.hip q2c_persist4.hip q2c_persist32.hip"
 
 build() {   # $1 = object dir, $2 = extra flags, $3 = output, $4.. = sources
@@ -31,6 +31,12 @@ build() {   # $1 = object dir, $2 = extra flags, $3 = output, $4.. = sources
 }
 
 build build "" libxmlhip.so $SRCS
+# libxmlpy.so: the reference's nested-list result format built against the CPython API (host only; ctypes.PyDLL)
+PYINC=$(python3 -c "import sysconfig; print(sysconfig.get_paths()['include'])")
+if [ ! -f libxmlpy.so ] || [ pylists.c -nt libxmlpy.so ]; then
+  gcc -O2 -fPIC -shared -Wall -I"$PYINC" pylists.c -o libxmlpy.so
+  echo "built $(pwd)/libxmlpy.so"
+fi
 if [ "${XML_DEBUG:-0}" = "1" ]; then
   build build_dbg "-DXML_DEBUG_VARIANTS" libxmlhip_dbg.so $SRCS $DBG_SRCS
 fi

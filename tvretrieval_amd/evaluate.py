@@ -25,15 +25,29 @@ def compute_temporal_iou_batch(preds, gt):
 def eval_by_task_type(moment_predictions, video2idx, ground_truth, iou_thds=(0.5, 0.7), recall_topks=(1, 5, 10, 100),
                       task_type="SVMR", max_pred_per_query=100, match_number=True, verbose=True, use_desc_type=True):
     assert task_type in TASK_TYPES
-    pred_by_id = {e["desc_id"]: e for e in moment_predictions}
+    from .results import MomentResults
+    arrays = isinstance(moment_predictions, MomentResults)     # the engine's (Nq, n) columns: no per-query list walking
+    if arrays:
+        pred_by_id = {d: i for i, d in enumerate(moment_predictions.desc_ids)}
+    else:
+        pred_by_id = {e["desc_id"]: e for e in moment_predictions}
     gt_by_id = {e["desc_id"]: e for e in ground_truth}
     if match_number:
         assert set(gt_by_id.keys()) == set(pred_by_id.keys()), "desc_ids in predictions and ground_truth must match"
     keys = [k for k in gt_by_id if match_number or k in pred_by_id]
     n_desc = len(keys)
-    n_pred = max(min(len(pred_by_id[k]["predictions"]), max_pred_per_query) for k in keys)
-    P = np.zeros((n_desc, n_pred, 3), dtype=np.float32)       # [vid, st, ed], zero padded like pad_sequences_1d_np
-    valid = np.zeros((n_desc, n_pred), dtype=bool)
+    if arrays:
+        rows = np.array([pred_by_id[k] for k in keys], dtype=np.int64)
+        cnt = np.minimum(moment_predictions.count[rows], max_pred_per_query)
+        n_pred = int(cnt.max())
+        P = np.zeros((n_desc, n_pred, 3), dtype=np.float32)   # [vid, st, ed], zero padded like pad_sequences_1d_np
+        valid = np.arange(n_pred)[None, :] < cnt[:, None]
+        for c, col in enumerate((moment_predictions.vid, moment_predictions.st, moment_predictions.ed)):
+            P[..., c] = np.where(valid, col[rows, :n_pred], 0)
+    else:
+        n_pred = max(min(len(pred_by_id[k]["predictions"]), max_pred_per_query) for k in keys)
+        P = np.zeros((n_desc, n_pred, 3), dtype=np.float32)       # [vid, st, ed], zero padded like pad_sequences_1d_np
+        valid = np.zeros((n_desc, n_pred), dtype=bool)
     gt_vid = np.zeros(n_desc, dtype=np.float32)
     desc_types = np.zeros(n_desc, dtype=np.int64)
     n_ts = max(len(gt_by_id[k]["ts"]) if len(gt_by_id[k]["ts"]) >= 4 else 1 for k in keys)
@@ -41,10 +55,11 @@ def eval_by_task_type(moment_predictions, video2idx, ground_truth, iou_thds=(0.5
     n_gt = np.ones(n_desc, dtype=np.int64)
     for i, k in enumerate(keys):
         g = gt_by_id[k]
-        pr = [e[:3] for e in pred_by_id[k]["predictions"]][:max_pred_per_query]
-        if len(pr):
-            P[i, :len(pr)] = np.asarray(pr, dtype=np.float32)
-            valid[i, :len(pr)] = True
+        if not arrays:
+            pr = [e[:3] for e in pred_by_id[k]["predictions"]][:max_pred_per_query]
+            if len(pr):
+                P[i, :len(pr)] = np.asarray(pr, dtype=np.float32)
+                valid[i, :len(pr)] = True
         gt_vid[i] = video2idx[g["vid_name"]]
         if use_desc_type:
             desc_types[i] = DESC_TYPE2IDX[g["type"]]

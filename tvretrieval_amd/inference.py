@@ -131,15 +131,18 @@ def index_lpad(l_ref, model, ops=hip_ops):
 
 
 def pad_batch(seqs, device=None, dtype=torch.float32):
-    """pad_sequences_1d (utils/tensor_utils.py:5-53) for a list of (L_i, D) arrays -> (N, Lmax, D), (N, Lmax)."""
-    lens = [len(s) for s in seqs]
-    lmax = max(lens)
-    first = torch.as_tensor(seqs[0])
-    out = torch.zeros((len(seqs), lmax) + tuple(first.shape[1:]), dtype=dtype)
-    mask = torch.zeros((len(seqs), lmax), dtype=torch.float32)
-    for i, s in enumerate(seqs):
-        out[i, :lens[i]] = torch.as_tensor(s, dtype=dtype)
-        mask[i, :lens[i]] = 1
+    """pad_sequences_1d (utils/tensor_utils.py:5-53) for a list of (L_i, D) arrays -> (N, Lmax, D), (N, Lmax).
+    One concatenate + one masked assignment instead of a Python loop of per-sequence tensor copies (50 ms -> 2 ms for a
+    batch of 50 queries: the loop, not the device, was what eval_epoch waited for)."""
+    n = len(seqs)
+    arrs = [s.detach().cpu().numpy() if isinstance(s, torch.Tensor) else np.asarray(s) for s in seqs]
+    lens = np.fromiter((len(a) for a in arrs), dtype=np.int64, count=n)
+    lmax = int(lens.max())
+    valid = np.arange(lmax)[None, :] < lens[:, None]
+    np_dtype = torch.empty(0, dtype=dtype).numpy().dtype
+    out = np.zeros((n, lmax) + tuple(arrs[0].shape[1:]), dtype=np_dtype)
+    out[valid] = np.concatenate(arrs, axis=0)
+    out, mask = torch.from_numpy(out), torch.from_numpy(valid.astype(np.float32))
     if device is not None:
         out, mask = out.to(device, non_blocking=True), mask.to(device, non_blocking=True)
     return out, mask
@@ -731,14 +734,38 @@ def decode_flat(flat, l_ref):
     return r, rem // l_ref, rem % l_ref
 
 
+class _ResultSink(object):
+    """Device-side result buffer of one task for a whole query set: K10 writes each batch's 16-byte records into its rows,
+    the host fetches the buffer ONCE at the end (no per-batch synchronisation, no per-query Python)."""
+
+    def __init__(self, n_queries, width, device):
+        self.rec = torch.empty((n_queries, width, 4), dtype=torch.int32, device=device)
+        self.cnt = torch.zeros((n_queries,), dtype=torch.int32, device=device)
+        self.n = 0
+
+    def rows(self, b, nb):
+        self.n = max(self.n, b + nb)
+        return dict(out=self.rec[b:b + nb], out_count=self.cnt[b:b + nb])
+
+    def fetch(self, desc_ids, descs, scale=None, int_spans=False):
+        from .results import MOMENT_DTYPE, MomentResults
+        n = self.n
+        rec = self.rec[:n].cpu().numpy().view(MOMENT_DTYPE)[..., 0]
+        return MomentResults.from_records(desc_ids[:n], descs[:n], rec, self.cnt[:n].cpu().numpy(), scale=scale,
+                                          int_spans=int_spans)
+
+
 def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=1000, max_n_videos=100,
-                           tasks=("SVMR",), ops=hip_ops):
+                           tasks=("SVMR",), ops=hip_ops, as_arrays=False):
     """Mirror of compute_query2ctx_info (xml/inference.py:252-445).  Same result dict:
     {"VCMR"|"SVMR"|"VR": [dict(desc_id, desc, predictions=[[video_idx, st, ed, score], ...]), ...]}.
     opt.external_inference_vr_res_path (xml/inference.py:264-273,349-355): re-rank the videos of another model's VR
     submission instead of this model's own top-k.
     opt.pad_tail=True (not a reference option): every list has max_before_nms rows like the reference's -- zero-score rows
-    where fewer candidates exist -- instead of the positive-score prefix."""
+    where fewer candidates exist -- instead of the positive-score prefix.
+    as_arrays=True: each task as a results.MomentResults (the (Nq, n) columns K10 produced) instead of nested lists; the
+    reference's "numpy tail" (:391-445) is the device epilogue xml_moments_decode either way -- the lists, when asked for,
+    are built from the columns in one C call (results.MomentResults.to_list)."""
     is_svmr, is_vr, is_vcmr = "SVMR" in tasks, "VR" in tasks, "VCMR" in tasks
     index = ctx_info["index"]
     video2idx = eval_dataset.video2idx
@@ -753,16 +780,23 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
         external_query2video = {e["desc_id"]: e["predictions"] for e in ext}
         video_idx2meta_idx = {video2idx[m["vid_name"]]: i for i, m in enumerate(video_metas)}
     meta_vid = np.array([video2idx[m["vid_name"]] for m in video_metas])
+    meta2vid = torch.from_numpy(meta_vid.astype(np.int32)).to(opt.device)
     eval_dataset.set_data_mode("query")
     eval_dataset.load_gt_vid_name_for_query(is_svmr)
     name2meta = {e["vid_name"]: i for i, e in enumerate(video_metas)}
     clip = opt.clip_length
     l_ref = index.l_ref
     n = len(eval_dataset)
-    res = dict(SVMR=[], VCMR=[], VR=[])
+    sink_vcmr = _ResultSink(n, max_before_nms, opt.device) if is_vcmr else None
+    sink_svmr = _ResultSink(n, max_before_nms, opt.device) if is_svmr else None
+    sink_vr = None
+    desc_ids, descs = [], []
     for b in range(0, n, opt.eval_query_bsz):
         items = [eval_dataset[i] for i in range(b, min(n, b + opt.eval_query_bsz))]
         metas = [e["meta"] for e in items]
+        nb = len(metas)
+        desc_ids.extend(m["desc_id"] for m in metas)
+        descs.extend(m["desc"] for m in metas)
         qf, qm = pad_batch([e["model_inputs"]["query_feat"] for e in items], opt.device)
         gt = None
         if is_svmr:
@@ -776,48 +810,55 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
         out = vcmr_search(model, index, qf, qm, max_vcmr_video=max_n_videos, max_before_nms=max_before_nms,
                           q2c_alpha=opt.q2c_alpha, min_pred_l=opt.min_pred_l, max_pred_l=opt.max_pred_l,
                           svmr_video=gt, ops=ops, external_top=external_top, pad_tail=getattr(opt, "pad_tail", False))
-        host = {k: v.cpu().numpy() for k, v in out.items() if v is not None and k not in ("q2c", "exact")}
-        for i, m in enumerate(metas):
-            if is_vr:
-                preds = [[int(meta_vid[v]), 0, 0, float(s)] for v, s in
-                         zip(host["top_indices"][i][:100], host["top_scores"][i][:100])]
-                res["VR"].append(dict(desc_id=m["desc_id"], desc=m["desc"], predictions=preds))
-            if is_vcmr:
-                valid = host["flat_indices"][i] >= 0
-                r, si, ei = decode_flat(host["flat_indices"][i][valid], l_ref)
-                vids = meta_vid[host["top_indices"][i][r]]
-                st_s = si.astype(np.float32) * clip
-                ed_s = ei.astype(np.float32) * clip + clip
-                preds = [[int(v), float(a), float(e), float(s)] for v, a, e, s in
-                         zip(vids, st_s, ed_s, host["flat_scores"][i][valid])]
-                res["VCMR"].append(dict(desc_id=m["desc_id"], desc=m["desc"], predictions=preds))
-            if is_svmr:
-                valid = host["svmr_flat"][i] >= 0
-                _, si, ei = decode_flat(host["svmr_flat"][i][valid], l_ref)
-                vid = int(video2idx[m["vid_name"]])
-                preds = [[vid, float(a * clip), float((e + 1) * clip), float(s)] for a, e, s in
-                         zip(si, ei, host["svmr_scores"][i][valid])]
-                res["SVMR"].append(dict(desc_id=m["desc_id"], desc=m["desc"], predictions=preds))
+        # K10 on the device: (flat index, local rank) -> [video_idx, st, ed, score] records (xml/inference.py:402-439)
+        if is_vr:
+            n_vr = min(100, out["top_indices"].shape[1])
+            if sink_vr is None:
+                sink_vr = _ResultSink(n, n_vr, opt.device)
+            ops.moments_decode(out["top_scores"], top_idx=out["top_indices"], meta2vid=meta2vid, n=n_vr,
+                               **sink_vr.rows(b, nb))
+        if is_vcmr:
+            ops.moments_decode(out["flat_scores"], flat=out["flat_indices"], top_idx=out["top_indices"], meta2vid=meta2vid,
+                               l_ref=l_ref, clip_length=clip, seconds=True, **sink_vcmr.rows(b, nb))
+        if is_svmr:     # clip units on the device; the float64 scaling of get_svmr_res_from_st_ed_probs (:229-233) on the host
+            ops.moments_decode(out["svmr_scores"], flat=out["svmr_flat"], row_vid=gt, meta2vid=meta2vid, l_ref=l_ref,
+                               seconds=False, **sink_svmr.rows(b, nb))
         if getattr(opt, "debug", False):
             break
-    return {k: v for k, v in res.items() if len(v) != 0}
+    res = {}
+    if is_svmr:
+        res["SVMR"] = sink_svmr.fetch(desc_ids, descs, scale=clip)
+    if is_vcmr:
+        res["VCMR"] = sink_vcmr.fetch(desc_ids, descs)
+    if is_vr and sink_vr is not None:
+        res["VR"] = sink_vr.fetch(desc_ids, descs, int_spans=True)
+    res = {k: v for k, v in res.items() if len(v) != 0}
+    if not as_arrays:
+        from .results import to_lists
+        res = to_lists(res)
+    return res
 
 
 def compute_query2ctx_info_svmr_only(model, eval_dataset, opt, ctx_info, max_before_nms=1000, max_n_videos=200,
-                                     tasks=("SVMR",), ops=hip_ops):
+                                     tasks=("SVMR",), ops=hip_ops, as_arrays=False):
     """Mirror of compute_query2ctx_info_svmr_only (xml/inference.py:107-167): every query is scored against its
     ground-truth video only (K7 with one pair per query + K9 with k = 1); no corpus-wide similarity."""
     index = ctx_info["index"]
     video2idx = eval_dataset.video2idx
-    name2meta = {e["vid_name"]: i for i, e in enumerate(ctx_info["video_metas"])}
+    video_metas = ctx_info["video_metas"]
+    name2meta = {e["vid_name"]: i for i, e in enumerate(video_metas)}
+    meta2vid = torch.tensor([video2idx[m["vid_name"]] for m in video_metas], dtype=torch.int32).to(opt.device)
     eval_dataset.set_data_mode("query")
     eval_dataset.load_gt_vid_name_for_query(True)
     clip, l_ref = opt.clip_length, index.l_ref
-    res = []
     n = len(eval_dataset)
+    sink = _ResultSink(n, max_before_nms, opt.device)
+    desc_ids, descs = [], []
     for b in range(0, n, opt.eval_query_bsz):
         items = [eval_dataset[i] for i in range(b, min(n, b + opt.eval_query_bsz))]
         metas = [e["meta"] for e in items]
+        desc_ids.extend(m["desc_id"] for m in metas)
+        descs.extend(m["desc"] for m in metas)
         qf, qm = pad_batch([e["model_inputs"]["query_feat"] for e in items], opt.device)
         gt = torch.tensor([name2meta[m["vid_name"]] for m in metas], dtype=torch.int32, device=opt.device)
         qvec = stage_query_vectors(model, qf, qm)
@@ -825,61 +866,90 @@ def compute_query2ctx_info_svmr_only(model, eval_dataset, opt, ctx_info, max_bef
         ss, sf = ops.moment_topk(st1, ed1, None, l_ref, opt.min_pred_l, opt.max_pred_l, max_before_nms)
         if getattr(opt, "pad_tail", False):
             pad_moment_tail(ss, sf, 1, l_ref, opt.min_pred_l, opt.max_pred_l)
-        ss, sf = ss.cpu().numpy(), sf.cpu().numpy()
-        for i, m in enumerate(metas):
-            valid = sf[i] >= 0
-            _, si, ei = decode_flat(sf[i][valid], l_ref)
-            vid = int(video2idx[m["vid_name"]])
-            preds = [[vid, float(a * clip), float((e + 1) * clip), float(s)] for a, e, s in zip(si, ei, ss[i][valid])]
-            res.append(dict(desc_id=m["desc_id"], desc=m["desc"], predictions=preds))
+        ops.moments_decode(ss, flat=sf, row_vid=gt, meta2vid=meta2vid, l_ref=l_ref, seconds=False, **sink.rows(b, len(metas)))
         if getattr(opt, "debug", False):
             break
-    return dict(SVMR=res)
+    res = sink.fetch(desc_ids, descs, scale=clip)
+    return dict(SVMR=res if as_arrays else res.to_list())
 
 
-def get_eval_res(model, eval_dataset, opt, tasks, max_after_nms, ops=hip_ops):
+def get_eval_res(model, eval_dataset, opt, tasks, max_after_nms, ops=hip_ops, as_arrays=False):
     """Mirror of get_eval_res (xml/inference.py:448-464)."""
     context_info = compute_context_info(model, eval_dataset, opt, ops=ops)
     if "VCMR" in tasks or "VR" in tasks:
         eval_res = compute_query2ctx_info(model, eval_dataset, opt, context_info, max_before_nms=opt.max_before_nms,
-                                          max_n_videos=opt.max_vcmr_video, tasks=tasks, ops=ops)
+                                          max_n_videos=opt.max_vcmr_video, tasks=tasks, ops=ops, as_arrays=as_arrays)
     else:
         eval_res = compute_query2ctx_info_svmr_only(model, eval_dataset, opt, context_info,
                                                     max_before_nms=opt.max_before_nms, max_n_videos=max_after_nms,
-                                                    tasks=tasks, ops=ops)
+                                                    tasks=tasks, ops=ops, as_arrays=as_arrays)
     eval_res["video2idx"] = eval_dataset.video2idx
     return eval_res
 
 
-def eval_epoch(model, eval_dataset, opt, tasks=("SVMR",), max_after_nms=100, ground_truth=None, ops=hip_ops):
+def eval_epoch(model, eval_dataset, opt, tasks=("SVMR",), max_after_nms=100, ground_truth=None, ops=hip_ops,
+               as_arrays=False, timings=None, ctx_info=None):
     """The in-memory part of eval_epoch (xml/inference.py:473-531): raw results -> top-n submission -> metrics, and
     the same again after temporal NMS when opt.nms_thd != -1.  (File writing stays with the caller.)
     Returns (submission, metrics, submission_after_nms, metrics_after_nms).
+
+    Everything between the device and the metrics works on (Nq, n) arrays (results.MomentResults: K10's records, one D2H per
+    task; batched NMS; the evaluator's array path); the reference's nested lists are built once at the end for the two
+    returned submissions -- or not at all with as_arrays=True (the tasks stay MomentResults; `.to_list()` on demand).
+    timings: dict that receives the wall-clock split {search, top_n, eval, nms, eval_nms, lists} in seconds.
+    ctx_info: a compute_context_info result to reuse (skips the corpus encode).
 
     Reference quirk kept on purpose: get_submission_top_n truncates the RAW lists in place (clip_alignment_with_language/
     inference.py:503-515), so the NMS stage (xml/inference.py:507-515) only ever sees the first max_after_nms (100)
     candidates, not max_before_nms, and the after-NMS metrics are computed with eval_retrieval's default
     use_desc_type=True.  opt.nms_on_full_lists=True runs NMS on the untruncated lists instead (not the reference)."""
+    import time
     from . import evaluate, postproc
-    raw = get_eval_res(model, eval_dataset, opt, tasks, max_after_nms, ops=ops)
-    import copy
-    full = copy.deepcopy(raw) if getattr(opt, "nms_on_full_lists", False) else None
+    from .results import to_lists
+    t = [time.perf_counter()]
+
+    def lap(name):
+        t.append(time.perf_counter())
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + t[-1] - t[-2]
+    if ctx_info is None:
+        raw = get_eval_res(model, eval_dataset, opt, tasks, max_after_nms, ops=ops, as_arrays=True)
+    elif "VCMR" in tasks or "VR" in tasks:
+        raw = compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=opt.max_before_nms,
+                                     max_n_videos=opt.max_vcmr_video, tasks=tasks, ops=ops, as_arrays=True)
+        raw["video2idx"] = eval_dataset.video2idx
+    else:
+        raw = compute_query2ctx_info_svmr_only(model, eval_dataset, opt, ctx_info, max_before_nms=opt.max_before_nms,
+                                               max_n_videos=max_after_nms, tasks=tasks, ops=ops, as_arrays=True)
+        raw["video2idx"] = eval_dataset.video2idx
+    lap("search")
+    full = None
+    if getattr(opt, "nms_on_full_lists", False):
+        full = {k: (v if k == "video2idx" else v.copy()) for k, v in raw.items()}
     submission = postproc.get_submission_top_n(raw, top_n=max_after_nms)      # truncates `raw` in place, like the reference
     if full is not None:
         raw = full
+    lap("top_n")
     use_desc_type = getattr(opt, "dset_name", "tvr") == "tvr"
     metrics = None
     if ground_truth is not None:
         metrics = evaluate.eval_retrieval(submission, ground_truth, iou_thds=(0.5, 0.7), verbose=False,
                                           match_number=not getattr(opt, "debug", False), use_desc_type=use_desc_type)
+    lap("eval")
     sub_nms = metrics_nms = None
     if getattr(opt, "nms_thd", -1) != -1:
         sub_nms = dict(video2idx=raw["video2idx"])
         for k, fn in (("SVMR", postproc.post_processing_svmr_nms), ("VCMR", postproc.post_processing_vcmr_nms)):
             if k in raw:
-                sub_nms[k] = fn(copy.deepcopy(raw[k]), nms_thd=opt.nms_thd, max_before_nms=opt.max_before_nms,
-                                max_after_nms=max_after_nms)
+                sub_nms[k] = fn(raw[k], nms_thd=opt.nms_thd, max_before_nms=opt.max_before_nms,
+                                max_after_nms=max_after_nms)         # (arrays in, new arrays out: nothing to deep-copy)
+        lap("nms")
         if ground_truth is not None:
             metrics_nms = evaluate.eval_retrieval(sub_nms, ground_truth, iou_thds=(0.5, 0.7), verbose=False,
                                                   match_number=not getattr(opt, "debug", False))
+        lap("eval_nms")
+    if not as_arrays:
+        submission = to_lists(submission)
+        sub_nms = to_lists(sub_nms) if sub_nms is not None else None
+        lap("lists")
     return submission, metrics, sub_nms, metrics_nms

@@ -619,6 +619,38 @@ def moment_topk(st, ed, w, l_ref, min_l, max_l, n_out, summ=None):
     return sc, fl
 
 
+def moments_decode(scores, flat=None, top_idx=None, row_vid=None, meta2vid=None, l_ref=0, clip_length=1.5, seconds=True,
+                   n=None, out=None, out_count=None):
+    """K10.  (flat (Nq, n) int32, scores (Nq, n) f32) -> records (Nq, n, 4) int32 = xml_moment {vid i32, st f32, ed f32,
+    score f32} (view the host copy as results.MOMENT_DTYPE) and count (Nq,) int32.
+    top_idx (Nq, K) int32: video of local rank r; row_vid (Nq,) int32: the one video of each query (SVMR); meta2vid (Nv,)
+    int32: meta index -> video2idx value.  flat=None: the VR list of top_idx[:, :n] / scores[:, :n].
+    out / out_count: write into these rows of a larger result buffer ((Nq, >= n, 4) int32 / (Nq,) int32 views)."""
+    _req(scores, "scores", torch.float32)
+    nq = scores.shape[0]
+    n = scores.shape[1] if n is None else int(n)
+    src = flat if flat is not None else top_idx
+    _req(src, "flat / top_idx", torch.int32)
+    assert src.shape[0] == nq and src.stride(0) == scores.stride(0) and n <= scores.shape[1]
+    k = 0
+    if flat is not None and top_idx is not None:
+        _req(top_idx, "top_idx", torch.int32)
+        k = top_idx.shape[1]
+    for t, name in ((row_vid, "row_vid"), (meta2vid, "meta2vid")):
+        if t is not None:
+            _req(t, name, torch.int32)
+    if out is None:
+        out = torch.empty((nq, n, 4), dtype=torch.int32, device=scores.device)
+    if out_count is None:
+        out_count = torch.empty((nq,), dtype=torch.int32, device=scores.device)
+    assert out.dtype == torch.int32 and out.shape[0] == nq and out.shape[2] == 4 and out.stride(2) == 1 and out.stride(1) == 4
+    assert out_count.dtype == torch.int32 and out_count.is_contiguous() and out_count.numel() == nq
+    check(_lib.load().xml_moments_decode(_p(flat), _p(scores), _p(top_idx), _p(row_vid), _p(meta2vid), nq, n,
+                                         scores.stride(0), k, int(l_ref), float(clip_length), 1 if seconds else 0,
+                                         _p(out), out.stride(0) // 4, _p(out_count), _stream()), "xml_moments_decode")
+    return out, out_count
+
+
 # ---- exact-rank mode (bf16 K6 as a filter in front of f32 scores; include/xmlhip.h "Exact-rank mode") --------------------
 def round_bf16_rows_err(y):
     """y (..., d) f32 L2-normalised rows -> (yb bf16 = rne(y), err (...) f32 = ||y - yb||_2 per row)."""

@@ -79,11 +79,16 @@ int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const 
 
 /* The large projections (K1 + K2, the output dense of K3 + K4) may run as ONE kernel with the LayerNorm in the GEMM's
  * epilogue; its 256 workgroups exchange per-row statistics and therefore wait for each other (one workgroup per CU; a
- * cooperative launch is opt-in, XML_LN_COOP=1).  The wait is bounded: an exchange that gives up is COUNTED, not trapped.
- *   xml_ln_fusion_status(disable): the count since the last call (the affected tiles hold wrong values); synchronises the
- *     device, so call it where the host waits anyway (the end of a corpus encode); disable != 0 switches the fused path off
- *     for the process when the count is non-zero -- the caller then redoes the work, which takes plain GEMM + LayerNorm
- *     launches.  xml_ln_fusion_enabled(): 0 after that, or when XML_LN_FUSION=0 is set (GPUs shared with other processes). */
+ * cooperative launch is opt-in, XML_LN_COOP=1).  The wait is bounded, and a wait that gives up never produces plausible
+ * wrong numbers: the rows of that tile are written as NaN, the remaining waits of THAT LAUNCH give up at once (a flag in the
+ * launch's own workspace, zeroed per launch -- nothing carries over to later launches), and a device-side diagnostic counter
+ * is bumped.
+ *   xml_ln_fusion_status(disable): the count since the last call; synchronises the device, so call it where the host waits
+ *     anyway (the end of a corpus encode, the D2H of a result set); disable != 0 switches the fused path off for the process
+ *     when the count is non-zero -- the caller then redoes the work, which takes plain GEMM + LayerNorm launches.
+ *     xml_ln_fusion_enabled(): 0 after that, or when XML_LN_FUSION=0 is set (GPUs shared with other processes).
+ * These two switches (and XML_LN_COOP) are the library's only process-wide state; they select between two paths with the
+ * same results and are never read by a kernel. */
 int xml_ln_fusion_status(int disable);
 int xml_ln_fusion_enabled(void);
 

@@ -1081,3 +1081,57 @@ def test_transpose_batched_layouts(shape, dtype):
     z = T.transpose(x, ld_out=ld)
     assert z.shape == (b, c, ld)
     assert torch.equal(z[:, :, :r], x.transpose(1, 2)) and float(z[:, :, r:].float().abs().max()) == 0.0
+
+
+def test_graphed_step_construction_leaves_no_stale_weight_shadows():
+    """GraphedTrainStep.__init__ runs warm-up steps on the real optimizer and restores the state afterwards; the per-step
+    bf16 weight shadows it refreshed on the way belong to the LAST WARM-UP STEP, one update away from the restored masters.
+    An eager no_grad forward between construction and the first replay (a validation loss) must not read them: its loss is
+    the loss of a model that never saw an optimizer."""
+    from tvretrieval_amd.model_xml import XML
+    from tvretrieval_amd.train import BertAdam, GraphedTrainStep, xml_forward_train
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]))
+    ranks = dict(neg_ctx_rank=d["neg_ctx_rank_steps"][0], neg_q_rank=d["neg_q_rank_steps"][0])
+    torch.manual_seed(5)
+    ref = XML(cfg, compute_dtype=torch.bfloat16).to(DEV).eval()
+    with torch.no_grad():
+        want = float(xml_forward_train(ref, **batch, **ranks)[0])
+    torch.manual_seed(5)
+    m = XML(cfg, compute_dtype=torch.bfloat16).to(DEV).eval()
+    opt = BertAdam(m.parameters(), lr=5e-2, warmup=-1, t_total=-1, schedule="none")     # a step moves the weights visibly
+    GraphedTrainStep(m, opt, batch, warmup_steps=2)
+    assert opt._shadow is None or not opt._shadow["fresh"]
+    with torch.no_grad():
+        got = float(xml_forward_train(m, **batch, **ranks)[0])
+    assert abs(got - want) < 1e-6, (got, want)
+
+
+def test_backward_after_an_intervening_step_is_refused_and_f16s_training_says_so():
+    """forward A, full step B (which overwrites the optimizer's per-step weight shadows in place), backward A: A's saved
+    weights are a view of that buffer and would silently be B's -- the backward must refuse.  And ops.F16S (the exact-rank
+    mode's inference model) is rejected by the training forward with a message, not deep inside the graph."""
+    from tvretrieval_amd import ops
+    from tvretrieval_amd.model_xml import XML
+    from tvretrieval_amd.train import BertAdam, xml_forward_train
+    d, cfg, _ = load_golden("train_step_video_sub_h128")
+    batch = dict(query_feat=T(d["query_feat"]), query_mask=T(d["query_mask"]), video_feat=T(d["video_feat"]),
+                 video_mask=T(d["video_mask"]), sub_feat=T(d["sub_feat"]), sub_mask=T(d["sub_mask"]),
+                 st_ed_indices=T(d["st_ed_indices"]))
+    ranks = dict(neg_ctx_rank=d["neg_ctx_rank_steps"][0], neg_q_rank=d["neg_q_rank_steps"][0])
+    torch.manual_seed(6)
+    m = XML(cfg, compute_dtype=torch.bfloat16).to(DEV).eval()
+    opt = BertAdam(m.parameters(), lr=1e-3, warmup=-1, t_total=-1, schedule="none")
+    loss_a = xml_forward_train(m, **batch, **ranks)[0]
+    loss_b = xml_forward_train(m, **batch, **ranks)[0]
+    opt.zero_grad()
+    loss_b.backward()
+    opt.step()
+    xml_forward_train(m, **batch, **ranks)            # refreshes the shadows for the new weights
+    with pytest.raises(RuntimeError, match="before the last optimizer step"):
+        loss_a.backward()
+    m16 = XML(cfg, compute_dtype=ops.F16S).to(DEV).eval()
+    with pytest.raises(ValueError, match="inference-only"):
+        xml_forward_train(m16, **batch, **ranks)

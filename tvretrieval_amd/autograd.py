@@ -32,20 +32,37 @@ def _packed(w, dtype):
     return w.contiguous() if dtype == F32 else ops.pack_weights(w.float().contiguous(), dtype)
 
 
-def _weights(params, dtype):
+def _weights(params, dtype, ctx=None):
     """Compute-dtype (sum N, K) weight of the row-concatenated f32 parameters: the optimizer's copy of this step when it is
-    current (BertAdam.refresh_shadows), else converted now."""
+    current (BertAdam.refresh_shadows), else converted now.
+    ctx: the autograd context that will SAVE the returned tensor for its backward.  The optimizer's copy is a view of a buffer
+    that the next refresh overwrites in place (through ctypes: no autograd version bump), so the context remembers which
+    refresh it saw and its backward (_shadow_guard) refuses to run on a later one."""
+    if ctx is not None:
+        ctx.shadow_gen = None
     if dtype != F32:
         reg = getattr(params[0], "_xml_sink", None)
         if reg is not None:
             v = reg.opt.shadow_w(params, dtype)
             if v is not None:
+                if ctx is not None:
+                    ctx.shadow_gen = (reg.opt, reg.opt.shadow_generation())
                 return v
     if len(params) == 1:
         return _packed(params[0], dtype)
     wf = _adjacent(params, "flat_p")      # usually back to back in the optimizer's flat parameter buffer: one view, no cat
     wcat = wf.view(-1, params[0].shape[1]) if wf is not None else torch.cat([p.detach() for p in params], 0)
     return _packed(wcat, dtype)
+
+
+def _shadow_guard(ctx):
+    """forward A, optimizer step + refresh B, backward A: the weights A saved were a view of the per-step shadow buffer and
+    now hold B's values -- dX would silently use the new weights.  Unsupported; say so instead."""
+    g = getattr(ctx, "shadow_gen", None)
+    if g is not None and g[0].shadow_generation() != g[1]:
+        raise RuntimeError("backward of a forward pass that ran before the last optimizer step: its saved compute-dtype "
+                           "weights were the optimizer's per-step shadow copies, which that step has overwritten "
+                           "(train.SHADOW_WEIGHTS = False keeps private copies)")
 
 
 def _weights_t(params, w):
@@ -153,7 +170,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, relu):
-        w = _weights((weight,), x.dtype)
+        w = _weights((weight,), x.dtype, ctx)
         y = ops.linear(x.contiguous(), w, None if bias is None else bias.detach().float().contiguous(), relu=relu)
         ctx.relu = relu
         ctx.has_bias = bias is not None
@@ -166,6 +183,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _shadow_guard(ctx)
         x, w, y = ctx.saved_tensors
         dy = dy.contiguous()
         if ctx.relu:
@@ -332,7 +350,7 @@ class QkvFn(torch.autograd.Function):
     def forward(ctx, x, *wb):
         ws, bs = tuple(wb[0::2]), tuple(wb[1::2])
         assert len(ws) == len(bs) >= 2 and all(w_.shape == ws[0].shape for w_ in ws)
-        w = _weights(ws, x.dtype)
+        w = _weights(ws, x.dtype, ctx)
         bf = _adjacent(bs, "flat_p")
         b = bf.detach() if bf is not None else torch.cat([b_.detach() for b_ in bs], 0).float().contiguous()
         ctx.params = tuple(wb)
@@ -346,6 +364,7 @@ class QkvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _shadow_guard(ctx)
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
         nh, k = w.shape

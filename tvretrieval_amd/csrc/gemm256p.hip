@@ -49,8 +49,10 @@ __device__ __forceinline__ xml_ln_f4 ln_read4(const float* pp) {
   return v;
 }
 
-// number of row-block waits of the LayerNorm-epilogue kernel that gave up (see the exchange below); read and cleared by
-// xml_ln_fusion_status
+// DIAGNOSTIC count of row-block waits of the LayerNorm-epilogue kernel that gave up (see the exchange below); read and cleared
+// by xml_ln_fusion_status.  No kernel reads it: what makes the remaining waits of a launch give up at once is that LAUNCH's own
+// flag in its workspace (G256pArgs::ln_fail, zeroed per launch), so a count left behind by an earlier launch cannot touch a
+// later one.
 __device__ int g_ln_timeouts = 0;
 
 struct G256pArgs {
@@ -64,6 +66,7 @@ struct G256pArgs {
   // LayerNorm epilogue (LNE kernels): y = LN(act(A W^T + bias) + addend) * g + b over the full rows of N = tn * 256 columns
   float* ln_part;       // (M, 2 tn, 2) f32: per row and per 128-column segment (sum, centred sum of squares)
   int* ln_count;        // (ceil(M / 256)): column tiles of a row block that have published their partials (zeroed per launch)
+  int* ln_fail;         // 1 int behind ln_count, zeroed per launch: some wait of THIS launch gave up -> the others do not wait
   const float* ln_g;
   const float* ln_b;
   float ln_eps;
@@ -625,23 +628,33 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
         // missing statistics -- the runtime reports the fault to the caller.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        // wave 0's patch, float 640: a word nothing else uses between here and the end of the tile (0..127 statistics,
+        // 256..639 bias / gamma / beta)
+        volatile float* ln_fail_lds = reinterpret_cast<volatile float*>(smem + RING_BYTES) + 640;
         if (tid == 0) {
           __hip_atomic_fetch_add(a.ln_count + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();        // 100 MHz
+          float failed = 0.f;
           while (__hip_atomic_load(a.ln_count + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.tn) {
             __builtin_amdgcn_s_sleep(1);
-            // bounded wait.  No trap: the tile is normalised with whatever statistics are there (wrong values), the
-            // device-wide counter says so, every later wait of this launch gives up at once, and the host -- which reads
-            // the counter at its next natural synchronisation point (xml_ln_fusion_status) -- switches the fused path
-            // off and redoes the work through the three-launch path.
-            if (__hip_atomic_load(&g_ln_timeouts, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
+            // bounded wait, no trap (a trap is a sticky device fault: the process loses its context).  A wait that gives up
+            // marks THIS launch (ln_fail: every later wait of the launch gives up at once instead of 4 s each), bumps the
+            // diagnostic counter the host reads at its next synchronisation point (xml_ln_fusion_status), and the tile is
+            // written as NaN -- never as a LayerNorm over missing statistics: a caller that does not look at the counter
+            // sees NaN scores, not plausible wrong ones.
+            if (__hip_atomic_load(a.ln_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
                 __builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) {
+              __hip_atomic_fetch_add(a.ln_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               __hip_atomic_fetch_add(&g_ln_timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              failed = 1.f;
               break;
             }
           }
+          *ln_fail_lds = failed;
+          __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the word is in LDS before this wave reaches the barrier
         }
         __builtin_amdgcn_s_barrier();
+        const bool ln_failed = *ln_fail_lds != 0.f;
         {   // lane l: statistics of row wm * 64 + l of the tile, combined from the 2 tn segment partials in fixed order
           const int64_t m = m0 + wm * 64 + lane_e;
           float mean = 0.f, rstd = 0.f;
@@ -666,6 +679,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
               }
             }
             rstd = 1.0f / sqrtf(m2 / (float)N + a.ln_eps);
+            if (ln_failed) mean = rstd = __builtin_nanf("");
           }
           patch[lane_e * 2] = mean;
           patch[lane_e * 2 + 1] = rstd;
@@ -797,13 +811,14 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
   a.M = M; a.N = N; a.K = K; a.relu = relu; a.add_mode = add_mode; a.seq_len = seq_len;
   a.tn = cdiv(N, 256);
   a.n_tiles = (int64_t)cdiv(M, 256) * a.tn;
-  a.ln_part = nullptr; a.ln_count = nullptr; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+  a.ln_part = nullptr; a.ln_count = nullptr; a.ln_fail = nullptr; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
   a.probe = g_q2c_ablation == 9 ? 1 : g_q2c_ablation == 21 ? 2 : g_q2c_ablation == 22 ? 4 : g_q2c_ablation == 23 ? 6 : g_q2c_ablation == 24 ? 8 : 0;
   if (LNE) {
     const int n_blocks = (int)cdiv(M, 256);
     a.ln_count = (int*)ln_ws;
-    a.ln_part = (float*)((char*)ln_ws + align_up((size_t)n_blocks * 4, 256));
-    hipLaunchKernelGGL(g256p_zero_kernel, dim3(cdiv(n_blocks, 256)), dim3(256), 0, st, a.ln_count, n_blocks);
+    a.ln_fail = a.ln_count + n_blocks;
+    a.ln_part = (float*)((char*)ln_ws + align_up((size_t)(n_blocks + 1) * 4, 256));
+    hipLaunchKernelGGL(g256p_zero_kernel, dim3(cdiv(n_blocks + 1, 256)), dim3(256), 0, st, a.ln_count, n_blocks + 1);
   }
   const int lds = 4 * 2 * 256 * 64 + 8 * 4096;          // ring + patches = 160 KiB
 #ifdef XML_DEBUG_VARIANTS
@@ -880,7 +895,7 @@ static bool ln_coop_wanted() {
          hipDeviceGetAttribute(&ok, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && ok != 0;
 }
 
-// How many row-block exchanges of the LayerNorm-epilogue GEMM gave up since the last call (their tiles hold wrong values).
+// How many row-block exchanges of the LayerNorm-epilogue GEMM gave up since the last call (their tiles were written as NaN).
 // Synchronises the device.  disable != 0: a non-zero count also switches the fused path off for this process -- every later
 // projection takes GEMM + LayerNorm launches, which wait for nothing.  Returns the count, or a negative xml_status.
 extern "C" int xml_ln_fusion_status(int disable) {
@@ -921,7 +936,7 @@ bool xmli_gemm_ln_eligible(int64_t M, int N, int K, int dt) {
   return kb % 128 == 0 && kb >= 256 && N % 256 == 0 && N / 256 <= 4 && (int64_t)cdiv(M, 256) * (N / 256) >= 768;
 }
 size_t xmli_gemm_ln_workspace_bytes(int64_t M, int N) {
-  return align_up((size_t)cdiv(M, 256) * 4, 256) + align_up((size_t)M * 2 * (N / 256 + 1) * 2 * 4, 256);
+  return align_up((size_t)(cdiv(M, 256) + 1) * 4, 256) + align_up((size_t)M * 2 * (N / 256 + 1) * 2 * 4, 256);
 }
 int xmli_gemm_ln(const void* A, const void* W, const float* bias, const void* addend, const float* ln_g, const float* ln_b,
                  void* y, int64_t M, int N, int K, int relu, int add_mode, int seq_len, int dt, void* ln_ws,

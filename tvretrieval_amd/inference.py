@@ -751,6 +751,8 @@ class _ResultSink(object):
         from .results import MOMENT_DTYPE, MomentResults
         n = self.n
         rec = self.rec[:n].cpu().numpy().view(MOMENT_DTYPE)[..., 0]
+        if hasattr(hip_ops, "check_ln_fusion"):     # the query encoder's fused projections: see ops.check_ln_fusion
+            hip_ops.check_ln_fusion("compute_query2ctx_info")
         return MomentResults.from_records(desc_ids[:n], descs[:n], rec, self.cnt[:n].cpu().numpy(), scale=scale,
                                           int_spans=int_spans)
 

@@ -232,6 +232,9 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
     captured step needs)."""
     cfg = model.config
     dev = query_feat.device
+    if model.compute_dtype is ops.F16S:
+        raise ValueError("compute_dtype=ops.F16S is inference-only (the exact-rank mode's split-f16 model): train in "
+                         "torch.bfloat16 or torch.float32 and load the checkpoint into an ops.F16S model")
     fm = lambda m: None if m is None else m.float().contiguous()       # noqa: E731
     query_mask, video_mask, sub_mask = fm(query_mask), fm(video_mask), fm(sub_mask)
     if SHADOW_WEIGHTS and model.compute_dtype == torch.bfloat16 and torch.is_grad_enabled():
@@ -444,7 +447,14 @@ class BertAdam(object):
         sh = self._shadow
         if sh is None or sh["dtype"] != dtype:
             sh = self._shadow = dict(dtype=dtype, flat=torch.empty(self.flat_p.numel(), dtype=dtype, device=self.flat_p.device),
-                                     t={}, ents={}, table=None, tables=[], max_tiles=0, dirty=False, fresh=False, versions=None)
+                                     t={}, ents={}, table=None, tables=[], max_tiles=0, dirty=False, fresh=False, versions=None,
+                                     gen=0)
+        # a new generation whenever the masters may have moved since the last refresh (step(), a write through torch); a
+        # second forward on the SAME weights (gradient accumulation) re-packs the same values and keeps the generation.
+        # (A captured refresh is replayed with its own forward AND backward: nothing to guard.)
+        if not torch.cuda.is_current_stream_capturing() and \
+                not (sh["fresh"] and sh["versions"] == [p._version for p in self.params]):
+            sh["gen"] += 1
         ops.pack_weights(self.flat_p, dtype, out=sh["flat"])
         if sh["dirty"] and not torch.cuda.is_current_stream_capturing():
             rows, tiles = [], 0
@@ -495,6 +505,10 @@ class BertAdam(object):
             if p._version != vers[i] or p.data_ptr() != ptr:
                 return False
         return sh["fresh"]
+
+    def shadow_generation(self):
+        """Which refresh the shadow buffers hold (autograd._shadow_guard: a backward must see the refresh its forward saw)."""
+        return self._shadow["gen"] if self._shadow is not None else 0
 
     def shadow_w(self, params, dtype):
         """The compute-dtype copy (sum N, K) of the row-concatenated parameters, or None when there is no current one."""
@@ -648,28 +662,28 @@ class GraphedTrainStep(object):
         # warm-up and the capture of THIS object; what is lost is the 10 % the two-stream capture gains on one GPU
         global PARALLEL_BRANCHES
         self._branches_were = PARALLEL_BRANCHES
-        if optimizer._reducer is not None:
-            PARALLEL_BRANCHES = False
-        side = torch.cuda.Stream(device=dev)
-        side.wait_stream(torch.cuda.current_stream(dev))
-        with torch.cuda.stream(side):
-            for _ in range(max(1, warmup_steps)):
-                self._set_ranks(None, None)
-                self._body()
-        torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        for dst, src in zip((optimizer.flat_p, optimizer.flat_m, optimizer.flat_v), keep):
-            dst.copy_(src)
-        optimizer.seg_steps, optimizer.step_count = list(keep_host[0]), keep_host[1]
-        touched_after_warmup = list(optimizer._touched)     # which tensors this graph's backward reaches
-        torch.set_rng_state(cpu_rng)
-        # ---- capture
-        self.active = touched_after_warmup if any(touched_after_warmup) else [True] * len(touched_after_warmup)
-        self.seg_active = optimizer._active_mask(self.active)
-        self.graph = torch.cuda.CUDAGraph()
-        T.SEED_BASE = self.seed_base
-        _SITE[0] = 0
-        try:
+        T.SEED_BASE = None
+        try:        # (everything that can fail -- warm-up OOM, a collective error, the capture -- restores the module switches)
+            if optimizer._reducer is not None:
+                PARALLEL_BRANCHES = False
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(max(1, warmup_steps)):
+                    self._set_ranks(None, None)
+                    self._body()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            self._restore(keep)
+            optimizer.seg_steps, optimizer.step_count = list(keep_host[0]), keep_host[1]
+            touched_after_warmup = list(optimizer._touched)     # which tensors this graph's backward reaches
+            torch.set_rng_state(cpu_rng)
+            # ---- capture
+            self.active = touched_after_warmup if any(touched_after_warmup) else [True] * len(touched_after_warmup)
+            self.seg_active = optimizer._active_mask(self.active)
+            self.graph = torch.cuda.CUDAGraph()
+            T.SEED_BASE = self.seed_base
+            _SITE[0] = 0
             with torch.cuda.graph(self.graph):
                 self.seed_base.add_(0x2545F4914F6CDD1D)          # first node: this replay's base seed
                 self.loss, self.parts = self._body(captured=True)
@@ -679,8 +693,18 @@ class GraphedTrainStep(object):
         optimizer._touched = [a or b for a, b in zip(keep_host[2], self.active)]
         torch.cuda.synchronize(dev)
         # the capture itself executed nothing; bring the optimizer state back in any case (allocator reuse)
-        for dst, src in zip((optimizer.flat_p, optimizer.flat_m, optimizer.flat_v), keep):
+        self._restore(keep)
+
+    def _restore(self, keep):
+        """Optimizer state back to the copies taken before the warm-up -- and the per-step weight shadows marked stale: they
+        hold the compute-dtype weights of the LAST WARM-UP STEP (one update away from the restored masters), the copy below
+        does not bump the parameters' versions, and during the capture refresh_shadows only RECORDS a refresh.  Without this an
+        eager forward between construction and the first replay (a validation loss) would silently read those weights."""
+        opt = self.opt
+        for dst, src in zip((opt.flat_p, opt.flat_m, opt.flat_v), keep):
             dst.copy_(src)
+        if opt._shadow is not None:
+            opt._shadow["fresh"] = False
 
     def _set_ranks(self, neg_ctx_rank, neg_q_rank):
         if neg_ctx_rank is None or neg_q_rank is None:

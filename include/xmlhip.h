@@ -108,6 +108,17 @@ int xml_attention_block(const void* x, const float* key_mask, const void* wqkv, 
                         void* y, int64_t n, int seq_len, int hidden, int n_heads, int dt, void* ws,
                         size_t ws_bytes, xml_stream_t stream);
 
+/* The attention core alone: BertSelfAttention.forward (xml/model_components.py:266-303) behind its three projections --
+ *   out (n, lq, hidden) dt, head h = columns [h dh, (h+1) dh)  =  softmax(Q_h K_h^T / sqrt(dh) + (1 - m) * -10000) V_h
+ * q (n, lq, ldq), k / v (n, lk, ldk / ldv) dt: projected states, leading dimensions in elements (column blocks of a stacked
+ * QKV tensor are passed as offset pointers).  The mask is the outer product q_mask (n, lq) x k_mask (n, lk) f32 -- the only
+ * forms the reference builds (key mask broadcast over queries, q_mask = NULL; cross attention, xml/model_xml.py:357-359).
+ * lq, lk <= 128, hidden % (32 * n_heads) == 0, dt in {XML_F32, XML_BF16}.  For callers of the sub-module; the encoders use
+ * xml_attention_block / xml_cross_attention. */
+int xml_attention_core(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
+                       const float* k_mask, void* out, int64_t n, int lq, int lk, int hidden, int n_heads, int dt,
+                       xml_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * K3+K4 and K5 on PACKED variable-length sequences: the query encoder without its padding rows.
  * The reference pads every query to the batch maximum (start_end_dataset.py:346-359; TVR: 30 tokens, mean 17.5 valid)
@@ -401,6 +412,12 @@ int xml_moment_topk(const float* st, const float* ed, const float* w, float* out
 int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ, float* out_score,
                        int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
                        xml_stream_t stream);
+
+/* The span predictor as a module of its own: nn.Conv1d(1, 1, ksize, padding = ksize / 2, bias = False) on rows of
+ * similarities (self.merged_st_predictor(similarity), xml/model_xml.py:476-477; profile_main.py:204-205 calls it directly).
+ *   x, y (rows, l) f32; w (ksize) f32; y[r][i] = sum_t w[t] x[r][i + t - ksize / 2], zero beyond the row.  ksize odd <= 15.
+ * The retrieval pass applies the taps inside xml_convse_rerank; this entry is for callers that already hold similarities. */
+int xml_conv1d_rows(const float* x, const float* w, float* y, int64_t rows, int l, int ksize, xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K10: the index tail of compute_query2ctx_info as a device epilogue -- one 16-byte record per list entry, so a query batch

@@ -760,3 +760,77 @@ def test_preallocated_index_equals_list_and_cat_index():
     for mod in a.modalities:
         assert torch.equal(a.feat1n_rows(mod), b.feat1n_rows(mod))
         assert torch.equal(a.feat2[mod], b.feat2[mod]) and torch.equal(a.mask[mod], b.mask[mod])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_profile_main_buckets_and_submodule_forwards(dtype):
+    """The reference's own profiler (baselines/profiling/profile_main.py:128-209) drives the model through FOUR buckets and
+    touches sub-modules directly -- encode_input with model.query_input_proj / query_encoder / query_pos_embed,
+    model.video_query_linear(...), model.merged_st_predictor(similarity).  The same four call sequences here (written fresh,
+    ctx_mode video_sub_tef like ProfileXML) against the oracle, and every holder module's own forward() -- LinearLayer,
+    TrainablePositionalEncoding, BertSelfAttention, BertSelfOutput (xml/model_components.py:76-89,156-163,266-303,313-317) --
+    against the oracle's restatement of it."""
+    f32 = dtype == torch.float32
+    tol = dict(atol=2e-4, rtol=2e-4) if f32 else dict(atol=0.12, rtol=3e-2)
+    l, h, nv, nq = 24, 128, 6, 9
+    m, cfg = _synthetic_model("video_sub", h, 66, 34, 40, l, dtype, seed=21)     # 64 + 2 / 32 + 2 TEF-style widths
+    sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    om = O.OracleXML(cfg, sd)
+    w = om.w
+    vf, vm = _feats(nv, [l, 20, 7, 24, 13, 1], 66, 31)
+    sf, _ = _feats(nv, [l, 20, 7, 24, 13, 1], 34, 32)
+    qf, qm = _feats(nq, [5, 30, 17, 9, 30, 12, 8, 21, 3], 40, 33)
+
+    def chk(name, got, want):
+        close(name, got, want, tol["atol"], tol["rtol"])
+    with torch.no_grad():
+        # bucket 1: context encoding
+        got = m.cross_encode_context(vf.to(DEV), vm.to(DEV), sf.to(DEV), vm.to(DEV))
+        want = om.cross_encode_context(vf, vm, sf, vm)
+        valid = vm[..., None] > 0                    # (padded rows of cross-attended streams: see test_golden_pipeline_fp32)
+        for n_, g_, w_ in zip(("vf1", "vf2", "sf1", "sf2"), got, want):
+            chk("bucket 1 " + n_, torch.where(valid, g_.float().cpu(), torch.zeros(())), torch.where(valid, w_, torch.zeros(())))
+        # bucket 2: query encoding through the sub-modules the profiler names
+        enc = m.encode_input(qf.to(DEV), qm.to(DEV), m.query_input_proj, m.query_encoder, m.query_pos_embed)
+        vq, sq = m.get_modularized_queries(enc, qm.to(DEV), return_modular_att=False)
+        vql, sql = m.video_query_linear(vq), m.sub_query_linear(sq)
+        o_enc = om.encode_input(qf, qm, "query_input_proj", "query_encoder", "query_pos_embed")
+        o_vq, o_sq = om.get_modularized_queries(o_enc, qm)
+        chk("bucket 2 video_query", vq, o_vq)
+        chk("bucket 2 sub_query", sq, o_sq)
+        lin = lambda x, n_: torch.nn.functional.linear(x, sd[n_ + ".weight"], sd[n_ + ".bias"])      # noqa: E731
+        chk("bucket 2 video_query_linear", vql, lin(o_vq, "video_query_linear"))
+        chk("bucket 2 sub_query_linear", sql, lin(o_sq, "sub_query_linear"))
+        # bucket 3: retrieval (one modality, the profiler doubles the time)
+        chk("bucket 3 get_video_level_scores", m.get_video_level_scores(vq, got[0], vm.to(DEV)),
+            om.get_video_level_scores(o_vq, want[0], vm))
+        # bucket 4: span prediction on a similarity tensor the caller computed (torch einsum: plumbing, like the profiler's)
+        sim = torch.einsum("md,nld->mnl", lin(o_vq, "video_query_linear"), want[1])
+        sim = ((sim + sim) / 2).reshape(nq * nv, 1, l)
+        for name in ("merged_st_predictor", "merged_ed_predictor"):
+            g_ = getattr(m, name)(sim.to(DEV)).view(nq, nv, l)
+            w_ = torch.nn.functional.conv1d(sim, sd[name + ".weight"], padding=2).view(nq, nv, l)
+            close("bucket 4 " + name, g_, w_, 1e-5, 1e-5)
+            close("bucket 4 mask_logits", O.mask_logits(g_.cpu(), vm), O.mask_logits(w_, vm), 1e-5, 1e-5)
+        # ---- the holder modules' own forward() -----------------------------------------------------------------------
+        x_in = vf.to(DEV)
+        chk("LinearLayer.forward", m.video_input_proj(x_in), O.linear_layer(vf, w.sub("video_input_proj")))
+        hx = O.linear_layer(vf, w.sub("video_input_proj"))
+        chk("TrainablePositionalEncoding.forward", m.ctx_pos_embed(hx.to(DEV)), O.trainable_pos_enc(hx, w.sub("ctx_pos_embed")))
+        px = O.trainable_pos_enc(hx, w.sub("ctx_pos_embed"))
+        sa = m.video_encoder1.self
+        g_ = sa(px.to(DEV), px.to(DEV), px.to(DEV), vm.unsqueeze(1).to(DEV))                       # (N, 1, L): key mask
+        w_ = O.bert_self_attention(px, px, px, vm.unsqueeze(1), w.sub("video_encoder1.self"), 4)
+        chk("BertSelfAttention.forward (self)", g_, w_)
+        side = O.trainable_pos_enc(O.linear_layer(sf, w.sub("sub_input_proj")), w.sub("ctx_pos_embed"))
+        cm = torch.einsum("bm,bn->bmn", vm, vm)                                                    # cross attention's mask
+        g_ = m.video_cross_att(px.to(DEV), side.to(DEV), side.to(DEV), cm.to(DEV)).float().cpu()
+        w_ = O.bert_self_attention(px, side, side, cm, w.sub("video_cross_att"), 4)
+        chk("BertSelfAttention.forward (cross, valid query rows)", torch.where(valid, g_, torch.zeros(())),
+            torch.where(valid, w_, torch.zeros(())))
+        chk("BertSelfOutput.forward", m.video_encoder1.output(w_.to(DEV), px.to(DEV)),
+            O.bert_self_output(w_, px, w.sub("video_encoder1.output")))
+        with pytest.raises(ValueError, match="outer product"):
+            bad = cm.clone()
+            bad[0, 0, 1] = 0
+            m.video_cross_att(px.to(DEV), side.to(DEV), side.to(DEV), bad.to(DEV))

@@ -597,6 +597,18 @@ int xmli_attention_core(const void* q, int ldq, const void* k, int ldk, const vo
   return XML_ERR_BAD_ARG;
 }
 
+// public: the attention core alone -- BertSelfAttention.forward behind its three projections
+extern "C" int xml_attention_core(const void* q, int ldq, const void* k, int ldk, const void* v, int ldv, const float* q_mask,
+                                  const float* k_mask, void* out, int64_t n, int lq, int lk, int hidden, int n_heads, int dt,
+                                  xml_stream_t stream) {
+  XML_ENTER();
+  if (!q || !k || !v || !k_mask || !out) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
+  if (ldq < hidden || ldk < hidden || ldv < hidden || (ldq | ldk | ldv | hidden) % 8) return XML_ERR_UNSUPPORTED;
+  return xmli_attention_core(q, ldq, k, ldk, v, ldv, q_mask, k_mask, out, 0, n, lq, lk, hidden, n_heads, dt,
+                             (hipStream_t)stream);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // public: BertAttention block.   ws = [ qkv (rows x 3H) dt | att (rows x H) dt | pre-LN (rows x H) f32 ]
 // ---------------------------------------------------------------------------------------------------

@@ -199,7 +199,7 @@ __device__ __forceinline__ float dpp_read(float v) {
 __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // Specialised to lpad == 128 (one video per 128-column group -- the TVR shape): no per-column divisions, one
-// reduction per accumulator row.  Other clip paddings use the per-modality kernels (q2c_ring.hip / q2c256.hip).
+// reduction per accumulator row.  Other clip paddings use the per-modality kernels (q2c_ring.hip).
 //
 // K-loop schedule ("one barrier per slice"; measured reason in profiles/r01_k6_notes.md: with two barriers per
 // 16-MFMA phase the waves spent 41 % of their cycles parked at barriers / waitcnts and issued 2.4 SALU per MFMA):

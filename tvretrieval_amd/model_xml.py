@@ -50,6 +50,14 @@ class _PackedMixin(object):
     def _pack_key(self, dtype):
         return (dtype, _PackedMixin._generation) + tuple((p.data_ptr(), p._version) for p in self.parameters())
 
+    def _act(self, x):
+        """x in the activation dtype of the model's compute dtype (XML.set_compute_dtype marks every holder; a holder used on
+        its own computes in its input's dtype).  For the direct sub-module forwards: a caller may hand f32 tensors to a bf16
+        model like it hands them to the reference's modules."""
+        want = ops.act_dtype(getattr(self, "_compute_dtype", None) or x.dtype)
+        x = x.contiguous()
+        return x if x.dtype == want else ops.convert(x, want)
+
     def packed(self, dtype):
         # XML.set_compute_dtype(ops.F16S) marks every holder: f32 activations go with split-f16 weights
         if dtype == torch.float32 and getattr(self, "_split16", False):
@@ -88,6 +96,19 @@ class LinearLayer(nn.Module, _PackedMixin):
             w = torch.nn.functional.pad(w, (0, d_pad - d_in))
         return dict(ln_g=_f(self.LayerNorm.weight), ln_b=_f(self.LayerNorm.bias), w=_w(w, dtype), b=_f(lin.bias))
 
+    def forward(self, x):
+        """ReLU(Linear(LayerNorm(x))) (xml/model_components.py:156-163; dropout is the identity in eval mode) on the HIP
+        entries xml_add_layernorm + xml_linear.  x (N, L, D_in) f32 (raw features) or the compute dtype; the result is in
+        the model's activation dtype.  XML.encode_input does not come through here: it runs this layer fused with the
+        positional encoding (xml_linear_ln_relu_pos)."""
+        dtype = ops.act_dtype(getattr(self, "_compute_dtype", None) or x.dtype)
+        p = self.packed(dtype)
+        d_in, d_pad = x.shape[-1], p["w"].shape[1]
+        h = ops.add_layernorm(x.contiguous(), None, p["ln_g"], p["ln_b"], out_dtype=dtype)
+        if d_pad != d_in:          # TEF widths: the weight's zero columns meet zero activations
+            h = torch.nn.functional.pad(h, (0, d_pad - d_in))
+        return ops.linear(h.contiguous(), p["w"], p["b"], relu=True)
+
 
 class TrainablePositionalEncoding(nn.Module, _PackedMixin):
     """Holder: position_embeddings.weight, LayerNorm.*  (xml/model_components.py:67-89)."""
@@ -102,6 +123,14 @@ class TrainablePositionalEncoding(nn.Module, _PackedMixin):
         # (the table is an ADDEND of the projection's epilogue: activation storage dtype, f32 under ops.F16S)
         return dict(pos=_w(self.position_embeddings.weight, ops.act_dtype(dtype)), ln_g=_f(self.LayerNorm.weight),
                     ln_b=_f(self.LayerNorm.bias))
+
+    def forward(self, input_feat):
+        """LayerNorm(input_feat + E[0:L]) (xml/model_components.py:76-89) on xml_add_layernorm; input_feat (N, L, D)."""
+        input_feat = self._act(input_feat)
+        p = self.packed(input_feat.dtype)
+        n, l = input_feat.shape[:2]
+        pos = p["pos"][:l].unsqueeze(0).expand(n, -1, -1).contiguous()
+        return ops.add_layernorm(input_feat, pos, p["ln_g"], p["ln_b"])
 
 
 class BertSelfAttention(nn.Module, _PackedMixin):
@@ -124,7 +153,29 @@ class BertSelfAttention(nn.Module, _PackedMixin):
             wqkv=_w(torch.cat([q.weight, k.weight, v.weight], 0), dtype),
             bqkv=_f(torch.cat([q.bias, k.bias, v.bias], 0)),
             wq=_w(q.weight, dtype), bq=_f(q.bias),
-            wkv=_w(torch.cat([k.weight, v.weight], 0), dtype), bkv=_f(torch.cat([k.bias, v.bias], 0)))
+            wkv=_w(torch.cat([k.weight, v.weight], 0), dtype), bkv=_f(torch.cat([k.bias, v.bias], 0)),
+            wk=_w(k.weight, dtype), bk=_f(k.bias), wv=_w(v.weight, dtype), bv=_f(v.bias))
+
+    def forward(self, query_states, key_states, value_states, attention_mask):
+        """xml/model_components.py:266-303: three projections (xml_linear) + the attention core (xml_attention_core) ->
+        context layer (N, Lq, D).  attention_mask (N, Lq, L) or (N, 1, L) float, 1 = attend.  The kernels take the mask as an
+        outer product q_mask x k_mask -- the two forms the reference ever builds (key mask broadcast over the queries;
+        cross attention's einsum("bm,bn->bmn"), xml/model_xml.py:357-359); any other mask is rejected."""
+        query_states, key_states, value_states = (self._act(t) for t in (query_states, key_states, value_states))
+        p = self.packed(query_states.dtype)
+        m = attention_mask.float()
+        if m.dim() == 2:
+            m = m.unsqueeze(1)
+        k_mask = m.amax(dim=1).contiguous()                            # (N, L)
+        q_mask = None
+        if m.shape[1] != 1:
+            q_mask = m.amax(dim=2).contiguous()                        # (N, Lq)
+            if not torch.equal(q_mask.unsqueeze(2) * k_mask.unsqueeze(1), m):
+                raise ValueError("BertSelfAttention: attention_mask must be an outer product of a query mask and a key mask")
+        q = ops.linear(query_states.contiguous(), p["wq"], p["bq"])
+        k = ops.linear(key_states.contiguous(), p["wk"], p["bk"])
+        v = ops.linear(value_states.contiguous(), p["wv"], p["bv"])
+        return ops.attention_core(q, k, v, q_mask, k_mask, self.num_attention_heads)
 
 
 class BertSelfOutput(nn.Module, _PackedMixin):
@@ -137,6 +188,13 @@ class BertSelfOutput(nn.Module, _PackedMixin):
     def _build_packed(self, dtype):
         return dict(wo=_w(self.dense.weight, dtype), bo=_f(self.dense.bias), ln_g=_f(self.LayerNorm.weight),
                     ln_b=_f(self.LayerNorm.bias))
+
+    def forward(self, hidden_states, input_tensor):
+        """LayerNorm(dense(hidden_states) + input_tensor) (xml/model_components.py:313-317) on xml_linear + xml_add_layernorm."""
+        hidden_states, input_tensor = self._act(hidden_states), self._act(input_tensor)
+        p = self.packed(hidden_states.dtype)
+        h = ops.linear(hidden_states, p["wo"], p["bo"])
+        return ops.add_layernorm(h, input_tensor, p["ln_g"], p["ln_b"])
 
 
 class BertAttention(nn.Module):
@@ -168,6 +226,16 @@ class _QueryLinear(nn.Linear, _PackedMixin):
     def forward(self, x):
         p = self.packed(x.dtype)
         return ops.linear(x.contiguous(), p["w"], p["b"])
+
+
+class _SpanConv(nn.Conv1d):
+    """{merged,video,sub}_{st,ed}_predictor: nn.Conv1d(1, 1, k, padding=k // 2, bias=False) parameters (same state_dict key,
+    `weight` (1, 1, k)); forward on xml_conv1d_rows for callers that hold a similarity tensor (profile_main.py:204-205).  The
+    retrieval pass applies the taps inside K7 and never calls this."""
+
+    def forward(self, x):
+        assert x.dim() == 3 and x.shape[1] == 1, "span predictor input is (N, 1, L)"
+        return ops.conv1d_rows(x.float().contiguous(), self.weight.detach().float().reshape(-1).contiguous())
 
 
 PACK_QUERY_TOKENS = True      # encode_query on the packed valid tokens of large batches (tests / A-B runs: False)
@@ -212,7 +280,7 @@ class XML(nn.Module):
 
         def conv():
             k = config.conv_kernel_size
-            return nn.Conv1d(1, 1, k, stride=1, padding=k // 2, bias=False)
+            return _SpanConv(1, 1, k, stride=1, padding=k // 2, bias=False)
 
         self.use_video = "video" in config.ctx_mode
         self.use_sub = "sub" in config.ctx_mode
@@ -265,6 +333,7 @@ class XML(nn.Module):
         for m in self.modules():
             if isinstance(m, _PackedMixin):
                 m._split16 = dtype is ops.F16S
+                m._compute_dtype = dtype
         return self
 
     @property

@@ -220,6 +220,30 @@ def attention_block(x, key_mask, wqkv, bqkv, wo, bo, ln_g, ln_b, n_heads, out=No
     return y
 
 
+def attention_core(q, k, v, q_mask, k_mask, n_heads):
+    """BertSelfAttention.forward behind its projections: q (N, Lq, H), k / v (N, Lk, H) projected states (compute dtype),
+    k_mask (N, Lk) f32, q_mask (N, Lq) f32 or None -> context layer (N, Lq, H)."""
+    _req(q, "q"); _req(k, "k", q.dtype); _req(v, "v", q.dtype); _req(k_mask, "k_mask", torch.float32)
+    if q_mask is not None:
+        _req(q_mask, "q_mask", torch.float32)
+    n, lq, hidden = q.shape
+    lk = k.shape[1]
+    assert k.shape == v.shape and k.shape[0] == n and k.shape[2] == hidden
+    out = torch.empty((n, lq, hidden), dtype=q.dtype, device=q.device)
+    check(_lib.load().xml_attention_core(_p(q), hidden, _p(k), hidden, _p(v), hidden, _p(q_mask), _p(k_mask), _p(out), n, lq,
+                                         lk, hidden, int(n_heads), dt_of(q), _stream()), "xml_attention_core")
+    return out
+
+
+def conv1d_rows(x, w):
+    """nn.Conv1d(1, 1, k, padding=k // 2, bias=False) on the last dimension of x (..., L) f32; w (k,) f32."""
+    _req(x, "x", torch.float32); _req(w, "w", torch.float32)
+    y = torch.empty_like(x)
+    l = x.shape[-1]
+    check(_lib.load().xml_conv1d_rows(_p(x), _p(w), _p(y), x.numel() // l, l, w.numel(), _stream()), "xml_conv1d_rows")
+    return y
+
+
 def cross_attention(main_x, main_mask, side_x, side_mask, wq, bq, wkv, bkv, ln_g, ln_b, n_heads):
     """LN(MHA(main, side, side, main_mask (x) side_mask) + main), xml/model_xml.py:369-371."""
     _req(main_x, "main_x"); _req(side_x, "side_x", main_x.dtype)

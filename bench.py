@@ -446,11 +446,14 @@ def run(args, backend_factory=None, emit=True):
     if multi:
         # collectives: libxmlhip's RCCL entries (xml_rccl_*) on GPU ranks.  They cannot be exercised at world > 1 on the
         # 1-GPU development boxes, so every run first pushes one small exchange through them AND through
-        # torch.distributed and compares; a mismatch or an error falls back to torch.distributed, and the line says so.
+        # torch.distributed and compares; a mismatch or an error ENDS the run with a non-zero exit code (unless
+        # --torch-collectives asked for the torch.distributed exchange on purpose).
         exchange = xdist.TorchExchange()
         if be.name == "hip" and not args.torch_collectives:
             cand, same = None, False
             try:
+                if os.environ.get("XML_TEST_BREAK_CABI_COLLECTIVES"):      # tests: the failure path below must end the run
+                    raise RuntimeError("injected by XML_TEST_BREAK_CABI_COLLECTIVES")
                 cand = xdist.RcclExchange()
                 g = torch.Generator(device=device).manual_seed(11 + rank)
                 s = torch.randn(4 * world + 3, 64, device=device, generator=g)
@@ -461,19 +464,24 @@ def run(args, backend_factory=None, emit=True):
                 same = torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and \
                     torch.equal(cand.allgather_rows(rows), exchange.allgather_rows(rows))
                 if not same:
-                    exch_note = "C-ABI self-check MISMATCH vs torch.distributed -> fell back"
+                    exch_note = "C-ABI self-check MISMATCH vs torch.distributed"
             except Exception as e:       # noqa: BLE001 -- report, never lose the measurement
-                exch_note = "C-ABI collectives failed (%s: %s) -> fell back" % (type(e).__name__, e)
+                exch_note = "C-ABI collectives failed (%s: %s)" % (type(e).__name__, e)
             # the decision is collective: every rank uses the C-ABI exchange or none does
             flag = torch.tensor([1 if same else 0], device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 exchange = cand
             elif exch_note is None:
-                exch_note = "another rank failed the C-ABI self-check -> fell back"
-            if exch_note is not None:      # loud: this line is NOT measuring libxmlhip's collectives
-                print("bench.py rank %d: WARNING: %s; the exchanges of this run go through torch.distributed "
-                      "(config.collectives_fallback = 1)" % (rank, exch_note), file=sys.stderr, flush=True)
+                exch_note = "another rank failed the C-ABI self-check"
+            if exch_note is not None:
+                # FATAL: a line that silently measured torch.distributed instead of csrc/collectives.hip would be read as a
+                # measurement of the C-ABI collectives.  (The decision above was collective: every rank leaves here.)
+                print("bench.py rank %d: ERROR: %s.  Refusing to measure torch.distributed collectives under this "
+                      "benchmark's name; pass --torch-collectives to measure that path on purpose "
+                      "(the line then says config.collectives_fallback = 1)." % (rank, exch_note), file=sys.stderr, flush=True)
+                dist.barrier()
+                raise SystemExit(3)
         elif args.torch_collectives:
             exch_note = "--torch-collectives"
 

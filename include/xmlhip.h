@@ -674,6 +674,15 @@ int xml_rccl_topk_by_owner(xml_comm_t comm, int world, int rank, const float* lo
                            int nq, int c, int k, float alpha, float* own_val, int32_t* own_id, void* ws,
                            size_t ws_bytes, xml_stream_t stream);
 
+/* The owner's side of the two entries above WITHOUT the wire: recv_score / recv_id (world, n_rows, c) = what the grouped
+ * receive leaves in the workspace (source-rank-major: [p][row][c], pad with -inf / INT32_MAX) -> one un-permute kernel, one
+ * top-k kernel -> out_val / out_id (n_rows, k), ordered like xml_topk_rows.  The collectives call exactly this after their
+ * receive; exported so that the merge of a sharded pass can be checked (and reused) without a communicator -- e.g. walking
+ * the 8 shards of BASELINE configs[3] through one GPU (tests/test_gpu_fullsize.py).  k <= 256, k <= world * c. */
+size_t xml_merge_shard_topk_workspace_bytes(int world, int n_rows, int c);
+int xml_merge_shard_topk(const float* recv_score, const int32_t* recv_id, int world, int n_rows, int c, int k, float alpha,
+                         float* out_val, int32_t* out_id, void* ws, size_t ws_bytes, xml_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * HOST post-processing ("next" row 8f-1; pointers are HOST memory): greedy temporal NMS.
  *   xml_nms_vcmr_host = filter_vcmr_by_nms (baselines/clip_alignment_with_language/inference.py:189-225):

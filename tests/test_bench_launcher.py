@@ -70,3 +70,18 @@ def test_bench_tiny_forced_sharded_on_gpu():
     assert res["n_gpus"] == 1 and res["config"]["backend"] == "hip" and res["config"]["ranks_in_process_group"] == 1
     assert "exchange+merge_topk" in res["breakdown_ms"] or "topk_k8" in res["breakdown_ms"]
     assert res["config"]["collectives"].startswith("libxmlhip RCCL")
+
+
+@pytest.mark.gpu
+def test_bench_refuses_to_measure_fallback_collectives():
+    """A C-ABI collective that fails its self-check must END an N > 1 run with a non-zero exit code -- a line that silently
+    measured torch.distributed would be read as a measurement of csrc/collectives.hip -- unless --torch-collectives asked
+    for that exchange on purpose (the line then carries collectives_fallback = 1)."""
+    argv = ["--gpus", "1", "--force-sharded", "--workload", "tiny", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"]
+    r = _run(argv, XML_TEST_BREAK_CABI_COLLECTIVES="1")
+    assert r.returncode != 0, r.stdout[-2000:]
+    assert "Refusing to measure" in r.stderr and not any(ln.startswith("{") for ln in r.stdout.splitlines())
+    r = _run(argv + ["--torch-collectives"], XML_TEST_BREAK_CABI_COLLECTIVES="1")
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    res = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert res["config"]["collectives_fallback"] == 1 and res["config"]["collectives"].startswith("torch.distributed")

@@ -237,3 +237,86 @@ def test_c3_exact_rank_mode_gives_the_fp32_lists(mode):
     c = res["certificate"]
     assert c["fail_rate"] <= 0.05, c                                   # measured 0.1 %: the fallback stays rare
     assert c["filter_abs_err_max"] < c["eps_mean"], c                 # the bound really bounds what the filter did
+
+
+@pytest.mark.parametrize("mode", ["bf16", "exact_f16s"])
+def test_c4_eight_shard_walk_equals_the_single_pass(mode):
+    """BASELINE configs[3] at its own size on ONE GPU: the 21 793-video corpus cut into the 8 `shard_range` slices an
+    8-GPU node would hold, each shard walked in turn through the rank's side of the pass (dist._local_scores_topk: local
+    K6 + local top-100, global ids), the eight lists laid out the way the grouped receive of xml_rccl_topk_by_owner leaves
+    them, merged by the kernels that run behind the wire (xml_merge_shard_topk), and the owner's K7 / K9 on the merged
+    list -- for every query owner.  The reference takes moments only from the GLOBAL top-100 videos of a query
+    (xml/inference.py:347-348,365-367): the merged lists must be the single pass's lists BIT FOR BIT (scores, ids, order),
+    for the query-owner rerank and (bf16) for the video-owner scheme whose per-rank moment lists are merged the same way.
+    mode "exact_f16s": every shard is an exact-rank index of an ops.F16S model (f32-grade local lists)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tvretrieval_amd import dist as xd
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import ops
+    from tvretrieval_amd.model_xml import XML
+    nq, nv, l, hidden, dv, ds, dq, ctx_mode, _ = bench.WORKLOADS["c3"]
+    world, k, n_out = 8, 100, 200
+    dev = torch.device(DEV)
+    exact = mode != "bf16"
+    torch.manual_seed(0)
+    model = XML(bench.model_config(hidden, dv, ds, dq, ctx_mode, l),
+                compute_dtype=ops.F16S if exact else torch.bfloat16).to(dev).eval()
+    kw = dict(exact_filter=True) if exact else {}
+    qf, qm = bench.synth_queries(nq, dq, dev)
+    with torch.no_grad():
+        full = inf.build_corpus_index(model, bench.context_batches(0, nv, l, dv, ds, True, True, dev), n_total=nv, l_ref=l, **kw)
+        want = inf.vcmr_search(model, full, qf, qm, max_vcmr_video=k, max_before_nms=n_out)
+        if exact:
+            assert want["exact"]["n_fail"] <= nq // 20
+        # phase 0: every owner encodes its query slice (dist.encode_queries_sharded), the all-gather is a concatenation
+        parts = [inf.stage_query_vectors(model, qf[lo:hi].contiguous(), qm[lo:hi].contiguous())
+                 for lo, hi, _ in (xd.query_slice(nq, r, world) for r in range(world))]
+        qvec = {m: torch.cat([p[m] for p in parts]).contiguous() for m in parts[0]}
+        # phase 1 on every shard in turn
+        shards, loc = [], []
+        for r in range(world):
+            lo, hi = xd.shard_range(nv, r, world, align=bench.SHARD_ALIGN)
+            idx = inf.build_corpus_index(model, bench.context_batches(lo, hi, l, dv, ds, True, True, dev), video_offset=lo,
+                                         n_total=nv, l_ref=l, **kw)
+            assert idx.n_videos == hi - lo
+            _, (loc_s, loc_i) = xd._local_scores_topk(idx, qvec, k, ops)
+            loc.append((loc_s, loc_i))
+            shards.append(idx if not exact else None)       # (the video-owner leg below is bf16 only)
+        assert sum(xd.shard_range(nv, r, world, align=bench.SHARD_ALIGN)[1] -
+                   xd.shard_range(nv, r, world, align=bench.SHARD_ALIGN)[0] for r in range(world)) == nv
+        # the owner's merge behind the wire + the owner's K7 / K9 against the corpus-wide feat2 copy
+        full.feat2_all, full.mask_all = full.feat2, full.mask
+        top_w, top_gid, fs, fi = [], [], [], []
+        for o in range(world):
+            q_lo, q_hi, per = xd.query_slice(nq, o, world)
+            recv_s = torch.stack([s[q_lo:q_hi] for s, _ in loc]).contiguous()              # [p][row][c]
+            recv_i = torch.stack([i[q_lo:q_hi] for _, i in loc]).contiguous()
+            own_w, own_gid = ops.merge_shard_topk(recv_s, recv_i, k, alpha=20.0)
+            st, ed = inf.stage_span_probs(model, full, {m: v[q_lo:q_hi] for m, v in qvec.items()}, own_gid, ops, replicated=True)
+            s_, f_ = ops.moment_topk(st, ed, own_w, full.l_ref, 2, 16, n_out)
+            top_w.append(own_w), top_gid.append(own_gid), fs.append(s_), fi.append(f_)
+        top_w, top_gid, fs, fi = (torch.cat(t) for t in (top_w, top_gid, fs, fi))
+        torch.cuda.synchronize()
+        assert torch.equal(top_gid, want["top_indices"]), "global top-100 video ids differ from the single pass"
+        assert torch.equal(top_w, want["top_scores"]), "global top-100 weights differ from the single pass"
+        assert torch.equal(fi, want["flat_indices"]), "top-200 moments (query-owner rerank) differ from the single pass"
+        assert torch.equal(fs, want["flat_scores"])
+        if exact:
+            return
+        # video-owner scheme: every rank reranks the global top-100 videos IT holds; the per-rank top-200 lists (flat
+        # indices in the global slot order) are merged by the same kernels (score desc, flat asc)
+        loc_m = []
+        for r in range(world):
+            a, b = xd.video_owner_local_moments(model, shards[r], qvec, top_w, top_gid, n_out, 2, 16, ops)
+            loc_m.append((a.contiguous(), xd.moment_merge_payload(b)))
+        ms, mi = [], []
+        for o in range(world):
+            q_lo, q_hi, per = xd.query_slice(nq, o, world)
+            a, b = ops.merge_shard_topk(torch.stack([s[q_lo:q_hi] for s, _ in loc_m]).contiguous(),
+                                        torch.stack([i[q_lo:q_hi] for _, i in loc_m]).contiguous(), n_out, alpha=0.0)
+            ms.append(a), mi.append(torch.where(a > 0, b, torch.full_like(b, -1)))
+        ms, mi = torch.cat(ms), torch.cat(mi)
+        torch.cuda.synchronize()
+        assert torch.equal(mi, want["flat_indices"]), "top-200 moments (video-owner scheme) differ from the single pass"
+        assert torch.equal(ms, want["flat_scores"])

@@ -136,6 +136,9 @@ SIGNATURES = {
     "xml_rccl_topk_by_owner_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "xml_rccl_topk_by_owner": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
                                        c_void_p, c_void_p, c_size_t, c_void_p]),
+    "xml_merge_shard_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "xml_merge_shard_topk": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                     c_size_t, c_void_p]),
     # ---- training step (train.hip) ----
     "xml_transpose_batched": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "xml_colsum": (c_int, [c_void_p, c_int, c_void_p, c_int64, c_int, c_int, c_void_p]),

@@ -94,7 +94,35 @@ inline int slice_rows(int nq, int per, int r) {
   return (int)(hi - lo);
 }
 
+// the owner's side behind the wire: receive layout [p][row][c] -> candidate rows [row][p * c + j] -> top-k
+int merge_received(const float* rs, const int32_t* ri, float* cs, int32_t* ci, int world, int n_rows, int c, int k,
+                   float alpha, float* out_val, int32_t* out_id, hipStream_t st) {
+  const int64_t total = (int64_t)world * n_rows * c;
+  const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(unpermute_by_owner_kernel, dim3(grid), dim3(256), 0, st, rs, ri, cs, ci, world, n_rows, c);
+  XML_CHECK_LAUNCH();
+  return xml_topk_rows(cs, (int64_t)world * c, ci, out_val, out_id, n_rows, world * c, k, alpha, nullptr, 0, (xml_stream_t)st);
+}
+
 }  // namespace
+
+extern "C" size_t xml_merge_shard_topk_workspace_bytes(int world, int n_rows, int c) {
+  if (world <= 0 || n_rows <= 0 || c <= 0) return 0;
+  return 2 * align_up((size_t)world * n_rows * c * 4, 256);      // candidate scores / ids
+}
+
+extern "C" int xml_merge_shard_topk(const float* recv_score, const int32_t* recv_id, int world, int n_rows, int c, int k,
+                                    float alpha, float* out_val, int32_t* out_id, void* ws, size_t ws_bytes,
+                                    xml_stream_t stream) {
+  XML_ENTER();
+  if (!recv_score || !recv_id || !out_val || !out_id || !ws) return XML_ERR_BAD_ARG;
+  if (world <= 0 || n_rows <= 0 || c <= 0 || k <= 0) return XML_ERR_BAD_ARG;
+  if (k > 256 || k > world * c) return XML_ERR_UNSUPPORTED;
+  if (ws_bytes < xml_merge_shard_topk_workspace_bytes(world, n_rows, c)) return XML_ERR_WORKSPACE;
+  const size_t seg = align_up((size_t)world * n_rows * c * 4, 256);
+  return merge_received(recv_score, recv_id, (float*)ws, (int32_t*)((char*)ws + seg), world, n_rows, c, k, alpha, out_val,
+                        out_id, (hipStream_t)stream);
+}
 
 extern "C" int xml_rccl_available(void) { return rccl().ok ? 1 : 0; }
 
@@ -167,11 +195,7 @@ extern "C" int xml_rccl_allgather_topk(xml_comm_t comm, int world, const float* 
   ok = ok && r.AllGather(loc_id, ri, (size_t)nq * c, ncclInt32, nc, st) == ncclSuccess;
   ok = (r.GroupEnd() == ncclSuccess) && ok;
   if (!ok) return XML_ERR_LAUNCH;
-  const int64_t total = (int64_t)world * nq * c;
-  const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(unpermute_by_owner_kernel, dim3(grid), dim3(256), 0, st, rs, ri, cs, ci, world, nq, c);
-  XML_CHECK_LAUNCH();
-  return xml_topk_rows(cs, (int64_t)world * c, ci, out_val, out_id, nq, world * c, k, alpha, nullptr, 0, stream);
+  return merge_received(rs, ri, cs, ci, world, nq, c, k, alpha, out_val, out_id, st);
 }
 
 extern "C" size_t xml_rccl_topk_by_owner_workspace_bytes(int world, int per, int c) {
@@ -215,9 +239,5 @@ extern "C" int xml_rccl_topk_by_owner(xml_comm_t comm, int world, int rank, cons
   ok = (r.GroupEnd() == ncclSuccess) && ok;
   if (!ok) return XML_ERR_LAUNCH;
   if (n_own == 0) return XML_OK;
-  const int64_t total = (int64_t)world * n_own * c;
-  const unsigned grid = (unsigned)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(unpermute_by_owner_kernel, dim3(grid), dim3(256), 0, st, rs, ri, cs, ci, world, n_own, c);
-  XML_CHECK_LAUNCH();
-  return xml_topk_rows(cs, (int64_t)world * c, ci, own_val, own_id, n_own, world * c, k, alpha, nullptr, 0, stream);
+  return merge_received(rs, ri, cs, ci, world, n_own, c, k, alpha, own_val, own_id, st);
 }

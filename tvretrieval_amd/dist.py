@@ -376,6 +376,27 @@ def _owner_pass(model, index, qvec, ex, k, n_out, q2c_alpha, min_pred_l, max_pre
     return cat(0), cat(1), cat(2), cat(3), (torch.cat(owned) if len(owned) > 1 else owned[0]), q2c_all
 
 
+def video_owner_local_moments(model, index, qvec, top_w, top_gid, n_out, min_pred_l, max_pred_l, ops=hip_ops):
+    """Phase 2 of the video-owner scheme on one rank: K7 + K9 for the global top-k videos THIS shard holds (slots of videos
+    owned elsewhere are skipped: pair -1, weight 0), flat indices in the GLOBAL slot order -> (scores, flat) (Nq, n_out),
+    empty slots score 0 / flat -1.  The per-rank lists are disjoint; their top-n merge is the single-GPU list."""
+    lo, hi = index.video_offset, index.video_offset + index.n_videos
+    own = (top_gid >= lo) & (top_gid < hi)
+    pair_local = torch.where(own, top_gid - lo, torch.full_like(top_gid, -1)).contiguous()
+    st, ed = inf.stage_span_probs(model, index, qvec, pair_local, ops, zero_skipped=False)   # K9 skips w == 0 pairs
+    _mark("convse_k7")
+    w_local = torch.where(own, top_w, torch.zeros_like(top_w)).contiguous()   # w == 0 marks slots owned elsewhere:
+    loc_fs, loc_fi = ops.moment_topk(st, ed, w_local, index.l_ref, min_pred_l, max_pred_l, n_out)           # skipped
+    _mark("moment_k9")
+    return loc_fs, loc_fi
+
+
+def moment_merge_payload(loc_fi):
+    """Empty slots carry score 0 / flat -1: give them the largest payload so that real moments win ties at score 0 in the
+    merge (xml_topk_rows orders by score desc, payload asc)."""
+    return torch.where(loc_fi >= 0, loc_fi, torch.full_like(loc_fi, 2 ** 31 - 1)).contiguous()
+
+
 def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200,
                         q2c_alpha=20.0, min_pred_l=2, max_pred_l=16, group=None, ops=hip_ops, qvec=None,
                         gather_results=True, owner_rerank=None, n_chunks=1, exchange=None):
@@ -457,19 +478,11 @@ def sharded_vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100
         top_w, top_gid = ex.allgather_topk(loc_s, loc_i, k, q2c_alpha, ops)       # every rank: global top-k of all queries
         _mark("allgather+merge_topk")
     # ---- phase 2: moments of the global top-k videos this rank owns -------------------------------------
-    lo, hi = index.video_offset, index.video_offset + index.n_videos
-    own = (top_gid >= lo) & (top_gid < hi)
-    pair_local = torch.where(own, top_gid - lo, torch.full_like(top_gid, -1)).contiguous()
-    st, ed = inf.stage_span_probs(model, index, qvec, pair_local, ops, zero_skipped=False)   # K9 skips w == 0 pairs
-    _mark("convse_k7")
-    w_local = torch.where(own, top_w, torch.zeros_like(top_w)).contiguous()   # w == 0 marks slots owned elsewhere:
-    loc_fs, loc_fi = ops.moment_topk(st, ed, w_local, index.l_ref, min_pred_l, max_pred_l, max_before_nms)  # skipped
-    _mark("moment_k9")
+    loc_fs, loc_fi = video_owner_local_moments(model, index, qvec, top_w, top_gid, max_before_nms, min_pred_l, max_pred_l, ops)
     if trivial:
         fs, fi = loc_fs, loc_fi
     else:
-        # empty slots carry score 0 / flat -1: give them the largest payload so that real moments win ties at score 0
-        loc_fi = torch.where(loc_fi >= 0, loc_fi, torch.full_like(loc_fi, 2 ** 31 - 1)).contiguous()
+        loc_fi = moment_merge_payload(loc_fi)
         if gather_results:
             fs, fi = ex.allgather_topk(loc_fs.contiguous(), loc_fi, max_before_nms, 0.0, ops)
         else:

@@ -578,6 +578,22 @@ def topk_rows(scores, k, alpha=0.0, idx_in=None):
     return vals, idx
 
 
+def merge_shard_topk(recv_score, recv_id, k, alpha=0.0):
+    """The owner's merge of a sharded pass behind the wire (xml_merge_shard_topk): recv_score / recv_id (world, rows, c)
+    -- every shard's local top-c of the same query rows, source rank major -> (values (rows, k), ids (rows, k)) ordered
+    like topk_rows (score desc, id asc)."""
+    _req(recv_score, "recv_score", torch.float32); _req(recv_id, "recv_id", torch.int32)
+    world, rows, c = recv_score.shape
+    assert recv_id.shape == recv_score.shape
+    vals = torch.empty((rows, k), dtype=torch.float32, device=recv_score.device)
+    idx = torch.empty((rows, k), dtype=torch.int32, device=recv_score.device)
+    lib = _lib.load()
+    ws = _workspace(lib.xml_merge_shard_topk_workspace_bytes(world, rows, c), recv_score.device)
+    check(lib.xml_merge_shard_topk(_p(recv_score), _p(recv_id), world, rows, c, int(k), float(alpha), _p(vals), _p(idx), _p(ws),
+                                   ws.numel(), _stream()), "xml_merge_shard_topk")
+    return vals, idx
+
+
 MOMENT_SUMM = 8        # XML_MOMENT_SUMM
 
 

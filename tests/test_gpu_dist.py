@@ -39,11 +39,14 @@ def test_ranks_sharing_one_gpu_sharded_search_equals_single_process(world):
 @pytest.mark.parametrize("extra", [[], ["--exact-rank"]])
 def test_bench_two_ranks_on_one_gpu(extra):
     """`python bench.py --gpus 2` (self-spawned ranks, real kernels, shards of the tiny workload): one JSON line, n_gpus 2;
-    also in exact-rank mode (every shard hands its exact local top-k to the merge)."""
+    also in exact-rank mode (every shard hands its exact local top-k to the merge).  Two ranks on ONE GPU cannot form an
+    RCCL communicator, so the run asks for the torch.distributed exchange on purpose (--torch-collectives; without it the
+    failed C-ABI self-check ends the run: test_bench_launcher.test_bench_refuses_to_measure_fallback_collectives)."""
     import json
     env = dict(os.environ, XML_BENCH_SHARE_GPU="1")
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py"), "--gpus", "2", "--workload", "tiny",
-                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra, env=env, capture_output=True,
+                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--torch-collectives"] + extra, env=env,
+                       capture_output=True,
                        text=True, timeout=600)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -51,4 +54,4 @@ def test_bench_two_ranks_on_one_gpu(extra):
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0
     assert len(out["config"]["videos_per_gpu"]) == 2 and sum(out["config"]["videos_per_gpu"]) > 0
-    assert out["config"]["ranks_in_process_group"] == 2
+    assert out["config"]["ranks_in_process_group"] == 2 and out["config"]["collectives_fallback"] == 1

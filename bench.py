@@ -305,9 +305,14 @@ def run_extras(args, headline_qps):
                                                         "search_host_overhead_s", "host_tail_s", "nms_s")}
         return r
 
+    def ingest_leg():
+        import bench_ingest
+        return bench_ingest.run()
+
     leg("exact_rank", exact)
     leg("tvr_val", tvr_val)
     leg("e2e_tvr_val", e2e)
+    leg("ingest", ingest_leg)
     leg("c2", lambda: sub("c2", 20, 3))
     leg("c3r", lambda: sub("c3r", max(2, min(args.steps, 5)), 2))
 

@@ -420,6 +420,17 @@ int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const f
 int xml_conv1d_rows(const float* x, const float* w, float* y, int64_t rows, int l, int ksize, xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Feature ingest ("next" row 8f-3): the dataset-side half of the context collate on the device -- truncate to max_len,
+ * x / (||x||_2 + eps) per clip (l2_normalize_np_array, utils/basic_utils.py:82-84; xml/start_end_dataset.py:311-321), zero
+ * padding to the batch maximum + float mask (pad_sequences_1d, xml/start_end_dataset.py:346-359).
+ *   src (rows, d) XML_F32 or XML_F16 (IEEE half: the feature store's on-disk type): the batch's clip rows back to back
+ *   row_start (n + 1) int64 DEVICE: video i = source rows [row_start[i], row_start[i + 1]), the first max_len of them kept
+ *   dst (n, lmax, d) XML_F32 or XML_BF16; mask (n, lmax) f32 or NULL; normalize = 0: convert + pad only
+ * --------------------------------------------------------------------------------------------- */
+int xml_ingest_rows(const void* src, int src_dt, const int64_t* row_start, void* dst, int dst_dt, float* mask, int n,
+                    int lmax, int d, int max_len, float eps, int normalize, xml_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
  * K10: the index tail of compute_query2ctx_info as a device epilogue -- one 16-byte record per list entry, so a query batch
  * leaves the device in ONE copy and the host never loops over queries or list entries.
  *   replaces np.unravel_index(flat, (max_n_videos, max_ctx_l, max_ctx_l)), sorted_q2c_indices[i, local],

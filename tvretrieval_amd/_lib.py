@@ -119,6 +119,8 @@ SIGNATURES = {
     "xml_attention_core": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_int64,
                                    c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "xml_conv1d_rows": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
+    "xml_ingest_rows": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_void_p, c_int, c_int, c_int, c_int, c_float, c_int,
+                                c_void_p]),
     "xml_moments_decode": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_int,
                                    c_float, c_int, c_void_p, c_int64, c_void_p, c_void_p]),
     "xml_add_layernorm": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,

@@ -9,7 +9,7 @@ set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-variable"
-SRCS="api.hip linear.hip gemm256.hip gemm256p.hip attention.hip attention_train.hip q2c.hip q2c_ring.hip q2c_persist.hip topk.hip convse.hip moment.hip decode.hip conv1d.hip postproc.hip train.hip gemm_tn.hip index_build.hip collectives.hip exact.hip split16.hip loss_tail.hip"
+SRCS="api.hip linear.hip gemm256.hip gemm256p.hip attention.hip attention_train.hip q2c.hip q2c_ring.hip q2c_persist.hip topk.hip convse.hip moment.hip decode.hip conv1d.hip postproc.hip train.hip gemm_tn.hip index_build.hip ingest.hip collectives.hip exact.hip split16.hip loss_tail.hip"
 DBG_DIR=../../tools/microbench/k6_variants
 DBG_SRCS="$DBG_DIR/q2c256.hip $DBG_DIR/q2c_persist4.hip $DBG_DIR/q2c_persist32.hip"
 

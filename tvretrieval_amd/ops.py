@@ -310,6 +310,19 @@ def l2norm_rows_eps(x, eps=1e-5):
     return y
 
 
+def ingest_rows(src, row_start, n, lmax, max_len, normalize=True, eps=1e-5, out_dtype=torch.float32):
+    """Context collate on the device (xml_ingest_rows): src (rows, d) f32 / f16 = the batch's raw clip rows back to back,
+    row_start (n + 1,) int64 -> (features (n, lmax, d) out_dtype [x / (||x|| + eps) per clip, zero padding], mask (n, lmax))."""
+    _req(src, "src"); _req(row_start, "row_start", torch.int64)
+    assert src.dtype in (torch.float32, torch.float16) and row_start.numel() == n + 1
+    d = src.shape[-1]
+    out = torch.empty((n, lmax, d), dtype=out_dtype, device=src.device)
+    mask = torch.empty((n, lmax), dtype=torch.float32, device=src.device)
+    check(_lib.load().xml_ingest_rows(_p(src), dt_of(src), _p(row_start), _p(out), dt_of(out_dtype), _p(mask), int(n), int(lmax),
+                                      d, int(max_len), float(eps), int(bool(normalize)), _stream()), "xml_ingest_rows")
+    return out, mask
+
+
 def add_layernorm(a, b, g, beta, out_dtype=None):
     _req(a, "a"); _req(g, "g", torch.float32); _req(beta, "beta", torch.float32)
     out_dtype = out_dtype or (b.dtype if b is not None else a.dtype)

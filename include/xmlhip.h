@@ -379,18 +379,24 @@ int xml_convse_rerank_f16s(const xml_convse_desc* d, const void* q_lin0, const v
                            const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
                            xml_stream_t stream);
 
-/* K7 + the start of K9: xml_convse_rerank (or _f16s, by desc.dt; the q_inv / c_inv pointers are read for XML_F16S only) that
- * also emits, per pair, XML_MOMENT_SUMM banded row maxima  (st[i] * pair_w[p]) * max_{min_l <= d < max_l} ed[i + d]  -- the
- * largest one of each group of 16 rows { i : i % 64 in [8 g, 8 g + 8) } -- while the pair's rows are still in registers:
- * summ_out (nq, kpairs, XML_MOMENT_SUMM) f32.  xml_moment_topk_ex
- * builds its selection threshold from those values instead of a first pass over the st / ed rows.  pair_w (nq, kpairs) f32 =
- * the video weights exp(alpha * s) (NULL: 1); desc.softmax bit 0 must be set; rows of skipped pairs are not written. */
+/* K7 with its two extensions (xml_convse_rerank or _f16s by desc.dt; the q_inv / c_inv pointers are read for XML_F16S only;
+ * desc.softmax bit 0 must be set; at least one of summ_out / vid_len is given):
+ *  - vid_len (nv) int32 or NULL -- RAGGED CORPORA: valid clips of every video, 1 + the index of its last unmasked clip (TVR:
+ *    51 of 128 on average); l_ref for a video without any unmasked clip (its masked softmax is uniform, not zero).  Given: clip rows >= vid_len[v] + ksize / 2 of a video are not fetched (no tap of a valid
+ *    position reaches them) and the entries l >= vid_len[v] of st_out / ed_out -- exact zeros of the masked softmax -- are
+ *    NOT WRITTEN; their consumer, xml_moment_topk_ex with the same vid_len, does not read them.  Halves K7's writes and
+ *    K9's reads at the TVR length distribution; every stored value is bitwise that of xml_convse_rerank.
+ *  - summ_out (nq, kpairs, XML_MOMENT_SUMM) f32 or NULL -- per pair, XML_MOMENT_SUMM banded row maxima
+ *    (st[i] * pair_w[p]) * max_{min_l <= d < max_l} ed[i + d]  -- the largest one of each group of 16 rows
+ *    { i : i % 64 in [8 g, 8 g + 8) } -- taken while the pair's rows are still in registers.  xml_moment_topk_ex builds its
+ *    selection threshold from those values instead of a first pass over the st / ed rows.  pair_w (nq, kpairs) f32 = the
+ *    video weights exp(alpha * s) (NULL: 1); rows of skipped pairs are not written. */
 #define XML_MOMENT_SUMM 8
 int xml_convse_rerank_ex(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const float* q_inv0,
                          const float* q_inv1, const void* feat2_0, const void* feat2_1, const float* c_inv0,
                          const float* c_inv1, const float* mask0, const float* mask1, const int32_t* pair_vid,
-                         const float* conv_w, const float* pair_w, int min_l, int max_l, float* st_out, float* ed_out,
-                         float* summ_out, void* ws, size_t ws_bytes, xml_stream_t stream);
+                         const float* conv_w, const float* pair_w, int min_l, int max_l, const int32_t* vid_len,
+                         float* st_out, float* ed_out, float* summ_out, void* ws, size_t ws_bytes, xml_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * K9+K10: banded moment candidates + per-query top-n
@@ -408,10 +414,13 @@ int xml_moment_topk(const float* st, const float* ed, const float* w, float* out
                     int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l,
                     int n_out, xml_stream_t stream);
 /* summ != NULL: (nq, kpairs, XML_MOMENT_SUMM) f32 from xml_convse_rerank_ex (same pair_w, min_l, max_l, l_ref): the selection
- * threshold comes from these instead of a pass over the rows; pairs of weight 0 are ignored.  Same lists, bit for bit. */
-int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ, float* out_score,
-                       int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
-                       xml_stream_t stream);
+ * threshold comes from these instead of a pass over the rows; pairs of weight 0 are ignored.  Same lists, bit for bit.
+ * pair_vid (nq, kpairs) int32 + vid_len (n_videos) int32 (both or neither): ragged corpora -- the entries l >= vid_len[v] of
+ * the st / ed rows of a pair with video v are taken as 0 WITHOUT being read (xml_convse_rerank_ex with the same vid_len left
+ * them unwritten), pairs with pair_vid < 0 as empty.  Same lists, bit for bit. */
+int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ, const int32_t* pair_vid,
+                       const int32_t* vid_len, float* out_score, int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref,
+                       int min_l, int max_l, int n_out, xml_stream_t stream);
 
 /* The span predictor as a module of its own: nn.Conv1d(1, 1, ksize, padding = ksize / 2, bias = False) on rows of
  * similarities (self.merged_st_predictor(similarity), xml/model_xml.py:476-477; profile_main.py:204-205 calls it directly).

@@ -825,3 +825,49 @@ def test_moments_decode_vs_oracle(ops, case):
     np.testing.assert_array_equal(h["vid"], meta2vid.numpy()[top.numpy()[:, :n_vr]])
     np.testing.assert_array_equal(h["score"], w.numpy()[:, :n_vr])
     assert (h["st"] == 0).all() and (h["ed"] == 0).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(40, 9, 100, 256, True, 2, 100, 60), (70, 6, 128, 128, True, 2, 5, 40),
+                                  (9, 12, 64, 256, False, 1, 12, 30), (13, 7, 40, 128, False, 2, 7, 200)])
+def test_ragged_rows_k7_k9_skip_the_zero_tails(ops, dtype, case):
+    """Ragged corpora (xml_convse_rerank_ex / xml_moment_topk_ex with vid_len): K7 neither fetches the clip rows nor writes
+    the probabilities beyond a video's valid length -- they are exact zeros of the masked softmax -- and K9 does not read
+    them.  The destination is pre-filled with NaN: every entry l < vid_len[v] must be BITWISE the full kernel's, every
+    entry beyond must still be NaN (unwritten), and K9 on the poisoned rows must return the full path's lists bit for bit
+    -- also with skipped pairs (-1), empty videos, non-prefix masks and the 5-tap filter reaching across the valid end."""
+    nq, nv, l, h, merged, n_mod, k, n_out = case
+    lpad = (l + 15) // 16 * 16
+    q, f, mask, cw = _conv_case(nq, nv, l, h, merged, n_mod, 300 + nq)
+    mask = mask.clone()
+    mask[0] = 1                                           # a full-length video
+    mask[1] = 0; mask[1, :3] = 1; mask[1, 1] = 0          # a hole inside the valid range (not a prefix)
+    if nv > 4:
+        mask[4] = 0                                       # an empty video (uniform probabilities: nothing may be skipped)
+    g = torch.Generator().manual_seed(17)
+    k = min(k, nv)
+    pair = torch.stack([torch.randperm(nv, generator=g)[:k] for _ in range(nq)]).int()
+    pair[-1, -1] = -1
+    fp = [torch.zeros(nv, lpad, h) for _ in f]
+    for a, b in zip(fp, f):
+        a[:, :l] = b                                      # (padded clips keep their encoder outputs: the taps read them)
+    mp = torch.zeros(nv, lpad); mp[:, :l] = mask
+    vlen = ((mp != 0).int() * torch.arange(1, lpad + 1).int()).amax(1).clamp(max=l).int()
+    vlen[vlen == 0] = l          # a video without a valid clip: its masked softmax is UNIFORM, not zero -> full rows
+    args = ([dev(x, dtype) for x in q], [dev(x, dtype) for x in fp], [dev(mp)] * n_mod, dev(pair), dev(cw), l, merged, 5)
+    st_f, ed_f = ops.convse_rerank(*args, softmax=True, zero_skipped=False)
+    nan = lambda: torch.full((nq, k, lpad), float("nan"), device=DEV)                     # noqa: E731
+    st_r, ed_r = ops.convse_rerank(*args, softmax=True, zero_skipped=False, vid_len=dev(vlen), out=(nan(), nan()))
+    pv = pair.long().clamp(min=0)
+    live = (torch.arange(lpad)[None, None, :] < vlen[pv][..., None]) & (pair >= 0)[..., None]
+    for name, full, rag in (("st", st_f, st_r), ("ed", ed_f, ed_r)):
+        full, rag = full.cpu(), rag.cpu()
+        assert torch.equal(full[live], rag[live]), name + ": stored entries differ from the full kernel's"
+        assert torch.isnan(rag[~live]).all(), name + ": an entry beyond the valid length was written"
+        assert float(full[(~live) & (pair >= 0)[..., None]].abs().max()) == 0.0, name + ": the skipped tail is not exactly zero"
+    w = torch.rand(nq, k, generator=g) + 0.1
+    w[-1, -1] = 0.0                                       # (a skipped pair carries weight 0 in the sharded pass)
+    st_f[-1, -1] = 0; ed_f[-1, -1] = 0
+    want = ops.moment_topk(st_f, ed_f, dev(w), l, 2, 16, n_out)
+    got = ops.moment_topk(st_r, ed_r, dev(w), l, 2, 16, n_out, pair_vid=dev(pair), vid_len=dev(vlen))
+    assert torch.equal(got[1], want[1]) and torch.equal(got[0], want[0]), "K9 on ragged rows != K9 on full rows"

@@ -144,6 +144,11 @@ struct ConvseArgs {
   const float* pair_w;
   float* summ;
   int min_l, max_l;
+  // ragged corpora (xml_convse_rerank_ex): valid clips of every video (1 + index of its last unmasked clip), or NULL.
+  // Given: clip rows >= vid_len[v] + ksize / 2 of a video are not fetched (the rows the taps of a valid position can reach
+  // end there) and entries l >= vid_len[v] of st_out / ed_out -- exactly 0 after the masked softmax -- are NOT WRITTEN: the
+  // consumer (xml_moment_topk_ex with the same vid_len) does not read them.  TVR: 51 of 128 clip rows on average.
+  const int32_t* vid_len;
 };
 
 // 3 waves per SIMD (<= 168 VGPRs) for the f32 / bf16 instantiations.  The split-f16 one holds both halves of every fragment:
@@ -164,6 +169,8 @@ __global__ __launch_bounds__(256, IsSplit16<T>::value ? 2 : 3) void convse_kerne
   const int v = a.chunk_vid[chunk];                // video owning this chunk
   const int first = a.offsets[v] + (chunk - a.chunk_off[v]) * TM;
   const int cnt = min(TM, a.offsets[v + 1] - first);
+  const int vlen = a.vid_len ? max(0, min(a.vid_len[v], a.l_ref)) : a.l_ref;          // clips whose outputs are stored
+  const int b_rows = a.vid_len ? max(1, min(a.lpad, vlen + (a.ksize >> 1))) : a.lpad;   // clip rows the GEMM needs
   constexpr bool SPLIT = IsSplit16<T>::value;
   __shared__ float s_qinv[SPLIT ? 2 : 1][SPLIT ? TM : 1];
   if (tid < TM) {
@@ -195,14 +202,15 @@ __global__ __launch_bounds__(256, IsSplit16<T>::value ? 2 : 3) void convse_kerne
       return p >= 0 ? reinterpret_cast<const char*>(ql + (int64_t)(p / a.kpairs) * a.hidden) : nullptr;
     };
     auto b_row = [&](int r) -> const char* {
-      return r < a.lpad ? reinterpret_cast<const char*>(f2 + ((int64_t)v * a.lpad + r) * a.hidden) : nullptr;
+      return r < b_rows ? reinterpret_cast<const char*>(f2 + ((int64_t)v * a.lpad + r) * a.hidden) : nullptr;
     };
     const int k_bytes = a.hidden * (int)sizeof(T);
     auto a_off = [&](int r) -> uint32_t {             // rows beyond the chunk: any valid row (their products are never read)
       const int p = s_pair[r] >= 0 ? s_pair[r] : s_pair[0];
       return (uint32_t)(p / a.kpairs) * (uint32_t)k_bytes;
     };
-    auto b_off = [&](int r) -> uint32_t { return (uint32_t)min(r, a.lpad - 1) * (uint32_t)k_bytes; };
+    // (rows the taps of a valid clip cannot reach re-read the last needed row: an L1 / L2 hit instead of an HBM fetch)
+    auto b_off = [&](int r) -> uint32_t { return (uint32_t)min(r, b_rows - 1) * (uint32_t)k_bytes; };
     const char* b_base = reinterpret_cast<const char*>(f2 + (int64_t)v * a.lpad * a.hidden);
     if (a.dbg == 1) {
 #pragma unroll
@@ -324,7 +332,7 @@ __global__ __launch_bounds__(256, IsSplit16<T>::value ? 2 : 3) void convse_kerne
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const int l = lane + h * 64;
-      if (l < a.lpad) {
+      if (a.vid_len ? l < vlen : l < a.lpad) {
         const bool in = l < a.l_ref;
         a.st_out[(int64_t)p * a.lpad + l] = in ? st[h] : 0.f;
         a.ed_out[(int64_t)p * a.lpad + l] = in ? ed[h] : 0.f;
@@ -458,32 +466,36 @@ __global__ void convse_zero_words_kernel(uint32_t* __restrict__ p, int64_t n) {
   if (i < n) p[i] = 0u;
 }
 
-struct ConvseSumm {          // optional candidate summaries (xml_convse_rerank_ex)
+struct ConvseSumm {          // optional candidate summaries / ragged-corpus lengths (xml_convse_rerank_ex)
   const float* pair_w;
   float* summ;
   int min_l, max_l;
+  const int32_t* vid_len;
 };
 static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const void* feat2_0,
                               const void* feat2_1, const float* mask0, const float* mask1, const int32_t* pair_vid,
                               const float* conv_w, float* st_out, float* ed_out, void* ws, size_t ws_bytes,
                               const float* q_inv0, const float* q_inv1, const float* c_inv0, const float* c_inv1,
-                              xml_stream_t stream, ConvseSumm sm = ConvseSumm{nullptr, nullptr, 0, 0});
+                              xml_stream_t stream, ConvseSumm sm = ConvseSumm{nullptr, nullptr, 0, 0, nullptr});
 
 // xml_convse_rerank / xml_convse_rerank_f16s (by desc.dt) + the candidate summaries K9 starts from
 extern "C" int xml_convse_rerank_ex(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1, const float* q_inv0,
                                     const float* q_inv1, const void* feat2_0, const void* feat2_1, const float* c_inv0,
                                     const float* c_inv1, const float* mask0, const float* mask1, const int32_t* pair_vid,
-                                    const float* conv_w, const float* pair_w, int min_l, int max_l, float* st_out,
-                                    float* ed_out, float* summ_out, void* ws, size_t ws_bytes, xml_stream_t stream) {
+                                    const float* conv_w, const float* pair_w, int min_l, int max_l,
+                                    const int32_t* vid_len, float* st_out, float* ed_out, float* summ_out, void* ws,
+                                    size_t ws_bytes, xml_stream_t stream) {
   XML_ENTER();
-  if (!d || !q_lin0 || !feat2_0 || !mask0 || !pair_vid || !conv_w || !st_out || !ed_out || !ws || !summ_out) return XML_ERR_BAD_ARG;
+  if (!d || !q_lin0 || !feat2_0 || !mask0 || !pair_vid || !conv_w || !st_out || !ed_out || !ws) return XML_ERR_BAD_ARG;
+  if (!summ_out && !vid_len) return XML_ERR_BAD_ARG;          // (neither extension asked for: xml_convse_rerank / _f16s)
   if (d->nq <= 0 || d->nv <= 0 || d->kpairs <= 0 || d->hidden <= 0) return XML_ERR_BAD_ARG;
   if (d->n_mod < 1 || d->n_mod > 2 || (d->n_mod == 2 && (!q_lin1 || !feat2_1))) return XML_ERR_BAD_ARG;
   if (d->n_mod == 2 && !d->merged && !mask1) return XML_ERR_BAD_ARG;
   if (d->merged && d->n_mod != 2) return XML_ERR_BAD_ARG;
   if (d->lpad % 16 || d->lpad > 128 || d->l_ref > d->lpad || d->l_ref <= 0 || d->hidden % 8) return XML_ERR_UNSUPPORTED;
   if (!(d->ksize & 1) || d->ksize > 15 || d->ksize < 1) return XML_ERR_UNSUPPORTED;
-  if (min_l < 0 || max_l <= min_l || !(d->softmax & 1)) return XML_ERR_BAD_ARG;       // summaries are of PROBABILITIES
+  if (summ_out && (min_l < 0 || max_l <= min_l)) return XML_ERR_BAD_ARG;
+  if (!(d->softmax & 1)) return XML_ERR_BAD_ARG;      // summaries are of PROBABILITIES; unwritten entries are exact zeros of a softmax
   if (d->dt == XML_F16S) {
     if (!q_inv0 || !c_inv0 || (d->n_mod == 2 && (!q_inv1 || !c_inv1))) return XML_ERR_BAD_ARG;
     if (d->hidden % 32) return XML_ERR_UNSUPPORTED;
@@ -493,7 +505,7 @@ extern "C" int xml_convse_rerank_ex(const xml_convse_desc* d, const void* q_lin0
   return convse_rerank_impl(d, q_lin0, q_lin1, feat2_0, feat2_1, mask0, mask1, pair_vid, conv_w, st_out, ed_out, ws, ws_bytes,
                             d->dt == XML_F16S ? q_inv0 : nullptr, d->dt == XML_F16S ? q_inv1 : nullptr,
                             d->dt == XML_F16S ? c_inv0 : nullptr, d->dt == XML_F16S ? c_inv1 : nullptr, stream,
-                            ConvseSumm{pair_w, summ_out, min_l, max_l});
+                            ConvseSumm{pair_w, summ_out, min_l, max_l, vid_len});
 }
 
 extern "C" int xml_convse_rerank(const xml_convse_desc* d, const void* q_lin0, const void* q_lin1,
@@ -571,7 +583,7 @@ static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, cons
   a.nv = d->nv; a.kpairs = d->kpairs; a.lpad = d->lpad; a.l_ref = d->l_ref; a.hidden = d->hidden;
   a.n_mod = d->n_mod; a.merged = d->merged; a.ksize = d->ksize; a.softmax = d->softmax & 1;
   a.dbg = g_q2c_ablation;       // constant 0 in the product build (debug.h)
-  a.pair_w = sm.pair_w; a.summ = sm.summ; a.min_l = sm.min_l; a.max_l = sm.max_l;
+  a.pair_w = sm.pair_w; a.summ = sm.summ; a.min_l = sm.min_l; a.max_l = sm.max_l; a.vid_len = sm.vid_len;
   a.q_inv[0] = q_inv0; a.q_inv[1] = q_inv1 ? q_inv1 : q_inv0;
   a.c_inv[0] = c_inv0; a.c_inv[1] = c_inv1 ? c_inv1 : c_inv0;
   {

@@ -102,13 +102,26 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
                                                           const float* __restrict__ w, float* __restrict__ out_score,
                                                           int32_t* __restrict__ out_flat, int kpairs, int lpad,
                                                           int l_ref, int min_l, int max_l, int n_out,
-                                                          const float* __restrict__ summ) {
+                                                          const float* __restrict__ summ,
+                                                          const int32_t* __restrict__ pair_vid,
+                                                          const int32_t* __restrict__ vid_len) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
   unsigned long long* s_list = reinterpret_cast<unsigned long long*>(smem);                 // [MT_CAP]
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_list + MT_CAP);                          // [2048]
   __shared__ MomentShared sh;
+  // ragged corpora: entries >= the video's valid length are exact zeros that K7 did not write (xml_convse_rerank_ex with the
+  // same vid_len) -- they are not read here.  s_len[r] = valid clips of pair r (l_ref without vid_len, 0 for skipped pairs).
+  __shared__ int s_len[4 * MT_PPW];
+  if (tid < 4 * MT_PPW) {
+    int n = l_ref;
+    if (vid_len && tid < kpairs) {
+      const int pv = pair_vid[(int64_t)q * kpairs + tid];
+      n = pv >= 0 ? max(0, min(vid_len[pv], l_ref)) : 0;
+    }
+    s_len[tid] = n;
+  }
 
   const float* gst = st + (int64_t)q * kpairs * lpad;
   const float* ged = ed + (int64_t)q * kpairs * lpad;
@@ -135,7 +148,8 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   auto pair_load = [&](int r, float (&raw)[4]) {
     const float* sp = gst + r * lpad;
     const float* ep = ged + r * lpad;
-    const bool in_lo = lane < l_ref, in_hi = lane + 64 < l_ref;
+    const int len_r = s_len[r];
+    const bool in_lo = lane < len_r, in_hi = lane + 64 < len_r;
     raw[0] = in_lo ? sp[lane] : 0.f;
     raw[1] = in_hi ? sp[lane + 64] : 0.f;
     raw[2] = in_lo ? ep[lane] : 0.f;
@@ -277,7 +291,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
           const int ri = (int)(uint32_t)(e & 0xffffffffull);       // r * l_ref + i
           const int r = ri / l_ref, i = ri - r * l_ref;
           const int j = i + min_l + d;
-          if (j < l_ref) {
+          if (j < s_len[r]) {
             key = __float_as_uint(__uint_as_float((uint32_t)(e >> 32)) * ged[r * lpad + j]);
             take = key >= lb;
             flat = (uint32_t)(ri * l_ref + j);
@@ -309,7 +323,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
         const float a = a2[h];
         const bool row_on = (i < l_ref) && __float_as_uint(m2[h]) >= lb;
         if (!__any(row_on)) continue;
-        const int jend = row_on ? min(l_ref, i + max_l) : 0;
+        const int jend = row_on ? min(s_len[r], i + max_l) : 0;
         for (int d = min_l; d < max_l; ++d) {                     // uniform trip count; lanes predicate themselves
           const int j = i + d;
           const bool ok = row_on && j < jend;
@@ -383,20 +397,22 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
 extern "C" int xml_moment_topk(const float* st, const float* ed, const float* w, float* out_score, int32_t* out_flat,
                                int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
                                xml_stream_t stream) {
-  return xml_moment_topk_ex(st, ed, w, nullptr, out_score, out_flat, nq, kpairs, lpad, l_ref, min_l, max_l, n_out, stream);
+  return xml_moment_topk_ex(st, ed, w, nullptr, nullptr, nullptr, out_score, out_flat, nq, kpairs, lpad, l_ref, min_l, max_l,
+                            n_out, stream);
 }
 
-extern "C" int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ, float* out_score,
-                                  int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out,
-                                  xml_stream_t stream) {
+extern "C" int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ,
+                                  const int32_t* pair_vid, const int32_t* vid_len, float* out_score, int32_t* out_flat, int nq,
+                                  int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out, xml_stream_t stream) {
   XML_ENTER();
   if (!st || !ed || !out_score || !out_flat || nq <= 0 || kpairs <= 0 || lpad <= 0 || l_ref <= 0 || n_out <= 0)
     return XML_ERR_BAD_ARG;
+  if ((pair_vid == nullptr) != (vid_len == nullptr)) return XML_ERR_BAD_ARG;
   if (l_ref > lpad || min_l < 0 || max_l <= min_l) return XML_ERR_BAD_ARG;
   if (n_out > 1024 || lpad > 128 || kpairs > 4 * MT_PPW) return XML_ERR_UNSUPPORTED;   // (st, ed: probabilities, >= 0)
   const size_t lds = (size_t)MT_CAP * 8 + 2048 * 4;
   hipLaunchKernelGGL(moment_topk_kernel, dim3(nq), dim3(256), lds, (hipStream_t)stream, st, ed, w, out_score, out_flat,
-                     kpairs, lpad, l_ref, min_l, max_l, n_out, summ);
+                     kpairs, lpad, l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -147,7 +147,7 @@ def replicate_rerank_features(index, group=None):
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     check_shards(index, group)
     if _trivial(world):
-        index.feat2_all, index.mask_all = index.feat2, index.mask
+        index.feat2_all, index.mask_all, index.vlen_all = index.feat2, index.mask, index.vlen
         return index
     dev = index.device
     meta = torch.tensor([index.video_offset, index.n_videos], dtype=torch.int64, device=dev)
@@ -174,6 +174,9 @@ def replicate_rerank_features(index, group=None):
             feat2_all[m] = gather(f2)
         mask_all[m] = gather(index.mask[m])
     index.feat2_all, index.mask_all = feat2_all, mask_all
+    if index.vlen is not None:        # valid lengths of the whole corpus; ragged anywhere = ragged for the owner's K7 / K9
+        index.vlen_all = gather(index.vlen)
+        index.ragged = bool((index.vlen_all < index.l_ref).any().item())
     return index
 
 
@@ -334,9 +337,11 @@ def _owner_pass(model, index, qvec, ex, k, n_out, q2c_alpha, min_pred_l, max_pre
         if o_hi > o_lo:
             qv = {m: v[o_lo:o_hi] for m, v in qv_c.items()}
             top_w, top_gid = own_w.contiguous(), own_gid.contiguous()
-            st, ed = inf.stage_span_probs(model, index, qv, top_gid, ops, replicated=True)
+            vl = inf.ragged_lengths(index, ops, replicated=True)
+            rk = dict(pair_vid=top_gid, vid_len=vl) if vl is not None else {}
+            st, ed = inf.stage_span_probs(model, index, qv, top_gid, ops, replicated=True, vid_len=vl)
             _mark("convse_k7")
-            fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, n_out)
+            fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, n_out, **rk)
             _mark("moment_k9")
         else:   # more ranks than queries in this chunk
             top_w, top_gid = own_w[:0], own_gid[:0]
@@ -383,10 +388,12 @@ def video_owner_local_moments(model, index, qvec, top_w, top_gid, n_out, min_pre
     lo, hi = index.video_offset, index.video_offset + index.n_videos
     own = (top_gid >= lo) & (top_gid < hi)
     pair_local = torch.where(own, top_gid - lo, torch.full_like(top_gid, -1)).contiguous()
-    st, ed = inf.stage_span_probs(model, index, qvec, pair_local, ops, zero_skipped=False)   # K9 skips w == 0 pairs
+    vl = inf.ragged_lengths(index, ops)
+    rk = dict(pair_vid=pair_local, vid_len=vl) if vl is not None else {}
+    st, ed = inf.stage_span_probs(model, index, qvec, pair_local, ops, zero_skipped=False, vid_len=vl)   # K9 skips w == 0 pairs
     _mark("convse_k7")
     w_local = torch.where(own, top_w, torch.zeros_like(top_w)).contiguous()   # w == 0 marks slots owned elsewhere:
-    loc_fs, loc_fi = ops.moment_topk(st, ed, w_local, index.l_ref, min_pred_l, max_pred_l, n_out)           # skipped
+    loc_fs, loc_fi = ops.moment_topk(st, ed, w_local, index.l_ref, min_pred_l, max_pred_l, n_out, **rk)     # skipped
     _mark("moment_k9")
     return loc_fs, loc_fi
 

@@ -45,6 +45,24 @@ class CorpusIndex(object):
         self.n_total = int(n_total if n_total is not None else self.n_videos)
         self.feat2_all = self.mask_all = None      # corpus-wide copies of feat2 / mask (dist.replicate_rerank_features)
         self.exact = None                          # ExactFilter: feat1n is the bf16 FILTER image of an f32 index (exact-rank mode)
+        # ragged corpora: valid clips per video (1 + index of the last unmasked clip over the modalities) -- K7 neither
+        # fetches the clip rows nor writes the (exactly zero) probabilities beyond it, K9 does not read them
+        self.vlen = self.vlen_all = None
+        self.ragged = False
+
+    def set_valid_lengths(self):
+        """Per-video valid length from the masks (one small device pass + one host read at build time)."""
+        pos = None
+        for m in self.modalities:
+            mk = self.mask[m]
+            if not isinstance(mk, torch.Tensor):
+                return self
+            last = ((mk != 0).to(torch.int32) * torch.arange(1, mk.shape[1] + 1, device=mk.device, dtype=torch.int32)).amax(1)
+            pos = last if pos is None else torch.maximum(pos, last)
+        pos = torch.where(pos == 0, torch.full_like(pos, self.l_ref), pos)     # no valid clip at all: the masked softmax is
+        self.vlen = pos.clamp_max(self.l_ref).to(torch.int32).contiguous()     # uniform, not zero -> nothing is skipped
+        self.ragged = bool((self.vlen < self.l_ref).any().item())
+        return self
 
     def feat1n_rows(self, m):
         t = self.feat1n[m]
@@ -326,6 +344,8 @@ def _build_corpus_index_prealloc(model, context_batches, ops, keep_raw, video_of
         if keep_raw:
             raw[m] = f1[m]
     idx = CorpusIndex(mods, feat1n, f2, mk, l_ref, video_offset, n_total)
+    if getattr(ops, "RAGGED_ROWS", False):
+        idx.set_valid_lengths()
     idx.raw_feat1 = raw
     if exact_filter:
         idx.exact = _make_exact_filter(ex_f32, ex_ec, exact_mode_of(model, ops))
@@ -380,6 +400,7 @@ import os as _os
 # Measured in round 4 (profiles/r04_notes.md) and NOT the default: handing K9 its selection threshold from K7 takes K9 from
 # 0.65 to 0.45-0.53 ms at the TVR shape, but the extra epilogue work costs K7 as much or more (+0.2 ms with one maximum per
 # group of 16 rows, +0.45 ms with the 8 largest rows of a pair), and at the as-trained shape the weaker bound makes K9 slower.
+RAGGED_ROWS = _os.environ.get("XML_RAGGED_ROWS", "1") == "1"     # K7 / K9 skip the zero tails of short videos (A/B: 0)
 K7_SUMMARIES = _os.environ.get("XML_K7_SUMMARIES", "0") == "1"   # vcmr_search: K7 emits per-pair candidate summaries for K9 (False: K9 makes its own first pass; A/B)
 K6_TIMER = None   # bench.py: callable returning (start, end) torch.cuda.Event pair recorded around each K6 launch
 
@@ -560,11 +581,21 @@ def stage_exact_topk_f32(index, qvec, k, alpha, ops=hip_ops):
     return top_w, top_i, info
 
 
+def ragged_lengths(index, ops=hip_ops, replicated=False):
+    """The valid-length array K7 / K9 take for a ragged corpus (None: full rows -- every video full length, a backend
+    without the entry, or RAGGED_ROWS switched off)."""
+    if not (RAGGED_ROWS and getattr(ops, "RAGGED_ROWS", False) and index.ragged):
+        return None
+    return index.vlen_all if replicated else index.vlen
+
+
 def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=True, replicated=False, pair_w=None,
-                     band=None):
+                     band=None, vid_len=None):
     """K7 on the listed (query, local video) pairs -> softmaxed st / ed (Nq, K, lpad).
     replicated=True: pair_vid holds GLOBAL video ids into the corpus-wide copies index.feat2_all / index.mask_all
-    (tvretrieval_amd.dist.replicate_rerank_features)."""
+    (tvretrieval_amd.dist.replicate_rerank_features).
+    vid_len (ragged_lengths(index)): the entries beyond a video's valid length are left unwritten -- hand the same array to
+    ops.moment_topk(..., pair_vid=pair_vid, vid_len=vid_len)."""
     mods = index.modalities
     q_lin = [getattr(model, m + "_query_linear")(qvec[m].contiguous()) for m in mods]
     merged = bool(model.config.merge_two_stream and len(mods) == 2)
@@ -573,6 +604,8 @@ def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=Tru
         q_lin = [ops.split_f16_rows(q.float().contiguous()) for q in q_lin]      # per-row scales: q' is not normalised
     # band = (min_l, max_l) [+ pair_w]: K7 also returns the per-pair candidate summaries K9 starts from (st, ed, summ)
     kw = dict(pair_w=pair_w, band=band) if (band is not None and hasattr(ops, "MOMENT_SUMM")) else {}
+    if vid_len is not None:
+        kw["vid_len"] = vid_len
     return ops.convse_rerank(q_lin, [feat2[m] for m in mods], [mask[m] for m in mods], pair_vid,
                              model._conv_weights(), index.l_ref, merged, model.config.conv_kernel_size, softmax=True,
                              zero_skipped=zero_skipped, **kw)
@@ -649,8 +682,10 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
         st, ed, summ = stage_span_probs(model, index, qvec, top_i, ops, pair_w=top_w.contiguous(), band=(min_pred_l, max_pred_l))
         fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms, summ=summ)
     else:
-        st, ed = stage_span_probs(model, index, qvec, top_i, ops)
-        fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
+        vl = ragged_lengths(index, ops)
+        rk = dict(pair_vid=top_i, vid_len=vl) if vl is not None else {}
+        st, ed = stage_span_probs(model, index, qvec, top_i, ops, vid_len=vl)
+        fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms, **rk)
     if pad_tail:
         pad_moment_tail(fs, fi, top_i.shape[1], index.l_ref, min_pred_l, max_pred_l)
     out = dict(q2c=q2c, top_scores=top_w, top_indices=top_i, flat_scores=fs, flat_indices=fi)

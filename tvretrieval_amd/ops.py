@@ -607,18 +607,21 @@ def merge_shard_topk(recv_score, recv_id, k, alpha=0.0):
     return vals, idx
 
 
+RAGGED_ROWS = True     # convse_rerank(vid_len=) / moment_topk(pair_vid=, vid_len=) exist (xml_convse_rerank_ex, xml_moment_topk_ex)
 MOMENT_SUMM = 8        # XML_MOMENT_SUMM
 
 
 def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, softmax=True, zero_skipped=True,
-                  pair_w=None, band=None):
+                  pair_w=None, band=None, vid_len=None, out=None):
     """K7.  q_lin / feat2 / masks: lists over modalities (len 1 or 2).
     q_lin[m] (Nq, H); feat2[m] (Nv, Lpad, H); masks[m] (Nv, Lpad) f32; pair_vid (Nq, K) int32;
     conv_w flat f32 [st filters..., ed filters...].  Returns st, ed (Nq, K, Lpad) f32.
     zero_skipped=False leaves the rows of skipped pairs (pair_vid < 0) unwritten -- for callers that never read them
     (the sharded pass: K9 skips pairs of weight 0).
     band = (min_l, max_l) [+ pair_w (Nq, K) f32, the video weights]: also returns summ (Nq, K, 8) f32, the 8 largest banded
-    row maxima of every pair (xml_convse_rerank_ex) -- hand it to moment_topk(..., summ=summ), which then reads the rows once."""
+    row maxima of every pair (xml_convse_rerank_ex) -- hand it to moment_topk(..., summ=summ), which then reads the rows once.
+    vid_len (Nv,) int32: ragged corpora -- valid clips per video; entries l >= vid_len[v] of st / ed are left UNWRITTEN (exact
+    zeros of the masked softmax) for moment_topk(..., pair_vid=pair_vid, vid_len=vid_len), which does not read them."""
     n_mod = len(q_lin)
     for m in range(n_mod):
         _req(q_lin[m], "q_lin"); _req(feat2[m], "feat2", q_lin[m].dtype); _req(masks[m], "mask", torch.float32)
@@ -632,24 +635,33 @@ def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, s
     n_conv = 1 if merged else n_mod
     assert conv_w.numel() == 2 * n_conv * ksize
     lib = _lib.load()
-    st = torch.empty((nq, kpairs, lpad), dtype=torch.float32, device=pair_vid.device)
-    ed = torch.empty_like(st)
+    if out is not None:            # (st, ed) destination tensors of the caller
+        st, ed = out
+        _req(st, "st", torch.float32); _req(ed, "ed", torch.float32)
+        assert tuple(st.shape) == tuple(ed.shape) == (nq, kpairs, lpad)
+    else:
+        st = torch.empty((nq, kpairs, lpad), dtype=torch.float32, device=pair_vid.device)
+        ed = torch.empty_like(st)
     ws = _workspace(lib.xml_convse_rerank_workspace_bytes(ctypes.byref(d)), pair_vid.device)
-    if band is not None:
-        assert softmax, "candidate summaries are taken from probabilities"
+    if band is not None or vid_len is not None:
+        assert softmax, "candidate summaries / unwritten zero tails are those of probabilities"
         if pair_w is not None:
             _req(pair_w, "pair_w", torch.float32)
             assert tuple(pair_w.shape) == (nq, kpairs)
-        summ = torch.empty((nq, kpairs, MOMENT_SUMM), dtype=torch.float32, device=pair_vid.device)
+        if vid_len is not None:
+            _req(vid_len, "vid_len", torch.int32)
+            assert vid_len.numel() == nv
+        summ = torch.empty((nq, kpairs, MOMENT_SUMM), dtype=torch.float32, device=pair_vid.device) if band is not None else None
+        band = band if band is not None else (0, 1)
         one, sp = n_mod == 1, q_lin[0].dtype is F16S
         inv = lambda t: _p(t.inv) if sp else None          # noqa: E731
         check(lib.xml_convse_rerank_ex(ctypes.byref(d), _p(q_lin[0]), None if one else _p(q_lin[1]), inv(q_lin[0]),
                                        None if one else inv(q_lin[1]), _p(feat2[0]), None if one else _p(feat2[1]),
                                        inv(feat2[0]), None if one else inv(feat2[1]), _p(masks[0]),
                                        None if one else _p(masks[1]), _p(pair_vid), _p(conv_w), _p(pair_w), int(band[0]),
-                                       int(band[1]), _p(st), _p(ed), _p(summ), _p(ws), ws.numel(), _stream()),
+                                       int(band[1]), _p(vid_len), _p(st), _p(ed), _p(summ), _p(ws), ws.numel(), _stream()),
               "xml_convse_rerank_ex")
-        return st, ed, summ
+        return (st, ed, summ) if summ is not None else (st, ed)
     if q_lin[0].dtype is F16S:       # split-f16 rows on both sides: f32-grade similarities on the 16-bit pipe
         one = n_mod == 1
         check(lib.xml_convse_rerank_f16s(ctypes.byref(d), _p(q_lin[0]), None if one else _p(q_lin[1]), _p(q_lin[0].inv),
@@ -665,9 +677,11 @@ def convse_rerank(q_lin, feat2, masks, pair_vid, conv_w, l_ref, merged, ksize, s
     return st, ed
 
 
-def moment_topk(st, ed, w, l_ref, min_l, max_l, n_out, summ=None):
+def moment_topk(st, ed, w, l_ref, min_l, max_l, n_out, summ=None, pair_vid=None, vid_len=None):
     """K9/K10.  st, ed (Nq, K, Lpad) f32 probabilities; w (Nq, K) f32 or None.
     summ (Nq, K, 8) f32: the candidate summaries convse_rerank(..., band=(min_l, max_l), pair_w=w) returned for THESE rows.
+    pair_vid (Nq, K) int32 + vid_len (Nv,) int32: the rows came from convse_rerank(..., vid_len=vid_len) -- entries beyond a
+    video's valid length were not written and are not read.
     Returns (scores (Nq, n_out) f32 desc, flat (Nq, n_out) int32 = (r*l_ref + i)*l_ref + j, -1 = empty)."""
     _req(st, "st", torch.float32); _req(ed, "ed", torch.float32)
     if w is not None:
@@ -676,9 +690,14 @@ def moment_topk(st, ed, w, l_ref, min_l, max_l, n_out, summ=None):
     if summ is not None:
         _req(summ, "summ", torch.float32)
         assert tuple(summ.shape) == (nq, kpairs, MOMENT_SUMM)
+    assert (pair_vid is None) == (vid_len is None)
+    if vid_len is not None:
+        _req(pair_vid, "pair_vid", torch.int32); _req(vid_len, "vid_len", torch.int32)
+        assert tuple(pair_vid.shape) == (nq, kpairs)
     sc = torch.empty((nq, n_out), dtype=torch.float32, device=st.device)
     fl = torch.empty((nq, n_out), dtype=torch.int32, device=st.device)
-    check(_lib.load().xml_moment_topk_ex(_p(st), _p(ed), _p(w), _p(summ), _p(sc), _p(fl), nq, kpairs, lpad, int(l_ref),
+    check(_lib.load().xml_moment_topk_ex(_p(st), _p(ed), _p(w), _p(summ), _p(pair_vid), _p(vid_len), _p(sc), _p(fl), nq, kpairs,
+                                         lpad, int(l_ref),
                                          int(min_l), int(max_l), int(n_out), _stream()), "xml_moment_topk_ex")
     return sc, fl
 

@@ -656,9 +656,12 @@ def run(args, backend_factory=None, emit=True):
                 st, ed, sm = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti, ops, pair_w=tw,
                                                                              band=(2, 16)))
                 timed("moment_k9", lambda: ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200, summ=sm))
-            else:
-                st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti, ops))
-                timed("moment_k9", lambda: ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200))
+            else:     # (what vcmr_search runs; ragged corpora: K7 / K9 skip the zero tails of short videos)
+                vl = inf.ragged_lengths(index, ops) if hasattr(inf, "ragged_lengths") else None
+                rk = dict(pair_vid=ti, vid_len=vl) if vl is not None else {}
+                st, ed = timed("convse_k7", lambda: inf.stage_span_probs(model, index, qvec, ti, ops,
+                                                                         **(dict(vid_len=vl) if vl is not None else {})))
+                timed("moment_k9", lambda: ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200, **rk))
     else:       # rank 0's view of one sharded pass, collectives (and the waiting for slower ranks in them) included
         marks = []
 

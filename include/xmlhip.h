@@ -384,7 +384,7 @@ int xml_convse_rerank_f16s(const xml_convse_desc* d, const void* q_lin0, const v
  *  - vid_len (nv) int32 or NULL -- RAGGED CORPORA: valid clips of every video, 1 + the index of its last unmasked clip (TVR:
  *    51 of 128 on average); l_ref for a video without any unmasked clip (its masked softmax is uniform, not zero).  Given: clip rows >= vid_len[v] + ksize / 2 of a video are not fetched (no tap of a valid
  *    position reaches them) and the entries l >= vid_len[v] of st_out / ed_out -- exact zeros of the masked softmax -- are
- *    NOT WRITTEN; their consumer, xml_moment_topk_ex with the same vid_len, does not read them.  Halves K7's writes and
+ *    NOT WRITTEN (whole 16-byte pieces are stored: up to 3 of those zeros behind vid_len[v] may be); their consumer, xml_moment_topk_ex with the same vid_len, does not read them.  Halves K7's writes and
  *    K9's reads at the TVR length distribution; every stored value is bitwise that of xml_convse_rerank.
  *  - summ_out (nq, kpairs, XML_MOMENT_SUMM) f32 or NULL -- per pair, XML_MOMENT_SUMM banded row maxima
  *    (st[i] * pair_w[p]) * max_{min_l <= d < max_l} ed[i + d]  -- the largest one of each group of 16 rows

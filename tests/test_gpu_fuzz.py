@@ -484,7 +484,9 @@ def test_fuzz_k7_candidate_summaries_feed_k9(ops, seed):
     st, ed, summ = ops.convse_rerank(dev(q_lin), dev(feat2), masks, pair.to(DEV), conv_w.to(DEV), l_ref, merged, 5,
                                      pair_w=wd, band=(min_l, max_l))
     st0, ed0 = ops.convse_rerank(dev(q_lin), dev(feat2), masks, pair.to(DEV), conv_w.to(DEV), l_ref, merged, 5)
-    assert torch.equal(st, st0) and torch.equal(ed, ed0)     # the summaries change nothing else
+    # the summaries change nothing else.  (Not bit for bit any more: without summaries the 5-tap case runs the half-wave
+    # epilogue, whose softmax sums its 128 terms in another order -- the last bit of a probability may differ.)
+    assert torch.allclose(st, st0, rtol=4e-6, atol=1e-9) and torch.allclose(ed, ed0, rtol=4e-6, atol=1e-9)
     # restatement: m[i] = (st[i] * w) * max_{min_l <= d < max_l, i + d < l_ref} ed[i + d]; top 8 per pair, descending
     s_, e_ = st.cpu()[..., :l_ref], ed.cpu()[..., :l_ref]
     a = s_ * (w[..., None] if w is not None else 1.0)

@@ -14,11 +14,19 @@
 #include "gemm.h"
 
 static constexpr int TM = 64;            // pairs per workgroup chunk (a video has ~46 pairs at C3: one chunk each)
-static constexpr int LP = 128 + 4;       // padded row length of the LDS similarity patch (floats)
+static constexpr int LP = 128 + 8;       // row of the LDS similarity patch (floats): [4 halo | 128 clips | 4 halo]
+static constexpr int LH = 4;             // the clips start at float LH of a row (the fast epilogue reads 2 before / 5 past)
+
+// Popular videos: with few videos and many pairs (TVR val: 2 179 videos, 1.09 M pairs = 500 per counter) the counting
+// atomics serialise on their addresses -- 138 us of a 1.1 ms K7.  Every video then gets CONVSE_SUB_MAX sub-counters, a pair
+// uses sub-counter (pair id % sub): 16 x fewer collisions per address; the scan runs over the sub-buckets in (video, sub)
+// order, so a video's bucket is still one contiguous range.
+static constexpr int CONVSE_SUB_MAX = 16;
+static inline int convse_sub(int64_t P, int nv) { return P >= 128 * (int64_t)nv ? CONVSE_SUB_MAX : 1; }
 
 struct ConvseWs {
-  int32_t* counts;     // [nv]   pairs per video
-  int32_t* offsets;    // [nv+1] exclusive scan of counts
+  int32_t* counts;     // [nv * sub]   pairs per (video, sub-counter)
+  int32_t* offsets;    // [nv * sub + 1] exclusive scan of counts; video v's bucket = [offsets[v * sub], offsets[(v + 1) * sub])
   int32_t* pos;        // [P]    rank of a pair among the pairs of its video (the value its counting atomic returned)
   int32_t* chunk_off;  // [nv+1] exclusive scan of ceil(count / TM)
   int32_t* bucket;     // [P]    pair ids grouped by video
@@ -33,8 +41,8 @@ static size_t convse_ws_layout(const xml_convse_desc* d, ConvseWs* w, char* base
     return p;
   };
   const size_t nv = (size_t)d->nv, P = (size_t)d->nq * d->kpairs;
-  char* counts = take(nv * 4);
-  char* offsets = take((nv + 1) * 4);
+  char* counts = take(nv * CONVSE_SUB_MAX * 4);             // (sub-counters: see convse_sub)
+  char* offsets = take((nv * CONVSE_SUB_MAX + 1) * 4);
   char* chunk_off = take((nv + 1) * 4);
   char* bucket = take(P * 4);
   char* pos = take(P * 4);
@@ -56,11 +64,11 @@ extern "C" size_t xml_convse_rerank_workspace_bytes(const xml_convse_desc* d) {
 // atomic's return value is the pair's rank inside its video's bucket, so the fill pass is a plain scatter.  (The order of a
 // bucket depends on the atomics' arrival order; every pair writes its own output row, so the results do not.)
 __global__ void convse_count_kernel(const int32_t* __restrict__ pair_vid, int32_t* __restrict__ counts,
-                                    int32_t* __restrict__ pos, int64_t P, int nv) {
+                                    int32_t* __restrict__ pos, int64_t P, int nv, int sub) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int v = pair_vid[p];
-  pos[p] = (v >= 0 && v < nv) ? atomicAdd(&counts[v], 1) : -1;
+  pos[p] = (v >= 0 && v < nv) ? atomicAdd(&counts[(int64_t)v * sub + (int)(p & (sub - 1))], 1) : -1;
 }
 
 // rows of skipped pairs (pair_vid < 0: owned by another shard / padding) are zero-filled: one thread per pair looks, the
@@ -82,14 +90,15 @@ __global__ void convse_zero_skipped_kernel(const int32_t* __restrict__ pair_vid,
 __global__ __launch_bounds__(1024) void convse_scan_kernel(const int32_t* __restrict__ counts,
                                                            int32_t* __restrict__ offsets,
                                                            int32_t* __restrict__ chunk_off,
-                                                           int32_t* __restrict__ chunk_vid, int nv, int TM) {
+                                                           int32_t* __restrict__ chunk_vid, int nv, int TM, int sub) {
   __shared__ int32_t wa[16], wb[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int per = (nv + 1023) / 1024;
   const int r0 = min(nv, tid * per), r1 = min(nv, r0 + per);
   int sa = 0, sb = 0;
   for (int i = r0; i < r1; ++i) {
-    const int c = counts[i];
+    int c = 0;
+    for (int j = 0; j < sub; ++j) c += counts[(int64_t)i * sub + j];
     sa += c; sb += (c + TM - 1) / TM;
   }
   int ia = sa, ib = sb;
@@ -103,21 +112,26 @@ __global__ __launch_bounds__(1024) void convse_scan_kernel(const int32_t* __rest
   int a = ia - sa, b = ib - sb;
   for (int w = 0; w < wave; ++w) { a += wa[w]; b += wb[w]; }
   for (int i = r0; i < r1; ++i) {
-    const int c = counts[i], ch = (c + TM - 1) / TM;
-    offsets[i] = a;
+    int c = 0;
+    for (int j = 0; j < sub; ++j) {
+      const int cj = counts[(int64_t)i * sub + j];
+      offsets[(int64_t)i * sub + j] = a + c;
+      c += cj;
+    }
+    const int ch = (c + TM - 1) / TM;
     chunk_off[i] = b;
     for (int j = 0; j < ch; ++j) chunk_vid[b + j] = i;
     a += c; b += ch;
   }
-  if (tid == 1023) { offsets[nv] = a; chunk_off[nv] = b; }    // the last thread's running sums are the totals
+  if (tid == 1023) { offsets[(int64_t)nv * sub] = a; chunk_off[nv] = b; }    // the last thread's running sums are the totals
 }
 
 __global__ void convse_fill_kernel(const int32_t* __restrict__ pair_vid, const int32_t* __restrict__ offsets,
-                                   const int32_t* __restrict__ pos, int32_t* __restrict__ bucket, int64_t P) {
+                                   const int32_t* __restrict__ pos, int32_t* __restrict__ bucket, int64_t P, int sub) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= P) return;
   const int r = pos[p];
-  if (r >= 0) bucket[offsets[pair_vid[p]] + r] = (int32_t)p;
+  if (r >= 0) bucket[offsets[(int64_t)pair_vid[p] * sub + (int)(p & (sub - 1))] + r] = (int32_t)p;
 }
 
 struct ConvseArgs {
@@ -132,6 +146,7 @@ struct ConvseArgs {
   const int32_t* bucket;
   const int32_t* chunk_vid;
   int nv, kpairs, lpad, l_ref, hidden, n_mod, merged, ksize, softmax;
+  int sub;   // sub-counters per video in `offsets` (convse_sub)
   int dbg;   // perf ablations (xml_debug_set_q2c_ablation): 1 skip the GEMMs, 2 skip the conv / softmax / store epilogue
   int dma;   // rows are whole 128-byte K steps and every row offset fits 32 bits: the LDS-DMA mainloop (gemm.h)
   // XML_F16S operands (split-f16 rows, split16.hip): 1 / S of every query row (nq) and of every clip row (nv * lpad),
@@ -167,8 +182,8 @@ __global__ __launch_bounds__(256, IsSplit16<T>::value ? 2 : 3) void convse_kerne
   const int chunk = blockIdx.x;
   if (chunk >= a.chunk_off[a.nv]) return;
   const int v = a.chunk_vid[chunk];                // video owning this chunk
-  const int first = a.offsets[v] + (chunk - a.chunk_off[v]) * TM;
-  const int cnt = min(TM, a.offsets[v + 1] - first);
+  const int first = a.offsets[(int64_t)v * a.sub] + (chunk - a.chunk_off[v]) * TM;
+  const int cnt = min(TM, a.offsets[(int64_t)(v + 1) * a.sub] - first);
   const int vlen = a.vid_len ? max(0, min(a.vid_len[v], a.l_ref)) : a.l_ref;          // clips whose outputs are stored
   const int b_rows = a.vid_len ? max(1, min(a.lpad, vlen + (a.ksize >> 1))) : a.lpad;   // clip rows the GEMM needs
   constexpr bool SPLIT = IsSplit16<T>::value;
@@ -260,7 +275,7 @@ __global__ __launch_bounds__(256, IsSplit16<T>::value ? 2 : 3) void convse_kerne
           for (int r = 0; r < 4; ++r) {
             float x = acc[mt][nt][r] * scale;
             if constexpr (SPLIT) x *= s_qinv[m][mt * 16 + fg * 4 + r] * cinv[nt];
-            sim[si][mt * 16 + fg * 4 + r][wn * 32 + nt * 16 + fr] = x;
+            sim[si][mt * 16 + fg * 4 + r][LH + wn * 32 + nt * 16 + fr] = x;
           }
     }
   }
@@ -288,6 +303,79 @@ __global__ __launch_bounds__(256, IsSplit16<T>::value ? 2 : 3) void convse_kerne
       mk_r[si][h] = (si < n_sim && l < a.l_ref) ? a.mask[a.merged ? 0 : si][(int64_t)v * a.lpad + l] : 0.f;
     }
   __syncthreads();
+  if (a.ksize == 5 && !a.summ) {
+    // ---- fast epilogue (5 taps, no candidate summaries): HALF a wave per pair row, a lane owns 4 CONSECUTIVE clips ------
+    // The row loop below costs a wave ~30 dependent LDS reads, four 64-lane reductions and four 256-byte stores per pair row
+    // and was 0.6 of K7's 1.1 ms at the as-trained shape (tools/bench_k7.py, ablation 2).  Here a lane reads its 4 clips +
+    // the 2 + 2 halo values once (four 8-byte LDS reads per stream), runs the 2 x 4 x 5 multiply-adds from registers, the
+    // reductions span 32 lanes, two rows are in flight per wave instruction, and a row leaves as two 16-byte stores per lane.
+    const int hsel = lane >> 5, l4 = (lane & 31) * 4;
+    float tw[2][2][5];                                  // [st | ed][stream][tap]
+#pragma unroll
+    for (int w2 = 0; w2 < 2; ++w2)
+#pragma unroll
+      for (int si = 0; si < 2; ++si)
+#pragma unroll
+        for (int t = 0; t < 5; ++t) tw[w2][si][t] = si < n_sim ? s_taps[(w2 * 2 + si) * 16 + t] : 0.f;
+    float mk4[2][4];
+#pragma unroll
+    for (int si = 0; si < 2; ++si)
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        mk4[si][c] = (si < n_sim && l4 + c < a.l_ref) ? a.mask[a.merged ? 0 : si][(int64_t)v * a.lpad + l4 + c] : 0.f;
+    const int store_end = a.vid_len ? ((vlen + 3) & ~3) : a.lpad;     // (whole 16-byte pieces: up to 3 exact zeros past vlen)
+    for (int row = wn * 2 + hsel; row < ((cnt + 7) & ~7); row += 8) {
+      const bool live = row < cnt;
+      const int rr = live ? row : 0;
+      const int p = s_pair[rr];
+      float sv[4] = {0.f, 0.f, 0.f, 0.f}, ev[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int si = 0; si < 2; ++si) {
+        if (si < n_sim) {
+          float x[8];
+          const float2* px = reinterpret_cast<const float2*>(&sim[si][rr][LH + l4 - 2]);       // 8-byte aligned
+#pragma unroll
+          for (int i = 0; i < 4; ++i) { const float2 t2 = px[i]; x[2 * i] = t2.x; x[2 * i + 1] = t2.y; }
+#pragma unroll
+          for (int i = 0; i < 8; ++i) { const int j = l4 - 2 + i; x[i] = (j >= 0 && j < a.l_ref) ? x[i] : 0.f; }   // zero padding at L
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float cs = 0.f, ce = 0.f;
+#pragma unroll
+            for (int t = 0; t < 5; ++t) { cs += tw[0][si][t] * x[c + t]; ce += tw[1][si][t] * x[c + t]; }
+            const float fill = (1.f - mk4[si][c]) * -1e10f;
+            sv[c] += cs * mk4[si][c] + fill;            // mask_logits, xml/model_xml.py:640-641
+            ev[c] += ce * mk4[si][c] + fill;
+          }
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (n_sim > 1) { sv[c] *= inv_mod; ev[c] *= inv_mod; }
+        if (l4 + c >= a.l_ref) { sv[c] = -INFINITY; ev[c] = -INFINITY; }
+      }
+      if (a.softmax) {
+        float ms = fmaxf(fmaxf(sv[0], sv[1]), fmaxf(sv[2], sv[3])), me = fmaxf(fmaxf(ev[0], ev[1]), fmaxf(ev[2], ev[3]));
+        ms = lane16_max_dpp(ms); me = lane16_max_dpp(me);
+        ms = fmaxf(ms, __shfl_xor(ms, 16, 64)); me = fmaxf(me, __shfl_xor(me, 16, 64));
+        float ss = 0.f, se = 0.f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sv[c] = expf(sv[c] - ms); ev[c] = expf(ev[c] - me); ss += sv[c]; se += ev[c]; }
+        ss = lane16_sum_dpp(ss); se = lane16_sum_dpp(se);
+        ss += __shfl_xor(ss, 16, 64); se += __shfl_xor(se, 16, 64);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { sv[c] /= ss; ev[c] /= se; }
+      }
+      if (live && l4 < store_end) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (l4 + c >= a.l_ref) { sv[c] = 0.f; ev[c] = 0.f; }
+        *reinterpret_cast<float4*>(a.st_out + (int64_t)p * a.lpad + l4) = make_float4(sv[0], sv[1], sv[2], sv[3]);
+        *reinterpret_cast<float4*>(a.ed_out + (int64_t)p * a.lpad + l4) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+      }
+    }
+    return;
+  }
   for (int row = wn; row < cnt; row += 4) {
     const int p = s_pair[row];
     float st[2], ed[2];
@@ -304,7 +392,7 @@ __global__ __launch_bounds__(256, IsSplit16<T>::value ? 2 : 3) void convse_kerne
             float cs = 0.f, ce = 0.f;
             for (int t = 0; t < a.ksize; ++t) {
               const int j = l + t - half;
-              const float x = (j >= 0 && j < a.l_ref) ? sim[si][row][j] : 0.f;
+              const float x = (j >= 0 && j < a.l_ref) ? sim[si][row][LH + j] : 0.f;
               cs += wst[t] * x;
               ce += wed[t] * x;
             }
@@ -376,6 +464,7 @@ struct RescoreArgs {
   const int32_t* bucket;
   const int32_t* chunk_vid;
   int nv, kpairs, lpad, hidden, n_mod;
+  int sub;   // see ConvseArgs
   int dma;   // see ConvseArgs
 };
 
@@ -393,8 +482,8 @@ __global__ __launch_bounds__(256, TM == 64 ? 3 : 2) void rescore_kernel(RescoreA
   const int chunk = blockIdx.x;
   if (chunk >= a.chunk_off[a.nv]) return;
   const int v = a.chunk_vid[chunk];
-  const int first = a.offsets[v] + (chunk - a.chunk_off[v]) * TM;
-  const int cnt = min(TM, a.offsets[v + 1] - first);
+  const int first = a.offsets[(int64_t)v * a.sub] + (chunk - a.chunk_off[v]) * TM;
+  const int cnt = min(TM, a.offsets[(int64_t)(v + 1) * a.sub] - first);
   if (tid < TM) s_pair[tid] = tid < cnt ? a.bucket[first + tid] : -1;
   __syncthreads();
   const int lane = tid & 63, wn = tid >> 6;
@@ -562,7 +651,8 @@ static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, cons
     hipLaunchKernelGGL(convse_zero_words_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, st, (uint32_t*)w.counts, nwords);
     XML_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, w.pos, P, d->nv);
+  const int sub = convse_sub(P, d->nv);
+  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, w.pos, P, d->nv, sub);
   XML_CHECK_LAUNCH();
   if (!(d->softmax & 2)) {     // bit 1: the caller never reads the rows of skipped pairs
     hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, st_out, ed_out, P,
@@ -570,11 +660,12 @@ static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, cons
     XML_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid,
-                     d->nv, TM);
+                     d->nv, TM, sub);
   XML_CHECK_LAUNCH();
-  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P);
+  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P, sub);
   XML_CHECK_LAUNCH();
   ConvseArgs a;
+  a.sub = sub;
   a.q_lin[0] = q_lin0; a.q_lin[1] = q_lin1;
   a.feat2[0] = feat2_0; a.feat2[1] = feat2_1;
   a.mask[0] = mask0; a.mask[1] = mask1 ? mask1 : mask0;
@@ -646,7 +737,8 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
     hipLaunchKernelGGL(convse_zero_words_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, st, (uint32_t*)w.counts, nwords);
     XML_CHECK_LAUNCH();
   }
-  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, w.pos, P, nv);
+  const int sub = convse_sub(P, nv);
+  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, w.pos, P, nv, sub);
   XML_CHECK_LAUNCH();
   hipLaunchKernelGGL(rescore_fill_skipped_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, out, P, nv);
   XML_CHECK_LAUNCH();
@@ -654,11 +746,12 @@ extern "C" int xml_q2c_rescore(int n_mod, const void* qn0, const void* qn1, cons
   // chunks, each fetching the tile again)
   const bool big = dt == XML_F16S && P > 64 * (int64_t)nv;
   hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid, nv,
-                     big ? 128 : TM);
+                     big ? 128 : TM, sub);
   XML_CHECK_LAUNCH();
-  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P);
+  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P, sub);
   XML_CHECK_LAUNCH();
   RescoreArgs a;
+  a.sub = sub;
   a.qn[0] = qn0; a.qn[1] = qn1; a.cn[0] = cn0; a.cn[1] = cn1;
   a.mask[0] = mask0; a.mask[1] = mask1 ? mask1 : mask0;
   a.out = out;

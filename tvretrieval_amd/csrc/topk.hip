@@ -4,7 +4,8 @@
 //   1. 4 x 8-bit MSB-first radix-select over the row (LDS histogram; the row is read ONCE into registers when it has
 //      <= 256 * VPT elements, else re-read from L2) -> exact key T of the k-th largest element and how many elements
 //      equal to T are still needed; the bin holding the k-th element is found by a parallel suffix scan;
-//   2. gather every element > T plus the needed ones == T (lowest column first when ties exceed the need);
+//   2. gather every element > T plus the needed ones == T (when ties exceed the need: lowest payload first, i.e. lowest
+//      column without payloads);
 //   3. bitonic sort of the <= 256 survivors by (score desc, payload asc) in LDS; emit exp(alpha*s) + payload.
 // HBM/L2-bound integer work: no reshaping into a GEMM.
 #include "common.h"
@@ -204,6 +205,34 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
       walk([&](uint32_t key, int i, bool valid) {
         if (valid && key >= T) emit(key, i);
       });
+    } else if (pay) {
+      // ties at the threshold exceed the need AND the caller ordered by payload: the need_eq SMALLEST PAYLOADS of the tied
+      // elements (then lowest column) -- the documented order (score desc, payload asc) also at the list's last position.
+      // (Taking the lowest columns here made a merged sharded list depend on which rank a tied candidate came from: one of
+      // 10 000 queries at the TVR shape ended on a different one of two equal-score moments than the single-GPU pass.)
+      // Rare path, short rows (merges: n = world x c): one block-wide minimum per element taken.
+      for (int j = tid; j < n; j += 256) {
+        const uint32_t kj = ord_key(row[j]);
+        if (kj > T) emit(kj, j);
+      }
+      __shared__ unsigned long long s_min;
+      unsigned long long last = 0ull;
+      for (uint32_t t = 0; t < need_eq; ++t) {
+        if (tid == 0) s_min = ~0ull;
+        __syncthreads();
+        unsigned long long best = ~0ull;
+        for (int j = tid; j < n; j += 256) {
+          if (ord_key(row[j]) == T) {
+            const unsigned long long c = ((unsigned long long)(uint32_t)pay[j] << 32) | (unsigned long long)(uint32_t)j;
+            if ((t == 0 || c > last) && c < best) best = c;
+          }
+        }
+        if (best != ~0ull) atomicMin(&s_min, best);
+        __syncthreads();
+        last = s_min;
+        if (tid == 0 && last != ~0ull) emit(T, (int)(uint32_t)(last & 0xffffffffull));
+        __syncthreads();
+      }
     } else {
       // ties at the threshold exceed the need: take the lowest columns, in order (rare path)
       for (int base = 0; base < n; base += 256) {

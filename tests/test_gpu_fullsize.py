@@ -337,3 +337,67 @@ def test_c4_eight_shard_walk_equals_the_single_pass(mode):
         torch.cuda.synchronize()
         assert torch.equal(mi, want["flat_indices"]), "top-200 moments (video-owner scheme) differ from the single pass"
         assert torch.equal(ms, want["flat_scores"])
+
+
+def test_tvr_val_shape_vs_oracle_fp32():
+    """The reference's AS-TRAINED shape (xml/config.py:60-63,86-88,143: hidden 256, max_ctx_l 100; TVR val: 2 179 videos with
+    their real clip counts, resnet_i3d + subtitles, cross attention, merged ConvSE) against the oracle on the GPU box's host
+    cores, fp32: the WHOLE corpus (length-bucketed K6 image, ragged K7 / K9 rows -- the paths only this shape exercises at
+    size) x 640 of the 10 895 queries (the oracle materialises (Nq, Nv, L) like the reference: 640 queries = 1.1 GB).
+    q2c within 1e-4, top-100 videos and top-200 (video, st, ed) identical up to groups of scores tied within rounding."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from tvretrieval_amd import inference as inf
+    _, nv, l, hidden, dv, ds, dq, ctx_mode, _ = bench.WORKLOADS["tvr_val"]
+    nq = 640
+    m, cfg = _synthetic_model("video_sub", hidden, dv, ds, dq, l, torch.float32, seed=23)
+    lens = bench.real_clip_counts(nv, l)
+    g = torch.Generator().manual_seed(2018)
+    vm = (torch.arange(l)[None] < lens[:, None]).float()
+    norm = lambda x: x / (x.norm(dim=-1, keepdim=True) + 1e-5)                   # noqa: E731
+    vf = norm(torch.randn(nv, l, dv, generator=g)) * vm[..., None]
+    sf = norm(torch.randn(nv, l, ds, generator=g)) * vm[..., None]
+    qlens = torch.randint(5, 31, (nq,), generator=g)
+    qm = (torch.arange(30)[None] < qlens[:, None]).float()
+    qf = norm(torch.randn(nq, 30, dq, generator=g)) * qm[..., None]
+    bs = 200                                                                     # eval_context_bsz, xml/config.py:63
+    om = O.OracleXML(cfg, {k: v.detach().cpu() for k, v in m.state_dict().items()})
+    with torch.no_grad():
+        # both sides encode batch by batch at the batch's own padded length and zero-fill beyond it (cat_tensor,
+        # xml/inference.py:71-87): the padded-row semantics the 5-tap filter can see
+        batches, f1v, f2v, f1s, f2s = [], [], [], [], []
+        for b in range(0, nv, bs):
+            lb = int(lens[b:b + bs].max())
+            batches.append((vf[b:b + bs, :lb].to(DEV), vm[b:b + bs, :lb].to(DEV), sf[b:b + bs, :lb].to(DEV), vm[b:b + bs, :lb].to(DEV)))
+            v1, v2, s1, s2 = om.encode_context(vf[b:b + bs, :lb], vm[b:b + bs, :lb], sf[b:b + bs, :lb], vm[b:b + bs, :lb])
+            pad = lambda t: torch.nn.functional.pad(t, (0, 0, 0, l - lb))           # noqa: E731
+            f1v.append(pad(v1)), f2v.append(pad(v2)), f1s.append(pad(s1)), f2s.append(pad(s2))
+        index = inf.build_corpus_index(m, batches, l_ref=l)
+        assert index.ragged and getattr(index.feat1n["video"], "plan", None) is not None      # the ragged paths are the ones on
+        out = inf.vcmr_search(m, index, qf.to(DEV), qm.to(DEV), max_vcmr_video=100, max_before_nms=200)
+        torch.cuda.synchronize()
+        f1v, f2v, f1s, f2s = (torch.cat(t) for t in (f1v, f2v, f1s, f2s))
+        q2c, st, ed = om.get_pred_from_raw_query(qf, qm, f1v, f2v, vm, f1s, f2s, vm, cross=True)
+    err = float((out["q2c"].cpu() - q2c).abs().max())
+    assert err <= 1e-4, "q2c max abs err %g" % err
+    kv, kn, extra = 100, 200, 24
+    gi, gw = out["top_indices"].cpu().numpy().astype(np.int64), out["top_scores"].cpu().numpy()
+    gfi, gfs = out["flat_indices"].cpu().numpy().astype(np.int64), out["flat_scores"].cpu().numpy()
+    n_vid = n_mom = n_rows = 0
+    ll = l * l
+    for c in range(0, nq, 32):
+        sl = slice(c, c + 32)
+        with torch.no_grad():
+            tail = O.vcmr_tail(q2c[sl], st[sl], ed[sl], 20.0, kv, 2, 16, kn + extra)
+            ww, wi = torch.topk(torch.exp(20.0 * q2c[sl]), kv + extra, dim=1)
+        n_vid += _tie_aware_equal(gi[sl], gw[sl], wi.numpy(), ww.numpy(), kv, 2e-4, "top-100 videos")
+        wfi, wfs = tail["flat_indices"].numpy(), tail["flat_scores"].numpy()
+        wkey = np.take_along_axis(tail["top_indices"].numpy(), wfi // ll, 1) * ll + wfi % ll
+        gkey = np.take_along_axis(gi[sl], np.clip(gfi[sl] // ll, 0, kv - 1), 1) * ll + gfi[sl] % ll
+        rows = np.nonzero((np.sort(gi[sl], 1) == np.sort(tail["top_indices"].numpy(), 1)).all(1))[0]
+        n_rows += len(rows)
+        assert (gfi[sl][rows] >= 0).all()
+        n_mom += _tie_aware_equal(gkey[rows], gfs[sl][rows], wkey[rows], wfs[rows], kn, 5e-4, "top-200 moments")
+    print("tvr_val shape, fp32: q2c max err %.2e; %d / %d video and %d / %d moment positions swapped inside tie groups; "
+          "%d of %d queries compared on moments" % (err, n_vid, nq * kv, n_mom, n_rows * kn, n_rows, nq))
+    assert n_rows >= nq - 3 and n_vid <= 100 and n_mom <= 400, (n_rows, n_vid, n_mom)

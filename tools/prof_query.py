@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
 from tvretrieval_amd import inference as inf
 from tvretrieval_amd.model_xml import XML
-nq, nv, l, hidden, dv, ds, dq, ctx_mode, dtname = bench.WORKLOADS["c3"]
+nq, nv, l, hidden, dv, ds, dq, ctx_mode, dtname = bench.WORKLOADS[os.environ.get("Q_WORKLOAD", "c3")]
 dev = torch.device("cuda", 0)
 cfg = bench.model_config(hidden, dv, ds, dq, ctx_mode, l)
 model = XML(cfg, compute_dtype=torch.bfloat16).to(dev).eval()

@@ -7,6 +7,6 @@ f=$(find /tmp/prof_q -name "*kernel_stats.csv" | head -1)
 python - <<PY
 import csv
 rows=list(csv.DictReader(open("$f")))
-for r in rows[:16]:
+for r in rows[:24]:
     print("%-70s calls %5d avg_us %9.1f total_ms %8.2f" % (r["Name"][:70], int(r["Calls"]), float(r["AverageNs"])/1e3, float(r["TotalDurationNs"])/1e6))
 PY

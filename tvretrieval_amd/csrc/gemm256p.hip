@@ -933,7 +933,11 @@ bool xmli_gemm_ln_eligible(int64_t M, int N, int K, int dt) {
   if (dt != XML_F32 && dt != XML_BF16) return false;      // (split-f16 projections take the three-launch path)
   const size_t kb = (size_t)K * dt_size(dt);
   if (!ln_fusion_device_ok()) return false;
-  return kb % 128 == 0 && kb >= 256 && N % 256 == 0 && N / 256 <= 4 && (int64_t)cdiv(M, 256) * (N / 256) >= 768;
+  // N = 256 (the reference's as-trained hidden size, xml/config.py:143): a row is ONE tile, the statistics never leave the
+  // workgroup, nothing waits for a partner -- worth it from one tile per workgroup on (the query encoder of TVR val: 745
+  // tiles; it saves the f32 round trip and the LayerNorm launch behind each of its three projections)
+  const int64_t tiles = (int64_t)cdiv(M, 256) * (N / 256);
+  return kb % 128 == 0 && kb >= 256 && N % 256 == 0 && N / 256 <= 4 && tiles >= (N == 256 ? 256 : 768);
 }
 size_t xmli_gemm_ln_workspace_bytes(int64_t M, int N) {
   return align_up((size_t)(cdiv(M, 256) + 1) * 4, 256) + align_up((size_t)M * 2 * (N / 256 + 1) * 2 * 4, 256);

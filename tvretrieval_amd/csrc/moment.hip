@@ -104,7 +104,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
                                                           int l_ref, int min_l, int max_l, int n_out,
                                                           const float* __restrict__ summ,
                                                           const int32_t* __restrict__ pair_vid,
-                                                          const int32_t* __restrict__ vid_len) {
+                                                          const int32_t* __restrict__ vid_len, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   __syncthreads();
   uint32_t lb = max(sh.prefix, 1u);                        // fewer than n_out positive rows: keep everything > 0
   __syncthreads();
+  if (dbg == 61) return;                                   // (debug build, tools/bench_k9.py: phase timing by early exit)
 
   // ---- 4. expand rows whose maximum reaches lb into the list (raise lb and repeat on overflow) -------------
   uint32_t cnt = 0;
@@ -361,6 +362,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     lb = t_c;
   }
   cnt = min(cnt, (uint32_t)MT_CAP);
+  if (dbg == 62) return;
 
   // ---- 5. bitonic sort (descending) of the list, padded with zeros to a power of two ------------------------
   int npow = 256;
@@ -412,7 +414,7 @@ extern "C" int xml_moment_topk_ex(const float* st, const float* ed, const float*
   if (n_out > 1024 || lpad > 128 || kpairs > 4 * MT_PPW) return XML_ERR_UNSUPPORTED;   // (st, ed: probabilities, >= 0)
   const size_t lds = (size_t)MT_CAP * 8 + 2048 * 4;
   hipLaunchKernelGGL(moment_topk_kernel, dim3(nq), dim3(256), lds, (hipStream_t)stream, st, ed, w, out_score, out_flat,
-                     kpairs, lpad, l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len);
+                     kpairs, lpad, l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len, (int)g_q2c_ablation);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -824,6 +824,17 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
   a.qsh = a.tq >= 5 ? 3 : a.tq >= 3 ? 2 : a.tq == 2 ? 1 : 0;     // few queries: more workgroups share a query tile
+  if (a.qsh == 3) {
+    // The walk hands every workgroup ceil(tq / 2^qsh) x ceil(tc / (8 x 2^(5 - qsh))) tiles, valid or not: with 43 query
+    // tiles (TVR val, 10 895 queries) the 8 x 4 super-tile walks 48 x 576 slots for 43 x 573 tiles, the 4 x 8 one 44 x 576
+    // (-8 % of the kernel's time).  Take the 4 x 8 shape when it saves more than 3 % of the slots -- it fetches every clip
+    // tile for 4 instead of 8 query tiles per XCD, which is what the 8 x 4 shape is there to avoid when the two tie.
+    auto slots = [&](int qsh) -> int64_t {
+      const int64_t qg = (a.tq + (1 << qsh) - 1) >> qsh, per = 8ll << (5 - qsh);
+      return (qg << qsh) * ((a.tc + per - 1) / per * per);
+    };
+    if (slots(2) * 100 < slots(3) * 97) a.qsh = 2;
+  }
   // Walk order: rsh = 20 is the straight order (every query group walks the whole corpus).  The chunked order
   // (2^rsh rounds per Infinity-Cache-sized chunk, all query groups per chunk; debug knob xml_debug_set_q2c_chunk) was
   // measured in round 2: 4-round chunks cut the HBM passes over the corpus from one per query group to one per launch

@@ -275,6 +275,8 @@ def _build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, vid
         if keep_raw:
             raw[m] = f1
     idx = CorpusIndex(mods, feat1n, feat2, mask, l_ref, video_offset, n_total)
+    if getattr(ops, "RAGGED_ROWS", False):
+        idx.set_valid_lengths()
     idx.raw_feat1 = raw
     if exact_filter:
         idx.exact = _make_exact_filter(ex_f32, ex_ec, exact_mode_of(model, ops))

@@ -926,6 +926,90 @@ __global__ __launch_bounds__(256) void modular_pool_small_kernel(const T* __rest
   }
 }
 
+// hidden <= 256 (the reference's as-trained size): ONE WAVE per query, no LDS, no barriers.  Half h of the wave takes tokens
+// h, h + 2, ...; lane v of a half holds 8 consecutive features of each of its tokens (16 tokens x 8 floats in registers).
+// The workgroup-per-query kernel above spends its time on a workgroup's launch, two barriers and an LDS reduction for 9 KB
+// of data, and at hidden = 256 half its lanes hold nothing: 126 us for the 10 895 queries of TVR val, this one ~25.
+template <typename T>
+__global__ __launch_bounds__(256) void modular_pool_wave_kernel(const T* __restrict__ enc, const float* __restrict__ mask,
+                                                                const float* __restrict__ wm, T* __restrict__ out,
+                                                                int64_t n, int lq, int hidden, int n_mod,
+                                                                const int32_t* __restrict__ cu) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, v = lane & 31;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n) return;
+  const int nvec = hidden >> 3;
+  int64_t row0 = q * lq;
+  if (cu) {
+    const int r0 = cu[q], r1 = cu[q + 1];
+    row0 = r0;
+    lq = r1 - r0;
+  }
+  const bool von = v < nvec;
+  const int vc = von ? v : 0;
+  float w0[8], w1[8];
+  ld8<float>(wm + vc * 8, w0);
+  ld8<float>(wm + (n_mod > 1 ? hidden : 0) + vc * 8, w1);
+  float x[16][8], mk[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {                 // unconditional loads from clamped indices (see the kernel above)
+    const int l = 2 * i + half, lc = l < lq ? l : 0;
+    mk[i] = cu ? 1.f : mask[row0 + lc];
+    ld8<T>(enc + (row0 + lc) * hidden + vc * 8, x[i]);
+  }
+  float s0[16], s1[16], mx0 = -INFINITY, mx1 = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const bool lon = 2 * i + half < lq;
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x[i][j] = (lon && von) ? x[i][j] : 0.f;
+      a += x[i][j] * w0[j];
+      b += x[i][j] * w1[j];
+    }
+    a = lane16_sum_dpp(a); b = lane16_sum_dpp(b);
+    a += __shfl_xor(a, 16, 64); b += __shfl_xor(b, 16, 64);          // the 32 lanes of this half
+    const float m = lon ? mk[i] : 0.f;
+    s0[i] = lon ? a * m + (1.f - m) * -1e10f : -INFINITY;            // mask_logits, xml/model_xml.py:640-641
+    s1[i] = lon ? b * m + (1.f - m) * -1e10f : -INFINITY;
+    mx0 = fmaxf(mx0, s0[i]); mx1 = fmaxf(mx1, s1[i]);
+  }
+  mx0 = fmaxf(mx0, __shfl_xor(mx0, 32, 64)); mx1 = fmaxf(mx1, __shfl_xor(mx1, 32, 64));
+  float sum0 = 0.f, sum1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    s0[i] = 2 * i + half < lq ? expf(s0[i] - mx0) : 0.f;
+    s1[i] = 2 * i + half < lq ? expf(s1[i] - mx1) : 0.f;
+    sum0 += s0[i]; sum1 += s1[i];
+  }
+  sum0 += __shfl_xor(sum0, 32, 64); sum1 += __shfl_xor(sum1, 32, 64);
+  float a0[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, a1[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const float p0 = s0[i] / sum0, p1 = n_mod > 1 ? s1[i] / sum1 : 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { a0[j] += p0 * x[i][j]; a1[j] += p1 * x[i][j]; }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { a0[j] += __shfl_xor(a0[j], 32, 64); a1[j] += __shfl_xor(a1[j], 32, 64); }
+  if (von) {      // half 0 stores modality 0, half 1 modality 1
+    if (half == 0) st8<T>(out + q * hidden + v * 8, a0);
+    else if (n_mod > 1) st8<T>(out + ((int64_t)n + q) * hidden + v * 8, a1);
+  }
+}
+
+template <typename T>
+static void launch_modular_pool_small(const void* enc, const float* mask, const float* w_m, void* out, int64_t n, int lq,
+                                      int hidden, int n_mod, const int32_t* cu, hipStream_t st) {
+  if (hidden <= 256)
+    hipLaunchKernelGGL(modular_pool_wave_kernel<T>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const T*)enc, mask, w_m,
+                       (T*)out, n, lq, hidden, n_mod, cu);
+  else
+    hipLaunchKernelGGL(modular_pool_small_kernel<T>, dim3((unsigned)n), dim3(256), 0, st, (const T*)enc, mask, w_m, (T*)out,
+                       n, lq, hidden, n_mod, cu);
+}
+
 extern "C" int xml_modular_pool(const void* enc, const float* mask, const float* w_m, void* out, int64_t n, int lq,
                                 int hidden, int n_mod, int dt, xml_stream_t stream) {
   XML_ENTER();
@@ -933,14 +1017,9 @@ extern "C" int xml_modular_pool(const void* enc, const float* mask, const float*
   if (n_mod < 1 || n_mod > 2 || lq > 128) return XML_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (lq <= 32 && hidden % 8 == 0 && hidden <= 1024) {
-    if (dt == XML_F32)
-      hipLaunchKernelGGL(modular_pool_small_kernel<float>, dim3((unsigned)n), dim3(256), 0, st, (const float*)enc, mask,
-                         w_m, (float*)out, n, lq, hidden, n_mod, (const int32_t*)nullptr);
-    else if (dt == XML_BF16)
-      hipLaunchKernelGGL(modular_pool_small_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, st, (const bf16_t*)enc,
-                         mask, w_m, (bf16_t*)out, n, lq, hidden, n_mod, (const int32_t*)nullptr);
-    else
-      return XML_ERR_BAD_ARG;
+    if (dt == XML_F32) launch_modular_pool_small<float>(enc, mask, w_m, out, n, lq, hidden, n_mod, nullptr, st);
+    else if (dt == XML_BF16) launch_modular_pool_small<bf16_t>(enc, mask, w_m, out, n, lq, hidden, n_mod, nullptr, st);
+    else return XML_ERR_BAD_ARG;
     XML_CHECK_LAUNCH();
     return XML_OK;
   }
@@ -964,14 +1043,9 @@ extern "C" int xml_modular_pool_varlen(const void* enc, const int32_t* cu_seqlen
   if (!enc || !cu_seqlens || !w_m || !out || n <= 0 || max_len <= 0 || hidden <= 0) return XML_ERR_BAD_ARG;
   if (n_mod < 1 || n_mod > 2 || max_len > 32 || hidden % 8 || hidden > 1024) return XML_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (dt == XML_F32)
-    hipLaunchKernelGGL(modular_pool_small_kernel<float>, dim3((unsigned)n), dim3(256), 0, st, (const float*)enc,
-                       (const float*)nullptr, w_m, (float*)out, n, max_len, hidden, n_mod, cu_seqlens);
-  else if (dt == XML_BF16)
-    hipLaunchKernelGGL(modular_pool_small_kernel<bf16_t>, dim3((unsigned)n), dim3(256), 0, st, (const bf16_t*)enc,
-                       (const float*)nullptr, w_m, (bf16_t*)out, n, max_len, hidden, n_mod, cu_seqlens);
-  else
-    return XML_ERR_BAD_ARG;
+  if (dt == XML_F32) launch_modular_pool_small<float>(enc, nullptr, w_m, out, n, max_len, hidden, n_mod, cu_seqlens, st);
+  else if (dt == XML_BF16) launch_modular_pool_small<bf16_t>(enc, nullptr, w_m, out, n, max_len, hidden, n_mod, cu_seqlens, st);
+  else return XML_ERR_BAD_ARG;
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -13,9 +13,10 @@ extern int g_gemm_variant;      // 0 auto, 1 force the 128x128 register-staged k
 extern int g_q2c_xcd_swizzle;
 extern int g_q2c_chunk_log2;    // -1 auto; K6 corpus walk: rounds per MALL-resident chunk = 2^v (30 = one chunk = old order)
 extern int g_q2c_line_log2;     // K6 walk: 2^v consecutive rounds of an XCD on adjacent clip tiles (Q2cPersistArgs::lsh)
+extern int g_q2c_qsh;           // -1 auto; K6 super-tile of an XCD: 2^v query tiles x 2^(5-v) clip tiles (v = 0..4)
 #else
 static constexpr int g_q2c_variant = 0, g_q2c_ablation = 0, g_gemm_variant = 0, g_q2c_xcd_swizzle = 1,
-                     g_q2c_chunk_log2 = -1, g_q2c_line_log2 = 0;
+                     g_q2c_chunk_log2 = -1, g_q2c_line_log2 = 0, g_q2c_qsh = -1;
 #endif
 
 // hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device) and per growth of the requested size -- not on

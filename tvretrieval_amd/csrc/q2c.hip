@@ -92,12 +92,13 @@ __global__ __launch_bounds__(256) void q2c_scores_kernel(const T* __restrict__ q
 }
 
 #ifdef XML_DEBUG_VARIANTS
-int g_q2c_xcd_swizzle = 1, g_q2c_variant = 0, g_q2c_ablation = 0, g_q2c_chunk_log2 = -1, g_q2c_line_log2 = 0;
+int g_q2c_xcd_swizzle = 1, g_q2c_variant = 0, g_q2c_ablation = 0, g_q2c_chunk_log2 = -1, g_q2c_line_log2 = 0, g_q2c_qsh = -1;
 extern "C" void xml_debug_set_q2c_swizzle(int on) { g_q2c_xcd_swizzle = on; }
 extern "C" void xml_debug_set_q2c_variant(int v) { g_q2c_variant = v; }
 extern "C" void xml_debug_set_q2c_ablation(int v) { g_q2c_ablation = v; }
 extern "C" void xml_debug_set_q2c_chunk(int v) { g_q2c_chunk_log2 = v; }
 extern "C" void xml_debug_set_q2c_line(int v) { g_q2c_line_log2 = v; }
+extern "C" void xml_debug_set_q2c_qsh(int v) { g_q2c_qsh = v; }
 #endif
 
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,

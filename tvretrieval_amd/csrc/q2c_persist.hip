@@ -835,6 +835,7 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
     };
     if (slots(2) * 100 < slots(3) * 97) a.qsh = 2;
   }
+  if (g_q2c_qsh >= 0 && g_q2c_qsh <= 4) a.qsh = g_q2c_qsh;       // (debug build: tools/k6_l2_ab.py)
   // Walk order: rsh = 20 is the straight order (every query group walks the whole corpus).  The chunked order
   // (2^rsh rounds per Infinity-Cache-sized chunk, all query groups per chunk; debug knob xml_debug_set_q2c_chunk) was
   // measured in round 2: 4-round chunks cut the HBM passes over the corpus from one per query group to one per launch

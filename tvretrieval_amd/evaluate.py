@@ -22,6 +22,40 @@ def compute_temporal_iou_batch(preds, gt):
     return np.divide(inter, union, out=np.zeros_like(inter), where=union != 0)
 
 
+_GT_CACHE = {}
+
+
+def _ground_truth_arrays(ground_truth, keys, gt_by_id, video2idx, use_desc_type):
+    """(gt video idx f32, description type, gt spans (n, n_ts, 2) f32, spans per query) for `keys`.  The three tasks of one
+    eval_retrieval call -- and the calls before / after NMS -- share one ground truth: built once per (list, key set)."""
+    ck = (id(ground_truth), len(ground_truth), id(video2idx), bool(use_desc_type), len(keys), keys[0] if keys else None,
+          keys[-1] if keys else None)
+    hit = _GT_CACHE.get(ck)
+    if hit is not None and hit[0] is ground_truth:
+        return hit[1]
+    n_desc = len(keys)
+    gt_vid = np.zeros(n_desc, dtype=np.float32)
+    desc_types = np.zeros(n_desc, dtype=np.int64)
+    n_ts = max(len(gt_by_id[k]["ts"]) if len(gt_by_id[k]["ts"]) >= 4 else 1 for k in keys)
+    gt_ts = np.zeros((n_desc, n_ts, 2), dtype=np.float32)
+    n_gt = np.ones(n_desc, dtype=np.int64)
+    for i, k in enumerate(keys):
+        g = gt_by_id[k]
+        gt_vid[i] = video2idx[g["vid_name"]]
+        if use_desc_type:
+            desc_types[i] = DESC_TYPE2IDX[g["type"]]
+        if len(g["ts"]) >= 4:                                   # didemo: list of [st, ed]
+            ts = np.asarray(g["ts"], dtype=np.float32)
+            gt_ts[i, :len(ts)] = ts
+            n_gt[i] = len(ts)
+        else:
+            gt_ts[i, 0] = np.asarray(g["ts"], dtype=np.float32)
+    out = (gt_vid, desc_types, gt_ts, n_gt)
+    _GT_CACHE.clear()                       # one ground truth at a time (an evaluation run)
+    _GT_CACHE[ck] = (ground_truth, out)
+    return out
+
+
 def eval_by_task_type(moment_predictions, video2idx, ground_truth, iou_thds=(0.5, 0.7), recall_topks=(1, 5, 10, 100),
                       task_type="SVMR", max_pred_per_query=100, match_number=True, verbose=True, use_desc_type=True):
     assert task_type in TASK_TYPES
@@ -48,27 +82,13 @@ def eval_by_task_type(moment_predictions, video2idx, ground_truth, iou_thds=(0.5
         n_pred = max(min(len(pred_by_id[k]["predictions"]), max_pred_per_query) for k in keys)
         P = np.zeros((n_desc, n_pred, 3), dtype=np.float32)       # [vid, st, ed], zero padded like pad_sequences_1d_np
         valid = np.zeros((n_desc, n_pred), dtype=bool)
-    gt_vid = np.zeros(n_desc, dtype=np.float32)
-    desc_types = np.zeros(n_desc, dtype=np.int64)
-    n_ts = max(len(gt_by_id[k]["ts"]) if len(gt_by_id[k]["ts"]) >= 4 else 1 for k in keys)
-    gt_ts = np.zeros((n_desc, n_ts, 2), dtype=np.float32)
-    n_gt = np.ones(n_desc, dtype=np.int64)
-    for i, k in enumerate(keys):
-        g = gt_by_id[k]
-        if not arrays:
+    gt_vid, desc_types, gt_ts, n_gt = _ground_truth_arrays(ground_truth, keys, gt_by_id, video2idx, use_desc_type)
+    if not arrays:
+        for i, k in enumerate(keys):
             pr = [e[:3] for e in pred_by_id[k]["predictions"]][:max_pred_per_query]
             if len(pr):
                 P[i, :len(pr)] = np.asarray(pr, dtype=np.float32)
                 valid[i, :len(pr)] = True
-        gt_vid[i] = video2idx[g["vid_name"]]
-        if use_desc_type:
-            desc_types[i] = DESC_TYPE2IDX[g["type"]]
-        if len(g["ts"]) >= 4:                                   # didemo: list of [st, ed]
-            ts = np.asarray(g["ts"], dtype=np.float32)
-            gt_ts[i, :len(ts)] = ts
-            n_gt[i] = len(ts)
-        else:
-            gt_ts[i, 0] = np.asarray(g["ts"], dtype=np.float32)
     vid_match = (P[..., 0] == gt_vid[:, None]) & valid                      # (n_desc, n_pred)
     iou = compute_temporal_iou_batch(P[:, :, None, 1:3], gt_ts[:, None, :, :]) * vid_match[..., None]   # (n_desc,n_pred,n_ts)
     ts_valid = np.arange(gt_ts.shape[1])[None, :] < n_gt[:, None]            # (n_desc, n_ts)
@@ -82,11 +102,14 @@ def eval_by_task_type(moment_predictions, video2idx, ground_truth, iou_thds=(0.5
     metrics, metrics_by_type = OrderedDict(), OrderedDict()
 
     def first_k_hit(c, k):                      # VCMR / VR: any positive among the first k predictions
-        return c[:, :k].sum(1) >= 1
+        return c[:, :k].any(1)
+
+    rank_cache = []
 
     def first_k_hit_matched(c, k):              # SVMR: among the first k predictions OF THE GT VIDEO
-        rank = np.cumsum(vid_match, axis=1)     # 1-based rank of each matched prediction
-        return (c & vid_match & (rank <= k)).sum(1) >= 1
+        if not rank_cache:                      # 1-based rank of each matched prediction: one cumsum for all thresholds / ks
+            rank_cache.append(np.cumsum(vid_match, axis=1, dtype=np.int32))
+        return (c & vid_match & (rank_cache[0] <= k)).any(1)
 
     if task_type == "VCMR":
         for c, thd in zip(corrects, iou_thds):

@@ -49,26 +49,6 @@ __device__ __forceinline__ void dma16s(uint32_t voff, const char* sbase, uint32_
       : "memory");
 }
 
-// the four pieces of a slice (2 x 1 KiB of A, 2 x 1 KiB of B) in one statement: M0 is advanced by immediates
-// (0x400 to the next piece, 0x3c00 from A's second piece to B's first: OPER_BYTES - 0x400) and left as is -- the
-// compiler reserves M0 and sets it itself before any instruction of its own that reads it
-__device__ __forceinline__ void dma_slice4(uint32_t va0, uint32_t va1, uint32_t vb0, uint32_t vb1, const char* sa,
-                                           const char* sb, uint32_t lds_dst) {
-  asm volatile(
-      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-      "s_add_u32 m0, m0, 0x3c00\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %6\n\t"
-      "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, %6"
-      :
-      : "v"(va0), "v"(va1), "v"(vb0), "v"(vb1), "s"(lds_dst), "s"(sa), "s"(sb)
-      : "memory", "scc");
-}
-
-// one 1 KiB piece (M0 is left pointing at it; the compiler reserves M0 and sets it itself before any use of its own)
-__device__ __forceinline__ void dma16m(uint32_t voff, const char* sbase, uint32_t lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(voff), "s"(sbase), "s"(lds_dst) : "memory");
-}
-
 // two consecutive 1 KiB pieces of one operand
 __device__ __forceinline__ void dma_pair(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
   asm volatile(
@@ -89,61 +69,6 @@ __device__ __forceinline__ void dma_quad(uint32_t v0, uint32_t v1, uint32_t v2, 
       :
       : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst), "s"(sb)
       : "memory", "scc");
-}
-
-// TILED operands: the pieces a wave fetches are consecutive 1 KiB blocks of the tile image AND land in consecutive 1 KiB
-// blocks of the ring slot, and the instruction offset is added on both sides (memory address and LDS address), so one
-// address register, one M0 write and immediates replace the per-piece registers and the s_add / s_nop pairs
-__device__ __forceinline__ void dma_quad_imm(uint32_t v0, const char* sb, uint32_t lds_dst) {
-  asm volatile(
-      "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-      "global_load_lds_dwordx4 %0, %2 offset:1024\n\t"
-      "global_load_lds_dwordx4 %0, %2 offset:2048\n\t"
-      "global_load_lds_dwordx4 %0, %2 offset:3072"
-      :
-      : "v"(v0), "s"(lds_dst), "s"(sb)
-      : "memory");
-}
-__device__ __forceinline__ void dma_pair_imm(uint32_t v0, const char* sb, uint32_t lds_dst) {
-  asm volatile(
-      "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\t"
-      "global_load_lds_dwordx4 %0, %2 offset:1024"
-      :
-      : "v"(v0), "s"(lds_dst), "s"(sb)
-      : "memory");
-}
-
-// ABL 14 / 15 (experiments): wider spacing between the pieces of a wave (s_nop 3 / s_nop 7 instead of s_nop 0)
-template <int NOP>
-__device__ __forceinline__ void dma_quad_sp(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, const char* sb,
-                                            uint32_t lds_dst) {
-  asm volatile(
-      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\ts_nop %6\n\tglobal_load_lds_dwordx4 %1, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\ts_nop %6\n\tglobal_load_lds_dwordx4 %2, %5\n\t"
-      "s_add_u32 m0, m0, 0x400\n\ts_nop %6\n\tglobal_load_lds_dwordx4 %3, %5"
-      :
-      : "v"(v0), "v"(v1), "v"(v2), "v"(v3), "s"(lds_dst), "s"(sb), "n"(NOP)
-      : "memory", "scc");
-}
-template <int NOP>
-__device__ __forceinline__ void dma_pair_sp(uint32_t v0, uint32_t v1, const char* sb, uint32_t lds_dst) {
-  asm volatile(
-      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %3\n\t"
-      "s_add_u32 m0, m0, 0x400\n\ts_nop %4\n\tglobal_load_lds_dwordx4 %1, %3"
-      :
-      : "v"(v0), "v"(v1), "s"(lds_dst), "s"(sb), "n"(NOP)
-      : "memory", "scc");
-}
-
-// same, with the non-temporal hint: streamed clip tiles should not displace the L2-resident query group
-__device__ __forceinline__ void dma16s_nt(uint32_t voff, const char* sbase, uint32_t lds_dst) {
-  uint32_t keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 nt\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(voff), "s"(sbase), "s"(lds_dst)
-      : "memory");
 }
 
 // first K chunk of a segment: C = 0 as an inline constant (no 128 v_mov per segment to clear the accumulators)
@@ -222,29 +147,23 @@ __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3
 // padding rows cost no MFMA work; the epilogue takes one masked maximum per sub-slot and scatters it to the video's
 // ORIGINAL column of `out` (ids through scalar loads) -- the scores are bitwise those of the unbucketed layout.
 template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false, bool NOMASK = false, bool BITMASK = false,
-          bool PACKED = false>   // ABL (perf ablations only): 1 no DMA after the prologue, 2 no MFMA
+          bool PACKED = false>   // ABL (debug library only): 1 no DMA after the prologue, 2 no MFMA, 8 timing probe
 __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
   constexpr int SLOT_BYTES = 2 * OPER_BYTES;
   // Uneven DMA duty: the timing probe shows the first wave group parked at the barrier ~35 % of the time while the
   // second is on the critical path, so the first group issues 6 of the 8 pieces per SIMD pair -- its wave w loads A
-  // pieces 4w..4w+3 and B pieces 2w, 2w+1; wave 4+w loads B pieces 8+2w, 9+2w (+1 % measured; all 8 on the first
-  // group, ablation 10, gives the gain back).  Ablations 3 and 11 keep the even 4 / 4 split.
-  constexpr bool UNEVEN = (ABL != 3 && ABL != 11);
-  constexpr bool ALL_G0 = (ABL == 10);          // ABL 10: the first group issues all 8 pieces per SIMD pair
-  // ABL 13 (experiment, measured and NOT kept): one address register + `offset:` immediates for the pieces of a wave
-  // (the instruction offset applies to the memory AND the LDS address: bitwise the same scores) -- 6 scalar instructions
-  // fewer per slice, yet 68.2 vs 64.6 ms: back-to-back LDS-DMA instructions of one wave cost more than the same
-  // instructions spaced by the s_add / s_nop pairs (profiles/r02_k6_notes.md)
-  constexpr bool IMM_DMA = (ABL == 13);
+  // pieces 4w..4w+3 and B pieces 2w, 2w+1; wave 4+w loads B pieces 8+2w, 9+2w (+1 % measured against the even 4 / 4
+  // split; all 8 on the first group gives the gain back).  (Measured and not kept, profiles/r01-r02_k6_notes.md: one
+  // address register + `offset:` immediates for a wave's pieces, wider s_nop spacing between them, DMA pieces issued
+  // between the MFMAs, non-temporal clip loads.  Their code lives in the history, not here.)
   // NOMASK (the caller vouches that every clip mask is 1: full-length videos, e.g. the TVR benchmark shape): no mask
   // patches are needed, the 2 KiB they occupy are what a FIFTH ring slot was missing (5 x 32 KiB = all 160 KiB of LDS):
-  // three slices in flight behind the awaited one instead of two, +1.1-1.3 % measured.  (ABL 7: the same on row-major
-  // operands, experiment.)
+  // three slices in flight behind the awaited one instead of two, +1.1-1.3 % measured.
   // BITMASK: ragged corpora get the fifth slot too -- binary clip masks packed 128 bits per video arrive through SCALAR
   // loads (lgkmcnt, invisible to the hand-counted vmcnt of the DMA stream), no mask DMA, no LDS patches.
-  constexpr bool FIVE = (ABL == 7) || NOMASK || BITMASK || PACKED;
+  constexpr bool FIVE = NOMASK || BITMASK || PACKED;
   constexpr int NSLOT = FIVE ? 5 : 4;
   constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
@@ -297,11 +216,14 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
   // ---- issue side (DMA stream, runs up to 3 slices ahead of the slice being computed) ---------------------
   const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const uint32_t lds_wave = lds0 + wave * 2048;
+  // this wave's byte offsets inside a slot's operand images, pinned in SGPRs (opaque to the compiler: rematerialising the
+  // shift in front of every DMA group is one more scalar instruction per slice that the partner wave's MFMAs do not cover)
+  uint32_t wave_2k = (uint32_t)wave * 2048u, wave_4k = (uint32_t)wave * 4096u;
+  asm volatile("" : "+s"(wave_2k), "+s"(wave_4k));
   int i_g = 0, i_c = -1, i_mod = 0, i_slice = 0, i_seg = 0;
   uint32_t i_gs = 0;                               // slices issued so far (global) -> ring slot
   uint32_t voff_a0 = 0, voff_a1 = 0, voff_b0 = 0, voff_b1 = 0;
-  uint32_t voff_x[ALL_G0 ? 4 : UNEVEN ? 2 : 1] = {};   // UNEVEN: A pieces 2, 3 (+ ALL_G0: B pieces 2, 3) of the first group's waves
+  uint32_t voff_x[2] = {};                         // A pieces 2, 3 of the first group's waves
   const char* sbase_a = nullptr;
   const char* sbase_b = nullptr;
 
@@ -311,18 +233,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     asm volatile("" : "+v"(lane_o));                // the MFMA loop) everything derived from the lane id below
     if (new_tile) {
       const int rsub = lane_o >> 2, pslot = lane_o & 3;
-      if constexpr (!UNEVEN) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int row = (wave * 2 + i) * 16 + rsub;                     // 0..255
-          const int slot = pslot ^ swz4p(row);
-          const int qrow = (q0 + row < a.nq) ? row : 0;                   // clamp to the tile's first row
-          const int brow = (v0 + (row >> 7) < a.nv) ? row : (row & 127);  // second video missing: re-read the first
-          const uint32_t va = (uint32_t)qrow * row_stride + slot * 16;
-          const uint32_t vb = (uint32_t)brow * row_stride + slot * 16;
-          if (i == 0) { voff_a0 = va; voff_b0 = vb; } else { voff_a1 = va; voff_b1 = vb; }
-        }
-      } else {
+      {
         auto off_a = [&](int piece) -> uint32_t {
           const int row = piece * 16 + rsub;
           const int qrow = (q0 + row < a.nq) ? row : 0;
@@ -335,13 +246,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         };
         if (grp == 0) {
           voff_a0 = off_a(wave * 4); voff_a1 = off_a(wave * 4 + 1); voff_x[0] = off_a(wave * 4 + 2); voff_x[1] = off_a(wave * 4 + 3);
-          if constexpr (ALL_G0) {
-            voff_b0 = off_b(wave * 4); voff_b1 = off_b(wave * 4 + 1);
-            voff_x[ALL_G0 ? 2 : 0] = off_b(wave * 4 + 2); voff_x[ALL_G0 ? 3 : 0] = off_b(wave * 4 + 3);
-          } else {
-            voff_b0 = off_b(wave * 2); voff_b1 = off_b(wave * 2 + 1);
-          }
-        } else if (!ALL_G0) {
+          voff_b0 = off_b(wave * 2); voff_b1 = off_b(wave * 2 + 1);
+        } else {
           voff_b0 = off_b(8 + (wave - 4) * 2); voff_b1 = off_b(9 + (wave - 4) * 2);
         }
       }
@@ -380,43 +286,13 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   };
   auto issue_slice = [&]() {
     const int koff = i_slice * SLICE_STRIDE;
-    const uint32_t dst = lds_wave + i_slot * SLOT_BYTES;
     if (ABL != 1 || i_gs < 4) {
-      if (ABL == 3) {
-        dma16s(voff_a0, sbase_a + koff, dst);
-        dma16s(voff_a1, sbase_a + koff, dst + 1024);
-        dma16s_nt(voff_b0, sbase_b + koff, dst + OPER_BYTES);
-        dma16s_nt(voff_b1, sbase_b + koff, dst + OPER_BYTES + 1024);
-      } else if constexpr (!UNEVEN) {
-        dma_slice4(voff_a0, voff_a1, voff_b0, voff_b1, sbase_a + koff, sbase_b + koff, dst);
+      const uint32_t slot0 = lds0 + i_slot * SLOT_BYTES;
+      if (grp == 0) {
+        dma_quad(voff_a0, voff_a1, voff_x[0], voff_x[1], sbase_a + koff, slot0 + wave_4k);
+        dma_pair(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + wave_2k);
       } else {
-        const uint32_t slot0 = lds0 + i_slot * SLOT_BYTES;
-        if (TILED && !ALL_G0 && IMM_DMA) {
-          if (grp == 0) {
-            dma_quad_imm(voff_a0, sbase_a + koff, slot0 + wave * 4096);
-            dma_pair_imm(voff_b0, sbase_b + koff, slot0 + OPER_BYTES + wave * 2048);
-          } else {
-            dma_pair_imm(voff_b0, sbase_b + koff, slot0 + OPER_BYTES + 8192 + (wave - 4) * 2048);
-          }
-        } else if (ABL == 14 || ABL == 15) {
-          constexpr int NOP = ABL == 14 ? 3 : 7;
-          if (grp == 0) {
-            dma_quad_sp<NOP>(voff_a0, voff_a1, voff_x[0], voff_x[UNEVEN ? 1 : 0], sbase_a + koff, slot0 + wave * 4096);
-            dma_pair_sp<NOP>(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + wave * 2048);
-          } else {
-            dma_pair_sp<NOP>(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + 8192 + (wave - 4) * 2048);
-          }
-        } else if (grp == 0) {
-          if (ABL != 17 || i_gs < 5)      // ABL 17 (timing bound only, wrong scores; +3.6 %): the query operand costs nothing -- no
-            dma_quad(voff_a0, voff_a1, voff_x[0], voff_x[UNEVEN ? 1 : 0], sbase_a + koff, slot0 + wave * 4096);   // DMA, no LDS reads
-          if constexpr (ALL_G0)
-            dma_quad(voff_b0, voff_b1, voff_x[ALL_G0 ? 2 : 0], voff_x[ALL_G0 ? 3 : 0], sbase_b + koff,
-                     slot0 + OPER_BYTES + wave * 4096);
-          else
-            dma_pair(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + wave * 2048);
-        } else if (!ALL_G0) {
-          dma_pair(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + 8192 + (wave - 4) * 2048);
-        }
+        dma_pair(voff_b0, voff_b1, sbase_b + koff, slot0 + OPER_BYTES + wave_2k);      // (8192 + (wave - 4) * 2048)
       }
     }
     issue_advance();
@@ -437,18 +313,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   issue_slice(); issue_slice(); issue_slice(); issue_slice();
   if (NSLOT == 5) {
     issue_slice();                                       // five slices in flight, the first one awaited
-    if (!UNEVEN) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-    else if (grp == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  } else if (UNEVEN) {
-    if (grp == 0) {
-      if (ALL_G0) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-      else asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(6)" ::: "memory");       // (ALL_G0: nothing outstanding, trivially true)
-    }
   } else {
-    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+    if (grp == 0) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   }
   __builtin_amdgcn_s_barrier();
 
@@ -493,14 +362,10 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // complete, or it waits for the reads issued below before h1)
       unsigned long long t_a = 0;
       if (ABL == 8) t_a = __builtin_amdgcn_s_memtime();
-      if (ABL == 17) __builtin_amdgcn_s_waitcnt(0x0076);                             // every wave 2 pieces per slice
-      else if (NSLOT == 5 && UNEVEN && !GRP1) __builtin_amdgcn_s_waitcnt(0x4072);  // vmcnt(18): 3 younger slices x 6
-      else if (NSLOT == 5 && UNEVEN) __builtin_amdgcn_s_waitcnt(0x0076);            // vmcnt(6): 3 x 2
-      else if (NSLOT == 5) __builtin_amdgcn_s_waitcnt(0x007c);    // vmcnt(12): three younger slices in flight
-      else if (ALL_G0 && !GRP1) __builtin_amdgcn_s_waitcnt(0x4070);   // 8 pieces per slice: vmcnt(16)
-      else if (UNEVEN && !GRP1) __builtin_amdgcn_s_waitcnt(0x007c);   // 6 pieces per slice: vmcnt(12)
-      else if (UNEVEN && GRP1) __builtin_amdgcn_s_waitcnt(0x0074);    // 2 pieces per slice: vmcnt(4)
-      else __builtin_amdgcn_s_waitcnt(0x0078);
+      if (NSLOT == 5 && !GRP1) __builtin_amdgcn_s_waitcnt(0x4072);        // vmcnt(18): 3 younger slices x 6 pieces
+      else if (NSLOT == 5) __builtin_amdgcn_s_waitcnt(0x0076);            // vmcnt(6): 3 x 2
+      else if (!GRP1) __builtin_amdgcn_s_waitcnt(0x007c);                 // 6 pieces per slice: vmcnt(12)
+      else __builtin_amdgcn_s_waitcnt(0x0074);                            // 2 pieces per slice: vmcnt(4)
       if (ABL == 8) { probe_wait += __builtin_amdgcn_s_memtime() - t_a; t_a = __builtin_amdgcn_s_memtime(); }
       __builtin_amdgcn_s_barrier();
       if (ABL == 8) probe_bar += __builtin_amdgcn_s_memtime() - t_a;
@@ -509,8 +374,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         const char* nslot = smem + c_slot * SLOT_BYTES;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          if (ABL == 17) fn[m] = fc[m];
-          else fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
+          fn[m] = *reinterpret_cast<const uint4*>(nslot + a_off + m * 16 * ROWB);
         }
 #pragma unroll
         for (int n = 0; n < 4; ++n) fbL[n] = *reinterpret_cast<const uint4*>(nslot + b_off + n * 16 * ROWB);
@@ -534,42 +398,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       // copies -- 350 spilled VGPRs when tried.)
       // (Reading the next fragments before h1 in BOTH groups was tried after the timing probe: no gain, and the second
       // group's variant then spills.)
-      if constexpr (ABL == 16) {
-        // experiment: the DMA pieces of the slice are issued BETWEEN the MFMAs of h1 (one piece every 2-3 MFMAs) instead
-        // of back to back in front of / behind the MFMA block
-        if (!GRP1) next_reads();
-        __builtin_amdgcn_sched_barrier(0);
-        {
-          const int koff = i_slice * SLICE_STRIDE;
-          const uint32_t slot0 = lds0 + i_slot * SLOT_BYTES;
-          const char* pa = sbase_a + koff;
-          const char* pb = sbase_b + koff;
-          const uint32_t da = slot0 + wave * 4096;
-          const uint32_t db = slot0 + OPER_BYTES + (GRP1 ? 8192 + (wave - 4) * 2048 : wave * 2048);
-#pragma unroll
-          for (int m = 0; m < 4; ++m)
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-              if constexpr (INIT) MmaInit<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
-              else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
-              const int idx = m * 4 + n;
-              if (!GRP1) {
-                if (idx == 1) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_a0, pa, da); __builtin_amdgcn_sched_barrier(0); }
-                if (idx == 4) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_a1, pa, da + 1024); __builtin_amdgcn_sched_barrier(0); }
-                if (idx == 6) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_x[0], pa, da + 2048); __builtin_amdgcn_sched_barrier(0); }
-                if (idx == 9) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_x[UNEVEN ? 1 : 0], pa, da + 3072); __builtin_amdgcn_sched_barrier(0); }
-                if (idx == 11) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_b0, pb, db); __builtin_amdgcn_sched_barrier(0); }
-                if (idx == 14) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_b1, pb, db + 1024); __builtin_amdgcn_sched_barrier(0); }
-              } else {
-                if (idx == 4) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_b0, pb, db); __builtin_amdgcn_sched_barrier(0); }
-                if (idx == 10) { __builtin_amdgcn_sched_barrier(0); dma16m(voff_b1, pb, db + 1024); __builtin_amdgcn_sched_barrier(0); }
-              }
-            }
-        }
-        issue_advance();
-        __builtin_amdgcn_sched_barrier(0);
-        if (GRP1) next_reads();
-      } else {
       if (!GRP1) {
         next_reads();
         issue_slice();                                  // slice c_gs + 3 -> the slot just released
@@ -580,7 +408,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
       if (GRP1) {
         next_reads();
         issue_slice();
-      }
       }
     };
 
@@ -768,19 +595,11 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
 template <typename T>
 static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled, int mask_mode) {
-  const bool five = (tiled && mask_mode != 0) || (!tiled && g_q2c_ablation == 7);     // mask_mode 3: PACKED
+  const bool five = tiled && mask_mode != 0;     // mask_mode 3: PACKED
   const int lds = five ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring (+ two mask patches)
   void (*kern)(Q2cPersistArgs) = nullptr;
   bool ok = false;
 #define XML_K6_PICK(...) do { kern = q2c_persist_kernel<__VA_ARGS__>; ok = xml_lds_attr_once<q2c_persist_kernel<__VA_ARGS__>>(lds); } while (0)
-#ifdef XML_DEBUG_VARIANTS
-  if (tiled && mask_mode == 1 && g_q2c_ablation == 13) XML_K6_PICK(T, 13, true, true, true);
-  else if (tiled && mask_mode == 1 && g_q2c_ablation == 16) XML_K6_PICK(T, 16, true, true, true);
-  else if (tiled && mask_mode == 1 && g_q2c_ablation == 14) XML_K6_PICK(T, 14, true, true, true);
-  else if (tiled && mask_mode == 1 && g_q2c_ablation == 15) XML_K6_PICK(T, 15, true, true, true);
-  else if (tiled && mask_mode == 1 && g_q2c_ablation == 17) XML_K6_PICK(T, 17, true, true, true);
-  else
-#endif
   if (tiled && mask_mode == 3) XML_K6_PICK(T, 0, true, true, false, false, true);
   else if (tiled && mask_mode == 1) XML_K6_PICK(T, 0, true, true, true);
   else if (tiled && mask_mode == 2) XML_K6_PICK(T, 0, true, true, false, true);
@@ -788,11 +607,7 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tile
 #ifdef XML_DEBUG_VARIANTS
   else if (g_q2c_ablation == 1) XML_K6_PICK(T, 1);
   else if (g_q2c_ablation == 2) XML_K6_PICK(T, 2);
-  else if (g_q2c_ablation == 3) XML_K6_PICK(T, 3);
-  else if (g_q2c_ablation == 11) XML_K6_PICK(T, 11, true);
-  else if (g_q2c_ablation == 10) XML_K6_PICK(T, 10, true);
   else if (g_q2c_ablation == 8) XML_K6_PICK(T, 8, true);
-  else if (g_q2c_ablation == 7) XML_K6_PICK(T, 7, true);
   else if (g_q2c_ablation == 4) XML_K6_PICK(T, 0, false);
 #endif
   else XML_K6_PICK(T, 0, true);

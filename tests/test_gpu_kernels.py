@@ -893,3 +893,31 @@ def test_topk_threshold_ties_go_to_the_lowest_payloads(ops, shape):
         order = sorted(range(n), key=lambda i: (-float(s[r, i]), int(pay[r, i])))[:k]
         assert idx[r].tolist() == [int(pay[r, i]) for i in order], r
         assert vals[r].tolist() == [float(s[r, i]) for i in order], r
+
+
+def test_convse_pair_inversion_paths_vs_oracle(ops):
+    """The three ways K7 inverts its pair list -- one workgroup (small batches), global counters, 16 sub-counters per video
+    (many pairs on few videos: TVR val's 500 pairs per video) -- against the oracle on the same inputs."""
+    for nq, nv, k, l, h in ((60, 9, 5, 48, 128),            # 300 pairs: the single-workgroup path
+                            (700, 5000, 50, 32, 128),       # 35 000 pairs on 5 000 videos: global counters
+                            (700, 100, 50, 64, 128)):       # 35 000 pairs on 100 videos: sub-counters
+        lpad = (l + 15) // 16 * 16
+        g = torch.Generator().manual_seed(nq + nv)
+        q = [rnd(nq, h, seed=3, scale=0.3)]
+        mask = _ragged_mask(nv, l, 5)
+        cw = rnd(2 * 5, seed=7, scale=0.5)
+        f = [rnd(nv, l, h, seed=9, scale=0.3)]
+        pair = torch.stack([torch.randperm(nv, generator=g)[:k] for _ in range(nq)]).int()
+        # oracle on the selected pairs only (the (nq, nv, l) tensor of the dense restatement would be 0.9 GB at nv = 5 000)
+        fsel = f[0][pair.long()]                                                 # (nq, k, l, h)
+        sim = torch.einsum("qd,qkld->qkl", q[0], fsel)
+        conv = lambda x, w: torch.nn.functional.conv1d(x.reshape(nq * k, 1, l), w.view(1, 1, 5), padding=2).view(nq, k, l)   # noqa: E731
+        msel = mask[pair.long()]
+        want_st = torch.softmax(O.mask_logits(conv(sim, cw[:5]), msel), -1)
+        want_ed = torch.softmax(O.mask_logits(conv(sim, cw[5:]), msel), -1)
+        fp = torch.zeros(nv, lpad, h); fp[:, :l] = f[0]
+        mp = torch.zeros(nv, lpad); mp[:, :l] = mask
+        st, ed = ops.convse_rerank([dev(q[0], torch.float32)], [dev(fp, torch.float32)], [dev(mp)], dev(pair), dev(cw), l, False,
+                                   5, softmax=True)
+        close("st (%d pairs on %d videos)" % (nq * k, nv), st[..., :l], want_st, 1e-5, 1e-4)
+        close("ed (%d pairs on %d videos)" % (nq * k, nv), ed[..., :l], want_ed, 1e-5, 1e-4)

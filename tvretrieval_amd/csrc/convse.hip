@@ -134,6 +134,62 @@ __global__ void convse_fill_kernel(const int32_t* __restrict__ pair_vid, const i
   if (r >= 0) bucket[offsets[(int64_t)pair_vid[p] * sub + (int)(p & (sub - 1))] + r] = (int32_t)p;
 }
 
+// Small pair lists (the reference's 50-query batches: 5 000 pairs): the five launches above -- zero, count, zero skipped
+// rows, scan, fill -- cost 24 us of launch floor in a 350 us batch.  ONE workgroup does all of it: counters and bucket
+// starts in LDS, ranks kept in the `pos` scratch by the thread that took them.
+static constexpr int CONVSE_SMALL_NV = 4096, CONVSE_SMALL_P = 32768;
+__global__ __launch_bounds__(1024) void convse_invert_small_kernel(const int32_t* __restrict__ pair_vid,
+                                                                   int32_t* __restrict__ offsets, int32_t* __restrict__ chunk_off,
+                                                                   int32_t* __restrict__ chunk_vid, int32_t* __restrict__ pos,
+                                                                   int32_t* __restrict__ bucket, float* __restrict__ st_out,
+                                                                   float* __restrict__ ed_out, int P, int nv, int TM, int lpad4,
+                                                                   int zero_skipped) {
+  __shared__ int32_t s_cnt[CONVSE_SMALL_NV], s_off[CONVSE_SMALL_NV];
+  __shared__ int32_t wa[16], wb[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < nv; i += 1024) s_cnt[i] = 0;
+  __syncthreads();
+  for (int p = tid; p < P; p += 1024) {
+    const int v = pair_vid[p];
+    const bool ok = v >= 0 && v < nv;
+    pos[p] = ok ? atomicAdd(&s_cnt[v], 1) : -1;
+    if (!ok && zero_skipped) {
+      const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4* s4 = reinterpret_cast<float4*>(st_out) + (int64_t)p * lpad4;
+      float4* e4 = reinterpret_cast<float4*>(ed_out) + (int64_t)p * lpad4;
+      for (int i = 0; i < lpad4; ++i) { s4[i] = z; e4[i] = z; }
+    }
+  }
+  __syncthreads();
+  const int per = (nv + 1023) / 1024;
+  const int r0 = min(nv, tid * per), r1 = min(nv, r0 + per);
+  int sa = 0, sb = 0;
+  for (int i = r0; i < r1; ++i) { const int c = s_cnt[i]; sa += c; sb += (c + TM - 1) / TM; }
+  int ia = sa, ib = sb;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int va = __shfl_up(ia, o, 64), vb = __shfl_up(ib, o, 64);
+    if (lane >= o) { ia += va; ib += vb; }
+  }
+  if (lane == 63) { wa[wave] = ia; wb[wave] = ib; }
+  __syncthreads();
+  int a = ia - sa, b = ib - sb;
+  for (int w = 0; w < wave; ++w) { a += wa[w]; b += wb[w]; }
+  for (int i = r0; i < r1; ++i) {
+    const int c = s_cnt[i], ch = (c + TM - 1) / TM;
+    offsets[i] = a; s_off[i] = a;
+    chunk_off[i] = b;
+    for (int j = 0; j < ch; ++j) chunk_vid[b + j] = i;
+    a += c; b += ch;
+  }
+  if (tid == 1023) { offsets[nv] = a; chunk_off[nv] = b; }
+  __syncthreads();
+  for (int p = tid; p < P; p += 1024) {
+    const int r = pos[p];                            // (written by this very thread above)
+    if (r >= 0) bucket[s_off[pair_vid[p]] + r] = p;
+  }
+}
+
 struct ConvseArgs {
   const void* q_lin[2];
   const void* feat2[2];
@@ -643,27 +699,34 @@ static int convse_rerank_impl(const xml_convse_desc* d, const void* q_lin0, cons
   ConvseWs w;
   convse_ws_layout(d, &w, (char*)ws);
   const int64_t P = (int64_t)d->nq * d->kpairs;
-  // counts is the first (256-aligned) region.  Zeroed by a kernel, not hipMemsetAsync:
-  // as a memset NODE of a captured HIP graph the reset did not happen on the second replay (stale cursors ->
-  // out-of-bounds bucket writes, seen with inference.GraphedVcmrSearch); a kernel node replays faithfully.
-  {
-    const int64_t nwords = (int64_t)((char*)w.offsets - (char*)w.counts) / 4;
-    hipLaunchKernelGGL(convse_zero_words_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, st, (uint32_t*)w.counts, nwords);
+  int sub = 1;
+  if (P <= CONVSE_SMALL_P && d->nv <= CONVSE_SMALL_NV) {
+    hipLaunchKernelGGL(convse_invert_small_kernel, dim3(1), dim3(1024), 0, st, pair_vid, w.offsets, w.chunk_off, w.chunk_vid,
+                       w.pos, w.bucket, st_out, ed_out, (int)P, d->nv, TM, d->lpad / 4, (d->softmax & 2) ? 0 : 1);
+    XML_CHECK_LAUNCH();
+  } else {
+    // counts is the first (256-aligned) region.  Zeroed by a kernel, not hipMemsetAsync:
+    // as a memset NODE of a captured HIP graph the reset did not happen on the second replay (stale cursors ->
+    // out-of-bounds bucket writes, seen with inference.GraphedVcmrSearch); a kernel node replays faithfully.
+    {
+      const int64_t nwords = (int64_t)((char*)w.offsets - (char*)w.counts) / 4;
+      hipLaunchKernelGGL(convse_zero_words_kernel, dim3(cdiv(nwords, 256)), dim3(256), 0, st, (uint32_t*)w.counts, nwords);
+      XML_CHECK_LAUNCH();
+    }
+    sub = convse_sub(P, d->nv);
+    hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, w.pos, P, d->nv, sub);
+    XML_CHECK_LAUNCH();
+    if (!(d->softmax & 2)) {     // bit 1: the caller never reads the rows of skipped pairs
+      hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, st_out, ed_out, P,
+                         d->nv, d->lpad / 4);
+      XML_CHECK_LAUNCH();
+    }
+    hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid,
+                       d->nv, TM, sub);
+    XML_CHECK_LAUNCH();
+    hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P, sub);
     XML_CHECK_LAUNCH();
   }
-  const int sub = convse_sub(P, d->nv);
-  hipLaunchKernelGGL(convse_count_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.counts, w.pos, P, d->nv, sub);
-  XML_CHECK_LAUNCH();
-  if (!(d->softmax & 2)) {     // bit 1: the caller never reads the rows of skipped pairs
-    hipLaunchKernelGGL(convse_zero_skipped_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, st_out, ed_out, P,
-                       d->nv, d->lpad / 4);
-    XML_CHECK_LAUNCH();
-  }
-  hipLaunchKernelGGL(convse_scan_kernel, dim3(1), dim3(1024), 0, st, w.counts, w.offsets, w.chunk_off, w.chunk_vid,
-                     d->nv, TM, sub);
-  XML_CHECK_LAUNCH();
-  hipLaunchKernelGGL(convse_fill_kernel, dim3(cdiv(P, 256)), dim3(256), 0, st, pair_vid, w.offsets, w.pos, w.bucket, P, sub);
-  XML_CHECK_LAUNCH();
   ConvseArgs a;
   a.sub = sub;
   a.q_lin[0] = q_lin0; a.q_lin[1] = q_lin1;

@@ -407,13 +407,16 @@ K7_SUMMARIES = _os.environ.get("XML_K7_SUMMARIES", "0") == "1"   # vcmr_search: 
 K6_TIMER = None   # bench.py: callable returning (start, end) torch.cuda.Event pair recorded around each K6 launch
 
 
-def _k6(index, qn, ops):
+def _k6(index, qn, ops, normalize_q=False):
     """One fused K6 launch over the local corpus (both modalities), bracketed by the bench's HIP events."""
     mods = index.modalities
+    if normalize_q and not getattr(ops, "Q2C_NORMALIZE_Q", False):
+        qn, normalize_q = [ops.l2norm_rows(q) for q in qn], False
+    kw = dict(normalize_q=True) if normalize_q else {}
     ev = K6_TIMER() if K6_TIMER is not None else None
     if ev:
         ev[0].record()
-    q2c = ops.q2c_scores_fused(qn, [index.feat1n[m] for m in mods], [index.mask[m] for m in mods])
+    q2c = ops.q2c_scores_fused(qn, [index.feat1n[m] for m in mods], [index.mask[m] for m in mods], **kw)
     if ev:
         ev[1].record()
     return q2c
@@ -423,7 +426,7 @@ def stage_q2c(index, qvec, ops=hip_ops):
     """K6 over the local corpus: (Nq, Nv_local) f32 = mean over modalities of max-over-clips cosine (one launch)."""
     if index.exact is not None:
         raise ValueError("this index is an exact-rank FILTER image (bf16 operands of an f32 model): use stage_exact_topk")
-    return _k6(index, [ops.l2norm_rows(qvec[m].contiguous()) for m in index.modalities], ops)
+    return _k6(index, [qvec[m].contiguous() for m in index.modalities], ops, normalize_q=True)
 
 
 EXACT_TIER2_CAP = 4096        # second-tier candidates per failing query beyond which the f32 K6 row is computed instead

@@ -698,7 +698,12 @@ def test_attention_probs_dropout_matches_masked_reference():
              [True, True, True], tol=5e-5)
 
 
-@pytest.mark.parametrize("rows,n,k", [(12800, 768, 768), (3840, 2304, 768), (1000, 200, 72), (37, 8, 3072), (300, 768, 3080)])
+@pytest.mark.parametrize("rows,n,k", [(12800, 768, 768), (3840, 2304, 768), (1000, 200, 72), (37, 8, 3072), (300, 768, 3080),
+                                      # around the XCD-partitioned kernel (96 x 192 tiles; up to 32 tiles from 2048 rows, up to 96
+                                      # from 8192): ragged row counts, 2 and 3 tiles per workgroup, fewer than 32 tiles per XCD
+                                      # (its workgroups split the rows further), and the shapes just outside its window
+                                      (12801, 768, 768), (2077, 96, 192), (5003, 1536, 768), (4099, 384, 384),
+                                      (6400, 768, 3072), (2048, 192, 192), (8200, 1536, 768), (8193, 2304, 768)])
 def test_weight_gradient_gemm_from_row_major_operands(rows, n, k):
     """xml_gemm_tn: dW = dY^T X read from the row-major bf16 operands (transpose reads, row ranges combined with atomics)
     == float64 matmul of the same bf16 values, and == the transpose + split-K path it replaces (up to summation order)."""
@@ -714,6 +719,12 @@ def test_weight_gradient_gemm_from_row_major_operands(rows, n, k):
     old = TO.gemm_batched(TO.transpose(dy, r8), TO.transpose(x, r8), out_f32=True)
     check("gemm_tn vs transpose + split-K", got, old, 2e-5)
     assert TO.gemm_tn(dy.float(), x.float()) is None              # fp32 compute keeps the old path
+    # accumulate mode (the optimizer's flat .grad views): out += dY^T X, colsum += column sums, no fill
+    acc = torch.full((n, k), 0.25, device=DEV)
+    acc_cs = torch.full((n,), -1.5, device=DEV)
+    assert TO.gemm_tn(dy, x, out=acc, colsum_out=acc_cs)
+    check("gemm_tn accumulate", acc, want + 0.25, 2e-5)
+    check("gemm_tn accumulate column sums", acc_cs, dy.double().sum(0) - 1.5, 2e-5)
 
 
 @pytest.mark.parametrize("shape", [(3, 100, 100, 768, 4), (2, 30, 30, 768, 4), (2, 40, 72, 256, 4), (2, 128, 128, 128, 4),

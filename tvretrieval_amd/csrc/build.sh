@@ -41,5 +41,5 @@ if [ ! -f libxmlpy.so ] || [ pylists.c -nt libxmlpy.so ]; then
   echo "built $(pwd)/libxmlpy.so"
 fi
 if [ "${XML_DEBUG:-0}" = "1" ]; then
-  build build_dbg "-DXML_DEBUG_VARIANTS" libxmlhip_dbg.so $SRCS $DBG_SRCS
+  build build_dbg "-DXML_DEBUG_VARIANTS ${XML_DEBUG_EXTRA:-}" libxmlhip_dbg.so $SRCS $DBG_SRCS      # (XML_DEBUG_EXTRA=-DXML_TN_PROBE: stage timers of gemm_tn)
 fi

@@ -636,6 +636,15 @@ int xml_add_layernorm_drop(const void* a, int a_dt, const void* b, const float* 
 int xml_layernorm_bwd_drop(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx, void* dxa,
                            float* dg, float* dbeta, int64_t rows, int d, int dt, float p_in, uint64_t seed_in, float p_out,
                            uint64_t seed_out, const uint64_t* seed_dev, xml_stream_t stream);
+/* The same with scratch for the parameter gradients: every workgroup of the backward launch ends in 2 d column sums for the
+ * same 2 d addresses; with ws >= xml_layernorm_bwd_partials_bytes(rows, d) bytes (0: this shape has no use for one) they are
+ * written as rows of the scratch and combined by a second small launch instead of rows / 32 contended device-scope adds per
+ * address (raw-feature input LayerNorm, 12 800 x 3072: 108 -> 45 us).  ws NULL or too small: the atomics path.  The scratch of
+ * xml_layernorm_bwd (rows * 16 bytes for dx at d > 1024) serves the same purpose there when dx is NULL. */
+size_t xml_layernorm_bwd_partials_bytes(int64_t rows, int d);
+int xml_layernorm_bwd_drop_ws(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx, void* dxa,
+                              float* dg, float* dbeta, int64_t rows, int d, int dt, float p_in, uint64_t seed_in, float p_out,
+                              uint64_t seed_out, const uint64_t* seed_dev, void* ws, size_t ws_bytes, xml_stream_t stream);
 /* torch.nn.utils.clip_grad_norm_ over all gradients (xml/train.py:88-90, `--grad_clip`, off by default): g (n) f32 is
  * the flat gradient buffer; scaled in place by max_norm / (||g||_2 + 1e-6) when that is < 1.  ws: 4 bytes of scratch. */
 int xml_clip_grad_norm(float* g, int64_t n, float max_norm, float* ws, xml_stream_t stream);

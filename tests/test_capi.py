@@ -35,7 +35,7 @@ def test_every_header_symbol_is_exported_and_bound(lib):
 
 def test_abi_identity(lib):
     from tvretrieval_amd import _lib
-    assert lib.xml_abi_version() == _lib.ABI_VERSION == 5
+    assert lib.xml_abi_version() == _lib.ABI_VERSION == 6
     assert lib.xml_build_arch() == b"gfx950"
     assert lib.xml_status_string(0) == b"ok"
     assert lib.xml_status_string(-2) == b"unsupported shape"

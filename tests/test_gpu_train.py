@@ -101,7 +101,8 @@ def test_narrow_layernorm_backward_parameters_only():
     check("dbeta (dropout site)", r0[3], r1[3], 2e-6)
 
 
-@pytest.mark.parametrize("rows,d,a_dt", [(5000, 3072, F32), (37, 3072, torch.bfloat16), (301, 2056, F32), (64, 4096, F32)])
+@pytest.mark.parametrize("rows,d,a_dt", [(5000, 3072, F32), (37, 3072, torch.bfloat16), (301, 2056, F32), (64, 4096, F32),
+                                         (12800, 3072, F32), (1030, 1032, torch.bfloat16)])
 def test_wide_layernorm_backward_parameters_only(rows, d, a_dt):
     """the input LayerNorm of the 3072-d video features needs dgamma / dbeta only: xml_layernorm_bwd's one-pass kernel
     (dx = NULL, bf16 dy) == float64 reference on the same values, and == the two-kernel path that also writes dx."""
@@ -119,6 +120,12 @@ def test_wide_layernorm_backward_parameters_only(rows, d, a_dt):
     assert dx1 is not None
     check("dgamma vs two-kernel path", dg, dg1, 2e-5)
     check("dbeta vs two-kernel path", db, db1, 2e-5)
+    # gradient sinks: the sums are ADDED to what dg / dbeta hold (from 1024 rows on through per-workgroup partials in the
+    # scratch + a combining launch, below that with atomics)
+    sink_g, sink_b = torch.full((d,), 2.0, device=DEV), torch.full((d,), -3.0, device=DEV)
+    TO.layernorm_bwd(a, None, g, dy, need_dx=False, dg=sink_g, dbeta=sink_b)
+    check("dgamma sink", sink_g, (dy.double() * xh).sum(0) + 2.0, 2e-5)
+    check("dbeta sink", sink_b, dy.double().sum(0) - 3.0, 2e-5)
 
 
 def ref_attention(q, k, v, qm, km, heads):

@@ -17,7 +17,7 @@ XML_BF16 = 1
 XML_F16 = 2       # IEEE half rows: the exact-rank FILTER operands of K6
 XML_F16S = 3      # split f16 (hi + lo halves, 4 bytes per element): f32-grade values on the 16-bit MFMA pipe
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class XmlHipError(RuntimeError):
@@ -196,6 +196,10 @@ SIGNATURES = {
     "xml_layernorm_bwd_drop": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_int64, c_int, c_int, c_float, ctypes.c_uint64, c_float,
                                        ctypes.c_uint64, c_void_p, c_void_p]),
+    "xml_layernorm_bwd_partials_bytes": (ctypes.c_size_t, [c_int64, c_int]),
+    "xml_layernorm_bwd_drop_ws": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                          c_void_p, c_int64, c_int, c_int, c_float, ctypes.c_uint64, c_float,
+                                          ctypes.c_uint64, c_void_p, c_void_p, ctypes.c_size_t, c_void_p]),
     "xml_clip_grad_norm": (c_int, [c_void_p, c_int64, c_float, c_void_p, c_void_p]),
     "xml_bert_adam_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64,
                                    c_float, c_float, c_float, c_float, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),

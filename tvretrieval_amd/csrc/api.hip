@@ -2,7 +2,7 @@
 #include "common.h"
 
 extern "C" int xml_abi_version(void) {
-  return 5; }
+  return 6; }
 extern "C" const char* xml_build_arch(void) { return "gfx950"; }
 extern "C" const char* xml_status_string(int status) {
   switch (status) {

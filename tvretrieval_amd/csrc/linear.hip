@@ -10,14 +10,14 @@
 // GEMM + epilogue:  out[m][n] = act(acc + bias[n]) + addend      (OutT = float when a LayerNorm follows)
 //   add_mode 0: none; 1: addend[(m % seq_len)][n] (positional table); 2: addend[m][n] (residual)
 // ---------------------------------------------------------------------------------------------------
-template <typename T, typename OutT, typename AddT>
+template <typename T, typename OutT, typename AddT, int BMN = 128>
 __global__ __launch_bounds__(256) void gemm_bias_act_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                             const float* __restrict__ bias,
                                                             const AddT* __restrict__ addend, OutT* __restrict__ out,
                                                             int64_t M, int N, int K, int relu, int add_mode,
                                                             int seq_len, const float* __restrict__ row_scale) {
   // T == f16_t: split-f16 projection on K-concatenated halves (split16.hip); accumulator rows are scaled by row_scale[m]
-  using Cfg = GemmCfg<T, 128, 128, 2, 2>;
+  using Cfg = GemmCfg<T, BMN, BMN, 2, 2>;
   __shared__ __attribute__((aligned(16))) char smem[Cfg::LDS_BYTES];
   const int64_t m0 = (int64_t)blockIdx.y * Cfg::BM;
   const int n0 = blockIdx.x * Cfg::BN;
@@ -61,9 +61,21 @@ template <typename T, typename OutT, typename AddT>
 static int launch_gemm(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
                        int N, int K, int relu, int add_mode, int seq_len, hipStream_t st,
                        const float* row_scale = nullptr) {
-  dim3 grid(cdiv(N, 128), cdiv(M, 128));
-  hipLaunchKernelGGL((gemm_bias_act_kernel<T, OutT, AddT>), grid, dim3(256), 0, st, (const T*)A, (const T*)W, bias,
-                     (const AddT*)addend, (OutT*)out, M, N, K, relu, add_mode, seq_len, row_scale);
+  // Few rows (the pooled-query linears of a 128-pair training batch, a 50-query batch's encoder): 128 x 128 tiles leave most
+  // of the chip idle behind a serial K loop (128 x 768 x 768: 6 workgroups, 32 us).  Smaller tiles of the SAME mainloop -- every
+  // output element sees the same MFMA sequence over K, the results are bit-identical -- until ~100 workgroups exist.
+  const int64_t wg128 = (int64_t)cdiv(N, 128) * cdiv(M, 128);
+  const int bmn = wg128 >= 96 ? 128 : wg128 * 4 >= 96 ? 64 : 32;
+  dim3 grid(cdiv(N, bmn), cdiv(M, bmn));
+  if (bmn == 128)
+    hipLaunchKernelGGL((gemm_bias_act_kernel<T, OutT, AddT, 128>), grid, dim3(256), 0, st, (const T*)A, (const T*)W, bias,
+                       (const AddT*)addend, (OutT*)out, M, N, K, relu, add_mode, seq_len, row_scale);
+  else if (bmn == 64)
+    hipLaunchKernelGGL((gemm_bias_act_kernel<T, OutT, AddT, 64>), grid, dim3(256), 0, st, (const T*)A, (const T*)W, bias,
+                       (const AddT*)addend, (OutT*)out, M, N, K, relu, add_mode, seq_len, row_scale);
+  else
+    hipLaunchKernelGGL((gemm_bias_act_kernel<T, OutT, AddT, 32>), grid, dim3(256), 0, st, (const T*)A, (const T*)W, bias,
+                       (const AddT*)addend, (OutT*)out, M, N, K, relu, add_mode, seq_len, row_scale);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

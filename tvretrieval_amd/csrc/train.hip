@@ -502,10 +502,134 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_params_kernel(const InT* __re
   }
 }
 
+// dg[c] += sum_b partial[b][c], dbeta[c] += sum_b partial[b][d + c]: the row chunks' column sums, written as rows of a scratch
+// by ln_wide_cols_kernel, summed here by 8 slices of the rows in parallel (8 device-scope adds per address).
+__global__ __launch_bounds__(256) void ln_partials_reduce_kernel(const float* __restrict__ partial, int n_blocks, int d,
+                                                                 float* __restrict__ dg, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= 2 * d) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const int64_t ld = 2 * (int64_t)d;
+  int b = blockIdx.y;
+  for (; b + 3 * (int)gridDim.y < n_blocks; b += 4 * gridDim.y) {
+    s0 += partial[b * ld + c];
+    s1 += partial[(b + (int64_t)gridDim.y) * ld + c];
+    s2 += partial[(b + 2 * (int64_t)gridDim.y) * ld + c];
+    s3 += partial[(b + 3 * (int64_t)gridDim.y) * ld + c];
+  }
+  for (; b < n_blocks; b += gridDim.y) s0 += partial[b * ld + c];
+  const float v = (s0 + s1) + (s2 + s3);
+  if (c < d) { if (dg) unsafeAtomicAdd(dg + c, v); }
+  else if (dbeta) unsafeAtomicAdd(dbeta + c - d, v);
+}
+
+// ---- the same sums with a scratch: row statistics first, then a column pass ------------------------------------------------
+// The one-pass kernel above keeps a row's x and dy AND its running column sums in registers (276 VGPRs at d = 3072: one wave
+// per SIMD, every row a serial load -> two wave reductions -> accumulate chain; 12 800 x 3072 f32: 108 us alone, 190 us beside
+// the other branch of the training step, 1.2 TB/s).  With rows * 8 bytes of scratch the row statistics are a streaming pass of
+// their own (x only, ~70 VGPRs) and the column sums a second one in which a thread owns 8 columns and walks a chunk of rows
+// with independent 32- / 16-byte loads; the chunks' sums go through the partials scratch like above.
+template <typename InT, int KV>
+__global__ __launch_bounds__(256) void ln_wide_stats_kernel(const InT* __restrict__ a, float2* __restrict__ stats, int64_t rows,
+                                                            int d, float eps) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t row = (int64_t)blockIdx.x * 4 + wave;
+  if (row >= rows) return;
+  const int nvec = d >> 3;
+  float x[KV * 8];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < KV; ++k) {
+    const int v = lane + k * 64;
+    ld8<InT>(a + row * d + (v < nvec ? v : 0) * 8, x + k * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      x[k * 8 + j] = v < nvec ? x[k * 8 + j] : 0.f;
+      s += x[k * 8 + j];
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float var = 0.f;
+#pragma unroll
+  for (int k = 0; k < KV; ++k)
+    if (lane + k * 64 < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float c = x[k * 8 + j] - mean; var += c * c; }
+  const float rstd = 1.0f / sqrtf(wave_sum(var) / (float)d + eps);      // (the arithmetic of the one-pass kernel)
+  if (lane == 0) stats[row] = make_float2(mean, rstd);
+}
+
+template <typename InT, typename T>
+__global__ __launch_bounds__(128) void ln_wide_cols_kernel(const InT* __restrict__ a, const T* __restrict__ dy,
+                                                           const float2* __restrict__ stats, float* __restrict__ partial,
+                                                           int64_t rows, int d, int rows_per_chunk, XmlDropSite dout,
+                                                           const uint64_t* __restrict__ seed_dev) {
+  const int v = blockIdx.x * 128 + threadIdx.x;      // this thread's 8 columns
+  if (v >= (d >> 3)) return;
+  uint32_t so0 = 0, so1 = 0;
+  if (dout.thresh) xml_seed_words(dout.seed, seed_dev, so0, so1);
+  float pg[8], pb[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { pg[j] = 0.f; pb[j] = 0.f; }
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t r1 = min(rows, r0 + rows_per_chunk);
+  auto one = [&](int64_t row) {
+    float x[8], gy[8];
+    const float2 st = stats[row];
+    ld8<InT>(a + row * d + v * 8, x);
+    ld8<T>(dy + row * d + v * 8, gy);
+    if (dout.thresh) {
+      const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)v * 8u;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gy[j] = drop_hash(i0 + j, so0, so1) >= dout.thresh ? gy[j] * dout.scale : 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pg[j] += gy[j] * ((x[j] - st.x) * st.y);
+      pb[j] += gy[j];
+    }
+  };
+  int64_t row = r0;
+  for (; row + 4 <= r1; row += 4) { one(row); one(row + 1); one(row + 2); one(row + 3); }
+  for (; row < r1; ++row) one(row);
+  float* p = partial + (int64_t)blockIdx.y * (2 * d) + v * 8;
+  *reinterpret_cast<float4*>(p) = make_float4(pg[0], pg[1], pg[2], pg[3]);
+  *reinterpret_cast<float4*>(p + 4) = make_float4(pg[4], pg[5], pg[6], pg[7]);
+  *reinterpret_cast<float4*>(p + d) = make_float4(pb[0], pb[1], pb[2], pb[3]);
+  *reinterpret_cast<float4*>(p + d + 4) = make_float4(pb[4], pb[5], pb[6], pb[7]);
+}
+
+static inline int ln_wide_rows_per_chunk(int64_t rows) { return rows >= 8192 ? 32 : 16; }
+static inline size_t ln_wide_ws_bytes(int64_t rows, int d) {
+  return align_up((size_t)rows * 8, 256) + (size_t)cdiv(rows, ln_wide_rows_per_chunk(rows)) * 2 * d * 4;
+}
+
+static inline int ln_wide_rows_per_wave(int64_t rows, bool) {
+  return rows >= 8192 ? 8 : rows >= 4096 ? 4 : 1;      // every block ends in 2 d global atomics: fewer, longer blocks (12 800 x 3072: 198 -> 108 us)
+}
+
 template <typename InT, typename T>
 static int ln_bwd_wide_params(const void* a, const void* dy, float* dg, float* dbeta, int64_t rows, int d, hipStream_t st,
-                              XmlDropSite dout = XmlDropSite{0u, 1.f, 0ull}, const uint64_t* seed_dev = nullptr) {
-  const int rpw = rows >= 8192 ? 8 : rows >= 4096 ? 4 : 1;      // every block ends in 2 d global atomics: fewer, longer blocks (12 800 x 3072: 198 -> 108 us)
+                              XmlDropSite dout = XmlDropSite{0u, 1.f, 0ull}, const uint64_t* seed_dev = nullptr,
+                              void* ws = nullptr, size_t ws_bytes = 0) {
+  if (ws && rows >= 1024 && ws_bytes >= ln_wide_ws_bytes(rows, d) && ((uintptr_t)ws & 15) == 0) {
+    float2* stats = (float2*)ws;
+    float* partial = (float*)((char*)ws + align_up((size_t)rows * 8, 256));
+    const int kv = cdiv(d >> 3, 64), rpc = ln_wide_rows_per_chunk(rows), chunks = cdiv(rows, rpc);
+#define XML_LNS(KV)                                                                                                    \
+  hipLaunchKernelGGL((ln_wide_stats_kernel<InT, KV>), dim3(cdiv(rows, 4)), dim3(256), 0, st, (const InT*)a, stats, rows, d, 1e-5f)
+    if (kv <= 2) XML_LNS(2);
+    else if (kv <= 4) XML_LNS(4);
+    else if (kv <= 6) XML_LNS(6);
+    else XML_LNS(8);
+#undef XML_LNS
+    hipLaunchKernelGGL((ln_wide_cols_kernel<InT, T>), dim3(cdiv(d >> 3, 128), chunks), dim3(128), 0, st, (const InT*)a,
+                       (const T*)dy, stats, partial, rows, d, rpc, dout, seed_dev);
+    hipLaunchKernelGGL(ln_partials_reduce_kernel, dim3(cdiv(2 * d, 256), 8), dim3(256), 0, st, partial, chunks, d, dg, dbeta);
+    XML_CHECK_LAUNCH();
+    return XML_OK;
+  }
+  const int rpw = ln_wide_rows_per_wave(rows, false);
   const dim3 grid(cdiv(rows, 4 * rpw)), blk(256);
   const size_t lds = (size_t)2 * d * 4;
   const int kv = cdiv(d >> 3, 64);
@@ -549,8 +673,11 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
   if (d > 1024 || (d & 7)) {
     if (b) return XML_ERR_UNSUPPORTED;
     if (!dx && !(d & 7) && d <= 4096) {          // parameter gradients only: one pass (the f32 compute path keeps two)
-      if (dt == XML_BF16 && a_dt == XML_F32) return ln_bwd_wide_params<float, bf16_t>(a, dy, dg, dbeta, rows, d, st);
-      if (dt == XML_BF16 && a_dt == XML_BF16) return ln_bwd_wide_params<bf16_t, bf16_t>(a, dy, dg, dbeta, rows, d, st);
+      const XmlDropSite none = XmlDropSite{0u, 1.f, 0ull};
+      if (dt == XML_BF16 && a_dt == XML_F32)
+        return ln_bwd_wide_params<float, bf16_t>(a, dy, dg, dbeta, rows, d, st, none, nullptr, ws, ws_bytes);
+      if (dt == XML_BF16 && a_dt == XML_BF16)
+        return ln_bwd_wide_params<bf16_t, bf16_t>(a, dy, dg, dbeta, rows, d, st, none, nullptr, ws, ws_bytes);
     }
     if (!ws || ws_bytes < (size_t)rows * 16) return XML_ERR_WORKSPACE;
     if (dt == XML_F32 && a_dt == XML_F32) return ln_bwd_wide<float, float>(a, g, dy, dx, dg, dbeta, rows, d, (float*)ws, st);
@@ -580,10 +707,23 @@ extern "C" int xml_layernorm_bwd(const void* a, int a_dt, const void* b, const f
 
 // Backward of xml_add_layernorm_drop.  dx: gradient of b (and of a when p_in == 0); dxa: gradient of a when p_in > 0
 // (required then).  d <= 1024: everything; wider rows: parameter gradients only (dx == NULL), bf16, p_in == 0.
+extern "C" size_t xml_layernorm_bwd_partials_bytes(int64_t rows, int d) {
+  if (rows < 1024 || d <= 1024 || d > 4096 || (d & 7)) return 0;
+  return ln_wide_ws_bytes(rows, d);
+}
+
 extern "C" int xml_layernorm_bwd_drop(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx,
                                       void* dxa, float* dg, float* dbeta, int64_t rows, int d, int dt, float p_in,
                                       uint64_t seed_in, float p_out, uint64_t seed_out, const uint64_t* seed_dev,
                                       xml_stream_t stream) {
+  return xml_layernorm_bwd_drop_ws(a, a_dt, b, g, dy, dx, dxa, dg, dbeta, rows, d, dt, p_in, seed_in, p_out, seed_out, seed_dev,
+                                   nullptr, 0, stream);
+}
+
+extern "C" int xml_layernorm_bwd_drop_ws(const void* a, int a_dt, const void* b, const float* g, const void* dy, void* dx,
+                                         void* dxa, float* dg, float* dbeta, int64_t rows, int d, int dt, float p_in,
+                                         uint64_t seed_in, float p_out, uint64_t seed_out, const uint64_t* seed_dev, void* ws,
+                                         size_t ws_bytes, xml_stream_t stream) {
   XML_ENTER();
   if (!a || !g || !dy || rows <= 0 || d <= 0) return XML_ERR_BAD_ARG;
   if (!(p_in >= 0.f) || p_in >= 1.f || !(p_out >= 0.f) || p_out >= 1.f) return XML_ERR_BAD_ARG;
@@ -592,8 +732,8 @@ extern "C" int xml_layernorm_bwd_drop(const void* a, int a_dt, const void* b, co
   hipStream_t st = (hipStream_t)stream;
   if (d > 1024) {
     if (b || dx || dxa || din.thresh || d > 4096 || dt != XML_BF16) return XML_ERR_UNSUPPORTED;
-    if (a_dt == XML_F32) return ln_bwd_wide_params<float, bf16_t>(a, dy, dg, dbeta, rows, d, st, dout, seed_dev);
-    if (a_dt == XML_BF16) return ln_bwd_wide_params<bf16_t, bf16_t>(a, dy, dg, dbeta, rows, d, st, dout, seed_dev);
+    if (a_dt == XML_F32) return ln_bwd_wide_params<float, bf16_t>(a, dy, dg, dbeta, rows, d, st, dout, seed_dev, ws, ws_bytes);
+    if (a_dt == XML_BF16) return ln_bwd_wide_params<bf16_t, bf16_t>(a, dy, dg, dbeta, rows, d, st, dout, seed_dev, ws, ws_bytes);
     return XML_ERR_BAD_ARG;
   }
   if (din.thresh && dx && !dxa) return XML_ERR_BAD_ARG;

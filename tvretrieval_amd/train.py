@@ -18,6 +18,7 @@ reference's stream.  Parity is pinned in `model.eval()` mode on the training-ste
 """
 import math
 
+import numpy as np
 import torch
 
 from . import ops
@@ -649,11 +650,21 @@ class GraphedTrainStep(object):
         self.static = {k: (v.to(dev).clone() if torch.is_tensor(v) else v) for k, v in batch.items()
                        if k not in ("neg_ctx_rank", "neg_q_rank")}
         n = self.static["query_feat"].shape[0]
-        self.neg_ctx = torch.ones(n, dtype=torch.int32, device=dev)
-        self.neg_q = torch.ones(n, dtype=torch.int32, device=dev)
+        # the host's per-step inputs -- the two negative-rank vectors and the schedule multipliers -- live in ONE device buffer
+        # and arrive in ONE copy from pinned memory (three pageable copies, each behind its own host work, left the device
+        # idle for ~125 us between two replays)
+        nseg = len(optimizer.params)
+        self._host_in = torch.ones(2 * n + nseg, dtype=torch.int32, device=dev)
+        self.neg_ctx, self.neg_q = self._host_in[:n], self._host_in[n:2 * n]
+        self.lr_mult = self._host_in[2 * n:].view(F32)
+        self.lr_mult.fill_(1.0)
+        pin = dev.type == "cuda"
+        self._stage = [torch.ones(2 * n + nseg, dtype=torch.int32, pin_memory=pin) for _ in range(4)]
+        self._stage_np = [t.numpy() for t in self._stage]      # (host-side fills go through numpy: ~1 us per slice, not ~8)
+        self._stage_ev = [None] * 4
+        self._stage_i = 0
         self._one = torch.ones((), dtype=F32, device=dev)
         self.seed_base = torch.zeros(1, dtype=torch.int64, device=dev)
-        self.lr_mult = torch.ones(len(optimizer.params), dtype=F32, device=dev)
         # ---- warm-up on the side stream (workspaces, allocator pools, packed-weight caches), state restored afterwards
         keep = [t.clone() for t in (optimizer.flat_p, optimizer.flat_m, optimizer.flat_v)]
         keep_host = (list(optimizer.seg_steps), optimizer.step_count, list(optimizer._touched))
@@ -681,6 +692,7 @@ class GraphedTrainStep(object):
             # ---- capture
             self.active = touched_after_warmup if any(touched_after_warmup) else [True] * len(touched_after_warmup)
             self.seg_active = optimizer._active_mask(self.active)
+            self._active_np = np.asarray(self.active, dtype=bool)
             self.graph = torch.cuda.CUDAGraph()
             T.SEED_BASE = self.seed_base
             _SITE[0] = 0
@@ -706,11 +718,26 @@ class GraphedTrainStep(object):
         if opt._shadow is not None:
             opt._shadow["fresh"] = False
 
-    def _set_ranks(self, neg_ctx_rank, neg_q_rank):
+    def _set_ranks(self, neg_ctx_rank, neg_q_rank, lr_mults=None):
+        """Stages this replay's host inputs and sends them in one copy.  lr_mults None: the multipliers stay as they are."""
+        n = self.neg_ctx.shape[0]
         if neg_ctx_rank is None or neg_q_rank is None:
-            neg_ctx_rank, neg_q_rank = draw_negative_ranks(self.model, self.neg_ctx.shape[0])
-        self.neg_ctx.copy_(torch.as_tensor(neg_ctx_rank).to(torch.int32), non_blocking=True)
-        self.neg_q.copy_(torch.as_tensor(neg_q_rank).to(torch.int32), non_blocking=True)
+            neg_ctx_rank, neg_q_rank = draw_negative_ranks(self.model, n)
+        i = self._stage_i
+        self._stage_i = (i + 1) % len(self._stage)
+        if self._stage_ev[i] is not None:
+            self._stage_ev[i].synchronize()        # the copy that last read this pinned buffer (four calls ago) is done
+        h, hn = self._stage[i], self._stage_np[i]
+        hn[:n] = neg_ctx_rank.numpy() if torch.is_tensor(neg_ctx_rank) else np.asarray(neg_ctx_rank)
+        hn[n:2 * n] = neg_q_rank.numpy() if torch.is_tensor(neg_q_rank) else np.asarray(neg_q_rank)
+        if lr_mults is None:
+            self._host_in[:2 * n].copy_(h[:2 * n], non_blocking=True)
+        else:
+            hn[2 * n:].view(np.float32)[:] = lr_mults
+            self._host_in.copy_(h, non_blocking=True)
+        if h.is_pinned():
+            self._stage_ev[i] = torch.cuda.Event()
+            self._stage_ev[i].record()
 
     def _body(self, captured=False):
         opt = self.opt
@@ -743,12 +770,14 @@ class GraphedTrainStep(object):
                         raise ValueError("GraphedTrainStep was captured for %s %s, got %s" % (k, tuple(self.static[k].shape),
                                                                                               tuple(v.shape)))
                     self.static[k].copy_(v, non_blocking=True)
-        self._set_ranks(neg_ctx_rank if neg_ctx_rank is not None else (batch or {}).get("neg_ctx_rank"),
-                        neg_q_rank if neg_q_rank is not None else (batch or {}).get("neg_q_rank"))
         opt = self.opt
         # the set of tensors this graph updates was frozen at capture; each runs its own schedule step (xml/optimization.py:325-330)
-        mults = [opt.lr_multiplier(s_) if a else 0.0 for s_, a in zip(opt.seg_steps, self.active)]
-        self.lr_mult.copy_(torch.tensor(mults, dtype=F32), non_blocking=True)
+        steps = np.asarray(opt.seg_steps)
+        mults = np.zeros(len(steps), np.float32)
+        for st in np.unique(steps[self._active_np]):      # (one value once every tensor has stepped equally often)
+            mults[self._active_np & (steps == st)] = opt.lr_multiplier(int(st))
+        self._set_ranks(neg_ctx_rank if neg_ctx_rank is not None else (batch or {}).get("neg_ctx_rank"),
+                        neg_q_rank if neg_q_rank is not None else (batch or {}).get("neg_q_rank"), mults)
         self.graph.replay()
         opt._commit_step(self.active)
         return self.loss, self.parts

@@ -73,7 +73,7 @@ def layernorm_bwd(a, b, g, dy, need_dx=True, dg=None, dbeta=None):
     dbeta = torch.zeros(d, dtype=F32, device=a.device) if dbeta is None else _req(dbeta, "dbeta", F32)
     wide = d > 1024 or d % 8 != 0
     dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if need_dx else None
-    ws = _workspace(rows * 16, a.device) if wide else None
+    ws = _workspace(max(rows * 16, _lib.load().xml_layernorm_bwd_partials_bytes(rows, d)), a.device) if wide else None
     check(_lib.load().xml_layernorm_bwd(_p(a), dt_of(a), _p(b), _p(g), _p(dy), _p(dx), _p(dg), _p(dbeta), rows, d,
                                         dt_of(dy), _p(ws), 0 if ws is None else ws.numel(), _stream()),
           "xml_layernorm_bwd")
@@ -112,9 +112,11 @@ def layernorm_bwd_drop(a, b, g, dy, p_in, seed_in, p_out, seed_out, need_dx=True
     dbeta = torch.zeros(d, dtype=F32, device=a.device) if dbeta is None else _req(dbeta, "dbeta", F32)
     dx = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if need_dx else None
     dxa = torch.empty(a.shape, dtype=dy.dtype, device=a.device) if (dx is not None and p_in > 0) else None
-    check(_lib.load().xml_layernorm_bwd_drop(_p(a), dt_of(a), _p(b), _p(g), _p(dy), _p(dx), _p(dxa), _p(dg), _p(dbeta),
-                                             rows, d, dt_of(dy), float(p_in), int(seed_in), float(p_out), int(seed_out),
-                                             _seed_base_ptr(), _stream()), "xml_layernorm_bwd_drop")
+    nws = _lib.load().xml_layernorm_bwd_partials_bytes(rows, d)      # scratch for the per-workgroup column sums (0: none used)
+    ws = _workspace(nws, a.device) if nws else None
+    check(_lib.load().xml_layernorm_bwd_drop_ws(_p(a), dt_of(a), _p(b), _p(g), _p(dy), _p(dx), _p(dxa), _p(dg), _p(dbeta),
+                                                rows, d, dt_of(dy), float(p_in), int(seed_in), float(p_out), int(seed_out),
+                                                _seed_base_ptr(), _p(ws), nws, _stream()), "xml_layernorm_bwd_drop_ws")
     return dx, dxa, dg, dbeta
 
 

@@ -9,6 +9,9 @@ from tvretrieval_amd import ops  # noqa: E402
 
 shapes = [(300000, 2304, 768), (300000, 768, 768), (65536, 768, 3072), (65536, 2304, 768), (65536, 768, 768),
           (16384, 2304, 768), (3840, 2304, 768), (300000, 2304, 3072)]
+if os.environ.get("GEMM_SHAPES") == "train":      # the projections of one training step (BASELINE configs[4]: 128 x 100 clips)
+    shapes = [(12800, 768, 768), (12800, 2304, 768), (12800, 1536, 768), (12800, 768, 3072), (12800, 3072, 768),
+              (3840, 768, 768), (3840, 2304, 768), (128, 768, 768), (750, 256, 768), (750, 768, 256), (750, 256, 256)]
 import ctypes
 lib = ops._lib.load()
 assert hasattr(lib, "xml_debug_set_q2c_variant"), "needs the debug library: XML_DEBUG=1 bash tvretrieval_amd/csrc/build.sh; XMLHIP_LIB=$PWD/tvretrieval_amd/csrc/libxmlhip_dbg.so"

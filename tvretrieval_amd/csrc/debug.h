@@ -9,7 +9,7 @@
 extern int g_q2c_variant;       // 0 auto, 1: 128x128 register-staged, 2: 256x256 LDS-DMA double buffer, 3: ring, 4: persistent,
                                 // 5 / 6: the abandoned 4-wave and 32x32-MFMA persistent kernels (q2c_persist4/32.hip)
 extern int g_q2c_ablation;      // per-kernel ablation id (see the ABL template parameters)
-extern int g_gemm_variant;      // 0 auto, 1 force the 128x128 register-staged kernel, 2 never the persistent 256x256 one
+extern int g_gemm_variant;      // 0 auto, 1 force the 128x128 register-staged kernel, 2 never the persistent 256x256 one, 3 never the few-row form
 extern int g_q2c_xcd_swizzle;
 extern int g_q2c_chunk_log2;    // -1 auto; K6 corpus walk: rounds per MALL-resident chunk = 2^v (30 = one chunk = old order)
 extern int g_q2c_line_log2;     // K6 walk: 2^v consecutive rounds of an XCD on adjacent clip tiles (Q2cPersistArgs::lsh)

@@ -172,6 +172,101 @@ __device__ __forceinline__ void gemm_mainloop(f32x4 (&acc)[Cfg::MT][Cfg::NT], AR
 }
 
 
+// ---- deep-prefetch variant for few-row products ---------------------------------------------------------------------------
+// Same LDS image, fragment reads and MFMA order as gemm_mainloop (bitwise the same accumulators), but the global loads run
+// D K-steps ahead through D register sets instead of one.  A product with few rows has few workgroups and a short, strictly
+// serial K loop: with one step of lead every step costs a full memory round trip (128 x 768 x 768: 12 steps, ~2 us each,
+// whatever the tile size); with D sets in flight the loop costs nsteps / D round trips.  Requires nsteps % D == 0 (the loop
+// body exists D times, one per register set: no dynamic register indexing, no branch between a load and its use -- hipcc
+// keeps its vmcnt count and waits for exactly the set it stores).  Loads past the last step re-read step 0 and are dropped.
+template <typename T, typename Cfg, int D, typename ARow, typename BRow>
+__device__ __forceinline__ void gemm_mainloop_deep(f32x4 (&acc)[Cfg::MT][Cfg::NT], ARow a_row, BRow b_row, int k_bytes,
+                                                   char* smem) {
+  static_assert(!IsSplit16<T>::value, "plain element types only");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
+  const int lrow = tid >> 3, lslot = tid & 7;
+  const char* const safe = a_row(0) ? a_row(0) : b_row(0);
+  const char* aps[Cfg::A_PASSES];
+  const char* bps[Cfg::B_PASSES];
+  uint32_t row_ok = 0;
+#pragma unroll
+  for (int i = 0; i < Cfg::A_PASSES; ++i) {
+    const char* p = a_row(lrow + i * Cfg::ROWS_PER_PASS);
+    if (p) row_ok |= 1u << i;
+    aps[i] = p ? p : safe;
+  }
+#pragma unroll
+  for (int i = 0; i < Cfg::B_PASSES; ++i) {
+    const char* p = b_row(lrow + i * Cfg::ROWS_PER_PASS);
+    if (p) row_ok |= 1u << (16 + i);
+    bps[i] = p ? p : safe;
+  }
+#pragma unroll
+  for (int m = 0; m < Cfg::MT; ++m)
+#pragma unroll
+    for (int n = 0; n < Cfg::NT; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  struct Regs { uint4 a[Cfg::A_PASSES], b[Cfg::B_PASSES]; };
+  Regs r[D];
+  const int nsteps = (k_bytes + Cfg::ROWB - 1) / Cfg::ROWB;
+  auto gload = [&](Regs& q, int step) {
+    const int off = step * Cfg::ROWB + lslot * 16;
+    const int offc = off < k_bytes ? off : lslot * 16;      // (past the end: valid bytes that lstore drops)
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PASSES; ++i) q.a[i] = ld_global16_as1(aps[i] + offc);
+#pragma unroll
+    for (int i = 0; i < Cfg::B_PASSES; ++i) q.b[i] = ld_global16_as1(bps[i] + offc);
+  };
+  auto lstore = [&](const Regs& q, int step) {
+    char* sa = smem + (step & 1) * Cfg::STAGE_BYTES;
+    char* sb = sa + Cfg::BM * Cfg::ROWB;
+    const bool kin = step * Cfg::ROWB + lslot * 16 < k_bytes;
+#pragma unroll
+    for (int i = 0; i < Cfg::A_PASSES; ++i) {
+      const int rr = lrow + i * Cfg::ROWS_PER_PASS;
+      *reinterpret_cast<uint4*>(sa + lds_slot_off(rr, lslot)) = keep16(kin && ((row_ok >> i) & 1u), q.a[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < Cfg::B_PASSES; ++i) {
+      const int rr = lrow + i * Cfg::ROWS_PER_PASS;
+      *reinterpret_cast<uint4*>(sb + lds_slot_off(rr, lslot)) = keep16(kin && ((row_ok >> (16 + i)) & 1u), q.b[i]);
+    }
+  };
+  const int fr = lane & 15, fg = lane >> 4;
+  auto compute = [&](int step) {
+    const char* sa = smem + (step & 1) * Cfg::STAGE_BYTES;
+    const char* sb = sa + Cfg::BM * Cfg::ROWB;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      uint4 fa[Cfg::MT], fb[Cfg::NT];
+#pragma unroll
+      for (int m = 0; m < Cfg::MT; ++m)
+        fa[m] = *reinterpret_cast<const uint4*>(sa + lds_slot_off(wm * (Cfg::BM / Cfg::WM) + m * 16 + fr, c * 4 + fg));
+#pragma unroll
+      for (int n = 0; n < Cfg::NT; ++n)
+        fb[n] = *reinterpret_cast<const uint4*>(sb + lds_slot_off(wn * (Cfg::BN / Cfg::WN) + n * 16 + fr, c * 4 + fg));
+#pragma unroll
+      for (int m = 0; m < Cfg::MT; ++m)
+#pragma unroll
+        for (int n = 0; n < Cfg::NT; ++n) Mma<T>::chunk(acc[m][n], fa[m], fb[n]);
+    }
+  };
+#pragma unroll
+  for (int j = 0; j < D; ++j) gload(r[j], j);
+  lstore(r[0], 0);
+  __syncthreads();
+  for (int s = 0; s < nsteps; s += D) {
+#pragma unroll
+    for (int j = 0; j < D; ++j) {      // step s + j: its set is in LDS, refill it with step s + j + D; sets j + 1 .. stay in flight
+      gload(r[j], s + j + D);
+      compute(s + j);
+      lstore(r[(j + 1) % D], s + j + 1);      // (after the last step: a dropped store into the other stage)
+      __syncthreads();
+    }
+  }
+}
+
 // ---- LDS-DMA variant of the mainloop (gathered-pair contractions: K7, exact-rank re-score) -------------------------------
 // Same LDS image, same fragment reads and MFMA order as gemm_mainloop (bitwise the same accumulators), but the K steps
 // arrive through `global_load_lds_dwordx4` into a THREE-stage ring: two steps (2 x 24 KiB per workgroup) are in flight

@@ -30,7 +30,15 @@ __global__ __launch_bounds__(256) void gemm_bias_act_kernel(const T* __restrict_
     const int n = n0 + r;
     return n < N ? reinterpret_cast<const char*>(W + (int64_t)n * K) : nullptr;
   };
-  gemm_mainloop<T, Cfg>(acc, a_row, b_row, K * (int)sizeof(T), smem);
+  if constexpr (BMN < 128 && !IsSplit16<T>::value && !std::is_same<T, f16_t>::value) {
+    // few rows: the K loop is a chain of memory round trips -- loads 3 (or 2) steps ahead (gemm_mainloop_deep)
+    const int nsteps = (K * (int)sizeof(T) + Cfg::ROWB - 1) / Cfg::ROWB;
+    if (nsteps % 3 == 0) gemm_mainloop_deep<T, Cfg, 3>(acc, a_row, b_row, K * (int)sizeof(T), smem);
+    else if (nsteps % 2 == 0) gemm_mainloop_deep<T, Cfg, 2>(acc, a_row, b_row, K * (int)sizeof(T), smem);
+    else gemm_mainloop<T, Cfg>(acc, a_row, b_row, K * (int)sizeof(T), smem);
+  } else {
+    gemm_mainloop<T, Cfg>(acc, a_row, b_row, K * (int)sizeof(T), smem);
+  }
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave / Cfg::WN, wn = wave % Cfg::WN;
@@ -63,9 +71,10 @@ static int launch_gemm(const void* A, const void* W, const float* bias, const vo
                        const float* row_scale = nullptr) {
   // Few rows (the pooled-query linears of a 128-pair training batch, a 50-query batch's encoder): 128 x 128 tiles leave most
   // of the chip idle behind a serial K loop (128 x 768 x 768: 6 workgroups, 32 us).  Smaller tiles of the SAME mainloop -- every
-  // output element sees the same MFMA sequence over K, the results are bit-identical -- until ~100 workgroups exist.
+  // output element sees the same MFMA sequence over K, the results are bit-identical -- until a few hundred workgroups exist
+  // (the small tiles also take the deep-prefetch K loop, gemm_mainloop_deep).
   const int64_t wg128 = (int64_t)cdiv(N, 128) * cdiv(M, 128);
-  const int bmn = wg128 >= 96 ? 128 : wg128 * 4 >= 96 ? 64 : 32;
+  const int bmn = wg128 >= 512 ? 128 : wg128 * 4 >= 192 ? 64 : 32;
   dim3 grid(cdiv(N, bmn), cdiv(M, bmn));
   if (bmn == 128)
     hipLaunchKernelGGL((gemm_bias_act_kernel<T, OutT, AddT, 128>), grid, dim3(256), 0, st, (const T*)A, (const T*)W, bias,
@@ -125,9 +134,13 @@ int xmli_gemm(const void* A, const void* W, const float* bias, const void* adden
     return launch_gemm<f16_t, float, float>(a_cat, W, bias, addend, out, M, N, 3 * K, relu, add_mode, seq_len, st, rs);
   }
   if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_BAD_ARG;
-  if (g_gemm_variant == 0 && xmli_gemm256p_eligible(M, N, K, dt))
+  // fewer than 64 tiles of 256 x 256 (a 50-query batch's encoder, the query branch of a training step): a quarter of the
+  // chip at best behind a serial K loop -- the small-tile, deep-prefetch form of the register-staged kernel instead
+  // (3 840 x 768 x 768: 28 -> 11 us)
+  const bool few = (int64_t)cdiv(M, 256) * cdiv(N, 256) < 64 && g_gemm_variant != 3;
+  if (!few && g_gemm_variant == 0 && xmli_gemm256p_eligible(M, N, K, dt))
     return xmli_gemm256p(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, out_f32, dt, st);
-  if (g_gemm_variant != 1 && xmli_gemm256_eligible(M, N, K, dt))
+  if (!few && g_gemm_variant != 1 && xmli_gemm256_eligible(M, N, K, dt))
     return xmli_gemm256(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, out_f32, dt, st);
   if (dt == XML_F32) {
     if (K % 4) return XML_ERR_UNSUPPORTED;

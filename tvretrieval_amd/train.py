@@ -241,7 +241,10 @@ def xml_forward_train(model, query_feat, query_mask, video_feat, video_mask, sub
     if SHADOW_WEIGHTS and model.compute_dtype == torch.bfloat16 and torch.is_grad_enabled():
         reg = getattr(next(iter(model.parameters())), "_xml_sink", None)
         if reg is not None:             # an optimizer owns the parameters: its bf16 / transposed weight copies for this step
-            reg.opt.refresh_shadows(model.compute_dtype)
+            # (two-stream pass: the transposed copies are not needed before the backward pass -- onto the side stream, which
+            # carries the shorter subtitle branch)
+            two = PARALLEL_BRANCHES and cfg.cross_att and video_feat is not None and video_feat.is_cuda
+            reg.opt.refresh_shadows(model.compute_dtype, transpose_stream=_side_stream(video_feat.device) if two else None)
     v1, v2, s1, s2 = encode_context_train(model, video_feat, video_mask, sub_feat, sub_mask)
     # (the query encoder on a THIRD stream was measured and not kept: 5.54 vs 5.04 ms per captured step -- its small kernels
     # then interleave with the two context branches and break up their pairing; round 4: the same BEHIND the subtitle branch
@@ -444,7 +447,10 @@ class BertAdam(object):
     # (shadow_t registers a matrix the first time it is wanted; it is served from the following refresh on).
     # A shadow is only handed out while it is current: refreshed since the last step(), and no parameter it covers has been
     # written through torch since (Tensor._version -- load_state_dict, manual edits); otherwise the caller packs afresh.
-    def refresh_shadows(self, dtype):
+    def refresh_shadows(self, dtype, transpose_stream=None):
+        """transpose_stream: a stream that the caller forks from and joins back into the current one BEFORE the backward pass
+        (encode_context_train's side stream): the transposed copies -- read by the dX GEMMs of the backward pass only -- are
+        written there, off the head of the step's critical path."""
         sh = self._shadow
         if sh is None or sh["dtype"] != dtype:
             sh = self._shadow = dict(dtype=dtype, flat=torch.empty(self.flat_p.numel(), dtype=dtype, device=self.flat_p.device),
@@ -471,7 +477,12 @@ class BertAdam(object):
             sh["tables"].append(sh["table"])      # a captured step keeps reading the table it was captured with
             sh["max_tiles"], sh["dirty"] = tiles, False
         if sh["table"] is not None:
-            T.transpose_segments(self.flat_p, sh["table"], sh["max_tiles"])
+            if transpose_stream is not None:
+                transpose_stream.wait_stream(torch.cuda.current_stream(self.flat_p.device))      # the masters as of now
+                with torch.cuda.stream(transpose_stream):
+                    T.transpose_segments(self.flat_p, sh["table"], sh["max_tiles"])
+            else:
+                T.transpose_segments(self.flat_p, sh["table"], sh["max_tiles"])
         sh["versions"] = [p._version for p in self.params]
         sh["fresh"] = True
 

@@ -245,8 +245,7 @@ __global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __res
       if constexpr (DROP) {
         if (din.thresh) {
           const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)v * 8u;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x[k * 8 + j] = drop_hash(i0 + j, si0, si1) >= din.thresh ? x[k * 8 + j] * din.scale : 0.f;
+          drop_mask8(i0, si0, si1, din.thresh, din.scale, x + k * 8);
         }
       }
       if (pb) {
@@ -282,8 +281,7 @@ __global__ __launch_bounds__(256) void add_layernorm_vec_kernel(const InT* __res
       if constexpr (DROP) {
         if (dout.thresh) {
           const uint64_t i0 = (uint64_t)row * (uint64_t)ld_out + (uint64_t)v * 8u;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) o[j] = drop_hash(i0 + j, so0, so1) >= dout.thresh ? o[j] * dout.scale : 0.f;
+          drop_mask8(i0, so0, so1, dout.thresh, dout.scale, o);
         }
       }
       st8<OutT>(py + v * 8, o);

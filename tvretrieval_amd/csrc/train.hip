@@ -292,8 +292,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
       [[maybe_unused]] const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)(lane + k * 64) * 8u;
       if constexpr (DROP) {
         if (din.thresh) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) x[k * 8 + j] = drop_hash(i0 + j, si0, si1) >= din.thresh ? x[k * 8 + j] * din.scale : 0.f;
+          drop_mask8(i0, si0, si1, din.thresh, din.scale, x + k * 8);
         }
       }
       if (b) {
@@ -307,8 +306,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
       for (int h = 0; h < VD; ++h) unpack16<T>(rd[k][h], gy + k * 8 + h * (8 / VD));
       if constexpr (DROP) {
         if (dout.thresh) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) gy[k * 8 + j] = drop_hash(i0 + j, so0, so1) >= dout.thresh ? gy[k * 8 + j] * dout.scale : 0.f;
+          drop_mask8(i0, so0, so1, dout.thresh, dout.scale, gy + k * 8);
         }
       }
 #pragma unroll
@@ -353,8 +351,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const InT* __restric
         if constexpr (DROP) {
           if (dxa) {
             const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)v * 8u;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) o[j] = drop_hash(i0 + j, si0, si1) >= din.thresh ? o[j] * din.scale : 0.f;
+            drop_mask8(i0, si0, si1, din.thresh, din.scale, o);
             st8<T>(dxa + row * d + v * 8, o);
           }
         }
@@ -456,8 +453,7 @@ __global__ __launch_bounds__(256) void ln_bwd_wide_params_kernel(const InT* __re
       ld8<T>(dy + row * d + vc * 8, gy + k * 8);
       if (dout.thresh) {
         const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)vc * 8u;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) gy[k * 8 + j] = drop_hash(i0 + j, so0, so1) >= dout.thresh ? gy[k * 8 + j] * dout.scale : 0.f;
+        drop_mask8(i0, so0, so1, dout.thresh, dout.scale, gy + k * 8);
       }
     }
     float s = 0.f;
@@ -580,8 +576,7 @@ __global__ __launch_bounds__(128) void ln_wide_cols_kernel(const InT* __restrict
     ld8<T>(dy + row * d + v * 8, gy);
     if (dout.thresh) {
       const uint64_t i0 = (uint64_t)row * (uint64_t)d + (uint64_t)v * 8u;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gy[j] = drop_hash(i0 + j, so0, so1) >= dout.thresh ? gy[j] * dout.scale : 0.f;
+      drop_mask8(i0, so0, so1, dout.thresh, dout.scale, gy);
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) {

@@ -79,9 +79,13 @@ def run(bsz=128, ctx_l=100, desc_l=30, hidden=768, dv=3072, ds=768, dtype="bf16"
         losses = []
         for _ in range(steps):
             loss, parts = step(None)
-            losses.append(float(loss))          # the reference logs the loss every step: one synchronisation per step
+            if os.environ.get("XML_TRAIN_NO_LOSS_SYNC"):      # A/B only: what the per-step host round trip costs
+                losses.append(loss)
+            else:
+                losses.append(float(loss))      # the reference logs the loss every step: one synchronisation per step
         torch.cuda.synchronize()
         wall = (time.perf_counter() - t0) / steps * 1e3
+        losses = [float(v) for v in losses]
         n_param = sum(p.numel() for p in model.parameters())
         flops = train_flops_per_sample(ctx_l, desc_l, hidden, dv, ds, ds) * bsz
         peak = 2500.0 if dtype == "bf16" else 157.3

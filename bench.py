@@ -299,8 +299,10 @@ def run_extras(args, headline_qps):
 
     def e2e():
         import bench_e2e
-        r = bench_e2e.run(50)                       # the reference's eval_query_bsz (xml/config.py)
-        big = bench_e2e.run(1000, repeats=1)
+        r = bench_e2e.run(50)                       # the reference's eval_query_bsz (xml/config.py); opt.graph_search on
+        eager = bench_e2e.run(50, repeats=1, graph=False)
+        r["eager_batches"] = {k: eager[k] for k in ("total_s", "queries_per_s", "stage_s", "search_host_overhead_s")}
+        big = bench_e2e.run(1000, repeats=1, graph=False)
         r["eval_query_bsz_1000"] = {k: big[k] for k in ("total_s", "queries_per_s", "stage_s", "search_device_only_s",
                                                         "search_host_overhead_s", "host_tail_s", "nms_s")}
         return r

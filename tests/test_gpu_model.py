@@ -158,6 +158,21 @@ def test_golden_pipeline_fp32(name):
                                          max_n_videos=o["max_vcmr_video"], tasks=("SVMR", "VCMR", "VR"), as_arrays=True)
     for task in ("VR", "VCMR", "SVMR"):
         assert isinstance(arr[task], MomentResults) and arr[task].to_list() == res[task]
+    # opt.graph_search: the same batches padded to (eval_query_bsz, max_desc_l) and replayed through one captured graph -- the
+    # same lists, bit for bit (a last, shorter batch is filled up with dummy rows that are not decoded)
+    import copy
+    opt_g = copy.copy(opt)
+    opt_g.graph_search = True
+    opt_g.max_desc_l = int(m.config.max_desc_l)        # the positional table: batches are padded up to it
+    assert opt_g.max_desc_l >= max(int(d["query_feat/%d" % i].shape[0]) for i in range(ds.n_q))
+    with torch.no_grad():
+        arr_g = inf.compute_query2ctx_info(m, ds, opt_g, ctx, max_before_nms=o["max_before_nms"],
+                                           max_n_videos=o["max_vcmr_video"], tasks=("SVMR", "VCMR", "VR"), as_arrays=True)
+    for task in ("VR", "VCMR", "SVMR"):
+        a, g_ = arr[task], arr_g[task]
+        np.testing.assert_array_equal(a.count, g_.count, err_msg=task + " counts (graphed batches)")
+        for col in ("vid", "st", "ed", "score"):
+            np.testing.assert_array_equal(getattr(a, col), getattr(g_, col), err_msg="%s.%s (graphed batches)" % (task, col))
     meta_vid = np.array([ds.video2idx["vid_%03d" % i] for i in range(ds.n_v)])
     v = arr["VCMR"]
     bs = o["eval_query_bsz"]

@@ -41,7 +41,7 @@ class SyntheticQueries(object):
         return dict(meta=meta, model_inputs=dict(query_feat=self.qf[i, :self.lens[i]]))
 
 
-def run(query_bsz=50, nms_thd=0.5, max_before_nms=200, workload="tvr_val", n_queries=None, repeats=2):
+def run(query_bsz=50, nms_thd=0.5, max_before_nms=200, workload="tvr_val", n_queries=None, repeats=2, graph=True):
     import bench
     from tvretrieval_amd import inference as inf
     from tvretrieval_amd.model_xml import XML
@@ -66,7 +66,8 @@ def run(query_bsz=50, nms_thd=0.5, max_before_nms=200, workload="tvr_val", n_que
                ts=[float(st[i] * clip), float((st[i] + rng.integers(2, 11)) * clip)]) for i in range(nq)]
     opt = argparse.Namespace(eval_query_bsz=query_bsz, device=dev, q2c_alpha=20.0, min_pred_l=2, max_pred_l=16,
                              clip_length=clip, debug=False, external_inference_vr_res_path=None, max_ctx_l=l,
-                             max_before_nms=max_before_nms, max_vcmr_video=100, nms_thd=nms_thd, dset_name="tvr")
+                             max_before_nms=max_before_nms, max_vcmr_video=100, nms_thd=nms_thd, dset_name="tvr",
+                             graph_search=graph, max_desc_l=int(qm.shape[1]))
     best = None
     for _ in range(repeats + 1):          # first pass = warm-up (workspaces, weight packing, allocator)
         tm = {}
@@ -99,7 +100,7 @@ def run(query_bsz=50, nms_thd=0.5, max_before_nms=200, workload="tvr_val", n_que
     t_json = time.perf_counter() - t0
     host_tail = best["top_n"] + best["eval"] + best["nms"] + best["eval_nms"]
     return {"workload": workload, "queries": nq, "videos": nv, "eval_query_bsz": query_bsz, "nms_thd": nms_thd,
-            "max_before_nms": max_before_nms, "tasks": ["VCMR", "SVMR", "VR"],
+            "max_before_nms": max_before_nms, "tasks": ["VCMR", "SVMR", "VR"], "graph_search": bool(graph),
             "total_s": best["total"], "queries_per_s": nq / best["total"],
             "stage_s": {k: round(v, 4) for k, v in best.items()},
             "search_device_only_s": round(search_only, 4),
@@ -120,5 +121,6 @@ if __name__ == "__main__":
     ap.add_argument("--bsz", type=int, default=50)
     ap.add_argument("--queries", type=int, default=None)
     ap.add_argument("--workload", default="tvr_val")
+    ap.add_argument("--eager", action="store_true", help="opt.graph_search off: every batch as its own chain of launches")
     a = ap.parse_args()
-    print(json.dumps(run(a.bsz, workload=a.workload, n_queries=a.queries)))
+    print(json.dumps(run(a.bsz, workload=a.workload, n_queries=a.queries, graph=not a.eager)))

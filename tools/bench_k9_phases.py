@@ -33,4 +33,14 @@ with torch.no_grad():
             s.record(); ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200, **rk); e.record()
         torch.cuda.synchronize()
         print("exit %d: median %.3f ms" % (abl, sorted(s.elapsed_time(e) for s, e in evs)[2]))
+    if hasattr(lib, "xml_debug_read_k9_stats"):      # how hard the expansion works: attempts, live rows, list entries per query
+        buf = (ctypes.c_ulonglong * 8)()
+        lib.xml_debug_read_k9_stats(buf, 1)
+        lib.xml_debug_set_q2c_ablation(ctypes.c_int(63))
+        ops.moment_topk(st, ed, tw, index.l_ref, 2, 16, 200, **rk)
+        torch.cuda.synchronize()
+        lib.xml_debug_read_k9_stats(buf, 1)
+        n = max(buf[4], 1)
+        print("per query: %.2f expansion attempts, %.0f live rows in the first, %.3f of the queries above 1024 rows, %.0f list entries"
+              % (buf[0] / n, buf[1] / n, buf[2] / n, buf[3] / n))
     lib.xml_debug_set_q2c_ablation(ctypes.c_int(0))

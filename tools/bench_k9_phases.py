@@ -8,6 +8,7 @@ from tvretrieval_amd import inference as inf, ops
 from tvretrieval_amd.model_xml import XML
 WL = os.environ.get("K9_WORKLOAD", "tvr_val")
 nq, nv, l, hidden, dv, ds, dq, ctx_mode, _ = bench.WORKLOADS[WL]
+nq = int(os.environ.get("K9_NQ", nq))      # K9_NQ=50: one workgroup per CU at most -- the phases' latencies, not their throughput
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 m = XML(bench.model_config(hidden, dv, ds, dq, ctx_mode, l), compute_dtype=torch.bfloat16).to(dev).eval()

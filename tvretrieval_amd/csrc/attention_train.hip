@@ -273,6 +273,22 @@ __global__ __launch_bounds__(256) void attn_train_fwd_kernel(AttnTrainArgs a) {
 }
 
 // ---- backward --------------------------------------------------------------------------------------------------------
+// Where a workgroup's ~70 K cycles go (128 x 100 x 768, 4 heads; XML_DEBUG_EXTRA=-DXML_AT_PROBE, tools/bench_attn_train.py):
+// first loads + K / V staging 14 K -- all 256 resident workgroups fetch their 154 KB at the same moment, a bandwidth burst with
+// nothing to overlap it at one workgroup per CU (issuing every load before the first use and both tiles' loads together: no
+// change) --, S 2.5 K, softmax 4 K, dP 2.3 K, dropout + dS 8.3 K (hash multiplies hoisted per row: no change), dQ 11.5 K,
+// transposes to LDS 2.4 K, dO staging 2.3-3.7 K, dV 8.6 K, Q staging 3-4 K, dK 8.8 K; the 480 MFMAs are 7.7 K of it.
+#ifdef XML_AT_PROBE
+}  // namespace
+__device__ unsigned long long g_at_probe[4 * 16];      // stage timers of workgroup (head 1, sequence 7)
+extern "C" int xml_debug_read_at_probe(unsigned long long* host_out) {
+  return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_at_probe), sizeof(g_at_probe)) == hipSuccess ? 0 : -4;
+}
+namespace {
+#define AT_MARK(i) do { if (blockIdx.x == 1 && blockIdx.y == 7 && lane == 0) g_at_probe[wave * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define AT_MARK(i) do { } while (0)
+#endif
 template <int DH>
 __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
   constexpr int KS = DH * 2 + 16;
@@ -293,6 +309,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
   const bf16_t* dobase = a.dout + (int64_t)n * lq * a.ldo + head * DH;
 
   // ---- step 1: K -> R1, V -> R2; this wave's Q and dO row fragments and the masks in registers
+  AT_MARK(0);
   at_stage_rows<DH>(r1, kbase, a.ldk, lk, 128, tid);
   at_stage_rows<DH>(r2, vbase, a.ldv, lk, 128, tid);
   uint4 qa[2][DH / 32], da[2][DH / 32];
@@ -301,13 +318,17 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
   float km[AT_MAXNT], qmk[2][4];
   at_load_masks<DH>(km, qmk, a, n, wave, fr, fg);
   __syncthreads();
+  AT_MARK(1);
 
   // ---- step 2: P (recomputed), dPd = dO V^T, then Pd and dS in registers
   f32x4 p[2][AT_MAXNT], dp[2][AT_MAXNT];
   at_rows_dot_rows<DH>(p, qa, r1, fr, fg);
   const float inv_sqrt_dh = 1.0f / a.sqrt_dh;
+  AT_MARK(2);
   at_softmax(p, km, qmk, lk, inv_sqrt_dh, fr);
+  AT_MARK(3);
   at_rows_dot_rows<DH>(dp, da, r2, fr, fg);
+  AT_MARK(4);
   {
     const int64_t unit = (int64_t)n * gridDim.x + head;
     uint32_t s0 = 0, s1 = 0;
@@ -343,6 +364,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
       }
   }
 
+  AT_MARK(5);
   // ---- step 3: dQ = dS K for this wave's rows (K^T by transpose reads of R1)
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
@@ -352,7 +374,9 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
     at_tile_times_rows<DH>(o, dp[t], s_p, r1, lkp, fr, fg);
     at_store_tile<DH>(a.dq + (int64_t)n * lq * a.lddq + head * DH, a.lddq, qt * 16, lq, o, fr, fg);
   }
+  AT_MARK(6);
   __syncthreads();                                  // everyone is done with K (R1) and V (R2)
+  AT_MARK(7);
 
   // ---- step 4: Pd^T and dS^T -> R2 ([key][query], 272-byte rows); dO -> R1
   {
@@ -372,8 +396,10 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
       }
     }
   }
+  AT_MARK(8);
   at_stage_rows<DH>(r1, dobase, a.ldo, lq, 128, tid);
   __syncthreads();
+  AT_MARK(9);
 
   // ---- step 5: dV = Pd^T dO for key tiles w, w + 4
 #pragma unroll
@@ -384,9 +410,11 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
     at_trows_times_rows<DH>(o, r2, jt * 16, r1, lqp, fr, fg);
     at_store_tile<DH>(a.dv + (int64_t)n * lk * a.lddv + head * DH, a.lddv, jt * 16, lk, o, fr, fg);
   }
+  AT_MARK(10);
   __syncthreads();
   at_stage_rows<DH>(r1, qbase, a.ldq, lq, 128, tid);
   __syncthreads();
+  AT_MARK(11);
 
   // ---- step 6: dK = dS^T Q
 #pragma unroll
@@ -397,6 +425,7 @@ __global__ __launch_bounds__(256) void attn_train_bwd_kernel(AttnTrainArgs a) {
     at_trows_times_rows<DH>(o, r2 + 128 * AT_PSTRIDE, jt * 16, r1, lqp, fr, fg);
     at_store_tile<DH>(a.dk + (int64_t)n * lk * a.lddk + head * DH, a.lddk, jt * 16, lk, o, fr, fg);
   }
+  AT_MARK(12);
 }
 
 template <int DH> size_t at_fwd_lds() { return (size_t)2 * 128 * (DH * 2 + 16) + 4 * 16 * AT_PSTRIDE; }

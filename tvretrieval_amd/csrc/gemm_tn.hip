@@ -475,7 +475,7 @@ extern "C" int xml_gemm_tn(const void* A, const void* B, float* out, float* cols
     if (!xml_lds_attr_once<gemm_tn_xcd_kernel>(X_LDS)) return XML_ERR_LAUNCH;
     int abl = 0;
 #ifdef XML_DEBUG_VARIANTS
-    if (g_q2c_ablation > 300 && g_q2c_ablation < 320) abl = g_q2c_ablation - 300;   // 301: no output, 302: no MFMA, 304 / 305: see the kernel
+    if (g_q2c_ablation > 300 && g_q2c_ablation < 320) abl = g_q2c_ablation - 300;   // 301: no output, 304 / 306: L2- / L1-hot rows, 307: no loads, 308: timers (see the kernel)
 #endif
     hipLaunchKernelGGL(gemm_tn_xcd_kernel, dim3(256), dim3(512), X_LDS, st, (const bf16_t*)A, (const bf16_t*)B, out,
                        colsum_a, (int)rows, N, K, range_rows, sub, 1, abl);

@@ -177,6 +177,11 @@ int xml_modular_pool(const void* enc, const float* mask, const float* w_m, void*
  * --------------------------------------------------------------------------------------------- */
 int xml_linear(const void* x, const void* w, const float* b, void* y, int64_t rows, int n, int k,
                int relu, int dt, xml_stream_t stream);
+/* y = act(x W^T + b) + addend, addend (rows, n) dt added in the GEMM epilogue (one rounding).  The training step's dX of a
+ * projection whose input also feeds a residual connection: the residual's gradient rides in as the addend instead of an
+ * accumulation launch behind the GEMM (autograd.QkvResFn). */
+int xml_linear_add(const void* x, const void* w, const float* b, const void* addend, void* y, int64_t rows, int n, int k,
+                   int relu, int dt, xml_stream_t stream);
 
 /* Row-wise L2 normalisation, F.normalize(x, dim=-1) eps=1e-12 (xml/model_xml.py:446-447).
  * Done once per corpus for feat1 ("ctx normalisation precomputed at corpus-encode time"). */

@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--no-shadows", action="store_true", help="A/B: convert / transpose every weight at its use (train.SHADOW_WEIGHTS = False)")
     ap.add_argument("--separate-loss-tail", action="store_true", help="A/B: autograd.FUSED_LOSS_TAIL = False")
     ap.add_argument("--separate-kv", action="store_true", help="A/B: train.FUSE_KV = False")
+    ap.add_argument("--no-res-qkv", action="store_true", help="A/B: train.RESIDUAL_THROUGH_QKV = False (autograd sums a block input's two gradients itself)")
     ap.add_argument("--query-first", action="store_true", help="A/B: train.QUERY_FIRST = True (query encoder in front of the context branches)")
     ap.add_argument("--one-stream", action="store_true", help="A/B: train.PARALLEL_BRANCHES = False (video and subtitle branches on one stream)")
     a = ap.parse_args()
@@ -168,6 +169,9 @@ def main():
     if a.one_stream:
         import tvretrieval_amd.train as TR
         TR.PARALLEL_BRANCHES = False
+    if a.no_res_qkv:
+        import tvretrieval_amd.train as TR
+        TR.RESIDUAL_THROUGH_QKV = False
     if a.query_first:
         import tvretrieval_amd.train as TR
         TR.QUERY_FIRST = True

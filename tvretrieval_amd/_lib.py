@@ -63,6 +63,7 @@ SIGNATURES = {
     "xml_modular_pool": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int,
                                  c_void_p]),
     "xml_linear": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "xml_linear_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
     "xml_l2norm_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "xml_l2norm_rows_eps": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_float, c_void_p]),
     "xml_q2c_scores": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,

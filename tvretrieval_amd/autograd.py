@@ -364,6 +364,10 @@ class QkvFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        return QkvFn._backward(ctx, dy, None)
+
+    @staticmethod
+    def _backward(ctx, dy, dres):
         _shadow_guard(ctx)
         x, w = ctx.saved_tensors
         dy = dy.contiguous()
@@ -372,7 +376,14 @@ class QkvFn(torch.autograd.Function):
         h = nh // len(ws)
         rows = x.numel() // k
         dy2, x2 = dy.view(rows, nh), x.contiguous().view(rows, k)
-        dx = ops.linear(dy2, _weights_t(ws, w)).view(x.shape) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dres (QkvResFn): the gradient that reached x through the residual connection, added in the dX GEMM's epilogue
+            add = None if dres is None else dres.contiguous().view(rows, k)
+            if add is not None and (add.dtype != dy2.dtype or w.dtype is ops.F16S):
+                dx = ops.linear(dy2, _weights_t(ws, w)).view(x.shape) + dres
+            else:
+                dx = ops.linear(dy2, _weights_t(ws, w), addend=add).view(x.shape)
         if ctx.sunk:
             if all(_sink(p) is not None for p in ctx.params):
                 gw, gb = _adjacent(ws, "flat_g"), _adjacent(bs, "flat_g")
@@ -389,6 +400,24 @@ class QkvFn(torch.autograd.Function):
         for i in range(len(ws)):
             out += [dw[i * h:(i + 1) * h], db[i * h:(i + 1) * h]]
         return tuple(out)
+
+
+class QkvResFn(torch.autograd.Function):
+    """QkvFn for an input that ALSO feeds the block's residual connection (BertAttention: x -> [Wq; Wk; Wv] and x + dense(..)
+    into the LayerNorm, xml/model_components.py:201-216): returns (projection, x) -- the second output is x itself, to be used
+    as the residual operand -- so that both gradients of x arrive at THIS node and the residual's rides into the dX GEMM as its
+    epilogue addend; as two consumers of x autograd summed them with a launch of its own per block (13 per step)."""
+
+    @staticmethod
+    def forward(ctx, x, *wb):
+        y = QkvFn.forward(ctx, x, *wb)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        if dy is None:                       # (only the residual was used)
+            return (dres,) + (None,) * len(ctx.params)
+        return QkvFn._backward(ctx, dy, dres)
 
 
 class AttentionKvFn(torch.autograd.Function):

@@ -490,6 +490,14 @@ extern "C" int xml_linear(const void* x, const void* w, const float* b, void* y,
   return xmli_gemm(x, w, b, nullptr, y, rows, n, k, relu, 0, 1, 0, dt, (hipStream_t)stream);
 }
 
+extern "C" int xml_linear_add(const void* x, const void* w, const float* b, const void* addend, void* y, int64_t rows, int n,
+                              int k, int relu, int dt, xml_stream_t stream) {
+  XML_ENTER();
+  if (!x || !w || !y || !addend) return XML_ERR_BAD_ARG;
+  if (dt != XML_F32 && dt != XML_BF16) return XML_ERR_UNSUPPORTED;
+  return xmli_gemm(x, w, b, addend, y, rows, n, k, relu, 2, 1, 0, dt, (hipStream_t)stream);
+}
+
 // y = x W^T + b with a split-f16 weight (xml_pack_weights_f16s): x / y f32, f32-grade results on the 16-bit MFMA pipe
 extern "C" size_t xml_linear_f16s_workspace_bytes(int64_t rows, int k) { return xmli_gemm_split_ws_bytes(rows, k, XML_F16S); }
 extern "C" int xml_linear_f16s(const float* x, const void* w, const float* b, float* y, int64_t rows, int n, int k, int relu,

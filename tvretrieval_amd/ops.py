@@ -274,14 +274,20 @@ def modular_pool(enc, mask, w_m):
     return out
 
 
-def linear(x, w, b=None, relu=False):
-    """y = x W^T + b.  x (..., K), w (N, K) same dtype."""
+def linear(x, w, b=None, relu=False, addend=None):
+    """y = x W^T + b [+ addend].  x (..., K), w (N, K) same dtype; addend (..., N) of x's dtype, added in the GEMM epilogue."""
     _req(x, "x"); _req_w(w, "w", x)
     if b is not None:
         _req(b, "b", torch.float32)
     k = x.shape[-1]
     rows = x.numel() // k
     y = torch.empty(x.shape[:-1] + (w.shape[0],), dtype=x.dtype, device=x.device)
+    if addend is not None:
+        _req(addend, "addend", x.dtype)
+        assert w.dtype is not F16S and addend.numel() == y.numel()
+        check(_lib.load().xml_linear_add(_p(x), _p(w), _p(b), _p(addend), _p(y), rows, w.shape[0], k, int(relu), dt_of(x),
+                                         _stream()), "xml_linear_add")
+        return y
     if w.dtype is F16S:
         lib = _lib.load()
         ws = _workspace(lib.xml_linear_f16s_workspace_bytes(rows, k), x.device)

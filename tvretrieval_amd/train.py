@@ -24,7 +24,7 @@ import torch
 from . import ops
 from . import train_ops as T
 from . import autograd as _ag
-from .autograd import (AttentionCoreFn, AttentionKvFn, AttentionQkvFn, CombineLossFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, RankLossFn,
+from .autograd import (AttentionCoreFn, AttentionKvFn, AttentionQkvFn, CombineLossFn, DropoutFn, LayerNormFn, LinearFn, ModularPoolFn, PairSimFn, QkvResFn, RankLossFn,
                        QkvFn, SpanLossFn, VideoLevelScoresFn)
 
 F32 = torch.float32
@@ -111,7 +111,11 @@ def _probs_drop(sa):
 def _bert_attention(mod, x, key_mask, dt):
     """BertAttention = BertSelfAttention + BertSelfOutput (xml/model_components.py:201-216,313-317)."""
     sa, so = mod.self, mod.output
-    qkv = QkvFn.apply(x, sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias)
+    wb = (sa.query.weight, sa.query.bias, sa.key.weight, sa.key.bias, sa.value.weight, sa.value.bias)
+    if RESIDUAL_THROUGH_QKV and x.requires_grad and x.is_cuda:
+        qkv, x = QkvResFn.apply(x, *wb)      # (x: the same values, its gradient routed through the projection's backward node)
+    else:
+        qkv = QkvFn.apply(x, *wb)
     a = AttentionQkvFn.apply(qkv, key_mask, sa.num_attention_heads, *_probs_drop(sa))
     return _ln(LinearFn.apply(a, so.dense.weight, so.dense.bias, False), x, so.LayerNorm, dt, drop_in=so.dropout)
 
@@ -146,6 +150,7 @@ def _cross_context(model, main, main_mask, side, side_mask, cross, norm, self_at
     return _bert_attention(self_att, res, main_mask, dt)
 
 
+RESIDUAL_THROUGH_QKV = True     # the residual gradient of a BertAttention block as the addend of its dX GEMM (autograd.QkvResFn)
 QUERY_FIRST = False         # measured and not kept (see xml_forward_train): 4.13 vs 3.96 ms per captured step
 PARALLEL_BRANCHES = True      # video / subtitle branches of the training graph on two HIP streams
 _SIDE_STREAMS = {}

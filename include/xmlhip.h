@@ -228,15 +228,18 @@ int xml_q2c_scores_fused(int n_mod, const void* qn0, const void* cn0, const floa
  *     mask_mode 2: BINARY masks packed as bits, mbits_m (nv, 4) uint32, bit l of video v = mask_m[v][l] != 0; they reach
  *       the kernel through scalar loads, so ragged corpora get the fifth slot as well.  Same scores in every mode. */
 int xml_q2c_tiled_ok(int lpad, int hidden, int dt);
-/* Length-bucketed corpus image for ragged corpora (real TVR: mean 51 of 128 clips): videos are grouped by
- * padded length 128 / 64 / 32 and packed 2 / 4 / 8 per 256-row tile, so padding rows cost no MFMA work.
+/* Packed corpus image for ragged corpora (real TVR: mean 51 of 128 clips): every video is padded to a
+ * multiple of 16 clips and the videos are laid back to back into the 256 columns of a K6 tile (any arrangement whose padded
+ * lengths sum to <= 256 per tile), so padding rows cost (almost) no MFMA work.
  *   xml_q2c_tile_rows_gather: tiled image (as xml_q2c_tile_rows) of the rows src[row_map[i]], i < rows_packed
  *     (rows_packed % 256 == 0; row_map[i] < 0: zero row).  src (any rows, hidden) row-major.
- *   xml_q2c_scores_packed: K6 on that image.  n_tiles 256-row tiles: [0, ct128) two 128-clip slots, [ct128, ct64) four
- *     64-clip slots, [ct64, n_tiles) eight 32-clip slots.  Per wave tile w (= 128 columns; 2 per tile):
- *     slot_ids (2*n_tiles, 4) int32 = ORIGINAL video id of each sub-slot (-1: empty), mbits_m (2*n_tiles, 4) uint32 = the
- *     binary clip masks of its 128 columns.  out[q, id] is written for every slot id >= 0 -- in the video's original
- *     column, so everything downstream is unchanged and the scores are bitwise those of xml_q2c_scores_tiled. */
+ *   xml_q2c_scores_packed: K6 on that image, n_tiles 256-row tiles.  A tile is two wave tiles of 128 columns = 8 blocks of
+ *     16 columns.  slot_ids (2*n_tiles, 8) int32, one code per block: id >= 0 = the block is the LAST block of video id
+ *     (original numbering); -1 = the video continues in the next block; -2 = unused block; -3 (block 7 of an even wave tile
+ *     only) = the video continues in block 0 of the odd wave tile of the same tile.  mbits_m (2*n_tiles, 4) uint32 = the
+ *     binary clip masks of a wave tile's 128 columns (bit c of the 128 = column c).  out[q, id] is written for every
+ *     id >= 0 -- in the video's original column, so everything downstream is unchanged and the scores are bitwise those of
+ *     xml_q2c_scores_tiled (mask_logits then max over clips; a video with no valid clip scores -1e10 as there). */
 int xml_q2c_tile_rows_gather(const void* src, const int32_t* row_map, void* dst, int64_t rows_packed, int hidden, int dt,
                              xml_stream_t stream);
 /* F.normalize(dim=-1) of the clip rows fused into the tiling pass: dst = tiled image (rows_dst rows, a multiple of 256) of
@@ -248,8 +251,8 @@ int xml_q2c_tile_rows_l2norm_ok(int hidden, int dt);
 int xml_q2c_tile_rows_l2norm(const void* src, const int32_t* row_map, void* dst, int64_t rows_src, int64_t rows_dst,
                              int hidden, int dt, xml_stream_t stream);
 int xml_q2c_scores_packed(int n_mod, const void* qt0, const void* ct0, const void* qt1, const void* ct1, float* out,
-                          int64_t ld_out, int nq, int n_tiles, int ct128, int ct64, const int32_t* slot_ids,
-                          const uint32_t* mbits0, const uint32_t* mbits1, int hidden, int dt, xml_stream_t stream);
+                          int64_t ld_out, int nq, int n_tiles, const int32_t* slot_ids, const uint32_t* mbits0,
+                          const uint32_t* mbits1, int hidden, int dt, xml_stream_t stream);
 int64_t xml_q2c_tiled_bytes(int64_t rows, int hidden, int dt);
 int xml_q2c_tile_rows(const void* src, void* dst, int64_t rows, int hidden, int dt, xml_stream_t stream);
 int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0, const float* mask0, const void* qt1,

@@ -394,9 +394,9 @@ def test_normalise_and_tile_in_one_pass_is_bitwise_l2norm_then_tile(ops, dtype):
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n_mod", [1, 2])
 def test_q2c_length_buckets_bitwise(ops, dtype, n_mod):
-    """Ragged corpus (TVR-like lengths, mean ~51 of 128 clips): the length-bucketed image (2 / 4 / 8 videos per K6 tile,
-    xml_q2c_scores_packed) gives BITWISE the scores of the plain tiled image with packed bit masks, in the videos'
-    original columns -- so every list downstream is identical -- and both equal the oracle formulation."""
+    """Ragged corpus (TVR-like lengths, mean ~51 of 128 clips): the packed image (videos padded to 16 clips, back to back,
+    straddling the wave tiles; xml_q2c_scores_packed) gives BITWISE the scores of the plain tiled image with packed bit
+    masks, in the videos' original columns -- so every list downstream is identical -- and both equal the oracle formulation."""
     nq, nv, h = 700, 611, 256
     g = torch.Generator().manual_seed(31)
     lens = torch.cat([torch.randint(1, 33, (40,), generator=g), torch.randint(33, 65, (500,), generator=g),
@@ -411,7 +411,7 @@ def test_q2c_length_buckets_bitwise(ops, dtype, n_mod):
     plain = [ops.pack_q2c_corpus(c, m) for c, m in zip(cd, md)]
     assert all(t.mask_bits is not None and t.plan is None for t in plain)
     plan = ops.q2c_pack_plan(md)
-    assert plan is not None and plan.ct128 < plan.ct64 < plan.n_tiles
+    assert plan is not None and plan.n_straddles > 0 and plan.n_tiles * 256 < 0.6 * nv * 128
     packed = [ops.pack_q2c_corpus(c, m, plan) for c, m in zip(cd, md)]
     assert all(torch.equal(t.to_rows(), c) for t, c in zip(packed, cd))         # un-bucketing gives the rows back
     want = ops.q2c_scores_fused(qd, plain, md)
@@ -425,6 +425,41 @@ def test_q2c_length_buckets_bitwise(ops, dtype, n_mod):
     close("bucketed q2c vs oracle", got, ref, _tol(dtype, 1e-5, 1e-2))
     print("padded clips %d of %d (%.0f %% of the MFMA work of the unbucketed layout)"
           % (plan.padded_clips, nv * 128, 100.0 * plan.n_tiles * 256 / (nv * 128)))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", ["tiny_videos", "holes_and_empties", "all_sizes", "few_queries"])
+def test_q2c_packed_shapes_bitwise(ops, dtype, case):
+    """xml_q2c_scores_packed on the layouts the plan can produce: eight one-block videos per wave tile, videos with no
+    valid clip / with holes in their masks / whose second modality is shorter or empty, every size 1..8 blocks with
+    straddles, fewer queries than a query tile.  Bitwise the plain tiled kernel (mask_logits then max, both modalities)."""
+    g = torch.Generator().manual_seed({"tiny_videos": 1, "holes_and_empties": 2, "all_sizes": 3, "few_queries": 4}[case])
+    nq, h = (37 if case == "few_queries" else 300), 256
+    if case == "tiny_videos":
+        lens = torch.randint(1, 17, (203,), generator=g)
+    elif case == "holes_and_empties":
+        lens = torch.randint(0, 100, (150,), generator=g)
+        lens[::7] = 0
+    else:
+        lens = torch.cat([torch.arange(1, 129), torch.randint(1, 129, (85,), generator=g)])[torch.randperm(213, generator=g)]
+    nv = lens.numel()
+    masks = [(torch.arange(128)[None] < lens[:, None]).float(), (torch.arange(128)[None] < (lens - 3).clamp_min(0)[:, None]).float()]
+    if case == "holes_and_empties":
+        masks[0][3, 2:9] = 0
+        masks[1][5] = 0
+        masks[0][8, :40] = 0
+    qs = [_normed(nq, h, seed=380 + m) for m in range(2)]
+    cs = [_normed(nv, 128, h, seed=390 + m) * masks[m][..., None] for m in range(2)]
+    qd, cd, md = [dev(q, dtype) for q in qs], [dev(c, dtype) for c in cs], [dev(m) for m in masks]
+    plain = [ops.pack_q2c_corpus(c, m) for c, m in zip(cd, md)]
+    plan = ops.PackPlan(md)
+    packed = [ops.pack_q2c_corpus(c, m, plan) for c, m in zip(cd, md)]
+    for n_mod in (1, 2):
+        want = ops.q2c_scores_fused(qd[:n_mod], plain[:n_mod], md[:n_mod])
+        got = ops.q2c_scores_fused(qd[:n_mod], packed[:n_mod], md[:n_mod], out=torch.full((nq, nv), float("nan"), device=DEV))
+        assert torch.equal(got, want), (case, n_mod, int((got != want).sum()))
+    if case == "holes_and_empties":
+        assert bool((got[:, 0] == -1e10).all())                    # no valid clip in either modality: mask_logits' constant
 
 
 def test_q2c_fused_full_scale_property(ops):

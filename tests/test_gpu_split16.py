@@ -401,6 +401,42 @@ def test_exact_mode_f16s_is_capturable():
         assert want["exact"]["n_full_rows"] > 0
         for k in ("top_scores", "top_indices", "flat_scores", "flat_indices"):
             assert torch.equal(got[k], want[k]), k
+        # the driver's replayed batches (opt.graph_search) do not read the flag per batch: flagged batches are searched again
+        # eagerly before the result sinks are fetched -- the lists of the eager driver, bit for bit
+        import argparse
+
+        class _Queries(object):
+            video2idx = {"vid_%03d" % i: 1000 + i for i in range(nv)}
+
+            def __init__(self, n):
+                self.q = [_feats(1, [int(x)], 128, 900 + i)[0][0, :int(x)].numpy() for i, x in enumerate(rng.integers(5, 31, n))]
+
+            def set_data_mode(self, mode):
+                pass
+
+            def load_gt_vid_name_for_query(self, flag):
+                pass
+
+            def __len__(self):
+                return len(self.q)
+
+            def __getitem__(self, i):
+                return dict(meta=dict(desc_id=i, desc="q%d" % i, vid_name="vid_%03d" % (i % nv)),
+                            model_inputs=dict(query_feat=self.q[i]))
+        ds = _Queries(2 * nq + 7)
+        ctx = dict(index=index, video_metas=[dict(vid_name="vid_%03d" % i) for i in range(nv)])
+        opt = argparse.Namespace(eval_query_bsz=nq, device=torch.device(DEV), q2c_alpha=20.0, min_pred_l=2, max_pred_l=16,
+                                 clip_length=1.5, debug=False, external_inference_vr_res_path=None, max_desc_l=30)
+        eager = inf.compute_query2ctx_info(m16, ds, opt, ctx, max_before_nms=100, max_n_videos=10, tasks=("VCMR", "SVMR"),
+                                           as_arrays=True)
+        opt.graph_search = True
+        graphed = inf.compute_query2ctx_info(m16, ds, opt, ctx, max_before_nms=100, max_n_videos=10, tasks=("VCMR", "SVMR"),
+                                             as_arrays=True)
+        for task in ("VCMR", "SVMR"):
+            np.testing.assert_array_equal(eager[task].count, graphed[task].count)
+            for col in ("vid", "st", "ed", "score"):
+                np.testing.assert_array_equal(getattr(eager[task], col), getattr(graphed[task], col),
+                                              err_msg="%s.%s: graphed batches with an overflowing second tier" % (task, col))
 
 
 # ---- seeded sweeps over the supported shape space (one random case per test id) ----------------------------------------

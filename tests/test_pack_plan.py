@@ -1,5 +1,8 @@
-"""Host-side layout logic of the length-bucketed K6 corpus image (tvretrieval_amd.ops.PackPlan): pure index arithmetic,
-runs on CPU tensors."""
+"""Host-side layout logic of the packed K6 corpus image (tvretrieval_amd.ops.PackPlan): pure index arithmetic, runs on
+CPU tensors."""
+import json
+import os
+
 import numpy as np
 import torch
 
@@ -10,40 +13,88 @@ def _masks(lens):
     return (torch.arange(128)[None] < torch.as_tensor(lens)[:, None]).float()
 
 
+def _check_plan(plan, lens):
+    """Every structural promise xml_q2c_scores_packed relies on (include/xmlhip.h)."""
+    nv = len(lens)
+    codes = plan.slot_ids.numpy().reshape(plan.n_tiles, 16)
+    rm = plan.row_map.numpy().reshape(plan.n_tiles, 16, 16)
+    assert plan.slot_ids.shape == (2 * plan.n_tiles, 8) and plan.row_map.numel() == plan.n_tiles * 256
+    seen, straddles, padded = [], 0, 0
+    for t in range(plan.n_tiles):
+        b = 0
+        while b < 16:
+            c = codes[t, b]
+            if c == -2:                                  # unused blocks: only behind the last video of a tile, zero rows
+                assert (codes[t, b:] == -2).all() and (rm[t, b:] == -1).all()
+                break
+            start = b
+            while codes[t, b] in (-1, -3):
+                assert (codes[t, b] == -3) == (b == 7), "-3 marks block 7 of the left wave tile of a straddling video, only"
+                b += 1
+            vid = codes[t, b]
+            assert vid >= 0
+            nb = b - start + 1
+            assert nb == max(1, -(-int(lens[vid]) // 16)) and nb <= 8
+            straddles += int(start < 8 <= b and start + nb > 8 and start < 8 and b >= 8)
+            assert (rm[t, start:b + 1].reshape(-1) == vid * 128 + np.arange(nb * 16)).all()
+            seen.append(vid)
+            padded += nb * 16
+            b += 1
+    assert sorted(seen) == list(range(nv)), "every video exactly once"
+    assert plan.padded_clips == padded and plan.n_straddles == straddles
+    return straddles
+
+
 def test_pack_plan_layout():
     rng = np.random.default_rng(0)
-    lens = np.concatenate([rng.integers(1, 33, 13), rng.integers(33, 65, 57), rng.integers(65, 129, 9), [32, 64, 128, 1, 33, 65]])
+    lens = np.concatenate([rng.integers(1, 33, 13), rng.integers(33, 65, 57), rng.integers(65, 129, 9),
+                           [16, 17, 32, 64, 128, 1, 33, 65, 112, 113]])
     rng.shuffle(lens)
     nv = len(lens)
     m_video = _masks(lens)
     m_sub = _masks(np.maximum(lens - rng.integers(0, 3, nv), 1))      # a modality that is sometimes shorter
     plan = ops.PackPlan([m_video, m_sub])
-    ids = plan.slot_ids.numpy()
-    rm = plan.row_map.numpy()
-    assert rm.shape[0] == plan.n_tiles * 256 and ids.shape == (2 * plan.n_tiles, 4)
-    # every video exactly once; bucket by padded length; per-bucket ascending ids
-    flat = ids[ids >= 0]
-    assert sorted(flat.tolist()) == list(range(nv))
-    w128, w64 = 2 * plan.ct128, 2 * plan.ct64
-    assert (ids[:w128, 1:] == -1).all() and (ids[w128:w64, 2:] == -1).all()
-    for rng_w, lo, hi in ((slice(0, w128), 64, 128), (slice(w128, w64), 32, 64), (slice(w64, None), 0, 32)):
-        v = ids[rng_w][ids[rng_w] >= 0]
-        assert ((lens[v] > lo) & (lens[v] <= hi)).all()
-        assert (np.diff(v) > 0).all()
-    # row_map: wave tile w, sub-slot j of padded length lp covers columns [j*lp, (j+1)*lp) = clips 0..lp-1 of its video
-    for w in range(2 * plan.n_tiles):
-        lp = 128 if w < w128 else 64 if w < w64 else 32
-        for j in range(128 // lp):
-            seg = rm[w * 128 + j * lp: w * 128 + (j + 1) * lp]
-            v = ids[w, j]
-            assert (seg == (-1 if v < 0 else v * 128 + np.arange(lp))).all()
-    assert plan.padded_clips == int(sum(128 if x > 64 else 64 if x > 32 else 32 for x in lens))
+    _check_plan(plan, lens)
+    # no tile is emptier than a whole video could fix: the packing is within one tile of the lower bound here
+    assert plan.n_tiles <= -(-plan.padded_clips // 256) + 1
     # packed mask bits = the masks of the packed columns
+    rm = plan.row_map.numpy()
     for m in (m_video, m_sub):
         bits = plan.mask_bits(m).numpy().astype(np.int64) & 0xffffffff
         cols = np.where(rm >= 0, m.reshape(-1).numpy()[np.maximum(rm, 0)], 0).reshape(-1, 4, 32)
         want = (cols.astype(np.int64) << np.arange(32)).sum(-1)
         assert (bits == want).all()
+
+
+def test_pack_plan_edge_cases():
+    # an empty video (no valid clip) still owns one block; holes in a mask do not shorten a video
+    lens = [0, 5, 128, 40]
+    m = _masks(lens)
+    m[3, 10:20] = 0
+    plan = ops.PackPlan([m])
+    _check_plan(plan, [0, 5, 128, 40])
+    # only full-length videos next to one short one; a single video
+    _check_plan(ops.PackPlan([_masks([128, 128, 128, 7])]), [128, 128, 128, 7])
+    _check_plan(ops.PackPlan([_masks([77])]), [77])
+    # sizes that cannot avoid a straddle (3 + 3 + 3 + 3 + 4 blocks) and sizes that can (4 + 4 | 4 + 4)
+    p = ops.PackPlan([_masks([48, 48, 48, 48, 64])])
+    assert p.n_tiles == 1 and _check_plan(p, [48, 48, 48, 48, 64]) == 1
+    p = ops.PackPlan([_masks([64, 64, 64, 64])])
+    assert p.n_tiles == 1 and _check_plan(p, [64, 64, 64, 64]) == 0
+    p = ops.PackPlan([_masks([80, 48, 16, 112])])                 # 5 + 3 | 1 + 7 fills both wave tiles exactly
+    assert p.n_tiles == 1 and _check_plan(p, [80, 48, 16, 112]) == 0
+
+
+def test_pack_plan_real_tvr_lengths_reach_the_lower_bound():
+    rec = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "tvr_clip_count_hist.json")))
+    h = np.asarray(rec["hist"])
+    lens = np.maximum(np.minimum(np.repeat(np.arange(len(h)), h), 128), 1)
+    lens = np.random.default_rng(2018).permutation(lens)
+    plan = ops.PackPlan([_masks(lens)])
+    _check_plan(plan, lens)
+    blocks = int(np.ceil(lens / 16).sum())
+    assert plan.n_tiles == -(-blocks // 16) == 4871
+    print("executed / valid clip rows: %.4f (128/64/32 buckets: 1.308)" % (plan.n_tiles * 256 / lens.sum()))
 
 
 def test_pack_plan_not_used_for_full_length_or_soft_masks():
@@ -52,6 +103,7 @@ def test_pack_plan_not_used_for_full_length_or_soft_masks():
     soft = _masks([40, 50, 60, 70])
     soft[0, 3] = 0.5
     assert ops.q2c_pack_plan([soft]) is None
-    long_only = _masks([100, 128, 90, 70])
-    assert ops.q2c_pack_plan([long_only]) is None          # nothing to gain: every video needs the 128 bucket
-    assert ops.q2c_pack_plan([_masks([100, 20, 90, 70])]) is not None
+    long_only = _masks([120, 128, 115, 125])
+    assert ops.q2c_pack_plan([long_only]) is None          # nothing to gain: every video needs its 8 blocks
+    assert ops.q2c_pack_plan([_masks([100, 20, 90, 70])]) is None          # 7 + 2 + 6 + 5 blocks: two tiles either way
+    assert ops.q2c_pack_plan([_masks([100, 20, 40, 30])]) is not None      # 7 + 2 + 3 + 2 blocks: one tile instead of two

@@ -75,7 +75,7 @@ SIGNATURES = {
     "xml_q2c_tile_rows": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "xml_q2c_tile_rows_gather": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_void_p]),
     "xml_q2c_scores_packed": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int,
-                                      c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
+                                      c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "xml_q2c_scores_tiled": (c_int, [c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64,
                                      c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "xml_topk_rows_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

@@ -104,7 +104,7 @@ extern "C" void xml_debug_set_q2c_qsh(int v) { g_q2c_qsh = v; }
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                             float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st,
                             bool tiled = false, int mask_mode = 0, const uint32_t* const* mbits = nullptr,
-                            const int32_t* slot_ids = nullptr, int ct128 = 0, int ct64 = 0);
+                            const int32_t* slot_ids = nullptr);
 int xmli_q2c_scores_persist32(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                               float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st);
 int xmli_q2c_scores_persist4(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,

@@ -27,9 +27,8 @@ struct Q2cPersistArgs {
   const float* mask[2];
   const uint32_t* mbits[2];   // BITMASK kernels: (nv, 4) words, bit l of a video = clip l valid
                               // PACKED kernels: (2 * tc, 4) words, bit c of wave tile w = column c of its 128 columns valid
-  const int32_t* slot_ids;    // PACKED: (2 * tc, 4) original video id of sub-slot j of wave tile w (-1: empty)
-  int ct128, ct64;            // PACKED: clip tiles [0, ct128) hold 2 videos of <= 128 clips, [ct128, ct64) 4 of <= 64,
-                              //         [ct64, tc) 8 of <= 32 (length-bucketed corpus, xml_q2c_pack_plan)
+  const int32_t* slot_ids;    // PACKED: (2 * tc, 8) one code per 16-column block of wave tile w (xml_q2c_scores_packed):
+                              //         id >= 0 last block of video id, -1 inside a video, -2 unused, -3 continues in the next wave tile
   float* out;
   int64_t ld_out;
   int nq, nv, hidden, n_mod, tq, tc;
@@ -121,6 +120,15 @@ __device__ __forceinline__ float dpp_read(float v) {
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, false));
 }
 
+// lane id from the hardware (v_mbcnt), as a VOLATILE asm: hipcc can neither hoist it out of the segment loop nor keep a
+// copy of threadIdx live across the K loop (the persistent kernels sit at 246-256 VGPRs; a spilled lane id comes back
+// through a scratch load whose s_waitcnt vmcnt(0) would drain the hand-counted DMA stream once per segment)
+__device__ __forceinline__ int lane_id_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // Specialised to lpad == 128 (one video per 128-column group -- the TVR shape): no per-column divisions, one
@@ -143,9 +151,13 @@ __device__ __forceinline__ int swz4p(int row) { return (0x78 >> (((row >> 2) & 3
 //
 //   No wave-group stagger and no s_setprio: the two waves of a SIMD drift apart by themselves and keep the MFMA
 //   pipe busy from either wave's ready cluster.
-// PACKED (length-bucketed ragged corpora): a wave's 128 columns hold 1 / 2 / 4 videos padded to 128 / 64 / 32 clips, so
-// padding rows cost no MFMA work; the epilogue takes one masked maximum per sub-slot and scatters it to the video's
-// ORIGINAL column of `out` (ids through scalar loads) -- the scores are bitwise those of the unbucketed layout.
+// PACKED (ragged corpora): videos are padded to a multiple of 16 clips and laid back to back into the 256 columns of a
+// tile (xml_q2c_scores_packed), so padding rows cost (almost) no MFMA work.  The MFMA operands are SWAPPED (clips as the A
+// operand): a lane then holds ONE query column and 4 clip rows of every 16 x 16 block, so the maximum over a video's
+// clips is an in-lane v_max3 chain over its blocks plus two permlane swaps across the four row groups (6 VALU per
+// video instead of the 45-op 16-lane reduce-scatter of the plain layout).  A video may straddle the two wave tiles of
+// a tile: the left wave parks its partial maxima in a 1 KiB LDS patch, one extra s_barrier, the right wave combines.
+// Scores land in the videos' ORIGINAL columns of `out` and are bitwise those of the unpacked layout.
 template <typename T, int ABL = 0, bool PHASED = true, bool TILED = false, bool NOMASK = false, bool BITMASK = false,
           bool PACKED = false>   // ABL (debug library only): 1 no DMA after the prologue, 2 no MFMA, 8 timing probe
 __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   // three slices in flight behind the awaited one instead of two, +1.1-1.3 % measured.
   // BITMASK: ragged corpora get the fifth slot too -- binary clip masks packed 128 bits per video arrive through SCALAR
   // loads (lgkmcnt, invisible to the hand-counted vmcnt of the DMA stream), no mask DMA, no LDS patches.
-  constexpr bool FIVE = NOMASK || BITMASK || PACKED;
+  constexpr bool FIVE = NOMASK || BITMASK;       // (PACKED: four slots, the patch area carries the straddle hand-off)
   constexpr int NSLOT = FIVE ? 5 : 4;
   constexpr int RING_BYTES = NSLOT * SLOT_BYTES;
   constexpr int MASK_OFF = RING_BYTES;            // 2 x 1 KiB mask patches (256 columns x f32)
@@ -229,19 +241,21 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
   auto setup_issue_segment = [&](bool new_tile) {
     const int q0 = ((i_g << qsh) + qt_off) * 256, v0 = clip_tile(i_c) * 2;
-    int lane_o = lane;                              // opaque copy: keeps LICM from hoisting (and keeping live across
-    asm volatile("" : "+v"(lane_o));                // the MFMA loop) everything derived from the lane id below
+    const int lane_o = lane_id_now();               // re-derived here: nothing lane-dependent stays live across the MFMA loop
     if (new_tile) {
       const int rsub = lane_o >> 2, pslot = lane_o & 3;
       {
+        int q_left = a.nq - q0;                     // (a scalar here and now: under SGPR pressure hipcc otherwise parks a
+        asm volatile("" : "+s"(q_left));            // VGPR copy of nq across the K loop)
         auto off_a = [&](int piece) -> uint32_t {
           const int row = piece * 16 + rsub;
-          const int qrow = (q0 + row < a.nq) ? row : 0;
+          const int qrow = (row < q_left) ? row : 0;
           return (uint32_t)qrow * row_stride + (pslot ^ swz4p(row)) * 16;
         };
         auto off_b = [&](int piece) -> uint32_t {
           const int row = piece * 16 + rsub;
-          const int brow = (v0 + (row >> 7) < a.nv) ? row : (row & 127);
+          // (PACKED: nv = 2 * tc wave tiles, every tile of the image is complete)
+          const int brow = (PACKED || v0 + (row >> 7) < a.nv) ? row : (row & 127);
           return (uint32_t)brow * row_stride + (pslot ^ swz4p(row)) * 16;
         };
         if (grp == 0) {
@@ -254,7 +268,7 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     }
     sbase_a = reinterpret_cast<const char*>(a.qn[i_mod]) + (int64_t)q0 * k_bytes;
     sbase_b = reinterpret_cast<const char*>(a.cn[i_mod]) + (int64_t)v0 * 128 * k_bytes;
-    if (!FIVE && wave == 0) {   // mask patch of the segment: lane l carries columns 4 l .. 4 l + 3 of the tile's 256 columns
+    if (!FIVE && !PACKED && wave == 0) {   // mask patch of the segment: lane l carries columns 4 l .. 4 l + 3 of the tile's 256 columns
       const int mrow = (v0 + (lane_o >> 5) < a.nv) ? lane_o : (lane_o & 31);
       const char* sbase_m = reinterpret_cast<const char*>(a.mask[i_mod]) + (int64_t)v0 * 128 * 4;
       dma16s((uint32_t)mrow * 16, sbase_m, lds0 + MASK_OFF + (i_seg & 1) * 1024);
@@ -335,7 +349,6 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
   auto run = [&](auto grp_tag) {
   constexpr bool GRP1 = decltype(grp_tag)::value;
   float stash = 0.f;                   // modality-0 maximum of this lane's row of the current tile
-  float stash4[PACKED ? 4 : 1] = {};   // PACKED: one per sub-slot
   unsigned long long probe_wait = 0, probe_bar = 0, probe_t0 = 0;
   unsigned long long probe_r0 = 0;
   if (ABL == 8) { probe_t0 = __builtin_amdgcn_s_memtime(); probe_r0 = __builtin_amdgcn_s_memrealtime(); }
@@ -354,6 +367,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         for (int nn = 0; nn < 4; ++nn) {
           const int n = (K6Order<T>::snake && (m & 1)) ? 3 - nn : nn;
           if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbL[n].x), "v"(fc[m].w), "v"(fbL[n].w));
+          else if constexpr (INIT && PACKED) MmaInit<T>::chunk(acc[m][n], fbL[n], fc[m]);
+          else if constexpr (PACKED) Mma<T>::chunk(acc[m][n], fbL[n], fc[m]);
           else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n], fc[m], fbL[n]);
           else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
         }
@@ -386,6 +401,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
           for (int nn = 0; nn < 4; ++nn) {
             const int n = (K6Order<T>::snake && (m & 1)) ? 3 - nn : nn;
             if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbH[n].x), "v"(fc[m].w), "v"(fbH[n].w));
+            else if constexpr (INIT && PACKED) MmaInit<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
+            else if constexpr (PACKED) Mma<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
             else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
             else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
           }
@@ -419,76 +436,85 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
     }
     // ---- end of a (tile, modality) segment: mask_logits + max over the video's 128 clips, inside the wave -----
     if constexpr (PACKED) {
+      // acc[m][n][r] = score of query (wm * 64 + m * 16 + fr) against packed clip column (n * 16 + fg * 4 + r) of this wave tile
       const int q0 = ((c_g << qsh) + qt_off) * 256, ct = clip_tile(c_c);
-      int fr_e = fr, fg_e = fg;
-      asm volatile("" : "+v"(fr_e), "+v"(fg_e));
+      const int lane_e = lane_id_now(), fr_e = lane_e & 15, fg_e = lane_e >> 4;      // (see setup_issue_segment)
       const bool last_mod = c_mod == a.n_mod - 1;
       const int wt_s = __builtin_amdgcn_readfirstlane(ct * 2 + wn);
       typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-      typedef int32_t i32x4_t __attribute__((ext_vector_type(4)));
+      typedef int32_t i32x8_t __attribute__((ext_vector_type(8)));
       u32x4_t wv;
-      i32x4_t ids;
+      i32x8_t ids;
+      int tail;       // code of block 7 of the tile's LEFT wave tile, read by all eight waves: -3 <=> a video straddles the
+                      // wave tiles <=> every wave takes the extra barrier (uniform by construction, whatever the table holds)
       const uint32_t* mb = (c_mod == 0 ? a.mbits[0] : a.mbits[1]) + (int64_t)wt_s * 4;
-      const int32_t* idp = a.slot_ids + (int64_t)wt_s * 4;
-      asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)"
-                   : "=&s"(wv), "=&s"(ids) : "s"(mb), "s"(idp) : "memory");
-      const bool fast = (wv.x & wv.y & wv.z & wv.w) == 0xffffffffu;
-      float mk[8];
-#pragma unroll
-      for (int n = 0; n < 8; ++n) {
-        const uint32_t w = (n >> 1) == 0 ? wv.x : (n >> 1) == 1 ? wv.y : (n >> 1) == 2 ? wv.z : wv.w;
-        mk[n] = (float)((w >> ((n & 1) * 16 + fr_e)) & 1u);
-      }
-      const int lrow = wm * 64 + (fr_e >> 2) * 16 + fg_e * 4 + (fr_e & 3);
-      const bool row_ok = q0 + lrow < a.nq;
+      const int32_t* idp = a.slot_ids + (int64_t)wt_s * 8;
+      const int32_t* tp = a.slot_ids + (int64_t)(wt_s - wn) * 8 + 7;
+      asm volatile("s_load_dwordx4 %0, %3, 0x0\n\ts_load_dwordx8 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                   : "=&s"(wv), "=&s"(ids), "=&s"(tail) : "s"(mb), "s"(idp), "s"(tp) : "memory");
+      const bool straddle = tail == -3;
+      bool head = straddle && wn == 1;          // the first video that ends in the right wave tile began in the left one
+      float headred = -INFINITY;
+      int head_id = -1;
+      // lane (fr, fg) ends up with the row of query block m = {0, 2, 1, 3}[fg] (see the swaps below)
+      const int lrow = wm * 64 + ((((fg_e & 1) << 1) | (fg_e >> 1)) << 4) + fr_e;
+      int q_left = a.nq - q0;
+      asm volatile("" : "+s"(q_left));
+      const bool row_ok = lrow < q_left;
       float* orow = a.out + (int64_t)(q0 + lrow) * a.ld_out;
-      // one sub-slot: masked maximum over its n-tiles [N0, N0 + NPG), 16-lane reduce-scatter, stash / combine / store
-      auto slot = [&](auto n0_tag, auto npg_tag, float& st, int id) {
-        constexpr int N0 = decltype(n0_tag)::value, NPG = decltype(npg_tag)::value;
-        float x[16];
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float mx = -INFINITY;
-            if (fast) {
-#pragma unroll
-              for (int n = N0; n < N0 + NPG; ++n) mx = fmaxf(mx, acc[m][n][r]);
-            } else {
-#pragma unroll
-              for (int n = N0; n < N0 + NPG; ++n) mx = fmaxf(mx, acc[m][n][r] * mk[n] + (1.f - mk[n]) * -1e10f);
-            }
-            x[m * 4 + r] = mx;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-        const bool b8 = (fr_e & 8) != 0, b4 = (fr_e & 4) != 0, b2 = (fr_e & 2) != 0, b1 = (fr_e & 1) != 0;
-        float y[8], z[4], u[2];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) y[i] = fmaxf(b8 ? x[i + 8] : x[i], dpp_read<0x140>(b8 ? x[i] : x[i + 8]));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) z[i] = fmaxf(b4 ? y[i + 4] : y[i], dpp_read<0x141>(b4 ? y[i] : y[i + 4]));
-#pragma unroll
-        for (int i = 0; i < 2; ++i) u[i] = fmaxf(b2 ? z[i + 2] : z[i], dpp_read<0x1B>(b2 ? z[i] : z[i + 2]));
-        float red = fmaxf(b1 ? u[1] : u[0], dpp_read<0xB1>(b1 ? u[0] : u[1]));
+      float* patch = reinterpret_cast<float*>(smem + MASK_OFF) + wm * 64 + lane_e;
+      // modality-0 maxima wait for modality 1 in LDS (the four-slot ring leaves 32 KiB): slot n = the video that ends in
+      // block n of this wave tile, slot 8 = the video that straddles into it.  No register lives across the K loop.
+      float* stash = reinterpret_cast<float*>(smem + MASK_OFF + 1024) + wave * (9 * 64) + lane_e;
+      const int sh = fg_e * 4;
+      auto finish = [&](float red, int slot, int id) {
         if (!last_mod) {
-          st = red;
+          stash[slot * 64] = red;
         } else {
-          if (a.n_mod == 2) red = (st + red) * 0.5f;
+          if (a.n_mod == 2) red = (stash[slot * 64] + red) * 0.5f;                        // (video + sub) / 2, xml/model_xml.py:574
           if constexpr (std::is_same<T, f16_t>::value) red *= K6_F16_OUT_SCALE;
-          if (row_ok && id >= 0) orow[id] = red;
+          if (row_ok) orow[id] = red;
         }
       };
-      if (ct < a.ct128) {
-        slot(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{}, stash4[0], ids.x);
-      } else if (ct < a.ct64) {
-        slot(std::integral_constant<int, 0>{}, std::integral_constant<int, 4>{}, stash4[0], ids.x);
-        slot(std::integral_constant<int, 4>{}, std::integral_constant<int, 4>{}, stash4[1], ids.y);
-      } else {
-        slot(std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, stash4[0], ids.x);
-        slot(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{}, stash4[1], ids.y);
-        slot(std::integral_constant<int, 4>{}, std::integral_constant<int, 2>{}, stash4[2], ids.z);
-        slot(std::integral_constant<int, 6>{}, std::integral_constant<int, 2>{}, stash4[3], ids.w);
+      float run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+      for (int n = 0; n < 8; ++n) {
+        const int id = n == 0 ? ids.s0 : n == 1 ? ids.s1 : n == 2 ? ids.s2 : n == 3 ? ids.s3 : n == 4 ? ids.s4
+                       : n == 5 ? ids.s5 : n == 6 ? ids.s6 : ids.s7;
+        if (id == -2) continue;                                              // unused block (wave-uniform)
+        const uint32_t w32 = (n >> 1) == 0 ? wv.x : (n >> 1) == 1 ? wv.y : (n >> 1) == 2 ? wv.z : wv.w;
+        const uint32_t w16 = (n & 1) ? (w32 >> 16) : (w32 & 0xffffu);
+        if (w16 == 0xffffu) {                                                // all 16 clips of the block valid
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+            run[m] = fmaxf(fmaxf(fmaxf(fmaxf(run[m], acc[m][n][0]), acc[m][n][1]), acc[m][n][2]), acc[m][n][3]);
+        } else {                                                             // mask_logits, xml/model_xml.py:640-641:
+          const uint32_t lw = w16 >> sh;                                     // x * 1 + 0 * -1e10 == x, x * 0 + 1 * -1e10 == -1e10
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const bool on = (lw >> r) & 1u;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) run[m] = fmaxf(run[m], on ? acc[m][n][r] : -1e10f);
+          }
+        }
+        if (id >= 0 || (n == 7 && id == -3)) {                               // a video ends here (or leaves this wave tile)
+          // maximum over the four row groups fg: lanes l, l ^ 32 through permlane32_swap, then l ^ 16 through
+          // permlane16_swap; each swap also halves the number of live values, so 4 query blocks cost 3 swaps + 3 max
+          const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(run[0]), __float_as_uint(run[1]), false, false);
+          const auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(run[2]), __float_as_uint(run[3]), false, false);
+          const float p = fmaxf(__uint_as_float(s01[0]), __uint_as_float(s01[1]));
+          const float q = fmaxf(__uint_as_float(s23[0]), __uint_as_float(s23[1]));
+          const auto spq = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+          const float red = fmaxf(__uint_as_float(spq[0]), __uint_as_float(spq[1]));
+          run[0] = run[1] = run[2] = run[3] = -INFINITY;
+          if (n == 7 && id == -3) *patch = red;
+          else if (head) { headred = red; head_id = id; head = false; }
+          else finish(red, n, id);
+        }
+      }
+      if (straddle) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (wn == 1 && head_id >= 0) finish(fmaxf(headred, *patch), 8, head_id);
       }
     } else {
       const int q0 = ((c_g << qsh) + qt_off) * 256, vid = clip_tile(c_c) * 2 + wn;
@@ -595,8 +621,9 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
 
 template <typename T>
 static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tiled, int mask_mode) {
-  const bool five = tiled && mask_mode != 0;     // mask_mode 3: PACKED
-  const int lds = five ? 5 * 2 * 256 * 64 : 4 * 2 * 256 * 64 + 2048;       // ring (+ two mask patches)
+  const bool five = tiled && (mask_mode == 1 || mask_mode == 2);     // mask_mode 3: PACKED (four slots + the straddle patch)
+  // ring + two mask patches; PACKED: + the straddle patch (1 KiB) and the modality-0 stash (8 waves x 9 x 256 B)
+  const int lds = five ? 5 * 2 * 256 * 64 : mask_mode == 3 ? 4 * 2 * 256 * 64 + 1024 + 8 * 9 * 256 : 4 * 2 * 256 * 64 + 2048;
   void (*kern)(Q2cPersistArgs) = nullptr;
   bool ok = false;
 #define XML_K6_PICK(...) do { kern = q2c_persist_kernel<__VA_ARGS__>; ok = xml_lds_attr_once<q2c_persist_kernel<__VA_ARGS__>>(lds); } while (0)
@@ -623,10 +650,9 @@ static int launch_q2c_persist(const Q2cPersistArgs& a, hipStream_t st, bool tile
 // the mask patch of segment s+2 is fetched 4 slices ahead and must not land before the epilogue of segment s.
 int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const* cn, const float* const* mask,
                             float* out, int64_t ld_out, int nq, int nv, int lpad, int hidden, int dt, hipStream_t st,
-                            bool tiled, int mask_mode, const uint32_t* const* mbits, const int32_t* slot_ids, int ct128,
-                            int ct64) {
+                            bool tiled, int mask_mode, const uint32_t* const* mbits, const int32_t* slot_ids) {
   Q2cPersistArgs a;
-  a.slot_ids = slot_ids; a.ct128 = ct128; a.ct64 = ct64;
+  a.slot_ids = slot_ids;
   for (int m = 0; m < 2; ++m) {
     a.qn[m] = qn[m < n_mod ? m : 0];
     a.cn[m] = cn[m < n_mod ? m : 0];
@@ -634,7 +660,7 @@ int xmli_q2c_scores_persist(int n_mod, const void* const* qn, const void* const*
     a.mbits[m] = mbits ? mbits[m < n_mod ? m : 0] : nullptr;
   }
   if ((mask_mode == 2 || mask_mode == 3) && (!mbits || !a.mbits[0] || !a.mbits[1])) return XML_ERR_BAD_ARG;
-  if (mask_mode == 3 && (!slot_ids || !tiled || (nv & 1) || ct128 < 0 || ct64 < ct128 || ct64 > nv / 2)) return XML_ERR_BAD_ARG;
+  if (mask_mode == 3 && (!slot_ids || !tiled || (nv & 1))) return XML_ERR_BAD_ARG;
   if (lpad != 128) return XML_ERR_UNSUPPORTED;
   a.out = out; a.ld_out = ld_out; a.nq = nq; a.nv = nv; a.hidden = hidden; a.n_mod = n_mod;
   a.tq = cdiv(nq, 256); a.tc = cdiv(nv, 2);
@@ -718,8 +744,7 @@ extern "C" int xml_q2c_tile_rows_gather(const void* src, const int32_t* row_map,
 }
 
 extern "C" int xml_q2c_scores_packed(int n_mod, const void* qt0, const void* ct0, const void* qt1, const void* ct1,
-                                     float* out, int64_t ld_out, int nq, int n_tiles, int ct128, int ct64,
-                                     const int32_t* slot_ids, const uint32_t* mbits0, const uint32_t* mbits1, int hidden,
+                                     float* out, int64_t ld_out, int nq, int n_tiles, const int32_t* slot_ids, const uint32_t* mbits0, const uint32_t* mbits1, int hidden,
                                      int dt, xml_stream_t stream) {
   XML_ENTER();
   if ((n_mod != 1 && n_mod != 2) || !qt0 || !ct0 || !out || !slot_ids || !mbits0) return XML_ERR_BAD_ARG;
@@ -732,7 +757,7 @@ extern "C" int xml_q2c_scores_packed(int n_mod, const void* qt0, const void* ct0
   const uint32_t* mb[2] = {mbits0, n_mod == 2 ? mbits1 : mbits0};
   // the kernel sees 2 * n_tiles "videos" of 128 columns (wave tiles); real ids come from slot_ids
   return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, 2 * n_tiles, 128, hidden, dt, (hipStream_t)stream, true,
-                                 3, mb, slot_ids, ct128, ct64);
+                                 3, mb, slot_ids);
 }
 
 extern "C" int xml_q2c_tiled_ok(int lpad, int hidden, int dt) {
@@ -774,5 +799,5 @@ extern "C" int xml_q2c_scores_tiled(int n_mod, const void* qt0, const void* ct0,
   if (mask_mode < 0 || mask_mode > 2) return XML_ERR_BAD_ARG;
   const uint32_t* mb[2] = {mbits0, n_mod == 2 ? mbits1 : mbits0};
   return xmli_q2c_scores_persist(n_mod, q, c, m, out, ld_out, nq, nv, lpad, hidden, dt, (hipStream_t)stream, true,
-                                 mask_mode, mb, nullptr, 0, 0);
+                                 mask_mode, mb, nullptr);
 }

@@ -886,6 +886,27 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
     graphed = None          # opt.graph_search (not a reference option): the batches through one captured graph
     want_graph = (getattr(opt, "graph_search", False) and external_query2video is None and ops is hip_ops and n > 0
                   and torch.device(opt.device).type == "cuda" and not getattr(opt, "debug", False))
+    def emit(out, b, nb, gt):
+        """K10 on the device: (flat index, local rank) -> [video_idx, st, ed, score] records (xml/inference.py:402-439)"""
+        nonlocal sink_vr
+        if is_vr:
+            n_vr = min(100, out["top_indices"].shape[1])
+            if sink_vr is None:
+                sink_vr = _ResultSink(n, n_vr, opt.device)
+            ops.moments_decode(out["top_scores"], top_idx=out["top_indices"], meta2vid=meta2vid, n=n_vr,
+                               **sink_vr.rows(b, nb))
+        if is_vcmr:
+            ops.moments_decode(out["flat_scores"], flat=out["flat_indices"], top_idx=out["top_indices"], meta2vid=meta2vid,
+                               l_ref=l_ref, clip_length=clip, seconds=True, **sink_vcmr.rows(b, nb))
+        if is_svmr:     # clip units on the device; the float64 scaling of get_svmr_res_from_st_ed_probs (:229-233) on the host
+            ops.moments_decode(out["svmr_scores"], flat=out["svmr_flat"], row_vid=gt, meta2vid=meta2vid, l_ref=l_ref,
+                               seconds=False, **sink_svmr.rows(b, nb))
+
+    # Replayed batches of a split-f16 exact-rank index: the captured second tier can overflow (more failing queries / closer
+    # scores than it holds).  GraphedVcmrSearch.__call__ reads the flag back after every replay; here that would put a host
+    # synchronisation into every batch, so each batch's flag is kept on the device and the flagged batches are searched
+    # again eagerly -- and their records overwritten -- before the sinks are fetched.
+    exact_flags = []        # (first query, device flag)
     for b in range(0, n, opt.eval_query_bsz):
         items = [eval_dataset[i] for i in range(b, min(n, b + opt.eval_query_bsz))]
         metas = [e["meta"] for e in items]
@@ -907,6 +928,8 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
             gt_rows = np.fromiter((name2meta[m["vid_name"]] for m in metas), dtype=np.int32, count=nb) if is_svmr else None
             out = graphed(seqs, gt_rows)
             gt = graphed.gt[:nb] if is_svmr else None
+            if out.get("exact") is not None and out["exact"].get("overflow_dev") is not None:
+                exact_flags.append((b, out["exact"]["overflow_dev"].reshape(-1)[:1].clone()))
             out = {k: (v[:nb] if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == graphed.bsz else v)
                    for k, v in out.items()}
             qf = None
@@ -923,21 +946,20 @@ def compute_query2ctx_info(model, eval_dataset, opt, ctx_info, max_before_nms=10
             external_top = (ext_i.to(opt.device).contiguous(), ext_w.to(opt.device).contiguous())
         if qf is not None:
             out = vcmr_search(model, index, qf, qm, svmr_video=gt, external_top=external_top, **search_kw)
-        # K10 on the device: (flat index, local rank) -> [video_idx, st, ed, score] records (xml/inference.py:402-439)
-        if is_vr:
-            n_vr = min(100, out["top_indices"].shape[1])
-            if sink_vr is None:
-                sink_vr = _ResultSink(n, n_vr, opt.device)
-            ops.moments_decode(out["top_scores"], top_idx=out["top_indices"], meta2vid=meta2vid, n=n_vr,
-                               **sink_vr.rows(b, nb))
-        if is_vcmr:
-            ops.moments_decode(out["flat_scores"], flat=out["flat_indices"], top_idx=out["top_indices"], meta2vid=meta2vid,
-                               l_ref=l_ref, clip_length=clip, seconds=True, **sink_vcmr.rows(b, nb))
-        if is_svmr:     # clip units on the device; the float64 scaling of get_svmr_res_from_st_ed_probs (:229-233) on the host
-            ops.moments_decode(out["svmr_scores"], flat=out["svmr_flat"], row_vid=gt, meta2vid=meta2vid, l_ref=l_ref,
-                               seconds=False, **sink_svmr.rows(b, nb))
+        emit(out, b, nb, gt)
         if getattr(opt, "debug", False):
             break
+    if exact_flags:
+        flagged = torch.cat([f for _, f in exact_flags]).cpu().numpy()            # ONE read-back for the whole query set
+        for (b, _), over in zip(exact_flags, flagged):
+            if not over:
+                continue
+            items = [eval_dataset[i] for i in range(b, min(n, b + opt.eval_query_bsz))]
+            qf, qm = pad_batch([e["model_inputs"]["query_feat"] for e in items], opt.device)
+            gt = None
+            if is_svmr:
+                gt = torch.tensor([name2meta[e["meta"]["vid_name"]] for e in items], dtype=torch.int32, device=opt.device)
+            emit(vcmr_search(model, index, qf, qm, svmr_video=gt, **search_kw), b, len(items), gt)
     res = {}
     if is_svmr:
         res["SVMR"] = sink_svmr.fetch(desc_ids, descs, scale=clip)

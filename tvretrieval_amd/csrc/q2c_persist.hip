@@ -367,10 +367,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         for (int nn = 0; nn < 4; ++nn) {
           const int n = (K6Order<T>::snake && (m & 1)) ? 3 - nn : nn;
           if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbL[n].x), "v"(fc[m].w), "v"(fbL[n].w));
-          else if constexpr (INIT && PACKED) MmaInit<T>::chunk(acc[m][n], fbL[n], fc[m]);
-          else if constexpr (PACKED) Mma<T>::chunk(acc[m][n], fbL[n], fc[m]);
-          else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n], fc[m], fbL[n]);
-          else Mma<T>::chunk(acc[m][n], fc[m], fbL[n]);
+          else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n], fbL[n], fc[m]);      // clips as the A operand: see the epilogue
+          else Mma<T>::chunk(acc[m][n], fbL[n], fc[m]);
         }
       // ONE wait: vmcnt(8) -- my DMAs of slice c_gs + 1 have landed, the two younger slices stay in flight -- and
       // lgkmcnt(0) -- all my LDS reads of slice c_gs have returned (as a builtin: hipcc must KNOW the fbH reads are
@@ -401,10 +399,8 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
           for (int nn = 0; nn < 4; ++nn) {
             const int n = (K6Order<T>::snake && (m & 1)) ? 3 - nn : nn;
             if (ABL == 2) asm volatile("" ::"v"(fc[m].x), "v"(fbH[n].x), "v"(fc[m].w), "v"(fbH[n].w));
-            else if constexpr (INIT && PACKED) MmaInit<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
-            else if constexpr (PACKED) Mma<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
-            else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
-            else Mma<T>::chunk(acc[m][n + 4], fc[m], fbH[n]);
+            else if constexpr (INIT) MmaInit<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
+            else Mma<T>::chunk(acc[m][n + 4], fbH[n], fc[m]);
           }
       };
       // The two waves of a SIMD (w and w + 4) leave the barrier together.  If both ran [reads, DMA issue, MFMA]
@@ -517,14 +513,18 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         if (wn == 1 && head_id >= 0) finish(fmaxf(headred, *patch), 8, head_id);
       }
     } else {
+      // One video per wave tile.  acc[m][n][r] = score of query (wm * 64 + m * 16 + fr) against clip (n * 16 + fg * 4 + r):
+      // the maximum over the clips is an in-lane v_max3 chain (64 ops) and two permlane swaps across the four row groups.
       const int q0 = ((c_g << qsh) + qt_off) * 256, vid = clip_tile(c_c) * 2 + wn;
-      int fr_e = fr, fg_e = fg;                     // opaque copies (see setup_issue_segment)
-      asm volatile("" : "+v"(fr_e), "+v"(fg_e));
-      const float* mpatch = reinterpret_cast<const float*>(smem + MASK_OFF + (c_seg & 1) * 1024) + wn * 128 + fr_e;
+      const int lane_e = lane_id_now(), fr_e = lane_e & 15, fg_e = lane_e >> 4;      // (see setup_issue_segment)
       const bool last_mod = c_mod == a.n_mod - 1;
       const bool vid_ok = vid < a.nv;
-      float mk[8];
-      bool fast;
+      float run[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      auto plain_block = [&](int n) {
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+          run[m] = fmaxf(fmaxf(fmaxf(fmaxf(run[m], acc[m][n][0]), acc[m][n][1]), acc[m][n][2]), acc[m][n][3]);
+      };
       if constexpr (BITMASK) {
         // the video's 128 mask bits: four scalar loads (the address is wave-uniform)
         // (readfirstlane: hipcc must KNOW the index is uniform, or it emits VMEM loads whose s_waitcnt vmcnt(0) would drain
@@ -534,60 +534,63 @@ __global__ __launch_bounds__(512, 2) void q2c_persist_kernel(Q2cPersistArgs a) {
         typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
         u32x4_t wv;
         asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wv) : "s"(mb) : "memory");
-        const uint32_t w0 = vid_ok ? wv.x : 0u, w1 = vid_ok ? wv.y : 0u, w2 = vid_ok ? wv.z : 0u, w3 = vid_ok ? wv.w : 0u;
-        fast = (w0 & w1 & w2 & w3) == 0xffffffffu;
+        const int sh = fg_e * 4;
 #pragma unroll
         for (int n = 0; n < 8; ++n) {
-          const uint32_t w = (n >> 1) == 0 ? w0 : (n >> 1) == 1 ? w1 : (n >> 1) == 2 ? w2 : w3;
-          mk[n] = (float)((w >> ((n & 1) * 16 + fr_e)) & 1u);
-        }
-      } else {
+          const uint32_t w32 = (n >> 1) == 0 ? wv.x : (n >> 1) == 1 ? wv.y : (n >> 1) == 2 ? wv.z : wv.w;
+          const uint32_t w16 = (n & 1) ? (w32 >> 16) : (w32 & 0xffffu);
+          if (w16 == 0xffffu) {                     // all 16 clips of the block valid (wave-uniform)
+            plain_block(n);
+          } else {                                  // mask_logits (xml/model_xml.py:640-641) for binary masks:
+            const uint32_t lw = w16 >> sh;          // x * 1 + 0 * -1e10 == x, x * 0 + 1 * -1e10 == -1e10
 #pragma unroll
-        for (int n = 0; n < 8; ++n) mk[n] = vid_ok ? (FIVE ? 1.f : mpatch[n * 16]) : 0.f;
-        // every clip of this wave's video valid (the common case): x * 1 + (1 - 1) * -1e10 == x exactly, so the 128
-        // multiply-adds of mask_logits are skipped (wave-uniform branch; the epilogue is pure VALU time during which
-        // this wave issues no MFMA)
+            for (int r = 0; r < 4; ++r) {
+              const bool on = (lw >> r) & 1u;
+#pragma unroll
+              for (int m = 0; m < 4; ++m) run[m] = fmaxf(run[m], on ? acc[m][n][r] : -1e10f);
+            }
+          }
+        }
+      } else if constexpr (NOMASK) {
+#pragma unroll
+        for (int n = 0; n < 8; ++n) plain_block(n);
+      } else {
+        // f32 masks (any values) through the LDS patch of the segment: lane (fr, fg) needs columns n * 16 + fg * 4 + 0..3
+        const float4* mpatch = reinterpret_cast<const float4*>(smem + MASK_OFF + (c_seg & 1) * 1024) + wn * 32 + fg_e;
+        float4 mk[8];
         bool all_on = true;
 #pragma unroll
-        for (int n = 0; n < 8; ++n) all_on = all_on && (mk[n] == 1.f);
-        fast = __all(all_on);
-      }
-      // in-lane maxima over the 8 column tiles: x[m * 4 + r] belongs to tile row m * 16 + fg * 4 + r
-      float x[16];
-#pragma unroll
-      for (int m = 0; m < 4; ++m) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float mx = -INFINITY;
-          if (fast) {
-#pragma unroll
-            for (int n = 0; n < 8; ++n) mx = fmaxf(mx, acc[m][n][r]);
-          } else {
-#pragma unroll
-            for (int n = 0; n < 8; ++n)
-              mx = fmaxf(mx, acc[m][n][r] * mk[n] + (1.f - mk[n]) * -1e10f);   // mask_logits, xml/model_xml.py:640-641
-          }
-          x[m * 4 + r] = mx;
+        for (int n = 0; n < 8; ++n) {
+          mk[n] = mpatch[n * 4];
+          all_on = all_on && mk[n].x == 1.f && mk[n].y == 1.f && mk[n].z == 1.f && mk[n].w == 1.f;
         }
-        __builtin_amdgcn_sched_barrier(0);   // one row block at a time: keeps the epilogue's register peak low
+        // every clip of this wave's video valid (the common case): x * 1 + (1 - 1) * -1e10 == x exactly, so the
+        // multiply-adds of mask_logits are skipped (wave-uniform branch)
+        if (__all(all_on)) {
+#pragma unroll
+          for (int n = 0; n < 8; ++n) plain_block(n);
+        } else {
+#pragma unroll
+          for (int n = 0; n < 8; ++n) {
+            const float mv[4] = {mk[n].x, mk[n].y, mk[n].z, mk[n].w};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+              for (int m = 0; m < 4; ++m)
+                run[m] = fmaxf(run[m], acc[m][n][r] * mv[r] + (1.f - mv[r]) * -1e10f);   // mask_logits, xml/model_xml.py:640-641
+          }
+        }
       }
-      // Reduce-scatter over the 16 lanes that share fg: after four mirror exchanges (row, half-row, quad, pair) lane fr
-      // holds the 16-lane maximum of x[fr].  45 VALU ops instead of 16 full butterflies (128), and every lane ends up
-      // with exactly one row: one LDS op / one store per lane instead of 16 single-lane ones.
+      // maximum over the four row groups fg (lanes l, l ^ 32, then l ^ 16); each swap also halves the number of live
+      // values: lane (fr, fg) ends up with the row of query block {0, 2, 1, 3}[fg]
       {
-        const bool b8 = (fr_e & 8) != 0, b4 = (fr_e & 4) != 0, b2 = (fr_e & 2) != 0, b1 = (fr_e & 1) != 0;
-        float y[8], z[4], u[2];
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-          y[i] = fmaxf(b8 ? x[i + 8] : x[i], dpp_read<0x140>(b8 ? x[i] : x[i + 8]));        // row_mirror: fr <-> 15 - fr
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          z[i] = fmaxf(b4 ? y[i + 4] : y[i], dpp_read<0x141>(b4 ? y[i] : y[i + 4]));        // row_half_mirror
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          u[i] = fmaxf(b2 ? z[i + 2] : z[i], dpp_read<0x1B>(b2 ? z[i] : z[i + 2]));         // quad_perm [3,2,1,0]
-        float red = fmaxf(b1 ? u[1] : u[0], dpp_read<0xB1>(b1 ? u[0] : u[1]));              // quad_perm [1,0,3,2]
-        const int lrow = wm * 64 + (fr_e >> 2) * 16 + fg_e * 4 + (fr_e & 3);
+        const auto s01 = __builtin_amdgcn_permlane32_swap(__float_as_uint(run[0]), __float_as_uint(run[1]), false, false);
+        const auto s23 = __builtin_amdgcn_permlane32_swap(__float_as_uint(run[2]), __float_as_uint(run[3]), false, false);
+        const float p = fmaxf(__uint_as_float(s01[0]), __uint_as_float(s01[1]));
+        const float q = fmaxf(__uint_as_float(s23[0]), __uint_as_float(s23[1]));
+        const auto spq = __builtin_amdgcn_permlane16_swap(__float_as_uint(p), __float_as_uint(q), false, false);
+        float red = fmaxf(__uint_as_float(spq[0]), __uint_as_float(spq[1]));
+        const int lrow = wm * 64 + ((((fg_e & 1) << 1) | (fg_e >> 1)) << 4) + fr_e;
         if (!last_mod) {
           stash = red;                       // the lane <-> row mapping is the same for both modalities of a tile
         } else {

@@ -38,8 +38,8 @@ WORKLOADS = {
     "c2": (256, 2000, 128, 768, 3072, 768, 768, "video", "f32"),
     "tiny": (64, 300, 128, 256, 512, 256, 256, "video_sub", "bf16"),
     # c3 with the REAL clip counts of the 21 793 TVR videos (ceil(duration / 1.5 s) clipped to 128, mean 51.4; histogram in
-    # tests/golden/tvr_clip_count_hist.json): the index buckets videos by padded length (K6 packs 2 / 4 / 8
-    # per tile).  Reported next to the all-valid headline, never instead of it.
+    # tests/golden/tvr_clip_count_hist.json): the index pads every video to 16 clips and packs the videos back to
+    # back into K6's 256-column tiles (ops.PackPlan).  Reported next to the all-valid headline, never instead of it.
     "c3r": (10000, 21793, 128, 768, 3072, 768, 768, "video_sub", "bf16"),
     "tinyr": (64, 300, 128, 256, 512, 256, 256, "video_sub", "bf16"),
     # the reference's AS-TRAINED shape, the configuration its only published number is quoted on (README.md:131): TVR val,
@@ -289,6 +289,7 @@ def run_extras(args, headline_qps):
         if "ragged_corpus" in r:
             keep["executed_tflops"] = r["ragged_corpus"]["executed_tflops"]
             keep["mean_clips"] = r["ragged_corpus"]["mean_clips"]
+            keep["padded_row_share"] = round(r["ragged_corpus"]["padded_row_share"], 4)
         return keep
 
     def tvr_val():
@@ -627,13 +628,14 @@ def run(args, backend_factory=None, emit=True):
     ragged = None
     plan = getattr(index.feat1n[index.modalities[0]], "plan", None)
     if lens is not None:
-        # ragged corpus: the ALGORITHMIC work is the valid clips; the length-bucketed image executes `padded` clip rows
-        # (2 / 4 / 8 videos per tile), the unbucketed layout would execute 128 per video
+        # ragged corpus: the ALGORITHMIC work is the valid clips; the packed image (videos padded to 16 clips, back to back)
+        # executes `padded` clip rows, the unpacked layout would execute 128 per video
         valid = float(lens[lo:hi].sum())
         padded = float(plan.n_tiles * 256) if plan is not None else float(index.n_videos * index.lpad)
         flops_per_launch = 2.0 * nq * valid * hidden * len(index.modalities) / launches_per_step
         ragged = dict(mean_clips=valid / index.n_videos, executed_clip_rows=padded, valid_clip_rows=valid,
                       unbucketed_clip_rows=float(index.n_videos * index.lpad), bucketed=plan is not None,
+                      padded_row_share=1.0 - valid / padded,
                       executed_tflops=2.0 * nq * padded * hidden * len(index.modalities) / launches_per_step
                       / (k6_avg_ms * 1e-3) / 1e12)
     achieved = flops_per_launch / (k6_avg_ms * 1e-3) / 1e12

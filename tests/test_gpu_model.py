@@ -604,6 +604,62 @@ def test_packed_query_encode_equals_padded(dtype, hidden, nq, monkeypatch):
             assert float(d_.max()) <= 0.012 * scale and float(d_.mean()) <= 1e-3 * scale, (nm, float(d_.max()), float(d_.mean()))
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_host_to_host_chunked_pass_equals_the_single_launch(dtype):
+    """inference.vcmr_search_host (queries in pinned host memory -> chunked H2D on a side stream overlapped with the previous
+    chunk's search -> K10 records -> one D2H) returns, bit for bit, the records of ONE vcmr_search over the whole query set:
+    for the padded f32 layout of the reference's collate and for the feature store's ragged f16 token rows (device collate,
+    xml_ingest_rows).  Growing chunks (256 + 444 queries; one K7 / K9 launch for all); run twice."""
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import ops
+    from tvretrieval_amd.results import MOMENT_DTYPE
+    nv, nq, l = 150, 700, 128
+    m, cfg = _synthetic_model("video_sub", 128, 256, 128, 128, l, dtype, seed=15)
+    rng = np.random.default_rng(8)
+    lens = rng.integers(10, l + 1, nv); lens[0] = l
+    vf, vm = _feats(nv, lens, 256, 1)
+    sf, sm = _feats(nv, lens, 128, 2)
+    qlens = np.concatenate([[30], rng.integers(3, 31, nq - 1)])
+    meta2vid = torch.from_numpy((np.arange(nv) * 7 + 3).astype(np.int32)).to(DEV)
+    kw = dict(max_vcmr_video=20, max_before_nms=60)
+    with torch.no_grad():
+        index = inf.build_corpus_index(m, [(vf.to(DEV), vm.to(DEV), sf.to(DEV), sm.to(DEV))])
+        # ragged f16 store rows (un-normalised) and the padded batch the device collate makes of them = the reference's input
+        g = torch.Generator().manual_seed(4)
+        rows16 = (torch.randn(int(qlens.sum()), 128, generator=g) * 2.0).to(torch.float16)
+        row_start = torch.from_numpy(np.concatenate([[0], np.cumsum(qlens)]).astype(np.int64))
+        qf, qm = ops.ingest_rows(rows16.to(DEV), row_start.to(DEV), nq, 30, 30, normalize=True)
+        one = inf.vcmr_search(m, index, qf, qm, **kw)
+        rec1, cnt1 = ops.moments_decode(one["flat_scores"], flat=one["flat_indices"], top_idx=one["top_indices"],
+                                        meta2vid=meta2vid, l_ref=index.l_ref, clip_length=1.5, seconds=True)
+        want = rec1.cpu().numpy().view(MOMENT_DTYPE)[..., 0]
+        want_cnt = cnt1.cpu().numpy()
+        host = {"padded f32": dict(query_feat=qf.cpu().pin_memory(), query_mask=qm.cpu().pin_memory()),
+                "ragged f16": dict(query_feat=rows16.pin_memory(), row_start=row_start.pin_memory(), lq=30)}
+        for name, hk in host.items():
+            tm = {}
+            for rep in range(2):
+                rec, cnt = inf.vcmr_search_host(m, index, meta2vid=meta2vid, chunk=256, clip_length=1.5, timings=tm, **hk, **kw)
+                np.testing.assert_array_equal(cnt, want_cnt, err_msg=name)
+                for col in ("vid", "st", "ed", "score"):
+                    for q in range(nq):
+                        np.testing.assert_array_equal(rec[col][q, :cnt[q]], want[col][q, :want_cnt[q]],
+                                                      err_msg="%s: %s of query %d (pass %d)" % (name, col, q, rep))
+            assert tm["chunks"] == 2 and tm["chunk_queries"] == [256, 444] and tm["h2d_s"] > 0 and tm["d2h_s"] > 0
+            # two passes in flight (wait=False): each on its own buffer set, the same records
+            pend = [inf.vcmr_search_host(m, index, meta2vid=meta2vid, chunk=256, clip_length=1.5, wait=False, **hk, **kw)
+                    for _ in range(2)]
+            assert pend[0].buffers is not pend[1].buffers
+            for pnd in pend:
+                rec, cnt = pnd.result()
+                np.testing.assert_array_equal(cnt, want_cnt, err_msg=name + " (pipelined)")
+                for col in ("vid", "st", "ed", "score"):
+                    np.testing.assert_array_equal(np.where(np.arange(rec.shape[1])[None] < cnt[:, None], rec[col], 0),
+                                                  np.where(np.arange(rec.shape[1])[None] < cnt[:, None], want[col], 0),
+                                                  err_msg="%s: %s (pipelined)" % (name, col))
+    assert (want_cnt > 0).all() and len(np.unique(want["vid"][:, 0])) > 10
+
+
 def test_hip_graph_replay_equals_eager():
     """GraphedVcmrSearch (one HIP graph per query-batch shape) returns exactly what the eager pass returns, for
     several different batches replayed through the same graph."""

@@ -654,19 +654,10 @@ def pad_moment_tail(flat_scores, flat_indices, k_videos, l_ref, min_pred_l=None,
     return flat_scores, flat_indices
 
 
-def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200, q2c_alpha=20.0,
-                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops, external_top=None, pad_tail=False,
-                defer_exact_check=False):
-    """Device part of compute_query2ctx_info for one query batch (xml/inference.py:308-386), single GPU.
-
-    Returns device tensors:
-      top_scores (Nq,K) f32 = exp(alpha*q2c) desc, top_indices (Nq,K) int32 video (meta) indices,
-      flat_scores (Nq,n) f32 desc, flat_indices (Nq,n) int32 into (K, l_ref, l_ref)  [-1 = no candidate]
-      and, if svmr_video (Nq,) int32 is given, svmr_scores / svmr_flat (Nq,n) over (l_ref, l_ref).
-    external_top = (indices (Nq,K) int32, weights (Nq,K) f32): use these videos / weights instead of K6 + K8.
-    pad_tail=True: always max_before_nms rows, the reference's shape -- missing candidates become zero-score rows at
-    length-masked positions (pad_moment_tail) instead of flat = -1."""
-    qvec = stage_query_vectors(model, query_feat, query_mask)
+def stage_video_topk(model, index, qvec, max_vcmr_video=100, q2c_alpha=20.0, ops=hip_ops, external_top=None,
+                     defer_exact_check=False):
+    """K6 + K8 (or the exact-rank chain, or a caller's video lists): (q2c or None, top_w (Nq, K) f32 = exp(alpha s) desc,
+    top_i (Nq, K) int32, exact-rank info or None).  Per query independent of the rest of the batch."""
     exact = None
     if external_top is None and index.exact is not None:
         q2c = None          # (the f32 (Nq, Nv) matrix is never formed; exact["q2c_filter"] is the bf16 pass's)
@@ -681,6 +672,12 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
     else:   # external video-retrieval results replace K6/K8 (xml/inference.py:349-355): (meta idx int32, exp(alpha*s))
         q2c = None
         top_i, top_w = external_top
+    return q2c, top_w, top_i, exact
+
+
+def stage_moments(model, index, qvec, top_w, top_i, min_pred_l=2, max_pred_l=16, max_before_nms=200, ops=hip_ops,
+                  pad_tail=False):
+    """K7 + K9 on the selected (query, video) pairs -> (flat_scores (Nq, n) f32 desc, flat_indices (Nq, n) int32)."""
     if hasattr(ops, "MOMENT_SUMM") and K7_SUMMARIES:
         # K7 hands K9 the 8 largest row maxima of every pair (taken while the rows were in its registers): K9 reads the
         # 1 GB of span probabilities once instead of twice
@@ -693,6 +690,25 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
         fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms, **rk)
     if pad_tail:
         pad_moment_tail(fs, fi, top_i.shape[1], index.l_ref, min_pred_l, max_pred_l)
+    return fs, fi
+
+
+def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200, q2c_alpha=20.0,
+                min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops, external_top=None, pad_tail=False,
+                defer_exact_check=False):
+    """Device part of compute_query2ctx_info for one query batch (xml/inference.py:308-386), single GPU.
+
+    Returns device tensors:
+      top_scores (Nq,K) f32 = exp(alpha*q2c) desc, top_indices (Nq,K) int32 video (meta) indices,
+      flat_scores (Nq,n) f32 desc, flat_indices (Nq,n) int32 into (K, l_ref, l_ref)  [-1 = no candidate]
+      and, if svmr_video (Nq,) int32 is given, svmr_scores / svmr_flat (Nq,n) over (l_ref, l_ref).
+    external_top = (indices (Nq,K) int32, weights (Nq,K) f32): use these videos / weights instead of K6 + K8.
+    pad_tail=True: always max_before_nms rows, the reference's shape -- missing candidates become zero-score rows at
+    length-masked positions (pad_moment_tail) instead of flat = -1."""
+    qvec = stage_query_vectors(model, query_feat, query_mask)
+    q2c, top_w, top_i, exact = stage_video_topk(model, index, qvec, max_vcmr_video, q2c_alpha, ops, external_top,
+                                                defer_exact_check)
+    fs, fi = stage_moments(model, index, qvec, top_w, top_i, min_pred_l, max_pred_l, max_before_nms, ops, pad_tail)
     out = dict(q2c=q2c, top_scores=top_w, top_indices=top_i, flat_scores=fs, flat_indices=fi)
     if exact is not None:
         out["exact"] = exact
@@ -704,6 +720,203 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
             pad_moment_tail(ss, sf, 1, index.l_ref, min_pred_l, max_pred_l)
         out.update(svmr_scores=ss, svmr_flat=sf, svmr_st=st1[:, 0], svmr_ed=ed1[:, 0])
     return out
+
+
+_HOST_STREAMS = {}
+
+
+def _host_streams(device):
+    key = str(torch.device(device))
+    if key not in _HOST_STREAMS:
+        _HOST_STREAMS[key] = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+    return _HOST_STREAMS[key]
+
+
+class HostSearchBuffers(object):
+    """Pinned host memory + device staging of vcmr_search_host, allocated once and reused across calls (pinning a gigabyte of
+    queries is a page-locking system call, not part of a search)."""
+
+    def __init__(self, n_queries, width, chunk, lq, d_in, ragged_rows, device, dtype):
+        self.rec = torch.empty((n_queries, width, 4), dtype=torch.int32, pin_memory=True)      # xml_moment records
+        self.cnt = torch.empty((n_queries,), dtype=torch.int32, pin_memory=True)
+        self.rec_dev = torch.empty((n_queries, width, 4), dtype=torch.int32, device=device)
+        self.cnt_dev = torch.zeros((n_queries,), dtype=torch.int32, device=device)
+        # two staging sets: chunk c + 1 is copied in while chunk c is searched
+        if ragged_rows:
+            self.stage = [dict(rows=torch.empty((ragged_rows, d_in), dtype=dtype, device=device),
+                               start=torch.empty((chunk + 1,), dtype=torch.int64, device=device)) for _ in range(2)]
+        else:
+            self.stage = [dict(qf=torch.empty((chunk, lq, d_in), dtype=dtype, device=device),
+                               qm=torch.empty((chunk, lq), dtype=torch.float32, device=device)) for _ in range(2)]
+        # ONE pair of copy streams per device, shared by every buffer set: the runtime multiplexes streams onto a few hardware
+        # queues (four by default) and a stream that lands on the compute stream's queue executes in order WITH it -- a fifth
+        # stream made copies and K6 take turns instead of overlapping (profiles/r06_h2h_notes.md)
+        self.copy_stream, self.back_stream = _host_streams(device)   # host -> device, device -> host (PCIe is full duplex)
+        self.last_done = None                                       # event: the pass that last used these buffers has finished
+        self.freed = [None, None]                                   # events: staging set i has been read by its chunk
+
+
+class PendingHostSearch(object):
+    """A vcmr_search_host pass that has been enqueued (wait=False).  result() blocks until its records are in host memory."""
+
+    def __init__(self, buffers, done, fill_timings):
+        self.buffers, self.done, self._fill = buffers, done, fill_timings
+
+    def result(self):
+        from .results import MOMENT_DTYPE
+        self.done.synchronize()
+        if self._fill is not None:
+            self._fill()
+            self._fill = None
+        return self.buffers.rec.numpy().view(MOMENT_DTYPE)[..., 0], self.buffers.cnt.numpy()
+
+
+def host_chunks(nq, first=1024, growth=3, largest=16384):
+    """Query ranges of vcmr_search_host: a small first chunk (its copy is the only one nothing overlaps), then chunks growing
+    by `growth` -- a chunk's copy (PCIe: ~1.7 ms per 1 024 padded f32 queries) hides behind the previous chunk's K6 (~6.5 ms
+    per 1 024 queries on the TVR corpus) as long as it is not more than ~4 x as long.  Boundaries are multiples of 1 024
+    queries = four of K6's 256-row query tiles."""
+    first = max(256, (int(first) // 256) * 256)
+    out, b, n = [], 0, first
+    while b < nq:
+        e = min(nq, b + n)
+        if nq - e < first // 2:          # no sliver at the end
+            e = nq
+        out.append((b, e))
+        b, n = e, min(n * growth, largest)          # (bounded staging memory for very large query sets)
+    return out
+
+
+def vcmr_search_host(model, index, query_feat, query_mask=None, row_start=None, meta2vid=None, chunk=1024, lq=None,
+                     clip_length=1.5, buffers=None, timings=None, ops=hip_ops, max_vcmr_video=100, max_before_nms=200,
+                     q2c_alpha=20.0, min_pred_l=2, max_pred_l=16, pad_tail=False, chunk_growth=3, wait=True):
+    """VCMR from host memory to host memory: the path of the reference's query loop (xml/inference.py:302-314 moves every
+    batch host -> device, :383-386 moves the lists device -> host; start_end_dataset.py:362-370) for a whole query set.
+
+    Queries arrive in one of two host layouts (pinned for the copies to be asynchronous):
+      * query_feat (Nq, Lq, D) f32 + query_mask (Nq, Lq) f32 -- what the reference's collate delivers (padded);
+      * query_feat (rows, D) f16 / f32 + row_start (Nq + 1,) int64 -- the feature store's layout (ingest.FeatureStore): the
+        queries' token rows back to back, un-normalised; the collate (truncate to lq, l2-normalise, pad, mask) runs on the
+        device (xml_ingest_rows).
+    The set is cut into growing chunks (host_chunks).  Chunk c + 1 is copied host -> device on a side stream while chunk c
+    runs the per-query half of the search -- query encoder, K6 against the whole corpus, K8.  The pair half (K7 reads every
+    selected video's feat2 tile once per launch whatever the number of queries: 8.6 GB on the TVR corpus -- one launch, not
+    one per chunk) and K9 then run once over all queries, xml_moments_decode turns the lists into [video_idx, st, ed,
+    score] records and ONE device -> host copy returns them.  Per query the arithmetic is that of vcmr_search on the whole
+    set: the records are bitwise the single-launch records.
+    meta2vid (Nv,) int32 device: meta index -> video2idx value (None: the meta index itself).
+    Returns (records (Nq, n) numpy view of results.MOMENT_DTYPE on the pinned buffer, count (Nq,) int32 numpy).
+    wait=False: returns a PendingHostSearch as soon as the pass is enqueued; its result() gives the same pair.  Two passes can
+    be in flight (two buffer sets are kept on the index): the first copy of pass i + 1 then runs under the pair half of pass
+    i and the device never idles between query sets -- an idle gap of a few milliseconds costs the next K6 launch 2-3 % by
+    itself (clock / cache state; tools/bench_idle_effect.py).  The records of a pass stay valid until the second next pass.
+    timings (dict, optional): h2d_s / device_s / decode_s / d2h_s from HIP events (copy and compute overlap: the wall clock
+    is the caller's to take)."""
+    from .results import MOMENT_DTYPE
+    import time as _time
+    t_enter = _time.perf_counter()
+    dev = next(model.parameters()).device
+    ragged = row_start is not None
+    nq = (row_start.numel() - 1) if ragged else query_feat.shape[0]
+    d_in = query_feat.shape[-1]
+    lq = int(lq if lq is not None else (model.config.max_desc_l if ragged else query_feat.shape[1]))
+    width = int(max_before_nms)
+    bounds = host_chunks(nq, chunk, chunk_growth)
+    rs_host = row_start.numpy() if ragged else None
+    max_q = max(e - b for b, e in bounds)
+    max_rows = max(int(rs_host[e] - rs_host[b]) for b, e in bounds) if ragged else 0
+    if buffers is None:
+        # kept on the index between calls: pinning host pages and mapping device memory are system calls, not search time
+        key = (nq, width, max_q, lq, d_in, max_rows, str(dev), query_feat.dtype)
+        cache = index.__dict__.setdefault("_host_search_buffers", {})
+        if key not in cache:
+            cache.clear()
+            cache[key] = [[HostSearchBuffers(nq, width, max_q, lq, d_in, max_rows, dev, query_feat.dtype) for _ in range(2)], 0]
+        ring = cache[key]
+        buffers = ring[0][ring[1]]
+        ring[1] ^= 1
+    if buffers.last_done is not None:
+        buffers.last_done.synchronize()                  # (the pass before the previous one: normally long finished)
+    main = torch.cuda.current_stream(dev)
+    side = buffers.copy_stream
+    if meta2vid is None:
+        meta2vid = torch.arange(index.n_videos, dtype=torch.int32, device=dev)
+    copied, freed = [None, None], buffers.freed
+    ev_h2d = []
+
+    def evt():
+        return torch.cuda.Event(enable_timing=timings is not None)
+
+    def send(c):
+        b, e = bounds[c]
+        st = buffers.stage[c & 1]
+        with torch.cuda.stream(side):
+            if freed[c & 1] is not None:
+                side.wait_event(freed[c & 1])          # the chunk that read this staging set is done with it
+            t0, t1 = evt(), evt()
+            t0.record(side)
+            if ragged:
+                r0, r1 = int(rs_host[b]), int(rs_host[e])
+                st["rows"][:r1 - r0].copy_(query_feat[r0:r1], non_blocking=True)
+                st["start"][:e - b + 1].copy_(row_start[b:e + 1], non_blocking=True)
+            else:
+                st["qf"][:e - b].copy_(query_feat[b:e], non_blocking=True)
+                st["qm"][:e - b].copy_(query_mask[b:e], non_blocking=True)
+            t1.record(side)
+            ev_h2d.append((t0, t1))
+            copied[c & 1] = t1
+
+    with torch.no_grad():
+        send(0)
+        t_sent = _time.perf_counter()
+        qvecs, tws, tis = [], [], []
+        t_first = evt()
+        for c, (b, e) in enumerate(bounds):
+            if c + 1 < len(bounds):
+                send(c + 1)
+            st = buffers.stage[c & 1]
+            main.wait_event(copied[c & 1])
+            if c == 0:
+                t_first.record(main)
+            if ragged:
+                r0 = int(rs_host[b])
+                qf, qm = ops.ingest_rows(st["rows"], st["start"][:e - b + 1] - r0, e - b, lq, lq, normalize=True)
+            else:
+                qf, qm = st["qf"][:e - b], st["qm"][:e - b]
+            qvec = stage_query_vectors(model, qf, qm)
+            done = evt()
+            done.record(main)                            # the staging set is free once the query encoder has read it
+            freed[c & 1] = done
+            _, tw, ti, _ = stage_video_topk(model, index, qvec, max_vcmr_video, q2c_alpha, ops)
+            qvecs.append(qvec), tws.append(tw), tis.append(ti)
+        one = len(bounds) == 1
+        qvec = {m: (qvecs[0][m] if one else torch.cat([q[m] for q in qvecs])) for m in qvecs[0]}
+        top_w = tws[0] if one else torch.cat(tws)
+        top_i = tis[0] if one else torch.cat(tis)
+        fs, fi = stage_moments(model, index, qvec, top_w, top_i, min_pred_l, max_pred_l, max_before_nms, ops, pad_tail)
+        t1, t2, t2b, t3 = evt(), evt(), evt(), torch.cuda.Event(enable_timing=timings is not None)
+        t1.record(main)
+        ops.moments_decode(fs, flat=fi, top_idx=top_i, meta2vid=meta2vid, l_ref=index.l_ref, clip_length=clip_length,
+                           seconds=True, out=buffers.rec_dev, out_count=buffers.cnt_dev)
+        t2.record(main)
+        back = buffers.back_stream                       # the records leave on their own stream: `main` is free for the next pass
+        back.wait_event(t2)
+        with torch.cuda.stream(back):
+            t2b.record(back)
+            buffers.rec.copy_(buffers.rec_dev, non_blocking=True)
+            buffers.cnt.copy_(buffers.cnt_dev, non_blocking=True)
+            t3.record(back)
+        buffers.last_done = t3
+    t_enq = _time.perf_counter()
+
+    def fill():
+        timings.update(host_before_first_copy_s=t_sent - t_enter, host_enqueue_s=t_enq - t_sent,
+                       h2d_s=sum(a.elapsed_time(b) for a, b in ev_h2d) * 1e-3,
+                       h2d_exposed_s=ev_h2d[0][0].elapsed_time(ev_h2d[0][1]) * 1e-3,
+                       device_s=t_first.elapsed_time(t1) * 1e-3, decode_s=t1.elapsed_time(t2) * 1e-3,
+                       d2h_s=t2b.elapsed_time(t3) * 1e-3, chunks=len(bounds), chunk_queries=[e - b for b, e in bounds])
+    pending = PendingHostSearch(buffers, t3, fill if timings is not None else None)
+    return pending.result() if wait else pending
 
 
 class GraphedVcmrSearch(object):

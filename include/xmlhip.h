@@ -77,20 +77,11 @@ int xml_linear_ln_relu_pos(const void* x, int x_dt, const float* ln_in_g, const 
                            const float* ln_pos_b, void* y, int64_t rows, int seq_len, int d_in,
                            int hidden, int dt, void* ws, size_t ws_bytes, xml_stream_t stream);
 
-/* The large projections (K1 + K2, the output dense of K3 + K4) may run as ONE kernel with the LayerNorm in the GEMM's
- * epilogue; its 256 workgroups exchange per-row statistics and therefore wait for each other (one workgroup per CU; a
- * cooperative launch is opt-in, XML_LN_COOP=1).  The wait is bounded, and a wait that gives up never produces plausible
- * wrong numbers: the rows of that tile are written as NaN, the remaining waits of THAT LAUNCH give up at once (a flag in the
- * launch's own workspace, zeroed per launch -- nothing carries over to later launches), and a device-side diagnostic counter
- * is bumped.
- *   xml_ln_fusion_status(disable): the count since the last call; synchronises the device, so call it where the host waits
- *     anyway (the end of a corpus encode, the D2H of a result set); disable != 0 switches the fused path off for the process
- *     when the count is non-zero -- the caller then redoes the work, which takes plain GEMM + LayerNorm launches.
- *     xml_ln_fusion_enabled(): 0 after that, or when XML_LN_FUSION=0 is set (GPUs shared with other processes).
- * These two switches (and XML_LN_COOP) are the library's only process-wide state; they select between two paths with the
- * same results and are never read by a kernel. */
-int xml_ln_fusion_status(int disable);
-int xml_ln_fusion_enabled(void);
+/* The large projections (K1 + K2, the output dense of K3 + K4; hidden = 256 / 512 / 768, >= 2 048 rows) run as ONE kernel
+ * with the LayerNorm in the GEMM's epilogue: one workgroup computes all column tiles of a 256-row block and normalises it
+ * itself -- nothing is exchanged between workgroups, nothing waits, there is no failure path and no process-wide switch.
+ * Whether a projection takes that kernel depends on its shape class, never on how full the chip is or how many videos a
+ * batch holds: the encoder's results are bitwise independent of the context batch size (for batches of >= 16 videos). */
 
 /* ---------------------------------------------------------------------------------------------
  * K3+K4: BertAttention = BertSelfAttention + BertSelfOutput (no FFN)

@@ -218,14 +218,16 @@ def test_c3_exact_rank_mode_gives_the_fp32_lists(mode):
     (tests/test_gpu_split16.py); "f32": round 3's bf16 filter + exact-f32 re-score (tests/test_gpu_exact.py) -- against the
     plain f32 HIP path on 1 000 queries x the full 21 793-video corpus: EQUALITY, not overlap floors -- every top-100
     video position and every top-192 (video, st, ed) position identical except inside groups of scores tied to f32
-    rounding (1e-6 on the cosine); top-1 video and top-1 moment identical for every query."""
+    rounding (1e-6 on the cosine) -- position 0 included: the top-1 video is identical for every query, the top-1 moment for
+    all but at most two in a thousand, whose two best moments tie to f32 rounding (which of two such paths the plain f32 run
+    takes moves with every last-bit change of the encoder, e.g. which batches run the LayerNorm-epilogue GEMM)."""
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import bench_exact
     res = bench_exact.run(1000, 21793, "perturbed", 1000, mode=mode)
     print(res)
     v = res["vs_plain_f32"]
     assert v["video_positions_really_different"] == 0 and v["moment_positions_really_different"] == 0, v
-    assert v["top1_video_same"] == 1.0 and v["top1_moment_same"] == 1.0, v
+    assert v["top1_video_same"] == 1.0 and v["top1_moment_same"] >= 0.998, v      # (a differing top-1 is inside a tie: line above)
     if mode == "f32":      # same kernels behind the filter as the plain path: almost nothing may move
         assert v["video_positions_swapped_in_f32_ties"] <= 50 and v["moment_positions_swapped_in_f32_ties"] <= 100, v
         assert v["queries_with_identical_top100_order"] >= 990, v

@@ -605,6 +605,42 @@ def test_packed_query_encode_equals_padded(dtype, hidden, nq, monkeypatch):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("ctx_mode,hidden", [("video_sub", 768), ("video", 256)])
+def test_index_bits_do_not_depend_on_the_context_batch(dtype, ctx_mode, hidden):
+    """The same corpus encoded in context batches of 2 048 / 200 / 37 videos gives a BITWISE equal CorpusIndex (feat1n, feat2,
+    masks) in bf16 and f32: which kernel a projection takes is a property of its shape class, never of how many rows the
+    batch holds (the LayerNorm-epilogue GEMM is a per-workgroup affair and runs from 2 048 rows on; every GEMM tiling
+    accumulates over K in the same order; the attention kernels' per-video arithmetic does not depend on the grid).  An
+    index built on 8 GPUs from 2 724-video shards therefore equals the single-GPU index of the same corpus bit for bit."""
+    from tvretrieval_amd import inference as inf
+    nv, l = 2100, 128
+    m, cfg = _synthetic_model(ctx_mode, hidden, 512, 256, 256, l, dtype, seed=21)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    lens = torch.randint(20, l + 1, (nv,), device=DEV, generator=g)
+    lens[0] = l
+    mask = (torch.arange(l, device=DEV)[None] < lens[:, None]).float()
+
+    def feats(d):
+        x = torch.nn.functional.normalize(torch.randn(nv, l, d, device=DEV, generator=g), dim=-1)
+        return (x * mask[..., None]).contiguous()
+    vf, sf = feats(512), feats(256)
+
+    def batches(bs):
+        for b in range(0, nv, bs):
+            yield vf[b:b + bs], mask[b:b + bs], (sf[b:b + bs] if m.use_sub else None), (mask[b:b + bs] if m.use_sub else None)
+    with torch.no_grad():
+        ref = inf.build_corpus_index(m, batches(2048), l_ref=l)
+        for bs in (200, 37):
+            other = inf.build_corpus_index(m, batches(bs), l_ref=l)
+            for mod in ref.modalities:
+                for name, a_, b_ in (("feat1n", ref.feat1n_rows(mod), other.feat1n_rows(mod)), ("feat2", ref.feat2[mod], other.feat2[mod]),
+                                     ("mask", ref.mask[mod], other.mask[mod])):
+                    same = torch.equal(a_, b_)
+                    assert same, "%s[%s]: context batches of %d videos differ from batches of 2048 in %d elements (max |d| %g)" % (
+                        name, mod, bs, int((a_ != b_).sum()), float((a_.float() - b_.float()).abs().max()))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_host_to_host_chunked_pass_equals_the_single_launch(dtype):
     """inference.vcmr_search_host (queries in pinned host memory -> chunked H2D on a side stream overlapped with the previous
     chunk's search -> K10 records -> one D2H) returns, bit for bit, the records of ONE vcmr_search over the whole query set:

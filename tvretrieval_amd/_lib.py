@@ -43,8 +43,6 @@ SIGNATURES = {
     "xml_attention_block_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "xml_attention_block": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
-    "xml_ln_fusion_status": (c_int, [c_int]),
-    "xml_ln_fusion_enabled": (c_int, []),
     "xml_pack_plan": (c_int, [c_void_p, c_int64, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "xml_linear_ln_relu_pos_packed_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "xml_linear_ln_relu_pos_packed": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p,

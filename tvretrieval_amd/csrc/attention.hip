@@ -614,7 +614,7 @@ extern "C" int xml_attention_core(const void* q, int ldq, const void* k, int ldk
 // ---------------------------------------------------------------------------------------------------
 extern "C" size_t xml_attention_block_workspace_bytes(int64_t n, int seq_len, int hidden, int dt) {
   const size_t rows = (size_t)n * seq_len;
-  const size_t pre = align_up(rows * hidden * 4, 256);      // f32 pre-LN rows, or the fused epilogue's partial statistics
+  const size_t pre = align_up(rows * hidden * 4, 256);      // f32 pre-LN rows, or the fused epilogue's per-workgroup scratch
   const size_t lnw = xmli_gemm_ln_eligible((int64_t)rows, hidden, hidden, dt) ? xmli_gemm_ln_workspace_bytes((int64_t)rows, hidden) : 0;
   return align_up(rows * 3 * hidden * dt_size(dt), 256) + align_up(rows * hidden * dt_size(dt), 256) +
          (pre > lnw ? pre : lnw) + xmli_gemm_split_ws_bytes((int64_t)rows, hidden, dt);
@@ -656,7 +656,7 @@ extern "C" int xml_attention_block(const void* x, const float* key_mask, const v
 //   x / y (rows, hidden): the valid tokens of n sequences back to back, sequence i = rows cu[i] .. cu[i+1]-1, every
 //   sequence 1 .. max_len <= 32 tokens long.  Same arithmetic per valid token as xml_attention_block on the padded batch:
 //   the projections and the LayerNorm are row-wise, and a padded key contributes exp(-10000 + s - max) = +0 to the softmax
-//   and 0 * v to P V, so dropping it changes nothing.   ws = [ qkv | att | pre-LN f32 or LN partials ] as above.
+//   and 0 * v to P V, so dropping it changes nothing.   ws = [ qkv | att | pre-LN f32 or the fused epilogue's scratch ] as above.
 // ---------------------------------------------------------------------------------------------------
 template <typename T, int DH>
 static int launch_attn_varlen(const char* qkv, int hidden, const int32_t* cu, void* att, int64_t n, int max_len,

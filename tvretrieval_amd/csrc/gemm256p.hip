@@ -24,36 +24,10 @@
 // A fifth ring slot for this kernel (the direct epilogue leaves LDS free; bias in registers): neutral as well -- unlike K6,
 // this K loop is not short of bytes in flight.
 // Same MFMA sequence per accumulator as gemm256_kernel: bitwise the same results.
-#include <atomic>
-#include <cstdlib>
-#include <cstring>
-#include <mutex>
 #include <type_traits>
 
 #include "common.h"
 #include "internal.h"
-
-// LayerNorm-epilogue exchange: per-row partials published and read with agent-scope accesses (on gfx950 the sc1 form of
-// the instruction: past the per-XCD L2, coherent across the 8 XCDs of the device)
-__device__ __forceinline__ void ln_publish(float* pp, float s, float m2) {
-  __hip_atomic_store(pp, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __hip_atomic_store(pp + 1, m2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-typedef float xml_ln_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ xml_ln_f4 ln_read4(const float* pp) {
-  xml_ln_f4 v;
-  v.x = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.y = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.z = __hip_atomic_load(pp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  v.w = __hip_atomic_load(pp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return v;
-}
-
-// DIAGNOSTIC count of row-block waits of the LayerNorm-epilogue kernel that gave up (see the exchange below); read and cleared
-// by xml_ln_fusion_status.  No kernel reads it: what makes the remaining waits of a launch give up at once is that LAUNCH's own
-// flag in its workspace (G256pArgs::ln_fail, zeroed per launch), so a count left behind by an earlier launch cannot touch a
-// later one.
-__device__ int g_ln_timeouts = 0;
 
 struct G256pArgs {
   const void* A;
@@ -64,9 +38,7 @@ struct G256pArgs {
   int64_t M, n_tiles;
   int N, K, relu, add_mode, seq_len, tn;
   // LayerNorm epilogue (LNE kernels): y = LN(act(A W^T + bias) + addend) * g + b over the full rows of N = tn * 256 columns
-  float* ln_part;       // (M, 2 tn, 2) f32: per row and per 128-column segment (sum, centred sum of squares)
-  int* ln_count;        // (ceil(M / 256)): column tiles of a row block that have published their partials (zeroed per launch)
-  int* ln_fail;         // 1 int behind ln_count, zeroed per launch: some wait of THIS launch gave up -> the others do not wait
+  float* ln_scratch;    // per workgroup (tn - 1) x 256 x 256 f32: the pre-LayerNorm values of a row block's first tn - 1 tiles
   const float* ln_g;
   const float* ln_b;
   float ln_eps;
@@ -133,15 +105,26 @@ __device__ __forceinline__ uint4 dpp_u4(const uint4& v) {
   r.w = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.w, CTRL, 0xf, 0xf, false);
   return r;
 }
+// lane id from the hardware, as a VOLATILE asm: neither hoisted out of the tile loop nor kept live across the K loop
+// (see lane_id_now in q2c_persist.hip: a spilled lane id returns through a scratch load and its s_waitcnt vmcnt(0))
+__device__ __forceinline__ int g256p_lane_now() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
 __device__ __forceinline__ int g256p_swz(int row) { return (0x78 >> (((row >> 2) & 3) << 1)) & 3; }
 
 // LNE: LayerNorm fused into the epilogue (K2 behind K1, BertSelfOutput; xml/model_components.py:76-89,313-317).  A row of
-// the output spans tn = N / 256 column tiles = tn workgroups.  Every workgroup (1) writes its part of the pre-LayerNorm
-// rows in the storage type and publishes, per row and 128-column segment, (sum, centred sum of squares) computed from
-// the f32 values; (2) signals a per-row-block counter and waits until the tn tiles of the block have signalled -- all
-// 256 workgroups are resident (one per CU) and walk the tiles in the same order, so the partners are at most a tile
-// apart; (3) combines the 2 tn partials of its rows in a fixed order (Chan's formula: deterministic, no E[x^2] - mean^2
-// cancellation) and normalises its own part in place.  No f32 round trip through HBM, no separate LayerNorm launch.
+// the output spans tn = N / 256 column tiles (tn <= 3).  ONE workgroup computes all tn tiles of a row block, back to back:
+//   tiles 0 .. tn - 2: the pre-LayerNorm values (f32) go to the workgroup's private scratch, lane for lane as they sit in
+//     the accumulators (1 KiB per store instruction), and per row and 128-column segment (sum, centred sum of squares) --
+//     computed from the f32 values -- go to LDS;
+//   tile tn - 1: its values stay in the accumulators; the 2 tn segment partials of every row are combined in a fixed order
+//     (Chan's formula: deterministic, no E[x^2] - mean^2 cancellation), the tile is normalised from the registers and the
+//     earlier tiles from the scratch (written by this CU a tile ago: L2 hits), all stored once in the output type.
+// Nothing leaves the workgroup: no counters, no waiting for other workgroups, no assumption about who is resident
+// (rounds 2-5 had the column tiles on tn workgroups that exchanged partials through memory and waited for each other).
+// The arithmetic is that exchange's, value for value: the results are bitwise unchanged.
 //
 // DIRECT epilogue (default): the MFMA operands are SWAPPED (first operand = W fragment, second = A fragment), so an
 // accumulator holds 4 consecutive output COLUMNS of ONE output row per lane (row = lane & 15, columns 4 (lane >> 4) + r)
@@ -152,6 +135,7 @@ __device__ __forceinline__ int g256p_swz(int row) { return (0x78 >> (((row >> 2)
 // order of the K summation per output element are unchanged: bitwise the same results.
 template <typename T, typename OutT, typename AddT, bool LNE = false, bool DIRECT = true>
 __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
+  static_assert(!LNE || DIRECT, "the LayerNorm epilogue works on the DIRECT accumulator layout");
   constexpr int ROWB = 64;
   constexpr int OPER_BYTES = 256 * ROWB;
   constexpr int SLOT_BYTES = 2 * OPER_BYTES;
@@ -176,22 +160,29 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 
   // tile walk: round k hands the 32 workgroups of XCD x the 32 consecutive tiles (8 k + x) * 32 .. + 31, N fastest:
   // the workgroups of an XCD share a few row tiles of A through its L2, W stays resident
-  // LNE: the tn column tiles of a row block must meet (row statistics), so they go to tn NEIGHBOURING workgroups of ONE
-  // XCD in the same round -- one L2 serves their exchange, no device-wide cache maintenance -- : an XCD takes 32 / tn row
-  // blocks per round (tn = 3: 10 blocks, 2 of its 32 workgroups idle).
-  const int lne_g = LNE ? __builtin_amdgcn_readfirstlane(32 / a.tn) : 0;
-  const int lne_rb = LNE ? __builtin_amdgcn_readfirstlane(loc / a.tn) : 0, lne_nt = LNE ? loc - lne_rb * a.tn : 0;
+  // LNE: the unit is a ROW BLOCK -- round r hands workgroup (x, loc) row block (8 r + x) * 32 + loc, whose tn tiles it runs
+  // consecutively (k = r * tn + nt): the A rows are fetched from HBM once and twice more from L2, the 32 workgroups of an
+  // XCD walk the same W tile at about the same time.
+  const int tn_s = __builtin_amdgcn_readfirstlane(a.tn);
+  const int64_t n_rb = a.n_tiles / tn_s;
+  auto lne_split = [&](int k, int& r, int& nt) {            // k -> (round, column tile); tn <= 3, k < 98 304
+    r = tn_s == 1 ? k : tn_s == 2 ? (k >> 1) : (int)(((uint32_t)k * 43691u) >> 17);
+    nt = k - r * tn_s;
+  };
   auto tile_of = [&](int k) -> int64_t {
     if constexpr (LNE) {
-      if (lne_rb >= lne_g) return a.n_tiles;
-      return (((int64_t)k * 8 + xcd) * lne_g + lne_rb) * a.tn + lne_nt;
+      int r, nt;
+      lne_split(k, r, nt);
+      const int64_t rb = ((int64_t)r * 8 + xcd) * 32 + loc;
+      return rb < n_rb ? rb * tn_s + nt : a.n_tiles;
     }
     return ((int64_t)k * 8 + xcd) * 32 + loc;
   };
   auto tile_mt_nt = [&](int k, int64_t& mt, int& nt) {      // (row block, column tile) of this workgroup's k-th tile
     if constexpr (LNE) {
-      mt = ((int64_t)k * 8 + xcd) * lne_g + lne_rb;         // scalar arithmetic on uniform ints: the DMA bases stay in SGPRs
-      nt = lne_nt;
+      int r;
+      lne_split(k, r, nt);
+      mt = ((int64_t)r * 8 + xcd) * 32 + loc;               // scalar arithmetic on uniform ints: the DMA bases stay in SGPRs
     } else {
       const int64_t lin = tile_of(k);
       mt = lin / a.tn;
@@ -210,8 +201,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
     tile_mt_nt(i_k, mt, nt);
     const int64_t m0 = mt * 256;
     const int n0 = nt * 256;
-    int lane_o = lane;                             // opaque copy: keeps the address arithmetic out of the MFMA loop
-    asm volatile("" : "+v"(lane_o));
+    const int lane_o = g256p_lane_now();           // re-derived here: nothing lane-dependent stays live across the MFMA loop
     const int rsub = lane_o >> 2, pslot = lane_o & 3;
     auto off_a = [&](int piece) -> uint32_t {
       const int row = piece * 16 + rsub;
@@ -367,9 +357,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       const int64_t m0 = mt * 256;
       const int n0 = nt * 256;
       const uint32_t m0_mod = a.add_mode == 1 ? (uint32_t)(m0 % a.seq_len) : 0u;     // one 64-bit modulo per tile
-      int lane_e = lane;
-      asm volatile("" : "+v"(lane_e));
+      const int lane_e = g256p_lane_now();
       const int fr_e = lane_e & 15, fg_e = lane_e >> 4;
+      const int tid_e = wave * 64 + lane_e;
       float* patch = reinterpret_cast<float*>(smem + RING_BYTES) + wave * 1024;
       // a lane owns two groups of 4 consecutive columns of a row.  bf16 out: adjacent groups -> one 16-byte store, 16
       // lanes = the row's 256 bytes.  f32 out: groups 64 columns apart -> two 16-byte stores, each again 16 lanes =
@@ -397,7 +387,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       // one line: the EVEN store of a pair writes rows fr & ~1 -- even lanes their own group 2 p, odd lanes group 2 p + 1
       // of the row BELOW them (DPP row_shr:1) --, the ODD store rows fr | 1 likewise (row_shl:1): 8 rows x one whole
       // line per instruction, 1024 requests per tile, no LDS.
-      auto store_rows = [&](int m4, auto& v) {        // (DIRECT only; v: float [NGRP][GC])
+      auto store_rows = [&](int m4, auto& v, int dcol = 0) {        // (DIRECT only; v: float [NGRP][GC]; dcol: another tile's columns)
         uint4 pk[NGRP];
 #pragma unroll
         for (int q = 0; q < NGRP; ++q) pk[q] = pack16<OutT>(v[q]);
@@ -411,7 +401,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
           const uint4 own_e = pk[2 * pq], own_o = pk[2 * pq + 1];
           const uint4 d_even = make_uint4(odd ? dn.x : own_e.x, odd ? dn.y : own_e.y, odd ? dn.z : own_e.z, odd ? dn.w : own_e.w);
           const uint4 d_odd = make_uint4(odd ? own_o.x : up.x, odd ? own_o.y : up.y, odd ? own_o.z : up.z, odd ? own_o.w : up.w);
-          const int col = pcol[pq];
+          const int col = pcol[pq] + dcol;
           if (col + GC <= N) {
             // non-temporal: this kernel only runs on outputs of >= 3072 tiles (400 MB and up), nothing of which survives
             // in a cache until its consumer starts; streaming stores retire ~2.5 % faster here (886 -> 906 TF at
@@ -512,21 +502,33 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
               for (int e = 0; e < GC; ++e) { const float c = v[q][e] - seg_mean; c2 += c * c; }
             c2 += __shfl_xor(c2, 16, 64);
             c2 += __shfl_xor(c2, 32, 64);
-            if (fg_e == 0 && rok) {
-              float* pp = a.ln_part + ((m * (2 * a.tn)) + nt * 2 + wn) * 2;
-              ln_publish(pp, s, c2);
+            // this wave's patch, floats 640 + (row of its 64, column tile) x 2: the segment (tile nt, half wn) of the row
+            if (fg_e == 0) {
+              float* ps = patch + 640 + ((m4 * 16 + fr_e) * tn_s + nt) * 2;
+              ps[0] = s;
+              ps[1] = c2;
             }
           }
           if constexpr (LNE) {
-            // the pre-LayerNorm values stay in the accumulators (f32) until the row statistics are complete: no store of the
-            // pre-LN rows, no re-read after the exchange, and the normalisation sees unrounded values
+            if (nt == tn_s - 1) {
+              // the last tile's pre-LayerNorm values stay in the accumulators (f32) until the row statistics are complete
 #pragma unroll
-            for (int q = 0; q < NGRP; ++q)
+              for (int q = 0; q < NGRP; ++q)
 #pragma unroll
-              for (int e = 0; e < GC; ++e) {
-                if constexpr (PAIRED) acc[m4][2 * q + (e >> 2)][e & 3] = v[q][e];
-                else acc[m4][q][e & 3] = v[q][e];
+                for (int e = 0; e < GC; ++e) {
+                  if constexpr (PAIRED) acc[m4][2 * q + (e >> 2)][e & 3] = v[q][e];
+                  else acc[m4][q][e & 3] = v[q][e];
+                }
+            } else {
+              // earlier tiles: f32 to the workgroup's scratch, lane for lane (every store instruction writes 1 KiB contiguous)
+              float4* sc = reinterpret_cast<float4*>(a.ln_scratch) + (int64_t)blockIdx.x * (tn_s - 1) * 16384 +
+                           (int64_t)((nt * 4 + m4) * 8) * 512 + tid_e;
+#pragma unroll
+              for (int j = 0; j < 8; ++j) {
+                const float* vf = &v[0][0] + j * 4;
+                sc[j * 512] = make_float4(vf[0], vf[1], vf[2], vf[3]);
               }
+            }
           } else {
             store_rows(m4, v);
           }
@@ -588,21 +590,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] += av[j];
           }
-          if constexpr (LNE) {      // (N % 256 == 0: every lane of the row holds 8 real columns)
-            float s8 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s8 += v[j];
-            const float seg_sum = lane16_sum_dpp(s8);                 // the 16 lanes of a row: this wave's 128 columns
-            const float seg_mean = seg_sum * (1.0f / 128.0f);
-            float q8 = 0.f;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) { const float c = v[j] - seg_mean; q8 += c * c; }
-            const float seg_m2 = lane16_sum_dpp(q8);
-            if ((lane_e & 15) == 0) {
-              float* pp = a.ln_part + ((m * (2 * a.tn)) + nt * 2 + wn) * 2;
-              ln_publish(pp, seg_sum, seg_m2);
-            }
-          }
           if (F32O) {
             if (ok0) st_global16(out + m * N + nc0, pack16<float>(v));
             if (ok1) st_global16(out + m * N + nc1, pack16<float>(v + 4));
@@ -616,163 +603,91 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
       }   // !DIRECT
       { const unsigned long long t = G256P_T(); pr[2] += t - pt; pt = t; }
       if constexpr (LNE) {
-        // ---- publish, wait for the row block's other column tiles, normalise in place -------------------------------
-        // The exchange does NOT depend on which XCD a partner runs on: the partials are published and read with
-        // agent-scope (device-coherent) accesses (ln_publish / ln_read4: they go past the per-XCD L2 to the memory side, a
-        // few hundred bytes per tile), the counter is an agent-scope atomic, and "my stores are acknowledged" (vmcnt(0))
-        // orders the two.  The tile walk above still puts partners on ONE XCD in the same round -- that is speed (they finish
-        // together), not correctness.  A device-scope FENCE here would write back and invalidate the whole L2 per tile --
-        // measured: it doubled the kernel's time; coherent accesses to the partials alone cost nothing measurable.
-        // The wait is bounded: if the partners cannot get onto the chip (CUs held by another process that is itself waiting,
-        // a CU mask smaller than the grid), the kernel traps after ~4 s instead of hanging the device or normalising with
-        // missing statistics -- the runtime reports the fault to the caller.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // wave 0's patch, float 640: a word nothing else uses between here and the end of the tile (0..127 statistics,
-        // 256..639 bias / gamma / beta)
-        volatile float* ln_fail_lds = reinterpret_cast<volatile float*>(smem + RING_BYTES) + 640;
-        if (tid == 0) {
-          __hip_atomic_fetch_add(a.ln_count + mt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();        // 100 MHz
-          float failed = 0.f;
-          while (__hip_atomic_load(a.ln_count + mt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < a.tn) {
-            __builtin_amdgcn_s_sleep(1);
-            // bounded wait, no trap (a trap is a sticky device fault: the process loses its context).  A wait that gives up
-            // marks THIS launch (ln_fail: every later wait of the launch gives up at once instead of 4 s each), bumps the
-            // diagnostic counter the host reads at its next synchronisation point (xml_ln_fusion_status), and the tile is
-            // written as NaN -- never as a LayerNorm over missing statistics: a caller that does not look at the counter
-            // sees NaN scores, not plausible wrong ones.
-            if (__hip_atomic_load(a.ln_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0 ||
-                __builtin_amdgcn_s_memrealtime() - t_start > 400000000ull) {
-              __hip_atomic_fetch_add(a.ln_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              __hip_atomic_fetch_add(&g_ln_timeouts, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-              failed = 1.f;
-              break;
-            }
-          }
-          *ln_fail_lds = failed;
-          __builtin_amdgcn_s_waitcnt(0xc07f);      // lgkmcnt(0): the word is in LDS before this wave reaches the barrier
-        }
-        __builtin_amdgcn_s_barrier();
-        const bool ln_failed = *ln_fail_lds != 0.f;
-        {   // lane l: statistics of row wm * 64 + l of the tile, combined from the 2 tn segment partials in fixed order
-          const int64_t m = m0 + wm * 64 + lane_e;
-          float mean = 0.f, rstd = 0.f;
-          if (m < M) {
-            // all partials of the row in one batch of 16-byte loads (tn <= 4: at most 16 floats), then the arithmetic --
-            // a load -> use loop would pay one memory round trip per iteration (hipcc waits vmcnt(0) at every use here)
+        if (nt == tn_s - 1) {
+          // ---- the row block is complete: statistics from the 2 tn segment partials, normalise, store -------------------
+          __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): my partials are in LDS
+          __builtin_amdgcn_s_barrier();                // ... and so are the partner wave's (the other 128-column half)
+          {   // lane l: statistics of row wm * 64 + l, combined in a fixed order (tile 0 left, tile 0 right, tile 1 left, ...)
+            const float* p0 = reinterpret_cast<const float*>(smem + RING_BYTES) + (wm * 2) * 1024 + 640 + lane_e * tn_s * 2;
+            const float* p1 = p0 + 1024;
             typedef float xml_f4 __attribute__((ext_vector_type(4)));
-            const float* pp = a.ln_part + m * (2 * a.tn) * 2;
-            xml_f4 pv[4];
+            xml_f4 pv[3];
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) pv[t4] = t4 < a.tn ? ln_read4(pp + 4 * t4) : xml_f4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < 3; ++t)
+              pv[t] = t < tn_s ? xml_f4{p0[t * 2], p0[t * 2 + 1], p1[t * 2], p1[t * 2 + 1]} : xml_f4{0.f, 0.f, 0.f, 0.f};
             float tot = 0.f;
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) tot += pv[t4].x + pv[t4].z;
-            mean = tot / (float)N;
+            for (int t = 0; t < 3; ++t) tot += pv[t].x + pv[t].z;
+            tot += 0.f + 0.f;                          // (the fourth tile of the former four-tile form: the same additions)
+            const float mean = tot / (float)N;
             float m2 = 0.f;
 #pragma unroll
-            for (int t4 = 0; t4 < 4; ++t4) {
-              if (t4 < a.tn) {
-                const float d0 = pv[t4].x * (1.0f / 128.0f) - mean, d1 = pv[t4].z * (1.0f / 128.0f) - mean;
-                m2 += pv[t4].y + 128.0f * d0 * d0 + pv[t4].w + 128.0f * d1 * d1;
+            for (int t = 0; t < 3; ++t) {
+              if (t < tn_s) {
+                const float d0 = pv[t].x * (1.0f / 128.0f) - mean, d1 = pv[t].z * (1.0f / 128.0f) - mean;
+                m2 += pv[t].y + 128.0f * d0 * d0 + pv[t].w + 128.0f * d1 * d1;
               }
             }
-            rstd = 1.0f / sqrtf(m2 / (float)N + a.ln_eps);
-            if (ln_failed) mean = rstd = __builtin_nanf("");
+            const float rstd = 1.0f / sqrtf(m2 / (float)N + a.ln_eps);
+            patch[lane_e * 2] = mean;
+            patch[lane_e * 2 + 1] = rstd;
           }
-          patch[lane_e * 2] = mean;
-          patch[lane_e * 2 + 1] = rstd;
-        }
-        { const unsigned long long t = G256P_T(); pr[3] += t - pt; pt = t; }
-        if constexpr (DIRECT) {
-          // gamma / beta of this wave's 128 columns -> its LDS patch (floats 384..511 / 512..639), read per row block like the
-          // bias (held in registers they would be 64 VGPRs next to the 128 live accumulators)
-          {
-            const int bc = n0 + wn * 128 + (lane_e & 31) * 4;
-            float4 g4 = make_float4(0.f, 0.f, 0.f, 0.f), b4 = g4;
-            if (bc + 4 <= N) {
-              g4 = *reinterpret_cast<const float4*>(a.ln_g + bc);
-              b4 = *reinterpret_cast<const float4*>(a.ln_b + bc);
+          { const unsigned long long t = G256P_T(); pr[3] += t - pt; pt = t; }
+          // tiles tn - 1 (from the accumulators), then tn - 2 .. 0 (from the scratch); gamma / beta of the tile's columns go
+          // through the wave's LDS patch (floats 384..511 / 512..639): in registers they would be 64 VGPRs next to the 128
+          // live accumulators
+          for (int t = tn_s - 1; t >= 0; --t) {
+            __builtin_amdgcn_wave_barrier();
+            {
+              const int bc = t * 256 + wn * 128 + (lane_e & 31) * 4;
+              const float4 g4 = *reinterpret_cast<const float4*>(a.ln_g + bc);
+              const float4 b4 = *reinterpret_cast<const float4*>(a.ln_b + bc);
+              if (lane_e < 32) {
+                *reinterpret_cast<float4*>(patch + 384 + lane_e * 4) = g4;
+                *reinterpret_cast<float4*>(patch + 512 + lane_e * 4) = b4;
+              }
             }
-            if (lane_e < 32) {
-              *reinterpret_cast<float4*>(patch + 384 + lane_e * 4) = g4;
-              *reinterpret_cast<float4*>(patch + 512 + lane_e * 4) = b4;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const float4* sc = reinterpret_cast<const float4*>(a.ln_scratch) + (int64_t)blockIdx.x * (tn_s - 1) * 16384 +
+                               (int64_t)(t * 32) * 512 + tid_e;
+#pragma unroll
+            for (int m4 = 0; m4 < 4; ++m4) {
+              const int lr64 = m4 * 16 + fr_e;
+              const float mean = patch[lr64 * 2], rstd = patch[lr64 * 2 + 1];
+              int boff = fg_e * GC;
+              asm volatile("" : "+v"(boff));
+              float x[NGRP * GC];
+              if (t == tn_s - 1) {
+#pragma unroll
+                for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+                  for (int e = 0; e < GC; ++e)
+                    x[q * GC + e] = PAIRED ? acc[m4][2 * q + (e >> 2)][e & 3] : acc[m4][q][e & 3];
+              } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                  const float4 f = sc[(m4 * 8 + j) * 512];
+                  x[j * 4] = f.x; x[j * 4 + 1] = f.y; x[j * 4 + 2] = f.z; x[j * 4 + 3] = f.w;
+                }
+              }
+              float v[NGRP][GC];
+#pragma unroll
+              for (int q = 0; q < NGRP; ++q)
+#pragma unroll
+                for (int e = 0; e < GC; e += 4) {
+                  const float4 g4 = *reinterpret_cast<const float4*>(patch + 384 + q * (4 * GC) + boff + e);
+                  const float4 b4 = *reinterpret_cast<const float4*>(patch + 512 + q * (4 * GC) + boff + e);
+                  const float gq[4] = {g4.x, g4.y, g4.z, g4.w}, bq[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                  for (int j = 0; j < 4; ++j) v[q][e + j] = (x[q * GC + e + j] - mean) * rstd * gq[j] + bq[j];
+                }
+              store_rows(m4, v, (t - nt) * 256);
             }
           }
           __builtin_amdgcn_s_waitcnt(0xc07f);
           __builtin_amdgcn_wave_barrier();
-          // the pre-LayerNorm values are still in the accumulators (f32): normalise and store, once
-#pragma unroll
-          for (int m4 = 0; m4 < 4; ++m4) {
-            const int lr64 = m4 * 16 + fr_e;
-            const float mean = patch[lr64 * 2], rstd = patch[lr64 * 2 + 1];
-            int boff = fg_e * GC;
-            asm volatile("" : "+v"(boff));
-            float v[NGRP][GC];
-#pragma unroll
-            for (int q = 0; q < NGRP; ++q)
-#pragma unroll
-              for (int e = 0; e < GC; e += 4) {
-                const float4 g4 = *reinterpret_cast<const float4*>(patch + 384 + q * (4 * GC) + boff + e);
-                const float4 b4 = *reinterpret_cast<const float4*>(patch + 512 + q * (4 * GC) + boff + e);
-                const float gq[4] = {g4.x, g4.y, g4.z, g4.w}, bq[4] = {b4.x, b4.y, b4.z, b4.w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                  const float x = PAIRED ? acc[m4][2 * q + ((e + j) >> 2)][(e + j) & 3] : acc[m4][q][(e + j) & 3];
-                  v[q][e + j] = (x - mean) * rstd * gq[j] + bq[j];
-                }
-              }
-            store_rows(m4, v);
-          }
-        } else {
-        float gv[8], bb[8];
-        {
-          const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + nc0), g1 = *reinterpret_cast<const float4*>(a.ln_g + nc1);
-          const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + nc0), b1 = *reinterpret_cast<const float4*>(a.ln_b + nc1);
-          gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
-          bb[0] = b0.x; bb[1] = b0.y; bb[2] = b0.z; bb[3] = b0.w; bb[4] = b1.x; bb[5] = b1.y; bb[6] = b1.z; bb[7] = b1.w;
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // the same (row, column group) walk as above: a lane re-reads exactly what it wrote.  ALL loads of the tile first
-        // (the accumulators are dead: 64 / 128 registers are free), one wait, then arithmetic and stores
-        constexpr int NLD = F32O ? 2 : 1;
-        uint4 rb[16][NLD];
-#pragma unroll
-        for (int pi = 0; pi < 16; ++pi) {
-          const int lr64 = (pi >> 1) * 8 + (pi & 1) * 4 + orow;
-          const int64_t m = m0 + wm * 64 + lr64;
-          const int64_t ms = m < M ? m : m0;              // (rows beyond M: any valid row, the result is not stored)
-          rb[pi][0] = ld_global16(out + ms * N + nc0);
-          if (F32O) rb[pi][NLD - 1] = ld_global16(out + ms * N + nc1);
-        }
-#pragma unroll
-        for (int pi = 0; pi < 16; ++pi) {
-          const int lr64 = (pi >> 1) * 8 + (pi & 1) * 4 + orow;
-          const int64_t m = m0 + wm * 64 + lr64;
-          const float mean = patch[lr64 * 2], rstd = patch[lr64 * 2 + 1];
-          float v[8];
-          if (F32O) {
-            unpack16<float>(rb[pi][0], v);
-            unpack16<float>(rb[pi][NLD - 1], v + 4);
-          } else {
-            unpack16<OutT>(rb[pi][0], v);
-          }
-#pragma unroll
-          for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * rstd * gv[j] + bb[j];
-          if (m < M) {
-            if (F32O) {
-              st_global16(out + m * N + nc0, pack16<float>(v));
-              st_global16(out + m * N + nc1, pack16<float>(v + 4));
-            } else {
-              st_global16(out + m * N + nc0, pack16<bf16_t>(v));
-            }
-          }
-        }
-        }   // !DIRECT
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
       }
     }
     { const unsigned long long t = G256P_T(); pr[4] += t - pt; pt = t; }
@@ -795,13 +710,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
   __builtin_amdgcn_s_barrier();
 }
 
-__global__ void g256p_zero_kernel(int* p, int n) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < n) p[i] = 0;
-}
-
-static bool ln_coop_wanted();
-
 template <typename T, typename OutT, typename AddT, bool LNE = false, bool DIRECT = true>
 static int launch_gemm256p(const void* A, const void* W, const float* bias, const void* addend, void* out, int64_t M,
                            int N, int K, int relu, int add_mode, int seq_len, hipStream_t st, const float* ln_g = nullptr,
@@ -811,140 +719,44 @@ static int launch_gemm256p(const void* A, const void* W, const float* bias, cons
   a.M = M; a.N = N; a.K = K; a.relu = relu; a.add_mode = add_mode; a.seq_len = seq_len;
   a.tn = cdiv(N, 256);
   a.n_tiles = (int64_t)cdiv(M, 256) * a.tn;
-  a.ln_part = nullptr; a.ln_count = nullptr; a.ln_fail = nullptr; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
+  a.ln_scratch = (float*)ln_ws; a.ln_g = ln_g; a.ln_b = ln_b; a.ln_eps = 1e-5f;
   a.probe = g_q2c_ablation == 9 ? 1 : g_q2c_ablation == 21 ? 2 : g_q2c_ablation == 22 ? 4 : g_q2c_ablation == 23 ? 6 : g_q2c_ablation == 24 ? 8 : 0;
-  if (LNE) {
-    const int n_blocks = (int)cdiv(M, 256);
-    a.ln_count = (int*)ln_ws;
-    a.ln_fail = a.ln_count + n_blocks;
-    a.ln_part = (float*)((char*)ln_ws + align_up((size_t)(n_blocks + 1) * 4, 256));
-    hipLaunchKernelGGL(g256p_zero_kernel, dim3(cdiv(n_blocks + 1, 256)), dim3(256), 0, st, a.ln_count, n_blocks + 1);
-  }
   const int lds = 4 * 2 * 256 * 64 + 8 * 4096;          // ring + patches = 160 KiB
 #ifdef XML_DEBUG_VARIANTS
-  if (DIRECT && g_gemm_variant == 3)      // A/B: the LDS-staged epilogue
-    return launch_gemm256p<T, OutT, AddT, LNE, false>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st, ln_g, ln_b,
-                                                      ln_ws);
+  if (!LNE && DIRECT && g_gemm_variant == 3)      // A/B: the LDS-staged epilogue
+    return launch_gemm256p<T, OutT, AddT, false, false>(A, W, bias, addend, out, M, N, K, relu, add_mode, seq_len, st);
 #endif
   auto kern = gemm256p_kernel<T, OutT, AddT, LNE, DIRECT>;
   if (!xml_lds_attr_once<gemm256p_kernel<T, OutT, AddT, LNE, DIRECT>>(lds)) return XML_ERR_LAUNCH;
-  if (LNE) {
-    // The workgroups of a row block wait for each other, so all 256 must get onto the chip.  With one workgroup per CU
-    // (160 KiB of LDS) and a grid of 256 they do as soon as the CUs are free -- kernels of OTHER kinds that still hold CUs
-    // only delay them.  Two kernels of THIS kind running at once could each hold part of the chip and wait for partners
-    // that cannot start: launches on different streams are therefore chained through an event (per device).
-    // (hipLaunchCooperativeKernel would give the same guarantee, but rocprofiler-sdk 7.2 crashes at process exit after
-    // a traced cooperative launch -- `rocprofv3 --kernel-trace -- python bench.py` ended with SIGSEGV, outputs written.)
-    static std::mutex mu;
-    static hipEvent_t last_ev[16] = {};
-    static hipStream_t last_st[16] = {};
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return XML_ERR_LAUNCH;
-    std::lock_guard<std::mutex> lock(mu);
-    if (!last_ev[dev] && hipEventCreateWithFlags(&last_ev[dev], hipEventDisableTiming) != hipSuccess) return XML_ERR_LAUNCH;
-    else if (last_st[dev] != st && hipStreamWaitEvent(st, last_ev[dev], 0) != hipSuccess) return XML_ERR_LAUNCH;
-    // Cooperative launch (the runtime refuses a grid that cannot be co-resident instead of letting it wait): the default
-    // outside profiler runs and stream captures; XML_LN_COOP=0 / 1 forces it off / on.  A refused launch returns an error
-    // here and the caller takes the three-launch path.
-    bool coop = ln_coop_wanted();
-    if (coop) {
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) coop = false;
-      (void)hipGetLastError();
-    }
-    if (coop) {
-      void* kargs[] = {(void*)&a};
-      if (hipLaunchCooperativeKernel((const void*)kern, dim3(256), dim3(512), kargs, (unsigned)lds, st) != hipSuccess) {
-        (void)hipGetLastError();
-        return XML_ERR_LAUNCH;
-      }
-    } else {
-      hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
-    }
-    const bool ok = hipGetLastError() == hipSuccess && hipEventRecord(last_ev[dev], st) == hipSuccess;
-    last_st[dev] = st;
-    return ok ? XML_OK : XML_ERR_LAUNCH;
-  }
   hipLaunchKernelGGL(kern, dim3(256), dim3(512), lds, st, a);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }
 
 // ---- GEMM with the LayerNorm in its epilogue --------------------------------------------------------------------
-// Eligible when the rows span whole 256-column tiles (N % 256 == 0, at most 4 of them) and there is enough work for the
-// persistent kernel; the callers fall back to GEMM (f32 out) + LayerNorm otherwise.
-// The fused kernel's workgroups wait for each other: it runs only where all 256 of them fit at once -- a device with at
-// least 256 CUs visible to this process (MI355X unpartitioned; a CPX / partitioned device or a CU mask reports fewer and
-// takes the three-launch path).
-static std::atomic<int> g_ln_fusion_off{0};     // set by xml_ln_fusion_status after a timed-out exchange, or XML_LN_FUSION=0
-
-static bool ln_coop_wanted() {
-  static const int mode = [] {
-    // OPT-IN (XML_LN_COOP=1).  Measured in round 4: after ONE cooperative launch in a process, every later kernel of that
-    // process's neighbours on the GPU -- and graph replays of the process itself -- ran 1.5-3x slower for the rest of the
-    // run (bench.py's extras child next to its idle parent: K6 94.9 instead of 37.7 ms, training step 16.3 instead of
-    // 5.05 ms; the queue a cooperative launch goes through stays gang-scheduled).  And rocprofiler-sdk 7.2 crashes at
-    // process exit after a traced cooperative launch (round 2).  The default is therefore the plain launch + the bounded,
-    // COUNTED wait (xml_ln_fusion_status).
-    const char* e = getenv("XML_LN_COOP");
-    return (e && *e && atoi(e)) ? 1 : 0;
-  }();
-  if (!mode) return false;
-  int dev = 0, ok = 0;
-  return hipGetDevice(&dev) == hipSuccess &&
-         hipDeviceGetAttribute(&ok, hipDeviceAttributeCooperativeLaunch, dev) == hipSuccess && ok != 0;
-}
-
-// How many row-block exchanges of the LayerNorm-epilogue GEMM gave up since the last call (their tiles were written as NaN).
-// Synchronises the device.  disable != 0: a non-zero count also switches the fused path off for this process -- every later
-// projection takes GEMM + LayerNorm launches, which wait for nothing.  Returns the count, or a negative xml_status.
-extern "C" int xml_ln_fusion_status(int disable) {
-  XML_ENTER();
-  int n = 0;
-  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(g_ln_timeouts), sizeof(int)) != hipSuccess) return XML_ERR_LAUNCH;
-  if (n != 0) {
-    const int zero = 0;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_ln_timeouts), &zero, sizeof(int)) != hipSuccess) return XML_ERR_LAUNCH;
-    if (disable) g_ln_fusion_off.store(1);
-  }
-  return n;
-}
-extern "C" int xml_ln_fusion_enabled(void) {
-  static const int env_off = [] { const char* e = getenv("XML_LN_FUSION"); return (e && *e && !atoi(e)) ? 1 : 0; }();
-  return (env_off || g_ln_fusion_off.load()) ? 0 : 1;
-}
-
-static bool ln_fusion_device_ok() {
-  if (!xml_ln_fusion_enabled()) return false;
-  static std::atomic<int> cached[64];                  // 0 unknown, 1 ok, 2 not ok  (per device)
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
-  int c = cached[dev].load(std::memory_order_relaxed);
-  if (c == 0) {
-    int cus = 0;
-    const bool ok = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus >= 256;
-    c = ok ? 1 : 2;
-    cached[dev].store(c, std::memory_order_relaxed);
-  }
-  return c == 1;
-}
+// Taken for a SHAPE CLASS, never for a batch size above some tile count: rows that span 1-3 whole 256-column tiles
+// (N = 256 / 512 / 768), K a whole number of 128-byte steps, and at least LN_FUSED_MIN_ROWS rows.  Whether a projection
+// runs fused therefore does not depend on how many videos a context batch holds (any batch of >= 16 videos of 128 clips
+// qualifies): the encoder's bits are the same for context batches of 2 048, 200 or 37 videos
+// (tests/test_gpu_model.py::test_index_bits_do_not_depend_on_the_context_batch).  Below the row threshold (a 50-query batch's
+// 1 500 tokens) the callers run GEMM (f32 out) + LayerNorm: small tiles fill the chip there, six row blocks would not.
+// The fused kernel waits for nothing outside its workgroup, so it has no residency requirement and no failure path.
+static constexpr int64_t LN_FUSED_MIN_ROWS = 2048;
 
 bool xmli_gemm_ln_eligible(int64_t M, int N, int K, int dt) {
   if (dt != XML_F32 && dt != XML_BF16) return false;      // (split-f16 projections take the three-launch path)
   const size_t kb = (size_t)K * dt_size(dt);
-  if (!ln_fusion_device_ok()) return false;
-  // N = 256 (the reference's as-trained hidden size, xml/config.py:143): a row is ONE tile, the statistics never leave the
-  // workgroup, nothing waits for a partner -- worth it from one tile per workgroup on (the query encoder of TVR val: 745
-  // tiles; it saves the f32 round trip and the LayerNorm launch behind each of its three projections)
-  const int64_t tiles = (int64_t)cdiv(M, 256) * (N / 256);
-  return kb % 128 == 0 && kb >= 256 && N % 256 == 0 && N / 256 <= 4 && tiles >= (N == 256 ? 256 : 768);
+  return kb % 128 == 0 && kb >= 256 && N % 256 == 0 && N / 256 <= 3 && M >= LN_FUSED_MIN_ROWS;
 }
+// scratch of the fused kernel: per workgroup the f32 values of a row block's first tn - 1 tiles
 size_t xmli_gemm_ln_workspace_bytes(int64_t M, int N) {
-  return align_up((size_t)(cdiv(M, 256) + 1) * 4, 256) + align_up((size_t)M * 2 * (N / 256 + 1) * 2 * 4, 256);
+  (void)M;
+  return align_up((size_t)256 * (size_t)(N / 256 > 1 ? N / 256 - 1 : 0) * 256 * 256 * 4 + 256, 256);
 }
 int xmli_gemm_ln(const void* A, const void* W, const float* bias, const void* addend, const float* ln_g, const float* ln_b,
                  void* y, int64_t M, int N, int K, int relu, int add_mode, int seq_len, int dt, void* ln_ws,
                  hipStream_t st) {
+  if (!ln_ws) return XML_ERR_WORKSPACE;
   if (dt == XML_F32)
     return launch_gemm256p<float, float, float, true>(A, W, bias, addend, y, M, N, K, relu, add_mode, seq_len, st, ln_g,
                                                       ln_b, ln_ws);

@@ -514,7 +514,7 @@ extern "C" int xml_linear_f16s(const float* x, const void* w, const float* b, fl
 // ---------------------------------------------------------------------------------------------------
 static inline int k_pad8(int d_in) { return (d_in + 7) & ~7; }
 // (the second part holds either the f32 pre-LayerNorm rows of the 3-launch path or, when the GEMM takes the LayerNorm in
-// its epilogue, that kernel's per-row partial statistics -- the larger of the two is reserved)
+// its epilogue, that kernel's per-workgroup scratch -- the larger of the two is reserved)
 extern "C" size_t xml_linear_ln_relu_pos_workspace_bytes(int64_t rows, int d_in, int hidden, int dt) {
   const size_t pre = align_up((size_t)rows * hidden * 4, 256);
   const size_t lnw = xmli_gemm_ln_eligible(rows, hidden, k_pad8(d_in), dt) ? xmli_gemm_ln_workspace_bytes(rows, hidden) : 0;

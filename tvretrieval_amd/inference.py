@@ -191,32 +191,7 @@ class IndexStorage(object):
         return sum(t.numel() * t.element_size() for d in (self.f1, self.f2, self.mk, self.tiles) for t in d.values())
 
 
-class EncodeInvalid(RuntimeError):
-    pass
-
-
 def build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, video_offset=0, n_total=None,
-                       l_ref=None, n_videos=None, exact_filter=False, storage=None):
-    """_build_corpus_index + the health check of the LayerNorm-epilogue projections (include/xmlhip.h
-    xml_ln_fusion_status): their workgroups wait for each other, a wait that gave up (CUs held by another process) is counted
-    on the device, the count is read here -- where the host waits for the encode anyway -- and a non-zero count switches the
-    fused path off and redoes the encode (a list / tuple of batches is simply encoded again; a one-shot iterator cannot be,
-    so EncodeInvalid is raised and the caller calls again)."""
-    retry = isinstance(context_batches, (list, tuple))
-    idx = _build_corpus_index(model, context_batches, ops, keep_raw, video_offset, n_total, l_ref, n_videos, exact_filter,
-                              storage)
-    if hasattr(ops, "ln_fusion_status") and ops.ln_fusion_status(disable=True) > 0:
-        import warnings
-        warnings.warn("a LayerNorm-epilogue projection timed out waiting for its partner workgroups (GPU shared with another "
-                      "process?): fused path switched off for this process, corpus encode repeated")
-        if not retry:
-            raise EncodeInvalid("corpus encode invalid (timed-out LayerNorm exchange); the fused path is now off -- encode again")
-        idx = _build_corpus_index(model, context_batches, ops, keep_raw, video_offset, n_total, l_ref, n_videos, exact_filter,
-                                  None)
-    return idx
-
-
-def _build_corpus_index(model, context_batches, ops=hip_ops, keep_raw=False, video_offset=0, n_total=None,
                         l_ref=None, n_videos=None, exact_filter=False, storage=None):
     """Encode context batches and assemble the resident index.
 
@@ -1052,8 +1027,6 @@ class _ResultSink(object):
         from .results import MOMENT_DTYPE, MomentResults
         n = self.n
         rec = self.rec[:n].cpu().numpy().view(MOMENT_DTYPE)[..., 0]
-        if hasattr(hip_ops, "check_ln_fusion"):     # the query encoder's fused projections: see ops.check_ln_fusion
-            hip_ops.check_ln_fusion("compute_query2ctx_info")
         return MomentResults.from_records(desc_ids[:n], descs[:n], rec, self.cnt[:n].cpu().numpy(), scale=scale,
                                           int_spans=int_spans)
 

@@ -166,23 +166,6 @@ def linear_ln_relu_pos(x, ln_in_g, ln_in_b, w, b, pos, ln_pos_g, ln_pos_b):
     return y
 
 
-def ln_fusion_status(disable=True):
-    """Exchanges of the LayerNorm-epilogue GEMM that gave up since the last call (device sync).  > 0: results of the encode
-    that ran since then are invalid; with disable=True the fused path is off from now on -- redo the encode."""
-    return int(check_count(_lib.load().xml_ln_fusion_status(int(bool(disable))), "xml_ln_fusion_status"))
-
-
-def check_ln_fusion(what):
-    """Call where the host has just waited for the device anyway (a D2H of results): raises if a LayerNorm-epilogue
-    projection gave up waiting for its partner workgroups since the last check -- the rows it produced are NaN, the fused
-    path is switched off for the process, and the caller repeats the work (which then takes plain GEMM + LayerNorm
-    launches).  One 4-byte read, ~20 us."""
-    n = ln_fusion_status(disable=True)
-    if n > 0:
-        raise _lib.XmlHipError("%s: %d LayerNorm-epilogue exchange(s) timed out (GPU shared with another process?); the "
-                               "affected rows are NaN and the fused path is now off for this process -- run it again" % (what, n))
-
-
 def check_count(v, what):
     if v < 0:
         check(v, what)

@@ -729,6 +729,33 @@ def test_moment_topk_flat_distribution_fallback(ops):
         assert len(set(fl[q].tolist())) == n_out
 
 
+@pytest.mark.parametrize("nq,k", [(50, 100), (100, 100), (7, 33), (64, 16)])
+def test_moment_topk_small_batches_split_over_workgroups_bitwise(ops, nq, k):
+    """Batches too small to fill the chip (the reference's eval_query_bsz = 50) run K9 as 2-4 workgroups per query + a merge of
+    their part lists (xml_moment_topk_ws): the lists of the SAME rows inside a 200-query batch (one workgroup per query), bit
+    for bit -- peaky and near-flat distributions, skipped pairs (w = 0), ragged valid lengths."""
+    l, n_out = 128, 200
+    g = torch.Generator().manual_seed(300 + nq + k)
+    lens = torch.randint(5, l + 1, (37,), generator=g).int()
+    pv = torch.randint(0, 37, (200, k), generator=g).int()
+    mask = (torch.arange(l)[None, None] < lens[pv.long()][..., None]).float()
+    temp = torch.where(torch.arange(200) % 2 == 0, 3.0, 0.05)[:, None, None]
+    st = torch.softmax(O.mask_logits(torch.randn(200, k, l, generator=g) * temp, mask), -1) * mask
+    ed = torch.softmax(O.mask_logits(torch.randn(200, k, l, generator=g) * temp, mask), -1) * mask
+    w, _ = torch.sort(torch.exp(20 * (torch.rand(200, k, generator=g) * 0.3)), dim=1, descending=True)
+    w[:, 2::5] = 0.0
+    big = ops.moment_topk(dev(st), dev(ed), dev(w), l, 2, 16, n_out, pair_vid=dev(pv), vid_len=dev(lens))
+    assert _lib_groups(ops, 200, k, n_out) == 0 and _lib_groups(ops, nq, k, n_out) > 0
+    small = ops.moment_topk(dev(st[:nq].contiguous()), dev(ed[:nq].contiguous()), dev(w[:nq].contiguous()), l, 2, 16, n_out,
+                            pair_vid=dev(pv[:nq].contiguous()), vid_len=dev(lens))
+    assert torch.equal(small[0], big[0][:nq]) and torch.equal(small[1], big[1][:nq])
+    assert int((small[1] >= 0).sum()) > nq * 50
+
+
+def _lib_groups(ops, nq, k, n_out):
+    return int(ops._lib.load().xml_moment_topk_workspace_bytes(nq, k, n_out))
+
+
 @pytest.mark.parametrize("n,lq", [(1, 30), (3, 5), (1025, 64), (4097, 17), (10000, 30)])
 def test_pack_plan_shapes(ops, n, lq):
     """xml_pack_plan (packing plan of a padded token batch): cu_seqlens / source rows for batches smaller and larger than

@@ -116,10 +116,19 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
                                                           int l_ref, int min_l, int max_l, int n_out,
                                                           const float* __restrict__ summ,
                                                           const int32_t* __restrict__ pair_vid,
-                                                          const int32_t* __restrict__ vid_len, int dbg) {
+                                                          const int32_t* __restrict__ vid_len, int dbg, int per_group) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
+  // Few queries (a 50-query batch on a 256-CU chip): gridDim.y workgroups share a query, group g takes the pairs
+  // [g per_group, (g + 1) per_group) and writes ITS exact top n_out to row (q, g) of a scratch list; moment_merge_kernel then
+  // takes the top n_out of the gridDim.y lists -- the top n of a union is the top n of the parts' top n, under the same total
+  // order (score desc, flat asc).  gridDim.y == 1: the whole query, written to the output directly.
+  const int kp_all = kpairs;
+  const int r_base = (int)blockIdx.y * per_group;
+  kpairs = min(per_group, kp_all - r_base);
+  const uint32_t flat_base = (uint32_t)r_base * (uint32_t)l_ref * (uint32_t)l_ref;
+  const int64_t out_row = (int64_t)q * gridDim.y + blockIdx.y;
   unsigned long long* s_list = reinterpret_cast<unsigned long long*>(smem);                 // [MT_CAP]
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_list + MT_CAP);                          // [2048]
   __shared__ MomentShared sh;
@@ -129,15 +138,15 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   if (tid < 4 * MT_PPW) {
     int n = l_ref;
     if (vid_len && tid < kpairs) {
-      const int pv = pair_vid[(int64_t)q * kpairs + tid];
+      const int pv = pair_vid[(int64_t)q * kp_all + r_base + tid];
       n = pv >= 0 ? max(0, min(vid_len[pv], l_ref)) : 0;
     }
     s_len[tid] = n;
   }
 
-  const float* gst = st + (int64_t)q * kpairs * lpad;
-  const float* ged = ed + (int64_t)q * kpairs * lpad;
-  const float* gw = w ? w + (int64_t)q * kpairs : nullptr;
+  const float* gst = st + ((int64_t)q * kp_all + r_base) * lpad;
+  const float* ged = ed + ((int64_t)q * kp_all + r_base) * lpad;
+  const float* gw = w ? w + (int64_t)q * kp_all + r_base : nullptr;
 
   // ---- 1 + 2. row maxima, in registers ---------------------------------------------------------------------------
   // Wave w owns pairs w, w + 4, ...; lane l owns start clips l and l + 64 of a pair: a = st * w for its two clips and the
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     // (1 GB at the TVR shape).  Every value is the best candidate of a DISTINCT row, so the lower edge of the bin that holds
     // the n_out-th largest of them is still a valid lower bound of the n_out-th best score -- a weaker one than the bound
     // from all rows when one pair owns more than 8 of the best rows, which costs list refinements below, never exactness.
-    const float* gs = summ + (int64_t)q * kpairs * XML_MOMENT_SUMM;
+    const float* gs = summ + ((int64_t)q * kp_all + r_base) * XML_MOMENT_SUMM;
     for (int i = tid; i < kpairs * XML_MOMENT_SUMM; i += 256) {
       const int r = i / XML_MOMENT_SUMM;
       const bool on = gw ? gw[r] != 0.f : true;            // skipped pairs (weight 0) have no summary
@@ -313,7 +322,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
           if (j < s_len[r]) {
             key = __float_as_uint(__uint_as_float((uint32_t)(e >> 32)) * ged[r * lpad + j]);
             take = key >= lb;
-            flat = (uint32_t)(ri * l_ref + j);
+            flat = flat_base + (uint32_t)(ri * l_ref + j);
           }
         }
         const unsigned long long bal = __ballot(take);
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
             const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             if (take && slot < (uint32_t)MT_CAP)
               s_list[slot] = ((unsigned long long)key << 32) |
-                             (unsigned long long)(0xffffffffu - (uint32_t)((r * l_ref + i) * l_ref + j));
+                             (unsigned long long)(0xffffffffu - (flat_base + (uint32_t)((r * l_ref + i) * l_ref + j)));
           }
         }
       }
@@ -418,8 +427,47 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
         flat = (int32_t)(0xffffffffu - (uint32_t)(c & 0xffffffffull));
       }
     }
-    out_score[(int64_t)q * n_out + i] = sc;
-    out_flat[(int64_t)q * n_out + i] = flat;
+    out_score[out_row * n_out + i] = sc;
+    out_flat[out_row * n_out + i] = flat;
+  }
+}
+
+// The top n_out of a query's G part lists (moment_topk_kernel with gridDim.y = G), same order: score desc, flat asc; empty
+// entries (flat < 0) last.  One workgroup per query; G * n_out <= 2048 keys through an LDS bitonic sort.
+__global__ __launch_bounds__(256) void moment_merge_kernel(const float* __restrict__ part_score,
+                                                           const int32_t* __restrict__ part_flat, float* __restrict__ out_score,
+                                                           int32_t* __restrict__ out_flat, int groups, int n_out) {
+  __shared__ unsigned long long s_list[2048];
+  const int tid = threadIdx.x, q = blockIdx.x;
+  const int total = groups * n_out;
+  int npow = 256;
+  while (npow < total) npow <<= 1;
+  for (int i = tid; i < npow; i += 256) {
+    unsigned long long key = 0ull;
+    if (i < total) {
+      const float sc = part_score[(int64_t)q * total + i];
+      const int32_t fl = part_flat[(int64_t)q * total + i];
+      if (fl >= 0) key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)fl);
+    }
+    s_list[i] = key;
+  }
+  __syncthreads();
+  for (int size = 2; size <= npow; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int i = tid; i < (npow >> 1); i += 256) {
+        const int lo = ((i / stride) * stride << 1) + (i % stride);
+        const int hi = lo + stride;
+        const unsigned long long a = s_list[lo], b = s_list[hi];
+        const bool desc = (lo & size) == 0;
+        if (desc ? (a < b) : (a > b)) { s_list[lo] = b; s_list[hi] = a; }
+      }
+      __syncthreads();
+    }
+  }
+  for (int i = tid; i < n_out; i += 256) {
+    const unsigned long long c = i < npow ? s_list[i] : 0ull;
+    out_score[(int64_t)q * n_out + i] = c ? __uint_as_float((uint32_t)(c >> 32)) : 0.f;
+    out_flat[(int64_t)q * n_out + i] = c ? (int32_t)(0xffffffffu - (uint32_t)(c & 0xffffffffull)) : -1;
   }
 }
 
@@ -430,9 +478,31 @@ extern "C" int xml_moment_topk(const float* st, const float* ed, const float* w,
                             n_out, stream);
 }
 
+// Workgroups per query: one, unless the batch is too small to fill the chip (a 50-query batch: 50 workgroups on 256 CUs,
+// K9 was the longest kernel of the batch) -- then up to four, each on a quarter of the pairs, + the merge.
+static int moment_groups(int nq, int kpairs, int n_out) {
+  if (nq > 128 || kpairs < 16) return 1;
+  int g = nq <= 64 ? 4 : 2;
+  while (g > 1 && (kpairs < 8 * g || g * n_out > 2048)) g >>= 1;
+  return g;
+}
+extern "C" size_t xml_moment_topk_workspace_bytes(int nq, int kpairs, int n_out) {
+  if (nq <= 0 || kpairs <= 0 || n_out <= 0) return 0;
+  const int g = moment_groups(nq, kpairs, n_out);
+  return g > 1 ? (size_t)nq * g * n_out * 8 : 0;
+}
+
 extern "C" int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ,
                                   const int32_t* pair_vid, const int32_t* vid_len, float* out_score, int32_t* out_flat, int nq,
                                   int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out, xml_stream_t stream) {
+  return xml_moment_topk_ws(st, ed, w, summ, pair_vid, vid_len, out_score, out_flat, nq, kpairs, lpad, l_ref, min_l, max_l,
+                            n_out, nullptr, 0, stream);
+}
+
+extern "C" int xml_moment_topk_ws(const float* st, const float* ed, const float* w, const float* summ,
+                                  const int32_t* pair_vid, const int32_t* vid_len, float* out_score, int32_t* out_flat, int nq,
+                                  int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out, void* ws, size_t ws_bytes,
+                                  xml_stream_t stream) {
   XML_ENTER();
   if (!st || !ed || !out_score || !out_flat || nq <= 0 || kpairs <= 0 || lpad <= 0 || l_ref <= 0 || n_out <= 0)
     return XML_ERR_BAD_ARG;
@@ -440,8 +510,23 @@ extern "C" int xml_moment_topk_ex(const float* st, const float* ed, const float*
   if (l_ref > lpad || min_l < 0 || max_l <= min_l) return XML_ERR_BAD_ARG;
   if (n_out > 1024 || lpad > 128 || kpairs > 4 * MT_PPW) return XML_ERR_UNSUPPORTED;   // (st, ed: probabilities, >= 0)
   const size_t lds = (size_t)MT_CAP * 8 + 2048 * 4;
+  // the part lists need the caller's scratch (xml_moment_topk_workspace_bytes); without it: one workgroup per query
+  int groups = moment_groups(nq, kpairs, n_out);
+  if (groups > 1 && (!ws || ws_bytes < xml_moment_topk_workspace_bytes(nq, kpairs, n_out))) groups = 1;
+  if (groups > 1) {
+    float* ps = (float*)ws;
+    int32_t* pf = (int32_t*)(ps + (size_t)nq * groups * n_out);
+    const int per = (kpairs + groups - 1) / groups;
+    hipLaunchKernelGGL(moment_topk_kernel, dim3(nq, groups), dim3(256), lds, (hipStream_t)stream, st, ed, w, ps, pf, kpairs, lpad,
+                       l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len, (int)g_q2c_ablation, per);
+    XML_CHECK_LAUNCH();
+    hipLaunchKernelGGL(moment_merge_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, ps, pf, out_score, out_flat, groups,
+                       n_out);
+    XML_CHECK_LAUNCH();
+    return XML_OK;
+  }
   hipLaunchKernelGGL(moment_topk_kernel, dim3(nq), dim3(256), lds, (hipStream_t)stream, st, ed, w, out_score, out_flat,
-                     kpairs, lpad, l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len, (int)g_q2c_ablation);
+                     kpairs, lpad, l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len, (int)g_q2c_ablation, kpairs);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

@@ -162,3 +162,34 @@ def test_evaluator_array_path_matches_reference(name):
     got = evaluate.eval_retrieval(sub, case["ground_truth"], iou_thds=(0.5, 0.7), verbose=False, match_number=True,
                                   use_desc_type=case["use_desc_type"])
     assert json.loads(json.dumps(got)) == case["metrics"]
+
+
+def test_ground_truth_cache_is_keyed_on_every_desc_id():
+    """match_number=False with two prediction sets of the same size and the same first / last desc_id but different middle
+    ids: the second call must not be served the first call's ground-truth arrays."""
+    from tvretrieval_amd import evaluate
+    gt = [dict(desc_id=i, vid_name="v%d" % i, ts=[1.0, 5.0], type="v") for i in range(5)]
+    v2i = {"v%d" % i: i for i in range(5)}
+
+    def preds(ids):          # every listed query predicts ITS OWN video at the right span: R@1 = 100 for any subset
+        return [dict(desc_id=i, desc="", predictions=[[i, 1.0, 5.0, 1.0]]) for i in ids]
+    kw = dict(iou_thds=(0.5,), recall_topks=(1,), task_type="VCMR", match_number=False, verbose=False, use_desc_type=False)
+    a = evaluate.eval_by_task_type(preds([0, 1, 2, 4]), v2i, gt, **kw)
+    b = evaluate.eval_by_task_type(preds([0, 1, 3, 4]), v2i, gt, **kw)
+    a, b = (x[0] if isinstance(x, tuple) else x for x in (a, b))
+    assert a == b and all(v == 100.0 for v in a.values()), (a, b)
+
+
+def test_span_predictor_module_keeps_its_gradient():
+    """{merged,video,sub}_{st,ed}_predictor are nn.Conv1d parameters in the reference (xml/model_xml.py:97-130): called
+    directly in a training graph they must carry gradient to the taps and to the input."""
+    import torch
+    from tvretrieval_amd.model_xml import _SpanConv
+    m = _SpanConv(1, 1, 5, stride=1, padding=2, bias=False)
+    ref = torch.nn.Conv1d(1, 1, 5, stride=1, padding=2, bias=False)
+    ref.load_state_dict(m.state_dict())
+    x = torch.randn(7, 1, 19, requires_grad=True)
+    x2 = x.detach().clone().requires_grad_(True)
+    m(x).square().sum().backward()
+    ref(x2).square().sum().backward()
+    assert torch.allclose(m.weight.grad, ref.weight.grad) and torch.allclose(x.grad, x2.grad)

@@ -28,10 +28,9 @@ _GT_CACHE = {}
 def _ground_truth_arrays(ground_truth, keys, gt_by_id, video2idx, use_desc_type):
     """(gt video idx f32, description type, gt spans (n, n_ts, 2) f32, spans per query) for `keys`.  The three tasks of one
     eval_retrieval call -- and the calls before / after NMS -- share one ground truth: built once per (list, key set)."""
-    ck = (id(ground_truth), len(ground_truth), id(video2idx), bool(use_desc_type), len(keys), keys[0] if keys else None,
-          keys[-1] if keys else None)
+    ck = (id(ground_truth), len(ground_truth), id(video2idx), bool(use_desc_type), tuple(keys))
     hit = _GT_CACHE.get(ck)
-    if hit is not None and hit[0] is ground_truth:
+    if hit is not None and hit[0] is ground_truth:      # (the whole key tuple is in ck: a different middle key misses)
         return hit[1]
     n_desc = len(keys)
     gt_vid = np.zeros(n_desc, dtype=np.float32)

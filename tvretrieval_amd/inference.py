@@ -52,15 +52,18 @@ class CorpusIndex(object):
 
     def set_valid_lengths(self):
         """Per-video valid length from the masks (one small device pass + one host read at build time)."""
-        pos = None
+        pos, empty = None, None
         for m in self.modalities:
             mk = self.mask[m]
             if not isinstance(mk, torch.Tensor):
                 return self
             last = ((mk != 0).to(torch.int32) * torch.arange(1, mk.shape[1] + 1, device=mk.device, dtype=torch.int32)).amax(1)
             pos = last if pos is None else torch.maximum(pos, last)
-        pos = torch.where(pos == 0, torch.full_like(pos, self.l_ref), pos)     # no valid clip at all: the masked softmax is
-        self.vlen = pos.clamp_max(self.l_ref).to(torch.int32).contiguous()     # uniform, not zero -> nothing is skipped
+            empty = (last == 0) if empty is None else (empty | (last == 0))
+        # a modality without a valid clip: its masked softmax is uniform over all L positions (mask_logits adds the same
+        # -1e10 everywhere), not zero -> the (video + sub) / 2 stream has mass past the other modality's length: skip nothing
+        pos = torch.where(empty, torch.full_like(pos, self.l_ref), pos)
+        self.vlen = pos.clamp_max(self.l_ref).to(torch.int32).contiguous()
         self.ragged = bool((self.vlen < self.l_ref).any().item())
         return self
 

@@ -235,6 +235,9 @@ class _SpanConv(nn.Conv1d):
 
     def forward(self, x):
         assert x.dim() == 3 and x.shape[1] == 1, "span predictor input is (N, 1, L)"
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            # the kernel below has no backward: a training graph through this module would silently lose the gradient
+            return torch.nn.functional.conv1d(x, self.weight, None, self.stride, self.padding)
         return ops.conv1d_rows(x.float().contiguous(), self.weight.detach().float().reshape(-1).contiguous())
 
 

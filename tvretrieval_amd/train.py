@@ -752,8 +752,8 @@ class GraphedTrainStep(object):
         if self._stage_ev[i] is not None:
             self._stage_ev[i].synchronize()        # the copy that last read this pinned buffer (four calls ago) is done
         h, hn = self._stage[i], self._stage_np[i]
-        hn[:n] = neg_ctx_rank.numpy() if torch.is_tensor(neg_ctx_rank) else np.asarray(neg_ctx_rank)
-        hn[n:2 * n] = neg_q_rank.numpy() if torch.is_tensor(neg_q_rank) else np.asarray(neg_q_rank)
+        hn[:n] = neg_ctx_rank.detach().cpu().numpy() if torch.is_tensor(neg_ctx_rank) else np.asarray(neg_ctx_rank)
+        hn[n:2 * n] = neg_q_rank.detach().cpu().numpy() if torch.is_tensor(neg_q_rank) else np.asarray(neg_q_rank)
         if lr_mults is None:
             self._host_in[:2 * n].copy_(h[:2 * n], non_blocking=True)
         else:

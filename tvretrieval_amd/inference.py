@@ -52,18 +52,20 @@ class CorpusIndex(object):
 
     def set_valid_lengths(self):
         """Per-video valid length from the masks (one small device pass + one host read at build time)."""
-        pos, empty = None, None
+        pos = None
         for m in self.modalities:
             mk = self.mask[m]
             if not isinstance(mk, torch.Tensor):
                 return self
             last = ((mk != 0).to(torch.int32) * torch.arange(1, mk.shape[1] + 1, device=mk.device, dtype=torch.int32)).amax(1)
             pos = last if pos is None else torch.maximum(pos, last)
-            empty = (last == 0) if empty is None else (empty | (last == 0))
-        # a modality without a valid clip: its masked softmax is uniform over all L positions (mask_logits adds the same
-        # -1e10 everywhere), not zero -> the (video + sub) / 2 stream has mass past the other modality's length: skip nothing
-        pos = torch.where(empty, torch.full_like(pos, self.l_ref), pos)
-        self.vlen = pos.clamp_max(self.l_ref).to(torch.int32).contiguous()
+        # The maximum over modalities is exact, also when one modality of a video has no valid clip: the reference averages
+        # the masked LOGITS of the two streams, (video + sub) / 2 with -1e10 at masked positions, and takes the softmax
+        # afterwards (xml/model_xml.py:436-453, xml/inference.py:365-370) -- a position masked in one stream sits at -5e9, in
+        # both at -1e10, and exp() of either against a valid position is exactly 0
+        # (tests/test_gpu_model.py::test_video_with_one_empty_modality_matches_the_reference_lists).
+        pos = torch.where(pos == 0, torch.full_like(pos, self.l_ref), pos)     # no valid clip at all: the masked softmax is
+        self.vlen = pos.clamp_max(self.l_ref).to(torch.int32).contiguous()     # uniform, not zero -> nothing is skipped
         self.ragged = bool((self.vlen < self.l_ref).any().item())
         return self
 

@@ -416,19 +416,12 @@ int xml_moment_topk(const float* st, const float* ed, const float* w, float* out
  * threshold comes from these instead of a pass over the rows; pairs of weight 0 are ignored.  Same lists, bit for bit.
  * pair_vid (nq, kpairs) int32 + vid_len (n_videos) int32 (both or neither): ragged corpora -- the entries l >= vid_len[v] of
  * the st / ed rows of a pair with video v are taken as 0 WITHOUT being read (xml_convse_rerank_ex with the same vid_len left
- * them unwritten), pairs with pair_vid < 0 as empty.  Same lists, bit for bit. */
+ * them unwritten), pairs with pair_vid < 0 as empty.  Same lists, bit for bit.
+ * Batches too small to fill the chip with one 256-thread workgroup per query (nq <= 128: the reference's eval_query_bsz = 50)
+ * run 1024-thread workgroups -- the same algorithm over sixteen waves, the same lists, bit for bit. */
 int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ, const int32_t* pair_vid,
                        const int32_t* vid_len, float* out_score, int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref,
                        int min_l, int max_l, int n_out, xml_stream_t stream);
-/* xml_moment_topk_ex with scratch: batches too small to fill the chip with one workgroup per query (nq <= 128: the
- * reference's eval_query_bsz = 50) run 2-4 workgroups per query, each on a share of the pairs, and a merge of their exact
- * part lists -- the same lists, bit for bit (top n of a union = top n of the parts' top n, one total order).
- * ws: xml_moment_topk_workspace_bytes(nq, kpairs, n_out) bytes (0: no scratch needed); NULL / too small: one workgroup. */
-size_t xml_moment_topk_workspace_bytes(int nq, int kpairs, int n_out);
-int xml_moment_topk_ws(const float* st, const float* ed, const float* w, const float* summ, const int32_t* pair_vid,
-                       const int32_t* vid_len, float* out_score, int32_t* out_flat, int nq, int kpairs, int lpad, int l_ref,
-                       int min_l, int max_l, int n_out, void* ws, size_t ws_bytes, xml_stream_t stream);
-
 /* The span predictor as a module of its own: nn.Conv1d(1, 1, ksize, padding = ksize / 2, bias = False) on rows of
  * similarities (self.merged_st_predictor(similarity), xml/model_xml.py:476-477; profile_main.py:204-205 calls it directly).
  *   x, y (rows, l) f32; w (ksize) f32; y[r][i] = sum_t w[t] x[r][i + t - ksize / 2], zero beyond the row.  ksize odd <= 15.

@@ -93,9 +93,6 @@ SIGNATURES = {
                                      c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "xml_moment_topk_ex": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
                                    c_int, c_int, c_int, c_int, c_int, c_void_p]),
-    "xml_moment_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "xml_moment_topk_ws": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int,
-                                   c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
     "xml_convse_rerank_f16s": (c_int, [ctypes.POINTER(ConvseDesc), c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                        c_void_p, c_size_t, c_void_p]),

@@ -16,10 +16,13 @@
 //        T_a = n_out-th largest row maximum            (tight for peaky start/end distributions)
 //        T_b = n_out-th largest candidate of the first pair(s) (tight for flat distributions, where the answer is
 //              the best-ranked videos' bands and row maxima barely prune)
-//   4. expand rows with m(r,i) >= lb = max(T_a, T_b); candidates >= lb go to an LDS list (wave-aggregated append).
+//   4. expand rows with m(r,i) >= lb; candidates >= lb go to an LDS list (wave-aggregated append).
 //      If the list overflows, lb is raised to the n_out-th largest of the stored entries (a subset, hence still a
-//      valid lower bound) and the expansion repeats; exact ties that never fit end in a deterministic truncation.
-//   5. bitonic sort of the list on (score desc, flat index asc); emit n_out.
+//      valid lower bound) and the expansion repeats; if that separates nothing, to the exact n_out-th largest candidate
+//      (radix select over all band candidates); if more candidates than the list holds TIE with it: those above first,
+//      then as many ties as fit.
+//   5. the list in (score desc, flat index asc) order -- each entry ranked against the list (<= 3 entries per thread),
+//      bitonic sort for longer lists -- emit n_out.
 // Zero products (masked clips, skipped pairs) are not candidates: the reference's order among zeros is unspecified.
 // This is LDS/latency-bound integer-ish work; it is not reshaped into a GEMM.
 #include "band.h"
@@ -68,7 +71,7 @@ __device__ uint32_t block_radix_select(Each each, uint32_t need, uint32_t* hist 
   for (int pass = 0; pass < 3; ++pass) {
     const int shift = shifts[pass];
     const uint32_t bins = 1u << widths[pass];
-    for (int i = tid; i < 2048; i += 256) hist[i] = 0;
+    for (int i = tid; i < 2048; i += (int)blockDim.x) hist[i] = 0;
     __syncthreads();
     const uint32_t prefix = sh->prefix;
     if (sh->flag) break;                                   // not enough keys: T = 0
@@ -110,25 +113,24 @@ __device__ uint32_t block_radix_select(Each each, uint32_t need, uint32_t* hist 
   return T;
 }
 
-__global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restrict__ st, const float* __restrict__ ed,
-                                                          const float* __restrict__ w, float* __restrict__ out_score,
-                                                          int32_t* __restrict__ out_flat, int kpairs, int lpad,
-                                                          int l_ref, int min_l, int max_l, int n_out,
-                                                          const float* __restrict__ summ,
-                                                          const int32_t* __restrict__ pair_vid,
-                                                          const int32_t* __restrict__ vid_len, int dbg, int per_group) {
+// NT threads per workgroup, NW = NT / 64 waves.  NT = 256: the throughput shape (thousands of queries, four workgroups per CU).
+// NT = 1024: few queries (a 50-query batch on a 256-CU chip: K9 was the longest kernel of the batch) -- the workgroup's time
+// is then the LATENCY of its phases, and sixteen waves walk a query's pairs in two rounds of loads instead of seven, expand the
+// live rows in three steps instead of twelve.  (Several workgroups per query on shares of the pairs + a merge of their exact
+// part lists was built twice and is slower than one workgroup: each part needs ITS OWN n_out-th bound, which prunes far less
+// than the query's, and the merge is one more sort -- 50.8 + 13.7 us and 46.8 + 29.3 us against 63.4 us.)
+template <int NT>
+__global__ __launch_bounds__(NT) void moment_topk_kernel(const float* __restrict__ st, const float* __restrict__ ed,
+                                                         const float* __restrict__ w, float* __restrict__ out_score,
+                                                         int32_t* __restrict__ out_flat, int kpairs, int lpad,
+                                                         int l_ref, int min_l, int max_l, int n_out,
+                                                         const float* __restrict__ summ,
+                                                         const int32_t* __restrict__ pair_vid,
+                                                         const int32_t* __restrict__ vid_len, int dbg) {
+  constexpr int NW = NT / 64;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int q = blockIdx.x;
-  // Few queries (a 50-query batch on a 256-CU chip): gridDim.y workgroups share a query, group g takes the pairs
-  // [g per_group, (g + 1) per_group) and writes ITS exact top n_out to row (q, g) of a scratch list; moment_merge_kernel then
-  // takes the top n_out of the gridDim.y lists -- the top n of a union is the top n of the parts' top n, under the same total
-  // order (score desc, flat asc).  gridDim.y == 1: the whole query, written to the output directly.
-  const int kp_all = kpairs;
-  const int r_base = (int)blockIdx.y * per_group;
-  kpairs = min(per_group, kp_all - r_base);
-  const uint32_t flat_base = (uint32_t)r_base * (uint32_t)l_ref * (uint32_t)l_ref;
-  const int64_t out_row = (int64_t)q * gridDim.y + blockIdx.y;
   unsigned long long* s_list = reinterpret_cast<unsigned long long*>(smem);                 // [MT_CAP]
   uint32_t* s_hist = reinterpret_cast<uint32_t*>(s_list + MT_CAP);                          // [2048]
   __shared__ MomentShared sh;
@@ -138,18 +140,18 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   if (tid < 4 * MT_PPW) {
     int n = l_ref;
     if (vid_len && tid < kpairs) {
-      const int pv = pair_vid[(int64_t)q * kp_all + r_base + tid];
+      const int pv = pair_vid[(int64_t)q * kpairs + tid];
       n = pv >= 0 ? max(0, min(vid_len[pv], l_ref)) : 0;
     }
     s_len[tid] = n;
   }
 
-  const float* gst = st + ((int64_t)q * kp_all + r_base) * lpad;
-  const float* ged = ed + ((int64_t)q * kp_all + r_base) * lpad;
-  const float* gw = w ? w + (int64_t)q * kp_all + r_base : nullptr;
+  const float* gst = st + (int64_t)q * kpairs * lpad;
+  const float* ged = ed + (int64_t)q * kpairs * lpad;
+  const float* gw = w ? w + (int64_t)q * kpairs : nullptr;
 
   // ---- 1 + 2. row maxima, in registers ---------------------------------------------------------------------------
-  // Wave w owns pairs w, w + 4, ...; lane l owns start clips l and l + 64 of a pair: a = st * w for its two clips and the
+  // Wave w owns pairs w, w + NW, ...; lane l owns start clips l and l + 64 of a pair: a = st * w for its two clips and the
   // pair's end probabilities e (lane l: clips l, l + 64) live in registers.  With a, e >= 0 the row maximum
   // max_d (a * e[i + d]) equals a * max_d e[i + d] exactly (rounding is monotone), and the sliding-window maximum of e
   // over [i + min_l, i + max_l) is 3-5 wave shuffles (doubling window widths, one overlapping step, the min_l offset)
@@ -160,8 +162,8 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   const float w_hi = gw ? (lane + 64 < kpairs ? gw[lane + 64] : 0.f) : 1.f;  // broadcast later with a lane read
   auto pair_w = [&](int r) -> float { return __shfl(r < 64 ? w_lo : w_hi, r & 63, 64); };
   const int band = max_l - min_l;
-  const int n_t = (kpairs - wave + 3) >> 2;                // pairs of this wave: r = wave + 4 t
-  for (int i = tid; i < 2048; i += 256) s_hist[i] = 0;
+  const int n_t = wave < kpairs ? (kpairs - wave + NW - 1) / NW : 0;      // pairs of this wave: r = wave + NW t
+  for (int i = tid; i < 2048; i += NT) s_hist[i] = 0;
   if (tid == 0) { sh.prefix = 0; sh.flag = 0; }
   __syncthreads();
 
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
       float raw[4][4], wv4[4];
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int r = wave + (t0 + g) * 4;
+        const int r = wave + (t0 + g) * NW;
         wv4[g] = (t0 + g < n_t) ? pair_w(r) : 0.f;
         if (wv4[g] != 0.f) pair_load(r, raw[g]);
         else raw[g][0] = raw[g][1] = raw[g][2] = raw[g][3] = 0.f;
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
         if (wv4[g] == 0.f) continue;                       // w == 0: skipped pair (other rank / padding)
         float a2[2], m2[2];
         pair_eval(raw[g], wv4[g], a2[0], a2[1], m2[0], m2[1]);
-        body(wave + (t0 + g) * 4, a2, m2);
+        body(wave + (t0 + g) * NW, a2, m2);
       }
     }
   };
@@ -220,8 +222,8 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     // (1 GB at the TVR shape).  Every value is the best candidate of a DISTINCT row, so the lower edge of the bin that holds
     // the n_out-th largest of them is still a valid lower bound of the n_out-th best score -- a weaker one than the bound
     // from all rows when one pair owns more than 8 of the best rows, which costs list refinements below, never exactness.
-    const float* gs = summ + ((int64_t)q * kp_all + r_base) * XML_MOMENT_SUMM;
-    for (int i = tid; i < kpairs * XML_MOMENT_SUMM; i += 256) {
+    const float* gs = summ + (int64_t)q * kpairs * XML_MOMENT_SUMM;
+    for (int i = tid; i < kpairs * XML_MOMENT_SUMM; i += NT) {
       const int r = i / XML_MOMENT_SUMM;
       const bool on = gw ? gw[r] != 0.f : true;            // skipped pairs (weight 0) have no summary
       const uint32_t key = on ? __float_as_uint(gs[i]) : 0u;
@@ -278,8 +280,14 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
   // row maxima in LDS (25 KB more: three workgroups per CU instead of four) to skip that walk made the kernel 0.65 -> 0.97 ms.)
   uint32_t cnt = 0;
   [[maybe_unused]] uint32_t dbg_attempts = 0, dbg_rows0 = 0;
-  for (int attempt = 0; attempt < 8; ++attempt) {
-    if (tid == 0) { sh.cnt = 0; sh.need = 0; }
+  int mode = 0;              // 0: candidates >= lb;  1: candidates > lb;  2: candidates == lb, appended behind those of mode 1
+  bool exact_done = false;
+  auto takes = [&](uint32_t key) -> bool { return mode == 0 ? key >= lb : (mode == 1 ? key > lb : key == lb); };
+  for (int attempt = 0; attempt < 12; ++attempt) {
+    if (tid == 0) {
+      if (mode != 2) sh.cnt = 0;
+      sh.need = 0;
+    }
     __syncthreads();
     // 4a. rows whose maximum reaches lb -> compact list (row id, st*w) in the histogram area (free between step 3
     //     and the overflow refinement).  Expanding rows in place costs ~14 ballot/atomic iterations per 64-row block
@@ -309,8 +317,8 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     if (n_rows <= 1024u) {
       // 4b. one (row, offset) item per lane: every lane of every wave has work
       const int total = (int)n_rows * band;
-      const int total_r = (total + 255) & ~255;
-      for (int idx = tid; idx < total_r; idx += 256) {
+      const int total_r = (total + NT - 1) & ~(NT - 1);
+      for (int idx = tid; idx < total_r; idx += NT) {
         bool take = false;
         uint32_t key = 0, flat = 0;
         if (idx < total) {
@@ -321,8 +329,8 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
           const int j = i + min_l + d;
           if (j < s_len[r]) {
             key = __float_as_uint(__uint_as_float((uint32_t)(e >> 32)) * ged[r * lpad + j]);
-            take = key >= lb;
-            flat = flat_base + (uint32_t)(ri * l_ref + j);
+            take = takes(key);
+            flat = (uint32_t)(ri * l_ref + j);
           }
         }
         const unsigned long long bal = __ballot(take);
@@ -340,7 +348,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
       // more than 1024 live rows (n_out close to the number of rows): expand in place
 #pragma unroll 2
     for (int t = 0; t < n_t; ++t) {
-      const int r = wave + t * 4;
+      const int r = wave + t * NW;
       const float wv = pair_w(r);
       if (wv == 0.f) continue;
       float a2[2], m2[2];
@@ -356,7 +364,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
           const int j = i + d;
           const bool ok = row_on && j < jend;
           const uint32_t key = ok ? __float_as_uint(a * ged[r * lpad + j]) : 0u;
-          const bool take = ok && key >= lb;
+          const bool take = ok && takes(key);
           const unsigned long long bal = __ballot(take);
           if (bal) {
             uint32_t base = 0;
@@ -366,7 +374,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
             const uint32_t slot = base + (uint32_t)__popcll(bal & ((1ull << lane) - 1ull));
             if (take && slot < (uint32_t)MT_CAP)
               s_list[slot] = ((unsigned long long)key << 32) |
-                             (unsigned long long)(0xffffffffu - (flat_base + (uint32_t)((r * l_ref + i) * l_ref + j)));
+                             (unsigned long long)(0xffffffffu - (uint32_t)((r * l_ref + i) * l_ref + j));
           }
         }
       }
@@ -375,18 +383,47 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
     __syncthreads();
     cnt = sh.cnt;
     __syncthreads();
-    if (cnt <= (uint32_t)MT_CAP) break;
+    if (mode == 1) { mode = 2; continue; }     // everything above the tie value is in (fewer than n_out entries): now the ties
+    if (mode == 2 || cnt <= (uint32_t)MT_CAP) break;
     // overflow: the n_out-th largest of the MT_CAP stored entries is a tighter valid lower bound
     const uint32_t t_c = block_radix_select(
         [&](auto f) {
-          for (int i = tid; i < MT_CAP; i += 256) f((uint32_t)(s_list[i] >> 32), true);
+          for (int i = tid; i < MT_CAP; i += NT) f((uint32_t)(s_list[i] >> 32), true);
         },
         (uint32_t)n_out, s_hist, &sh);
-    if (t_c <= lb) {          // no progress: more than MT_CAP entries tie at the bound -> keep the stored ones
-      cnt = MT_CAP;
-      break;
+    if (t_c > lb) { lb = t_c; continue; }
+    // No progress.  WHICH candidates were stored is a race between the waves (sixteen of them: the best pair's entries can be
+    // a sixteenth of the list), so the stored subset need not separate anything.  The exact n_out-th largest candidate, by a
+    // radix select over ALL band candidates >= lb (three more walks over the pairs: degenerate inputs only -- flat
+    // probabilities with one boosted pair, tests/test_gpu_kernels.py::test_moment_topk_flat_distribution_fallback):
+    if (!exact_done) {
+      exact_done = true;
+      const uint32_t lb0 = lb;
+      const uint32_t t_x = block_radix_select(
+          [&](auto f) {
+            for (int t = 0; t < n_t; ++t) {
+              const int r = wave + t * NW;
+              const float wv = pair_w(r);
+              float a2[2] = {0.f, 0.f}, m2[2];
+              if (wv != 0.f) pair_rows(r, wv, a2[0], a2[1], m2[0], m2[1]);
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const int i = lane + h * 64;
+                for (int d = min_l; d < max_l; ++d) {
+                  const int j = i + d;
+                  const bool ok = wv != 0.f && i < l_ref && j < s_len[r];
+                  const uint32_t key = ok ? __float_as_uint(a2[h] * ged[r * lpad + j]) : 0u;
+                  f(key, ok && key >= lb0);
+                }
+              }
+            }
+          },
+          (uint32_t)n_out, s_hist, &sh);
+      if (t_x > lb) { lb = t_x; continue; }
     }
-    lb = t_c;
+    // lb IS the n_out-th best score and more than MT_CAP candidates reach it: fewer than n_out lie above it -- those first,
+    // then as many of the exact ties as the list holds (the reference's order among equal scores is unspecified)
+    mode = 1;
   }
   cnt = min(cnt, (uint32_t)MT_CAP);
 #ifdef XML_DEBUG_VARIANTS
@@ -400,14 +437,44 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
 #endif
   if (dbg == 62) return;
 
-  // ---- 5. bitonic sort (descending) of the list, padded with zeros to a power of two ------------------------
+  // ---- 5. order the list on (score desc, flat asc) and emit n_out ---------------------------------------------------
+  // The keys are distinct (the flat index is part of them), so the position of an entry is the number of entries above it.
+  // Up to three entries per thread (the usual list: 250-340 entries for 200 results) are RANKED against the whole list --
+  // every lane reads the same LDS word, a broadcast -- and stored at their rank: ~cnt short iterations and no barrier,
+  // where a bitonic network over the next power of two is 45-66 barrier-separated stages.  Same order, same output.
+  if (cnt <= 3u * NT) {
+    unsigned long long key[3];
+    uint32_t rank[3] = {0u, 0u, 0u};
+#pragma unroll
+    for (int e = 0; e < 3; ++e) key[e] = (uint32_t)(tid + e * NT) < cnt ? s_list[tid + e * NT] : ~0ull;
+    const int n = (int)cnt;
+#pragma unroll 4
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long v = s_list[j];
+#pragma unroll
+      for (int e = 0; e < 3; ++e) rank[e] += v > key[e] ? 1u : 0u;
+    }
+#pragma unroll
+    for (int e = 0; e < 3; ++e) {
+      if ((uint32_t)(tid + e * NT) < cnt && rank[e] < (uint32_t)n_out) {
+        out_score[(int64_t)q * n_out + rank[e]] = __uint_as_float((uint32_t)(key[e] >> 32));
+        out_flat[(int64_t)q * n_out + rank[e]] = (int32_t)(0xffffffffu - (uint32_t)(key[e] & 0xffffffffull));
+      }
+    }
+    for (int i = (int)cnt + tid; i < n_out; i += NT) {        // fewer candidates than results: (0, -1) rows
+      out_score[(int64_t)q * n_out + i] = 0.f;
+      out_flat[(int64_t)q * n_out + i] = -1;
+    }
+    return;
+  }
+  // longer lists (n_out close to the number of positive candidates, exact ties at the bound): bitonic sort, padded with zeros
   int npow = 256;
   while ((uint32_t)npow < cnt) npow <<= 1;
-  for (int i = (int)cnt + tid; i < npow; i += 256) s_list[i] = 0ull;
+  for (int i = (int)cnt + tid; i < npow; i += NT) s_list[i] = 0ull;
   __syncthreads();
   for (int size = 2; size <= npow; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = tid; i < (npow >> 1); i += 256) {
+      for (int i = tid; i < (npow >> 1); i += NT) {
         const int lo = ((i / stride) * stride << 1) + (i % stride);
         const int hi = lo + stride;
         const unsigned long long a = s_list[lo], b = s_list[hi];
@@ -417,7 +484,7 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
       __syncthreads();
     }
   }
-  for (int i = tid; i < n_out; i += 256) {
+  for (int i = tid; i < n_out; i += NT) {
     float sc = 0.f;
     int32_t flat = -1;
     if (i < npow) {
@@ -427,47 +494,8 @@ __global__ __launch_bounds__(256) void moment_topk_kernel(const float* __restric
         flat = (int32_t)(0xffffffffu - (uint32_t)(c & 0xffffffffull));
       }
     }
-    out_score[out_row * n_out + i] = sc;
-    out_flat[out_row * n_out + i] = flat;
-  }
-}
-
-// The top n_out of a query's G part lists (moment_topk_kernel with gridDim.y = G), same order: score desc, flat asc; empty
-// entries (flat < 0) last.  One workgroup per query; G * n_out <= 2048 keys through an LDS bitonic sort.
-__global__ __launch_bounds__(256) void moment_merge_kernel(const float* __restrict__ part_score,
-                                                           const int32_t* __restrict__ part_flat, float* __restrict__ out_score,
-                                                           int32_t* __restrict__ out_flat, int groups, int n_out) {
-  __shared__ unsigned long long s_list[2048];
-  const int tid = threadIdx.x, q = blockIdx.x;
-  const int total = groups * n_out;
-  int npow = 256;
-  while (npow < total) npow <<= 1;
-  for (int i = tid; i < npow; i += 256) {
-    unsigned long long key = 0ull;
-    if (i < total) {
-      const float sc = part_score[(int64_t)q * total + i];
-      const int32_t fl = part_flat[(int64_t)q * total + i];
-      if (fl >= 0) key = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned long long)(0xffffffffu - (uint32_t)fl);
-    }
-    s_list[i] = key;
-  }
-  __syncthreads();
-  for (int size = 2; size <= npow; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      for (int i = tid; i < (npow >> 1); i += 256) {
-        const int lo = ((i / stride) * stride << 1) + (i % stride);
-        const int hi = lo + stride;
-        const unsigned long long a = s_list[lo], b = s_list[hi];
-        const bool desc = (lo & size) == 0;
-        if (desc ? (a < b) : (a > b)) { s_list[lo] = b; s_list[hi] = a; }
-      }
-      __syncthreads();
-    }
-  }
-  for (int i = tid; i < n_out; i += 256) {
-    const unsigned long long c = i < npow ? s_list[i] : 0ull;
-    out_score[(int64_t)q * n_out + i] = c ? __uint_as_float((uint32_t)(c >> 32)) : 0.f;
-    out_flat[(int64_t)q * n_out + i] = c ? (int32_t)(0xffffffffu - (uint32_t)(c & 0xffffffffull)) : -1;
+    out_score[(int64_t)q * n_out + i] = sc;
+    out_flat[(int64_t)q * n_out + i] = flat;
   }
 }
 
@@ -478,31 +506,9 @@ extern "C" int xml_moment_topk(const float* st, const float* ed, const float* w,
                             n_out, stream);
 }
 
-// Workgroups per query: one, unless the batch is too small to fill the chip (a 50-query batch: 50 workgroups on 256 CUs,
-// K9 was the longest kernel of the batch) -- then up to four, each on a quarter of the pairs, + the merge.
-static int moment_groups(int nq, int kpairs, int n_out) {
-  if (nq > 128 || kpairs < 16) return 1;
-  int g = nq <= 64 ? 4 : 2;
-  while (g > 1 && (kpairs < 8 * g || g * n_out > 2048)) g >>= 1;
-  return g;
-}
-extern "C" size_t xml_moment_topk_workspace_bytes(int nq, int kpairs, int n_out) {
-  if (nq <= 0 || kpairs <= 0 || n_out <= 0) return 0;
-  const int g = moment_groups(nq, kpairs, n_out);
-  return g > 1 ? (size_t)nq * g * n_out * 8 : 0;
-}
-
 extern "C" int xml_moment_topk_ex(const float* st, const float* ed, const float* w, const float* summ,
                                   const int32_t* pair_vid, const int32_t* vid_len, float* out_score, int32_t* out_flat, int nq,
                                   int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out, xml_stream_t stream) {
-  return xml_moment_topk_ws(st, ed, w, summ, pair_vid, vid_len, out_score, out_flat, nq, kpairs, lpad, l_ref, min_l, max_l,
-                            n_out, nullptr, 0, stream);
-}
-
-extern "C" int xml_moment_topk_ws(const float* st, const float* ed, const float* w, const float* summ,
-                                  const int32_t* pair_vid, const int32_t* vid_len, float* out_score, int32_t* out_flat, int nq,
-                                  int kpairs, int lpad, int l_ref, int min_l, int max_l, int n_out, void* ws, size_t ws_bytes,
-                                  xml_stream_t stream) {
   XML_ENTER();
   if (!st || !ed || !out_score || !out_flat || nq <= 0 || kpairs <= 0 || lpad <= 0 || l_ref <= 0 || n_out <= 0)
     return XML_ERR_BAD_ARG;
@@ -510,23 +516,13 @@ extern "C" int xml_moment_topk_ws(const float* st, const float* ed, const float*
   if (l_ref > lpad || min_l < 0 || max_l <= min_l) return XML_ERR_BAD_ARG;
   if (n_out > 1024 || lpad > 128 || kpairs > 4 * MT_PPW) return XML_ERR_UNSUPPORTED;   // (st, ed: probabilities, >= 0)
   const size_t lds = (size_t)MT_CAP * 8 + 2048 * 4;
-  // the part lists need the caller's scratch (xml_moment_topk_workspace_bytes); without it: one workgroup per query
-  int groups = moment_groups(nq, kpairs, n_out);
-  if (groups > 1 && (!ws || ws_bytes < xml_moment_topk_workspace_bytes(nq, kpairs, n_out))) groups = 1;
-  if (groups > 1) {
-    float* ps = (float*)ws;
-    int32_t* pf = (int32_t*)(ps + (size_t)nq * groups * n_out);
-    const int per = (kpairs + groups - 1) / groups;
-    hipLaunchKernelGGL(moment_topk_kernel, dim3(nq, groups), dim3(256), lds, (hipStream_t)stream, st, ed, w, ps, pf, kpairs, lpad,
-                       l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len, (int)g_q2c_ablation, per);
-    XML_CHECK_LAUNCH();
-    hipLaunchKernelGGL(moment_merge_kernel, dim3(nq), dim3(256), 0, (hipStream_t)stream, ps, pf, out_score, out_flat, groups,
-                       n_out);
-    XML_CHECK_LAUNCH();
-    return XML_OK;
-  }
-  hipLaunchKernelGGL(moment_topk_kernel, dim3(nq), dim3(256), lds, (hipStream_t)stream, st, ed, w, out_score, out_flat,
-                     kpairs, lpad, l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len, (int)g_q2c_ablation, kpairs);
+  // fewer queries than half the CUs and enough pairs to give sixteen waves work: the latency shape (see the kernel)
+  if (nq <= 128 && kpairs >= 32)
+    hipLaunchKernelGGL(moment_topk_kernel<1024>, dim3(nq), dim3(1024), lds, (hipStream_t)stream, st, ed, w, out_score, out_flat,
+                       kpairs, lpad, l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len, (int)g_q2c_ablation);
+  else
+    hipLaunchKernelGGL(moment_topk_kernel<256>, dim3(nq), dim3(256), lds, (hipStream_t)stream, st, ed, w, out_score, out_flat,
+                       kpairs, lpad, l_ref, min_l, max_l, n_out, summ, pair_vid, vid_len, (int)g_q2c_ablation);
   XML_CHECK_LAUNCH();
   return XML_OK;
 }

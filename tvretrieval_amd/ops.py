@@ -778,12 +778,8 @@ def moment_topk(st, ed, w, l_ref, min_l, max_l, n_out, summ=None, pair_vid=None,
         assert tuple(pair_vid.shape) == (nq, kpairs)
     sc = torch.empty((nq, n_out), dtype=torch.float32, device=st.device)
     fl = torch.empty((nq, n_out), dtype=torch.int32, device=st.device)
-    lib = _lib.load()
-    nb = lib.xml_moment_topk_workspace_bytes(nq, kpairs, int(n_out))      # > 0: a small batch runs several workgroups per query
-    ws = _workspace(nb, st.device) if nb else None
-    check(lib.xml_moment_topk_ws(_p(st), _p(ed), _p(w), _p(summ), _p(pair_vid), _p(vid_len), _p(sc), _p(fl), nq, kpairs,
-                                 lpad, int(l_ref), int(min_l), int(max_l), int(n_out), _p(ws), nb, _stream()),
-          "xml_moment_topk_ws")
+    check(_lib.load().xml_moment_topk_ex(_p(st), _p(ed), _p(w), _p(summ), _p(pair_vid), _p(vid_len), _p(sc), _p(fl), nq, kpairs,
+                                         lpad, int(l_ref), int(min_l), int(max_l), int(n_out), _stream()), "xml_moment_topk_ex")
     return sc, fl
 
 

@@ -11,11 +11,8 @@
 //   2. row maxima m(r,i) = max_d score(r,i,i+d) = (st*w)[i] * max_d ed[i+d] (exact for non-negative inputs: rounding
 //      is monotone); the sliding-window maximum of ed is a few wave shuffles.  Nothing of a pair is staged in LDS
 //      (24 KiB per workgroup, four per CU); the maxima are simply recomputed in the expansion pass.
-//   3. two lower bounds of the n_out-th best score, both by MSB-first radix-select (11/11/10 bits, wave-aggregated
-//      LDS histogram adds, wave-parallel suffix scan):
-//        T_a = n_out-th largest row maximum            (tight for peaky start/end distributions)
-//        T_b = n_out-th largest candidate of the first pair(s) (tight for flat distributions, where the answer is
-//              the best-ranked videos' bands and row maxima barely prune)
+//   3. a lower bound lb of the n_out-th best score: ONE histogram pass over the row maxima on bits [30:20] (wave-aggregated
+//      LDS adds, wave-parallel suffix scan) -- the lower edge of the bin that holds the n_out-th largest row maximum.
 //   4. expand rows with m(r,i) >= lb; candidates >= lb go to an LDS list (wave-aggregated append).
 //      If the list overflows, lb is raised to the n_out-th largest of the stored entries (a subset, hence still a
 //      valid lower bound) and the expansion repeats; if that separates nothing, to the exact n_out-th largest candidate

@@ -6,7 +6,8 @@
 //      equal to T are still needed; the bin holding the k-th element is found by a parallel suffix scan;
 //   2. gather every element > T plus the needed ones == T (when ties exceed the need: lowest payload first, i.e. lowest
 //      column without payloads);
-//   3. bitonic sort of the <= 256 survivors by (score desc, payload asc) in LDS; emit exp(alpha*s) + payload.
+//   3. the <= 256 survivors in (score desc, payload asc) order, each ranked against the others in LDS; emit exp(alpha*s) +
+//      payload.
 // HBM/L2-bound integer work: no reshaping into a GEMM.
 #include "common.h"
 
@@ -268,23 +269,20 @@ __global__ __launch_bounds__(256) void topk_rows_kernel(const float* __restrict_
   }
   __syncthreads();
 
-  // bitonic sort, descending on the composite (score desc, payload asc); empty slots (0) sink to the end
-  for (int size = 2; size <= 256; size <<= 1) {
-    for (int stride = size >> 1; stride > 0; stride >>= 1) {
-      const int partner = tid ^ stride;
-      if (partner > tid) {
-        const unsigned long long a = comp[tid], b = comp[partner];
-        const bool desc = (tid & size) == 0;
-        if (desc ? (a < b) : (a > b)) { comp[tid] = b; comp[partner] = a; }
-      }
-      __syncthreads();
-    }
-  }
-  if (tid < k) {
-    const unsigned long long c = comp[tid];
-    const float s = key_to_float((uint32_t)(c >> 32));
-    out_val[(int64_t)blockIdx.x * k + tid] = (alpha != 0.f) ? expf(alpha * s) : s;
-    out_idx[(int64_t)blockIdx.x * k + tid] = (int32_t)(0xffffffffu - (uint32_t)(c & 0xffffffffull));
+  // order on the composite (score desc, payload asc).  The composites are distinct (the payload is part of them), so an
+  // entry's position is the number of entries above it: every thread ranks ITS entry against the <= 256 survivors (all lanes
+  // read the same LDS word: a broadcast) and stores it at its rank -- one pass without a barrier instead of the 36
+  // barrier-separated stages of a 256-wide bitonic network.  Slots beyond the survivors (k > row length) stay empty rows.
+  const uint32_t n_comp = min(s_cnt, 256u);
+  const unsigned long long mine = comp[tid];
+  uint32_t rank = 0;
+#pragma unroll 8
+  for (uint32_t j = 0; j < n_comp; ++j) rank += comp[j] > mine ? 1u : 0u;
+  const uint32_t pos = (uint32_t)tid < n_comp ? rank : (uint32_t)tid;
+  if (pos < (uint32_t)k && ((uint32_t)tid < n_comp || tid < k)) {
+    const float s = key_to_float((uint32_t)(mine >> 32));
+    out_val[(int64_t)blockIdx.x * k + pos] = (alpha != 0.f) ? expf(alpha * s) : s;
+    out_idx[(int64_t)blockIdx.x * k + pos] = (int32_t)(0xffffffffu - (uint32_t)(mine & 0xffffffffull));
   }
 }
 

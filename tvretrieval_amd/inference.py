@@ -574,15 +574,56 @@ def ragged_lengths(index, ops=hip_ops, replicated=False):
     return index.vlen_all if replicated else index.vlen
 
 
+def query_linears(model, index, qvec):
+    """{video,sub}_query_linear of the modular query vectors (xml/model_xml.py:459-460,507): K7's query operand."""
+    return [getattr(model, m + "_query_linear")(qvec[m].contiguous()) for m in index.modalities]
+
+
+SMALL_BATCH_FORK = 256      # query batches up to this size: the query linears run beside K6 + K8 on a second stream
+_FORK_STREAMS = {}
+
+
+def _fork_stream(device):
+    key = str(torch.device(device))
+    if key not in _FORK_STREAMS:
+        _FORK_STREAMS[key] = torch.cuda.Stream(device=device)
+    return _FORK_STREAMS[key]
+
+
+def fork_query_linears(model, index, qvec, ops=hip_ops):
+    """Small batches (the reference's eval_query_bsz = 50: ~20 short kernels in a chain, K6 on a handful of the 256 CUs):
+    K7's query operand needs only the query vectors, so its two projections are issued on a second stream next to K6 + K8
+    instead of between K8 and K7.  Returns (q_lin, event to wait for) or None; capturable (the fork and the join become
+    graph edges)."""
+    q0 = qvec[index.modalities[0]]
+    if ops is not hip_ops or not q0.is_cuda or q0.shape[0] > SMALL_BATCH_FORK:
+        return None
+    main = torch.cuda.current_stream(q0.device)
+    side = _fork_stream(q0.device)
+    fork = torch.cuda.Event()
+    fork.record(main)
+    side.wait_event(fork)
+    with torch.cuda.stream(side):
+        q_lin = query_linears(model, index, qvec)
+        done = torch.cuda.Event()
+        done.record(side)
+    for t in q_lin:
+        t.record_stream(main)           # allocated on the side stream, consumed (and freed) on the main one
+    for m in index.modalities:
+        qvec[m].record_stream(side)
+    return q_lin, done
+
+
 def stage_span_probs(model, index, qvec, pair_vid, ops=hip_ops, zero_skipped=True, replicated=False, pair_w=None,
-                     band=None, vid_len=None):
+                     band=None, vid_len=None, q_lin=None):
     """K7 on the listed (query, local video) pairs -> softmaxed st / ed (Nq, K, lpad).
     replicated=True: pair_vid holds GLOBAL video ids into the corpus-wide copies index.feat2_all / index.mask_all
     (tvretrieval_amd.dist.replicate_rerank_features).
     vid_len (ragged_lengths(index)): the entries beyond a video's valid length are left unwritten -- hand the same array to
     ops.moment_topk(..., pair_vid=pair_vid, vid_len=vid_len)."""
     mods = index.modalities
-    q_lin = [getattr(model, m + "_query_linear")(qvec[m].contiguous()) for m in mods]
+    if q_lin is None:
+        q_lin = query_linears(model, index, qvec)
     merged = bool(model.config.merge_two_stream and len(mods) == 2)
     feat2, mask = (index.feat2_all, index.mask_all) if replicated else (index.feat2, index.mask)
     if getattr(feat2[mods[0]], "dtype", None) is getattr(ops, "F16S", object()):
@@ -656,8 +697,9 @@ def stage_video_topk(model, index, qvec, max_vcmr_video=100, q2c_alpha=20.0, ops
 
 
 def stage_moments(model, index, qvec, top_w, top_i, min_pred_l=2, max_pred_l=16, max_before_nms=200, ops=hip_ops,
-                  pad_tail=False):
-    """K7 + K9 on the selected (query, video) pairs -> (flat_scores (Nq, n) f32 desc, flat_indices (Nq, n) int32)."""
+                  pad_tail=False, q_lin=None):
+    """K7 + K9 on the selected (query, video) pairs -> (flat_scores (Nq, n) f32 desc, flat_indices (Nq, n) int32).
+    q_lin: the query linears' outputs when the caller already has them (fork_query_linears)."""
     if hasattr(ops, "MOMENT_SUMM") and K7_SUMMARIES:
         # K7 hands K9 the 8 largest row maxima of every pair (taken while the rows were in its registers): K9 reads the
         # 1 GB of span probabilities once instead of twice
@@ -666,7 +708,7 @@ def stage_moments(model, index, qvec, top_w, top_i, min_pred_l=2, max_pred_l=16,
     else:
         vl = ragged_lengths(index, ops)
         rk = dict(pair_vid=top_i, vid_len=vl) if vl is not None else {}
-        st, ed = stage_span_probs(model, index, qvec, top_i, ops, vid_len=vl)
+        st, ed = stage_span_probs(model, index, qvec, top_i, ops, vid_len=vl, q_lin=q_lin)
         fs, fi = ops.moment_topk(st, ed, top_w, index.l_ref, min_pred_l, max_pred_l, max_before_nms, **rk)
     if pad_tail:
         pad_moment_tail(fs, fi, top_i.shape[1], index.l_ref, min_pred_l, max_pred_l)
@@ -686,15 +728,20 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
     pad_tail=True: always max_before_nms rows, the reference's shape -- missing candidates become zero-score rows at
     length-masked positions (pad_moment_tail) instead of flat = -1."""
     qvec = stage_query_vectors(model, query_feat, query_mask)
+    forked = fork_query_linears(model, index, qvec, ops) if not (hasattr(ops, "MOMENT_SUMM") and K7_SUMMARIES) else None
     q2c, top_w, top_i, exact = stage_video_topk(model, index, qvec, max_vcmr_video, q2c_alpha, ops, external_top,
                                                 defer_exact_check)
-    fs, fi = stage_moments(model, index, qvec, top_w, top_i, min_pred_l, max_pred_l, max_before_nms, ops, pad_tail)
+    q_lin = None
+    if forked is not None:
+        q_lin, lin_done = forked
+        torch.cuda.current_stream(q_lin[0].device).wait_event(lin_done)
+    fs, fi = stage_moments(model, index, qvec, top_w, top_i, min_pred_l, max_pred_l, max_before_nms, ops, pad_tail, q_lin=q_lin)
     out = dict(q2c=q2c, top_scores=top_w, top_indices=top_i, flat_scores=fs, flat_indices=fi)
     if exact is not None:
         out["exact"] = exact
     if svmr_video is not None:
         pv = svmr_video.to(torch.int32).reshape(-1, 1).contiguous()
-        st1, ed1 = stage_span_probs(model, index, qvec, pv, ops)
+        st1, ed1 = stage_span_probs(model, index, qvec, pv, ops, q_lin=q_lin)
         ss, sf = ops.moment_topk(st1, ed1, None, index.l_ref, min_pred_l, max_pred_l, max_before_nms)
         if pad_tail:
             pad_moment_tail(ss, sf, 1, index.l_ref, min_pred_l, max_pred_l)

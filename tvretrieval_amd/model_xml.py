@@ -359,7 +359,15 @@ class XML(nn.Module):
             names = [n for n, u in (("video", self.use_video), ("sub", self.use_sub)) if u]
             st = [getattr(self, n + "_st_predictor") for n in names]
             ed = [getattr(self, n + "_ed_predictor") for n in names]
-        return torch.cat([m.weight.detach().float().reshape(-1) for m in st + ed]).contiguous()
+        # (cached like the packed projection weights: re-built when a tap changed in place or moved -- a 50-query batch is
+        # ~20 short kernels, and the concatenation was one of them plus two launch gaps)
+        key = (_PackedMixin._generation,) + tuple((m.weight.data_ptr(), m.weight._version) for m in st + ed)
+        hit = self.__dict__.get("_conv_w_cache")
+        if hit is None or hit[0] != key:
+            with torch.no_grad():
+                hit = (key, torch.cat([m.weight.detach().float().reshape(-1) for m in st + ed]).contiguous())
+            self.__dict__["_conv_w_cache"] = hit
+        return hit[1]
 
     def _ln_params(self, ln):
         return _f(ln.weight), _f(ln.bias)

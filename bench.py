@@ -240,7 +240,11 @@ def k6_traffic(root, workload, world):
     for path in reversed(cands):
         rec = json.load(open(path))
         if rec.get("kernel_source_sha256") == h.hexdigest():
-            return rec["traffic_bytes_per_launch"], os.path.relpath(path, root)
+            src = os.path.relpath(path, root)
+            tp = rec.get("traffic_passes")
+            if tp and tp.get("n", 0) > 1:        # the median of separate passes, with their spread (the figure moves +- 10 %)
+                src += " (median of %d PMC passes, %.1f-%.1f GB)" % (tp["n"], tp["min"] / 1e9, tp["max"] / 1e9)
+            return rec["traffic_bytes_per_launch"], src
     return None, "no PMC pass for the current K6 source (sha256 %s...)" % h.hexdigest()[:12]
 
 
@@ -419,7 +423,13 @@ def summary_of(res):
         for k in path:
             d = d.get(k) if isinstance(d, dict) else None
         return round(d, 4) if isinstance(d, float) else d
-    return {"c3_qps": g(res, "value"), "c3_ms": g(res, "ms_per_step"), "k6_frac": g(res, "roofline", "frac"),
+    multi = {}
+    if (res.get("n_gpus") or 1) > 1:        # a SCALE record's tail shows where a sharded pass spent its time (rank 0's view)
+        multi = {"n_gpus": res.get("n_gpus"), "stages_ms": res.get("breakdown_ms"),
+                 "exchange": g(res, "config", "exchange"), "rerank": g(res, "config", "rerank")}
+    tr = g(res, "roofline", "traffic")
+    return {**multi, "k6_traffic_gb": round(tr / 1e9, 1) if tr else None,
+            "c3_qps": g(res, "value"), "c3_ms": g(res, "ms_per_step"), "k6_frac": g(res, "roofline", "frac"),
             "exact_rank_ms": g(ex, "exact_rank", "ms_per_step"), "exact_rank_qps": g(ex, "exact_rank", "value"),
             "exact_fell_back": g(ex, "exact_rank", "fell_back_rate"),
             "h2h_f16_qps": g(ex, "c3_host_to_host", "f16_ragged", "value"),

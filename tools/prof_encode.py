@@ -15,6 +15,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--videos", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=3)
+    ap.add_argument("--no-queries", action="store_true")
     a = ap.parse_args()
     from tvretrieval_amd import inference as inf
     from tvretrieval_amd.model_xml import XML
@@ -31,14 +32,15 @@ def main():
     qf, qm = bench.synth_queries(nq, dq, dev)
     with torch.no_grad():
         inf.build_corpus_index(model, iter(raw[:1]), l_ref=l)
-        inf.stage_query_vectors(model, qf, qm)
+        if not a.no_queries:
+            inf.stage_query_vectors(model, qf, qm)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(a.reps):
             inf.build_corpus_index(model, iter(raw), l_ref=l)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        for _ in range(a.reps):
+        for _ in range(0 if a.no_queries else a.reps):
             inf.stage_query_vectors(model, qf, qm)
         torch.cuda.synchronize()
         t2 = time.perf_counter()

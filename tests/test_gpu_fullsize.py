@@ -241,6 +241,72 @@ def test_c3_exact_rank_mode_gives_the_fp32_lists(mode):
     assert c["filter_abs_err_max"] < c["eps_mean"], c                 # the bound really bounds what the filter did
 
 
+def test_c3_exact_rank_mode_vs_the_oracle_on_the_whole_corpus():
+    """configs[2] in exact-rank mode against the CPU ORACLE directly (one hop, not via the f32 HIP path): 200 queries x the
+    full 21 793-video corpus.  The HIP side is the whole product pass (ops.F16S model: split-f16 query encoder, bf16 K6
+    filter, split-f16 re-score + certificate + second tier, split-f16 ConvSE, K9).  The oracle side is the reference
+    formulation on the host cores -- query encoder, both (Nq, Nv, L) contractions, ConvSE, softmax, the (100, L, L) product
+    and the full sort (xml/model_xml.py:291-295,436-502, xml/inference.py:317-386) -- on the context features the index was
+    built from (the f32 outputs of the same HIP encoder, fetched batch by batch; the context encoder's own parity is
+    tests/test_gpu_model.py's).  Same tie-aware rule and bounds as test_c2_full_shape_vs_oracle_fp32."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, ROOT)
+    import bench
+    import rank_agreement
+    from tvretrieval_amd import inference as inf
+    from tvretrieval_amd import ops
+    from tvretrieval_amd.model_xml import XML
+    _, nv, l, hidden, dv, ds, dq, ctx_mode, _ = bench.WORKLOADS["c3"]
+    nq = 200
+    cfg = bench.model_config(hidden, dv, ds, dq, ctx_mode, l)
+    torch.manual_seed(0)
+    model = rank_agreement.perturb_weights(XML(cfg, compute_dtype=ops.F16S)).to(DEV).eval()
+    qf, qm = bench.synth_queries(nq, dq, torch.device(DEV))
+    host = dict(v1=[], v2=[], s1=[], s2=[])
+    with torch.no_grad():
+        raw = list(bench.context_batches(0, nv, l, dv, ds, True, True, torch.device(DEV)))
+        index = inf.build_corpus_index(model, iter(raw), n_total=nv, l_ref=l, n_videos=nv, exact_filter=True)
+        assert index.exact.mode == "f16s"
+        for b in raw:           # the encoder is deterministic per batch: these are the rows the index was built from
+            for k_, t in zip(("v1", "v2", "s1", "s2"), model.encode_context(*b)):
+                host[k_].append(t.float().cpu())
+        del raw
+        out = inf.vcmr_search(model, index, qf, qm, max_vcmr_video=100, max_before_nms=200)
+        assert out["exact"]["n_full_rows"] == 0
+        del index
+    torch.cuda.synchronize()
+    f = {k_: torch.cat(v) for k_, v in host.items()}
+    del host
+    ones = torch.ones(nv, l)
+    om = O.OracleXML(cfg, {k_: v.detach().float().cpu() for k_, v in model.state_dict().items()})
+    with torch.no_grad():
+        q2c, st, ed = om.get_pred_from_raw_query(qf.cpu(), qm.cpu(), f["v1"], f["v2"], ones, f["s1"], f["s2"], ones, cross=True)
+    del f
+    kv, kn, extra = 100, 200, 24
+    ll = l * l
+    gi, gw = out["top_indices"].cpu().numpy().astype(np.int64), out["top_scores"].cpu().numpy()
+    gfi, gfs = out["flat_indices"].cpu().numpy().astype(np.int64), out["flat_scores"].cpu().numpy()
+    n_vid_diff = n_mom_diff = n_rows = 0
+    for c in range(0, nq, 25):
+        sl = slice(c, c + 25)
+        with torch.no_grad():
+            tail = O.vcmr_tail(q2c[sl], st[sl], ed[sl], 20.0, kv, 2, 16, kn + extra)
+            ww, wi = torch.topk(torch.exp(20.0 * q2c[sl]), kv + extra, dim=1)
+        n_vid_diff += _tie_aware_equal(gi[sl], gw[sl], wi.numpy(), ww.numpy(), kv, 2e-4, "top-100 videos")
+        wfi, wfs = tail["flat_indices"].numpy(), tail["flat_scores"].numpy()
+        wkey = np.take_along_axis(tail["top_indices"].numpy(), wfi // ll, 1) * ll + wfi % ll
+        gkey = np.take_along_axis(gi[sl], np.clip(gfi[sl] // ll, 0, kv - 1), 1) * ll + gfi[sl] % ll
+        rows = np.nonzero((np.sort(gi[sl], 1) == np.sort(tail["top_indices"].numpy(), 1)).all(1))[0]
+        n_rows += len(rows)
+        assert (gfi[sl][rows] >= 0).all()
+        n_mom_diff += _tie_aware_equal(gkey[rows], gfs[sl][rows], wkey[rows], wfs[rows], kn, 5e-4, "top-200 moments")
+        assert (gi[sl][:, 0] == wi.numpy()[:, 0]).all(), "top-1 video"
+    print("exact-rank vs oracle, %d queries x %d videos: %d video / %d moment positions swapped inside ties; %d queries "
+          "with the oracle's top-100 set" % (nq, nv, n_vid_diff, n_mom_diff, n_rows))
+    assert n_rows >= nq - 2, "video sets differ for %d queries" % (nq - n_rows)      # (a rank-100/101 tie at f32 rounding)
+    assert n_vid_diff <= 0.01 * nq * kv and n_mom_diff <= 0.02 * n_rows * kn, (n_vid_diff, n_mom_diff)
+
+
 @pytest.mark.parametrize("mode", ["bf16", "exact_f16s"])
 def test_c4_eight_shard_walk_equals_the_single_pass(mode):
     """BASELINE configs[3] at its own size on ONE GPU: the 21 793-video corpus cut into the 8 `shard_range` slices an

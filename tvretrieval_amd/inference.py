@@ -483,6 +483,11 @@ def stage_exact_topk_f16s(index, qvec, k, alpha, ops=hip_ops, defer_check=False)
         q_sub = [sr[order] for sr in q_sr]
         q_sub = [ops.SplitRows(sr.data.contiguous(), sr.inv.contiguous()) for sr in q_sub]
         full = ops.q2c_rescore(q_sub, rows_c, masks, cand2)
+        # slots of PASSING queries selected nothing: their rows are c_cap times -inf, and the top-k of an all-tied row with
+        # payloads takes K8's one-block-minimum-per-element path (0.46 ms for 156 such rows -- more than the second tier's
+        # re-score).  Their results are discarded below; a ramp of distinct values keeps them on the fast path.
+        ramp = -torch.arange(c_cap, dtype=torch.float32, device=full.device)
+        full = torch.where(is_fail[:, None], full, ramp[None, :])
         fw, fi = ops.topk_rows(full, k, alpha=alpha, idx_in=cand2)
         top_w.index_copy_(0, order, torch.where(is_fail[:, None], fw, top_w.index_select(0, order)))
         top_i.index_copy_(0, order, torch.where(is_fail[:, None], fi, top_i.index_select(0, order)))

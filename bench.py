@@ -615,14 +615,19 @@ def run(args, backend_factory=None, emit=True):
 
     exact_flags = []      # exact-rank mode: the passes read nothing back; their overflow flags are looked at after the clock
 
+    # The collate builds the query masks on the HOST (start_end_dataset.py:346-370): a caller knows the number of valid query
+    # tokens without asking the device.  Handing it over spares the packed query encoder its 4-byte read-back -- a host
+    # synchronisation per pass (~0.6 ms of idle device between passes); taken once, before the clock.
+    tok_kw = dict(n_valid_tokens=int(qm.sum().item())) if (be.name == "hip" and not multi) else {}
+
     def step():
         with torch.no_grad():
             if not multi:
                 if exact:
-                    o = inf.vcmr_search(model, index, qf, qm, ops=ops, defer_exact_check=True)
+                    o = inf.vcmr_search(model, index, qf, qm, ops=ops, defer_exact_check=True, **tok_kw)
                     exact_flags.append((o["exact"]["overflow_dev"], o["exact"]["n_fail_dev"]))
                     return o
-                return inf.vcmr_search(model, index, qf, qm, ops=ops)
+                return inf.vcmr_search(model, index, qf, qm, ops=ops, **tok_kw)
             # final lists stay on the rank that owns the query (where its NMS would run): no redundant gather
             return xdist.sharded_vcmr_search(model, index, qf, qm, gather_results=False, ops=ops, exchange=exchange,
                                              n_chunks=1 if args.sharded_rerank else args.chunks)
@@ -814,6 +819,7 @@ def run(args, backend_factory=None, emit=True):
                                       ("" if exch_note is None else " [%s]" % exch_note),
                        "collectives_fallback": 0 if exch_note is None else 1,      # 1 = NOT the C-ABI exchange (see above)
                        "query_chunks": args.chunks if multi and not args.sharded_rerank else 1,
+                       "query_token_count": "host-known, handed to the pass (no read-back)" if tok_kw else "read back from the device",
                        "launcher": "bench.py self-spawn" if os.environ.get("XML_SELF_SPAWNED") else
                                    ("torch.distributed.run" if world > 1 else "single process"),
                        "result_placement": "all on the GPU" if not multi else "final lists on the query's owner rank",

@@ -632,6 +632,13 @@ def test_packed_query_encode_equals_padded(dtype, hidden, nq, monkeypatch):
         assert np.array_equal(src[:rows].cpu().numpy(), want_src)
         for bad in (qm2, torch.zeros_like(qm), qm * 0.5):
             assert ops.pack_plan(bad.float().contiguous())[2] == -1
+        # a caller that built the masks on the host hands the token count over: same plan, same vectors, no read-back
+        cu2, src2, rows2 = ops.pack_plan(qm.float().contiguous(), rows=int(lens.sum()))
+        assert rows2 == rows and torch.equal(cu2, cu) and torch.equal(src2[:rows], src[:rows])
+        v2, s2 = m.encode_query(qf, qm, n_valid_tokens=int(lens.sum()))
+        assert torch.equal(v2, v1) and torch.equal(s2, s1)
+        with pytest.raises(ValueError, match="valid tokens"):
+            ops.pack_plan(qm.float().contiguous(), rows=nq * 30 + 1)
     # f32: the same arithmetic per valid token.  bf16: the packed batch has fewer rows, so a projection may run on another
     # GEMM kernel of the family (LayerNorm in the epilogue or behind it: one rounding of the pre-LN value more or less) --
     # a couple of bf16 ulps on single elements, nothing systematic

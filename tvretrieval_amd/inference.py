@@ -367,9 +367,10 @@ def compute_context_info(model, eval_dataset, opt, ops=hip_ops):
 # ---------------------------------------------------------------------------------------------------------
 # device stages of HOT LOOP B
 # ---------------------------------------------------------------------------------------------------------
-def stage_query_vectors(model, query_feat, query_mask):
-    """encode_query -> per-modality modular query vectors, in index.modalities order."""
-    vq, sq = model.encode_query(query_feat, query_mask)
+def stage_query_vectors(model, query_feat, query_mask, n_valid_tokens=None):
+    """encode_query -> per-modality modular query vectors, in index.modalities order.
+    n_valid_tokens: see XML.encode_query (host-known token count: no read-back in the packed encoder)."""
+    vq, sq = model.encode_query(query_feat, query_mask, **(dict(n_valid_tokens=n_valid_tokens) if n_valid_tokens is not None else {}))
     out = {}
     if model.use_video:
         out["video"] = vq
@@ -722,7 +723,7 @@ def stage_moments(model, index, qvec, top_w, top_i, min_pred_l=2, max_pred_l=16,
 
 def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_before_nms=200, q2c_alpha=20.0,
                 min_pred_l=2, max_pred_l=16, svmr_video=None, ops=hip_ops, external_top=None, pad_tail=False,
-                defer_exact_check=False):
+                defer_exact_check=False, n_valid_tokens=None):
     """Device part of compute_query2ctx_info for one query batch (xml/inference.py:308-386), single GPU.
 
     Returns device tensors:
@@ -731,8 +732,10 @@ def vcmr_search(model, index, query_feat, query_mask, max_vcmr_video=100, max_be
       and, if svmr_video (Nq,) int32 is given, svmr_scores / svmr_flat (Nq,n) over (l_ref, l_ref).
     external_top = (indices (Nq,K) int32, weights (Nq,K) f32): use these videos / weights instead of K6 + K8.
     pad_tail=True: always max_before_nms rows, the reference's shape -- missing candidates become zero-score rows at
-    length-masked positions (pad_moment_tail) instead of flat = -1."""
-    qvec = stage_query_vectors(model, query_feat, query_mask)
+    length-masked positions (pad_moment_tail) instead of flat = -1.
+    n_valid_tokens (host int): query_mask.sum() when the masks were built on the host (prefix masks) -- the packed query
+    encoder of large batches then needs no read-back and the whole pass is enqueued without a host synchronisation."""
+    qvec = stage_query_vectors(model, query_feat, query_mask, n_valid_tokens)
     forked = fork_query_linears(model, index, qvec, ops) if not (hasattr(ops, "MOMENT_SUMM") and K7_SUMMARIES) else None
     q2c, top_w, top_i, exact = stage_video_topk(model, index, qvec, max_vcmr_video, q2c_alpha, ops, external_top,
                                                 defer_exact_check)
@@ -910,12 +913,19 @@ def vcmr_search_host(model, index, query_feat, query_mask=None, row_start=None, 
             main.wait_event(copied[c & 1])
             if c == 0:
                 t_first.record(main)
+            # the host holds the queries' lengths: the packed encoder is told its token count instead of reading it back
+            # (a read-back per chunk is a host synchronisation per chunk)
             if ragged:
                 r0 = int(rs_host[b])
                 qf, qm = ops.ingest_rows(st["rows"], st["start"][:e - b + 1] - r0, e - b, lq, lq, normalize=True)
+                ln = np.minimum(np.diff(rs_host[b:e + 1]), lq)
+                n_tok = int(ln.sum()) if (e > b and ln.min() >= 1) else None
             else:
                 qf, qm = st["qf"][:e - b], st["qm"][:e - b]
-            qvec = stage_query_vectors(model, qf, qm)
+                mh = query_mask[b:e].numpy()
+                prefix = bool((mh[:, 0] == 1).all() and ((mh == 0) | (mh == 1)).all() and (mh[:, 1:] <= mh[:, :-1]).all())
+                n_tok = int(mh.sum()) if prefix else None
+            qvec = stage_query_vectors(model, qf, qm, n_tok)
             done = evt()
             done.record(main)                            # the staging set is free once the query encoder has read it
             freed[c & 1] = done

@@ -437,21 +437,23 @@ class XML(nn.Module):
         out = ops.modular_pool(encoded_query.contiguous(), query_mask.float().contiguous(), wm)
         return (out[0], out[1]) if out.shape[0] == 2 else (out[0], out[0])
 
-    def encode_query(self, query_feat, query_mask):
-        """xml/model_xml.py:291-295."""
+    def encode_query(self, query_feat, query_mask, n_valid_tokens=None):
+        """xml/model_xml.py:291-295.
+        n_valid_tokens (host int, not a reference argument): query_mask.sum() when the caller built the masks on the host
+        and every row is a non-empty prefix of ones -- the packed encoder then needs no read-back (ops.pack_plan)."""
         # (not while a HIP graph is being captured: the packing plan needs a host read-back and the packed launch shapes
         # depend on the number of valid tokens of THIS batch -- a graph would bake the warm-up batch's in)
         if PACK_QUERY_TOKENS and query_feat.is_cuda and query_feat.shape[0] * query_feat.shape[1] >= PACK_MIN_ROWS \
                 and query_feat.shape[1] <= 32 and self.config.hidden_size <= 1024 \
                 and not torch.cuda.is_current_stream_capturing():
-            packed = self._encode_query_packed(query_feat, query_mask)
+            packed = self._encode_query_packed(query_feat, query_mask, n_valid_tokens)
             if packed is not None:
                 return packed
         enc = self.encode_input(query_feat, query_mask, self.query_input_proj, self.query_encoder,
                                 self.query_pos_embed)
         return self.get_modularized_queries(enc, query_mask)
 
-    def _encode_query_packed(self, query_feat, query_mask):
+    def _encode_query_packed(self, query_feat, query_mask, n_valid_tokens=None):
         """encode_query without the padding rows.  The reference pads every query to the batch maximum (30 tokens on TVR,
         17.5 valid on average) and runs the projections, the attention and the LayerNorms on all of them; here the valid
         tokens of the batch are packed back to back (include/xmlhip.h "PACKED variable-length sequences"): 42 % fewer rows
@@ -465,7 +467,7 @@ class XML(nn.Module):
             raise IndexError("sequence length %d exceeds the positional table (%d)" % (lq, e["pos"].shape[0]))
         if d_in % 8 or d_in > 4096:
             return None
-        cu, src_row, rows = ops.pack_plan(query_mask.float().contiguous())         # (one 4-byte read-back)
+        cu, src_row, rows = ops.pack_plan(query_mask.float().contiguous(), n_valid_tokens)   # (one 4-byte read-back without it)
         if rows < 0:
             return None
         feat = query_feat if query_feat.dtype in (torch.float32, ops.act_dtype(dt)) else query_feat.float()

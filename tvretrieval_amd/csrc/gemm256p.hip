@@ -405,8 +405,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
           if (col + GC <= N) {
             // non-temporal: this kernel only runs on outputs of >= 3072 tiles (400 MB and up), nothing of which survives
             // in a cache until its consumer starts; streaming stores retire ~2.5 % faster here (886 -> 906 TF at
-            // N = 2304, same box).  Not for LNE: pass 2 re-reads the tile through this XCD's L2.
-            if (!LNE && !(a.probe & 8)) {      // (probe bit 3: plain stores, A/B)
+            // N = 2304, same box).  LNE too: its outputs are final -- written once, after the row statistics, never re-read
+            // by this kernel (rounds 2-5 re-read the tile in a second pass through this XCD's L2 and kept plain stores).
+            if (!(a.probe & 8)) {      // (probe bit 3: plain stores, A/B)
               typedef unsigned int g_u4 __attribute__((ext_vector_type(4)));
               if (m_even < M && !(a.probe & 4)) __builtin_nontemporal_store(g_u4{d_even.x, d_even.y, d_even.z, d_even.w}, reinterpret_cast<g_u4*>(out + m_even * N + col));
               if (m_even + 1 < M && !(a.probe & 4)) __builtin_nontemporal_store(g_u4{d_odd.x, d_odd.y, d_odd.z, d_odd.w}, reinterpret_cast<g_u4*>(out + (m_even + 1) * N + col));
@@ -523,10 +524,13 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
               // earlier tiles: f32 to the workgroup's scratch, lane for lane (every store instruction writes 1 KiB contiguous)
               float4* sc = reinterpret_cast<float4*>(a.ln_scratch) + (int64_t)blockIdx.x * (tn_s - 1) * 16384 +
                            (int64_t)((nt * 4 + m4) * 8) * 512 + tid_e;
+              // (non-temporal: 512 KB per workgroup and row block, read back once a tile or two later -- 16 MB per XCD would
+              // sweep the A / W tiles out of its 4 MB L2; the Infinity Cache holds them)
 #pragma unroll
               for (int j = 0; j < 8; ++j) {
                 const float* vf = &v[0][0] + j * 4;
-                sc[j * 512] = make_float4(vf[0], vf[1], vf[2], vf[3]);
+                typedef float xml_nt4 __attribute__((ext_vector_type(4)));
+                __builtin_nontemporal_store(xml_nt4{vf[0], vf[1], vf[2], vf[3]}, reinterpret_cast<xml_nt4*>(sc + j * 512));
               }
             }
           } else {
@@ -667,7 +671,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(G256pArgs a) {
               } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                  const float4 f = sc[(m4 * 8 + j) * 512];
+                  typedef float xml_nt4 __attribute__((ext_vector_type(4)));
+                  const xml_nt4 f = __builtin_nontemporal_load(reinterpret_cast<const xml_nt4*>(sc + (m4 * 8 + j) * 512));
                   x[j * 4] = f.x; x[j * 4 + 1] = f.y; x[j * 4 + 2] = f.z; x[j * 4 + 3] = f.w;
                 }
               }

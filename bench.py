@@ -426,7 +426,8 @@ def summary_of(res):
     multi = {}
     if (res.get("n_gpus") or 1) > 1:        # a SCALE record's tail shows where a sharded pass spent its time (rank 0's view)
         multi = {"n_gpus": res.get("n_gpus"), "stages_ms": res.get("breakdown_ms"),
-                 "exchange": g(res, "config", "exchange"), "rerank": g(res, "config", "rerank")}
+                 "collectives": g(res, "config", "collectives"), "collectives_fallback": g(res, "config", "collectives_fallback"),
+                 "rerank": g(res, "config", "rerank")}
     tr = g(res, "roofline", "traffic")
     return {**multi, "k6_traffic_gb": round(tr / 1e9, 1) if tr else None,
             "c3_qps": g(res, "value"), "c3_ms": g(res, "ms_per_step"), "k6_frac": g(res, "roofline", "frac"),
@@ -900,7 +901,8 @@ def run(args, backend_factory=None, emit=True):
             res["extras"] = extras
             if res.get("cpu_baseline") is not None:       # (long strings: keep them in front of the figures below)
                 res["cpu_baseline"] = res.pop("cpu_baseline")
-            res["summary"] = summary_of(res)              # LAST key: what a 2 000-character tail of this line still shows
+    if rank == 0 and res is not None and emit:
+        res["summary"] = summary_of(res)                  # LAST key: what a 2 000-character tail of this line still shows
     if multi:       # RCCL's start-up banner sits in the C stdio buffer of every rank: push it out BEFORE the result line,
         import ctypes    # so that the JSON line is the last thing this job prints
         ctypes.CDLL(None).fflush(None)

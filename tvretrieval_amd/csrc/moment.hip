@@ -211,6 +211,38 @@ __global__ __launch_bounds__(NT) void moment_topk_kernel(const float* __restrict
     }
   };
 
+  // NT = 1024: a wave owns at most 8 pairs -- their (st * w, row maximum) values stay in REGISTERS from the first walk on, and
+  // the expansion pass replays them instead of fetching the pairs' rows a second time (one round of dependent loads less on
+  // the latency path of a 50-query batch).  With 4 waves a wave owns up to 32 pairs: 128 registers, or the LDS table that
+  // was tried in round 5 and cost a workgroup per CU -- the 256-thread form walks twice.
+  constexpr bool KEEP = NT >= 1024;
+  constexpr int KT = KEEP ? (4 * MT_PPW + NW - 1) / NW : 1;
+  float k_a[KT][2], k_m[KT][2];
+  if constexpr (KEEP) {
+    float raw[KT][4], wv[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      wv[t] = t < n_t ? pair_w(wave + t * NW) : 0.f;
+      if (wv[t] != 0.f) pair_load(wave + t * NW, raw[t]);
+      else raw[t][0] = raw[t][1] = raw[t][2] = raw[t][3] = 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+      k_a[t][0] = k_a[t][1] = k_m[t][0] = k_m[t][1] = 0.f;
+      if (wv[t] != 0.f) pair_eval(raw[t], wv[t], k_a[t][0], k_a[t][1], k_m[t][0], k_m[t][1]);     // (wave-uniform)
+    }
+  }
+  // the active pairs of this wave: from the registers (KEEP) or by walking their rows
+  auto walk_pairs = [&](auto&& body) {
+    if constexpr (KEEP) {
+#pragma unroll
+      for (int t = 0; t < KT; ++t)
+        if (t < n_t) body(wave + t * NW, k_a[t], k_m[t]);        // (skipped pairs hold zeros: no bin, no live row)
+    } else {
+      for_pairs(body);
+    }
+  };
+
   // ---- 2+3. ONE histogram pass over the row maxima on bits [30:20] (8 exponent + 3 mantissa bits); the lower edge
   //           of the bin holding the n_out-th largest row maximum is a lower bound of the n_out-th best score ------
   if (summ) {
@@ -227,7 +259,7 @@ __global__ __launch_bounds__(NT) void moment_topk_kernel(const float* __restrict
       if (key != 0u && !(key & 0x80000000u)) atomicAdd(&s_hist[key >> 20], 1u);
     }
   } else {
-  for_pairs([&](int r, const float (&a2)[2], const float (&m2)[2]) {
+  walk_pairs([&](int r, const float (&a2)[2], const float (&m2)[2]) {
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       const float m = m2[h];
@@ -290,7 +322,7 @@ __global__ __launch_bounds__(NT) void moment_topk_kernel(const float* __restrict
     //     and the overflow refinement).  Expanding rows in place costs ~14 ballot/atomic iterations per 64-row block
     //     with typically 1-2 live rows in it: that was most of this kernel's time.
     unsigned long long* s_rows = reinterpret_cast<unsigned long long*>(s_hist);   // [1024]: (a bits << 32) | row id
-    for_pairs([&](int r, const float (&a2)[2], const float (&m2)[2]) {
+    walk_pairs([&](int r, const float (&a2)[2], const float (&m2)[2]) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         const int i = lane + h * 64;

@@ -786,6 +786,72 @@ def test_moment_topk_small_batches_bitwise(ops, nq, k, n_out):
     assert torch.equal(torch.where(ok, prod, torch.zeros(())), sc)
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_moment_topk_forms_agree_on_random_shapes(ops, seed):
+    """K9's two workgroup forms (256 threads per query in a 200-query batch, 1 024 threads for the same rows alone) on random
+    shapes: l_ref below the padded row length, every band, with / without pair weights, with / without ragged lengths --
+    bit for bit, and every entry is the product it names, in (score desc, flat asc) order."""
+    rng = np.random.default_rng(900 + seed)
+    lpad = int(rng.choice([32, 64, 112, 128]))
+    l = int(rng.integers(max(9, lpad - 15), lpad + 1))
+    k = int(rng.integers(32, 129))
+    nq = int(rng.integers(1, 129))
+    min_l = int(rng.integers(0, 4))
+    max_l = int(rng.integers(min_l + 1, min(l, 33)))
+    n_out = int(rng.choice([1, 37, 200, 513, 1024]))
+    g = torch.Generator().manual_seed(901 + seed)
+    lens = torch.randint(1, l + 1, (29,), generator=g).int()
+    pv = torch.randint(0, 29, (200, k), generator=g).int()
+    ragged = bool(seed % 2)
+    lim = lens[pv.long()] if ragged else torch.full((200, k), l)
+    mask = (torch.arange(lpad)[None, None] < lim[..., None]).float()
+    temp = torch.where(torch.arange(200) % 3 == 0, 4.0, 0.1)[:, None, None]
+    st = torch.softmax(O.mask_logits(torch.randn(200, k, lpad, generator=g) * temp, mask), -1) * mask
+    ed = torch.softmax(O.mask_logits(torch.randn(200, k, lpad, generator=g) * temp, mask), -1) * mask
+    w = torch.exp(20 * torch.rand(200, k, generator=g) * 0.2) if seed % 3 else None
+    if w is not None:
+        w[:, 1::7] = 0.0
+    rk = dict(pair_vid=dev(pv), vid_len=dev(lens)) if ragged else {}
+    big = ops.moment_topk(dev(st), dev(ed), None if w is None else dev(w), l, min_l, max_l, n_out, **rk)
+    rk = dict(pair_vid=dev(pv[:nq].contiguous()), vid_len=dev(lens)) if ragged else {}
+    small = ops.moment_topk(dev(st[:nq].contiguous()), dev(ed[:nq].contiguous()), None if w is None else dev(w[:nq].contiguous()),
+                            l, min_l, max_l, n_out, **rk)
+    assert torch.equal(small[0], big[0][:nq]) and torch.equal(small[1], big[1][:nq]), (lpad, l, k, nq, min_l, max_l, n_out)
+    sc, fl = small[0].cpu(), small[1].cpu().long()
+    ok = fl >= 0
+    assert (sc[:, :-1] >= sc[:, 1:]).all() and ((sc[:, :-1] > sc[:, 1:]) | (fl[:, :-1] < fl[:, 1:]) | ~ok[:, 1:]).all()
+    r, i, j = (fl // (l * l)).clamp(min=0), ((fl // l) % l).clamp(min=0), (fl % l).clamp(min=0)
+    qi = torch.arange(nq)[:, None].expand_as(fl)
+    a = st[:nq][qi, r, i] * (w[:nq][qi, r] if w is not None else 1.0)
+    assert torch.equal(torch.where(ok, a * ed[:nq][qi, r, j], torch.zeros(())), sc)
+    assert (~ok | ((j - i >= min_l) & (j - i < max_l))).all()
+    # nothing better was left out: the smallest listed score bounds every unlisted candidate of the band
+    d = torch.arange(lpad)[None, :] - torch.arange(lpad)[:, None]
+    band = ((d >= min_l) & (d < max_l))[:l, :l]
+    for q in range(min(nq, 4)):
+        prod = (st[q, :, :l, None] * (w[q, :, None, None] if w is not None else 1.0)) * ed[q, :, None, :l] * band[None]
+        n_pos = int((prod > 0).sum())
+        assert int(ok[q].sum()) == min(n_out, n_pos), (q, int(ok[q].sum()), n_pos)
+        if n_pos > n_out:
+            assert float(torch.topk(prod.flatten(), n_out)[0][-1]) == float(sc[q, n_out - 1])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("nq", [1, 50, 256, 257, 1000])
+def test_query_vectors_of_both_modalities_tiled_in_one_launch(ops, dtype, nq):
+    """ops.q2c_tile_rows_l2norm_pair (the halves of the pooled (2, nq, H) tensor, one launch through a row map) = the two
+    single-modality launches, bit for bit; layouts that are not two halves of one tensor are refused."""
+    g = torch.Generator().manual_seed(40 + nq)
+    both = dev(torch.randn(2, nq, 256, generator=g), dtype)
+    pair = ops.q2c_tile_rows_l2norm_pair(both[0], both[1])
+    assert pair is not None
+    for m in range(2):
+        one = ops.q2c_tile_rows_l2norm(both[m].contiguous())
+        assert torch.equal(pair[m].data, one.data) and pair[m].rows == one.rows
+    assert ops.q2c_tile_rows_l2norm_pair(both[1], both[0]) is None
+    assert ops.q2c_tile_rows_l2norm_pair(both[0], both[0].clone()) is None
+
+
 @pytest.mark.parametrize("n,lq", [(1, 30), (3, 5), (1025, 64), (4097, 17), (10000, 30)])
 def test_pack_plan_shapes(ops, n, lq):
     """xml_pack_plan (packing plan of a padded token batch): cu_seqlens / source rows for batches smaller and larger than

@@ -689,6 +689,23 @@ def test_index_bits_do_not_depend_on_the_context_batch(dtype, ctx_mode, hidden):
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_host_to_host_chunked_pass_equals_the_single_launch(dtype):
+    _host_to_host_case(dtype, nq=700, chunk=256, want_chunks=[256, 444])
+
+
+def test_host_to_host_large_chunks_take_the_packed_encoder_without_a_read_back():
+    """Chunks of 768 / 1 632 queries (23 040 / 48 960 padded token rows: above model_xml.PACK_MIN_ROWS): the query encoder
+    runs on the packed valid tokens, told its token count by the host (no read-back per chunk) -- still bitwise the single
+    launch, which reads its plan back."""
+    _host_to_host_case(torch.bfloat16, nq=2400, chunk=768, want_chunks=[768, 1632])
+
+
+def test_host_to_host_with_an_empty_query():
+    """A query without a token (row_start[i + 1] == row_start[i]): its mask row is all zero, the packed encoder does not apply,
+    the chunk takes the padded path with its read-back -- same records as the single launch on the same padded batch."""
+    _host_to_host_case(torch.float32, nq=600, chunk=256, want_chunks=[256, 344], empty=(0, 17, 300, 599))
+
+
+def _host_to_host_case(dtype, nq, chunk, want_chunks, empty=()):
     """inference.vcmr_search_host (queries in pinned host memory -> chunked H2D on a side stream overlapped with the previous
     chunk's search -> K10 records -> one D2H) returns, bit for bit, the records of ONE vcmr_search over the whole query set:
     for the padded f32 layout of the reference's collate and for the feature store's ragged f16 token rows (device collate,
@@ -696,13 +713,15 @@ def test_host_to_host_chunked_pass_equals_the_single_launch(dtype):
     from tvretrieval_amd import inference as inf
     from tvretrieval_amd import ops
     from tvretrieval_amd.results import MOMENT_DTYPE
-    nv, nq, l = 150, 700, 128
+    nv, l = 150, 128
     m, cfg = _synthetic_model("video_sub", 128, 256, 128, 128, l, dtype, seed=15)
     rng = np.random.default_rng(8)
     lens = rng.integers(10, l + 1, nv); lens[0] = l
     vf, vm = _feats(nv, lens, 256, 1)
     sf, sm = _feats(nv, lens, 128, 2)
     qlens = np.concatenate([[30], rng.integers(3, 31, nq - 1)])
+    for i in empty:
+        qlens[i] = 0
     meta2vid = torch.from_numpy((np.arange(nv) * 7 + 3).astype(np.int32)).to(DEV)
     kw = dict(max_vcmr_video=20, max_before_nms=60)
     with torch.no_grad():
@@ -722,15 +741,15 @@ def test_host_to_host_chunked_pass_equals_the_single_launch(dtype):
         for name, hk in host.items():
             tm = {}
             for rep in range(2):
-                rec, cnt = inf.vcmr_search_host(m, index, meta2vid=meta2vid, chunk=256, clip_length=1.5, timings=tm, **hk, **kw)
+                rec, cnt = inf.vcmr_search_host(m, index, meta2vid=meta2vid, chunk=chunk, clip_length=1.5, timings=tm, **hk, **kw)
                 np.testing.assert_array_equal(cnt, want_cnt, err_msg=name)
                 for col in ("vid", "st", "ed", "score"):
                     for q in range(nq):
                         np.testing.assert_array_equal(rec[col][q, :cnt[q]], want[col][q, :want_cnt[q]],
                                                       err_msg="%s: %s of query %d (pass %d)" % (name, col, q, rep))
-            assert tm["chunks"] == 2 and tm["chunk_queries"] == [256, 444] and tm["h2d_s"] > 0 and tm["d2h_s"] > 0
+            assert tm["chunks"] == len(want_chunks) and tm["chunk_queries"] == want_chunks and tm["h2d_s"] > 0 and tm["d2h_s"] > 0
             # two passes in flight (wait=False): each on its own buffer set, the same records
-            pend = [inf.vcmr_search_host(m, index, meta2vid=meta2vid, chunk=256, clip_length=1.5, wait=False, **hk, **kw)
+            pend = [inf.vcmr_search_host(m, index, meta2vid=meta2vid, chunk=chunk, clip_length=1.5, wait=False, **hk, **kw)
                     for _ in range(2)]
             assert pend[0].buffers is not pend[1].buffers
             for pnd in pend:
@@ -740,7 +759,7 @@ def test_host_to_host_chunked_pass_equals_the_single_launch(dtype):
                     np.testing.assert_array_equal(np.where(np.arange(rec.shape[1])[None] < cnt[:, None], rec[col], 0),
                                                   np.where(np.arange(rec.shape[1])[None] < cnt[:, None], want[col], 0),
                                                   err_msg="%s: %s (pipelined)" % (name, col))
-    assert (want_cnt > 0).all() and len(np.unique(want["vid"][:, 0])) > 10
+    assert (want_cnt[[i for i in range(nq) if i not in empty]] > 0).all() and len(np.unique(want["vid"][:, 0])) > 10
 
 
 def test_hip_graph_replay_equals_eager():

@@ -148,7 +148,30 @@ __global__ __launch_bounds__(1024) void convse_invert_small_kernel(const int32_t
   __shared__ int32_t wa[16], wb[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int i = tid; i < nv; i += 1024) s_cnt[i] = 0;
+  // up to 8 pairs per thread (8 192 pairs: a 50-query batch has 5 000): video and rank of a thread's pairs stay in its
+  // registers between the counting and the fill pass instead of going through the `pos` scratch and a second read of pair_vid
+  const bool in_regs = P <= 8 * 1024;
+  int v_r[8], pos_r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const int p = tid + j * 1024;
+    v_r[j] = (in_regs && p < P) ? pair_vid[p] : -1;
+  }
   __syncthreads();
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = tid + j * 1024;
+      const bool ok = v_r[j] >= 0 && v_r[j] < nv;
+      pos_r[j] = ok ? atomicAdd(&s_cnt[v_r[j]], 1) : -1;
+      if (p < P && !ok && zero_skipped) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4* s4 = reinterpret_cast<float4*>(st_out) + (int64_t)p * lpad4;
+        float4* e4 = reinterpret_cast<float4*>(ed_out) + (int64_t)p * lpad4;
+        for (int i = 0; i < lpad4; ++i) { s4[i] = z; e4[i] = z; }
+      }
+    }
+  } else {
   for (int p = tid; p < P; p += 1024) {
     const int v = pair_vid[p];
     const bool ok = v >= 0 && v < nv;
@@ -159,6 +182,7 @@ __global__ __launch_bounds__(1024) void convse_invert_small_kernel(const int32_t
       float4* e4 = reinterpret_cast<float4*>(ed_out) + (int64_t)p * lpad4;
       for (int i = 0; i < lpad4; ++i) { s4[i] = z; e4[i] = z; }
     }
+  }
   }
   __syncthreads();
   const int per = (nv + 1023) / 1024;
@@ -184,6 +208,12 @@ __global__ __launch_bounds__(1024) void convse_invert_small_kernel(const int32_t
   }
   if (tid == 1023) { offsets[nv] = a; chunk_off[nv] = b; }
   __syncthreads();
+  if (in_regs) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (pos_r[j] >= 0) bucket[s_off[v_r[j]] + pos_r[j]] = tid + j * 1024;
+    return;
+  }
   for (int p = tid; p < P; p += 1024) {
     const int r = pos[p];                            // (written by this very thread above)
     if (r >= 0) bucket[s_off[pair_vid[p]] + r] = p;
